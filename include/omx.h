@@ -1,0 +1,428 @@
+/*
+ * omx.h — C-ABI boundary of the MI355X-native OpenMeters DSP hot path.
+ *
+ * Every entry point below replaces one inherent method of a reference
+ * `<Visual>Processor` (the seam `VisualModule::ingest` calls through,
+ * reference src/visuals/registry.rs:107-115, :247-256).  The reference is
+ * Rust; a maintainer binds these with an `extern "C"` block (see
+ * INTEGRATION.md).  Signatures are plain pointers and sizes: no C++ types,
+ * no torch types, nothing HIP-specific leaks out.
+ *
+ * Conventions
+ *   - return  1  : a snapshot was produced   (reference: `Some(snapshot)`)
+ *   - return  0  : nothing to show           (reference: `None`)
+ *   - return <0  : backend failure (omx_status) — a case the reference does not have
+ *   - all snapshot pointers are callee-owned and stay valid until the next call
+ *     on the same handle (superset of the reference's borrowed `&SpectrumSnapshot`,
+ *     reference src/visuals/spectrum/processor.rs:255)
+ *   - handles are not thread-safe; calls on one handle are serialised by the
+ *     caller (reference: `Rc<RefCell<..>>`, src/visuals/registry.rs:23)
+ *   - PCM is interleaved f32, frame-major `[frame][channel]`
+ *     (reference src/dsp.rs:219-229)
+ *
+ * Two families per visual:
+ *   omx_<visual>_*        one stream, host pointers in/out: the drop-in for
+ *                         `<Visual>Processor::{new,config,update_config,
+ *                         reset_audio,prepare,process_block}`
+ *   omx_<visual>_bank_*   S independent streams per call, device-resident
+ *                         in/out: the batched MI355X path (one HIP launch
+ *                         covers every ready (stream, hop)).
+ */
+#ifndef OMX_H
+#define OMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMX_MAX_CHANNELS 8 /* reference src/dsp.rs:6 MAX_AUDIO_CHANNELS */
+
+typedef enum omx_status {
+    OMX_PRODUCED = 1,
+    OMX_NONE = 0,
+    OMX_ERR_BACKEND = -1,     /* HIP runtime error (see omx_last_error) */
+    OMX_ERR_UNSUPPORTED = -2, /* config shape outside what the HIP path implements */
+    OMX_ERR_INVALID = -3,     /* null handle / null pointer */
+    OMX_ERR_NO_DEVICE = -4    /* no gfx950 device visible: there is no CPU fallback */
+} omx_status;
+
+/* reference src/dsp.rs:8-22 ChannelPosition; Aux(n) = OMX_POS_AUX0 + n */
+enum {
+    OMX_POS_FRONT_LEFT = 0,
+    OMX_POS_FRONT_RIGHT = 1,
+    OMX_POS_FRONT_CENTER = 2,
+    OMX_POS_LOW_FREQUENCY = 3,
+    OMX_POS_REAR_LEFT = 4,
+    OMX_POS_REAR_RIGHT = 5,
+    OMX_POS_SIDE_LEFT = 6,
+    OMX_POS_SIDE_RIGHT = 7,
+    OMX_POS_MONO = 8,
+    OMX_POS_UNKNOWN = 9,
+    OMX_POS_AUX0 = 16
+};
+
+/* reference src/util/audio/window.rs:9-18 WindowKind */
+enum {
+    OMX_WINDOW_RECTANGULAR = 0,
+    OMX_WINDOW_HANN = 1,
+    OMX_WINDOW_HAMMING = 2,
+    OMX_WINDOW_BLACKMAN = 3,
+    OMX_WINDOW_BLACKMAN_HARRIS = 4
+};
+
+/* reference src/util/audio/channel.rs:4-10 Channel */
+enum {
+    OMX_CHANNEL_LEFT = 0,
+    OMX_CHANNEL_RIGHT = 1,
+    OMX_CHANNEL_MID = 2,
+    OMX_CHANNEL_SIDE = 3,
+    OMX_CHANNEL_NONE = 4
+};
+
+/* reference src/dsp.rs:108-115 AudioBlock (borrowed for the call only).
+ * `positions` are used as given (the reference normalises them upstream in
+ * AudioFormat::new, src/dsp.rs:88-101; omx_positions_normalize does the same). */
+typedef struct omx_block {
+    const float* samples; /* interleaved, n_samples = frames * channels */
+    uint64_t n_samples;
+    uint32_t channels;    /* clamped to 1..=8 like AudioBlock::with_positions */
+    float sample_rate;    /* sanitised like src/util/audio/rate.rs:9-13 */
+    uint8_t positions[OMX_MAX_CHANNELS];
+} omx_block;
+
+/* reference src/dsp.rs:36-47 ChannelPosition::fallback */
+void omx_positions_fallback(uint32_t channels, uint8_t out[OMX_MAX_CHANNELS]);
+/* reference src/dsp.rs:49-76 ChannelPosition::normalize */
+void omx_positions_normalize(uint32_t channels, const uint8_t in[OMX_MAX_CHANNELS],
+                             uint8_t out[OMX_MAX_CHANNELS]);
+
+/* Text of the most recent backend error on this thread ("" if none). */
+const char* omx_last_error(void);
+/* 1 if a gfx950 device is usable, else 0.  Never falls back to the CPU. */
+int omx_device_available(void);
+/* Library version string. */
+const char* omx_version(void);
+
+/* ===================================================================== *
+ * Spectrogram — reference src/visuals/spectrogram/processor.rs
+ * ===================================================================== */
+
+/* reference :45-56 SpectrogramConfig (field for field) */
+typedef struct omx_spectrogram_config {
+    float sample_rate;
+    uint32_t window;           /* OMX_WINDOW_* */
+    uint64_t fft_size;
+    uint64_t hop_size;
+    uint64_t history_length;
+    uint64_t zero_padding_factor;
+    uint32_t use_reassignment; /* bool */
+    uint32_t _pad;
+} omx_spectrogram_config;
+
+/* reference :37-43 SpectrogramPoint, #[repr(C)] 12-byte Pod */
+typedef struct omx_spectrogram_point {
+    float time_offset;
+    float freq_hz;
+    float power;
+} omx_spectrogram_point;
+
+enum { OMX_COLUMN_REASSIGNED = 0, OMX_COLUMN_CLASSIC = 1 };
+
+/* reference :160-168 SpectrogramUpdate; `new_columns: Vec<SpectrogramColumn>`
+ * is flattened CSR-style: column c owns
+ *   points[column_offsets[c] .. column_offsets[c+1])   (reassigned) or
+ *   codes [column_offsets[c] .. column_offsets[c+1])   (classic, u16 packed dB) */
+typedef struct omx_spectrogram_update {
+    uint64_t fft_size;
+    uint64_t hop_size;
+    uint64_t history_length;
+    uint64_t n_columns;
+    const uint64_t* column_offsets; /* n_columns + 1 entries */
+    const omx_spectrogram_point* points;
+    const uint16_t* codes;
+    float sample_rate;
+    float reassigned_power_scale;
+    uint32_t reset; /* bool */
+    uint32_t kind;  /* OMX_COLUMN_* */
+} omx_spectrogram_update;
+
+typedef struct omx_spectrogram omx_spectrogram;
+
+void omx_spectrogram_config_default(omx_spectrogram_config* out);                 /* :45-59 defaults */
+int omx_spectrogram_create(const omx_spectrogram_config* cfg, omx_spectrogram** out); /* ::new :188-206 */
+void omx_spectrogram_destroy(omx_spectrogram* h);
+int omx_spectrogram_get_config(const omx_spectrogram* h, omx_spectrogram_config* out);    /* ::config :208-210 */
+int omx_spectrogram_update_config(omx_spectrogram* h, const omx_spectrogram_config* cfg); /* :518-543 */
+int omx_spectrogram_reset_audio(omx_spectrogram* h);                              /* :212-217 */
+int omx_spectrogram_prepare(omx_spectrogram* h);                                  /* :219-223 */
+int omx_spectrogram_process_block(omx_spectrogram* h, const omx_block* block,
+                                  omx_spectrogram_update* out);                   /* :490-516 */
+
+/* reference :103-108 pack_classic_db, :144-158 col_byte_stride / history_columns */
+uint16_t omx_pack_classic_db(float db);
+uint64_t omx_spectrogram_history_columns(uint32_t kind, uint32_t points, uint64_t requested);
+
+/* ---- batched bank: S independent SpectrogramProcessors, one launch ---- */
+typedef struct omx_spectrogram_bank omx_spectrogram_bank;
+
+/* Result of one bank call.  All streams receive the same number of frames per
+ * call, so every stream emits the same number of columns.  Device buffers:
+ *   d_counts : uint32 [n_streams][n_columns]            points kept per column
+ *   d_points : omx_spectrogram_point [n_streams][n_columns][column_stride]
+ *              (reassigned; first d_counts[s][c] entries valid, ascending bin order)
+ *   d_codes  : uint16 [n_streams][n_columns][column_stride] (classic)            */
+typedef struct omx_spectrogram_bank_update {
+    uint64_t fft_size;
+    uint64_t hop_size;
+    uint64_t history_length;
+    uint64_t n_streams;
+    uint64_t n_columns;
+    uint64_t column_stride; /* elements between consecutive columns */
+    const uint32_t* d_counts;
+    const omx_spectrogram_point* d_points;
+    const uint16_t* d_codes;
+    float sample_rate;
+    float reassigned_power_scale;
+    uint32_t reset;
+    uint32_t kind;
+} omx_spectrogram_bank_update;
+
+int omx_spectrogram_bank_create(const omx_spectrogram_config* cfg, uint32_t n_streams,
+                                omx_spectrogram_bank** out);
+void omx_spectrogram_bank_destroy(omx_spectrogram_bank* b);
+int omx_spectrogram_bank_update_config(omx_spectrogram_bank* b, const omx_spectrogram_config* cfg);
+int omx_spectrogram_bank_reset_audio(omx_spectrogram_bank* b);
+/* pcm: [n_streams][frames][channels] f32.  pcm_on_device != 0 ⇒ `pcm` is a device
+ * pointer (the timed path); otherwise it is copied host→device first.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ * The call enqueues work and returns; outputs are ordered on `stream`. */
+int omx_spectrogram_bank_process(omx_spectrogram_bank* b, const float* pcm, int pcm_on_device,
+                                 uint64_t frames, uint32_t channels, float sample_rate,
+                                 const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                                 omx_spectrogram_bank_update* out);
+/* Copy one column of one stream to host memory (synchronises `stream`). */
+int omx_spectrogram_bank_fetch_column(omx_spectrogram_bank* b, uint64_t stream_index,
+                                      uint64_t column, void* dst, uint64_t dst_capacity_elems,
+                                      uint64_t* n_out);
+/* Average duration (ms) of the dominant STFT kernel over the launches since the
+ * last call, measured with HIP events on the launch stream; resets the tally. */
+int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, uint64_t* launches);
+
+/* ===================================================================== *
+ * Spectrum — reference src/visuals/spectrum/processor.rs
+ * ===================================================================== */
+
+enum { OMX_AVERAGING_NONE = 0, OMX_AVERAGING_EXPONENTIAL = 1, OMX_AVERAGING_PEAK_HOLD = 2 };
+
+/* reference :39-51 SpectrumConfig; AveragingMode (:64-70) is (mode, param):
+ * Exponential{factor} / PeakHold{decay_per_second} */
+typedef struct omx_spectrum_config {
+    float sample_rate;
+    uint32_t window;
+    uint64_t fft_size;
+    uint64_t hop_size;
+    uint32_t averaging_mode;
+    float averaging_param;
+    uint32_t source;           /* OMX_CHANNEL_* */
+    uint32_t secondary_source; /* OMX_CHANNEL_* */
+    float floor_db;
+    uint32_t _pad;
+} omx_spectrum_config;
+
+/* reference :33-37 SpectrumSnapshot: traces[trace] = [weighted_db, raw_db] */
+typedef struct omx_spectrum_snapshot {
+    uint64_t bins;
+    const float* frequency_bins;
+    const float* traces[2][2]; /* [trace][0 = A-weighted dB, 1 = raw dB], `bins` floats each */
+} omx_spectrum_snapshot;
+
+typedef struct omx_spectrum omx_spectrum;
+
+void omx_spectrum_config_default(omx_spectrum_config* out);
+int omx_spectrum_create(const omx_spectrum_config* cfg, omx_spectrum** out);      /* ::new :89-106 */
+void omx_spectrum_destroy(omx_spectrum* h);
+int omx_spectrum_get_config(const omx_spectrum* h, omx_spectrum_config* out);
+int omx_spectrum_update_config(omx_spectrum* h, const omx_spectrum_config* cfg);  /* :300-322 */
+int omx_spectrum_reset_audio(omx_spectrum* h);                                    /* :112-118 */
+int omx_spectrum_prepare(omx_spectrum* h);                                        /* :120-124 */
+int omx_spectrum_process_block(omx_spectrum* h, const omx_block* block,
+                               omx_spectrum_snapshot* out);                       /* :255-269 */
+float omx_a_weight(float freq_hz);                                                /* :410-425 */
+
+typedef struct omx_spectrum_bank omx_spectrum_bank;
+/* d_traces: f32 [n_streams][n_hops_out][2 traces][2 weightings][bins]; with
+ * emit_all_hops == 0 only the newest hop is materialised (reference semantics:
+ * the snapshot reflects the last hop, :268) and n_hops_out == 1. */
+typedef struct omx_spectrum_bank_update {
+    uint64_t bins;
+    uint64_t n_streams;
+    uint64_t n_hops;     /* hops processed in this call */
+    uint64_t n_hops_out; /* hops materialised in d_traces */
+    const float* d_traces;
+    const float* d_frequency_bins;
+} omx_spectrum_bank_update;
+int omx_spectrum_bank_create(const omx_spectrum_config* cfg, uint32_t n_streams, int emit_all_hops,
+                             omx_spectrum_bank** out);
+void omx_spectrum_bank_destroy(omx_spectrum_bank* b);
+int omx_spectrum_bank_reset_audio(omx_spectrum_bank* b);
+int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on_device,
+                              uint64_t frames, uint32_t channels, float sample_rate,
+                              const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                              omx_spectrum_bank_update* out);
+int omx_spectrum_bank_fetch(omx_spectrum_bank* b, uint64_t stream_index, uint64_t hop,
+                            float* dst /* [2][2][bins] */);
+
+/* ===================================================================== *
+ * Loudness — reference src/visuals/loudness/processor.rs
+ * ===================================================================== */
+
+/* reference :210-216 LoudnessConfig */
+typedef struct omx_loudness_config {
+    float sample_rate;
+    float floor_db;
+} omx_loudness_config;
+
+/* reference :185-194 LoudnessSnapshot */
+typedef struct omx_loudness_snapshot {
+    float short_term_loudness;
+    float momentary_loudness;
+    float rms_fast_db[OMX_MAX_CHANNELS];
+    float rms_slow_db[OMX_MAX_CHANNELS];
+    float true_peak_db[OMX_MAX_CHANNELS];
+    uint32_t channel_count;
+    uint8_t positions[OMX_MAX_CHANNELS];
+    uint32_t _pad;
+} omx_loudness_snapshot;
+
+typedef struct omx_loudness omx_loudness;
+
+void omx_loudness_config_default(omx_loudness_config* out);
+int omx_loudness_create(const omx_loudness_config* cfg, omx_loudness** out);      /* ::new :225-232 */
+void omx_loudness_destroy(omx_loudness* h);
+int omx_loudness_reset_audio(omx_loudness* h);                                    /* :234-236 */
+int omx_loudness_process_block(omx_loudness* h, const omx_block* block,
+                               omx_loudness_snapshot* out);                       /* :253-311 */
+/* reference :22-55 k_weighting_coefficients → b[5], a[5] */
+void omx_k_weighting_coefficients(double fs, double b[5], double a[5]);
+
+typedef struct omx_loudness_bank omx_loudness_bank;
+/* One call = `n_blocks` consecutive blocks of `block_frames` frames for every
+ * stream; a snapshot is produced per (stream, block) exactly as if the
+ * reference had been fed block by block (true peak resets per block, :301).
+ * d_snapshots: omx_loudness_snapshot [n_streams][n_blocks]. */
+int omx_loudness_bank_create(const omx_loudness_config* cfg, uint32_t n_streams, uint32_t channels,
+                             omx_loudness_bank** out);
+void omx_loudness_bank_destroy(omx_loudness_bank* b);
+int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
+int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device,
+                              uint64_t block_frames, uint64_t n_blocks, float sample_rate,
+                              const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                              const omx_loudness_snapshot** d_snapshots);
+int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block,
+                            omx_loudness_snapshot* dst);
+int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t* launches);
+
+/* ===================================================================== *
+ * Stereometer — reference src/visuals/stereometer/processor.rs
+ * ===================================================================== */
+
+/* reference :11-21 StereometerConfig */
+typedef struct omx_stereometer_config {
+    float sample_rate;
+    float segment_duration;
+    uint64_t target_sample_count;
+    float correlation_window;
+    uint32_t analyze_bands;
+    uint32_t emit_band_points;
+    uint32_t _pad;
+} omx_stereometer_config;
+
+/* reference :23-26 StereometerSnapshot: points[band] = (left,right) pairs,
+ * band 0 = full band, 1..3 = low/mid/high */
+typedef struct omx_stereometer_snapshot {
+    const float* points[4]; /* interleaved l,r; n_points[band] pairs */
+    uint64_t n_points[4];
+    float correlations[4];
+} omx_stereometer_snapshot;
+
+typedef struct omx_stereometer omx_stereometer;
+
+void omx_stereometer_config_default(omx_stereometer_config* out);
+int omx_stereometer_create(const omx_stereometer_config* cfg, omx_stereometer** out); /* :75-86 */
+void omx_stereometer_destroy(omx_stereometer* h);
+int omx_stereometer_get_config(const omx_stereometer* h, omx_stereometer_config* out);
+int omx_stereometer_update_config(omx_stereometer* h, const omx_stereometer_config* cfg); /* :183-207 */
+int omx_stereometer_reset_audio(omx_stereometer* h);                              /* :92-97 */
+int omx_stereometer_process_block(omx_stereometer* h, const omx_block* block,
+                                  omx_stereometer_snapshot* out);                 /* :99-182 */
+
+typedef struct omx_stereometer_bank omx_stereometer_bank;
+/* d_correlations: f32 [n_streams][n_blocks][4]; d_points: f32 [n_streams][4][target][2]
+ * for the newest block; d_produced: uint32 [n_streams][n_blocks]. */
+typedef struct omx_stereometer_bank_update {
+    uint64_t n_streams;
+    uint64_t n_blocks;
+    uint64_t target;
+    const float* d_correlations;
+    const float* d_points;
+    const uint32_t* d_produced;
+} omx_stereometer_bank_update;
+int omx_stereometer_bank_create(const omx_stereometer_config* cfg, uint32_t n_streams,
+                                omx_stereometer_bank** out);
+void omx_stereometer_bank_destroy(omx_stereometer_bank* b);
+int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
+int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int pcm_on_device,
+                                 uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
+                                 void* stream, omx_stereometer_bank_update* out);
+int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block,
+                               float correlations[4], uint32_t* produced);
+
+/* ===================================================================== *
+ * Oscilloscope — reference src/visuals/oscilloscope/processor.rs
+ * ===================================================================== */
+
+enum { OMX_TRIGGER_ZERO_CROSSING = 0, OMX_TRIGGER_STABLE = 1 };
+
+/* reference :33-43 OscilloscopeConfig; TriggerMode (:21-31) is (mode, num_cycles) */
+typedef struct omx_oscilloscope_config {
+    float sample_rate;
+    float segment_duration;
+    uint32_t trigger_mode;
+    uint32_t trigger_source; /* OMX_CHANNEL_* */
+    uint64_t num_cycles;
+    uint32_t channel_1;
+    uint32_t channel_2;
+} omx_oscilloscope_config;
+
+/* reference :553-560 OscilloscopeSnapshot */
+typedef struct omx_oscilloscope_snapshot {
+    uint64_t epoch;
+    uint64_t channels;
+    uint64_t slots[2];
+    uint64_t samples_per_channel;
+    uint64_t n_samples; /* channels * samples_per_channel */
+    const float* samples;
+} omx_oscilloscope_snapshot;
+
+typedef struct omx_oscilloscope omx_oscilloscope;
+
+void omx_oscilloscope_config_default(omx_oscilloscope_config* out);
+int omx_oscilloscope_create(const omx_oscilloscope_config* cfg, omx_oscilloscope** out); /* :579-587 */
+void omx_oscilloscope_destroy(omx_oscilloscope* h);
+int omx_oscilloscope_get_config(const omx_oscilloscope* h, omx_oscilloscope_config* out);
+int omx_oscilloscope_update_config(omx_oscilloscope* h, const omx_oscilloscope_config* cfg); /* :752-758 */
+int omx_oscilloscope_reset_audio(omx_oscilloscope* h);                            /* :593-600 */
+int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block,
+                                   omx_oscilloscope_snapshot* out);               /* :611-712 */
+/* Test/diagnostic view of the trigger state (reference `last_cycle_rate`, :602-609):
+ * returns 1 and writes Hz when a period is locked, else 0. */
+int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMX_H */

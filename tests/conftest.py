@@ -1,0 +1,59 @@
+"""pytest wiring.
+
+Markers
+  gpu : needs a real MI355X; run on the GPU box with `-m gpu`.  Everything else runs on CPU.
+
+Fixtures
+  oracle : Api bound to oracle/libomx_oracle.so (prefix omxo_) — the CPU checker (test infra only)
+  omx    : Api bound to the product libomx_hip.so (prefix omx_) — loading it needs no GPU
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (gfx950) device")
+
+
+def _build_oracle() -> str:
+    path = os.path.join(ROOT, "oracle", "libomx_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
+            if f.endswith((".cpp", ".hpp"))] + [os.path.join(ROOT, "include", "omx.h")]
+    stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    return path
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from openmeters_amd.capi import Api
+    return Api(_build_oracle(), "omxo_")
+
+
+@pytest.fixture(scope="session")
+def omx():
+    import openmeters_amd
+    return openmeters_amd.api()
+
+
+def _backend_params():
+    return ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=_backend_params())
+def backend(request):
+    """Api under test: the CPU oracle (runs everywhere) or the HIP product (-m gpu)."""
+    if request.param == "oracle":
+        return request.getfixturevalue("oracle")
+    api = request.getfixturevalue("omx")
+    import openmeters_amd
+    assert openmeters_amd.device_available(), "gpu-marked test but no gfx950 device is visible"
+    return api
