@@ -210,6 +210,12 @@ int omx_spectrogram_bank_fetch_column(omx_spectrogram_bank* b, uint64_t stream_i
 /* Average duration (ms) of the dominant STFT kernel over the launches since the
  * last call, measured with HIP events on the launch stream; resets the tally. */
 int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, uint64_t* launches);
+/* Diagnostics knobs shared by the banks. */
+enum {
+    OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
+    OMX_OPT_FORCE_GENERIC = 2  /* value != 0: route through the generic any-size kernels (A/B checks) */
+};
+int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *
  * Spectrum — reference src/visuals/spectrum/processor.rs

@@ -1,0 +1,182 @@
+// openmeters_amd — shared host-side plumbing for the HIP product library (libomx_hip.so).
+// No DSP lives here: error reporting, device buffers, the per-call audio format, and the
+// closed-form coefficient tables that the reference also computes once per config on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/omx.h"
+
+namespace omx {
+
+// ---------------------------------------------------------------- errors
+void set_last_error(const std::string& msg);
+int device_ready();  // OMX_NONE when a gfx950 device is usable, else OMX_ERR_NO_DEVICE / OMX_ERR_BACKEND
+
+struct BackendError {
+    int status;
+};
+
+#define OMX_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            ::omx::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                  ":" + std::to_string(__LINE__) + ")");                                \
+            throw ::omx::BackendError{OMX_ERR_BACKEND};                                                 \
+        }                                                                                               \
+    } while (0)
+
+[[noreturn]] inline void unsupported(const std::string& what) {
+    set_last_error("unsupported configuration for the HIP path: " + what);
+    throw BackendError{OMX_ERR_UNSUPPORTED};
+}
+
+// Runs `body` and converts BackendError into a negative omx_status: nothing unwinds across the C ABI.
+template <class F>
+inline int guarded(F&& body) {
+    try {
+        return body();
+    } catch (const BackendError& e) {
+        return e.status;
+    } catch (const std::exception& e) {
+        set_last_error(std::string("exception: ") + e.what());
+        return OMX_ERR_BACKEND;
+    } catch (...) {
+        set_last_error("unknown exception");
+        return OMX_ERR_BACKEND;
+    }
+}
+
+// ---------------------------------------------------------------- device memory
+template <class T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    // Grow-only; contents are NOT preserved.
+    void reserve(size_t n) {
+        if (n <= count) return;
+        release();
+        OMX_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(n, 1) * sizeof(T)));
+        count = n;
+    }
+    // Blocking upload (setup paths only): the host vector may be a temporary.
+    void upload(const std::vector<T>& host, hipStream_t stream) {
+        reserve(host.size());
+        if (!host.empty()) {
+            OMX_HIP(hipMemcpyAsync(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+    }
+};
+
+struct EventTimer {  // HIP-event timing of one kernel family on its launch stream
+    hipEvent_t start = nullptr, stop = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    bool enabled = false;
+    ~EventTimer() {
+        for (auto& p : pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    }
+    void begin(hipStream_t s) {
+        if (!enabled) return;
+        OMX_HIP(hipEventCreate(&start));
+        OMX_HIP(hipEventCreate(&stop));
+        OMX_HIP(hipEventRecord(start, s));
+    }
+    void end(hipStream_t s) {
+        if (!enabled) return;
+        OMX_HIP(hipEventRecord(stop, s));
+        pending.emplace_back(start, stop);
+    }
+    // average ms over the recorded launches; clears the tally
+    double collect(uint64_t* launches) {
+        double total = 0.0;
+        uint64_t n = 0;
+        for (auto& p : pending) {
+            OMX_HIP(hipEventSynchronize(p.second));
+            float ms = 0.0f;
+            OMX_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+            total += ms;
+            ++n;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        pending.clear();
+        if (launches) *launches = n;
+        return n ? total / (double)n : 0.0;
+    }
+};
+
+// ---------------------------------------------------------------- small numeric helpers (host)
+constexpr float kDefaultSampleRate = 48000.0f;  // reference src/util/audio/rate.rs:6
+constexpr float kMaxSampleRate = 768000.0f;     // rate.rs:7
+constexpr float kDbFloor = -140.0f;             // level.rs:4
+constexpr float kLnToDb = 4.3429448f;           // level.rs:5
+constexpr float kTau = 6.28318530717958647692f;
+constexpr float kFrac1Sqrt2 = 0.707106781186547524400844362104849039f;
+
+inline float sanitize_sample_rate(float r) {  // rate.rs:9-13
+    float v = (std::isfinite(r) && r > 0.0f) ? r : kDefaultSampleRate;
+    return v < 1.0f ? 1.0f : (v > kMaxSampleRate ? kMaxSampleRate : v);
+}
+inline size_t f2usize(double x) {  // Rust `as usize`
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551615.0) return SIZE_MAX;
+    return (size_t)x;
+}
+inline bool is_pow2(size_t n) { return n >= 1 && (n & (n - 1)) == 0; }
+inline unsigned log2_exact(size_t n) {
+    unsigned l = 0;
+    while ((size_t(1) << l) < n) ++l;
+    return l;
+}
+inline size_t next_pow2(size_t v) {
+    size_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline float db_to_power_host(float db) {  // level.rs:36-39
+    const float DB_TO_LOG2 = 0.1f * 3.32192809488736234787f;
+    return std::exp2(db * DB_TO_LOG2);
+}
+
+// ---------------------------------------------------------------- audio format of one call
+// Host mirror of AudioBlock::with_positions' derived data (reference src/dsp.rs:117-213): the 8x2
+// stereo down-mix matrix.  `stereo_channels` trimming (dsp.rs:197-204) is a CPU-side shortcut with no
+// observable effect (trimmed channels are all-zero bits and contribute +0.0), so the device folds
+// over every channel.
+struct AudioFormatArgs {
+    uint32_t channels;       // 1..=8
+    float m[OMX_MAX_CHANNELS][2];
+};
+AudioFormatArgs make_format(uint32_t channels, const uint8_t positions[OMX_MAX_CHANNELS]);
+void positions_fallback(uint32_t channels, uint8_t out[OMX_MAX_CHANNELS]);
+void positions_normalize(uint32_t channels, const uint8_t in[OMX_MAX_CHANNELS], uint8_t out[OMX_MAX_CHANNELS]);
+
+// window.rs:20-43 (periodic cosine-sum windows, f32) and :90-109 (bin normalisation)
+std::vector<float> window_coefficients(uint32_t kind, size_t len);
+std::vector<float> fft_bin_normalization(const std::vector<float>& window, size_t fft_size);
+// exp(-2*pi*i*k/n) for k < count, computed in f64 and rounded to f32 (interleaved re,im)
+std::vector<float> twiddle_table(size_t n, size_t count);
+
+}  // namespace omx

@@ -1,0 +1,172 @@
+// Device-side FFT building blocks for gfx950 (CDNA4), hand-written for 64-wide wavefronts.
+//
+// Two families:
+//   * fft4096_*  — the hot path: one 4096-point complex FFT per 256-thread workgroup as three
+//     radix-16 Stockham passes (16 complex values per thread in VGPRs, exchanged through LDS with a
+//     +1/16 padded layout that keeps ds_read_b64 / ds_write_b64 conflict-free in every pass).
+//   * fft_radix2_* — the generic path: any power-of-two size in a caller-supplied buffer (LDS or
+//     global scratch), plain radix-2 with the bit-reversal order of the CPU oracle, used for the
+//     config shapes the specialised kernels do not cover.
+//
+// Built with -ffp-contract=off: every fused multiply-add below is spelled `__builtin_fmaf`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace omx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // (re, im)
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {  // a * b
+    return v2f{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+}
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) {  // a * conj(b)
+    return v2f{__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y))};
+}
+template <bool INV>
+__device__ __forceinline__ v2f twmul(v2f a, v2f w) {  // forward: a*w ; inverse: a*conj(w)
+    return INV ? cmulc(a, w) : cmul(a, w);
+}
+template <bool INV>
+__device__ __forceinline__ v2f rot90(v2f a) {  // forward: a * (-i) ; inverse: a * (+i)
+    return INV ? v2f{-a.y, a.x} : v2f{a.y, -a.x};
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<INV>(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+
+// In-register 16-point DFT (4x4 Cooley-Tukey).  On return X[k] sits in v[DFT16_OUT(k)].
+#define DFT16_OUT(k) (4 * ((k)&3) + ((k) >> 2))
+template <bool INV>
+__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+    constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
+    constexpr float H = 0.70710678118654752440f;   // sqrt(1/2)
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    // v[4*k1 + n2] *= w16^(n2*k1), w16 = exp(-+ 2*pi*i/16)
+    const v2f w1{C1, -S1}, w3{S1, -C1}, w9{-C1, S1};
+    v[5] = twmul<INV>(v[5], w1);                     // k1=1,n2=1
+    {                                                // k1=1,n2=2 : w^2 = H(1 -+ i)
+        const v2f a = v[6];
+        v[6] = INV ? v2f{(a.x - a.y) * H, (a.x + a.y) * H} : v2f{(a.x + a.y) * H, (a.y - a.x) * H};
+    }
+    v[7] = twmul<INV>(v[7], w3);                     // k1=1,n2=3
+    {                                                // k1=2,n2=1 : w^2
+        const v2f a = v[9];
+        v[9] = INV ? v2f{(a.x - a.y) * H, (a.x + a.y) * H} : v2f{(a.x + a.y) * H, (a.y - a.x) * H};
+    }
+    v[10] = rot90<INV>(v[10]);                       // k1=2,n2=2 : w^4 = -+ i
+    {                                                // k1=2,n2=3 : w^6 = H(-1 -+ i)
+        const v2f a = v[11];
+        v[11] = INV ? v2f{(-a.x - a.y) * H, (a.x - a.y) * H} : v2f{(a.y - a.x) * H, (-a.x - a.y) * H};
+    }
+    v[13] = twmul<INV>(v[13], w3);                   // k1=3,n2=1
+    {                                                // k1=3,n2=2 : w^6
+        const v2f a = v[14];
+        v[14] = INV ? v2f{(-a.x - a.y) * H, (a.x - a.y) * H} : v2f{(a.y - a.x) * H, (-a.x - a.y) * H};
+    }
+    v[15] = twmul<INV>(v[15], w9);                   // k1=3,n2=3
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4096-point FFT, 256 threads, LDS buffer of FFT4096_LDS complex values.
+// PAD(a) = a + a/16 spreads every pass's 16-lane access groups over all banks.
+constexpr int FFT4096_LDS = 4096 + 256;
+__device__ __forceinline__ int pad16(int a) { return a + (a >> 4); }
+
+// Twiddle tables (global, L1/L2 resident): tw256[k] = exp(-2*pi*i*k/256), tw4096[k] = exp(-2*pi*i*k/4096)
+struct Fft4096Tables {
+    const v2f* tw256;
+    const v2f* tw4096;
+};
+
+// Pass 1 (Ns = 1): thread j holds x[j + 256 t] in v[t]; writes y[16 j + t].  No twiddles.
+template <bool INV>
+__device__ __forceinline__ void fft4096_pass1(v2f (&v)[16], v2f* lds, int j) {
+    dft16<INV>(v);
+    const int base = 17 * j;  // pad16(16 j + t) = 17 j + t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lds[base + t] = v[DFT16_OUT(t)];
+}
+// Pass 2 (Ns = 16): reads y[j + 256 t], twiddle exp(-+2*pi*i*(j%16)*t/256), writes z[(j/16)*256 + j%16 + 16 t].
+template <bool INV>
+__device__ __forceinline__ void fft4096_pass2(v2f* lds, int j, const Fft4096Tables& tb) {
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = lds[pad16(j + 256 * t)];
+    const int k = j & 15;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw256[k * t]);
+    dft16<INV>(v);
+    __syncthreads();  // every thread has read its inputs: in-place overwrite is safe
+    const int base = (j >> 4) * 272 + k;  // pad16((j/16)*256 + k + 16 t) = (j/16)*272 + k + 17 t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lds[base + 17 * t] = v[DFT16_OUT(t)];
+}
+// Pass 3 (Ns = 256): reads z[j + 256 t], twiddle exp(-+2*pi*i*j*t/4096); X[j + 256 t] is left in v[t].
+template <bool INV>
+__device__ __forceinline__ void fft4096_pass3(v2f (&out)[16], const v2f* lds, int j, const Fft4096Tables& tb) {
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = lds[pad16(j + 256 * t)];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw4096[j * t]);
+    dft16<INV>(v);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) out[t] = v[DFT16_OUT(t)];
+}
+// Whole transform: x[j + 256 t] in v[t] on entry, X[j + 256 t] in v[t] on return.  The caller must
+// have a barrier between any earlier use of `lds` and this call.
+template <bool INV>
+__device__ __forceinline__ void fft4096(v2f (&v)[16], v2f* lds, int j, const Fft4096Tables& tb) {
+    fft4096_pass1<INV>(v, lds, j);
+    __syncthreads();
+    fft4096_pass2<INV>(lds, j, tb);
+    __syncthreads();
+    fft4096_pass3<INV>(v, lds, j, tb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic radix-2 FFT over `n = 1 << logn` complex values in `a` (LDS or global), executed by all
+// `nthreads` threads of the workgroup.  Same decimation-in-time order and twiddles (tw[k] =
+// exp(-2*pi*i*k/n), k < n/2) as the CPU oracle's fft.hpp, without mul+add fusion.
+__device__ __forceinline__ unsigned bitrev(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+__device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* tw, bool inverse, unsigned tid,
+                                  unsigned nthreads) {
+    if (n <= 1) return;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += nthreads) {
+        const unsigned r = bitrev(i, logn);
+        if (i < r) {
+            const v2f t = a[i];
+            a[i] = a[r];
+            a[r] = t;
+        }
+    }
+    __syncthreads();
+    for (unsigned s = 1; s <= logn; ++s) {
+        const unsigned half = 1u << (s - 1), stride = n >> s;
+        for (unsigned b = tid; b < n / 2; b += nthreads) {
+            const unsigned k = b & (half - 1);
+            const unsigned base = ((b >> (s - 1)) << s) + k;
+            v2f w = tw[k * stride];
+            if (inverse) w.y = -w.y;
+            const v2f u = a[base], x = a[base + half];
+            const v2f t{x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};
+            a[base] = u + t;
+            a[base + half] = u - t;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace omx

@@ -1,0 +1,431 @@
+// Host side of the spectrogram path: the integer state machine of
+// reference src/visuals/spectrogram/processor.rs:170-544 (config normalisation, pending-audio
+// bookkeeping, the bit-exact frame-index rule `ready = (pending - read_len)/hop + 1`, retention/skip,
+// pending_skip for hop > window, reset flag) driving the HIP kernels.  All sample data stays on the
+// device: per-stream mono rings, `audio_last_nonzero` as a device-side absolute position.
+#include "spectrogram.hpp"
+
+namespace omx {
+
+constexpr size_t kDefaultFftSize = 2048;                      // :58
+constexpr size_t kDefaultHopSize = 64;                        // :59
+constexpr size_t kMaxHistoryColumns = 8192;                   // :60
+constexpr size_t kHistoryByteBudget = 128u * 1024u * 1024u;   // :61
+
+void spectrogram_config_default(omx_spectrogram_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->sample_rate = kDefaultSampleRate;
+    c->window = OMX_WINDOW_HANN;
+    c->fft_size = kDefaultFftSize;
+    c->hop_size = kDefaultHopSize;
+    c->history_length = 0;
+    c->zero_padding_factor = 1;
+    c->use_reassignment = 1;
+}
+
+static void normalize(omx_spectrogram_config& c) {  // :71-82
+    c.sample_rate = sanitize_sample_rate(c.sample_rate);
+    if (c.fft_size == 0) c.fft_size = kDefaultFftSize;
+    if (c.hop_size == 0) c.hop_size = std::max<uint64_t>(std::min<uint64_t>(kDefaultHopSize, c.fft_size), 1);
+    c.zero_padding_factor = std::max<uint64_t>(c.zero_padding_factor, 1);
+    c.use_reassignment = c.use_reassignment ? 1 : 0;
+    c._pad = 0;
+}
+
+uint64_t col_byte_stride(uint32_t kind, uint32_t points) {  // :144-151
+    if (kind == OMX_COLUMN_REASSIGNED) return (uint64_t)points * sizeof(omx_spectrogram_point);
+    return (((uint64_t)points + 1) / 2) * 4;
+}
+uint64_t history_columns(uint32_t kind, uint32_t points, uint64_t requested) {  // :153-158
+    const uint64_t clamped = std::min<uint64_t>(std::max<uint64_t>(requested, 1), kMaxHistoryColumns);
+    const uint64_t budget = (uint64_t)kHistoryByteBudget * (1 + (kind == OMX_COLUMN_REASSIGNED ? 1 : 0)) /
+                            std::max<uint64_t>(col_byte_stride(kind, points), 1);
+    return std::min(clamped, budget);
+}
+uint16_t pack_classic_db_host(float db) {  // :103-108
+    const float SCALE = 65535.0f / 156.0f;
+    float v = std::round((db - (-144.0f)) * SCALE);
+    v = v < 0.0f ? 0.0f : (v > 65535.0f ? 65535.0f : v);
+    return (v == v) ? (uint16_t)v : (uint16_t)0;
+}
+static size_t hilbert_len_for(size_t window_size) { return std::max<size_t>(next_pow2(window_size * 2), 2); }  // :225-227
+
+SpectrogramBank::SpectrogramBank(const omx_spectrogram_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {
+    cfg_ = cfg;
+    normalize(cfg_);
+    last_nonzero_.reserve(n_streams_);
+    OMX_HIP(hipMemset(last_nonzero_.ptr, 0xFF, n_streams_ * sizeof(long long)));  // -1 = None
+}
+
+void SpectrogramBank::reset_audio() {  // :212-217
+    tail_ = head_;
+    pending_skip_ = 0;
+    clear_last_nonzero(last_stream_);
+    reset_ = true;
+}
+
+void SpectrogramBank::clear_last_nonzero(hipStream_t stream) {
+    OMX_HIP(hipMemsetAsync(last_nonzero_.ptr, 0xFF, n_streams_ * sizeof(long long), stream));
+}
+
+void SpectrogramBank::ensure_ring(uint64_t incoming, hipStream_t stream) {
+    const uint64_t pending = head_ - tail_;
+    const uint64_t need = pending + incoming;
+    if (need <= ring_cap_) return;
+    uint64_t cap = std::max<uint64_t>(next_pow2(need), 1024);
+    DeviceBuffer<float> bigger;
+    bigger.reserve((size_t)(cap * n_streams_));
+    if (pending > 0 && ring_.ptr) {
+        // re-home the pending samples: absolute positions are kept, only the modulus changes
+        for (uint32_t s = 0; s < n_streams_; ++s) {
+            uint64_t pos = tail_;
+            while (pos < head_) {
+                const uint64_t src_off = pos & (ring_cap_ - 1), dst_off = pos & (cap - 1);
+                const uint64_t run = std::min({head_ - pos, ring_cap_ - src_off, cap - dst_off});
+                OMX_HIP(hipMemcpyAsync(bigger.ptr + s * cap + dst_off, ring_.ptr + s * ring_cap_ + src_off,
+                                       run * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                pos += run;
+            }
+        }
+        OMX_HIP(hipStreamSynchronize(stream));
+    }
+    std::swap(ring_.ptr, bigger.ptr);
+    std::swap(ring_.count, bigger.count);
+    ring_cap_ = cap;
+}
+
+void SpectrogramBank::drain(uint64_t count) {  // :397-404 (audio_last_nonzero is an absolute position here)
+    tail_ += std::min<uint64_t>(count, head_ - tail_);
+}
+void SpectrogramBank::advance(uint64_t count) {  // :406-410
+    const uint64_t len = head_ - tail_;
+    const uint64_t missing = count > len ? count - len : 0;
+    drain(count);
+    pending_skip_ += missing;
+}
+
+void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
+    const size_t W = (size_t)cfg_.fft_size;
+    if (!is_pow2(W)) unsupported("spectrogram fft_size must be a power of two, got " + std::to_string(W));
+    if (!is_pow2((size_t)cfg_.zero_padding_factor))
+        unsupported("spectrogram zero_padding_factor must be a power of two, got " + std::to_string(cfg_.zero_padding_factor));
+    fft_size_ = W * (size_t)cfg_.zero_padding_factor;
+    hilbert_len_ = hilbert_len_for(W);
+    if (fft_size_ > (size_t(1) << 24)) unsupported("spectrogram padded FFT longer than 2^24");
+    const bool reassign = cfg_.use_reassignment != 0;
+    const size_t active_len = reassign ? hilbert_len_ : fft_size_;
+
+    const std::vector<float> window = window_coefficients(cfg_.window, W);
+    std::vector<float> bin_norm = fft_bin_normalization(window, fft_size_);
+    d_window_.upload(window, stream);
+    d_tw_fft_.upload(twiddle_table(fft_size_, std::max<size_t>(fft_size_ / 2, 1)), stream);
+    if (reassign) {
+        const float inv_h = 1.0f / (float)hilbert_len_;  // :263-266
+        for (float& n : bin_norm) n *= inv_h * inv_h;
+        d_tw_hilbert_.upload(twiddle_table(hilbert_len_, hilbert_len_ / 2), stream);
+        // derivative window (:569-599): FFT-based, computed on the device
+        d_dwindow_.reserve(W);
+        if (W <= 1) {
+            OMX_HIP(hipMemsetAsync(d_dwindow_.ptr, 0, std::max<size_t>(W, 1) * sizeof(float), stream));
+        } else {
+            DeviceBuffer<float> tw_w, scratch;
+            tw_w.upload(twiddle_table(W, W / 2), stream);
+            scratch.reserve(2 * W);
+            launch_derivative_window(d_window_.ptr, (uint32_t)W, tw_w.ptr, scratch.ptr, d_dwindow_.ptr, stream);
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+        std::vector<float> tw(W);  // :601-608
+        const float center = (float)(W ? W - 1 : 0) * 0.5f;
+        for (size_t i = 0; i < W; ++i) tw[i] = ((float)i - center) * window[i];
+        d_twindow_.upload(tw, stream);
+        double sum = 0.0, squares = 0.0;  // :111-117
+        for (float xf : window) {
+            const double x = (double)xf;
+            sum = sum + x;
+            squares = squares + x * x;
+        }
+        power_scale_ = (float)(sum * sum / ((double)fft_size_ * squares));
+        fast4096_ = (W == 4096 && fft_size_ == 4096);
+        if (fast4096_) {
+            d_tw256_.upload(twiddle_table(256, 256), stream);
+            d_tw4096_.upload(twiddle_table(4096, 4096), stream);
+            d_tw8192_.upload(twiddle_table(8192, 4096), stream);
+        }
+    } else {
+        power_scale_ = 1.0f;
+        fast4096_ = false;
+    }
+    d_bin_norm_.upload(bin_norm, stream);
+    OMX_HIP(hipStreamSynchronize(stream));  // host vectors above go out of scope
+    prepared_ = true;
+
+    const uint64_t buffered_len = (uint64_t)active_len * 2;  // :275-278 keep the newest 2*active_len samples
+    const uint64_t pending = head_ - tail_;
+    drain(pending > buffered_len ? pending - buffered_len : 0);
+    pending_skip_ = 0;
+}
+
+void SpectrogramBank::prepare(hipStream_t stream) {
+    if (!prepared_) rebuild_fft(stream);
+}
+
+void SpectrogramBank::update_config(const omx_spectrogram_config& in, hipStream_t stream) {  // :518-543
+    omx_spectrogram_config cfg = in;
+    normalize(cfg);
+    const omx_spectrogram_config prev = cfg_;
+    const bool prepared = prepared_;
+    cfg_ = cfg;
+    const bool rate_changed = prev.sample_rate != cfg.sample_rate;
+    const bool rebuild = prev.fft_size != cfg.fft_size || prev.zero_padding_factor != cfg.zero_padding_factor ||
+                         prev.window != cfg.window || prev.use_reassignment != cfg.use_reassignment || rate_changed;
+    if (rebuild && prepared) {
+        rebuild_fft(stream);
+        if (rate_changed) {
+            tail_ = head_;
+            clear_last_nonzero(stream);
+        }
+    }
+    const bool hop_changed = prev.hop_size != cfg.hop_size;
+    if (hop_changed) pending_skip_ = 0;
+    reset_ = reset_ || rebuild || hop_changed;
+}
+
+int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in,
+                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                             omx_spectrogram_bank_update* out) {  // :490-516
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (frames == 0) return OMX_NONE;  // block.is_empty()
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (cfg_.sample_rate != sample_rate) {
+        cfg_.sample_rate = sample_rate;
+        rebuild_fft(stream);
+        tail_ = head_;
+        clear_last_nonzero(stream);
+        reset_ = true;
+    }
+    prepare(stream);
+
+    // ---- push_audio (:412-437)
+    const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
+    pending_skip_ -= skip;
+    if (skip != frames) {
+        const uint64_t count = frames - skip;
+        ensure_ring(count, stream);
+        const float* d_pcm = pcm;
+        if (!pcm_on_device) {
+            const size_t n = (size_t)n_streams_ * frames * channels;
+            staging_.reserve(n);
+            OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+            d_pcm = staging_.ptr;
+        }
+        IngestArgs ia{};
+        ia.pcm = d_pcm;
+        ia.frames_total = frames;
+        ia.skip = skip;
+        ia.count = count;
+        ia.fmt = make_format(channels, positions);
+        ia.n_out = 1;
+        ia.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
+        ia.ring[0] = ring_.ptr;
+        ia.cap = ring_cap_;
+        ia.head = head_;
+        ia.last_nonzero = last_nonzero_.ptr;
+        launch_ingest(ia, n_streams_, stream);
+        head_ += count;
+    }
+
+    // ---- process_ready_windows (:281-388)
+    const uint64_t W = cfg_.fft_size, hop = cfg_.hop_size;
+    const bool reassign = cfg_.use_reassignment != 0;
+    const uint64_t bin_count = fft_size_ / 2 + 1;
+    const uint64_t read_len = reassign ? hilbert_len_ : W;
+    const uint64_t center_offset = reassign ? (hilbert_len_ - W) / 2 : 0;
+    const uint64_t pending = head_ - tail_;
+    const uint64_t ready = pending >= read_len ? (pending - read_len) / hop + 1 : 0;
+    const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;
+    const uint64_t retained = history_columns(kind, (uint32_t)bin_count, cfg_.history_length);
+    const uint64_t skip_cols = ready > retained ? ready - retained : 0;
+    advance(skip_cols * hop);
+    const uint64_t n_cols = ready - skip_cols;
+    if (n_cols == 0) return OMX_NONE;
+    if (n_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
+
+    const uint64_t stride = bin_count;
+    d_counts_.reserve((size_t)(n_streams_ * n_cols));
+    if (reassign) d_points_.reserve((size_t)(n_streams_ * n_cols * stride));
+    else d_codes_.reserve((size_t)(n_streams_ * n_cols * stride));
+
+    const float sr = cfg_.sample_rate;
+    const float bin_hz = sr / (float)fft_size_;             // :446-450
+    const float max_hz = sr * 0.5f;
+    const float inv_2pi = sr / kTau;
+    const float inv_hop = 1.0f / (float)hop;
+    const float latency_hops = (float)center_offset * inv_hop;
+
+    timer_.begin(stream);
+    const bool fast = fast4096_ && reassign && !force_generic_;
+    if (fast) {
+        StftFastArgs fa{};
+        fa.ring = ring_.ptr;
+        fa.cap = ring_cap_;
+        fa.tail = tail_;
+        fa.hop = (uint32_t)hop;
+        fa.n_streams = n_streams_;
+        fa.n_cols = (uint32_t)n_cols;
+        fa.column_stride = (uint32_t)stride;
+        fa.last_nonzero = last_nonzero_.ptr;
+        fa.window = d_window_.ptr;
+        fa.dwindow = d_dwindow_.ptr;
+        fa.twindow = d_twindow_.ptr;
+        fa.bin_norm = d_bin_norm_.ptr;
+        fa.tw256 = reinterpret_cast<const v2f*>(d_tw256_.ptr);
+        fa.tw4096 = reinterpret_cast<const v2f*>(d_tw4096_.ptr);
+        fa.tw8192 = reinterpret_cast<const v2f*>(d_tw8192_.ptr);
+        fa.bin_hz = bin_hz;
+        fa.max_hz = max_hz;
+        fa.inv_2pi = inv_2pi;
+        fa.inv_hop = inv_hop;
+        fa.latency_hops = latency_hops;
+        fa.points = d_points_.ptr;
+        fa.counts = d_counts_.ptr;
+        launch_stft_reassigned_4096(fa, stream);
+    } else {
+        if (hop > 0xFFFFFFFFull) unsupported("hop_size beyond 2^32");
+        const uint64_t per_wg = reassign ? hilbert_len_ + 3 * fft_size_ : fft_size_;
+        const uint64_t total = (uint64_t)n_streams_ * n_cols;
+        // bound the workspace to ~1 GiB
+        uint64_t wgs = std::min<uint64_t>(total, 1024);
+        while (wgs > 1 && wgs * per_wg * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
+        d_workspace_.reserve((size_t)(wgs * per_wg * 2));
+        StftGenericArgs ga{};
+        ga.ring = ring_.ptr;
+        ga.cap = ring_cap_;
+        ga.tail = tail_;
+        ga.hop = (uint32_t)hop;
+        ga.n_streams = n_streams_;
+        ga.n_cols = (uint32_t)n_cols;
+        ga.column_stride = (uint32_t)stride;
+        ga.last_nonzero = last_nonzero_.ptr;
+        ga.reassign = reassign ? 1 : 0;
+        ga.window_size = (uint32_t)W;
+        ga.fft_size = (uint32_t)fft_size_;
+        ga.hilbert_len = (uint32_t)hilbert_len_;
+        ga.log_fft = log2_exact(fft_size_);
+        ga.log_hilbert = log2_exact(hilbert_len_);
+        ga.window = d_window_.ptr;
+        ga.dwindow = d_dwindow_.ptr;
+        ga.twindow = d_twindow_.ptr;
+        ga.bin_norm = d_bin_norm_.ptr;
+        ga.tw_fft = reinterpret_cast<const v2f*>(d_tw_fft_.ptr);
+        ga.tw_hilbert = reinterpret_cast<const v2f*>(d_tw_hilbert_.ptr);
+        ga.bin_hz = bin_hz;
+        ga.max_hz = max_hz;
+        ga.inv_2pi = inv_2pi;
+        ga.inv_hop = inv_hop;
+        ga.latency_hops = latency_hops;
+        ga.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
+        ga.workspace_stride = per_wg;
+        ga.points = d_points_.ptr;
+        ga.counts = d_counts_.ptr;
+        ga.codes = d_codes_.ptr;
+        launch_stft_generic(ga, (uint32_t)wgs, stream);
+    }
+    timer_.end(stream);
+    OMX_HIP(hipGetLastError());
+
+    for (uint64_t c = 0; c < n_cols; ++c) advance(hop);  // :384 per column (missing samples -> pending_skip)
+
+    last_cols_ = n_cols;
+    last_stride_ = stride;
+    last_kind_ = kind;
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->fft_size = fft_size_;
+        out->hop_size = hop;
+        out->history_length = cfg_.history_length;
+        out->n_streams = n_streams_;
+        out->n_columns = n_cols;
+        out->column_stride = stride;
+        out->d_counts = d_counts_.ptr;
+        out->d_points = reassign ? d_points_.ptr : nullptr;
+        out->d_codes = reassign ? nullptr : d_codes_.ptr;
+        out->sample_rate = cfg_.sample_rate;
+        out->reassigned_power_scale = power_scale_;
+        out->reset = reset_ ? 1 : 0;
+        out->kind = kind;
+    }
+    reset_ = false;  // std::mem::take (:511)
+    return OMX_PRODUCED;
+}
+
+int SpectrogramBank::fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out,
+                                  hipStream_t stream) {
+    if (stream_index >= n_streams_ || column >= last_cols_) {
+        set_last_error("fetch_column: index out of range");
+        return OMX_ERR_INVALID;
+    }
+    const uint64_t slot = stream_index * last_cols_ + column;
+    if (last_kind_ == OMX_COLUMN_REASSIGNED) {
+        uint32_t n = 0;
+        OMX_HIP(hipMemcpyAsync(&n, d_counts_.ptr + slot, sizeof(n), hipMemcpyDeviceToHost, stream));
+        OMX_HIP(hipStreamSynchronize(stream));
+        const uint64_t take = std::min<uint64_t>(n, cap);
+        if (take) {
+            OMX_HIP(hipMemcpyAsync(dst, d_points_.ptr + slot * last_stride_, take * sizeof(omx_spectrogram_point),
+                                   hipMemcpyDeviceToHost, stream));
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+        if (n_out) *n_out = n;
+    } else {
+        const uint64_t take = std::min<uint64_t>(last_stride_, cap);
+        OMX_HIP(hipMemcpyAsync(dst, d_codes_.ptr + slot * last_stride_, take * sizeof(uint16_t), hipMemcpyDeviceToHost,
+                               stream));
+        OMX_HIP(hipStreamSynchronize(stream));
+        if (n_out) *n_out = last_stride_;
+    }
+    return OMX_NONE;
+}
+
+// ------------------------------------------------------------------ single-stream handle (host in/out)
+int SpectrogramSingle::process_block(const omx_block* block, omx_spectrogram_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+    if (block->n_samples < channels) return OMX_NONE;  // AudioBlock::is_empty (dsp.rs:259-261)
+    const uint64_t frames = block->n_samples / channels;
+    omx_spectrogram_bank_update bu;
+    const int rc = bank.process(block->samples, false, frames, channels, block->sample_rate, block->positions, nullptr, &bu);
+    if (rc != OMX_PRODUCED) return rc;
+    const uint64_t n_cols = bu.n_columns, stride = bu.column_stride;
+    offsets.assign(1, 0);
+    points.clear();
+    codes.clear();
+    if (bu.kind == OMX_COLUMN_REASSIGNED) {
+        std::vector<uint32_t> counts(n_cols);
+        OMX_HIP(hipMemcpy(counts.data(), bu.d_counts, n_cols * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<omx_spectrogram_point> all(n_cols * stride);
+        OMX_HIP(hipMemcpy(all.data(), bu.d_points, all.size() * sizeof(omx_spectrogram_point), hipMemcpyDeviceToHost));
+        for (uint64_t c = 0; c < n_cols; ++c) {
+            points.insert(points.end(), all.begin() + c * stride, all.begin() + c * stride + counts[c]);
+            offsets.push_back(points.size());
+        }
+    } else {
+        codes.resize(n_cols * stride);
+        OMX_HIP(hipMemcpy(codes.data(), bu.d_codes, codes.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (uint64_t c = 0; c < n_cols; ++c) offsets.push_back((c + 1) * stride);
+    }
+    std::memset(out, 0, sizeof(*out));
+    out->fft_size = bu.fft_size;
+    out->hop_size = bu.hop_size;
+    out->history_length = bu.history_length;
+    out->n_columns = n_cols;
+    out->column_offsets = offsets.data();
+    out->points = points.data();
+    out->codes = codes.data();
+    out->sample_rate = bu.sample_rate;
+    out->reassigned_power_scale = bu.reassigned_power_scale;
+    out->reset = bu.reset;
+    out->kind = bu.kind;
+    return OMX_PRODUCED;
+}
+
+}  // namespace omx

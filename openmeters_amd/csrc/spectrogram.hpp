@@ -1,0 +1,63 @@
+// SpectrogramBank: S independent SpectrogramProcessors (reference
+// src/visuals/spectrogram/processor.rs:170-544) advanced in lock-step, one HIP launch per call.
+#pragma once
+#include "stft_kernels.hpp"
+
+namespace omx {
+
+void spectrogram_config_default(omx_spectrogram_config* c);
+uint64_t col_byte_stride(uint32_t kind, uint32_t points);
+uint64_t history_columns(uint32_t kind, uint32_t points, uint64_t requested);
+uint16_t pack_classic_db_host(float db);
+
+class SpectrogramBank {
+public:
+    SpectrogramBank(const omx_spectrogram_config& cfg, uint32_t n_streams);
+    const omx_spectrogram_config& config() const { return cfg_; }
+    void update_config(const omx_spectrogram_config& cfg, hipStream_t stream);
+    void reset_audio();
+    void prepare(hipStream_t stream);
+    int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
+                const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrogram_bank_update* out);
+    int fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out, hipStream_t stream);
+    EventTimer& timer() { return timer_; }
+    void force_generic(bool on) { force_generic_ = on; }
+    hipStream_t last_stream() const { return last_stream_; }
+
+private:
+    void rebuild_fft(hipStream_t stream);
+    void ensure_ring(uint64_t incoming, hipStream_t stream);
+    void drain(uint64_t count);
+    void advance(uint64_t count);
+    void clear_last_nonzero(hipStream_t stream);
+
+    omx_spectrogram_config cfg_{};
+    uint32_t n_streams_;
+    bool prepared_ = false, reset_ = true, fast4096_ = false, force_generic_ = false;
+    size_t fft_size_ = 0, hilbert_len_ = 0;
+    float power_scale_ = 1.0f;
+    // pending audio: absolute sample counters shared by all streams (lock-step pushes)
+    uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
+    DeviceBuffer<float> ring_, staging_;
+    DeviceBuffer<long long> last_nonzero_;
+    DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
+    DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_workspace_;
+    DeviceBuffer<omx_spectrogram_point> d_points_;
+    DeviceBuffer<uint32_t> d_counts_;
+    DeviceBuffer<uint16_t> d_codes_;
+    uint64_t last_cols_ = 0, last_stride_ = 0;
+    uint32_t last_kind_ = OMX_COLUMN_REASSIGNED;
+    EventTimer timer_;
+    hipStream_t last_stream_ = nullptr;
+};
+
+struct SpectrogramSingle {
+    SpectrogramBank bank;
+    std::vector<uint64_t> offsets;
+    std::vector<omx_spectrogram_point> points;
+    std::vector<uint16_t> codes;
+    explicit SpectrogramSingle(const omx_spectrogram_config& c) : bank(c, 1) {}
+    int process_block(const omx_block* block, omx_spectrogram_update* out);
+};
+
+}  // namespace omx

@@ -1,0 +1,474 @@
+// HIP kernels of the STFT hot path (gfx950 only).
+//
+//   K0 ingest_project      AudioBlock::stereo_frames + Channel::project + deque push
+//                          (reference src/dsp.rs:223-257, src/util/audio/channel.rs:13-21,
+//                           src/visuals/spectrogram/processor.rs:412-437)
+//   K2 stft_reassigned_4096 the headline kernel: Hilbert analytic signal + three windowed FFTs +
+//                          reassignment + ordered compaction, fused, one (stream, hop) per workgroup
+//                          (reference spectrogram/processor.rs:318-348, :439-488, :546-567)
+//   K1/K2 stft_generic      any power-of-two window / zero-padding, classic or reassigned, radix-2 in
+//                          global scratch in the oracle's operation order
+//                          (reference spectrogram/processor.rs:306-385)
+//   derivative_window       spectral derivative of the window (reference :569-599)
+#include "stft_kernels.hpp"
+
+#include "fft_device.hpp"
+
+namespace omx {
+
+// ================================================================================================
+// K0: fold C interleaved channels to [L,R], project, append to the per-stream mono rings.
+// ================================================================================================
+__device__ __forceinline__ float project_lr(int channel, float left, float right) {
+    switch (channel) {  // channel.rs:13-21
+        case OMX_CHANNEL_LEFT: return left;
+        case OMX_CHANNEL_RIGHT: return right;
+        case OMX_CHANNEL_MID: return (left + right) * 0.5f;
+        case OMX_CHANNEL_SIDE: return (left - right) * 0.5f;
+        default: return 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
+    const uint32_t s = blockIdx.y;
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < a.count;
+    float out[OMX_INGEST_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) out[o] = 0.0f;
+    if (live) {
+        const float* frame = a.pcm + ((uint64_t)s * a.frames_total + a.skip + idx) * a.fmt.channels;
+        // dsp.rs:223-249: left = (0.0 + s0*w00) + s1*w10 + ...  (same order as the general fold; the
+        // 1- and 2-channel specialisations of the reference are bit-identical to it, dsp.rs:591-624)
+        float left = 0.0f, right = 0.0f;
+        const float first = frame[0];
+        for (uint32_t c = 0; c < a.fmt.channels; ++c) {
+            const float v = frame[c];
+            left = left + v * a.fmt.m[c][0];
+            right = right + v * a.fmt.m[c][1];
+        }
+#pragma unroll
+        for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+            if (o >= a.n_out) break;
+            // OMX_PROJECT_RAW: spectrogram's `channels == 1` path pushes the raw samples (:420-428)
+            out[o] = a.project[o] == OMX_PROJECT_RAW ? first : project_lr(a.project[o], left, right);
+            a.ring[o][(uint64_t)s * a.cap + ((a.head + idx) & (a.cap - 1))] = out[o];
+        }
+    }
+    if (a.last_nonzero) {  // audio_last_nonzero (:423-425, :432-434) for ring 0
+        const unsigned long long nz = __ballot(live && out[0] != 0.0f);
+        if (nz != 0ull && (threadIdx.x & 63) == 0) {
+            const int hi = 63 - __clzll((long long)nz);
+            const long long pos = (long long)(a.head + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u) + hi);
+            atomicMax(&a.last_nonzero[s], pos);
+        }
+    }
+}
+
+void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) {
+    if (a.count == 0 || n_streams == 0) return;
+    dim3 grid((unsigned)((a.count + 255) / 256), n_streams);
+    hipLaunchKernelGGL(ingest_project_kernel, grid, dim3(256), 0, stream, a);
+}
+
+// ================================================================================================
+// Shared pieces of the STFT kernels
+// ================================================================================================
+__device__ __forceinline__ float power_to_db_dev(float power, float floor) {  // level.rs:28-34
+    return power > 0.0f ? fmaxf(logf(power) * 4.3429448f, floor) : floor;
+}
+__device__ __forceinline__ uint16_t pack_classic_db_dev(float db) {  // spectrogram/processor.rs:103-108
+    const float SCALE = 65535.0f / 156.0f;
+    float v = roundf((db - (-144.0f)) * SCALE);
+    v = v < 0.0f ? 0.0f : (v > 65535.0f ? 65535.0f : v);
+    return (v == v) ? (uint16_t)v : (uint16_t)0;
+}
+
+// XCD-aware block -> (stream, column) map: block b runs on XCD b % 8 (observed dispatch order), so
+// stream s is pinned to XCD s % 8 and its consecutive columns are consecutive blocks on that XCD:
+// the 97 % overlap between neighbouring windows is served from that XCD's L2.
+__device__ __forceinline__ bool block_to_stream_column(uint32_t n_streams, uint32_t n_cols, uint32_t& s, uint32_t& col) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, q = b >> 3;
+    s = (q / n_cols) * 8u + xcd;
+    col = q % n_cols;
+    return s < n_streams;
+}
+uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols) { return ((n_streams + 7u) / 8u) * 8u * n_cols; }
+
+// spectrogram/processor.rs:459-485 for one bin; returns keep flag
+struct ReassignConsts {
+    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
+};
+__device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, float norm, const ReassignConsts& c,
+                                             omx_spectrogram_point& p) {
+    const float pow = b.x * b.x + b.y * b.y;
+    const float scaled_power = pow * norm;
+    if (scaled_power < 1e-14f) return false;  // ANALYSIS_FLOOR_POWER (:69)
+    const float inv_pow = 1.0f / pow;
+    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
+    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
+    if (!(freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f)) return false;
+    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
+    p.freq_hz = freq_hz;
+    p.power = scaled_power;
+    return true;
+}
+
+// ================================================================================================
+// K2: fused reassigned STFT, W = F = 4096, H = 8192.  256 threads, two padded 4096-complex LDS
+// buffers (68 KiB) -> two workgroups per CU.  Algorithm (all f32):
+//   1. 8192 real samples packed as 4096 complex -> FFT4096 -> real-FFT split gives X[0..4096]
+//   2. Hilbert: drop X[0], keep X[1..4096]; the unnormalised 8192-point inverse restricted to a
+//      half-filled spectrum is two 4096-point inverses (even / odd output samples)
+//   3. s = analytic[2048 .. 6144); three windowed forward FFT4096 (w, w', t*w)
+//   4. per-bin reassignment + ordered compaction (ascending bin), 12-byte points
+// ================================================================================================
+template <bool INV>
+__device__ __forceinline__ void fft4096_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const Fft4096Tables& tb) {
+    fft4096_pass1<INV>(v0, A, j);
+    fft4096_pass1<INV>(v1, B, j);
+    __syncthreads();
+    {  // pass 2 on both buffers with shared barriers
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(j + 256 * t)];
+            b[t] = B[pad16(j + 256 * t)];
+        }
+        const int k = j & 15;
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tb.tw256[k * t];
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+        __syncthreads();
+        const int base = (j >> 4) * 272 + k;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            A[base + 17 * t] = a[DFT16_OUT(t)];
+            B[base + 17 * t] = b[DFT16_OUT(t)];
+        }
+    }
+    __syncthreads();
+    {
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(j + 256 * t)];
+            b[t] = B[pad16(j + 256 * t)];
+        }
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tb.tw4096[j * t];
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            v0[t] = a[DFT16_OUT(t)];
+            v1[t] = b[DFT16_OUT(t)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void stft_reassigned_4096_kernel(StftFastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* A = reinterpret_cast<v2f*>(smem_raw);
+    v2f* B = A + FFT4096_LDS;
+    uint32_t* scan = reinterpret_cast<uint32_t*>(B + FFT4096_LDS);  // [9][4] wave counts
+
+    uint32_t s, col;
+    if (!block_to_stream_column(a.n_streams, a.n_cols, s, col)) return;
+    const int j = threadIdx.x;
+    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;  // absolute position of this window's first sample
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+
+    // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
+    if (a.last_nonzero[s] < (long long)p0) {
+        if (j == 0) *count_out = 0;
+        return;
+    }
+    const Fft4096Tables tb{a.tw256, a.tw4096};
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint64_t mask = a.cap - 1;
+
+    // ---- 1. packed real FFT of the 8192-sample window ------------------------------------------
+    v2f v[16];
+    if ((p0 & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            v[t] = *reinterpret_cast<const v2f*>(ring + ((p0 + 2u * (uint32_t)(j + 256 * t)) & mask));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint64_t q = p0 + 2u * (uint32_t)(j + 256 * t);
+            v[t] = v2f{ring[q & mask], ring[(q + 1) & mask]};
+        }
+    }
+    fft4096<false>(v, A, j, tb);  // v[t] = Z[j + 256 t]
+
+    // ---- 2. real-FFT split + Hilbert mask -> inputs of the two half-length inverses -------------
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
+    __syncthreads();
+    v2f y0[16], y1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = j + 256 * t;
+        const v2f z = v[t];
+        const v2f zr = A[pad16((4096 - k) & 4095)];
+        const v2f zc{zr.x, -zr.y};                               // conj(Z[N-k])
+        const v2f e{(z.x + zc.x) * 0.5f, (z.y + zc.y) * 0.5f};   // spectrum of the even samples
+        const v2f dd{z.x - zc.x, z.y - zc.y};
+        const v2f o{dd.y * 0.5f, -dd.x * 0.5f};                  // (Z - Zc) / (2i): spectrum of the odd samples
+        const v2f w = a.tw8192[k];                               // exp(-2*pi*i*k/8192)
+        const v2f x = e + cmul(w, o);                            // X[k], 0 <= k < 4096
+        if (k == 0) {                                            // X[0] is dropped; X[4096] = E[0] - O[0] aliases to index 0
+            const float xn = e.x - o.x;
+            y0[t] = v2f{xn, 0.0f};
+            y1[t] = v2f{-xn, 0.0f};
+        } else {
+            y0[t] = x;                                           // even output samples
+            y1[t] = cmulc(x, w);                                 // odd output samples: X[k] * exp(+2*pi*i*k/8192)
+        }
+    }
+    __syncthreads();
+    fft4096_dual<true>(y0, y1, A, B, j, tb);  // y0[t] = a[2(j+256t)], y1[t] = a[2(j+256t)+1]
+
+    // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t --------------------------------------
+    __syncthreads();
+#pragma unroll
+    for (int t = 4; t < 12; ++t) {
+        const int i = 2 * (j + 256 * t - 1024);
+        B[pad16(i)] = y0[t];
+        B[pad16(i + 1)] = y1[t];
+    }
+    __syncthreads();
+    v2f sv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sv[t] = B[pad16(j + 256 * t)];
+    __syncthreads();
+
+    // ---- three windowed FFTs; keep bins j + 256 t (t < 8) and bin 2048 (thread 0, t = 8) ----------
+    v2f bb[9], bd[9], bt[9];
+    {
+        v2f vb[16], vd[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float w = a.window[j + 256 * t], dw = a.dwindow[j + 256 * t];
+            vb[t] = v2f{sv[t].x * w, sv[t].y * w};
+            vd[t] = v2f{sv[t].x * dw, sv[t].y * dw};
+        }
+        fft4096_dual<false>(vb, vd, A, B, j, tb);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            bb[t] = vb[t];
+            bd[t] = vd[t];
+        }
+    }
+    {
+        v2f vt[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float w = a.twindow[j + 256 * t];
+            vt[t] = v2f{sv[t].x * w, sv[t].y * w};
+        }
+        __syncthreads();
+        fft4096<false>(vt, A, j, tb);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bt[t] = vt[t];
+    }
+
+    // ---- 4. reassignment + ordered compaction -----------------------------------------------------
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    omx_spectrogram_point pts[9];
+    unsigned long long masks[9];
+    const int lane = j & 63, wave = j >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t bin = (uint32_t)(j + 256 * t);
+        bool keep = false;
+        if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], a.bin_norm[bin], rc, pts[t]);
+        masks[t] = __ballot(keep);
+        if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
+    }
+    __syncthreads();
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t before = running;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = scan[t * 4 + w];
+            if (w < wave) before += c;
+            running += c;
+        }
+        if ((masks[t] >> lane) & 1ull) {
+            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+            out[pos] = pts[t];
+        }
+    }
+    if (j == 0) *count_out = running;
+}
+
+void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    const size_t lds = (size_t)2 * FFT4096_LDS * sizeof(v2f) + 9 * 4 * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stft_reassigned_4096_kernel, dim3(stream_column_grid(a.n_streams, a.n_cols)), dim3(256), lds,
+                       stream, a);
+}
+
+// ================================================================================================
+// Generic spectrogram kernel: any power-of-two W, F = W * zp, H = next_pow2(2W); persistent
+// workgroups with a global-memory workspace each; operation order follows the reference loop.
+// ================================================================================================
+__global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
+    __shared__ uint32_t scan[4];
+    __shared__ uint32_t running_sh;
+    __shared__ float mean_sh;
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t total = (uint64_t)a.n_streams * a.n_cols;
+    v2f* ws = a.workspace + (uint64_t)blockIdx.x * a.workspace_stride;
+    const uint32_t bins = a.fft_size / 2 + 1;
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+
+    for (uint64_t item = blockIdx.x; item < total; item += gridDim.x) {
+        const uint32_t s = (uint32_t)(item / a.n_cols), col = (uint32_t)(item % a.n_cols);
+        const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+        const float* ring = a.ring + (uint64_t)s * a.cap;
+        const uint64_t mask = a.cap - 1;
+        const bool silent = a.last_nonzero[s] < (long long)p0;
+        __syncthreads();
+        if (a.reassign) {
+            omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+            uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+            if (silent) {
+                if (tid == 0) *count_out = 0;
+                continue;
+            }
+            v2f* hil = ws;
+            v2f* spec = ws + a.hilbert_len;
+            for (uint32_t i = tid; i < a.hilbert_len; i += nt) hil[i] = v2f{ring[(p0 + i) & mask], 0.0f};
+            fft_radix2(hil, a.hilbert_len, a.log_hilbert, a.tw_hilbert, false, tid, nt);
+            for (uint32_t i = tid; i < a.hilbert_len; i += nt)
+                if (i == 0 || i > a.hilbert_len / 2) hil[i] = v2f{0.0f, 0.0f};  // :554-555
+            fft_radix2(hil, a.hilbert_len, a.log_hilbert, a.tw_hilbert, true, tid, nt);
+            const uint32_t center = (a.hilbert_len - a.window_size) / 2;
+            for (uint32_t i = tid; i < a.fft_size; i += nt) {  // :559-567 x3
+                v2f b{0.0f, 0.0f}, d{0.0f, 0.0f}, t{0.0f, 0.0f};
+                if (i < a.window_size) {
+                    const v2f z = hil[center + i];
+                    const float w = a.window[i], dw = a.dwindow[i], tw = a.twindow[i];
+                    b = v2f{z.x * w, z.y * w};
+                    d = v2f{z.x * dw, z.y * dw};
+                    t = v2f{z.x * tw, z.y * tw};
+                }
+                spec[i] = b;
+                spec[a.fft_size + i] = d;
+                spec[2 * a.fft_size + i] = t;
+            }
+            for (int q = 0; q < 3; ++q)
+                fft_radix2(spec + (uint64_t)q * a.fft_size, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
+            if (tid == 0) running_sh = 0;
+            __syncthreads();
+            for (uint32_t base = 0; base < bins; base += nt) {  // ordered compaction, ascending bins
+                const uint32_t i = base + tid;
+                omx_spectrogram_point p;
+                bool keep = false;
+                if (i < bins)
+                    keep = reassign_bin(i, spec[i], spec[a.fft_size + i], spec[2 * a.fft_size + i], a.bin_norm[i], rc, p);
+                const unsigned long long m = __ballot(keep);
+                const unsigned lane = tid & 63, wave = tid >> 6;
+                if (lane == 0) scan[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t before = running_sh, all = 0;
+                for (unsigned w = 0; w < (nt + 63) / 64; ++w) {
+                    if (w < wave) before += scan[w];
+                    all += scan[w];
+                }
+                if (keep) out[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+                __syncthreads();
+                if (tid == 0) running_sh += all;
+                __syncthreads();
+            }
+            if (tid == 0) *count_out = running_sh;
+        } else {
+            uint16_t* out = a.codes + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+            if (silent) {
+                const uint16_t floor_code = pack_classic_db_dev(-140.0f);
+                for (uint32_t i = tid; i < bins; i += nt) out[i] = floor_code;
+                continue;
+            }
+            // window.rs:66-88: mean is the reference's sequential f32 sum (kept sequential here: this is
+            // the generic, order-faithful kernel)
+            if (tid == 0) {
+                float sum = -0.0f;
+                for (uint32_t i = 0; i < a.window_size; ++i) sum = sum + ring[(p0 + i) & mask];
+                mean_sh = sum / (float)a.window_size;
+            }
+            __syncthreads();
+            const float mean = mean_sh;
+            for (uint32_t i = tid; i < a.fft_size; i += nt) {
+                float x = 0.0f;
+                if (i < a.window_size) x = (ring[(p0 + i) & mask] - mean) * a.window[i];
+                ws[i] = v2f{x, 0.0f};
+            }
+            fft_radix2(ws, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
+            for (uint32_t i = tid; i < bins; i += nt) {  // :369-379
+                const v2f c = ws[i];
+                out[i] = pack_classic_db_dev(power_to_db_dev((c.x * c.x + c.y * c.y) * a.bin_norm[i], -140.0f));
+            }
+        }
+    }
+}
+
+void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_workgroups), dim3(256), 0, stream, a);
+}
+
+// ================================================================================================
+// compute_derivative_spectral (spectrogram/processor.rs:569-599) on the device, once per config.
+// ================================================================================================
+__global__ __launch_bounds__(256) void derivative_window_kernel(const float* window, uint32_t n, uint32_t logn,
+                                                                const v2f* tw, v2f* scratch, float* out) {
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    for (uint32_t i = tid; i < n; i += nt) scratch[i] = v2f{window[i], 0.0f};
+    fft_radix2(scratch, n, logn, tw, false, tid, nt);
+    const float scale = 6.28318530717958647692f / (float)n;
+    const uint32_t half = n / 2;
+    for (uint32_t k = tid; k < n; k += nt) {
+        v2f b = scratch[k];
+        if (k == 0 || k == half) b = v2f{0.0f, 0.0f};  // n is a power of two >= 2 here, so even
+        if (k >= 1) {
+            const float omega = scale * ((float)k - (k > half ? (float)n : 0.0f));
+            b = v2f{-omega * b.y, omega * b.x};
+        }
+        scratch[k] = b;
+    }
+    fft_radix2(scratch, n, logn, tw, true, tid, nt);
+    const float inv_n = 1.0f / (float)n;
+    for (uint32_t i = tid; i < n; i += nt) out[i] = scratch[i].x * inv_n;
+}
+
+void launch_derivative_window(const float* window, uint32_t n, const void* tw, void* scratch, float* out,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(derivative_window_kernel, dim3(1), dim3(256), 0, stream, window, n, log2_exact(n),
+                       reinterpret_cast<const v2f*>(tw), reinterpret_cast<v2f*>(scratch), out);
+}
+
+}  // namespace omx

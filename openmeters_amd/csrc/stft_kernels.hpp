@@ -1,0 +1,89 @@
+// Launch interfaces of the STFT kernels (see stft_kernels.hip / spectrum_kernels.hip).  Plain structs
+// of device pointers and scalars, passed by value as kernel arguments.  Every translation unit of
+// the library is compiled by hipcc, so the clang vector type below is available on both sides.
+#pragma once
+#include "common.hpp"
+
+namespace omx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // (re, im)
+
+// ---------------------------------------------------------------- K0 ingest
+constexpr int OMX_INGEST_MAX_OUT = 3;
+constexpr int OMX_PROJECT_RAW = -1;  // push frame[0] unprojected (spectrogram mono path)
+
+struct IngestArgs {
+    const float* pcm;         // [n_streams][frames_total][channels]
+    uint64_t frames_total;    // frames per stream in `pcm`
+    uint64_t skip;            // leading frames not pushed (pending_skip)
+    uint64_t count;           // frames pushed per stream = frames_total - skip
+    AudioFormatArgs fmt;
+    int n_out;
+    int project[OMX_INGEST_MAX_OUT];
+    float* ring[OMX_INGEST_MAX_OUT];  // [n_streams][cap] each
+    uint64_t cap;             // power of two
+    uint64_t head;            // absolute write position of the first pushed sample
+    long long* last_nonzero;  // [n_streams] absolute position of the newest non-zero sample of ring 0, or nullptr
+};
+void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream);
+
+// ---------------------------------------------------------------- K2 fast reassigned STFT (W = F = 4096)
+struct StftFastArgs {
+    const float* ring;  // [n_streams][cap]
+    uint64_t cap;
+    uint64_t tail;      // absolute position of column 0's first sample
+    uint32_t hop;
+    uint32_t n_streams;
+    uint32_t n_cols;
+    uint32_t column_stride;  // points per column slot
+    const long long* last_nonzero;
+    const float* window;     // [4096]
+    const float* dwindow;    // [4096] derivative window
+    const float* twindow;    // [4096] time-weighted window
+    const float* bin_norm;   // [2049]
+    const v2f* tw256;        // exp(-2*pi*i*k/256),  k < 256
+    const v2f* tw4096;       // exp(-2*pi*i*k/4096), k < 4096
+    const v2f* tw8192;       // exp(-2*pi*i*k/8192), k < 4096
+    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
+    omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
+    uint32_t* counts;               // [n_streams][n_cols]
+};
+void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream);
+uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
+
+// ---------------------------------------------------------------- K1/K2 generic spectrogram
+struct StftGenericArgs {
+    const float* ring;
+    uint64_t cap;
+    uint64_t tail;
+    uint32_t hop;
+    uint32_t n_streams;
+    uint32_t n_cols;
+    uint32_t column_stride;
+    const long long* last_nonzero;
+    uint32_t reassign;      // 0 classic, 1 reassigned
+    uint32_t window_size;   // W
+    uint32_t fft_size;      // F = W * zero_padding_factor
+    uint32_t hilbert_len;   // H (reassigned only)
+    uint32_t log_fft, log_hilbert;
+    const float* window;
+    const float* dwindow;
+    const float* twindow;
+    const float* bin_norm;  // [F/2+1]
+    const v2f* tw_fft;      // exp(-2*pi*i*k/F), k < F/2
+    const v2f* tw_hilbert;  // exp(-2*pi*i*k/H), k < H/2
+    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
+    v2f* workspace;            // [n_workgroups][workspace_stride]
+    uint64_t workspace_stride; // >= H + 3F (reassigned) or F (classic)
+    omx_spectrogram_point* points;
+    uint32_t* counts;
+    uint16_t* codes;           // [n_streams][n_cols][column_stride] (classic)
+};
+void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream);
+
+// compute_derivative_spectral on the device: n = power of two >= 2, tw = exp(-2*pi*i*k/n) (k < n/2),
+// scratch = n complex values.
+void launch_derivative_window(const float* window, uint32_t n, const void* tw, void* scratch, float* out,
+                              hipStream_t stream);
+
+}  // namespace omx

@@ -1,0 +1,78 @@
+"""Column-level parity metrics between the HIP product and the CPU oracle (test infra).
+
+Reassigned columns are variable-length, ascending-bin lists of (time_offset, freq_hz, power) with no
+bin index, and a bin sitting on the 1e-14 analysis floor or on the 0 < f < fs/2 edge may appear in
+one list only.  `align_points` walks both lists like a merge: points whose power agrees are paired;
+anything else is an orphan and must be weak (checked by the caller).  All errors are normalised the
+way SURVEY §7 defines "1e-5 relative": against the column's maximum, not per-bin.
+"""
+import numpy as np
+
+
+def align_points(a, b, max_power):
+    """Returns (pairs, orphans_a, orphans_b); pairs index into a / b."""
+    i = j = 0
+    pairs, oa, ob = [], [], []
+    tol_abs = 1e-5 * max_power
+    while i < len(a) and j < len(b):
+        pa, pb = a[i, 2], b[j, 2]
+        if abs(pa - pb) <= tol_abs + 2e-3 * min(pa, pb) and abs(a[i, 1] - b[j, 1]) <= max(50.0, 0.02 * abs(b[j, 1])):
+            pairs.append((i, j))
+            i += 1
+            j += 1
+            continue
+        # look ahead a few entries for a re-synchronisation point
+        found = None
+        for da in range(0, 4):
+            for db in range(0, 4):
+                if da == db == 0 or i + da >= len(a) or j + db >= len(b):
+                    continue
+                qa, qb = a[i + da, 2], b[j + db, 2]
+                if abs(qa - qb) <= tol_abs + 2e-3 * min(qa, qb) and abs(a[i + da, 1] - b[j + db, 1]) <= max(
+                        50.0, 0.02 * abs(b[j + db, 1])):
+                    found = (da, db)
+                    break
+            if found:
+                break
+        if not found:
+            found = (1, 1)
+        oa.extend(range(i, i + found[0]))
+        ob.extend(range(j, j + found[1]))
+        i += found[0]
+        j += found[1]
+    oa.extend(range(i, len(a)))
+    ob.extend(range(j, len(b)))
+    return pairs, oa, ob
+
+
+def reassigned_column_metrics(hip, ora, sample_rate, hop):
+    """Normalised error metrics for one column.
+      power : max |dP| / max P
+      freq  : max |df| * r / (fs/2),  r = sqrt(P / max P)   (amplitude-weighted: the reassignment ratio
+              d*conj(b)/|b|^2 amplifies the f32 FFT noise floor by 1/r on weak bins)
+      time  : max |dt| * r   (hops)
+      orphan: max P(orphan) / max P
+    """
+    max_power = float(max(ora[:, 2].max() if len(ora) else 0.0, hip[:, 2].max() if len(hip) else 0.0))
+    if max_power <= 0.0:
+        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, n=0, orphans=len(hip) + len(ora))
+    pairs, oa, ob = align_points(hip, ora, max_power)
+    pa = np.array([p[0] for p in pairs], int)
+    pb = np.array([p[1] for p in pairs], int)
+    m = dict(n=len(pairs), orphans=len(oa) + len(ob))
+    if len(pairs):
+        h, o = hip[pa].astype(np.float64), ora[pb].astype(np.float64)
+        r = np.sqrt(o[:, 2] / max_power)
+        m["power"] = float(np.abs(h[:, 2] - o[:, 2]).max() / max_power)
+        m["freq"] = float((np.abs(h[:, 1] - o[:, 1]) * r).max() / (sample_rate * 0.5))
+        m["time"] = float((np.abs(h[:, 0] - o[:, 0]) * r).max())
+    else:
+        m.update(power=0.0, freq=0.0, time=0.0)
+    orphan_p = [hip[i, 2] for i in oa] + [ora[j, 2] for j in ob]
+    m["orphan"] = float(max(orphan_p) / max_power) if orphan_p else 0.0
+    return m
+
+
+def classic_column_metrics(hip, ora):
+    d = np.abs(hip.astype(np.int64) - ora.astype(np.int64))
+    return dict(max_code_diff=int(d.max()) if len(d) else 0, n_diff=int((d > 0).sum()), n=len(d))
