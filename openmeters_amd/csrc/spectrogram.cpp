@@ -231,6 +231,8 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         ia.cap = ring_cap_;
         ia.head = head_;
         ia.last_nonzero = last_nonzero_.ptr;
+        partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(count));
+        ia.partial_nonzero = partial_nonzero_.ptr;
         launch_ingest(ia, n_streams_, stream);
         head_ += count;
     }

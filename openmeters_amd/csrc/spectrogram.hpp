@@ -39,7 +39,7 @@ private:
     // pending audio: absolute sample counters shared by all streams (lock-step pushes)
     uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
     DeviceBuffer<float> ring_, staging_;
-    DeviceBuffer<long long> last_nonzero_;
+    DeviceBuffer<long long> last_nonzero_, partial_nonzero_;
     DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
     DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_workspace_;
     DeviceBuffer<omx_spectrogram_point> d_points_;

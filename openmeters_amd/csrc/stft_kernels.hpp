@@ -23,8 +23,10 @@ struct IngestArgs {
     float* ring[OMX_INGEST_MAX_OUT];  // [n_streams][cap] each
     uint64_t cap;             // power of two
     uint64_t head;            // absolute write position of the first pushed sample
-    long long* last_nonzero;  // [n_streams] absolute position of the newest non-zero sample of ring 0, or nullptr
+    long long* last_nonzero;     // [n_streams] absolute position of the newest non-zero sample of ring 0, or nullptr
+    long long* partial_nonzero;  // [n_streams][ingest_partials_per_stream(count)] scratch, or nullptr
 };
+uint32_t ingest_partials_per_stream(uint64_t count);
 void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream);
 
 // ---------------------------------------------------------------- K2 fast reassigned STFT (W = F = 4096)

@@ -31,11 +31,18 @@ struct FftPlan {
 
 template <class T>
 inline std::shared_ptr<const FftPlan<T>> fft_plan(size_t n) {
+    // per-thread front cache so the timed multi-thread baseline does not serialise on the mutex
+    static thread_local std::map<size_t, std::shared_ptr<const FftPlan<T>>> local;
+    auto lit = local.find(n);
+    if (lit != local.end()) return lit->second;
     static std::mutex mu;
     static std::map<size_t, std::shared_ptr<const FftPlan<T>>> cache;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(n);
-    if (it != cache.end()) return it->second;
+    if (it != cache.end()) {
+        local[n] = it->second;
+        return it->second;
+    }
     auto p = std::make_shared<FftPlan<T>>();
     p->n = n;
     p->pow2 = n >= 1 && (n & (n - 1)) == 0;
@@ -59,6 +66,7 @@ inline std::shared_ptr<const FftPlan<T>> fft_plan(size_t n) {
             p->tw[k] = std::complex<T>((T)std::cos(step * (double)k), (T)std::sin(step * (double)k));
     }
     cache[n] = p;
+    local[n] = p;
     return p;
 }
 
