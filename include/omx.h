@@ -280,6 +280,7 @@ int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on
                               omx_spectrum_bank_update* out);
 int omx_spectrum_bank_fetch(omx_spectrum_bank* b, uint64_t stream_index, uint64_t hop,
                             float* dst /* [2][2][bins] */);
+int omx_spectrum_bank_set_option(omx_spectrum_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *
  * Loudness — reference src/visuals/loudness/processor.rs

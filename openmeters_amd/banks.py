@@ -81,3 +81,58 @@ class SpectrogramBank:
         self.api.check(self.api.fn("spectrogram_bank_kernel_time", C.c_int,
                                    [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)])(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class SpectrumBank:
+    """S lock-step SpectrumProcessors (reference src/visuals/spectrum/processor.rs:72-323).
+    emit_all_hops=True materialises every hop's traces (what a caller feeding one-hop blocks would have
+    seen); False keeps the reference's snapshot semantics (latest hop only)."""
+
+    def __init__(self, api: Api, config: capi.SpectrumConfig, n_streams: int, emit_all_hops: bool = False):
+        self.api = api
+        self.n_streams = n_streams
+        self._h = C.c_void_p()
+        c = config.to_c()
+        api.check(api.fn("spectrum_bank_create", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)])(
+            C.byref(c), n_streams, int(emit_all_hops), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.fn("spectrum_bank_destroy", None, [C.c_void_p])(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_audio(self):
+        self.api.check(self.api.fn("spectrum_bank_reset_audio", C.c_int, [C.c_void_p])(self._h))
+
+    def set_option(self, option: int, value: int):
+        self.api.check(self.api.fn("spectrum_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(
+            self._h, option, value))
+
+    def _process(self, ptr, on_device, frames, channels, sample_rate, positions, stream):
+        out = capi.CSpectrumBankUpdate()
+        f = self.api.fn("spectrum_bank_process", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        rc = self.api.check(f(self._h, C.c_void_p(ptr), int(on_device), frames, channels, sample_rate,
+                              _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out if rc == capi.PRODUCED else None
+
+    def process_device(self, device_ptr, frames, channels, sample_rate, positions, stream=0):
+        return self._process(device_ptr, True, frames, channels, sample_rate, positions, stream)
+
+    def process_host(self, pcm, channels, sample_rate, positions=None):
+        pcm = np.ascontiguousarray(pcm, np.float32).reshape(self.n_streams, -1, channels)
+        positions = positions if positions is not None else capi.positions_fallback(channels)
+        return self._process(pcm.ctypes.data, False, pcm.shape[1], channels, sample_rate, positions, 0)
+
+    def fetch(self, stream_index: int, hop: int, bins: int) -> np.ndarray:
+        """-> float32 [2 traces][2 = (A-weighted, raw)][bins]"""
+        buf = np.zeros((2, 2, bins), np.float32)
+        self.api.check(self.api.fn("spectrum_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p])(
+            self._h, stream_index, hop, buf.ctypes.data))
+        return buf

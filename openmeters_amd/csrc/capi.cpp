@@ -3,6 +3,7 @@
 // negative omx_status values with the text available from omx_last_error().
 #include "common.hpp"
 #include "spectrogram.hpp"
+#include "spectrum.hpp"
 
 namespace omx {
 const std::string& last_error();
@@ -22,6 +23,15 @@ struct omx_spectrogram {
 struct omx_spectrogram_bank {
     SpectrogramBank impl;
     omx_spectrogram_bank(const omx_spectrogram_config& c, uint32_t n) : impl(c, n) {}
+};
+
+struct omx_spectrum {
+    SpectrumSingle impl;
+    explicit omx_spectrum(const omx_spectrum_config& c) : impl(c) {}
+};
+struct omx_spectrum_bank {
+    SpectrumBank impl;
+    omx_spectrum_bank(const omx_spectrum_config& c, uint32_t n, bool all) : impl(c, n, all) {}
 };
 
 extern "C" {
@@ -127,6 +137,89 @@ int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, ui
     });
 }
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value) {
+    if (!b) return OMX_ERR_INVALID;
+    switch (option) {
+        case OMX_OPT_KERNEL_TIMING: b->impl.timer().enabled = value != 0; return OMX_NONE;
+        case OMX_OPT_FORCE_GENERIC: b->impl.force_generic(value != 0); return OMX_NONE;
+        default: return OMX_ERR_INVALID;
+    }
+}
+
+// ------------------------------------------------------------------ spectrum
+void omx_spectrum_config_default(omx_spectrum_config* out) {
+    if (out) spectrum_config_default(out);
+}
+int omx_spectrum_create(const omx_spectrum_config* cfg, omx_spectrum** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_spectrum(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_spectrum_destroy(omx_spectrum* h) { delete h; }
+int omx_spectrum_get_config(const omx_spectrum* h, omx_spectrum_config* out) {
+    if (!h || !out) return OMX_ERR_INVALID;
+    *out = h->impl.bank.config();
+    return OMX_NONE;
+}
+int omx_spectrum_update_config(omx_spectrum* h, const omx_spectrum_config* cfg) {
+    if (!h || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->impl.bank.update_config(*cfg, nullptr);
+        return (int)OMX_NONE;
+    });
+}
+int omx_spectrum_reset_audio(omx_spectrum* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->impl.bank.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_spectrum_prepare(omx_spectrum* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->impl.bank.prepare(nullptr);
+        return (int)OMX_NONE;
+    });
+}
+int omx_spectrum_process_block(omx_spectrum* h, const omx_block* block, omx_spectrum_snapshot* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    return guarded([&] { return h->impl.process_block(block, out); });
+}
+float omx_a_weight(float freq_hz) { return a_weight_host(freq_hz); }
+
+int omx_spectrum_bank_create(const omx_spectrum_config* cfg, uint32_t n_streams, int emit_all_hops, omx_spectrum_bank** out) {
+    if (!cfg || !out || n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_spectrum_bank(*cfg, n_streams, emit_all_hops != 0);
+        return (int)OMX_NONE;
+    });
+}
+void omx_spectrum_bank_destroy(omx_spectrum_bank* b) { delete b; }
+int omx_spectrum_bank_reset_audio(omx_spectrum_bank* b) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on_device, uint64_t frames, uint32_t channels,
+                              float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                              omx_spectrum_bank_update* out) {
+    if (!b || !pcm || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process(pcm, pcm_on_device != 0, frames, channels, sample_rate, positions,
+                               static_cast<hipStream_t>(stream), out);
+    });
+}
+int omx_spectrum_bank_fetch(omx_spectrum_bank* b, uint64_t stream_index, uint64_t hop, float* dst) {
+    if (!b || !dst) return OMX_ERR_INVALID;
+    return guarded([&] { return b->impl.fetch(stream_index, hop, dst, b->impl.last_stream()); });
+}
+int omx_spectrum_bank_set_option(omx_spectrum_bank* b, uint32_t option, uint64_t value) {
     if (!b) return OMX_ERR_INVALID;
     switch (option) {
         case OMX_OPT_KERNEL_TIMING: b->impl.timer().enabled = value != 0; return OMX_NONE;

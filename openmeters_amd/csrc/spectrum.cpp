@@ -1,0 +1,332 @@
+// Host side of the spectrum path: the state machine of reference
+// src/visuals/spectrum/processor.rs:72-323 (config normalisation, per-trace pending audio, hop
+// draining with pending_skip, level-buffer resets) driving the K3 kernels.
+#include "spectrum.hpp"
+
+namespace omx {
+
+constexpr float kDefaultSpectrumFloor = -100.0f;  // :22
+constexpr size_t kDefaultHopDivisor = 16;         // :24
+constexpr size_t kDefaultSpectrumFft = 16384;     // :25
+
+void spectrum_config_default(omx_spectrum_config* c) {  // :39-51
+    std::memset(c, 0, sizeof(*c));
+    c->sample_rate = kDefaultSampleRate;
+    c->window = OMX_WINDOW_HANN;
+    c->fft_size = kDefaultSpectrumFft;
+    c->hop_size = kDefaultSpectrumFft / kDefaultHopDivisor;
+    c->averaging_mode = OMX_AVERAGING_NONE;
+    c->averaging_param = 0.0f;
+    c->source = OMX_CHANNEL_MID;
+    c->secondary_source = OMX_CHANNEL_NONE;
+    c->floor_db = kDefaultSpectrumFloor;
+}
+
+static void normalize(omx_spectrum_config& c) {  // :53-62
+    c.sample_rate = sanitize_sample_rate(c.sample_rate);
+    c.fft_size = std::max<uint64_t>(c.fft_size, 1);
+    if (c.hop_size == 0) c.hop_size = std::max<uint64_t>(c.fft_size / kDefaultHopDivisor, 1);
+    c.floor_db = (std::isfinite(c.floor_db) && c.floor_db < 0.0f) ? c.floor_db : kDefaultSpectrumFloor;  // level.rs:20-26
+    c._pad = 0;
+}
+
+float a_weight_host(float freq_hz) {  // :410-425
+    const double C1 = 20.598997 * 20.598997, C2 = 107.65265 * 107.65265, C3 = 737.86223 * 737.86223,
+                 C4 = 12194.217 * 12194.217;
+    if (freq_hz <= 0.0f) return -std::numeric_limits<float>::infinity();
+    const double f = (double)freq_hz, f2 = f * f;
+    const double numerator = C4 * f2 * f2;
+    const double denom = (f2 + C1) * std::sqrt((f2 + C2) * (f2 + C3)) * (f2 + C4);
+    return (float)(20.0 * std::log10(numerator / denom) + 2.0);
+}
+
+SpectrumBank::SpectrumBank(const omx_spectrum_config& cfg, uint32_t n_streams, bool emit_all_hops)
+    : n_streams_(n_streams), emit_all_(emit_all_hops) {
+    cfg_ = cfg;
+    normalize(cfg_);
+}
+
+void SpectrumBank::active_traces(bool out[2]) const {  // :174-177
+    out[0] = cfg_.source != OMX_CHANNEL_NONE;
+    out[1] = cfg_.secondary_source != OMX_CHANNEL_NONE && cfg_.secondary_source != cfg_.source;
+}
+
+void SpectrumBank::reset_audio() {  // :112-118
+    if (prepared_) reset_level_buffers(last_stream_);
+    tail_ = head_;
+    pending_skip_ = 0;
+}
+
+void SpectrumBank::prepare(hipStream_t stream) {
+    if (!prepared_) rebuild_fft(stream);
+}
+
+void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
+    const size_t N = (size_t)cfg_.fft_size;
+    if (!is_pow2(N)) unsupported("spectrum fft_size must be a power of two, got " + std::to_string(N));
+    if (N > (size_t(1) << 24)) unsupported("spectrum FFT longer than 2^24");
+    const std::vector<float> window = window_coefficients(cfg_.window, N);
+    d_window_.upload(window, stream);
+    d_bin_norm_.upload(fft_bin_normalization(window, N), stream);
+    d_tw_fft_.upload(twiddle_table(N, std::max<size_t>(N / 2, 1)), stream);
+    fast4096_ = N == 4096;
+    if (fast4096_) {
+        d_tw256_.upload(twiddle_table(256, 256), stream);
+        d_tw4096_.upload(twiddle_table(4096, 4096), stream);
+    }
+    prepared_ = true;
+    reset_buffers(stream);
+}
+
+void SpectrumBank::reset_buffers(hipStream_t stream) {  // :138-150
+    const size_t bins = (size_t)cfg_.fft_size / 2 + 1;
+    const float bin_hz = cfg_.sample_rate / (float)cfg_.fft_size;
+    freq_bins_.resize(bins);
+    a_weight_.resize(bins);
+    for (size_t b = 0; b < bins; ++b) {
+        const float f = (float)b * bin_hz;
+        freq_bins_[b] = f;
+        a_weight_[b] = a_weight_host(f);
+    }
+    d_freq_bins_.upload(freq_bins_, stream);
+    d_a_weight_.upload(a_weight_, stream);
+    reset_level_buffers(stream);
+    tail_ = head_;
+    pending_skip_ = 0;
+}
+
+void SpectrumBank::reset_level_buffers(hipStream_t stream) {  // :152-168
+    const size_t bins = (size_t)cfg_.fft_size / 2 + 1;
+    float headroom = 0.0f;  // :332-336 smoothing_state_floor
+    for (float w : a_weight_) headroom = std::fmax(headroom, w);
+    state_floor_ = std::fmax(db_to_power_host(cfg_.floor_db - headroom), std::numeric_limits<float>::min());
+    if (cfg_.averaging_mode != OMX_AVERAGING_NONE) {
+        d_smoothed_.reserve((size_t)n_streams_ * 2 * bins);
+        OMX_HIP(hipMemsetAsync(d_smoothed_.ptr, 0, (size_t)n_streams_ * 2 * bins * sizeof(float), stream));
+    }
+    traces_dirty_ = true;  // snapshot traces go back to the floor
+}
+
+void SpectrumBank::update_config(const omx_spectrum_config& in, hipStream_t stream) {  // :300-322
+    const omx_spectrum_config old = cfg_;
+    omx_spectrum_config cfg = in;
+    normalize(cfg);
+    cfg_ = cfg;
+    if (!prepared_) return;
+    const bool mode_changed = old.averaging_mode != cfg.averaging_mode;
+    if (old.fft_size != cfg.fft_size || old.window != cfg.window) {
+        rebuild_fft(stream);
+    } else if (old.sample_rate != cfg.sample_rate || old.hop_size != cfg.hop_size || old.source != cfg.source ||
+               old.secondary_source != cfg.secondary_source) {
+        reset_buffers(stream);
+    } else if (mode_changed || std::fabs(old.floor_db - cfg.floor_db) > std::numeric_limits<float>::epsilon()) {
+        reset_level_buffers(stream);
+    }
+}
+
+void SpectrumBank::ensure_ring(uint64_t incoming, hipStream_t stream) {
+    const uint64_t pending = head_ - tail_;
+    const uint64_t need = pending + incoming;
+    if (need <= ring_cap_ && ring_[0].ptr && ring_[1].ptr) return;
+    const uint64_t cap = std::max<uint64_t>(next_pow2(std::max(need, ring_cap_)), 1024);
+    for (int t = 0; t < 2; ++t) {
+        DeviceBuffer<float> bigger;
+        bigger.reserve((size_t)(cap * n_streams_));
+        if (pending > 0 && ring_[t].ptr && ring_cap_) {
+            for (uint32_t s = 0; s < n_streams_; ++s) {
+                uint64_t pos = tail_;
+                while (pos < head_) {
+                    const uint64_t src_off = pos & (ring_cap_ - 1), dst_off = pos & (cap - 1);
+                    const uint64_t run = std::min({head_ - pos, ring_cap_ - src_off, cap - dst_off});
+                    OMX_HIP(hipMemcpyAsync(bigger.ptr + s * cap + dst_off, ring_[t].ptr + s * ring_cap_ + src_off,
+                                           run * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                    pos += run;
+                }
+            }
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+        std::swap(ring_[t].ptr, bigger.ptr);
+        std::swap(ring_[t].count, bigger.count);
+    }
+    ring_cap_ = cap;
+}
+
+int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in, float sample_rate_in,
+                          const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (frames == 0) return OMX_NONE;
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (sample_rate != cfg_.sample_rate) {  // :258-263
+        cfg_.sample_rate = sample_rate;
+        if (prepared_) reset_buffers(stream);
+    }
+    prepare(stream);
+    bool active[2];
+    active_traces(active);
+    const uint32_t n_traces = (active[0] ? 1 : 0) + (active[1] ? 1 : 0);
+
+    // ---- push_sources (:271-298)
+    const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
+    pending_skip_ -= skip;
+    if (skip != frames && n_traces > 0) {
+        const uint64_t count = frames - skip;
+        ensure_ring(count, stream);
+        const float* d_pcm = pcm;
+        if (!pcm_on_device) {
+            const size_t n = (size_t)n_streams_ * frames * channels;
+            staging_.reserve(n);
+            OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+            d_pcm = staging_.ptr;
+        }
+        IngestArgs ia{};
+        ia.pcm = d_pcm;
+        ia.frames_total = frames;
+        ia.skip = skip;
+        ia.count = count;
+        ia.fmt = make_format(channels, positions);
+        ia.n_out = 0;
+        if (active[0]) { ia.project[ia.n_out] = (int)cfg_.source; ia.ring[ia.n_out] = ring_[0].ptr; ++ia.n_out; }
+        if (active[1]) { ia.project[ia.n_out] = (int)cfg_.secondary_source; ia.ring[ia.n_out] = ring_[1].ptr; ++ia.n_out; }
+        ia.cap = ring_cap_;
+        ia.head = head_;
+        ia.last_nonzero = nullptr;
+        ia.partial_nonzero = nullptr;
+        launch_ingest(ia, n_streams_, stream);
+        head_ += count;
+    }
+
+    // ---- process_ready_windows (:179-213)
+    if (n_traces == 0) return OMX_NONE;
+    const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size;
+    const uint64_t tail0 = tail_;
+    uint64_t n_hops = 0;
+    while (head_ - tail_ >= N) {
+        const uint64_t len = head_ - tail_;
+        const uint64_t d = std::min<uint64_t>(hop, len);
+        tail_ += d;
+        pending_skip_ += hop - d;
+        ++n_hops;
+    }
+    if (n_hops == 0) return OMX_NONE;
+    if (hop > 0xFFFFFFFFull || n_hops > 0x7FFFFFFFull) unsupported("hop / hop count beyond 2^31");
+
+    const uint64_t bins = N / 2 + 1;
+    const bool averaging = cfg_.averaging_mode != OMX_AVERAGING_NONE;
+    const uint64_t hops_out = emit_all_ ? n_hops : 1;
+    // AveragingMode::None with latest-hop output: earlier hops cannot influence the snapshot (:364-365)
+    const uint64_t first_hop = (!averaging && !emit_all_) ? n_hops - 1 : 0;
+    const uint64_t hops_launch = n_hops - first_hop;
+
+    d_power_.reserve((size_t)(n_streams_ * n_traces * hops_launch * bins));
+    const size_t traces_count = (size_t)(n_streams_ * hops_out * 4 * bins);
+    if (d_traces_.count < traces_count) {
+        d_traces_.reserve(traces_count);
+        traces_dirty_ = true;
+    }
+    if (traces_dirty_ || hops_out != last_hops_out_) {  // inactive traces stay at the floor (:155-157)
+        launch_fill(d_traces_.ptr, d_traces_.count, cfg_.floor_db, stream);
+        traces_dirty_ = false;
+    }
+    last_hops_out_ = hops_out;
+
+    timer_.begin(stream);
+    SpectrumPowerArgs pa{};
+    uint32_t slot = 0, slots[2] = {0, 0};
+    for (int t = 0; t < 2; ++t)
+        if (active[t]) {
+            pa.ring[slot] = ring_[t].ptr;
+            slots[slot] = (uint32_t)t;
+            ++slot;
+        }
+    pa.cap = ring_cap_;
+    pa.tail = tail0;
+    pa.hop = (uint32_t)hop;
+    pa.first_hop = (uint32_t)first_hop;
+    pa.n_hops = (uint32_t)hops_launch;
+    pa.n_streams = n_streams_;
+    pa.n_traces = n_traces;
+    pa.fft_size = (uint32_t)N;
+    pa.log_fft = log2_exact(N);
+    pa.bins = (uint32_t)bins;
+    pa.window = d_window_.ptr;
+    pa.bin_norm = d_bin_norm_.ptr;
+    pa.tw_fft = reinterpret_cast<const v2f*>(d_tw_fft_.ptr);
+    pa.tw256 = reinterpret_cast<const v2f*>(d_tw256_.ptr);
+    pa.tw4096 = reinterpret_cast<const v2f*>(d_tw4096_.ptr);
+    const bool fast = fast4096_ && !force_generic_;
+    uint64_t wgs = 0;
+    if (!fast) {
+        wgs = std::min<uint64_t>((uint64_t)n_streams_ * n_traces * hops_launch, 1024);
+        while (wgs > 1 && wgs * N * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
+        d_workspace_.reserve((size_t)(wgs * N * 2));
+        pa.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
+    }
+    pa.power = d_power_.ptr;
+    launch_spectrum_power(pa, fast, (uint32_t)wgs, stream);
+
+    SpectrumLevelsArgs la{};
+    la.power = d_power_.ptr;
+    la.smoothed = averaging ? d_smoothed_.ptr : nullptr;
+    la.traces = d_traces_.ptr;
+    la.a_weighting_db = d_a_weight_.ptr;
+    la.trace_slot[0] = slots[0];
+    la.trace_slot[1] = slots[1];
+    la.n_streams = n_streams_;
+    la.n_traces = n_traces;
+    la.n_hops = (uint32_t)hops_launch;
+    la.n_hops_out = (uint32_t)hops_out;
+    la.bins = (uint32_t)bins;
+    la.mode = cfg_.averaging_mode;
+    la.emit_all = emit_all_ ? 1 : 0;
+    const float dt_seconds = (float)hop / cfg_.sample_rate;  // :184
+    const float factor = cfg_.averaging_param;
+    la.alpha = factor < 0.0f ? 0.0f : (factor > 0.9999f ? 0.9999f : factor);           // :367
+    la.decay = db_to_power_host(-std::fmax(cfg_.averaging_param, 0.0f) * dt_seconds);  // :381
+    la.state_floor = state_floor_;
+    la.floor_db = cfg_.floor_db;
+    launch_spectrum_levels(la, stream);
+    timer_.end(stream);
+    OMX_HIP(hipGetLastError());
+
+    if (out) {
+        out->bins = bins;
+        out->n_streams = n_streams_;
+        out->n_hops = n_hops;
+        out->n_hops_out = hops_out;
+        out->d_traces = d_traces_.ptr;
+        out->d_frequency_bins = d_freq_bins_.ptr;
+    }
+    return OMX_PRODUCED;
+}
+
+int SpectrumBank::fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStream_t stream) {
+    if (stream_index >= n_streams_ || hop >= last_hops_out_ || !d_traces_.ptr) {
+        set_last_error("spectrum fetch: index out of range");
+        return OMX_ERR_INVALID;
+    }
+    const uint64_t bins = cfg_.fft_size / 2 + 1;
+    OMX_HIP(hipMemcpyAsync(dst, d_traces_.ptr + (stream_index * last_hops_out_ + hop) * 4 * bins, 4 * bins * sizeof(float),
+                           hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    return OMX_NONE;
+}
+
+int SpectrumSingle::process_block(const omx_block* block, omx_spectrum_snapshot* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+    if (block->n_samples < channels) return OMX_NONE;
+    omx_spectrum_bank_update bu;
+    const int rc = bank.process(block->samples, false, block->n_samples / channels, channels, block->sample_rate,
+                                block->positions, nullptr, &bu);
+    if (rc != OMX_PRODUCED) return rc;
+    traces.resize(4 * bu.bins);
+    const int frc = bank.fetch(0, 0, traces.data(), nullptr);
+    if (frc < 0) return frc;
+    out->bins = bu.bins;
+    out->frequency_bins = bank.frequency_bins().data();
+    for (int t = 0; t < 2; ++t)
+        for (int w = 0; w < 2; ++w) out->traces[t][w] = traces.data() + (size_t)(t * 2 + w) * bu.bins;
+    return OMX_PRODUCED;
+}
+
+}  // namespace omx

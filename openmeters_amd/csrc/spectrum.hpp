@@ -1,0 +1,55 @@
+// SpectrumBank: S independent SpectrumProcessors (reference src/visuals/spectrum/processor.rs:72-323)
+// advanced in lock-step.
+#pragma once
+#include "stft_kernels.hpp"
+
+namespace omx {
+
+void spectrum_config_default(omx_spectrum_config* c);
+float a_weight_host(float freq_hz);  // spectrum/processor.rs:410-425
+
+class SpectrumBank {
+public:
+    SpectrumBank(const omx_spectrum_config& cfg, uint32_t n_streams, bool emit_all_hops);
+    const omx_spectrum_config& config() const { return cfg_; }
+    void update_config(const omx_spectrum_config& cfg, hipStream_t stream);
+    void reset_audio();
+    void prepare(hipStream_t stream);
+    int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
+                const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out);
+    int fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStream_t stream);
+    const std::vector<float>& frequency_bins() const { return freq_bins_; }
+    uint64_t bins() const { return cfg_.fft_size / 2 + 1; }
+    hipStream_t last_stream() const { return last_stream_; }
+    void force_generic(bool on) { force_generic_ = on; }
+    EventTimer& timer() { return timer_; }
+
+private:
+    void rebuild_fft(hipStream_t stream);
+    void reset_buffers(hipStream_t stream);
+    void reset_level_buffers(hipStream_t stream);
+    void active_traces(bool out[2]) const;
+    void ensure_ring(uint64_t incoming, hipStream_t stream);
+
+    omx_spectrum_config cfg_{};
+    uint32_t n_streams_;
+    bool emit_all_, prepared_ = false, fast4096_ = false, force_generic_ = false, traces_dirty_ = true;
+    uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
+    DeviceBuffer<float> ring_[2], staging_;
+    DeviceBuffer<float> d_window_, d_bin_norm_, d_a_weight_, d_freq_bins_, d_tw_fft_, d_tw256_, d_tw4096_, d_workspace_;
+    DeviceBuffer<float> d_power_, d_smoothed_, d_traces_;
+    std::vector<float> freq_bins_, a_weight_;
+    float state_floor_ = 0.0f;
+    uint64_t last_hops_out_ = 0;
+    EventTimer timer_;
+    hipStream_t last_stream_ = nullptr;
+};
+
+struct SpectrumSingle {
+    SpectrumBank bank;
+    std::vector<float> traces;  // [2][2][bins]
+    explicit SpectrumSingle(const omx_spectrum_config& c) : bank(c, 1, false) {}
+    int process_block(const omx_block* block, omx_spectrum_snapshot* out);
+};
+
+}  // namespace omx

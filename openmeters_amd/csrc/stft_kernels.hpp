@@ -83,6 +83,40 @@ struct StftGenericArgs {
 };
 void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream);
 
+// ---------------------------------------------------------------- K3 spectrum
+struct SpectrumPowerArgs {
+    const float* ring[2];  // per active trace: [n_streams][cap]
+    uint64_t cap;
+    uint64_t tail;         // absolute position of hop 0's first sample
+    uint32_t hop;
+    uint32_t first_hop;    // first hop index computed by this launch
+    uint32_t n_hops;       // hops computed by this launch
+    uint32_t n_streams;
+    uint32_t n_traces;     // active traces (1 or 2)
+    uint32_t fft_size, log_fft, bins;
+    const float* window;
+    const float* bin_norm;
+    const v2f* tw_fft;     // generic: exp(-2*pi*i*k/N), k < N/2
+    const v2f* tw256;      // fast 4096
+    const v2f* tw4096;
+    v2f* workspace;        // generic: [wgs][fft_size]
+    float* power;          // [n_streams][n_traces][n_hops][bins]
+};
+void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream);
+
+struct SpectrumLevelsArgs {
+    const float* power;    // [n_streams][n_traces][n_hops][bins]
+    float* smoothed;       // [n_streams][2][bins] averaging state, or nullptr for AveragingMode::None
+    float* traces;         // [n_streams][n_hops_out][2 traces][2 weightings][bins]
+    const float* a_weighting_db;  // [bins]
+    uint32_t trace_slot[2];
+    uint32_t n_streams, n_traces, n_hops, n_hops_out, bins;
+    uint32_t mode, emit_all;
+    float alpha, decay, state_floor, floor_db;
+};
+void launch_spectrum_levels(const SpectrumLevelsArgs& a, hipStream_t stream);
+void launch_fill(float* p, uint64_t n, float v, hipStream_t stream);
+
 // compute_derivative_spectral on the device: n = power of two >= 2, tw = exp(-2*pi*i*k/n) (k < n/2),
 // scratch = n complex values.
 void launch_derivative_window(const float* window, uint32_t n, const void* tw, void* scratch, float* out,
