@@ -325,12 +325,13 @@ int omx_loudness_bank_create(const omx_loudness_config* cfg, uint32_t n_streams,
 void omx_loudness_bank_destroy(omx_loudness_bank* b);
 int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
 int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device,
-                              uint64_t block_frames, uint64_t n_blocks, float sample_rate,
-                              const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
-                              const omx_loudness_snapshot** d_snapshots);
+                              uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                              float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
+                              void* stream, const omx_loudness_snapshot** d_snapshots);
 int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block,
                             omx_loudness_snapshot* dst);
 int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t* launches);
+int omx_loudness_bank_set_option(omx_loudness_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *
  * Stereometer — reference src/visuals/stereometer/processor.rs
@@ -428,6 +429,41 @@ int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block,
 /* Test/diagnostic view of the trigger state (reference `last_cycle_rate`, :602-609):
  * returns 1 and writes Hz when a period is locked, else 0. */
 int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz);
+
+
+/* ---- batched bank: S independent OscilloscopeProcessors, one workgroup per stream ---- */
+typedef struct omx_oscilloscope_bank omx_oscilloscope_bank;
+/* per (stream, block) result header; `produced` mirrors `process_block(..).is_some()`,
+ * `locked`/`period` mirror the trigger behind `last_cycle_rate` (:602-609). */
+typedef struct omx_oscilloscope_block_header {
+    uint32_t produced;
+    uint32_t channels;
+    uint32_t slots[2];
+    uint32_t samples_per_channel;
+    uint32_t locked;
+    float period;
+    uint32_t _pad;
+} omx_oscilloscope_block_header;
+/* d_headers: [n_streams][n_blocks]; d_samples: f32 [n_streams][2][sample_stride], the snapshot of
+ * the newest block (first samples_per_channel entries of each of the `channels` rows are valid). */
+typedef struct omx_oscilloscope_bank_update {
+    uint64_t n_streams;
+    uint64_t n_blocks;
+    uint64_t epoch;
+    uint64_t sample_stride;
+    const omx_oscilloscope_block_header* d_headers;
+    const float* d_samples;
+} omx_oscilloscope_bank_update;
+int omx_oscilloscope_bank_create(const omx_oscilloscope_config* cfg, uint32_t n_streams,
+                                 omx_oscilloscope_bank** out);
+void omx_oscilloscope_bank_destroy(omx_oscilloscope_bank* b);
+int omx_oscilloscope_bank_reset_audio(omx_oscilloscope_bank* b);
+int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, int pcm_on_device,
+                                  uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                                  float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
+                                  void* stream, omx_oscilloscope_bank_update* out);
+int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
+                                omx_oscilloscope_block_header* header, float* samples);
 
 #ifdef __cplusplus
 }

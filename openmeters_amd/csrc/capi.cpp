@@ -4,6 +4,9 @@
 #include "common.hpp"
 #include "spectrogram.hpp"
 #include "spectrum.hpp"
+#include "loudness.hpp"
+#include "stereometer.hpp"
+#include "oscilloscope.hpp"
 
 namespace omx {
 const std::string& last_error();
@@ -32,6 +35,35 @@ struct omx_spectrum {
 struct omx_spectrum_bank {
     SpectrumBank impl;
     omx_spectrum_bank(const omx_spectrum_config& c, uint32_t n, bool all) : impl(c, n, all) {}
+};
+
+struct omx_loudness {
+    LoudnessBank bank;
+    explicit omx_loudness(const omx_loudness_config& c) : bank(c, 1) {}
+};
+struct omx_loudness_bank {
+    LoudnessBank impl;
+    omx_loudness_bank(const omx_loudness_config& c, uint32_t n) : impl(c, n) {}
+};
+struct omx_stereometer {
+    StereometerBank bank;
+    std::vector<float> points[4];
+    explicit omx_stereometer(const omx_stereometer_config& c) : bank(c, 1) {}
+};
+struct omx_stereometer_bank {
+    StereometerBank impl;
+    omx_stereometer_bank(const omx_stereometer_config& c, uint32_t n) : impl(c, n) {}
+};
+struct omx_oscilloscope {
+    OscilloscopeBank bank;
+    std::vector<float> samples;
+    ScopeBlockHeader last{};
+    bool have_last = false;
+    explicit omx_oscilloscope(const omx_oscilloscope_config& c) : bank(c, 1) {}
+};
+struct omx_oscilloscope_bank {
+    OscilloscopeBank impl;
+    omx_oscilloscope_bank(const omx_oscilloscope_config& c, uint32_t n) : impl(c, n) {}
 };
 
 extern "C" {
@@ -226,6 +258,289 @@ int omx_spectrum_bank_set_option(omx_spectrum_bank* b, uint32_t option, uint64_t
         case OMX_OPT_FORCE_GENERIC: b->impl.force_generic(value != 0); return OMX_NONE;
         default: return OMX_ERR_INVALID;
     }
+}
+
+// ------------------------------------------------------------------ loudness
+void omx_loudness_config_default(omx_loudness_config* out) {
+    if (out) loudness_config_default(out);
+}
+int omx_loudness_create(const omx_loudness_config* cfg, omx_loudness** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_loudness(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_loudness_destroy(omx_loudness* h) { delete h; }
+int omx_loudness_reset_audio(omx_loudness* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_loudness_process_block(omx_loudness* h, const omx_block* block, omx_loudness_snapshot* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+        if (block->n_samples < channels) return (int)OMX_NONE;
+        const int rc = h->bank.process(block->samples, false, block->n_samples / channels, 1, channels, block->sample_rate,
+                                       block->positions, nullptr, nullptr);
+        if (rc != OMX_PRODUCED) return rc;
+        const int frc = h->bank.fetch(0, 0, out, nullptr);
+        return frc < 0 ? frc : (int)OMX_PRODUCED;
+    });
+}
+void omx_k_weighting_coefficients(double fs, double b[5], double a[5]) { k_weighting_coefficients(fs, b, a); }
+
+int omx_loudness_bank_create(const omx_loudness_config* cfg, uint32_t n_streams, uint32_t channels, omx_loudness_bank** out) {
+    (void)channels;  // the channel count is taken from each call, like LoudnessProcessor::ensure_state
+    if (!cfg || !out || n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_loudness_bank(*cfg, n_streams);
+        return (int)OMX_NONE;
+    });
+}
+void omx_loudness_bank_destroy(omx_loudness_bank* b) { delete b; }
+int omx_loudness_bank_reset_audio(omx_loudness_bank* b) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device, uint64_t block_frames, uint64_t n_blocks,
+                              uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                              const omx_loudness_snapshot** d_snapshots) {
+    if (!b || !pcm || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process(pcm, pcm_on_device != 0, block_frames, n_blocks, channels, sample_rate, positions,
+                               static_cast<hipStream_t>(stream), d_snapshots);
+    });
+}
+int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst) {
+    if (!b || !dst) return OMX_ERR_INVALID;
+    return guarded([&] { return b->impl.fetch(stream_index, block, dst, b->impl.last_stream()); });
+}
+int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t* launches) {
+    if (!b || !avg_ms) return OMX_ERR_INVALID;
+    return guarded([&] {
+        *avg_ms = b->impl.timer().collect(launches);
+        return (int)OMX_NONE;
+    });
+}
+int omx_loudness_bank_set_option(omx_loudness_bank* b, uint32_t option, uint64_t value) {
+    if (!b) return OMX_ERR_INVALID;
+    if (option == OMX_OPT_KERNEL_TIMING) {
+        b->impl.timer().enabled = value != 0;
+        return OMX_NONE;
+    }
+    return OMX_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ stereometer
+void omx_stereometer_config_default(omx_stereometer_config* out) {
+    if (out) stereometer_config_default(out);
+}
+int omx_stereometer_create(const omx_stereometer_config* cfg, omx_stereometer** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_stereometer(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_stereometer_destroy(omx_stereometer* h) { delete h; }
+int omx_stereometer_get_config(const omx_stereometer* h, omx_stereometer_config* out) {
+    if (!h || !out) return OMX_ERR_INVALID;
+    *out = h->bank.config();
+    return OMX_NONE;
+}
+int omx_stereometer_update_config(omx_stereometer* h, const omx_stereometer_config* cfg) {
+    if (!h || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.update_config(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+int omx_stereometer_reset_audio(omx_stereometer* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_stereometer_process_block(omx_stereometer* h, const omx_block* block, omx_stereometer_snapshot* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+        if (block->n_samples < channels) return (int)OMX_NONE;
+        omx_stereometer_bank_update bu;
+        const int rc = h->bank.process(block->samples, false, block->n_samples / channels, 1, channels, block->sample_rate,
+                                       block->positions, nullptr, &bu);
+        if (rc != OMX_PRODUCED) return rc;
+        uint32_t produced = 0;
+        int frc = h->bank.fetch(0, 0, out->correlations, &produced, nullptr);
+        if (frc < 0) return frc;
+        for (uint32_t band = 0; band < 4; ++band) {
+            h->points[band].resize((size_t)h->bank.target() * 2);
+            uint64_t n = 0;
+            frc = h->bank.fetch_points(0, band, h->points[band].data(), &n, nullptr);
+            if (frc < 0) return frc;
+            out->points[band] = h->points[band].data();
+            out->n_points[band] = n;
+        }
+        return (int)OMX_PRODUCED;
+    });
+}
+
+int omx_stereometer_bank_create(const omx_stereometer_config* cfg, uint32_t n_streams, omx_stereometer_bank** out) {
+    if (!cfg || !out || n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_stereometer_bank(*cfg, n_streams);
+        return (int)OMX_NONE;
+    });
+}
+void omx_stereometer_bank_destroy(omx_stereometer_bank* b) { delete b; }
+int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int pcm_on_device, uint64_t block_frames,
+                                 uint64_t n_blocks, uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
+                                 void* stream, omx_stereometer_bank_update* out) {
+    if (!b || !pcm || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process(pcm, pcm_on_device != 0, block_frames, n_blocks, channels, sample_rate, positions,
+                               static_cast<hipStream_t>(stream), out);
+    });
+}
+int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block, float correlations[4],
+                               uint32_t* produced) {
+    if (!b || !correlations) return OMX_ERR_INVALID;
+    return guarded([&] { return b->impl.fetch(stream_index, block, correlations, produced, b->impl.last_stream()); });
+}
+
+// ------------------------------------------------------------------ oscilloscope
+void omx_oscilloscope_config_default(omx_oscilloscope_config* out) {
+    if (out) oscilloscope_config_default(out);
+}
+int omx_oscilloscope_create(const omx_oscilloscope_config* cfg, omx_oscilloscope** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_oscilloscope(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_oscilloscope_destroy(omx_oscilloscope* h) { delete h; }
+int omx_oscilloscope_get_config(const omx_oscilloscope* h, omx_oscilloscope_config* out) {
+    if (!h || !out) return OMX_ERR_INVALID;
+    *out = h->bank.config();
+    return OMX_NONE;
+}
+int omx_oscilloscope_update_config(omx_oscilloscope* h, const omx_oscilloscope_config* cfg) {
+    if (!h || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const uint64_t before = h->bank.epoch();
+        h->bank.update_config(*cfg);
+        if (h->bank.epoch() != before) h->have_last = false;  // rebuilt: every trigger starts unlocked
+        return (int)OMX_NONE;
+    });
+}
+int omx_oscilloscope_reset_audio(omx_oscilloscope* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.reset_audio();
+        h->have_last = false;
+        return (int)OMX_NONE;
+    });
+}
+int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block, omx_oscilloscope_snapshot* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+        if (block->n_samples < channels) return (int)OMX_NONE;
+        const int rc = h->bank.process(block->samples, false, block->n_samples / channels, 1, channels, block->sample_rate,
+                                       block->positions, nullptr);
+        if (rc != OMX_PRODUCED) return rc;
+        int frc = h->bank.fetch_header(0, 0, &h->last, nullptr);
+        if (frc < 0) return frc;
+        h->have_last = true;
+        if (!h->last.produced) return (int)OMX_NONE;
+        const uint64_t spc = h->last.samples_per_channel, ch = h->last.channels;
+        std::vector<float> raw(2 * (size_t)kScopeTarget);
+        frc = h->bank.fetch_samples(0, raw.data(), raw.size(), nullptr);
+        if (frc < 0) return frc;
+        h->samples.resize((size_t)(ch * spc));
+        for (uint64_t c = 0; c < ch; ++c)
+            std::copy(raw.begin() + c * kScopeTarget, raw.begin() + c * kScopeTarget + spc, h->samples.begin() + c * spc);
+        out->epoch = h->bank.epoch();
+        out->channels = ch;
+        out->slots[0] = h->last.slots[0];
+        out->slots[1] = h->last.slots[1];
+        out->samples_per_channel = spc;
+        out->n_samples = ch * spc;
+        out->samples = h->samples.data();
+        return (int)OMX_PRODUCED;
+    });
+}
+int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz) {
+    if (!h || !hz || !h->have_last || !h->last.locked) return 0;
+    *hz = h->bank.config().sample_rate / h->last.period;
+    return 1;
+}
+
+int omx_oscilloscope_bank_create(const omx_oscilloscope_config* cfg, uint32_t n_streams, omx_oscilloscope_bank** out) {
+    if (!cfg || !out || n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_oscilloscope_bank(*cfg, n_streams);
+        return (int)OMX_NONE;
+    });
+}
+void omx_oscilloscope_bank_destroy(omx_oscilloscope_bank* b) { delete b; }
+int omx_oscilloscope_bank_reset_audio(omx_oscilloscope_bank* b) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, int pcm_on_device, uint64_t block_frames,
+                                  uint64_t n_blocks, uint32_t channels, float sample_rate,
+                                  const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_bank_update* out) {
+    if (!b || !pcm || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const int rc = b->impl.process(pcm, pcm_on_device != 0, block_frames, n_blocks, channels, sample_rate, positions,
+                                       static_cast<hipStream_t>(stream));
+        if (rc == OMX_PRODUCED && out) {
+            out->n_streams = b->impl.n_streams();
+            out->n_blocks = n_blocks;
+            out->epoch = b->impl.epoch();
+            out->d_headers = reinterpret_cast<const omx_oscilloscope_block_header*>(b->impl.d_headers());
+            out->d_samples = b->impl.d_samples();
+            out->sample_stride = kScopeTarget;
+        }
+        return rc;
+    });
+}
+int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
+                                omx_oscilloscope_block_header* header, float* samples /* [2][4096] or NULL */) {
+    if (!b || !header) return OMX_ERR_INVALID;
+    return guarded([&] {
+        static_assert(sizeof(omx_oscilloscope_block_header) == sizeof(ScopeBlockHeader), "header layout");
+        int rc = b->impl.fetch_header(stream_index, block, reinterpret_cast<ScopeBlockHeader*>(header), b->impl.last_stream());
+        if (rc < 0) return rc;
+        if (samples) rc = b->impl.fetch_samples(stream_index, samples, 2 * kScopeTarget, b->impl.last_stream());
+        return rc;
+    });
 }
 
 }  // extern "C"

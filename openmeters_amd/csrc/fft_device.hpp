@@ -140,8 +140,9 @@ __device__ __forceinline__ void fft4096(v2f (&v)[16], v2f* lds, int j, const Fft
 // exp(-2*pi*i*k/n), k < n/2) as the CPU oracle's fft.hpp, without mul+add fusion.
 __device__ __forceinline__ unsigned bitrev(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
+// `tw_step` lets a table built for a larger size N' = n * tw_step serve this size.
 __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* tw, bool inverse, unsigned tid,
-                                  unsigned nthreads) {
+                                  unsigned nthreads, unsigned tw_step = 1) {
     if (n <= 1) return;
     __syncthreads();
     for (unsigned i = tid; i < n; i += nthreads) {
@@ -158,7 +159,7 @@ __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* 
         for (unsigned b = tid; b < n / 2; b += nthreads) {
             const unsigned k = b & (half - 1);
             const unsigned base = ((b >> (s - 1)) << s) + k;
-            v2f w = tw[k * stride];
+            v2f w = tw[k * stride * tw_step];
             if (inverse) w.y = -w.y;
             const v2f u = a[base], x = a[base + half];
             const v2f t{x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x};

@@ -1,0 +1,165 @@
+// Host side of the loudness path: reference src/visuals/loudness/processor.rs:22-55 (K-weighting
+// design), :73-97 (true-peak FIR taps), :164-251 (channel state lifecycle) driving kernel K4.
+#include "loudness.hpp"
+
+namespace omx {
+
+constexpr float kLoudnessDefaultFloor = -99.9f;                           // :11
+constexpr float kLoudnessWindowsSecs[4] = {3.0f, 0.4f, 0.3f, 1.0f};       // :13
+constexpr size_t kTruePeakTaps = 48;                                      // :75
+
+void loudness_config_default(omx_loudness_config* c) {
+    c->sample_rate = kDefaultSampleRate;
+    c->floor_db = kLoudnessDefaultFloor;
+}
+
+void k_weighting_coefficients(double fs, double b[5], double a[5]) {  // :22-55
+    double f0 = 1681.974450955533, g = 3.999843853973347, q = 0.7071752369554196;
+    double k = std::tan(M_PI * f0 / fs);
+    const double vh = std::pow(10.0, g / 20.0);
+    const double vb = std::pow(vh, 0.4996667741545416);
+    double a0 = 1.0 + k / q + k * k;
+    const double pb[3] = {(vh + vb * k / q + k * k) / a0, 2.0 * (k * k - vh) / a0, (vh - vb * k / q + k * k) / a0};
+    const double pa[3] = {1.0, 2.0 * (k * k - 1.0) / a0, (1.0 - k / q + k * k) / a0};
+    f0 = 38.13547087602444;
+    q = 0.5003270373238773;
+    k = std::tan(M_PI * f0 / fs);
+    a0 = 1.0 + k / q + k * k;
+    const double rb[3] = {1.0, -2.0, 1.0};
+    const double ra[3] = {1.0, 2.0 * (k * k - 1.0) / a0, (1.0 - k / q + k * k) / a0};
+    auto conv = [](const double p[3], const double r[3], double out[5]) {
+        out[0] = p[0] * r[0];
+        out[1] = p[0] * r[1] + p[1] * r[0];
+        out[2] = p[0] * r[2] + p[1] * r[1] + p[2] * r[0];
+        out[3] = p[1] * r[2] + p[2] * r[1];
+        out[4] = p[2] * r[2];
+    };
+    conv(pb, rb, b);
+    conv(pa, ra, a);
+}
+
+static float true_peak_coefficient(size_t j, size_t factor) {  // :79-84
+    const double offset = (double)j - (double)kTruePeakTaps * 0.5;
+    const double window = 0.5 * (1.0 - std::cos(2.0 * M_PI * (double)j / (double)kTruePeakTaps));
+    const double x = offset * M_PI / (double)factor;
+    return (float)(window * std::sin(x) / x);
+}
+static size_t window_length(float sample_rate, float secs) {  // :68-71
+    const float len = sample_rate * secs;
+    return len < 1.0f ? 1 : f2usize((double)len);
+}
+static double channel_weight(uint8_t position) {  // :174-183
+    switch (position) {
+        case OMX_POS_LOW_FREQUENCY: return 0.0;
+        case OMX_POS_REAR_LEFT:
+        case OMX_POS_REAR_RIGHT:
+        case OMX_POS_SIDE_LEFT:
+        case OMX_POS_SIDE_RIGHT: return 1.41;
+        default: return 1.0;
+    }
+}
+
+LoudnessBank::LoudnessBank(const omx_loudness_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {
+    cfg_ = cfg;  // :225-232: the config is stored as given; the weighting uses the sanitised rate
+    k_weighting_coefficients((double)sanitize_sample_rate(cfg.sample_rate), b_, a_);
+}
+
+void LoudnessBank::clear_state(hipStream_t stream) {
+    frames_seen_ = 0;
+    if (state_.ptr) OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(LoudnessChannelState), stream));
+    if (ring_.ptr) OMX_HIP(hipMemsetAsync(ring_.ptr, 0, ring_.count * sizeof(double), stream));
+    state_clean_ = true;
+}
+
+void LoudnessBank::reset_audio() {  // :234-236 every ChannelState back to default
+    clear_state(last_stream_);
+}
+
+void LoudnessBank::ensure_state(uint32_t requested, float sample_rate_in, hipStream_t stream) {  // :238-251
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(requested, 1), OMX_MAX_CHANNELS);
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    const bool rate_changed = cfg_.sample_rate != sample_rate;
+    if (rate_changed) {
+        cfg_.sample_rate = sample_rate;
+        k_weighting_coefficients((double)sample_rate, b_, a_);
+    }
+    uint64_t len = 1;
+    for (int w = 0; w < 4; ++w) len = std::max<uint64_t>(len, window_length(cfg_.sample_rate, kLoudnessWindowsSecs[w]));
+    const bool realloc = ring_len_ != len || !ring_.ptr;
+    if (realloc) {
+        ring_len_ = len;
+        ring_.reserve((size_t)(len * n_streams_ * 8));
+        state_.reserve((size_t)n_streams_ * 8);
+    }
+    if (rate_changed || channels_ != channels || realloc) {
+        channels_ = channels;
+        clear_state(stream);
+    }
+}
+
+int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                          float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                          const omx_loudness_snapshot** d_snapshots) {  // :253-311
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (block_frames == 0 || n_blocks == 0) return OMX_NONE;  // block.is_empty()
+    if (block_frames > 0xFFFFFFFFull || n_blocks > 0xFFFFFFFFull) unsupported("loudness block shape beyond 2^32");
+    ensure_state(channels, sample_rate, stream);
+    const uint64_t frames = block_frames * n_blocks;
+    const float* d_pcm = pcm;
+    if (!pcm_on_device) {
+        const size_t n = (size_t)n_streams_ * frames * channels;
+        staging_.reserve(n);
+        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        d_pcm = staging_.ptr;
+    }
+    snapshots_.reserve((size_t)(n_streams_ * n_blocks));
+    LoudnessArgs la{};
+    la.pcm = d_pcm;
+    la.frames_total = frames;
+    la.block_frames = (uint32_t)block_frames;
+    la.n_blocks = (uint32_t)n_blocks;
+    la.n_streams = n_streams_;
+    la.channels = channels;
+    for (int i = 0; i < 5; ++i) {
+        la.b[i] = b_[i];
+        la.a[i] = a_[i];
+    }
+    for (int i = 0; i < OMX_MAX_CHANNELS; ++i) {
+        la.weights[i] = channel_weight(positions[i]);
+        la.positions[i] = positions[i];
+    }
+    for (size_t tap = 0; tap < 12; ++tap)
+        for (size_t phase = 0; phase < 3; ++phase) la.fir4[tap][phase] = true_peak_coefficient(tap * 4 + phase + 1, 4);
+    for (size_t tap = 0; tap < 24; ++tap) la.fir2[tap] = true_peak_coefficient(tap * 2 + 1, 2);
+    const double sr = (double)cfg_.sample_rate;
+    la.delay_len = sr < 96000.0 ? 12 : (sr < 192000.0 ? 24 : 0);  // :107-114
+    for (int w = 0; w < 4; ++w) la.capacities[w] = std::max<uint64_t>(window_length(cfg_.sample_rate, kLoudnessWindowsSecs[w]), 1);
+    la.ring_len = ring_len_;
+    la.frames_seen = frames_seen_;
+    la.ring = ring_.ptr;
+    la.state = state_.ptr;
+    la.floor_db = cfg_.floor_db;
+    la.snapshots = snapshots_.ptr;
+    timer_.begin(stream);
+    launch_loudness(la, stream);
+    timer_.end(stream);
+    OMX_HIP(hipGetLastError());
+    frames_seen_ += frames;
+    state_clean_ = false;
+    last_blocks_ = n_blocks;
+    if (d_snapshots) *d_snapshots = snapshots_.ptr;
+    return OMX_PRODUCED;
+}
+
+int LoudnessBank::fetch(uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst, hipStream_t stream) {
+    if (stream_index >= n_streams_ || block >= last_blocks_) {
+        set_last_error("loudness fetch: index out of range");
+        return OMX_ERR_INVALID;
+    }
+    OMX_HIP(hipMemcpyAsync(dst, snapshots_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    return OMX_NONE;
+}
+
+}  // namespace omx

@@ -1,0 +1,219 @@
+// Host side of the oscilloscope path: reference src/visuals/oscilloscope/processor.rs:570-767 (config
+// rebuild + epoch, history sizing, trace/trigger-source routing) driving kernels K6/K7.
+#include "oscilloscope.hpp"
+
+namespace omx {
+
+void oscilloscope_config_default(omx_oscilloscope_config* c) {  // :27-43
+    std::memset(c, 0, sizeof(*c));
+    c->sample_rate = kDefaultSampleRate;
+    c->segment_duration = 0.02f;
+    c->trigger_mode = OMX_TRIGGER_STABLE;
+    c->num_cycles = 2;
+    c->trigger_source = OMX_CHANNEL_MID;
+    c->channel_1 = OMX_CHANNEL_MID;
+    c->channel_2 = OMX_CHANNEL_NONE;
+}
+
+static bool config_eq(const omx_oscilloscope_config& a, const omx_oscilloscope_config& b) {  // derive(PartialEq)
+    const bool mode_eq = a.trigger_mode == b.trigger_mode && (a.trigger_mode != OMX_TRIGGER_STABLE || a.num_cycles == b.num_cycles);
+    return a.sample_rate == b.sample_rate && a.segment_duration == b.segment_duration && mode_eq &&
+           a.trigger_source == b.trigger_source && a.channel_1 == b.channel_1 && a.channel_2 == b.channel_2;
+}
+static uint32_t trigger_kernel_len_host(float period, float rate) {  // :184-189
+    return (uint32_t)std::min<size_t>(f2usize((double)std::fmax(std::round(std::fmax(rate * 0.04f, period * 2.0f)), 2.0f)), 0x7FFFFFFFu);
+}
+static uint32_t stable_history_frames(uint32_t max_period, uint64_t cycles, float sample_rate) {  // :761-767
+    const float max_period_f = (float)max_period;
+    const uint64_t max_kernel = trigger_kernel_len_host(max_period_f, sample_rate);
+    const uint64_t max_tail = std::max<uint64_t>((uint64_t)max_period * std::max<uint64_t>(cycles, 1) + 1, (max_kernel + 1) / 2);
+    const uint64_t max_search = f2usize((double)std::ceil(max_period_f * 1.5f));
+    return (uint32_t)std::min<uint64_t>(max_kernel / 2 + max_tail + max_search + 2, 0x7FFFFFFFu);
+}
+
+OscilloscopeBank::OscilloscopeBank(const omx_oscilloscope_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {
+    trig_.reserve((size_t)n_streams_ * kScopeTraces);
+    rebuild(cfg);
+}
+
+void OscilloscopeBank::rebuild(const omx_oscilloscope_config& cfg) {  // Self::new (:579-587)
+    cfg_ = cfg;
+    has_history_channels_ = false;
+    for (int t = 0; t < kScopeTraces; ++t) len_[t] = 0;
+    pending_unlock_ = true;
+}
+
+void OscilloscopeBank::clear_history() {  // :714-723
+    epoch_ += 1;
+    has_history_channels_ = false;
+    for (int t = 0; t < kScopeTraces; ++t) len_[t] = 0;
+    pending_unlock_ = true;
+}
+
+void OscilloscopeBank::reset_audio() { clear_history(); }  // :593-600 (epoch survives the snapshot reset)
+
+void OscilloscopeBank::update_config(const omx_oscilloscope_config& cfg) {  // :752-758
+    if (!config_eq(cfg_, cfg)) {
+        const uint64_t epoch = epoch_ + 1;
+        rebuild(cfg);
+        epoch_ = epoch;
+    }
+}
+
+int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                              float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream) {  // :611-712
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (block_frames == 0 || n_blocks == 0) return OMX_NONE;
+    if (block_frames > 0x7FFFFFFFull || n_blocks > 0x7FFFFFFFull) unsupported("oscilloscope block shape beyond 2^31");
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (cfg_.sample_rate != sample_rate) {
+        omx_oscilloscope_config c = cfg_;
+        c.sample_rate = sample_rate;
+        update_config(c);
+    }
+    if (has_history_channels_ && history_channels_ != channels) clear_history();
+    has_history_channels_ = true;
+    history_channels_ = channels;
+
+    const float sr = cfg_.sample_rate;
+    const uint32_t base_frames = (uint32_t)std::min<size_t>(f2usize((double)std::fmax(std::round(sr * cfg_.segment_duration), 1.0f)), 0x3FFFFFFFu);
+    const uint32_t max_period = (uint32_t)f2usize((double)std::ceil(sr / 20.0f));
+    const uint32_t probe_frames = std::max<uint32_t>((uint32_t)f2usize((double)std::round(sr * 0.1f)), max_period * 2);
+    const uint32_t trigger_frames = cfg_.trigger_mode == OMX_TRIGGER_ZERO_CROSSING ? base_frames + max_period
+                                                                                   : stable_history_frames(max_period, cfg_.num_cycles, sr);
+    const uint32_t history_frames = std::max(std::max(probe_frames, base_frames), trigger_frames);
+    const uint32_t trace_channels[2] = {cfg_.channel_1, cfg_.channel_2};
+    const bool active[2] = {trace_channels[0] != OMX_CHANNEL_NONE, trace_channels[1] != OMX_CHANNEL_NONE};
+    int matching = -1;
+    for (int s = 0; s < 2; ++s)
+        if (trace_channels[s] == cfg_.trigger_source) { matching = s; break; }
+    if (matching >= 0 && !active[matching]) matching = -1;
+    const bool separate = matching < 0 && cfg_.trigger_source != OMX_CHANNEL_NONE;
+    if (cfg_.trigger_source == OMX_CHANNEL_NONE) len_[2] = 0;
+
+    // ---- device buffers
+    const uint64_t cap = next_pow2((uint64_t)history_frames + std::max<uint64_t>(block_frames, 4096));
+    if (cap != cap_ || !rings_.ptr) {
+        DeviceBuffer<float> bigger;
+        bigger.reserve((size_t)(cap * kScopeTraces * n_streams_));
+        OMX_HIP(hipMemsetAsync(bigger.ptr, 0, bigger.count * sizeof(float), stream));
+        if (rings_.ptr && cap_) {
+            for (uint32_t s = 0; s < n_streams_; ++s)
+                for (int t = 0; t < kScopeTraces; ++t) {
+                    uint64_t pos = head_[t] - len_[t];
+                    while (pos < head_[t]) {
+                        const uint64_t so = pos & (cap_ - 1), dof = pos & (cap - 1);
+                        const uint64_t run = std::min({head_[t] - pos, cap_ - so, cap - dof});
+                        OMX_HIP(hipMemcpyAsync(bigger.ptr + ((uint64_t)s * kScopeTraces + t) * cap + dof,
+                                               rings_.ptr + ((uint64_t)s * kScopeTraces + t) * cap_ + so, run * sizeof(float),
+                                               hipMemcpyDeviceToDevice, stream));
+                        pos += run;
+                    }
+                }
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+        std::swap(rings_.ptr, bigger.ptr);
+        std::swap(rings_.count, bigger.count);
+        cap_ = cap;
+    }
+    const uint32_t max_kernel = trigger_kernel_len_host((float)(max_period + 2), sr) + 8;
+    const uint32_t fft_size = (uint32_t)next_pow2((uint64_t)probe_frames + max_period + 1);
+    if (max_kernel != max_kernel_ || !reference_.ptr) {
+        max_kernel_ = max_kernel;
+        reference_.reserve((size_t)n_streams_ * kScopeTraces * max_kernel);
+        pending_unlock_ = true;  // reference layout changed: the stored templates are void
+    }
+    if (fft_size != fft_size_) {
+        fft_size_ = fft_size;
+        tw_fft_.upload(twiddle_table(fft_size, fft_size / 2), stream);
+    }
+    const uint64_t scratch_stride = scope_scratch_floats(max_kernel, 0, probe_frames, max_period);
+    scratch_.reserve((size_t)(scratch_stride * n_streams_));
+    const bool fft_in_lds = (uint64_t)fft_size * sizeof(v2f) <= 64 * 1024;
+    if (!fft_in_lds) fft_global_.reserve((size_t)n_streams_ * fft_size * 2);
+    if (pending_unlock_) {
+        OMX_HIP(hipMemsetAsync(trig_.ptr, 0, trig_.count * sizeof(ScopeTriggerState), stream));
+        pending_unlock_ = false;
+    }
+    headers_.reserve((size_t)(n_streams_ * n_blocks));
+    samples_.reserve((size_t)n_streams_ * 2 * kScopeTarget);
+    const uint64_t total = block_frames * n_blocks;
+    const float* d_pcm = pcm;
+    if (!pcm_on_device) {
+        const size_t n = (size_t)n_streams_ * total * channels;
+        staging_.reserve(n);
+        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        d_pcm = staging_.ptr;
+    }
+
+    ScopeArgs sa{};
+    sa.pcm = d_pcm;
+    sa.frames_total = total;
+    sa.block_frames = (uint32_t)block_frames;
+    sa.n_blocks = (uint32_t)n_blocks;
+    sa.n_streams = n_streams_;
+    sa.fmt = make_format(channels, positions);
+    sa.sample_rate = sr;
+    sa.trigger_mode = cfg_.trigger_mode;
+    sa.num_cycles = (uint32_t)std::min<uint64_t>(cfg_.num_cycles, 0x7FFFFFFFu);
+    sa.trace_channel[0] = trace_channels[0];
+    sa.trace_channel[1] = trace_channels[1];
+    sa.trigger_source = cfg_.trigger_source;
+    sa.matching_trace = matching;
+    sa.separate_source = separate ? 1 : 0;
+    sa.base_frames = base_frames;
+    sa.max_period = max_period;
+    sa.probe_frames = probe_frames;
+    sa.history_frames = history_frames;
+    sa.rings = rings_.ptr;
+    sa.cap = cap_;
+    for (int t = 0; t < kScopeTraces; ++t) {
+        sa.head[t] = head_[t];
+        sa.len[t] = len_[t];
+    }
+    sa.trig = trig_.ptr;
+    sa.reference = reference_.ptr;
+    sa.scratch = scratch_.ptr;
+    sa.scratch_stride = scratch_stride;
+    sa.max_kernel = max_kernel;
+    sa.fft_size = fft_size;
+    sa.log_fft = log2_exact(fft_size);
+    sa.tw_fft = reinterpret_cast<const v2f*>(tw_fft_.ptr);
+    sa.fft_global = fft_in_lds ? nullptr : reinterpret_cast<v2f*>(fft_global_.ptr);
+    sa.headers = headers_.ptr;
+    sa.samples = samples_.ptr;
+    launch_oscilloscope(sa, stream);
+    OMX_HIP(hipGetLastError());
+
+    for (int t = 0; t < kScopeTraces; ++t) {  // same bookkeeping as the kernel (:673-681)
+        const bool on = t < 2 ? active[t] : separate;
+        if (on) {
+            head_[t] += total;
+            len_[t] = std::min<uint64_t>(len_[t] + total, history_frames);
+        } else {
+            len_[t] = 0;
+        }
+    }
+    last_blocks_ = n_blocks;
+    return OMX_PRODUCED;
+}
+
+int OscilloscopeBank::fetch_header(uint64_t stream_index, uint64_t block, ScopeBlockHeader* dst, hipStream_t stream) {
+    if (stream_index >= n_streams_ || block >= last_blocks_) {
+        set_last_error("oscilloscope fetch: index out of range");
+        return OMX_ERR_INVALID;
+    }
+    OMX_HIP(hipMemcpyAsync(dst, headers_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    return OMX_NONE;
+}
+
+int OscilloscopeBank::fetch_samples(uint64_t stream_index, float* dst, uint64_t count, hipStream_t stream) {
+    if (stream_index >= n_streams_ || count > 2 * kScopeTarget) return OMX_ERR_INVALID;
+    OMX_HIP(hipMemcpyAsync(dst, samples_.ptr + stream_index * 2 * kScopeTarget, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    return OMX_NONE;
+}
+
+}  // namespace omx

@@ -1,0 +1,104 @@
+// OscilloscopeBank: S independent OscilloscopeProcessors (reference
+// src/visuals/oscilloscope/processor.rs:570-759).  One workgroup per stream; the NSDF period estimate
+// (K6) and the template-correlation trigger (K7) run inside the same kernel, block after block.
+#pragma once
+#include "stft_kernels.hpp"
+
+namespace omx {
+
+constexpr int kScopeTraces = 3;        // traces[0], traces[1], separate trigger source
+constexpr int kScopeTarget = 4096;     // write_snapshot TARGET (:726)
+
+struct ScopeTriggerState {  // StableTrigger persistent fields (:272-282)
+    int has_period;
+    float period;
+    uint32_t missed_periods;
+    float reference_period;
+    float mean;
+    uint32_t ref_len;       // reference.len()
+    uint32_t _pad[2];
+};
+
+struct ScopeBlockHeader {   // per (stream, block) snapshot header
+    uint32_t produced;      // process_block returned Some
+    uint32_t channels;
+    uint32_t slots[2];
+    uint32_t samples_per_channel;
+    uint32_t locked;        // last_cycle_rate().is_some() after this block (:602-609)
+    float period;           // the period behind last_cycle_rate
+    uint32_t _pad;
+};
+
+struct ScopeArgs {
+    const float* pcm;       // [n_streams][frames_total][channels]
+    uint64_t frames_total;
+    uint32_t block_frames, n_blocks, n_streams;
+    AudioFormatArgs fmt;
+    float sample_rate;
+    uint32_t trigger_mode;  // OMX_TRIGGER_*
+    uint32_t num_cycles;
+    uint32_t trace_channel[2];   // OMX_CHANNEL_*
+    uint32_t trigger_source;
+    int matching_trace;     // slot whose channel == trigger_source (and active), else -1
+    uint32_t separate_source;
+    uint32_t base_frames, max_period, probe_frames, history_frames;
+    // trace rings: [n_streams][kScopeTraces][cap]; lengths are uniform over streams (lock-step pushes)
+    float* rings;
+    uint64_t cap;           // power of two >= history_frames + block_frames
+    uint64_t head[kScopeTraces];  // absolute position of the next pushed sample at the start of the call
+    uint64_t len[kScopeTraces];   // deque length at the start of the call
+    // per-stream trigger state + scratch
+    ScopeTriggerState* trig;     // [n_streams][kScopeTraces]  (index 2 = the `source` trigger)
+    float* reference;       // [n_streams][kScopeTraces][max_kernel]
+    float* scratch;         // [n_streams][scratch_stride] work / candidate / periodicity / energy_prefix
+    uint64_t scratch_stride;
+    uint32_t max_kernel;    // capacity of reference / candidate
+    uint32_t fft_size, log_fft;  // NSDF FFT (next_pow2(probe + max_lag))
+    const v2f* tw_fft;      // exp(-2*pi*i*k/fft_size), k < fft_size/2
+    v2f* fft_global;        // [n_streams][fft_size] when the FFT does not fit the LDS budget, else nullptr
+    ScopeBlockHeader* headers;   // [n_streams][n_blocks]
+    float* samples;         // [n_streams][2][kScopeTarget] snapshot of the newest block
+};
+void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
+uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search, uint32_t probe_frames, uint32_t max_period);
+
+void oscilloscope_config_default(omx_oscilloscope_config* c);
+
+class OscilloscopeBank {
+public:
+    OscilloscopeBank(const omx_oscilloscope_config& cfg, uint32_t n_streams);
+    const omx_oscilloscope_config& config() const { return cfg_; }
+    void update_config(const omx_oscilloscope_config& cfg);
+    void reset_audio();
+    // returns OMX_PRODUCED when the newest block produced a snapshot for stream 0 .. (per stream flags in headers)
+    int process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream);
+    int fetch_header(uint64_t stream_index, uint64_t block, ScopeBlockHeader* dst, hipStream_t stream);
+    int fetch_samples(uint64_t stream_index, float* dst, uint64_t count, hipStream_t stream);
+    uint64_t epoch() const { return epoch_; }
+    uint32_t n_streams() const { return n_streams_; }
+    uint64_t last_blocks() const { return last_blocks_; }
+    hipStream_t last_stream() const { return last_stream_; }
+    const ScopeBlockHeader* d_headers() const { return headers_.ptr; }
+    const float* d_samples() const { return samples_.ptr; }
+
+private:
+    void rebuild(const omx_oscilloscope_config& cfg);
+    void clear_history();
+
+    omx_oscilloscope_config cfg_{};
+    uint32_t n_streams_;
+    uint64_t epoch_ = 0;
+    bool has_history_channels_ = false;
+    uint32_t history_channels_ = 0;
+    uint64_t head_[kScopeTraces] = {0, 0, 0}, len_[kScopeTraces] = {0, 0, 0};
+    uint64_t cap_ = 0, last_blocks_ = 0;
+    bool pending_unlock_ = true;
+    uint32_t max_kernel_ = 0, fft_size_ = 0;
+    DeviceBuffer<float> rings_, reference_, scratch_, samples_, staging_, tw_fft_, fft_global_;
+    DeviceBuffer<ScopeTriggerState> trig_;
+    DeviceBuffer<ScopeBlockHeader> headers_;
+    hipStream_t last_stream_ = nullptr;
+};
+
+}  // namespace omx

@@ -1,0 +1,758 @@
+// K6 nsdf_period + K7 template_trigger (+ zero-crossing trigger and trace resampling) — one 256-thread
+// workgroup per stream, blocks processed in timeline order.
+// reference src/visuals/oscilloscope/processor.rs:85-182 (PeriodEstimator), :184-263 (helpers),
+// :272-528 (StableTrigger), :530-551, :769-803 (zero crossing, downsample), :611-750 (process_block).
+//
+// Scalar control decisions (stabilise, lock bookkeeping, coarse-to-fine argmax replay) run on thread 0
+// and are broadcast; every map / reduction / FFT is spread over the workgroup.  Reductions use a tree
+// order, so sums differ from the reference's sequential f32 sums at the 1e-7 level (see tests for the
+// decision-level parity this implies).
+#include "oscilloscope.hpp"
+
+#include "fft_device.hpp"
+
+namespace omx {
+
+namespace {
+
+constexpr float F32_EPS = 1.1920929e-7f;
+constexpr float NEG_INF = -__builtin_huge_valf();
+// PeriodEstimator (:86-91)
+constexpr float MIN_HZ = 20.0f, MAX_HZ = 8000.0f, MIN_SIGNAL_PEAK = 0.001f, MIN_PERIODICITY = 0.5f, PEAK_CUTOFF = 0.93f;
+// StableTrigger (:285-296)
+constexpr float SEARCH_PERIODS = 1.5f, NORMALIZE_FLOOR = 0.01f, MEAN_RESPONSIVENESS = 0.25f, EDGE_STRENGTH = 1.0f,
+                BUFFER_RESPONSIVENESS = 0.5f, BUFFER_FALLOFF_PERIODS = 0.5f, BUFFER_RETUNE_SEMITONES = 1.0f,
+                SLOPE_WIDTH_PERIODS = 0.25f, RESET_BELOW_MATCH = 0.3f, WINDOW_SECONDS = 0.04f, MIN_CYCLES = 2.0f;
+constexpr uint32_t MAX_MISSED_PERIODS = 4;
+
+struct View {  // a contiguous logical slice of a trace ring
+    const float* ring;
+    uint64_t start, mask;
+    uint32_t n;
+    __device__ __forceinline__ float at(uint32_t i) const { return ring[(start + i) & mask]; }
+    __device__ __forceinline__ View sub(uint32_t off, uint32_t len) const { return View{ring, start + off, mask, len}; }
+};
+
+struct Shared {
+    float redf[8];
+    unsigned long long redu[8];
+    float f[8];
+    uint32_t u[8];
+    int i[4];
+};
+
+__device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ uint32_t f2u(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)x); }
+
+__device__ float block_sum(float v, Shared& sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh.redf[0] + sh.redf[1]) + sh.redf[2]) + sh.redf[3];
+}
+__device__ float block_max(float v, Shared& sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh.redf[0], sh.redf[1]), fmaxf(sh.redf[2], sh.redf[3]));
+}
+__device__ unsigned long long block_max_u64(unsigned long long v, Shared& sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.redu[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long m = sh.redu[0];
+    for (int w = 1; w < 4; ++w) m = sh.redu[w] > m ? sh.redu[w] : m;
+    return m;
+}
+__device__ uint32_t block_min_u32(uint32_t v, Shared& sh) { return ~(uint32_t)block_max_u64((unsigned long long)(~v), sh); }
+__device__ __forceinline__ uint32_t total_order_key(float x) {  // monotone under f32::total_cmp
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float parabolic_refine(float y_prev, float y_curr, float y_next, uint32_t tau) {  // :14-19
+    const float denom = y_prev - 2.0f * y_curr + y_next;
+    if (fabsf(denom) < F32_EPS) return (float)tau;
+    const float delta = 0.5f * (y_prev - y_next) / denom;
+    return fmaxf((float)tau + rclamp(delta, -1.0f, 1.0f), 1.0f);
+}
+__device__ __forceinline__ uint32_t trigger_kernel_len(float period, float rate) {  // :184-189
+    return f2u(fmaxf(roundf(fmaxf(rate * WINDOW_SECONDS, period * MIN_CYCLES)), 2.0f));
+}
+__device__ __forceinline__ float gaussian(uint32_t len, uint32_t index, float std_) {  // :199-204
+    if (len <= 1 || std_ <= F32_EPS) return 0.0f;
+    const float center = (float)(len - 1) * 0.5f;
+    const float r = ((float)index - center) / std_;
+    return expf(-0.5f * (r * r));
+}
+__device__ __forceinline__ float sample_linear_zero(const float* data, uint32_t n, float pos) {  // :238-247
+    if (n == 0 || pos < 0.0f || pos > (float)(n - 1)) return 0.0f;
+    const uint32_t idx = f2u(pos);
+    const float frac = pos - (float)idx;
+    if (frac > F32_EPS && idx + 1 < n) return data[idx] + (data[idx + 1] - data[idx]) * frac;
+    return data[idx];
+}
+__device__ __forceinline__ float sample_linear_zero_view(const View& v, float pos) {
+    if (v.n == 0 || pos < 0.0f || pos > (float)(v.n - 1)) return 0.0f;
+    const uint32_t idx = f2u(pos);
+    const float frac = pos - (float)idx;
+    if (frac > F32_EPS && idx + 1 < v.n) {
+        const float a = v.at(idx), b = v.at(idx + 1);
+        return a + (b - a) * frac;
+    }
+    return v.at(idx);
+}
+
+struct Capture {
+    int some;
+    float span;
+    uint32_t start;
+    float frac_offset;
+};
+
+struct Estimate {
+    int some;
+    float period, confidence;
+};
+
+struct Scratch {
+    float* work;        // [max_kernel + max_search]
+    float* candidate;   // [max_kernel]
+    float* retuned;     // [max_kernel]
+    float* nsdf;        // [max_period + 2]
+    float* scores;      // [max_search + 2]
+    float* energy;      // [probe_frames + 1]
+};
+
+// ---------------------------------------------------------------- PeriodEstimator::estimate_period (:93-181)
+__device__ Estimate estimate_period(const View& x, float rate, float& last_peak, const ScopeArgs& a, v2f* fft, Scratch& sc,
+                                    Shared& sh) {
+    const unsigned tid = threadIdx.x;
+    Estimate none{0, 0.0f, 0.0f};
+    last_peak = 0.0f;
+    const uint32_t n = x.n;
+    if (n < 3) return none;
+    float part = 0.0f;
+    for (uint32_t i = tid; i < n; i += 256) part += x.at(i);
+    const float mean = block_sum(part, sh) / (float)n;
+    float pk = 0.0f;
+    for (uint32_t i = tid; i < n; i += 256) pk = fmaxf(pk, fabsf(x.at(i) - mean));
+    last_peak = block_max(pk, sh);
+    if (last_peak < MIN_SIGNAL_PEAK) return none;
+    const uint32_t min_period = f2u(fmaxf(roundf(rate / MAX_HZ), 2.0f));
+    const uint32_t max_period = min(f2u(roundf(rate / MIN_HZ)), n / 2);
+    if (max_period <= min_period + 1) return none;
+
+    // compute_periodicity (:133-181)
+    const uint32_t max_lag = max_period;
+    uint32_t fft_size = 1, logn = 0;
+    while (fft_size < n + max_lag) {
+        fft_size <<= 1;
+        ++logn;
+    }
+    const uint32_t tw_step = a.fft_size / fft_size;  // a.fft_size is the largest size this config can need
+    const uint32_t chunk = (n + 255) / 256;
+    {  // centred copy + prefix energy (block scan: per-thread chunk sums, serial scan of 256 partials)
+        const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+        float local = 0.0f;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float c = x.at(i) - mean;
+            fft[i] = v2f{c, 0.0f};
+            local = c * c + local;
+        }
+        for (uint32_t i = n + tid; i < fft_size; i += 256) fft[i] = v2f{0.0f, 0.0f};
+        __syncthreads();
+        sc.scores[tid] = local;  // scores doubles as the 256-entry partials buffer here
+        __syncthreads();
+        if (tid == 0) {
+            float run = 0.0f;
+            for (int t = 0; t < 256; ++t) {
+                const float v = sc.scores[t];
+                sc.scores[t] = run;
+                run += v;
+            }
+            sc.energy[0] = 0.0f;
+        }
+        __syncthreads();
+        float run = sc.scores[tid];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float c = fft[i].x;
+            run = c * c + run;
+            sc.energy[i + 1] = run;
+        }
+    }
+    fft_radix2(fft, fft_size, logn, a.tw_fft, false, tid, 256, tw_step);
+    for (uint32_t k = tid; k < fft_size; k += 256) {
+        const v2f b = fft[k];
+        fft[k] = v2f{b.x * b.x + b.y * b.y, 0.0f};
+    }
+    fft_radix2(fft, fft_size, logn, a.tw_fft, true, tid, 256, tw_step);
+    const float norm = 1.0f / (float)fft_size;
+    const float total_energy = sc.energy[n];
+    if (total_energy <= F32_EPS) return none;
+    for (uint32_t tau = tid; tau <= max_lag; tau += 256) {
+        const float left = sc.energy[n - tau], right = total_energy - sc.energy[tau];
+        const float denom = left + right;
+        sc.nsdf[tau] = denom > F32_EPS ? 2.0f * fft[tau].x * norm / denom : 0.0f;
+    }
+    __syncthreads();
+    const float* nsdf = sc.nsdf;
+    // first tau >= 1 with nsdf <= 0 (:110)
+    uint32_t zc = 0xFFFFFFFFu;
+    for (uint32_t tau = 1 + tid; tau <= max_period; tau += 256)
+        if (nsdf[tau] <= 0.0f) { zc = tau; break; }
+    zc = block_min_u32(zc, sh);
+    if (zc == 0xFFFFFFFFu) return none;
+    const uint32_t first_tau = max(min_period, zc);
+    if (first_tau >= max_period) return none;
+    auto is_candidate = [&](uint32_t tau) {
+        return nsdf[tau] >= MIN_PERIODICITY && nsdf[tau] >= nsdf[tau - 1] && nsdf[tau] >= nsdf[tau + 1];
+    };
+    // max_by(total_cmp) keeps the LAST maximum (:119-121): order by (value, index)
+    unsigned long long bestk = 0ull;
+    for (uint32_t tau = first_tau + tid; tau < max_period; tau += 256)
+        if (is_candidate(tau)) {
+            const unsigned long long k = ((unsigned long long)total_order_key(nsdf[tau]) << 32) | tau;
+            bestk = k > bestk ? k : bestk;
+        }
+    bestk = block_max_u64(bestk, sh);
+    if (bestk == 0ull) return none;
+    const uint32_t best = (uint32_t)(bestk & 0xFFFFFFFFull);
+    const float cutoff = nsdf[best] * PEAK_CUTOFF;
+    uint32_t peak = 0xFFFFFFFFu;
+    for (uint32_t tau = first_tau + tid; tau <= best; tau += 256)
+        if (is_candidate(tau) && nsdf[tau] >= cutoff) { peak = tau; break; }
+    peak = block_min_u32(peak, sh);
+    if (peak == 0xFFFFFFFFu) peak = best;
+    Estimate e;
+    e.some = 1;
+    e.period = parabolic_refine(nsdf[peak - 1], nsdf[peak], nsdf[peak + 1], peak);
+    e.confidence = rclamp(nsdf[peak], 0.0f, 1.0f);
+    return e;
+}
+
+// ---------------------------------------------------------------- StableTrigger pieces
+__device__ void trigger_unlock(ScopeTriggerState& t) {  // :298-304
+    t.has_period = 0;
+    t.missed_periods = 0;
+    t.ref_len = 0;
+    t.reference_period = 0.0f;
+    t.mean = 0.0f;
+}
+
+__device__ Estimate stabilize(ScopeTriggerState& t, Estimate detected) {  // :336-356 (uniform scalar code)
+    if (!detected.some) {
+        if (!t.has_period) return Estimate{0, 0.0f, 0.0f};
+        const float p = t.period;
+        t.missed_periods = t.missed_periods >= 255 ? 255 : t.missed_periods + 1;
+        if (t.missed_periods > MAX_MISSED_PERIODS) {
+            trigger_unlock(t);
+            return Estimate{0, 0.0f, 0.0f};
+        }
+        return Estimate{1, p, 0.0f};
+    }
+    t.missed_periods = 0;
+    if (t.has_period) {
+        const float prev = t.period, r = detected.period / prev;
+        if (r >= 0.9f && r <= 1.1f) detected.period = prev + 0.35f * (detected.period - prev);
+    }
+    t.has_period = 1;
+    t.period = detected.period;
+    return detected;
+}
+
+// normalized_correlation (:210-236) of x (len n) against y with precomputed stats of y; one wave.
+__device__ float wave_normalized_correlation(const float* x, const float* y, uint32_t n, float sum_y, float sum_yy) {
+    const unsigned lane = threadIdx.x & 63;
+    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float xv = x[i], yv = y[i];
+        sx += xv;
+        sxx += xv * xv;
+        sxy += xv * yv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sx += __shfl_xor(sx, off);
+        sxx += __shfl_xor(sxx, off);
+        sxy += __shfl_xor(sxy, off);
+    }
+    if (n == 0) return 0.0f;
+    const float nf = (float)n;
+    const float dot = sxy - sx * sum_y / nf;
+    const float ex = fmaxf(sxx - sx * sx / nf, 0.0f);
+    const float ey = fmaxf(sum_yy - sum_y * sum_y / nf, 0.0f);
+    const float denom = sqrtf(ex * ey);
+    return denom > F32_EPS ? rclamp(dot / denom, -1.0f, 1.0f) : 0.0f;
+}
+
+__device__ void correlation_stats(const float* y, uint32_t n, float& sum, float& squares, Shared& sh) {  // :206-208
+    float s = 0.0f, q = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        s += y[i];
+        q += y[i] * y[i];
+    }
+    sum = block_sum(s, sh);
+    squares = block_sum(q, sh);
+}
+
+__device__ void normalize_peak(float* data, uint32_t n, Shared& sh) {  // :191-197
+    float pk = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) pk = fmaxf(pk, fabsf(data[i]));
+    pk = block_max(pk, sh);
+    const float scale = 1.0f / fmaxf(pk, NORMALIZE_FLOOR);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) data[i] *= scale;
+    __syncthreads();
+}
+
+// prepare_template (:422-439)
+__device__ void prepare_template(float* candidate, const float* reference, uint32_t len, float period, bool use_reference) {
+    const uint32_t midpoint = len / 2;
+    const float max_width = fmaxf((float)max(midpoint, 1u) / 3.0f, 1.0f);
+    const float width = rclamp(SLOPE_WIDTH_PERIODS * period, 1.0f, max_width);
+    for (uint32_t i = threadIdx.x; i < (len + 1) / 2; i += 256) {
+        const uint32_t mirror = len - 1 - i;
+        const float weight = gaussian(len, i, width);
+        candidate[i] = -0.5f * EDGE_STRENGTH * 2.0f * weight;
+        candidate[mirror] = 0.5f * EDGE_STRENGTH * 2.0f * weight;
+    }
+    __syncthreads();
+    if (use_reference)
+        for (uint32_t i = threadIdx.x; i < len; i += 256) candidate[i] += reference[i];
+    __syncthreads();
+}
+
+// Evaluate scores[offset] for offsets lo + k*step (k = 0..count-1); one wave per offset.
+__device__ void eval_scores(float* scores, const float* work, const float* tmpl, uint32_t len, float sum_y, float sum_yy,
+                            uint32_t lo, uint32_t step, uint32_t count) {
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t k = wave; k < count; k += 4) {
+        const uint32_t off = lo + k * step;
+        const float v = wave_normalized_correlation(work + off, tmpl, len, sum_y, sum_yy);
+        if (lane == 0) scores[off] = v;
+    }
+    __syncthreads();
+}
+
+// find_best (:441-484): coarse-to-fine search; the lazily filled score cache of the reference becomes
+// "evaluate the offsets of this round in parallel, then replay the strict-> scan on thread 0".
+__device__ void find_best(float* scores, const float* work, const float* tmpl, uint32_t len, uint32_t search, float period,
+                          uint32_t& best_off_out, float& frac_out, Shared& sh) {
+    float sum_y, sum_yy;
+    correlation_stats(tmpl, len, sum_y, sum_yy, sh);
+    uint32_t stride = f2u(roundf(period / 16.0f));
+    stride = min(max(stride, 1u), 128u);
+    stride = min(stride, max(search, 1u));
+    // coarse: (0..=search).rev().step_by(stride).chain([0])
+    const uint32_t n_coarse = search / stride + 1;
+    const uint32_t lowest = search - (n_coarse - 1) * stride;
+    eval_scores(scores, work, tmpl, len, sum_y, sum_yy, lowest, stride, n_coarse);
+    if (lowest != 0) eval_scores(scores, work, tmpl, len, sum_y, sum_yy, 0, 1, 1);
+    if (threadIdx.x == 0) {
+        uint32_t bo = search / 2;
+        float bs = NEG_INF;
+        for (uint32_t k = 0; k < n_coarse; ++k) {
+            const uint32_t off = search - k * stride;
+            if (scores[off] > bs) { bo = off; bs = scores[off]; }
+        }
+        if (scores[0] > bs) { bo = 0; bs = scores[0]; }
+        sh.u[0] = bo;
+        sh.f[0] = bs;
+    }
+    __syncthreads();
+    uint32_t best_off = sh.u[0];
+    float best_score = sh.f[0];
+    __syncthreads();
+    uint32_t step = stride;
+    while (step > 1) {
+        const uint32_t next = max(step / 4, 1u);
+        const uint32_t lo = best_off > step ? best_off - step : 0;
+        const uint32_t hi = min(best_off + step, search);
+        const uint32_t cnt = (hi - lo) / next + 1;
+        const uint32_t first = hi - (cnt - 1) * next;
+        eval_scores(scores, work, tmpl, len, sum_y, sum_yy, first, next, cnt);
+        if (threadIdx.x == 0) {
+            uint32_t bo = best_off;
+            float bs = best_score;
+            for (uint32_t k = 0; k < cnt; ++k) {  // (lo..=hi).rev().step_by(next)
+                const uint32_t off = hi - k * next;
+                if (scores[off] > bs) { bo = off; bs = scores[off]; }
+            }
+            sh.u[0] = bo;
+            sh.f[0] = bs;
+        }
+        __syncthreads();
+        best_off = sh.u[0];
+        best_score = sh.f[0];
+        __syncthreads();
+        step = next;
+    }
+    float frac = 0.0f;
+    if (best_off > 0 && best_off < search) {
+        eval_scores(scores, work, tmpl, len, sum_y, sum_yy, best_off - 1, 2, 2);
+        const float prev = scores[best_off - 1], nxt = scores[best_off + 1];
+        frac = rclamp(parabolic_refine(prev, best_score, nxt, best_off) - (float)best_off, -0.5f, 0.5f);
+    }
+    best_off_out = best_off;
+    frac_out = frac;
+}
+
+// write_candidate (:509-527): candidate = windowed, peak-normalised, mean-removed segment; returns the
+// correlation with the reference.
+__device__ float write_candidate(float* candidate, const float* reference, const View& seg, float period, Shared& sh) {
+    const uint32_t n = seg.n;
+    float part = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) part += seg.at(i);
+    const float mean = block_sum(part, sh) / (float)max(n, 1u);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) candidate[i] = seg.at(i) - mean;
+    __syncthreads();
+    normalize_peak(candidate, n, sh);
+    const float std_ = fmaxf(period * BUFFER_FALLOFF_PERIODS, 1.0f);
+    for (uint32_t i = threadIdx.x; i < (n + 1) / 2; i += 256) {
+        const uint32_t mirror = n - 1 - i;
+        const float weight = gaussian(n, i, std_);
+        candidate[i] *= weight;
+        if (mirror != i) candidate[mirror] *= weight;
+    }
+    __syncthreads();
+    float sum_y, sum_yy;
+    correlation_stats(candidate, n, sum_y, sum_yy, sh);
+    // normalized_correlation(reference, candidate) across the whole workgroup
+    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const float xv = reference[i], yv = candidate[i];
+        sx += xv;
+        sxx += xv * xv;
+        sxy += xv * yv;
+    }
+    sx = block_sum(sx, sh);
+    sxx = block_sum(sxx, sh);
+    sxy = block_sum(sxy, sh);
+    if (n == 0) return 0.0f;
+    const float nf = (float)n;
+    const float dot = sxy - sx * sum_y / nf;
+    const float ex = fmaxf(sxx - sx * sx / nf, 0.0f);
+    const float ey = fmaxf(sum_yy - sum_y * sum_y / nf, 0.0f);
+    const float denom = sqrtf(ex * ey);
+    return denom > F32_EPS ? rclamp(dot / denom, -1.0f, 1.0f) : 0.0f;
+}
+
+// locate (:358-411)
+__device__ Capture locate(ScopeTriggerState& t, float* reference, const View& trace, Estimate est, uint32_t cycles, float rate,
+                          Scratch& sc, Shared& sh) {
+    Capture none{0, 0.0f, 0, 0.0f};
+    const uint32_t n = trace.n;
+    const float period = fmaxf(est.period, 1.0f);
+    const float span = period * (float)max(cycles, 1u);
+    const uint32_t frames = f2u(ceilf(span)) + 1;
+    const uint32_t len = trigger_kernel_len(period, rate);
+    const uint32_t before = len / 2, after = len - before;
+    const uint32_t tail = max(frames, after);
+    if (n < tail) return none;
+    const uint32_t right = n - tail;
+    if (right < before) return none;
+    uint32_t search = max(f2u(roundf(period * SEARCH_PERIODS)), 1u);
+    search = min(min(search, len / 2), right - before);
+    const uint32_t left = right - search;
+    const View data = trace.sub(left - before, (right + after) - (left - before));
+
+    // prepare (:413-420): retune_reference (:486-498) + EMA-tracked mean + work = data - mean
+    if (t.ref_len == 0) {
+        for (uint32_t i = threadIdx.x; i < len; i += 256) reference[i] = 0.0f;
+        t.ref_len = len;
+        t.reference_period = period;
+    } else {
+        const float semitones = log2f(period / t.reference_period) * 12.0f;
+        if (t.ref_len != len || fabsf(semitones) >= BUFFER_RETUNE_SEMITONES) {  // retune_reference fn (:249-263)
+            const float ratio = period / t.reference_period;
+            const bool bad = !isfinite(ratio) || ratio <= F32_EPS;
+            const float old_center = (float)(t.ref_len ? t.ref_len - 1 : 0) * 0.5f;
+            const float new_center = (float)(len ? len - 1 : 0) * 0.5f;
+            for (uint32_t i = threadIdx.x; i < len; i += 256)
+                sc.retuned[i] = bad ? 0.0f : sample_linear_zero(reference, t.ref_len, old_center + ((float)i - new_center) / ratio);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < len; i += 256) reference[i] = sc.retuned[i];
+            t.ref_len = len;
+            t.reference_period = period;
+        }
+    }
+    __syncthreads();
+    float part = 0.0f;
+    for (uint32_t i = threadIdx.x; i < data.n; i += 256) part += data.at(i);
+    const float mean = block_sum(part, sh) / (float)max(data.n, 1u);
+    t.mean += MEAN_RESPONSIVENESS * (mean - t.mean);
+    for (uint32_t i = threadIdx.x; i < data.n; i += 256) sc.work[i] = data.at(i) - t.mean;
+    __syncthreads();
+
+    float refpk = 0.0f;
+    for (uint32_t i = threadIdx.x; i < len; i += 256) refpk = fmaxf(refpk, fabsf(reference[i]));
+    const bool use_reference = block_max(refpk, sh) > 1.0e-3f;  // any(|sample| > 1e-3) (:381)
+    prepare_template(sc.candidate, reference, len, period, use_reference);
+    uint32_t offset;
+    float frac_offset;
+    find_best(sc.scores, sc.work, sc.candidate, len, search, period, offset, frac_offset, sh);
+    const bool confident = est.confidence >= MIN_PERIODICITY;
+    bool reset = false;
+    bool candidate_written = false;
+    if (confident && use_reference) {
+        reset = write_candidate(sc.candidate, reference, trace.sub(left + offset - before, len), period, sh) < RESET_BELOW_MATCH;
+        candidate_written = true;
+    }
+    if (reset) {
+        for (uint32_t i = threadIdx.x; i < len; i += 256) reference[i] = 0.0f;
+        __syncthreads();
+        prepare_template(sc.candidate, reference, len, period, false);
+        find_best(sc.scores, sc.work, sc.candidate, len, search, period, offset, frac_offset, sh);
+        candidate_written = false;
+    }
+    if (confident) {
+        if (!use_reference || reset || !candidate_written)
+            write_candidate(sc.candidate, reference, trace.sub(left + offset - before, len), period, sh);
+        // update_reference (:500-507)
+        normalize_peak(reference, len, sh);
+        for (uint32_t i = threadIdx.x; i < len; i += 256) reference[i] += BUFFER_RESPONSIVENESS * (sc.candidate[i] - reference[i]);
+        t.reference_period += BUFFER_RESPONSIVENESS * (period - t.reference_period);
+        __syncthreads();
+    }
+    uint32_t start = left + offset;
+    if (frac_offset < 0.0f && start > 0) {
+        start -= 1;
+        frac_offset += 1.0f;
+    }
+    return Capture{1, span, start, frac_offset};
+}
+
+// StableTrigger::capture (:306-334)
+__device__ Capture stable_capture(ScopeTriggerState& t, float* reference, const View& trace, const ScopeArgs& a, v2f* fft,
+                                  Scratch& sc, Shared& sh) {
+    const uint32_t n = trace.n;
+    const uint32_t probe_len = min(a.probe_frames, n);
+    float last_peak = 0.0f;
+    Estimate detected{0, 0.0f, 0.0f};
+    if (probe_len >= 3) detected = estimate_period(trace.sub(n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh);
+    if (probe_len > 0 && last_peak < MIN_SIGNAL_PEAK) trigger_unlock(t);
+    const Estimate est = stabilize(t, detected);
+    if (est.some) {
+        const Capture c = locate(t, reference, trace, est, a.num_cycles, a.sample_rate, sc, sh);
+        if (c.some) return c;
+    }
+    Capture c;
+    c.some = 1;
+    c.span = (float)max(a.base_frames > 0 ? a.base_frames - 1 : 0u, 1u);
+    c.start = n > a.base_frames ? n - a.base_frames : 0;
+    c.frac_offset = 0.0f;
+    return c;
+}
+
+// find_rising_zero_crossing over indices lo..=hi (:530-551); reversed = iterate from hi down
+__device__ uint32_t find_rising_zero_crossing(const View& v, uint32_t lo, uint32_t hi, bool reversed, Shared& sh) {
+    if (lo > hi) return 0xFFFFFFFFu;  // callers only pass in-range spans (hi < v.n)
+    // a crossing between adjacent indices (i-1, i): v[i] > 0 && v[i-1] <= 0, reported as i
+    if (!reversed) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t i = lo + 1 + threadIdx.x; i <= hi; i += 256)
+            if (v.at(i) > 0.0f && v.at(i - 1) <= 0.0f) { best = i; break; }
+        return block_min_u32(best, sh);
+    }
+    unsigned long long best = 0ull;
+    for (uint32_t i = lo + 1 + threadIdx.x; i <= hi; i += 256)
+        if (v.at(i) > 0.0f && v.at(i - 1) <= 0.0f) best = (unsigned long long)i + 1ull;  // keep the largest
+    best = block_max_u64(best, sh);
+    return best == 0ull ? 0xFFFFFFFFu : (uint32_t)(best - 1ull);
+}
+
+// zero_crossing_capture (:769-786)
+__device__ Capture zero_crossing_capture(const View& v, uint32_t frames_in, uint32_t search_range, Shared& sh) {
+    const uint32_t frames = min(frames_in, v.n);
+    if (frames == 0) return Capture{0, 0.0f, 0, 0.0f};
+    const uint32_t end = v.n > 0 ? v.n - 1 : 0;
+    const uint32_t right_lo = end > search_range ? end - search_range : 0;
+    uint32_t right = find_rising_zero_crossing(v, right_lo, end, true, sh);
+    if (right == 0xFFFFFFFFu) right = end;
+    const uint32_t left_lo = right > frames ? right - frames : 0;
+    const uint32_t left_hi = min(left_lo + search_range, right > 2 ? right - 2 : 0u);
+    uint32_t left = find_rising_zero_crossing(v, left_lo, left_hi, false, sh);
+    if (left == 0xFFFFFFFFu) left = left_lo;
+    return Capture{1, (float)max(right > left ? right - left : 0u, 1u), left, 0.0f};
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ Shared sh;
+    __shared__ ScopeTriggerState trig[kScopeTraces];
+    const unsigned tid = threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    v2f* fft = a.fft_global ? a.fft_global + (uint64_t)s * a.fft_size : reinterpret_cast<v2f*>(smem_raw);
+    float* scratch = a.scratch + (uint64_t)s * a.scratch_stride;
+    Scratch sc;
+    {
+        // layout mirrors scope_scratch_floats()
+        const uint32_t ms = f2u(ceilf((float)a.max_period * SEARCH_PERIODS)) + 2;
+        uint64_t off = 0;
+        sc.work = scratch + off;       off += (uint64_t)a.max_kernel + ms + 8;
+        sc.candidate = scratch + off;  off += (uint64_t)a.max_kernel + 8;
+        sc.retuned = scratch + off;    off += (uint64_t)a.max_kernel + 8;
+        sc.nsdf = scratch + off;       off += (uint64_t)a.max_period + 8;
+        sc.scores = scratch + off;     off += (uint64_t)max(ms, 256u) + 8;
+        sc.energy = scratch + off;
+    }
+    if (tid < kScopeTraces) trig[tid] = a.trig[(uint64_t)s * kScopeTraces + tid];
+    __syncthreads();
+    const uint64_t mask = a.cap - 1;
+    float* rings = a.rings + (uint64_t)s * kScopeTraces * a.cap;
+    const float* pcm = a.pcm + (uint64_t)s * a.frames_total * a.fmt.channels;
+    uint64_t head[kScopeTraces], len[kScopeTraces];
+    for (int t = 0; t < kScopeTraces; ++t) {
+        head[t] = a.head[t];
+        len[t] = a.len[t];
+    }
+    const bool active[2] = {a.trace_channel[0] != OMX_CHANNEL_NONE, a.trace_channel[1] != OMX_CHANNEL_NONE};
+
+    for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
+        // ---- push projected frames (:657-681)
+        for (uint32_t f = tid; f < a.block_frames; f += 256) {
+            const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
+            float left = 0.0f, right = 0.0f;
+            for (uint32_t c = 0; c < a.fmt.channels; ++c) {
+                const float v = frame[c];
+                left = left + v * a.fmt.m[c][0];
+                right = right + v * a.fmt.m[c][1];
+            }
+            for (int t = 0; t < kScopeTraces; ++t) {
+                const uint32_t ch = t < 2 ? a.trace_channel[t] : a.trigger_source;
+                const bool on = t < 2 ? active[t] : a.separate_source != 0;
+                if (!on) continue;
+                float v;
+                switch (ch) {
+                    case OMX_CHANNEL_LEFT: v = left; break;
+                    case OMX_CHANNEL_RIGHT: v = right; break;
+                    case OMX_CHANNEL_MID: v = (left + right) * 0.5f; break;
+                    case OMX_CHANNEL_SIDE: v = (left - right) * 0.5f; break;
+                    default: v = 0.0f; break;
+                }
+                rings[(uint64_t)t * a.cap + ((head[t] + f) & mask)] = v;
+            }
+        }
+        for (int t = 0; t < kScopeTraces; ++t) {
+            const bool on = t < 2 ? active[t] : a.separate_source != 0;
+            if (on) {
+                head[t] += a.block_frames;
+                len[t] = min(len[t] + (uint64_t)a.block_frames, (uint64_t)a.history_frames);
+            } else {
+                len[t] = 0;
+            }
+        }
+        __syncthreads();
+        View views[kScopeTraces];
+        for (int t = 0; t < kScopeTraces; ++t)
+            views[t] = View{rings + (uint64_t)t * a.cap, head[t] - len[t], mask, (uint32_t)len[t]};
+
+        // ---- captures (:683-700)
+        auto capture = [&](const View& trace, int trig_index) -> Capture {
+            if (a.trigger_mode == OMX_TRIGGER_ZERO_CROSSING) return zero_crossing_capture(trace, a.base_frames, a.max_period, sh);
+            if (trace.n >= a.base_frames) {
+                float* reference = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
+                // the trigger state lives in LDS; thread-uniform updates are done redundantly by every thread
+                ScopeTriggerState local = trig[trig_index];
+                const Capture c = stable_capture(local, reference, trace, a, fft, sc, sh);
+                __syncthreads();
+                if (tid == 0) trig[trig_index] = local;
+                __syncthreads();
+                return c;
+            }
+            return Capture{0, 0.0f, 0, 0.0f};
+        };
+        Capture linked{0, 0.0f, 0, 0.0f};
+        if (a.matching_trace >= 0) linked = capture(views[a.matching_trace], 2);
+        else if (a.separate_source) linked = capture(views[2], 2);
+        Capture caps[2];
+        for (int slot = 0; slot < 2; ++slot) {
+            caps[slot] = Capture{0, 0.0f, 0, 0.0f};
+            if (!active[slot]) continue;
+            caps[slot] = linked.some ? linked : capture(views[slot], slot);
+        }
+
+        // ---- write_snapshot (:725-750) + downsample_trace (:788-803)
+        ScopeBlockHeader hdr;
+        memset(&hdr, 0, sizeof(hdr));
+        if (caps[0].some || caps[1].some) {
+            uint32_t target = 0;
+            bool any = false;
+            for (int slot = 0; slot < 2; ++slot)
+                if (caps[slot].some) {
+                    const uint32_t tt = f2u(fmaxf(roundf(caps[slot].span), 1.0f)) + 1;
+                    target = any ? max(target, tt) : tt;
+                    any = true;
+                }
+            target = min(max(target, 2u), (uint32_t)kScopeTarget);
+            hdr.produced = 1;
+            const bool newest = blk + 1 == a.n_blocks;
+            for (int slot = 0; slot < 2; ++slot) {
+                if (!caps[slot].some) continue;
+                const View& tr = views[slot];
+                const uint32_t start = min(caps[slot].start, tr.n);
+                const View data = tr.sub(start, tr.n - start);
+                if (data.n < 2) continue;
+                const float last = (float)(data.n - 1);
+                const float start_offset = rclamp(caps[slot].frac_offset, 0.0f, last);
+                const float span = fminf(caps[slot].span, last - start_offset);
+                if (!(isfinite(span) && span > 0.0f)) continue;
+                const float step = span / (float)(target - 1);
+                if (newest) {
+                    float* out = a.samples + ((uint64_t)s * 2 + hdr.channels) * kScopeTarget;
+                    for (uint32_t i = tid; i < target; i += 256) out[i] = sample_linear_zero_view(data, start_offset + (float)i * step);
+                }
+                hdr.slots[hdr.channels] = (uint32_t)slot;
+                hdr.channels += 1;
+            }
+            hdr.samples_per_channel = hdr.channels == 0 ? 0 : target;
+        }
+        // last_cycle_rate (:602-609): source trigger first, then the traces
+        {
+            int which = -1;
+            if (trig[2].has_period) which = 2;
+            else if (trig[0].has_period) which = 0;
+            else if (trig[1].has_period) which = 1;
+            hdr.locked = which >= 0 ? 1 : 0;
+            hdr.period = which >= 0 ? trig[which].period : 0.0f;
+        }
+        if (tid == 0) a.headers[(uint64_t)s * a.n_blocks + blk] = hdr;
+        __syncthreads();
+    }
+    if (tid < kScopeTraces) a.trig[(uint64_t)s * kScopeTraces + tid] = trig[tid];
+}
+
+uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search_unused, uint32_t probe_frames, uint32_t max_period) {
+    (void)max_search_unused;
+    const uint32_t ms = (uint32_t)std::ceil((float)max_period * 1.5f) + 2;
+    uint64_t off = 0;
+    off += (uint64_t)max_kernel + ms + 8;
+    off += (uint64_t)max_kernel + 8;
+    off += (uint64_t)max_kernel + 8;
+    off += (uint64_t)max_period + 8;
+    off += (uint64_t)std::max(ms, 256u) + 8;
+    off += (uint64_t)probe_frames + 8;
+    return off;
+}
+
+void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream) {
+    if (a.n_streams == 0 || a.n_blocks == 0) return;
+    const size_t lds = a.fft_global ? 0 : (size_t)a.fft_size * sizeof(v2f);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(oscilloscope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(oscilloscope_kernel, dim3(a.n_streams), dim3(256), lds, stream, a);
+}
+
+}  // namespace omx

@@ -1,0 +1,224 @@
+// Host side of the stereometer path: reference src/visuals/stereometer/processor.rs:64-212 (history
+// length bookkeeping, config updates, EMA alpha) and src/dsp.rs:399-420 (RBJ Butterworth design).
+#include "stereometer.hpp"
+
+namespace omx {
+
+constexpr float kBandSplitsHz[2] = {200.0f, 2000.0f};  // reference src/util/audio.rs:26
+
+void stereometer_config_default(omx_stereometer_config* c) {  // :11-21
+    std::memset(c, 0, sizeof(*c));
+    c->sample_rate = kDefaultSampleRate;
+    c->segment_duration = 0.02f;
+    c->target_sample_count = 2000;
+    c->correlation_window = 0.05f;
+    c->analyze_bands = 0;
+    c->emit_band_points = 0;
+}
+
+BiquadCoef make_biquad(bool highpass, float sample_rate, float frequency) {  // dsp.rs:402-420
+    float ratio = frequency / sample_rate;
+    ratio = ratio < 1.0e-6f ? 1.0e-6f : (ratio > 0.49f ? 0.49f : ratio);
+    const float ang = kTau * ratio;
+    const float sn = std::sin(ang), cs = std::cos(ang);
+    const float alpha = sn * kFrac1Sqrt2;
+    const float gain = highpass ? 1.0f + cs : 1.0f - cs;
+    const float sign = highpass ? -1.0f : 1.0f;
+    const float inv_a0 = 1.0f / (1.0f + alpha);
+    BiquadCoef c;
+    c.b[0] = gain * 0.5f * inv_a0;
+    c.b[1] = gain * inv_a0 * sign;
+    c.b[2] = gain * 0.5f * inv_a0;
+    c.a[0] = -2.0f * cs * inv_a0;
+    c.a[1] = (1.0f - alpha) * inv_a0;
+    return c;
+}
+
+static double ema_alpha(float sample_rate, float window) {  // :210-212
+    return 1.0 - std::exp(-1.0 / std::fmax((double)sample_rate * (double)window, 1.0));
+}
+
+StereometerBank::StereometerBank(const omx_stereometer_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {
+    state_.reserve((size_t)n_streams_ * 4);
+    init(cfg);
+}
+
+void StereometerBank::init(const omx_stereometer_config& in) {  // ::new (:75-86)
+    cfg_ = in;
+    cfg_.analyze_bands = (cfg_.analyze_bands || cfg_.emit_band_points) ? 1 : 0;
+    cfg_.emit_band_points = cfg_.emit_band_points ? 1 : 0;
+    cfg_._pad = 0;
+    history_channels_ = 0;
+    for (int b = 0; b < 4; ++b) hist_len_[b] = hist_pos_[b] = 0;
+    alpha_ = ema_alpha(cfg_.sample_rate, cfg_.correlation_window);
+    pending_full_reset_ = true;
+}
+
+uint32_t StereometerBank::segment_frames() const {  // :142-144
+    return (uint32_t)std::min<size_t>(f2usize((double)std::fmax(std::round(cfg_.sample_rate * cfg_.segment_duration), 1.0f)),
+                                      0x7FFFFFFFu);
+}
+
+void StereometerBank::reset_audio() {  // :92-97
+    for (int b = 0; b < 4; ++b) hist_len_[b] = 0;
+    pending_full_reset_ = true;  // band_splitter.clear() + correlators = default
+}
+
+void StereometerBank::update_config(const omx_stereometer_config& in) {  // :183-207
+    omx_stereometer_config cfg = in;
+    cfg.analyze_bands = (cfg.analyze_bands || cfg.emit_band_points) ? 1 : 0;
+    cfg.emit_band_points = cfg.emit_band_points ? 1 : 0;
+    cfg._pad = 0;
+    const bool rate_changed = cfg_.sample_rate != cfg.sample_rate;
+    const bool window_changed = std::fabs(cfg_.correlation_window - cfg.correlation_window) > std::numeric_limits<float>::epsilon();
+    const bool bands_changed = cfg_.analyze_bands != cfg.analyze_bands;
+    cfg_ = cfg;
+    if (rate_changed) {
+        init(cfg_);
+    } else {
+        if (window_changed) alpha_ = ema_alpha(cfg.sample_rate, cfg.correlation_window);
+        if (bands_changed) pending_band_reset_ = true;  // new splitter + correlators[1..] = default
+    }
+    if (!cfg.emit_band_points)
+        for (int b = 1; b < 4; ++b) hist_len_[b] = 0;
+}
+
+int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                             omx_stereometer_bank_update* out) {  // :99-182
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (block_frames == 0 || n_blocks == 0) return OMX_NONE;
+    if (block_frames > 0xFFFFFFFFull || n_blocks > 0xFFFFFFFFull) unsupported("stereometer block shape beyond 2^32");
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (cfg_.sample_rate != sample_rate) {
+        omx_stereometer_config c = cfg_;
+        c.sample_rate = sample_rate;
+        update_config(c);
+    }
+    if (history_channels_ != channels) {
+        hist_len_[0] = 0;
+        history_channels_ = channels;
+    }
+    const uint32_t frames = segment_frames();
+    if (frames != hist_frames_ || !history_.ptr) {  // ring geometry changed: old pairs cannot be re-homed
+        hist_frames_ = frames;
+        history_.reserve((size_t)n_streams_ * 4 * frames * 2);
+        OMX_HIP(hipMemsetAsync(history_.ptr, 0, history_.count * sizeof(float), stream));
+        for (int b = 0; b < 4; ++b) {
+            hist_len_[b] = 0;
+            hist_pos_[b] = 0;
+        }
+    }
+    if (pending_full_reset_) {
+        OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(StereoLaneState), stream));
+        pending_full_reset_ = pending_band_reset_ = false;
+    } else if (pending_band_reset_) {
+        for (uint32_t s = 0; s < n_streams_; ++s)
+            OMX_HIP(hipMemsetAsync(state_.ptr + (size_t)s * 4 + 1, 0, 3 * sizeof(StereoLaneState), stream));
+        pending_band_reset_ = false;
+    }
+    const uint64_t total = block_frames * n_blocks;
+    const float* d_pcm = pcm;
+    if (!pcm_on_device) {
+        const size_t n = (size_t)n_streams_ * total * channels;
+        staging_.reserve(n);
+        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        d_pcm = staging_.ptr;
+    }
+    correlations_.reserve((size_t)(n_streams_ * n_blocks * 4));
+
+    StereometerArgs sa{};
+    sa.pcm = d_pcm;
+    sa.frames_total = total;
+    sa.block_frames = (uint32_t)block_frames;
+    sa.n_blocks = (uint32_t)n_blocks;
+    sa.n_streams = n_streams_;
+    sa.fmt = make_format(channels, positions);
+    const BiquadCoef lp_lo = make_biquad(false, cfg_.sample_rate, kBandSplitsHz[0]);
+    const BiquadCoef hp_lo = make_biquad(true, cfg_.sample_rate, kBandSplitsHz[0]);
+    const BiquadCoef lp_hi = make_biquad(false, cfg_.sample_rate, kBandSplitsHz[1]);
+    const BiquadCoef hp_hi = make_biquad(true, cfg_.sample_rate, kBandSplitsHz[1]);
+    sa.stage_a[1] = lp_lo; sa.use_a[1] = 1; sa.use_b[1] = 0; sa.stage_b[1] = lp_lo;
+    sa.stage_a[2] = hp_lo; sa.use_a[2] = 1; sa.stage_b[2] = lp_hi; sa.use_b[2] = 1;
+    sa.stage_a[3] = hp_lo; sa.use_a[3] = 1; sa.stage_b[3] = hp_hi; sa.use_b[3] = 1;
+    sa.stage_a[0] = lp_lo; sa.stage_b[0] = lp_lo; sa.use_a[0] = sa.use_b[0] = 0;
+    sa.analyze_bands = cfg_.analyze_bands;
+    sa.emit_band_points = cfg_.emit_band_points;
+    sa.alpha = alpha_;
+    sa.state = state_.ptr;
+    sa.history = history_.ptr;
+    sa.hist_frames = frames;
+    for (int b = 0; b < 4; ++b) sa.hist_pos[b] = hist_pos_[b];
+    sa.correlations = correlations_.ptr;
+    launch_stereometer(sa, stream);
+    OMX_HIP(hipGetLastError());
+
+    // deque lengths per block (:116, :129, :146-150): produced iff the full-band history is full
+    produced_host_.assign((size_t)n_blocks, 0);
+    for (uint64_t blk = 0; blk < n_blocks; ++blk) {
+        hist_len_[0] = std::min<uint64_t>(hist_len_[0] + block_frames, frames);
+        if (cfg_.analyze_bands && cfg_.emit_band_points)
+            for (int b = 1; b < 4; ++b) hist_len_[b] = std::min<uint64_t>(hist_len_[b] + block_frames, frames);
+        produced_host_[blk] = hist_len_[0] >= frames ? 1u : 0u;
+    }
+    hist_pos_[0] += total;
+    if (cfg_.analyze_bands && cfg_.emit_band_points)
+        for (int b = 1; b < 4; ++b) hist_pos_[b] += total;
+    std::vector<uint32_t> flat((size_t)(n_streams_ * n_blocks));
+    for (uint32_t s = 0; s < n_streams_; ++s)
+        for (uint64_t blk = 0; blk < n_blocks; ++blk) flat[s * n_blocks + blk] = produced_host_[blk];
+    produced_.reserve(flat.size());
+    OMX_HIP(hipMemcpyAsync(produced_.ptr, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    OMX_HIP(hipStreamSynchronize(stream));  // `flat` is a stack temporary
+
+    const uint32_t target = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cfg_.target_sample_count, 1), frames);  // :152
+    last_target_ = target;
+    last_blocks_ = n_blocks;
+    const bool produced_last = produced_host_.back() != 0;
+    for (int b = 0; b < 4; ++b) {
+        const bool in_play = b == 0 || cfg_.emit_band_points;
+        band_valid_[b] = (produced_last && in_play && hist_len_[b] >= frames) ? 1u : 0u;
+    }
+    if (produced_last) {
+        points_.reserve((size_t)n_streams_ * 4 * target * 2);
+        launch_stereometer_points(history_.ptr, n_streams_, frames, hist_pos_, band_valid_, target, points_.ptr, stream);
+        OMX_HIP(hipGetLastError());
+    }
+    if (out) {
+        out->n_streams = n_streams_;
+        out->n_blocks = n_blocks;
+        out->target = target;
+        out->d_correlations = correlations_.ptr;
+        out->d_points = produced_last ? points_.ptr : nullptr;
+        out->d_produced = produced_.ptr;
+    }
+    return produced_last ? OMX_PRODUCED : OMX_NONE;
+}
+
+int StereometerBank::fetch(uint64_t stream_index, uint64_t block, float correlations[4], uint32_t* produced, hipStream_t stream) {
+    if (stream_index >= n_streams_ || block >= last_blocks_) {
+        set_last_error("stereometer fetch: index out of range");
+        return OMX_ERR_INVALID;
+    }
+    OMX_HIP(hipMemcpyAsync(correlations, correlations_.ptr + (stream_index * last_blocks_ + block) * 4, 4 * sizeof(float),
+                           hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    if (produced) *produced = produced_host_[block];
+    return OMX_NONE;
+}
+
+int StereometerBank::fetch_points(uint64_t stream_index, uint32_t band, float* dst, uint64_t* n_pairs, hipStream_t stream) {
+    if (stream_index >= n_streams_ || band >= 4) return OMX_ERR_INVALID;
+    if (!band_valid_[band]) {
+        *n_pairs = 0;
+        return OMX_NONE;
+    }
+    OMX_HIP(hipMemcpyAsync(dst, points_.ptr + (stream_index * 4 + band) * (uint64_t)last_target_ * 2,
+                           (size_t)last_target_ * 2 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    *n_pairs = last_target_;
+    return OMX_NONE;
+}
+
+}  // namespace omx
