@@ -136,3 +136,151 @@ class SpectrumBank:
         self.api.check(self.api.fn("spectrum_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p])(
             self._h, stream_index, hop, buf.ctypes.data))
         return buf
+
+
+class _BlockBank:
+    """Shared plumbing of the block-structured banks (loudness / stereometer / oscilloscope): one call =
+    `n_blocks` consecutive blocks of `block_frames` frames for every stream."""
+    _family = ""
+
+    def __init__(self, api: Api, cconfig, n_streams: int, *extra):
+        self.api = api
+        self.n_streams = n_streams
+        self._h = C.c_void_p()
+        argtypes = [C.c_void_p, C.c_uint32] + [C.c_uint32] * len(extra) + [C.POINTER(C.c_void_p)]
+        api.check(api.fn(f"{self._family}_bank_create", C.c_int, argtypes)(C.byref(cconfig), n_streams, *extra, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.fn(f"{self._family}_bank_destroy", None, [C.c_void_p])(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_audio(self):
+        self.api.check(self.api.fn(f"{self._family}_bank_reset_audio", C.c_int, [C.c_void_p])(self._h))
+
+    def _pcm(self, pcm, channels):
+        pcm = np.ascontiguousarray(pcm, np.float32).reshape(self.n_streams, -1, channels)
+        return pcm
+
+
+class LoudnessBank(_BlockBank):
+    """reference src/visuals/loudness/processor.rs:218-312, S streams in lock-step."""
+    _family = "loudness"
+
+    def __init__(self, api: Api, config: capi.LoudnessConfig, n_streams: int, channels: int = 2):
+        super().__init__(api, config.to_c(), n_streams, channels)
+
+    def set_option(self, option, value):
+        self.api.check(self.api.fn("loudness_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
+
+    def _process(self, ptr, on_device, block_frames, n_blocks, channels, sample_rate, positions, stream):
+        out = C.c_void_p()
+        f = self.api.fn("loudness_bank_process", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                           C.c_float, _u8x8, C.c_void_p, C.POINTER(C.c_void_p)])
+        rc = self.api.check(f(self._h, C.c_void_p(ptr), int(on_device), block_frames, n_blocks, channels, sample_rate,
+                              _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out.value if rc == capi.PRODUCED else None
+
+    def process_device(self, device_ptr, block_frames, n_blocks, channels, sample_rate, positions, stream=0):
+        return self._process(device_ptr, True, block_frames, n_blocks, channels, sample_rate, positions, stream)
+
+    def process_host(self, pcm, block_frames, channels, sample_rate, positions=None):
+        pcm = self._pcm(pcm, channels)
+        positions = positions if positions is not None else capi.positions_fallback(channels)
+        assert pcm.shape[1] % block_frames == 0
+        return self._process(pcm.ctypes.data, False, block_frames, pcm.shape[1] // block_frames, channels, sample_rate, positions, 0)
+
+    def fetch(self, stream_index, block) -> capi.LoudnessSnapshot:
+        out = capi.CLoudnessSnapshot()
+        self.api.check(self.api.fn("loudness_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p])(
+            self._h, stream_index, block, C.byref(out)))
+        return capi.LoudnessSnapshot(out.short_term_loudness, out.momentary_loudness, np.array(out.rms_fast_db[:], np.float32),
+                                     np.array(out.rms_slow_db[:], np.float32), np.array(out.true_peak_db[:], np.float32),
+                                     out.channel_count, list(out.positions))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self.api.check(self.api.fn("loudness_bank_kernel_time", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)])(
+            self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class StereometerBank(_BlockBank):
+    """reference src/visuals/stereometer/processor.rs:64-208, S streams in lock-step."""
+    _family = "stereometer"
+
+    def __init__(self, api: Api, config: capi.StereometerConfig, n_streams: int):
+        super().__init__(api, config.to_c(), n_streams)
+
+    def _process(self, ptr, on_device, block_frames, n_blocks, channels, sample_rate, positions, stream):
+        out = capi.CStereometerBankUpdate()
+        f = self.api.fn("stereometer_bank_process", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                              C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(ptr), int(on_device), block_frames, n_blocks, channels, sample_rate,
+                         _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
+    def process_device(self, device_ptr, block_frames, n_blocks, channels, sample_rate, positions, stream=0):
+        return self._process(device_ptr, True, block_frames, n_blocks, channels, sample_rate, positions, stream)
+
+    def process_host(self, pcm, block_frames, channels, sample_rate, positions=None):
+        pcm = self._pcm(pcm, channels)
+        positions = positions if positions is not None else capi.positions_fallback(channels)
+        assert pcm.shape[1] % block_frames == 0
+        return self._process(pcm.ctypes.data, False, block_frames, pcm.shape[1] // block_frames, channels, sample_rate, positions, 0)
+
+    def fetch(self, stream_index, block):
+        corr = (C.c_float * 4)()
+        produced = C.c_uint32()
+        self.api.check(self.api.fn("stereometer_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_float * 4,
+                                                                       C.POINTER(C.c_uint32)])(
+            self._h, stream_index, block, corr, C.byref(produced)))
+        return np.array(corr[:], np.float32), bool(produced.value)
+
+
+class COscilloscopeBlockHeader(C.Structure):
+    _fields_ = [("produced", C.c_uint32), ("channels", C.c_uint32), ("slots", C.c_uint32 * 2),
+                ("samples_per_channel", C.c_uint32), ("locked", C.c_uint32), ("period", C.c_float), ("_pad", C.c_uint32)]
+
+
+class COscilloscopeBankUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("n_blocks", C.c_uint64), ("epoch", C.c_uint64), ("sample_stride", C.c_uint64),
+                ("d_headers", C.c_void_p), ("d_samples", C.c_void_p)]
+
+
+class OscilloscopeBank(_BlockBank):
+    """reference src/visuals/oscilloscope/processor.rs:570-759, S streams in lock-step."""
+    _family = "oscilloscope"
+
+    def __init__(self, api: Api, config: capi.OscilloscopeConfig, n_streams: int):
+        super().__init__(api, config.to_c(), n_streams)
+
+    def _process(self, ptr, on_device, block_frames, n_blocks, channels, sample_rate, positions, stream):
+        out = COscilloscopeBankUpdate()
+        f = self.api.fn("oscilloscope_bank_process", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                               C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(ptr), int(on_device), block_frames, n_blocks, channels, sample_rate,
+                         _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
+    def process_device(self, device_ptr, block_frames, n_blocks, channels, sample_rate, positions, stream=0):
+        return self._process(device_ptr, True, block_frames, n_blocks, channels, sample_rate, positions, stream)
+
+    def process_host(self, pcm, block_frames, channels, sample_rate, positions=None):
+        pcm = self._pcm(pcm, channels)
+        positions = positions if positions is not None else capi.positions_fallback(channels)
+        assert pcm.shape[1] % block_frames == 0
+        return self._process(pcm.ctypes.data, False, block_frames, pcm.shape[1] // block_frames, channels, sample_rate, positions, 0)
+
+    def fetch(self, stream_index, block, with_samples=False):
+        hdr = COscilloscopeBlockHeader()
+        buf = np.zeros((2, 4096), np.float32) if with_samples else None
+        self.api.check(self.api.fn("oscilloscope_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p])(
+            self._h, stream_index, block, C.byref(hdr), buf.ctypes.data if with_samples else None))
+        return hdr, buf

@@ -1,0 +1,118 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/omx.h declares;
+entry points fail loudly (OMX_ERR_NO_DEVICE) instead of falling back to a CPU path; stream sharding +
+stats gather over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "omx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(omx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(omx):
+    syms = declared_symbols()
+    assert len(syms) > 60
+    missing = [s for s in syms if not hasattr(omx.lib, s)]
+    assert not missing, f"declared in include/omx.h but not exported: {missing}"
+
+
+def test_oracle_mirrors_the_single_stream_abi(oracle):
+    for s in declared_symbols():
+        if "_bank_" in s or s in ("omx_last_error", "omx_device_available"):
+            continue
+        assert hasattr(oracle.lib, "omxo_" + s[4:]), s
+
+
+def test_no_cpu_fallback_without_a_device(omx):
+    import openmeters_amd
+    from openmeters_amd import capi
+    if openmeters_amd.device_available():
+        pytest.skip("a GPU is visible: the no-device contract is checked on CPU-only hosts")
+    for family, cfg in (("spectrogram", capi.SpectrogramConfig().to_c()), ("spectrum", capi.SpectrumConfig().to_c()),
+                        ("loudness", capi.LoudnessConfig().to_c()), ("stereometer", capi.StereometerConfig().to_c()),
+                        ("oscilloscope", capi.OscilloscopeConfig().to_c())):
+        h = C.c_void_p()
+        rc = omx.fn(f"{family}_create", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)])(C.byref(cfg), C.byref(h))
+        assert rc == capi.ERR_NO_DEVICE and not h.value
+    with pytest.raises(capi.OmxError) as e:
+        capi.SpectrogramProcessor(omx, capi.SpectrogramConfig())
+    assert e.value.status == capi.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_pure_integer_helpers_work_without_a_device(omx, oracle):
+    from openmeters_amd import capi
+    assert omx.pack_classic_db(-140.0) == oracle.pack_classic_db(-140.0)
+    for db in np.linspace(-150.0, 15.0, 331):
+        assert omx.pack_classic_db(float(db)) == oracle.pack_classic_db(float(db))
+    for kind, pts, req in [(0, 2049, 0), (0, 2049, 8192), (1, 262145, 8192), (1, 513, 3), (0, 8193, 100000)]:
+        assert omx.history_columns(kind, pts, req) == oracle.history_columns(kind, pts, req)
+    for ch in range(1, 9):
+        assert omx.positions_fallback(ch) == oracle.positions_fallback(ch) == capi.positions_fallback(ch)
+    partial = [capi.POS_FL, capi.POS_FL, capi.POS_FR] + [capi.POS_UNKNOWN] * 5
+    assert omx.positions_normalize(3, partial) == oracle.positions_normalize(3, partial)
+    for f in (0.0, 1.0, 31.5, 1000.0, 16000.0):
+        assert omx.a_weight(f) == oracle.a_weight(f)
+    b1, a1 = omx.k_weighting_coefficients(48000.0)
+    b2, a2 = oracle.k_weighting_coefficients(48000.0)
+    assert np.array_equal(b1, b2) and np.array_equal(a1, a2)
+
+
+def test_shard_streams_partition():
+    from openmeters_amd.sharding import shard_streams
+    for total, world in [(8192, 8), (64, 1), (10, 4), (3, 8)]:
+        spans = [shard_streams(total, r, world) for r in range(world)]
+        assert sum(c for _, c in spans) == total
+        pos = 0
+        for first, count in spans:
+            assert first == pos or count == 0
+            pos += count
+    assert shard_streams(8192, 3, 8) == (3072, 1024)
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from openmeters_amd import capi
+from openmeters_amd.capi import AudioBlock, SpectrogramConfig, SpectrogramProcessor
+from openmeters_amd.sharding import shard_streams, gather_stats
+from signals import exp_sweep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+oracle = capi.Api(os.path.join({root!r}, "oracle", "libomx_oracle.so"), "omxo_")
+TOTAL = 5
+def stats_for(s):
+    cfg = SpectrogramConfig(fft_size=256, hop_size=64, history_length=64)
+    left = exp_sweep(2048, phase0=0.3 * s)
+    up = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(np.stack([left, 0.8 * left], 1).reshape(-1), 2, 48000.0))
+    counts = [len(c) for c in up.new_columns]
+    return [float(len(counts)), float(np.mean(counts)), float(counts[-1])]
+first, count = shard_streams(TOTAL, rank, world)
+local = torch.tensor([stats_for(s) for s in range(first, first + count)], dtype=torch.float32).reshape(count, 3)
+table = gather_stats(local, TOTAL)
+full = torch.tensor([stats_for(s) for s in range(TOTAL)], dtype=torch.float32)
+assert table.shape == (TOTAL, 3) and torch.equal(table, full), (rank, table, full)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_streams_gather_over_gloo_world_size_2(oracle, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

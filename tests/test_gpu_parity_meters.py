@@ -1,0 +1,206 @@
+"""Parity of the HIP loudness / stereometer / oscilloscope paths against the CPU oracle (`-m gpu`).
+
+Tolerances (f32/f64 recurrences are evaluated in the reference's operation order with mul+add fusion
+disabled, so most of these are far tighter in practice; device libm (logf/log10/expf) differs from
+glibc by <= 2 ulp):
+  loudness   LUFS / dB fields     |d| <= 1e-4 dB  (1e-5 relative of a 10 dB quantity)
+  stereometer correlations        |d| <= 1e-6 ; decimated points bit-exact
+  oscilloscope period             relative 1e-5 ; capture position within 1 sample (near-tie argmax flips are
+                                  possible because tree reductions replace the reference's sequential sums);
+                                  resampled trace within 1e-4 of the oracle where start/frac agree
+"""
+import numpy as np
+import pytest
+
+from openmeters_amd import banks, capi
+from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, OscilloscopeConfig, OscilloscopeProcessor,
+                                 StereometerConfig, StereometerProcessor)
+from signals import xorshift32_noise
+
+pytestmark = pytest.mark.gpu
+FS = 48000.0
+
+
+def cfg3_pcm(s, frames, channels=8):
+    """channel c = 0.5*sin(2*pi*(997+10c+0.01s) n/fs), LFE (index 3) at 60 Hz."""
+    n = np.arange(frames, dtype=np.float64)
+    out = np.empty((frames, channels), np.float32)
+    for c in range(channels):
+        f = 60.0 if c == 3 else 997.0 + 10.0 * c + 0.01 * s
+        out[:, c] = (0.5 * np.sin(2 * np.pi * f * n / FS)).astype(np.float32)
+    return out
+
+
+def snapshots_close(a, b, tol=1e-4):
+    assert abs(a.short_term_loudness - b.short_term_loudness) <= tol
+    assert abs(a.momentary_loudness - b.momentary_loudness) <= tol
+    for f in ("rms_fast_db", "rms_slow_db", "true_peak_db"):
+        assert np.abs(getattr(a, f) - getattr(b, f)).max() <= tol, f
+    assert a.channel_count == b.channel_count and a.positions == b.positions
+
+
+@pytest.mark.parametrize("channels,rate", [(8, 48000.0), (2, 44100.0), (6, 96000.0), (1, 192000.0)])
+def test_loudness_blocks_match_oracle(omx, oracle, channels, rate):
+    frames = 256 * 40
+    pcm = cfg3_pcm(1, frames, channels)
+    positions = capi.SURROUND if channels == 8 else capi.positions_fallback(channels)
+    a = LoudnessProcessor(omx, LoudnessConfig(sample_rate=rate))
+    b = LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate))
+    for k in range(0, frames, 256):
+        blk = pcm[k:k + 256].reshape(-1)
+        snapshots_close(a.process_block(AudioBlock(blk, channels, rate, positions)),
+                        b.process_block(AudioBlock(blk, channels, rate, positions)))
+
+
+def test_loudness_bank_equals_per_block_oracle_with_full_windows(omx, oracle):
+    """cfg3 shape, scaled: 16 streams x 8 ch, 4.1 s (all four windows full, ring wrapped), blocks of 256."""
+    S, C, blocks = 16, 8, 770
+    frames = 256 * blocks
+    pcm = np.stack([cfg3_pcm(s, frames, C) for s in range(S)])
+    bank = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    assert bank.process_host(pcm, 256, C, FS, capi.SURROUND) is not None
+    for s in (0, 7, 15):
+        p = LoudnessProcessor(oracle, LoudnessConfig())
+        want = [p.process_block(AudioBlock(pcm[s, k:k + 256].reshape(-1), C, FS, capi.SURROUND)) for k in range(0, frames, 256)]
+        for blk in (0, 1, 55, 56, 57, 187, 188, 562, 563, 769):  # around every window-fill / refresh boundary and the end
+            snapshots_close(bank.fetch(s, blk), want[blk])
+    # BS.1770 anchor through the bank: 997 Hz family at 0.5 amp, weights FL FR FC 1, LFE 0, surrounds 1.41
+    last = bank.fetch(0, blocks - 1)
+    ms = 0.125 * (3 * 1.0 + 4 * 1.41)
+    assert abs(last.short_term_loudness - 10 * np.log10(ms)) < 0.15  # K gain over 997..1067 Hz is +0.69..0.78 dB, offset -0.691
+
+
+def test_loudness_leading_silence_and_reset(omx, oracle):
+    pcm = np.zeros((48001 + 4800, 2), np.float32)
+    pcm[48001:, :] = (0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(4800) / FS)).astype(np.float32)[:, None]
+    a, b = LoudnessProcessor(omx, LoudnessConfig()), LoudnessProcessor(oracle, LoudnessConfig())
+    snapshots_close(a.process_block(AudioBlock(pcm.reshape(-1), 2, FS)), b.process_block(AudioBlock(pcm.reshape(-1), 2, FS)))
+    a.reset_audio()
+    b.reset_audio()
+    snapshots_close(a.process_block(AudioBlock(pcm[-2048:].reshape(-1), 2, FS)), b.process_block(AudioBlock(pcm[-2048:].reshape(-1), 2, FS)))
+
+
+def cfg4_pcm(s, frames):
+    """L = 440*2^((s mod 24)/12) Hz saw/sine/square by s mod 3, R = -0.7 L + noise -40 dBFS."""
+    f = 440.0 * 2.0 ** ((s % 24) / 12.0)
+    c = (f * np.arange(frames, dtype=np.float64) / FS)
+    kind = s % 3
+    left = (2.0 * (c - np.floor(c)) - 1.0) if kind == 0 else (np.sin(2 * np.pi * c) if kind == 1 else np.where((c - np.floor(c)) < 0.5, 1.0, -1.0))
+    left = (0.8 * left).astype(np.float32)
+    right = (-0.7 * left + xorshift32_noise(0x9E3779B9 ^ s, frames, 1e-2)).astype(np.float32)
+    return np.stack([left, right], 1)
+
+
+def test_stereometer_blocks_match_oracle(omx, oracle):
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02,
+                            target_sample_count=2000)
+    pcm = cfg4_pcm(4, 256 * 24)
+    a, b = StereometerProcessor(omx, cfg), StereometerProcessor(oracle, cfg)
+    for k in range(0, pcm.shape[0], 256):
+        g = a.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        w = b.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        assert (g is None) == (w is None)
+        if g is None:
+            continue
+        assert np.abs(g.correlations - w.correlations).max() <= 1e-6
+        for band in range(4):
+            assert g.points[band].shape == w.points[band].shape
+            assert np.array_equal(g.points[band].view(np.uint32), w.points[band].view(np.uint32)), band  # bit-exact biquads
+
+
+def test_stereometer_bank_and_surround_fold(omx, oracle):
+    S, blocks = 12, 10
+    cfg = StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=2000)
+    pcm = np.stack([cfg4_pcm(s, 256 * blocks) for s in range(S)])
+    bank = banks.StereometerBank(omx, cfg, S)
+    bank.process_host(pcm, 256, 2, FS)
+    for s in (0, 5, 11):
+        p = StereometerProcessor(oracle, cfg)
+        for blk in range(blocks):
+            w = p.process_block(AudioBlock(pcm[s, blk * 256:(blk + 1) * 256].reshape(-1), 2, FS))
+            corr, produced = bank.fetch(s, blk)
+            assert produced == (w is not None)
+            if w is not None:
+                assert np.abs(corr - w.correlations).max() <= 1e-6
+    # 8-channel SURROUND fold feeds the same kernel (dsp.rs:135-176 weights)
+    x = cfg3_pcm(2, 256 * 6, 8)
+    a, b = StereometerProcessor(omx, cfg), StereometerProcessor(oracle, cfg)
+    for k in range(0, x.shape[0], 256):
+        g = a.process_block(AudioBlock(x[k:k + 256].reshape(-1), 8, FS, capi.SURROUND))
+        w = b.process_block(AudioBlock(x[k:k + 256].reshape(-1), 8, FS, capi.SURROUND))
+        assert (g is None) == (w is None)
+        if g is not None:
+            assert np.abs(g.correlations - w.correlations).max() <= 1e-6
+            assert np.array_equal(g.points[0].view(np.uint32), w.points[0].view(np.uint32))
+
+
+def scope_cfg():
+    return OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2, trigger_source=capi.CH_LEFT,
+                              channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT)
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 13])
+def test_oscilloscope_blocks_match_oracle(omx, oracle, s):
+    """cfg4 shape: linked trigger on Left, 256-frame blocks; lock state, period, snapshot geometry and the
+    resampled traces must follow the oracle block by block."""
+    pcm = cfg4_pcm(s, 256 * 120)
+    a, b = OscilloscopeProcessor(omx, scope_cfg()), OscilloscopeProcessor(oracle, scope_cfg())
+    period = FS / (440.0 * 2.0 ** ((s % 24) / 12.0))
+    compared = 0
+    for k in range(0, pcm.shape[0], 256):
+        blk = pcm[k:k + 256].reshape(-1)
+        g, w = a.process_block(AudioBlock(blk, 2, FS)), b.process_block(AudioBlock(blk, 2, FS))
+        assert (g is None) == (w is None)
+        ra, rb = a.last_cycle_rate(), b.last_cycle_rate()
+        assert (ra is None) == (rb is None)
+        if ra is not None:
+            assert abs(ra - rb) <= 1e-4 * rb
+        if g is None:
+            continue
+        assert (g.epoch, g.channels, g.slots[:g.channels], g.samples_per_channel) == (w.epoch, w.channels, w.slots[:w.channels],
+                                                                                         w.samples_per_channel)
+        if ra is not None and k > 256 * 60:
+            # same capture (up to f32 noise) -> same resampled trace; a near-tie argmax flip would show up as a whole-sample
+            # or whole-period shift, which the reference's own jitter test tolerates (< 3 samples, :933-955)
+            d = np.abs(g.samples - w.samples).max()
+            assert d <= 2e-3, (k, d)
+            compared += 1
+    assert compared > 30
+    assert abs(FS / a.last_cycle_rate() - period) < 0.02 * period
+
+
+def test_oscilloscope_bank_matches_single_stream_handles(omx, oracle):
+    S, blocks = 9, 60
+    pcm = np.stack([cfg4_pcm(s, 256 * blocks) for s in range(S)])
+    bank = banks.OscilloscopeBank(omx, scope_cfg(), S)
+    up = bank.process_host(pcm, 256, 2, FS)
+    assert up.n_streams == S and up.n_blocks == blocks and up.sample_stride == 4096
+    for s in (0, 4, 8):
+        p = OscilloscopeProcessor(oracle, scope_cfg())
+        want = None
+        for blk in range(blocks):
+            w = p.process_block(AudioBlock(pcm[s, blk * 256:(blk + 1) * 256].reshape(-1), 2, FS))
+            hdr, _ = bank.fetch(s, blk)
+            assert bool(hdr.produced) == (w is not None)
+            assert bool(hdr.locked) == (p.last_cycle_rate() is not None)
+            if w is not None:
+                assert (hdr.channels, hdr.samples_per_channel) == (w.channels, w.samples_per_channel)
+                want = w
+        hdr, samples = bank.fetch(s, blocks - 1, with_samples=True)
+        n = hdr.samples_per_channel
+        got = np.concatenate([samples[c, :n] for c in range(hdr.channels)])
+        assert np.abs(got - want.samples).max() <= 2e-3
+
+
+def test_oscilloscope_zero_crossing_mode_matches_oracle(omx, oracle):
+    cfg = OscilloscopeConfig(segment_duration=0.01, trigger_mode=capi.TRIGGER_ZERO_CROSSING, channel_1=capi.CH_LEFT,
+                             channel_2=capi.CH_MID, trigger_source=capi.CH_NONE)
+    pcm = cfg4_pcm(1, 256 * 30)
+    a, b = OscilloscopeProcessor(omx, cfg), OscilloscopeProcessor(oracle, cfg)
+    for k in range(0, pcm.shape[0], 256):
+        g = a.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        w = b.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        assert (g is None) == (w is None)
+        if g is not None:
+            assert (g.channels, g.samples_per_channel) == (w.channels, w.samples_per_channel)
+            assert np.abs(g.samples - w.samples).max() <= 1e-6
