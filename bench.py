@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=256 * 1024, help="new PCM frames per stream per step")
     ap.add_argument("--cpu-columns", type=int, default=2048, help="columns per stream in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spectrum", action="store_true", help="leave the A-weighted spectrum bank out of the step")
     return ap.parse_args()
 
 
@@ -134,7 +135,8 @@ def main():
 
     import openmeters_amd
     from openmeters_amd import capi
-    from openmeters_amd.banks import SpectrogramBank
+    from openmeters_amd.banks import SpectrogramBank, SpectrumBank
+    from openmeters_amd.sharding import STATS_COLUMNS, gather_stats
 
     api = openmeters_amd.api()
     assert openmeters_amd.device_available()
@@ -150,16 +152,27 @@ def main():
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
     bank = SpectrogramBank(api, cfg, S)
+    spectrum = None
+    if not args.no_spectrum:
+        # "+ A-weighted spectrum" of configs[1]: Spectrum{4096, hop 256, Hann, averaging None, source Mid}; every hop
+        # is materialised (what the reference computes when fed one hop per block)
+        spectrum = SpectrumBank(api, capi.SpectrumConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
+                                                         averaging_mode=capi.AVG_NONE, source=capi.CH_MID,
+                                                         secondary_source=capi.CH_NONE, floor_db=-100.0), S, emit_all_hops=True)
     positions = capi.positions_fallback(2)
 
     def step():
         up = bank.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
+        if spectrum is not None:
+            spectrum.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
         if world > 1 and up is not None:
-            # per-stream summary row gathered over RCCL/xGMI once per step (tiny: latency-bound)
-            counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device)
-            stats = torch.stack([counts.to(torch.float32).mean(dim=1), counts[:, -1].to(torch.float32)], dim=1)
-            gathered = torch.empty((world * S, 2), device=device, dtype=torch.float32)
-            dist.all_gather_into_tensor(gathered, stats.contiguous())
+            # K8: per-stream summary rows all-gathered over RCCL/xGMI once per step (40 B/stream: latency-bound)
+            counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).to(torch.float32)
+            stats = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
+            stats[:, 7] = float(up.n_columns)
+            stats[:, 8] = counts.mean(dim=1)
+            stats[:, 9] = counts[:, -1]
+            gather_stats(stats, world * S)
         return up
 
     for _ in range(args.warmup):
@@ -209,7 +222,9 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: 64-stream x 2-ch 48 kHz, 4096-pt Hann STFT hop 256, "
                                "time-frequency reassignment",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "columns_per_step_per_gpu": frames_per_launch,
-                   "spectrum": "not in the timed step yet", "parallelism": f"streams sharded x{world}"},
+                   "spectrum": ("A-weighted Spectrum{4096, hop 256, Hann, avg None, Mid}, every hop materialised, in the timed step"
+                                if spectrum is not None else "excluded (--no-spectrum)"),
+                   "parallelism": f"streams sharded x{world}"},
         "roofline": {
             "bound": "hbm",
             "achieved": achieved_gbs,
