@@ -16,28 +16,62 @@ namespace omx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // (re, im)
 
-__device__ __forceinline__ v2f cmul(v2f a, v2f b) {  // a * b
-    return v2f{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+// Complex products as two packed-f32 VALU ops.  hipcc lowers the plain C++ form to v_xor + v_mov +
+// v_pk_mul + v_pk_fma (it materialises (-w.y, w.x) in registers); the VOP3P op_sel / neg modifiers do
+// the swizzle and the sign inside the multiply, halving the instruction count of every twiddle.
+// Rounding is identical to  fma(a.x, w.x, -(a.y*w.y)), fma(a.x, w.y, a.y*w.x).
+__device__ __forceinline__ v2f cmul(v2f a, v2f w) {  // a * w
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-__device__ __forceinline__ v2f cmulc(v2f a, v2f b) {  // a * conj(b)
-    return v2f{__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y))};
+__device__ __forceinline__ v2f cmulc(v2f a, v2f w) {  // a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
 template <bool INV>
 __device__ __forceinline__ v2f twmul(v2f a, v2f w) {  // forward: a*w ; inverse: a*conj(w)
     return INV ? cmulc(a, w) : cmul(a, w);
 }
+// t + (-i) d = (t.x + d.y, t.y - d.x)   and   t + (+i) d = (t.x - d.y, t.y + d.x), one packed add each
+__device__ __forceinline__ v2f add_mi(v2f t, v2f d) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(t), "v"(d));
+    return r;
+}
+__device__ __forceinline__ v2f add_pi(v2f t, v2f d) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(d));
+    return r;
+}
 template <bool INV>
-__device__ __forceinline__ v2f rot90(v2f a) {  // forward: a * (-i) ; inverse: a * (+i)
-    return INV ? v2f{-a.y, a.x} : v2f{a.y, -a.x};
+__device__ __forceinline__ v2f add_rot(v2f t, v2f d) {  // t + rot(d), rot = *(-i) forward, *(+i) inverse
+    return INV ? add_pi(t, d) : add_mi(t, d);
+}
+template <bool INV>
+__device__ __forceinline__ v2f sub_rot(v2f t, v2f d) {  // t - rot(d)
+    return INV ? add_mi(t, d) : add_pi(t, d);
 }
 
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<INV>(a1 - a3);
+    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
-    a1 = t1 + t3;
+    a1 = add_rot<INV>(t1, d);
     a2 = t0 - t2;
-    a3 = t1 - t3;
+    a3 = sub_rot<INV>(t1, d);
+}
+// dft4 whose third input still has to be multiplied by rot (the w16^4 twiddle of the 4x4 split)
+template <bool INV>
+__device__ __forceinline__ void dft4_rot2(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    const v2f t0 = add_rot<INV>(a0, a2), t1 = sub_rot<INV>(a0, a2), t2 = a1 + a3, d = a1 - a3;
+    a0 = t0 + t2;
+    a1 = add_rot<INV>(t1, d);
+    a2 = t0 - t2;
+    a3 = sub_rot<INV>(t1, d);
 }
 
 // In-register 16-point DFT (4x4 Cooley-Tukey).  On return X[k] sits in v[DFT16_OUT(k)].
@@ -50,30 +84,20 @@ __device__ __forceinline__ void dft16(v2f (&v)[16]) {
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
     // v[4*k1 + n2] *= w16^(n2*k1), w16 = exp(-+ 2*pi*i/16)
-    const v2f w1{C1, -S1}, w3{S1, -C1}, w9{-C1, S1};
-    v[5] = twmul<INV>(v[5], w1);                     // k1=1,n2=1
-    {                                                // k1=1,n2=2 : w^2 = H(1 -+ i)
-        const v2f a = v[6];
-        v[6] = INV ? v2f{(a.x - a.y) * H, (a.x + a.y) * H} : v2f{(a.x + a.y) * H, (a.y - a.x) * H};
-    }
-    v[7] = twmul<INV>(v[7], w3);                     // k1=1,n2=3
-    {                                                // k1=2,n2=1 : w^2
-        const v2f a = v[9];
-        v[9] = INV ? v2f{(a.x - a.y) * H, (a.x + a.y) * H} : v2f{(a.x + a.y) * H, (a.y - a.x) * H};
-    }
-    v[10] = rot90<INV>(v[10]);                       // k1=2,n2=2 : w^4 = -+ i
-    {                                                // k1=2,n2=3 : w^6 = H(-1 -+ i)
-        const v2f a = v[11];
-        v[11] = INV ? v2f{(-a.x - a.y) * H, (a.x - a.y) * H} : v2f{(a.y - a.x) * H, (-a.x - a.y) * H};
-    }
-    v[13] = twmul<INV>(v[13], w3);                   // k1=3,n2=1
-    {                                                // k1=3,n2=2 : w^6
-        const v2f a = v[14];
-        v[14] = INV ? v2f{(-a.x - a.y) * H, (a.x - a.y) * H} : v2f{(a.y - a.x) * H, (-a.x - a.y) * H};
-    }
-    v[15] = twmul<INV>(v[15], w9);                   // k1=3,n2=3
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    const v2f w1{C1, -S1}, w3{S1, -C1}, w9{-C1, S1}, hh{H, H}, nh{-H, -H};
+    v[5] = twmul<INV>(v[5], w1);                    // k1=1,n2=1
+    v[6] = add_rot<INV>(v[6], v[6]) * hh;           // k1=1,n2=2 : w^2 = H(1 -+ i)
+    v[7] = twmul<INV>(v[7], w3);                    // k1=1,n2=3
+    v[9] = add_rot<INV>(v[9], v[9]) * hh;           // k1=2,n2=1 : w^2
+    // k1=2,n2=2 : w^4 = -+ i, folded into dft4_rot2 below
+    v[11] = sub_rot<INV>(v[11], v[11]) * nh;        // k1=2,n2=3 : w^6 = -H(1 +- i)
+    v[13] = twmul<INV>(v[13], w3);                  // k1=3,n2=1
+    v[14] = sub_rot<INV>(v[14], v[14]) * nh;        // k1=3,n2=2 : w^6
+    v[15] = twmul<INV>(v[15], w9);                  // k1=3,n2=3
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+    dft4<INV>(v[4], v[5], v[6], v[7]);
+    dft4_rot2<INV>(v[8], v[9], v[10], v[11]);
+    dft4<INV>(v[12], v[13], v[14], v[15]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,12 +126,12 @@ __device__ __forceinline__ void fft4096_pass2(v2f* lds, int j, const Fft4096Tabl
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = lds[pad16(j + 256 * t)];
-    const int k = j & 15;
+    const unsigned k = (unsigned)j & 15u;
 #pragma unroll
-    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw256[k * t]);
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw256[k * (unsigned)t]);
     dft16<INV>(v);
     __syncthreads();  // every thread has read its inputs: in-place overwrite is safe
-    const int base = (j >> 4) * 272 + k;  // pad16((j/16)*256 + k + 16 t) = (j/16)*272 + k + 17 t
+    const int base = (j >> 4) * 272 + (int)k;  // pad16((j/16)*256 + k + 16 t) = (j/16)*272 + k + 17 t
 #pragma unroll
     for (int t = 0; t < 16; ++t) lds[base + 17 * t] = v[DFT16_OUT(t)];
 }
@@ -118,7 +142,7 @@ __device__ __forceinline__ void fft4096_pass3(v2f (&out)[16], const v2f* lds, in
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = lds[pad16(j + 256 * t)];
 #pragma unroll
-    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw4096[j * t]);
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw4096[(unsigned)j * (unsigned)t]);
     dft16<INV>(v);
 #pragma unroll
     for (int t = 0; t < 16; ++t) out[t] = v[DFT16_OUT(t)];

@@ -218,7 +218,7 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     const uint64_t first_hop = (!averaging && !emit_all_) ? n_hops - 1 : 0;
     const uint64_t hops_launch = n_hops - first_hop;
 
-    d_power_.reserve((size_t)(n_streams_ * n_traces * hops_launch * bins));
+    if (averaging) d_power_.reserve((size_t)(n_streams_ * n_traces * hops_launch * bins));
     const size_t traces_count = (size_t)(n_streams_ * hops_out * 4 * bins);
     if (d_traces_.count < traces_count) {
         d_traces_.reserve(traces_count);
@@ -263,7 +263,29 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         pa.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
     }
     pa.power = d_power_.ptr;
+    pa.fused_db = averaging ? 0 : 1;
+    pa.emit_all = emit_all_ ? 1 : 0;
+    pa.n_hops_out = (uint32_t)hops_out;
+    pa.trace_slot[0] = slots[0];
+    pa.trace_slot[1] = slots[1];
+    pa.state_floor = state_floor_;
+    pa.floor_db = cfg_.floor_db;
+    pa.a_weighting_db = d_a_weight_.ptr;
+    pa.traces = d_traces_.ptr;
     launch_spectrum_power(pa, fast, (uint32_t)wgs, stream);
+    if (!averaging) {  // the power kernel wrote the traces itself
+        timer_.end(stream);
+        OMX_HIP(hipGetLastError());
+        if (out) {
+            out->bins = bins;
+            out->n_streams = n_streams_;
+            out->n_hops = n_hops;
+            out->n_hops_out = hops_out;
+            out->d_traces = d_traces_.ptr;
+            out->d_frequency_bins = d_freq_bins_.ptr;
+        }
+        return OMX_PRODUCED;
+    }
 
     SpectrumLevelsArgs la{};
     la.power = d_power_.ptr;

@@ -8,42 +8,88 @@
 
 namespace omx {
 
-// ---- K3a fast: N = 4096, one (stream, trace, hop) per 256-thread workgroup, FFT in LDS ------------
+// ---- K3a fast: N = 4096.  Two consecutive hops of one (stream, trace) share one complex FFT: hop 2p is
+// the real part, hop 2p+1 the imaginary part, X_a = (Z[k] + conj Z[N-k])/2, X_b = (Z[k] - conj Z[N-k])/(2i).
+// With AveragingMode::None the dB conversion (:391-401) is fused here and the traces are written directly;
+// otherwise the per-hop power goes to the scratch buffer for spectrum_levels_kernel.
+__device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint32_t s, uint32_t tr, uint32_t h, uint32_t k,
+                                               float power) {
+    if (a.fused_db) {
+        float raw = a.floor_db, weighted = a.floor_db;
+        if (!(power < a.state_floor)) {
+            const float db = logf(power) * 4.3429448f;
+            raw = fmaxf(db, a.floor_db);
+            weighted = fmaxf(db + a.a_weighting_db[k], a.floor_db);
+        }
+        const uint32_t ho = a.emit_all ? h : 0;
+        float* out = a.traces + (((uint64_t)s * a.n_hops_out + ho) * 2 + a.trace_slot[tr]) * 2 * a.bins + k;
+        out[0] = weighted;
+        out[a.bins] = raw;
+    } else {
+        a.power[(((uint64_t)s * a.n_traces + tr) * a.n_hops + h) * a.bins + k] = power;
+    }
+}
+
 __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerArgs a) {
     __shared__ v2f A[FFT4096_LDS];
-    __shared__ float wave_sum[4];
-    const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * n_hops + h, hop fastest
-    const uint32_t h = item % a.n_hops, st = item / a.n_hops;
+    __shared__ float wave_sum[2][4];
+    const uint32_t pairs = (a.n_hops + 1) / 2;
+    const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * pairs + pair, pair fastest
+    const uint32_t pr = item % pairs, st = item / pairs;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+    const uint32_t h0 = 2 * pr;
+    const bool has_b = h0 + 1 < a.n_hops;
     const int j = threadIdx.x;
     const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
     const uint64_t mask = a.cap - 1;
-    const uint64_t p0 = a.tail + (uint64_t)(a.first_hop + h) * a.hop;
-    float x[16];
-    float partial = 0.0f;
+    const uint64_t p0 = a.tail + (uint64_t)(a.first_hop + h0) * a.hop;
+    float xa[16], xb[16];
+    float sa = 0.0f, sb = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        x[t] = ring[(p0 + (uint32_t)(j + 256 * t)) & mask];
-        partial += x[t];
+        const uint64_t q = p0 + (uint32_t)(j + 256 * t);
+        xa[t] = ring[q & mask];
+        xb[t] = has_b ? ring[(q + a.hop) & mask] : 0.0f;
+        sa += xa[t];
+        sb += xb[t];
     }
     // window.rs:80-84 mean (tree order here; the generic kernel keeps the sequential order)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) partial += __shfl_xor(partial, off);
-    if ((j & 63) == 0) wave_sum[j >> 6] = partial;
+    for (int off = 32; off >= 1; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+    }
+    if ((j & 63) == 0) {
+        wave_sum[0][j >> 6] = sa;
+        wave_sum[1][j >> 6] = sb;
+    }
     __syncthreads();
-    const float mean = (wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]) / 4096.0f;
+    const float mean_a = (wave_sum[0][0] + wave_sum[0][1] + wave_sum[0][2] + wave_sum[0][3]) / 4096.0f;
+    const float mean_b = (wave_sum[1][0] + wave_sum[1][1] + wave_sum[1][2] + wave_sum[1][3]) / 4096.0f;
     v2f v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = v2f{(x[t] - mean) * a.window[j + 256 * t], 0.0f};
+    for (int t = 0; t < 16; ++t) {
+        const float w = a.window[j + 256 * t];
+        v[t] = v2f{(xa[t] - mean_a) * w, (xb[t] - mean_b) * w};
+    }
     const Fft4096Tables tb{a.tw256, a.tw4096};
     fft4096<false>(v, A, j, tb);
-    float* out = a.power + (uint64_t)item * a.bins;
+    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int k = j + 256 * t;
-        out[k] = (v[t].x * v[t].x + v[t].y * v[t].y) * a.bin_norm[k];
+    for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t == 8 && j != 0) break;
+        const uint32_t k = (uint32_t)(j + 256 * t);
+        const v2f z = v[t];
+        const v2f zr = A[pad16((int)((4096u - k) & 4095u))];
+        const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
+        const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
+        const float norm = a.bin_norm[k];
+        spectrum_store(a, s, tr, h0, k, (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm);
+        if (has_b) spectrum_store(a, s, tr, h0 + 1, k, (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm);
     }
-    if (j == 0) out[2048] = (v[8].x * v[8].x + v[8].y * v[8].y) * a.bin_norm[2048];
 }
 
 // ---- K3a generic: any power-of-two N, radix-2 in a global workspace, reference operation order ------
@@ -68,10 +114,9 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
         const float mean = mean_sh;
         for (uint32_t i = tid; i < a.fft_size; i += nt) ws[i] = v2f{(ring[(p0 + i) & mask] - mean) * a.window[i], 0.0f};
         fft_radix2(ws, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
-        float* out = a.power + item * a.bins;
         for (uint32_t i = tid; i < a.bins; i += nt) {
             const v2f c = ws[i];
-            out[i] = (c.x * c.x + c.y * c.y) * a.bin_norm[i];
+            spectrum_store(a, s, tr, h, i, (c.x * c.x + c.y * c.y) * a.bin_norm[i]);
         }
     }
 }
@@ -79,7 +124,8 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream) {
     const uint64_t total = (uint64_t)a.n_streams * a.n_traces * a.n_hops;
     if (total == 0) return;
-    if (fast4096) hipLaunchKernelGGL(spectrum_power_4096_kernel, dim3((uint32_t)total), dim3(256), 0, stream, a);
+    const uint64_t pairs = (uint64_t)a.n_streams * a.n_traces * ((a.n_hops + 1) / 2);
+    if (fast4096) hipLaunchKernelGGL(spectrum_power_4096_kernel, dim3((uint32_t)pairs), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(spectrum_power_generic_kernel, dim3(generic_wgs), dim3(256), 0, stream, a);
 }
 

@@ -166,9 +166,9 @@ __device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, fl
 // ================================================================================================
 // K2: fused reassigned STFT, W = F = 4096, H = 8192.  256 threads, two padded 4096-complex LDS
 // buffers (68 KiB) -> two workgroups per CU.  Algorithm (all f32):
-//   1. 8192 real samples packed as 4096 complex -> FFT4096 -> real-FFT split gives X[0..4096]
-//   2. Hilbert: drop X[0], keep X[1..4096]; the unnormalised 8192-point inverse restricted to a
-//      half-filled spectrum is two 4096-point inverses (even / odd output samples)
+//   1. 8192 real samples packed as 4096 complex -> FFT4096 (the real-FFT split is folded into step 2)
+//   2. Hilbert: Re(analytic) = 4096 x - X[0]/2 + X[4096](-1)^n/2 needs no transform; Im(analytic) is an
+//      inverse REAL FFT of -i X[k] = one 4096-point complex inverse (5 FFT-4096 per frame in total)
 //   3. s = analytic[2048 .. 6144); three windowed forward FFT4096 (w, w', t*w)
 //   4. per-bin reassignment + ordered compaction (ascending bin), 12-byte points
 // ================================================================================================
@@ -184,17 +184,17 @@ __device__ __forceinline__ void fft4096_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* 
             a[t] = A[pad16(j + 256 * t)];
             b[t] = B[pad16(j + 256 * t)];
         }
-        const int k = j & 15;
+        const unsigned k = (unsigned)j & 15u;
 #pragma unroll
         for (int t = 1; t < 16; ++t) {
-            const v2f w = tb.tw256[k * t];
+            const v2f w = tb.tw256[k * (unsigned)t];
             a[t] = twmul<INV>(a[t], w);
             b[t] = twmul<INV>(b[t], w);
         }
         dft16<INV>(a);
         dft16<INV>(b);
         __syncthreads();
-        const int base = (j >> 4) * 272 + k;
+        const int base = (j >> 4) * 272 + (int)k;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             A[base + 17 * t] = a[DFT16_OUT(t)];
@@ -211,7 +211,7 @@ __device__ __forceinline__ void fft4096_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* 
         }
 #pragma unroll
         for (int t = 1; t < 16; ++t) {
-            const v2f w = tb.tw4096[j * t];
+            const v2f w = tb.tw4096[(unsigned)j * (unsigned)t];
             a[t] = twmul<INV>(a[t], w);
             b[t] = twmul<INV>(b[t], w);
         }
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_kernel(StftFastAr
     v2f* A = reinterpret_cast<v2f*>(smem_raw);
     v2f* B = A + FFT4096_LDS;
     uint32_t* scan = reinterpret_cast<uint32_t*>(B + FFT4096_LDS);  // [9][4] wave counts
+    float* hil = reinterpret_cast<float*>(scan + 36);                // X[0]/2, X[4096]/2
 
     uint32_t s, col;
     if (!block_to_stream_column(a.n_streams, a.n_cols, s, col)) return;
@@ -261,47 +262,53 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_kernel(StftFastAr
     }
     fft4096<false>(v, A, j, tb);  // v[t] = Z[j + 256 t]
 
-    // ---- 2. real-FFT split + Hilbert mask -> inputs of the two half-length inverses -------------
+    // ---- 2. Hilbert transform with ONE half-length inverse ------------------------------------------
+    // analytic[n] = sum_{k=1..4096} X[k] e^{+2 pi i k n / 8192} (X[0] dropped, no x2, unnormalised; :546-557).
+    // Its real part needs no transform:  Re = 4096 x[n] - X[0]/2 + X[4096] (-1)^n / 2.
+    // Its imaginary part is half of the real sequence with spectrum V[k] = -i X[k] (0 < k < 4096), an inverse
+    // REAL FFT = one 4096-point complex inverse of
+    //     Z'[k] = ( conj(w^k) (Zf[k] + conj Zf[N-k]) - w^k (Zf[k] - conj Zf[N-k]) ) / 2,   Z'[0] = 0,
+    // whose output holds (Im analytic[2m], Im analytic[2m+1]) in (re, im).  w = exp(-2 pi i / 8192).
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
+    if (j == 0) {
+        hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[4096] / 2
+    }
     __syncthreads();
-    v2f y0[16], y1[16];
+    v2f y[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const int k = j + 256 * t;
+        const unsigned k = (unsigned)(j + 256 * t);
         const v2f z = v[t];
-        const v2f zr = A[pad16((4096 - k) & 4095)];
-        const v2f zc{zr.x, -zr.y};                               // conj(Z[N-k])
-        const v2f e{(z.x + zc.x) * 0.5f, (z.y + zc.y) * 0.5f};   // spectrum of the even samples
-        const v2f dd{z.x - zc.x, z.y - zc.y};
-        const v2f o{dd.y * 0.5f, -dd.x * 0.5f};                  // (Z - Zc) / (2i): spectrum of the odd samples
-        const v2f w = a.tw8192[k];                               // exp(-2*pi*i*k/8192)
-        const v2f x = e + cmul(w, o);                            // X[k], 0 <= k < 4096
-        if (k == 0) {                                            // X[0] is dropped; X[4096] = E[0] - O[0] aliases to index 0
-            const float xn = e.x - o.x;
-            y0[t] = v2f{xn, 0.0f};
-            y1[t] = v2f{-xn, 0.0f};
-        } else {
-            y0[t] = x;                                           // even output samples
-            y1[t] = cmulc(x, w);                                 // odd output samples: X[k] * exp(+2*pi*i*k/8192)
-        }
+        const v2f zr = A[pad16((int)((4096u - k) & 4095u))];
+        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};   // (Zf[k] + conj Zf[N-k]) / 2
+        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};   // (Zf[k] - conj Zf[N-k]) / 2
+        const v2f w = a.tw8192[k];
+        y[t] = cmulc(sum, w) - cmul(dif, w);
+        if (k == 0) y[t] = v2f{0.0f, 0.0f};
     }
+    const float half_x0 = hil[0], half_xn = hil[1];
     __syncthreads();
-    fft4096_dual<true>(y0, y1, A, B, j, tb);  // y0[t] = a[2(j+256t)], y1[t] = a[2(j+256t)+1]
+    fft4096<true>(y, A, j, tb);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
 
-    // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t --------------------------------------
+    // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t -----------------------------------------
     __syncthreads();
+    float* imag = reinterpret_cast<float*>(B);  // 4096 floats
 #pragma unroll
-    for (int t = 4; t < 12; ++t) {
-        const int i = 2 * (j + 256 * t - 1024);
-        B[pad16(i)] = y0[t];
-        B[pad16(i + 1)] = y1[t];
-    }
+    for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + 256 * t - 1024)) = y[t];
     __syncthreads();
     v2f sv[16];
+    {
+        const float parity = (j & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of j
+        const uint64_t q0 = p0 + 2048u + (unsigned)j;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) sv[t] = B[pad16(j + 256 * t)];
+        for (int t = 0; t < 16; ++t) {
+            const float xr = ring[(q0 + 256u * (unsigned)t) & mask];
+            sv[t] = v2f{4096.0f * xr - half_x0 + parity, imag[j + 256 * t]};
+        }
+    }
     __syncthreads();
 
     // ---- three windowed FFTs; keep bins j + 256 t (t < 8) and bin 2048 (thread 0, t = 8) ----------
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_kernel(StftFastAr
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    const size_t lds = (size_t)2 * FFT4096_LDS * sizeof(v2f) + 9 * 4 * sizeof(uint32_t);
+    const size_t lds = (size_t)2 * FFT4096_LDS * sizeof(v2f) + 9 * 4 * sizeof(uint32_t) + 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel),

@@ -100,7 +100,13 @@ struct SpectrumPowerArgs {
     const v2f* tw256;      // fast 4096
     const v2f* tw4096;
     v2f* workspace;        // generic: [wgs][fft_size]
-    float* power;          // [n_streams][n_traces][n_hops][bins]
+    float* power;          // [n_streams][n_traces][n_hops][bins] (when !fused_db)
+    // AveragingMode::None: dB conversion fused into the power kernel, traces written directly
+    uint32_t fused_db, emit_all, n_hops_out;
+    uint32_t trace_slot[2];
+    float state_floor, floor_db;
+    const float* a_weighting_db;  // [bins]
+    float* traces;         // [n_streams][n_hops_out][2 traces][2 weightings][bins]
 };
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream);
 
