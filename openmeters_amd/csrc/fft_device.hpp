@@ -159,6 +159,118 @@ __device__ __forceinline__ void fft4096(v2f (&v)[16], v2f* lds, int j, const Fft
 }
 
 // ------------------------------------------------------------------------------------------------
+// Twiddle-source policies for the fused STFT kernel.  Pass-2 twiddles exp(-2 pi i (j%16) t / 256) come
+// either from the global table or from a 2 KiB LDS copy; pass-3 twiddles exp(-2 pi i j t / 4096) depend
+// only on the thread and come either from the global table or from 15 VGPR pairs loaded once.
+template <bool TW2_LDS, bool TW3_REGS>
+struct TwiddleSource {
+    const v2f* tw2;         // LDS copy when TW2_LDS, else the global tw256 table
+    const v2f* tw3_global;  // global tw4096 table
+    v2f tw3[TW3_REGS ? 15 : 1];
+    unsigned j;
+    __device__ __forceinline__ v2f w2(unsigned k, int t) const { return tw2[k * (unsigned)t]; }
+    __device__ __forceinline__ v2f w3(int t) const {
+        if constexpr (TW3_REGS) return tw3[t - 1];
+        else return tw3_global[j * (unsigned)t];
+    }
+};
+
+template <bool INV, class TW>
+__device__ __forceinline__ void fft4096t_pass2(const v2f* src, v2f* dst, int j, const TW& tw, bool same_buffer) {
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[pad16(j + 256 * t)];
+    const unsigned k = (unsigned)j & 15u;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw.w2(k, t));
+    dft16<INV>(v);
+    if (same_buffer) __syncthreads();
+    const int base = (j >> 4) * 272 + (int)k;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dst[base + 17 * t] = v[DFT16_OUT(t)];
+}
+template <bool INV, class TW>
+__device__ __forceinline__ void fft4096t_pass3(v2f (&out)[16], const v2f* lds, int j, const TW& tw) {
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = lds[pad16(j + 256 * t)];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw.w3(t));
+    dft16<INV>(v);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) out[t] = v[DFT16_OUT(t)];
+}
+// x[j + 256 t] in v[t] -> X[j + 256 t] in v[t].  PINGPONG: writes `first`, then `second`, reads `second` last
+// (caller guarantees nobody still reads `first` and `second` is free).  Otherwise in place in `first`.
+template <bool INV, bool PINGPONG, class TW>
+__device__ __forceinline__ void fft4096t(v2f (&v)[16], v2f* first, v2f* second, int j, const TW& tw) {
+    fft4096_pass1<INV>(v, first, j);
+    __syncthreads();
+    if constexpr (PINGPONG) {
+        fft4096t_pass2<INV>(first, second, j, tw, false);
+        __syncthreads();
+        fft4096t_pass3<INV>(v, second, j, tw);
+    } else {
+        fft4096t_pass2<INV>(first, first, j, tw, true);
+        __syncthreads();
+        fft4096t_pass3<INV>(v, first, j, tw);
+    }
+}
+// Two transforms at once on the two LDS buffers (in place, shared barriers).
+template <bool INV, class TW>
+__device__ __forceinline__ void fft4096t_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const TW& tw) {
+    fft4096_pass1<INV>(v0, A, j);
+    fft4096_pass1<INV>(v1, B, j);
+    __syncthreads();
+    {
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(j + 256 * t)];
+            b[t] = B[pad16(j + 256 * t)];
+        }
+        const unsigned k = (unsigned)j & 15u;
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tw.w2(k, t);
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+        __syncthreads();
+        const int base = (j >> 4) * 272 + (int)k;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            A[base + 17 * t] = a[DFT16_OUT(t)];
+            B[base + 17 * t] = b[DFT16_OUT(t)];
+        }
+    }
+    __syncthreads();
+    {
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(j + 256 * t)];
+            b[t] = B[pad16(j + 256 * t)];
+        }
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tw.w3(t);
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            v0[t] = a[DFT16_OUT(t)];
+            v1[t] = b[DFT16_OUT(t)];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic radix-2 FFT over `n = 1 << logn` complex values in `a` (LDS or global), executed by all
 // `nthreads` threads of the workgroup.  Same decimation-in-time order and twiddles (tw[k] =
 // exp(-2*pi*i*k/n), k < n/2) as the CPU oracle's fft.hpp, without mul+add fusion.

@@ -172,219 +172,292 @@ __device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, fl
 //   3. s = analytic[2048 .. 6144); three windowed forward FFT4096 (w, w', t*w)
 //   4. per-bin reassignment + ordered compaction (ascending bin), 12-byte points
 // ================================================================================================
-template <bool INV>
-__device__ __forceinline__ void fft4096_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const Fft4096Tables& tb) {
-    fft4096_pass1<INV>(v0, A, j);
-    fft4096_pass1<INV>(v1, B, j);
-    __syncthreads();
-    {  // pass 2 on both buffers with shared barriers
-        v2f a[16], b[16];
+// Compile-time switches of the fused kernel (A/B-tested on MI355X; see DESIGN.md §4 and profiles/).
+template <uint32_t COLS, bool TW2_LDS_, bool TW3_REGS_, bool DUAL_, bool PINGPONG_, bool ONEBUF_ = false, int MINW = 2,
+          bool RECOMPUTE_S_ = false>
+struct K2Variant {
+    static constexpr bool RECOMPUTE_S = RECOMPUTE_S_;  // rebuild the analytic slice per windowed FFT instead of holding it
+    static constexpr bool ONEBUF = ONEBUF_;        // one 34 KiB FFT buffer + 16 KiB imag[] (53 KiB -> 3 workgroups per CU)
+    static constexpr int MIN_WAVES = MINW;         // __launch_bounds__ waves per SIMD
+    static constexpr uint32_t COLS_PER_WG = COLS;  // consecutive columns of one stream per workgroup
+    static constexpr bool TW2_LDS = TW2_LDS_;      // pass-2 twiddles from a 2 KiB LDS table
+    static constexpr bool TW3_REGS = TW3_REGS_;    // pass-3 twiddles resident in VGPRs
+    static constexpr bool DUAL = DUAL_;            // window and derivative-window FFTs run together
+    static constexpr bool PINGPONG = PINGPONG_;    // single transforms alternate between the two LDS buffers
+};
+
+template <class V>
+__global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel(StftFastArgs a) {
+    static_assert(!V::ONEBUF || (!V::DUAL && !V::PINGPONG), "one buffer: sequential in-place transforms only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* A = reinterpret_cast<v2f*>(smem_raw);
+    v2f* B = A + FFT4096_LDS;                                      // ONEBUF: only its first 16 KiB exist (imag[])
+    v2f* tw2_lds = B + (V::ONEBUF ? 2048 : FFT4096_LDS);           // [256] exp(-2 pi i k / 256)
+    uint32_t* scan = reinterpret_cast<uint32_t*>(tw2_lds + 256);   // [9][4] wave counts
+    float* hil = reinterpret_cast<float*>(scan + 36);              // X[0]/2, X[4096]/2
+
+    const uint32_t chunks = (a.n_cols + V::COLS_PER_WG - 1) / V::COLS_PER_WG;
+    uint32_t s, chunk;
+    if (!block_to_stream_column(a.n_streams, chunks, s, chunk)) return;
+    const int j = threadIdx.x;
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint64_t mask = a.cap - 1;
+    const long long last_nonzero = a.last_nonzero[s];
+    const int lane = j & 63, wave = j >> 6;
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+
+    using TW = TwiddleSource<V::TW2_LDS, V::TW3_REGS>;
+    TW tw;
+    tw.j = (unsigned)j;
+    tw.tw3_global = a.tw4096;
+    tw.tw2 = V::TW2_LDS ? tw2_lds : a.tw256;
+    if constexpr (V::TW3_REGS) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            a[t] = A[pad16(j + 256 * t)];
-            b[t] = B[pad16(j + 256 * t)];
-        }
-        const unsigned k = (unsigned)j & 15u;
-#pragma unroll
-        for (int t = 1; t < 16; ++t) {
-            const v2f w = tb.tw256[k * (unsigned)t];
-            a[t] = twmul<INV>(a[t], w);
-            b[t] = twmul<INV>(b[t], w);
-        }
-        dft16<INV>(a);
-        dft16<INV>(b);
-        __syncthreads();
-        const int base = (j >> 4) * 272 + (int)k;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            A[base + 17 * t] = a[DFT16_OUT(t)];
-            B[base + 17 * t] = b[DFT16_OUT(t)];
-        }
+        for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[(unsigned)j * (unsigned)t];
     }
-    __syncthreads();
-    {
-        v2f a[16], b[16];
+    if constexpr (V::TW2_LDS) {
+        tw2_lds[j] = a.tw256[j];
+        __syncthreads();
+    }
+
+    const uint32_t col_end = min(a.n_cols, (chunk + 1) * V::COLS_PER_WG);
+    for (uint32_t col = chunk * V::COLS_PER_WG; col < col_end; ++col) {
+        const uint64_t p0 = a.tail + (uint64_t)col * a.hop;  // absolute position of this window's first sample
+        uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+        const float *win = a.window, *dwin = a.dwindow, *twin = a.twindow, *bnorm = a.bin_norm;
+        const v2f* tw8192 = a.tw8192;
+        if constexpr (V::COLS_PER_WG > 1) {
+            // The tables are thread-invariant; without this the compiler hoists ~80 loads out of the column
+            // loop and spills.  Re-reading them per column from L1/L2 is the cheaper side of that trade.
+            asm volatile("" : "+s"(win), "+s"(dwin), "+s"(twin), "+s"(bnorm), "+s"(tw8192));
+        }
+        // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
+        if (last_nonzero < (long long)p0) {
+            if (j == 0) *count_out = 0;
+            continue;
+        }
+
+        // ---- 1. packed real FFT of the 8192-sample window ----------------------------------------------
+        v2f v[16];
+        if ((p0 & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                v[t] = *reinterpret_cast<const v2f*>(ring + ((p0 + 2u * (uint32_t)(j + 256 * t)) & mask));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint64_t q = p0 + 2u * (uint32_t)(j + 256 * t);
+                v[t] = v2f{ring[q & mask], ring[(q + 1) & mask]};
+            }
+        }
+        if constexpr (V::COLS_PER_WG > 1) __syncthreads();  // previous column may still be reading A / B / scan
+        fft4096t<false, V::PINGPONG>(v, A, B, j, tw);  // v[t] = Zf[j + 256 t]; last read: B (pingpong) or A
+
+        // ---- 2. Hilbert transform with ONE half-length inverse ----------------------------------------
+        // analytic[n] = sum_{k=1..4096} X[k] e^{+2 pi i k n / 8192} (X[0] dropped, no x2, unnormalised; :546-557).
+        // Its real part needs no transform:  Re = 4096 x[n] - X[0]/2 + X[4096] (-1)^n / 2.
+        // Its imaginary part is half of the real sequence with spectrum V[k] = -i X[k] (0 < k < 4096), an inverse
+        // REAL FFT = one 4096-point complex inverse of
+        //     Z'[k] = ( conj(w^k) (Zf[k] + conj Zf[N-k]) - w^k (Zf[k] - conj Zf[N-k]) ) / 2,   Z'[0] = 0,
+        // whose output holds (Im analytic[2m], Im analytic[2m+1]) in (re, im).  w = exp(-2 pi i / 8192).
+        v2f* X = (V::PINGPONG || V::ONEBUF) ? A : B;  // exchange buffer
+        v2f* Y = V::PINGPONG ? B : A;
+        if constexpr (!V::PINGPONG) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = v[t];
+        if (j == 0) {
+            hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
+            hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[4096] / 2
+        }
+        __syncthreads();
+        v2f y[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            a[t] = A[pad16(j + 256 * t)];
-            b[t] = B[pad16(j + 256 * t)];
+            const unsigned k = (unsigned)(j + 256 * t);
+            const v2f z = v[t];
+            const v2f zr = X[pad16((int)((4096u - k) & 4095u))];
+            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Zf[k] + conj Zf[N-k]) / 2
+            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};  // (Zf[k] - conj Zf[N-k]) / 2
+            const v2f w = tw8192[k];
+            y[t] = cmulc(sum, w) - cmul(dif, w);
+            if (k == 0) y[t] = v2f{0.0f, 0.0f};
         }
+        const float half_x0 = hil[0], half_xn = hil[1];
+        if constexpr (V::ONEBUF) __syncthreads();  // partners are read from the buffer the inverse is about to overwrite
+        // Y was last read before the barrier above; X is released by pass 1's barrier (ping-pong writes it in pass 2)
+        fft4096t<true, V::PINGPONG>(y, Y, X, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
+
+        // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t ---------------------------------------
+        // ping-pong: the inverse read X (= A) last, so Y (= B) is free; in place: it read Y (= A) last, X (= B) is free
+        float* imag = reinterpret_cast<float*>(B);
 #pragma unroll
-        for (int t = 1; t < 16; ++t) {
-            const v2f w = tb.tw4096[(unsigned)j * (unsigned)t];
-            a[t] = twmul<INV>(a[t], w);
-            b[t] = twmul<INV>(b[t], w);
-        }
-        dft16<INV>(a);
-        dft16<INV>(b);
+        for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + 256 * t - 1024)) = y[t];
+        __syncthreads();
+        const float parity = (j & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of j
+        const uint64_t q0 = p0 + 2048u + (unsigned)j;
+        auto analytic = [&](int t) -> v2f {  // s[j + 256 t]
+            const float xr = ring[(q0 + 256u * (unsigned)t) & mask];
+            return v2f{4096.0f * xr - half_x0 + parity, imag[j + 256 * t]};
+        };
+        v2f bb[9], bd[9], bt[9];
+        if constexpr (V::RECOMPUTE_S) {
+            static_assert(V::ONEBUF, "RECOMPUTE_S keeps imag[] alive, which needs the separate imag region");
+            v2f vv[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            v0[t] = a[DFT16_OUT(t)];
-            v1[t] = b[DFT16_OUT(t)];
+            for (int t = 0; t < 16; ++t) {
+                const v2f sa = analytic(t);
+                const float w = win[j + 256 * t];
+                vv[t] = v2f{sa.x * w, sa.y * w};
+            }
+            fft4096t<false, false>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bb[t] = vv[t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const v2f sa = analytic(t);
+                const float w = dwin[j + 256 * t];
+                vv[t] = v2f{sa.x * w, sa.y * w};
+            }
+            __syncthreads();
+            fft4096t<false, false>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bd[t] = vv[t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const v2f sa = analytic(t);
+                const float w = twin[j + 256 * t];
+                vv[t] = v2f{sa.x * w, sa.y * w};
+            }
+            __syncthreads();
+            fft4096t<false, false>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bt[t] = vv[t];
+        } else {
+        v2f sv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sv[t] = analytic(t);
+        __syncthreads();
+
+        // ---- three windowed FFTs; keep bins j + 256 t (t < 8) and bin 2048 (thread 0, t = 8) ----------
+        if constexpr (V::DUAL) {
+            v2f vb[16], vd[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = win[j + 256 * t], dw = dwin[j + 256 * t];
+                vb[t] = v2f{sv[t].x * w, sv[t].y * w};
+                vd[t] = v2f{sv[t].x * dw, sv[t].y * dw};
+            }
+            fft4096t_dual<false>(vb, vd, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                bb[t] = vb[t];
+                bd[t] = vd[t];
+            }
+            v2f vt[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = twin[j + 256 * t];
+                vt[t] = v2f{sv[t].x * w, sv[t].y * w};
+            }
+            __syncthreads();  // the dual transform's last pass still reads A and B
+            fft4096t<false, V::PINGPONG>(vt, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bt[t] = vt[t];
+        } else {
+            v2f vv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = win[j + 256 * t];
+                vv[t] = v2f{sv[t].x * w, sv[t].y * w};
+            }
+            fft4096t<false, V::PINGPONG>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bb[t] = vv[t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = dwin[j + 256 * t];
+                vv[t] = v2f{sv[t].x * w, sv[t].y * w};
+            }
+            if constexpr (!V::PINGPONG) __syncthreads();
+            fft4096t<false, V::PINGPONG>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bd[t] = vv[t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = twin[j + 256 * t];
+                vv[t] = v2f{sv[t].x * w, sv[t].y * w};
+            }
+            if constexpr (!V::PINGPONG) __syncthreads();
+            fft4096t<false, V::PINGPONG>(vv, A, B, j, tw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bt[t] = vv[t];
         }
+        }
+
+        // ---- 4. reassignment + ordered compaction -------------------------------------------------------
+        omx_spectrogram_point pts[9];
+        unsigned long long masks[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t bin = (uint32_t)(j + 256 * t);
+            bool keep = false;
+            if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], bnorm[bin], rc, pts[t]);
+            masks[t] = __ballot(keep);
+            if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
+        }
+        __syncthreads();
+        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        uint32_t running = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            uint32_t before = running;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t c = scan[t * 4 + w];
+                if (w < wave) before += c;
+                running += c;
+            }
+            if ((masks[t] >> lane) & 1ull) {
+                const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+                out[pos] = pts[t];
+            }
+        }
+        if (j == 0) *count_out = running;
     }
 }
 
-__global__ __launch_bounds__(256, 2) void stft_reassigned_4096_kernel(StftFastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    v2f* A = reinterpret_cast<v2f*>(smem_raw);
-    v2f* B = A + FFT4096_LDS;
-    uint32_t* scan = reinterpret_cast<uint32_t*>(B + FFT4096_LDS);  // [9][4] wave counts
-    float* hil = reinterpret_cast<float*>(scan + 36);                // X[0]/2, X[4096]/2
-
-    uint32_t s, col;
-    if (!block_to_stream_column(a.n_streams, a.n_cols, s, col)) return;
-    const int j = threadIdx.x;
-    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;  // absolute position of this window's first sample
-    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
-
-    // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
-    if (a.last_nonzero[s] < (long long)p0) {
-        if (j == 0) *count_out = 0;
-        return;
+template <class V>
+static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)((V::ONEBUF ? FFT4096_LDS + 2048 : 2 * FFT4096_LDS) + 256) * sizeof(v2f) + 9 * 4 * sizeof(uint32_t) +
+                       2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel<V>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
     }
-    const Fft4096Tables tb{a.tw256, a.tw4096};
-    const float* ring = a.ring + (uint64_t)s * a.cap;
-    const uint64_t mask = a.cap - 1;
-
-    // ---- 1. packed real FFT of the 8192-sample window ------------------------------------------
-    v2f v[16];
-    if ((p0 & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            v[t] = *reinterpret_cast<const v2f*>(ring + ((p0 + 2u * (uint32_t)(j + 256 * t)) & mask));
-    } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint64_t q = p0 + 2u * (uint32_t)(j + 256 * t);
-            v[t] = v2f{ring[q & mask], ring[(q + 1) & mask]};
-        }
-    }
-    fft4096<false>(v, A, j, tb);  // v[t] = Z[j + 256 t]
-
-    // ---- 2. Hilbert transform with ONE half-length inverse ------------------------------------------
-    // analytic[n] = sum_{k=1..4096} X[k] e^{+2 pi i k n / 8192} (X[0] dropped, no x2, unnormalised; :546-557).
-    // Its real part needs no transform:  Re = 4096 x[n] - X[0]/2 + X[4096] (-1)^n / 2.
-    // Its imaginary part is half of the real sequence with spectrum V[k] = -i X[k] (0 < k < 4096), an inverse
-    // REAL FFT = one 4096-point complex inverse of
-    //     Z'[k] = ( conj(w^k) (Zf[k] + conj Zf[N-k]) - w^k (Zf[k] - conj Zf[N-k]) ) / 2,   Z'[0] = 0,
-    // whose output holds (Im analytic[2m], Im analytic[2m+1]) in (re, im).  w = exp(-2 pi i / 8192).
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
-    if (j == 0) {
-        hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
-        hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[4096] / 2
-    }
-    __syncthreads();
-    v2f y[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned k = (unsigned)(j + 256 * t);
-        const v2f z = v[t];
-        const v2f zr = A[pad16((int)((4096u - k) & 4095u))];
-        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};   // (Zf[k] + conj Zf[N-k]) / 2
-        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};   // (Zf[k] - conj Zf[N-k]) / 2
-        const v2f w = a.tw8192[k];
-        y[t] = cmulc(sum, w) - cmul(dif, w);
-        if (k == 0) y[t] = v2f{0.0f, 0.0f};
-    }
-    const float half_x0 = hil[0], half_xn = hil[1];
-    __syncthreads();
-    fft4096<true>(y, A, j, tb);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
-
-    // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t -----------------------------------------
-    __syncthreads();
-    float* imag = reinterpret_cast<float*>(B);  // 4096 floats
-#pragma unroll
-    for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + 256 * t - 1024)) = y[t];
-    __syncthreads();
-    v2f sv[16];
-    {
-        const float parity = (j & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of j
-        const uint64_t q0 = p0 + 2048u + (unsigned)j;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float xr = ring[(q0 + 256u * (unsigned)t) & mask];
-            sv[t] = v2f{4096.0f * xr - half_x0 + parity, imag[j + 256 * t]};
-        }
-    }
-    __syncthreads();
-
-    // ---- three windowed FFTs; keep bins j + 256 t (t < 8) and bin 2048 (thread 0, t = 8) ----------
-    v2f bb[9], bd[9], bt[9];
-    {
-        v2f vb[16], vd[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float w = a.window[j + 256 * t], dw = a.dwindow[j + 256 * t];
-            vb[t] = v2f{sv[t].x * w, sv[t].y * w};
-            vd[t] = v2f{sv[t].x * dw, sv[t].y * dw};
-        }
-        fft4096_dual<false>(vb, vd, A, B, j, tb);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            bb[t] = vb[t];
-            bd[t] = vd[t];
-        }
-    }
-    {
-        v2f vt[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float w = a.twindow[j + 256 * t];
-            vt[t] = v2f{sv[t].x * w, sv[t].y * w};
-        }
-        __syncthreads();
-        fft4096<false>(vt, A, j, tb);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) bt[t] = vt[t];
-    }
-
-    // ---- 4. reassignment + ordered compaction -----------------------------------------------------
-    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
-    omx_spectrogram_point pts[9];
-    unsigned long long masks[9];
-    const int lane = j & 63, wave = j >> 6;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const uint32_t bin = (uint32_t)(j + 256 * t);
-        bool keep = false;
-        if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], a.bin_norm[bin], rc, pts[t]);
-        masks[t] = __ballot(keep);
-        if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
-    }
-    __syncthreads();
-    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
-    uint32_t running = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        uint32_t before = running;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t c = scan[t * 4 + w];
-            if (w < wave) before += c;
-            running += c;
-        }
-        if ((masks[t] >> lane) & 1ull) {
-            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
-            out[pos] = pts[t];
-        }
-    }
-    if (j == 0) *count_out = running;
+    const uint32_t chunks = (a.n_cols + V::COLS_PER_WG - 1) / V::COLS_PER_WG;
+    hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
 }
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    const size_t lds = (size_t)2 * FFT4096_LDS * sizeof(v2f) + 9 * 4 * sizeof(uint32_t) + 2 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    // OMX_K2_VARIANT selects an A/B build of the kernel (tuning only; every variant computes the same thing)
+    static const int variant = [] {
+        const char* e = getenv("OMX_K2_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    // Measured on MI355X, 65 536 frames per launch (kernel ms): 100 -> 2.54, 1 -> 2.57, 2 -> 2.43, 3 -> 2.34,
+    // default -> 2.28; persistent multi-column loops (4.5 ms) and 3-workgroup/CU single-buffer forms (2.8-5.6 ms)
+    // lost to register spills and were removed except variant 13, kept as the documented negative result.
+    switch (variant) {                                  //     cols tw2lds tw3reg dual  pingpong onebuf minw recompute
+        case 100: launch_k2_variant<K2Variant<1, false, false, true, false>>(a, stream); break;  // round-1 first form
+        case 1: launch_k2_variant<K2Variant<1, false, false, true, true>>(a, stream); break;
+        case 2: launch_k2_variant<K2Variant<1, true, false, true, false>>(a, stream); break;
+        case 3: launch_k2_variant<K2Variant<1, false, true, true, false>>(a, stream); break;
+        case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
+        default: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;
     }
-    hipLaunchKernelGGL(stft_reassigned_4096_kernel, dim3(stream_column_grid(a.n_streams, a.n_cols)), dim3(256), lds,
-                       stream, a);
 }
 
 // ================================================================================================
