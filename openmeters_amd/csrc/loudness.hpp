@@ -1,5 +1,5 @@
 // LoudnessBank: S independent LoudnessProcessors (reference src/visuals/loudness/processor.rs:218-312),
-// one thread per (stream, channel) register pipeline.
+// four lanes per (stream, channel): register pipelines with per-lane window / true-peak phase.
 #pragma once
 #include "common.hpp"
 

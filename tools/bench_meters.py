@@ -1,0 +1,79 @@
+"""Throughput of the non-headline banks at the BASELINE.json shapes (cfg3 loudness, cfg4 scope + stereometer).
+Not the driver's bench line (bench.py is); used to fill DESIGN.md and to tune K4/K5/K6/K7."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import openmeters_amd  # noqa: E402
+from openmeters_amd import banks, capi  # noqa: E402
+
+api = openmeters_amd.api()
+dev = torch.device("cuda", 0)
+FS = 48000.0
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def loudness(S=1024, C=8, blocks=64, reps=5):
+    frames = 256 * blocks
+    n = torch.arange(frames, device=dev, dtype=torch.float64)
+    pcm = torch.empty((S, frames, C), device=dev, dtype=torch.float32)
+    for c in range(C):
+        f = 60.0 if c == 3 else 997.0 + 10.0 * c
+        pcm[:, :, c] = (0.5 * torch.sin(2 * np.pi * f * n / FS)).to(torch.float32)[None, :]
+    bank = banks.LoudnessBank(api, capi.LoudnessConfig(), S, C)
+    bank.set_option(capi.OPT_KERNEL_TIMING, 1)
+    run = lambda: bank.process_device(pcm.data_ptr(), 256, blocks, C, FS, capi.SURROUND, stream)
+    for _ in range(12):  # > 4 s of audio so all four windows are full
+        run()
+    bank.kernel_time()
+    dt = timed(run, reps)
+    kms, _ = bank.kernel_time()
+    cs = S * C * frames
+    print(f"cfg3 loudness: {S}x{C}ch, {blocks} blocks/call: {dt*1e3:.2f} ms/call (kernel {kms:.2f} ms) -> {cs/dt/1e9:.2f} G channel-samples/s, "
+          f"{cs/dt/(S*C*FS):.0f}x real time, algorithmic {cs*44/ (kms*1e-3)/1e9:.0f} GB/s = {cs*44/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s")
+    snap = bank.fetch(0, blocks - 1)
+    print("   stream0 last snapshot:", snap.short_term_loudness, snap.momentary_loudness, snap.true_peak_db[:3])
+
+
+def scope_stereo(S=256, blocks=64, reps=5):
+    frames = 256 * blocks
+    n = torch.arange(frames, device=dev, dtype=torch.float64)
+    pcm = torch.empty((S, frames, 2), device=dev, dtype=torch.float32)
+    for s in range(S):
+        f = 440.0 * 2.0 ** ((s % 24) / 12.0)
+        left = (0.8 * torch.sin(2 * np.pi * f * n / FS)).to(torch.float32)
+        pcm[s, :, 0] = left
+        pcm[s, :, 1] = -0.7 * left
+    pos = capi.positions_fallback(2)
+    st = banks.StereometerBank(api, capi.StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02,
+                                                           target_sample_count=2000), S)
+    dt = timed(lambda: st.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
+    print(f"cfg4 stereometer: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
+          f"{S*frames/dt/(S*FS):.0f}x real time")
+    sc = banks.OscilloscopeBank(api, capi.OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2,
+                                                             trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT), S)
+    dt = timed(lambda: sc.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
+    hdr, _ = sc.fetch(0, blocks - 1)
+    print(f"cfg4 oscilloscope: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.1f} k blocks/s, "
+          f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel}")
+
+
+if __name__ == "__main__":
+    loudness()
+    scope_stereo()
