@@ -127,11 +127,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("OMX_BENCH_BACKEND", "nccl")  # "gloo": test hook to exercise N > 1 on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import openmeters_amd
     from openmeters_amd import capi
@@ -172,7 +178,7 @@ def main():
             stats[:, 7] = float(up.n_columns)
             stats[:, 8] = counts.mean(dim=1)
             stats[:, 9] = counts[:, -1]
-            gather_stats(stats, world * S)
+            gather_stats(stats if backend == "nccl" else stats.cpu(), world * S)
         return up
 
     for _ in range(args.warmup):
@@ -192,7 +198,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        te = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
