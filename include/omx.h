@@ -431,6 +431,39 @@ int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block,
 int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz);
 
 
+/* ===================================================================== *
+ * DspBatcher — reference src/meter.rs:15-80, :145-166
+ * The caller of the processors: turns capture packets into the fixed block
+ * partition the per-block snapshots depend on (256 frames @ 48 kHz scaled by
+ * the sample rate, backlog chunks of up to 1024 frames, <= 2 s of silence
+ * replayed, format change never mixes generations).  Host-side integer logic;
+ * every emitted block is handed to `ingest` (VisualManager::ingest_samples,
+ * src/visuals/registry.rs:396-418), `reset` mirrors VisualManager::reset_audio.
+ * ===================================================================== */
+typedef struct omx_audio_format { /* reference src/dsp.rs:79-85 AudioFormat */
+    uint64_t generation;
+    float sample_rate;
+    uint32_t channels;
+    uint8_t positions[OMX_MAX_CHANNELS];
+} omx_audio_format;
+typedef void (*omx_ingest_fn)(void* user, const float* samples, uint64_t n_samples, const omx_audio_format* format);
+typedef void (*omx_reset_fn)(void* user);
+typedef struct omx_batcher omx_batcher;
+int omx_batcher_create(omx_batcher** out);                                     /* DspBatcher::new :33-38 */
+void omx_batcher_destroy(omx_batcher* b);
+/* DspBatcher::push :40-69 — returns the number of ingest calls made */
+uint64_t omx_batcher_push(omx_batcher* b, const float* samples, uint64_t n_samples, const omx_audio_format* format,
+                          omx_ingest_fn ingest, void* user);
+/* ingest_silence :145-166 — returns the number of ingest calls made (0 after a reset) */
+uint64_t omx_batcher_push_silence(omx_batcher* b, uint64_t frames, const omx_audio_format* format, omx_ingest_fn ingest,
+                                  omx_reset_fn reset, void* user);
+void omx_batcher_reset(omx_batcher* b, omx_reset_fn reset, void* user);        /* :71-74 */
+void omx_batcher_clear(omx_batcher* b);                                        /* :76-79 */
+/* pending samples (batcher.samples.len()); copies up to `cap` of them to dst when dst != NULL */
+uint64_t omx_batcher_pending(const omx_batcher* b, float* dst, uint64_t cap);
+/* 1 and *out filled when a format is latched (batcher.format), else 0 */
+int omx_batcher_format(const omx_batcher* b, omx_audio_format* out);
+
 /* ---- batched bank: S independent OscilloscopeProcessors, one workgroup per stream ---- */
 typedef struct omx_oscilloscope_bank omx_oscilloscope_bank;
 /* per (stream, block) result header; `produced` mirrors `process_block(..).is_some()`,

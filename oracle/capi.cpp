@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#include "batcher.hpp"
 #include "loudness.hpp"
 #include "oscilloscope.hpp"
 #include "primitives.hpp"
@@ -524,6 +525,65 @@ int omxo_kat_find_rising_zero_crossing(const float* samples, uint64_t n, uint64_
     const auto r = find_rising_zero_crossing(samples, (size_t)n, (size_t)lo, (size_t)hi, reversed != 0);
     if (!r) return 0;
     *index = *r;
+    return 1;
+}
+
+// ------------------------------------------------------------------ batcher (meter.rs)
+struct omxo_batcher {
+    DspBatcher b;
+};
+static AudioFormat fmt_from_c(const omx_audio_format* f) {
+    AudioFormat o;
+    o.channels = f->channels;
+    o.sample_rate = f->sample_rate;
+    o.generation = f->generation;
+    for (int i = 0; i < MAX_CH; ++i) o.positions[i] = f->positions[i];
+    return o;
+}
+static void fmt_to_c(const AudioFormat& f, omx_audio_format* o) {
+    o->generation = f.generation;
+    o->sample_rate = f.sample_rate;
+    o->channels = (uint32_t)f.channels;
+    for (int i = 0; i < MAX_CH; ++i) o->positions[i] = f.positions[i];
+}
+int omxo_batcher_create(omxo_batcher** out) {
+    *out = new omxo_batcher();
+    return OMX_NONE;
+}
+void omxo_batcher_destroy(omxo_batcher* b) { delete b; }
+uint64_t omxo_batcher_push(omxo_batcher* b, const float* samples, uint64_t n, const omx_audio_format* format, omx_ingest_fn ingest,
+                           void* user) {
+    return b->b.push(samples, (size_t)n, fmt_from_c(format), [&](const float* p, size_t len, const AudioFormat& f) {
+        omx_audio_format cf;
+        fmt_to_c(f, &cf);
+        if (ingest) ingest(user, p, len, &cf);
+    });
+}
+uint64_t omxo_batcher_push_silence(omxo_batcher* b, uint64_t frames, const omx_audio_format* format, omx_ingest_fn ingest,
+                                   omx_reset_fn reset, void* user) {
+    size_t count = 0;
+    const bool ok = b->b.push_silence(frames, fmt_from_c(format), [&](const float* p, size_t len, const AudioFormat& f) {
+        omx_audio_format cf;
+        fmt_to_c(f, &cf);
+        if (ingest) ingest(user, p, len, &cf);
+    }, &count);
+    if (!ok && reset) reset(user);
+    return count;
+}
+void omxo_batcher_reset(omxo_batcher* b, omx_reset_fn reset, void* user) {
+    b->b.clear();
+    if (reset) reset(user);
+}
+void omxo_batcher_clear(omxo_batcher* b) { b->b.clear(); }
+uint64_t omxo_batcher_pending(const omxo_batcher* b, float* dst, uint64_t cap) {
+    const auto& p = b->b.pending();
+    if (dst)
+        for (size_t i = 0; i < p.size() && i < cap; ++i) dst[i] = p[i];
+    return p.size();
+}
+int omxo_batcher_format(const omxo_batcher* b, omx_audio_format* out) {
+    if (!b->b.format()) return 0;
+    if (out) fmt_to_c(*b->b.format(), out);
     return 1;
 }
 
