@@ -432,6 +432,70 @@ int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz);
 
 
 /* ===================================================================== *
+ * Waveform — reference src/visuals/waveform/processor.rs
+ * ===================================================================== */
+
+/* reference :31-40 WaveformConfig */
+typedef struct omx_waveform_config {
+    float sample_rate;
+    float scroll_speed;
+    uint64_t max_columns;
+    uint32_t analyze_bands;
+    uint32_t track_history;
+} omx_waveform_config;
+
+/* reference :54-62 WaveColumn (11 floats) */
+typedef struct omx_wave_column {
+    float min;
+    float max;
+    float color_bands[3];
+    float rms_db[2][3];
+} omx_wave_column;
+
+/* reference :66-76 WaveformUpdate: `columns` = n_columns frames of 4 WaveColumns (Left, Right, Mid, Side) */
+typedef struct omx_waveform_update {
+    uint64_t n_columns;
+    const omx_wave_column* columns; /* [n_columns][4] */
+    uint32_t reset;
+    uint32_t preview_some;          /* preview.columns.is_some() */
+    float preview_progress;
+    uint32_t _pad;
+    omx_wave_column preview[4];
+} omx_waveform_update;
+
+typedef struct omx_waveform omx_waveform;
+void omx_waveform_config_default(omx_waveform_config* out);
+int omx_waveform_create(const omx_waveform_config* cfg, omx_waveform** out);            /* ::new :147-159 */
+void omx_waveform_destroy(omx_waveform* h);
+int omx_waveform_get_config(const omx_waveform* h, omx_waveform_config* out);           /* ::config :161-163 */
+int omx_waveform_update_config(omx_waveform* h, const omx_waveform_config* cfg);        /* :336-352 */
+int omx_waveform_reset_audio(omx_waveform* h);                                          /* :165-167 */
+int omx_waveform_prepare(omx_waveform* h);                                              /* :169-173 */
+int omx_waveform_process_block(omx_waveform* h, const omx_block* block, omx_waveform_update* out); /* :308-334 */
+
+typedef struct omx_waveform_bank omx_waveform_bank;
+/* One block per call for every stream.  d_columns: omx_wave_column [n_streams][n_columns][4] (already capped to the
+ * newest max_columns); d_preview: omx_wave_column [n_streams][4]. */
+typedef struct omx_waveform_bank_update {
+    uint64_t n_streams;
+    uint64_t n_columns;
+    const omx_wave_column* d_columns;
+    const omx_wave_column* d_preview;
+    uint32_t reset;
+    uint32_t preview_some;
+    float preview_progress;
+    uint32_t _pad;
+} omx_waveform_bank_update;
+int omx_waveform_bank_create(const omx_waveform_config* cfg, uint32_t n_streams, omx_waveform_bank** out);
+void omx_waveform_bank_destroy(omx_waveform_bank* b);
+int omx_waveform_bank_reset_audio(omx_waveform_bank* b);
+int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on_device, uint64_t frames,
+                              uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
+                              void* stream, omx_waveform_bank_update* out);
+int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns /* [n_columns][4] */,
+                            omx_wave_column* preview /* [4] or NULL */);
+
+/* ===================================================================== *
  * DspBatcher — reference src/meter.rs:15-80, :145-166
  * The caller of the processors: turns capture packets into the fixed block
  * partition the per-block snapshots depend on (256 frames @ 48 kHz scaled by

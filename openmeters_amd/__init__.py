@@ -12,7 +12,7 @@ import os
 
 from . import capi
 from .capi import (  # noqa: F401  (re-exported: the reference's config / snapshot vocabulary)
-    AudioBlock, LoudnessConfig, OscilloscopeConfig, SpectrogramConfig, SpectrumConfig, StereometerConfig,
+    AudioBlock, LoudnessConfig, OscilloscopeConfig, SpectrogramConfig, SpectrumConfig, StereometerConfig, WaveformConfig,
     OmxError,
 )
 

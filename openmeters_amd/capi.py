@@ -137,6 +137,26 @@ class COscilloscopeSnapshot(C.Structure):
                 ("samples_per_channel", C.c_uint64), ("n_samples", C.c_uint64), ("samples", _f32p)]
 
 
+class CWaveformConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_float), ("scroll_speed", C.c_float), ("max_columns", C.c_uint64),
+                ("analyze_bands", C.c_uint32), ("track_history", C.c_uint32)]
+
+
+class CWaveColumn(C.Structure):
+    _fields_ = [("min", C.c_float), ("max", C.c_float), ("color_bands", C.c_float * 3), ("rms_db", (C.c_float * 3) * 2)]
+
+
+class CWaveformUpdate(C.Structure):
+    _fields_ = [("n_columns", C.c_uint64), ("columns", C.POINTER(CWaveColumn)), ("reset", C.c_uint32),
+                ("preview_some", C.c_uint32), ("preview_progress", C.c_float), ("_pad", C.c_uint32),
+                ("preview", CWaveColumn * 4)]
+
+
+class CWaveformBankUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("n_columns", C.c_uint64), ("d_columns", C.c_void_p), ("d_preview", C.c_void_p),
+                ("reset", C.c_uint32), ("preview_some", C.c_uint32), ("preview_progress", C.c_float), ("_pad", C.c_uint32)]
+
+
 # ----------------------------------------------------------------------------- config dataclasses
 @dataclass
 class SpectrogramConfig:
@@ -233,7 +253,34 @@ class OscilloscopeConfig:
                                   c.channel_1, c.channel_2)
 
 
+@dataclass
+class WaveformConfig:
+    """reference src/visuals/waveform/processor.rs:31-40"""
+    sample_rate: float = DEFAULT_SAMPLE_RATE
+    scroll_speed: float = 300.0
+    max_columns: int = 8192
+    analyze_bands: bool = True
+    track_history: bool = False
+
+    def to_c(self) -> CWaveformConfig:
+        return CWaveformConfig(self.sample_rate, self.scroll_speed, self.max_columns, int(self.analyze_bands), int(self.track_history))
+
+    @staticmethod
+    def from_c(c: CWaveformConfig) -> "WaveformConfig":
+        return WaveformConfig(c.sample_rate, c.scroll_speed, c.max_columns, bool(c.analyze_bands), bool(c.track_history))
+
+
 # ----------------------------------------------------------------------------- snapshots
+@dataclass
+class WaveformUpdate:
+    """reference src/visuals/waveform/processor.rs:66-76; columns: float32 [n, 4 channels, 11] with the WaveColumn
+    fields flattened as (min, max, color_bands[3], rms_db[2][3])"""
+    reset: bool
+    columns: np.ndarray
+    preview_progress: float
+    preview: Optional[np.ndarray]  # [4, 11] or None
+
+
 @dataclass
 class SpectrogramUpdate:
     """reference src/visuals/spectrogram/processor.rs:160-168; columns are numpy arrays:
@@ -509,6 +556,39 @@ class StereometerProcessor(_Handle):
             pts.append(np.ctypeslib.as_array(out.points[b], shape=(n * 2,)).copy().reshape(n, 2) if n
                        else np.zeros((0, 2), np.float32))
         return StereometerSnapshot(pts, np.array(out.correlations[:], np.float32))
+
+
+class WaveformProcessor(_Handle):
+    """reference src/visuals/waveform/processor.rs:135-353"""
+    _family = "waveform"
+
+    def __init__(self, api: Api, config: WaveformConfig):
+        super().__init__(api, config.to_c())
+
+    def config(self) -> WaveformConfig:
+        c = CWaveformConfig()
+        self._call("get_config", C.byref(c), argtypes=[C.c_void_p])
+        return WaveformConfig.from_c(c)
+
+    def update_config(self, config: WaveformConfig):
+        c = config.to_c()
+        self._call("update_config", C.byref(c), argtypes=[C.c_void_p])
+
+    def prepare(self):
+        self._call("prepare")
+
+    def process_block(self, block: AudioBlock) -> Optional[WaveformUpdate]:
+        cb = block.to_c()
+        out = CWaveformUpdate()
+        if self._call("process_block", C.byref(cb), C.byref(out), argtypes=[C.c_void_p, C.c_void_p]) == NONE:
+            return None
+        n = int(out.n_columns)
+        cols = (np.ctypeslib.as_array(C.cast(out.columns, _f32p), shape=(n * 4 * 11,)).copy().reshape(n, 4, 11) if n
+                else np.zeros((0, 4, 11), np.float32))
+        prev = None
+        if out.preview_some:
+            prev = np.frombuffer(bytes(out.preview), dtype=np.float32).reshape(4, 11).copy()
+        return WaveformUpdate(bool(out.reset), cols, out.preview_progress, prev)
 
 
 class OscilloscopeProcessor(_Handle):

@@ -7,6 +7,7 @@
 #include "loudness.hpp"
 #include "stereometer.hpp"
 #include "oscilloscope.hpp"
+#include "waveform.hpp"
 
 namespace omx {
 const std::string& last_error();
@@ -64,6 +65,16 @@ struct omx_oscilloscope {
 struct omx_oscilloscope_bank {
     OscilloscopeBank impl;
     omx_oscilloscope_bank(const omx_oscilloscope_config& c, uint32_t n) : impl(c, n) {}
+};
+
+struct omx_waveform {
+    WaveformBank bank;
+    std::vector<omx_wave_column> columns;
+    explicit omx_waveform(const omx_waveform_config& c) : bank(c, 1) {}
+};
+struct omx_waveform_bank {
+    WaveformBank impl;
+    omx_waveform_bank(const omx_waveform_config& c, uint32_t n) : impl(c, n) {}
 };
 
 extern "C" {
@@ -541,6 +552,95 @@ int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index,
         if (samples) rc = b->impl.fetch_samples(stream_index, samples, 2 * kScopeTarget, b->impl.last_stream());
         return rc;
     });
+}
+
+// ------------------------------------------------------------------ waveform
+void omx_waveform_config_default(omx_waveform_config* out) {
+    if (out) waveform_config_default(out);
+}
+int omx_waveform_create(const omx_waveform_config* cfg, omx_waveform** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_waveform(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_waveform_destroy(omx_waveform* h) { delete h; }
+int omx_waveform_get_config(const omx_waveform* h, omx_waveform_config* out) {
+    if (!h || !out) return OMX_ERR_INVALID;
+    *out = h->bank.config();
+    return OMX_NONE;
+}
+int omx_waveform_update_config(omx_waveform* h, const omx_waveform_config* cfg) {
+    if (!h || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.update_config(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+int omx_waveform_reset_audio(omx_waveform* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_waveform_prepare(omx_waveform* h) {
+    if (!h) return OMX_ERR_INVALID;
+    return guarded([&] {
+        h->bank.prepare(nullptr);
+        return (int)OMX_NONE;
+    });
+}
+int omx_waveform_process_block(omx_waveform* h, const omx_block* block, omx_waveform_update* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    return guarded([&] {
+        const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
+        if (block->n_samples < channels) return (int)OMX_NONE;
+        omx_waveform_bank_update bu;
+        const int rc = h->bank.process(block->samples, false, block->n_samples / channels, channels, block->sample_rate,
+                                       block->positions, nullptr, &bu);
+        if (rc != OMX_PRODUCED) return rc;
+        h->columns.resize((size_t)bu.n_columns * 4);
+        std::memset(out, 0, sizeof(*out));
+        const int frc = h->bank.fetch(0, h->columns.data(), out->preview, nullptr);
+        if (frc < 0) return frc;
+        out->n_columns = bu.n_columns;
+        out->columns = h->columns.data();
+        out->reset = bu.reset;
+        out->preview_some = bu.preview_some;
+        out->preview_progress = bu.preview_progress;
+        return (int)OMX_PRODUCED;
+    });
+}
+int omx_waveform_bank_create(const omx_waveform_config* cfg, uint32_t n_streams, omx_waveform_bank** out) {
+    if (!cfg || !out || n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_waveform_bank(*cfg, n_streams);
+        return (int)OMX_NONE;
+    });
+}
+void omx_waveform_bank_destroy(omx_waveform_bank* b) { delete b; }
+int omx_waveform_bank_reset_audio(omx_waveform_bank* b) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on_device, uint64_t frames, uint32_t channels,
+                              float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                              omx_waveform_bank_update* out) {
+    if (!b || !pcm || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process(pcm, pcm_on_device != 0, frames, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out);
+    });
+}
+int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview) {
+    if (!b) return OMX_ERR_INVALID;
+    return guarded([&] { return b->impl.fetch(stream_index, columns, preview, b->impl.last_stream()); });
 }
 
 }  // extern "C"

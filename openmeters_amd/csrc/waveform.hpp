@@ -1,0 +1,72 @@
+// WaveformBank: S independent WaveformProcessors (reference src/visuals/waveform/processor.rs:135-353).
+// 16 lanes per stream: lane = channel * 3 + band for channel in {Left, Right, Mid, Side}, band in {low, mid, high}
+// (12 live lanes); band-0 lanes also carry the channel's min/max column state machine.
+#pragma once
+#include "stereometer.hpp"  // BiquadCoef, make_biquad
+
+namespace omx {
+
+struct WaveLaneState {
+    float za[2][2], zb[2][2];      // biquad states [L/R][z0,z1]: stage A (HP_low, mid band only), stage B
+    double color[4];               // CompensatedPair of the colour window: sum0, sum1, cor0, cor1
+    double hist[2][4];             // history windows (fast, slow)
+    // min/max column state of the channel (band-0 lanes): current = Option<(min, max, Option<last>)>, last_sample
+    float cur_min, cur_max, cur_last, last_sample;
+    uint32_t cur_some, cur_has_last, last_valid, _pad;
+};
+
+struct WaveformArgs {
+    const float* pcm;  // [n_streams][frames][channels]
+    uint64_t frames;
+    uint32_t n_streams;
+    AudioFormatArgs fmt;
+    uint32_t analyze, track_history;
+    BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;  // ThreeBand<Biquad,false> (dsp.rs:473-504), 200 / 2000 Hz
+    double step;          // (scroll_speed / sample_rate).clamp(0, 1) (:253-254)
+    double column_phase;  // at the start of the call
+    uint64_t pushes;      // tracker pushes since the trackers were created
+    uint32_t color_len, slow_len;
+    float* color_ring;    // [color_len][n_streams * 16]
+    float* hist_ring;     // [slow_len][n_streams * 16]
+    WaveLaneState* state; // [n_streams * 16]
+    uint64_t n_emit;      // columns emitted by this call (host-simulated phase)
+    uint64_t first_kept;  // n_emit - min(n_emit, max_columns)
+    omx_wave_column* columns;  // [n_streams][n_emit - first_kept][4]
+    omx_wave_column* preview;  // [n_streams][4]
+    uint32_t write_preview;
+};
+void launch_waveform(const WaveformArgs& a, hipStream_t stream);
+
+void waveform_config_default(omx_waveform_config* c);
+
+class WaveformBank {
+public:
+    WaveformBank(const omx_waveform_config& cfg, uint32_t n_streams);
+    const omx_waveform_config& config() const { return cfg_; }
+    void update_config(const omx_waveform_config& cfg);
+    void reset_audio() { rebuild(); }
+    void prepare(hipStream_t stream);
+    int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
+                const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_bank_update* out);
+    int fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream);
+    hipStream_t last_stream() const { return last_stream_; }
+    uint64_t last_columns() const { return last_cols_; }
+
+private:
+    void rebuild();
+    void reset_trackers();
+
+    omx_waveform_config cfg_{};
+    uint32_t n_streams_;
+    uint32_t source_channels_ = 2;
+    bool analysis_ = false, reset_pending_ = true, clear_minmax_ = true, clear_trackers_ = true;
+    double column_phase_ = 0.0;
+    uint64_t pushes_ = 0, last_cols_ = 0;
+    uint32_t color_len_ = 0, slow_len_ = 0;
+    DeviceBuffer<float> color_ring_, hist_ring_, staging_;
+    DeviceBuffer<WaveLaneState> state_;
+    DeviceBuffer<omx_wave_column> columns_, preview_;
+    hipStream_t last_stream_ = nullptr;
+};
+
+}  // namespace omx

@@ -17,6 +17,7 @@
 #include "spectrogram.hpp"
 #include "spectrum.hpp"
 #include "stereometer.hpp"
+#include "waveform.hpp"
 
 using namespace omxo;
 
@@ -526,6 +527,75 @@ int omxo_kat_find_rising_zero_crossing(const float* samples, uint64_t n, uint64_
     if (!r) return 0;
     *index = *r;
     return 1;
+}
+
+// ------------------------------------------------------------------ waveform
+struct omxo_waveform {
+    WaveformProcessor p;
+    WaveformProcessor::Update last;
+    explicit omxo_waveform(WaveformConfig c) : p(c) {}
+};
+static WaveformConfig wf_from_c(const omx_waveform_config& c) {
+    WaveformConfig o;
+    o.sample_rate = c.sample_rate;
+    o.scroll_speed = c.scroll_speed;
+    o.max_columns = (size_t)c.max_columns;
+    o.analyze_bands = c.analyze_bands != 0;
+    o.track_history = c.track_history != 0;
+    return o;
+}
+static void wf_to_c(const WaveformConfig& c, omx_waveform_config* o) {
+    o->sample_rate = c.sample_rate;
+    o->scroll_speed = c.scroll_speed;
+    o->max_columns = c.max_columns;
+    o->analyze_bands = c.analyze_bands;
+    o->track_history = c.track_history;
+}
+void omxo_waveform_config_default(omx_waveform_config* out) { wf_to_c(WaveformConfig(), out); }
+int omxo_waveform_create(const omx_waveform_config* cfg, omxo_waveform** out) {
+    if (!cfg || !out) return OMX_ERR_INVALID;
+    *out = new omxo_waveform(wf_from_c(*cfg));
+    return OMX_NONE;
+}
+void omxo_waveform_destroy(omxo_waveform* h) { delete h; }
+int omxo_waveform_get_config(const omxo_waveform* h, omx_waveform_config* out) {
+    wf_to_c(h->p.config(), out);
+    return OMX_NONE;
+}
+int omxo_waveform_update_config(omxo_waveform* h, const omx_waveform_config* cfg) {
+    h->p.update_config(wf_from_c(*cfg));
+    return OMX_NONE;
+}
+int omxo_waveform_reset_audio(omxo_waveform* h) {
+    h->p.reset_audio();
+    return OMX_NONE;
+}
+int omxo_waveform_prepare(omxo_waveform* h) {
+    h->p.prepare();
+    return OMX_NONE;
+}
+int omxo_waveform_process_block(omxo_waveform* h, const omx_block* block, omx_waveform_update* out) {
+    if (!h || !block || !out) return OMX_ERR_INVALID;
+    if (!h->p.process_block(to_block(block), h->last)) return OMX_NONE;
+    std::memset(out, 0, sizeof(*out));
+    out->n_columns = h->last.columns.size() / WF_CHANNELS;
+    out->columns = h->last.columns.data();
+    out->reset = h->last.reset ? 1 : 0;
+    out->preview_some = h->last.preview_some ? 1 : 0;
+    out->preview_progress = h->last.preview_progress;
+    for (int c = 0; c < WF_CHANNELS; ++c) out->preview[c] = h->last.preview[c];
+    return OMX_PRODUCED;
+}
+int omxo_waveform_has_band_analysis(const omxo_waveform* h) { return h->p.has_band_analysis() ? 1 : 0; }
+double omxo_waveform_column_phase(const omxo_waveform* h) { return h->p.column_phase(); }
+// ThreeBand<Biquad,false> over mono samples -> out[n][3] (reference test :410-436)
+void omxo_kat_threeband_12db(float sample_rate, const float* x, uint64_t n, float* out) {
+    BandFilter f(sample_rate, BAND_SPLITS_HZ[0], BAND_SPLITS_HZ[1]);
+    for (uint64_t i = 0; i < n; ++i) {
+        float in[1] = {x[i]}, bands[3][1];
+        f.process(in, bands);
+        for (int b = 0; b < 3; ++b) out[3 * i + b] = bands[b][0];
+    }
 }
 
 // ------------------------------------------------------------------ batcher (meter.rs)

@@ -204,3 +204,28 @@ def test_oscilloscope_zero_crossing_mode_matches_oracle(omx, oracle):
         if g is not None:
             assert (g.channels, g.samples_per_channel) == (w.channels, w.samples_per_channel)
             assert np.abs(g.samples - w.samples).max() <= 1e-6
+
+
+def test_waveform_blocks_match_oracle(omx, oracle):
+    """min/max bit-exact, colour bands / RMS history within 1e-5 relative (f32 biquads are evaluated in
+    the reference's order without fusion; the KBN sums are sequential in both)."""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=512, analyze_bands=True, track_history=True)
+    pcm = cfg4_pcm(7, 256 * 200)
+    pcm[3000:3003, 0] = np.nan  # non-finite samples break column continuity (:275-291)
+    a, b = WaveformProcessor(omx, cfg), WaveformProcessor(oracle, cfg)
+    total = 0
+    for k in range(0, pcm.shape[0], 256):
+        g = a.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        w = b.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        assert g.reset == w.reset and g.columns.shape == w.columns.shape and g.preview_progress == w.preview_progress
+        total += len(g.columns)
+        assert np.array_equal(g.columns[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32))  # min / max
+        if len(g.columns):
+            assert np.abs(g.columns[:, :, 2:5] - w.columns[:, :, 2:5]).max() <= 1e-6 * max(1.0, np.abs(w.columns[:, :, 2:5]).max())
+            assert np.abs(g.columns[:, :, 5:] - w.columns[:, :, 5:]).max() <= 2e-4  # dB
+        assert (g.preview is None) == (w.preview is None)
+        if g.preview is not None:
+            assert np.array_equal(g.preview[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32))
+            assert np.abs(g.preview[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-6
+    assert total in (319, 320)  # 0.00625 is not exact in f64: the reference phase accumulator lands one column short
