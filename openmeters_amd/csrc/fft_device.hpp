@@ -74,30 +74,35 @@ __device__ __forceinline__ void dft4_rot2(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
     a3 = sub_rot<INV>(t1, d);
 }
 
-// In-register 16-point DFT (4x4 Cooley-Tukey).  On return X[k] sits in v[DFT16_OUT(k)].
+// In-register 16-point DFT (4x4 Cooley-Tukey) on v[OFF .. OFF+15] of an N-element register array (constant
+// indices only, so the array stays in VGPRs).  On return X[k] sits in v[OFF + DFT16_OUT(k)].
 #define DFT16_OUT(k) (4 * ((k)&3) + ((k) >> 2))
-template <bool INV>
-__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+template <bool INV, int N, int OFF>
+__device__ __forceinline__ void dft16_at(v2f (&v)[N]) {
     constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
     constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
     constexpr float H = 0.70710678118654752440f;   // sqrt(1/2)
 #pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[OFF + n2], v[OFF + 4 + n2], v[OFF + 8 + n2], v[OFF + 12 + n2]);
     // v[4*k1 + n2] *= w16^(n2*k1), w16 = exp(-+ 2*pi*i/16)
     const v2f w1{C1, -S1}, w3{S1, -C1}, w9{-C1, S1}, hh{H, H}, nh{-H, -H};
-    v[5] = twmul<INV>(v[5], w1);                    // k1=1,n2=1
-    v[6] = add_rot<INV>(v[6], v[6]) * hh;           // k1=1,n2=2 : w^2 = H(1 -+ i)
-    v[7] = twmul<INV>(v[7], w3);                    // k1=1,n2=3
-    v[9] = add_rot<INV>(v[9], v[9]) * hh;           // k1=2,n2=1 : w^2
+    v[OFF + 5] = twmul<INV>(v[OFF + 5], w1);                      // k1=1,n2=1
+    v[OFF + 6] = add_rot<INV>(v[OFF + 6], v[OFF + 6]) * hh;       // k1=1,n2=2 : w^2 = H(1 -+ i)
+    v[OFF + 7] = twmul<INV>(v[OFF + 7], w3);                      // k1=1,n2=3
+    v[OFF + 9] = add_rot<INV>(v[OFF + 9], v[OFF + 9]) * hh;       // k1=2,n2=1 : w^2
     // k1=2,n2=2 : w^4 = -+ i, folded into dft4_rot2 below
-    v[11] = sub_rot<INV>(v[11], v[11]) * nh;        // k1=2,n2=3 : w^6 = -H(1 +- i)
-    v[13] = twmul<INV>(v[13], w3);                  // k1=3,n2=1
-    v[14] = sub_rot<INV>(v[14], v[14]) * nh;        // k1=3,n2=2 : w^6
-    v[15] = twmul<INV>(v[15], w9);                  // k1=3,n2=3
-    dft4<INV>(v[0], v[1], v[2], v[3]);
-    dft4<INV>(v[4], v[5], v[6], v[7]);
-    dft4_rot2<INV>(v[8], v[9], v[10], v[11]);
-    dft4<INV>(v[12], v[13], v[14], v[15]);
+    v[OFF + 11] = sub_rot<INV>(v[OFF + 11], v[OFF + 11]) * nh;    // k1=2,n2=3 : w^6 = -H(1 +- i)
+    v[OFF + 13] = twmul<INV>(v[OFF + 13], w3);                    // k1=3,n2=1
+    v[OFF + 14] = sub_rot<INV>(v[OFF + 14], v[OFF + 14]) * nh;    // k1=3,n2=2 : w^6
+    v[OFF + 15] = twmul<INV>(v[OFF + 15], w9);                    // k1=3,n2=3
+    dft4<INV>(v[OFF + 0], v[OFF + 1], v[OFF + 2], v[OFF + 3]);
+    dft4<INV>(v[OFF + 4], v[OFF + 5], v[OFF + 6], v[OFF + 7]);
+    dft4_rot2<INV>(v[OFF + 8], v[OFF + 9], v[OFF + 10], v[OFF + 11]);
+    dft4<INV>(v[OFF + 12], v[OFF + 13], v[OFF + 14], v[OFF + 15]);
+}
+template <bool INV>
+__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+    dft16_at<INV, 16, 0>(v);
 }
 
 // ------------------------------------------------------------------------------------------------

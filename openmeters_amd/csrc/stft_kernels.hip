@@ -13,6 +13,7 @@
 #include "stft_kernels.hpp"
 
 #include "fft_device.hpp"
+#include "fft_wave_device.hpp"
 
 namespace omx {
 
@@ -426,6 +427,143 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     }
 }
 
+// ================================================================================================
+// K2W: the same fused pipeline with ONE WAVEFRONT PER FRAME (4 frames per 256-thread workgroup, no s_barrier).
+// Each lane keeps 64 complex values; a 4096-point FFT is two radix-64 passes with one wave-private LDS exchange
+// (half the LDS traffic of the radix-16 form).  The inverse transform is conj(FFT(conj(.))).  Registers instead of
+// occupancy: ~400 VGPRs, one wave per SIMD, latency hidden by the straight-line instruction stream itself.
+// ================================================================================================
+constexpr uint32_t K2W_FRAMES_PER_WG = 4;
+
+__global__ __launch_bounds__(256, 1) void stft_reassigned_4096_wave_kernel(StftFastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v2f* buf = reinterpret_cast<v2f*>(smem_raw) + wave * FFT4096W_LDS;
+    const uint32_t chunks = (a.n_cols + K2W_FRAMES_PER_WG - 1) / K2W_FRAMES_PER_WG;
+    uint32_t s, chunk;
+    if (!block_to_stream_column(a.n_streams, chunks, s, chunk)) return;
+    const uint32_t col = chunk * K2W_FRAMES_PER_WG + (uint32_t)wave;
+    if (col >= a.n_cols) return;  // no workgroup barriers anywhere: a wave may leave early
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint64_t mask = a.cap - 1;
+    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+    if (a.last_nonzero[s] < (long long)p0) {  // silent fast path (:307-316)
+        if (lane == 0) *count_out = 0;
+        return;
+    }
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+
+    // ---- 1. packed real FFT of the 8192-sample window ----------------------------------------------
+    v2f v[64];
+    if ((p0 & 1ull) == 0) {
+#pragma unroll
+        for (int t = 0; t < 64; ++t) v[t] = *reinterpret_cast<const v2f*>(ring + ((p0 + 2u * (uint32_t)(lane + 64 * t)) & mask));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            const uint64_t q = p0 + 2u * (uint32_t)(lane + 64 * t);
+            v[t] = v2f{ring[q & mask], ring[(q + 1) & mask]};
+        }
+    }
+    fft4096_wave(v, buf, lane, a.tw4096);  // Zf[lane + 64 t] = v[DFT64_OUT(t)]
+
+    // ---- 2. Hilbert: Z'[k] from Zf[k], Zf[N-k] (see the radix-16 kernel for the derivation); inverse = conj FFT conj
+#pragma unroll
+    for (int t = 0; t < 64; ++t) buf[lane + 65 * t] = v[DFT64_OUT(t)];  // natural order, pad64(lane + 64 t)
+    const float z0x = __shfl(v[DFT64_OUT(0)].x, 0), z0y = __shfl(v[DFT64_OUT(0)].y, 0);
+    const float half_x0 = (z0x + z0y) * 0.5f, half_xn = (z0x - z0y) * 0.5f;  // X[0]/2, X[4096]/2
+    __builtin_amdgcn_wave_barrier();
+    // own Zf[k] is re-read from LDS in natural order so the 64 result registers can be reused for Z'
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = 16 * c + i;
+            const unsigned k = (unsigned)(lane + 64 * t);
+            const v2f z = buf[lane + 65 * t];
+            const unsigned kr = (4096u - k) & 4095u;
+            const v2f zr = buf[kr + (kr >> 6)];
+            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
+            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+            const v2f w = a.tw8192[k];
+            const v2f y = cmulc(sum, w) - cmul(dif, w);
+            v[t] = (k == 0) ? v2f{0.0f, 0.0f} : v2f{y.x, -y.y};  // conj(Z'[k])
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fft4096_wave(v, buf, lane, a.tw4096);  // conj of it = (Im a[2m], Im a[2m+1]), m = lane + 64 t
+
+    // ---- 3. redistribute the imaginary parts: imag[t] = Im analytic[2048 + lane + 64 t] ---------------
+    float* fbuf = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int t = 16; t < 48; ++t) {
+        const v2f o = v[DFT64_OUT(t)];
+        *reinterpret_cast<v2f*>(fbuf + 2 * (lane + 64 * (t - 16))) = v2f{o.x, -o.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+    float imag[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) imag[t] = fbuf[lane + 64 * t];
+    __builtin_amdgcn_wave_barrier();
+    const float parity = (lane & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of the lane
+    const uint64_t q0 = p0 + 2048u + (unsigned)lane;
+
+    // ---- three windowed FFTs; lane keeps bins lane + 64 t (t < 32) and lane 0 also bin 2048 ------------
+    v2f bb[33], bd[33];
+#pragma nounroll
+    for (int q = 0; q < 3; ++q) {
+        const float* win = q == 0 ? a.window : (q == 1 ? a.dwindow : a.twindow);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int t = 16 * c + i;
+                const float xr = ring[(q0 + 64u * (unsigned)t) & mask];
+                const float w = win[lane + 64 * t];
+                const float re = 4096.0f * xr - half_x0 + parity;
+                v[t] = v2f{re * w, imag[t] * w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fft4096_wave(v, buf, lane, a.tw4096);
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < 33; ++t) bb[t] = v[DFT64_OUT(t)];
+        } else if (q == 1) {
+#pragma unroll
+            for (int t = 0; t < 33; ++t) bd[t] = v[DFT64_OUT(t)];
+        }
+    }
+
+    // ---- 4. reassignment + ordered compaction (wave-local: bins ascend with t, then with the lane) ------
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+#pragma unroll
+    for (int t = 0; t < 33; ++t) {
+        const uint32_t bin = (uint32_t)(lane + 64 * t);
+        omx_spectrogram_point p;
+        bool keep = false;
+        if (t < 32 || lane == 0) keep = reassign_bin(bin, bb[t], bd[t], v[DFT64_OUT(t)], a.bin_norm[bin], rc, p);
+        const unsigned long long m = __ballot(keep);
+        if (keep) out[running + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+        running += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) *count_out = running;
+}
+
+static void launch_k2_wave(const StftFastArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)K2W_FRAMES_PER_WG * FFT4096W_LDS * sizeof(v2f);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_wave_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const uint32_t chunks = (a.n_cols + K2W_FRAMES_PER_WG - 1) / K2W_FRAMES_PER_WG;
+    hipLaunchKernelGGL(stft_reassigned_4096_wave_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
+}
+
 template <class V>
 static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)((V::ONEBUF ? FFT4096_LDS + 2048 : 2 * FFT4096_LDS) + 256) * sizeof(v2f) + 9 * 4 * sizeof(uint32_t) +
@@ -436,8 +574,16 @@ static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    // OMX_K2_LDS_PAD (bytes): occupancy experiment only — a larger LDS request lowers the workgroups per CU
+    static const size_t pad = [] {
+        const char* e = getenv("OMX_K2_LDS_PAD");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    if (pad)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel<V>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
     const uint32_t chunks = (a.n_cols + V::COLS_PER_WG - 1) / V::COLS_PER_WG;
-    hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds + pad, stream, a);
 }
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
@@ -456,6 +602,7 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 2: launch_k2_variant<K2Variant<1, true, false, true, false>>(a, stream); break;
         case 3: launch_k2_variant<K2Variant<1, false, true, true, false>>(a, stream); break;
         case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
+        case 20: launch_k2_wave(a, stream); break;  // one wavefront per frame
         default: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;
     }
 }

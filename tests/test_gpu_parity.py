@@ -164,3 +164,18 @@ def test_spectrum_bank_all_hops_equal_per_block_snapshots(omx, oracle):
             got = bank.fetch(s, h, 2049)
             for wt in range(2):
                 check_trace(got[0, wt], snaps[h].traces[0][wt])
+
+
+@pytest.mark.parametrize("variant", ["100", "3", "13", "20"])
+def test_k2_alternate_builds_stay_correct(variant):
+    """The A/B builds of the fused kernel (OMX_K2_VARIANT: first form, register twiddles, single-buffer form,
+    wave-per-frame form) must compute the same columns; run in a subprocess because the variant is latched at first use."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMX_K2_VARIANT=variant)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k",
+                        "fast_kernel_equals or partition or silent_and_mixed"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert "3 passed" in r.stdout
