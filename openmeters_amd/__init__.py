@@ -29,6 +29,14 @@ def api() -> capi.Api:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  openmeters_amd has no CPU fallback.")
+        # PyTorch wheels bundle their own libamdhip64; a process must not end up with two HIP runtimes (the second one
+        # sees no device).  Loading torch first makes libomx_hip.so's NEEDED libamdhip64.so.7 resolve to the copy that is
+        # already mapped, whatever order the caller imports things in.  Hosts without torch (the Rust binding) have one
+        # runtime anyway.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _API = capi.Api(LIB_PATH, "omx_")
     return _API
 

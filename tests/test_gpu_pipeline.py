@@ -1,0 +1,40 @@
+"""cfg5 shape on one GPU: the full pipeline helper feeds three banks from the same device PCM and assembles the per-stream
+summary rows (what K8 all-gathers); every row is checked against the CPU oracle run stream by stream."""
+import numpy as np
+import pytest
+
+from openmeters_amd import capi
+from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
+                                 StereometerConfig, StereometerProcessor)
+from golden_inputs import cfg2_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_pipeline_summary_rows_match_oracle(omx, oracle):
+    import torch
+    from openmeters_amd.pipeline import FullPipeline, gather_stats
+    dev = torch.device("cuda", 0)
+    S, frames = 6, 256 * 48
+    pcm = np.stack([cfg2_pcm(s, frames) for s in range(S)])
+    pcm[:, :, 1] *= -1.0  # anti-phase right channel: rho < 0
+    d_pcm = torch.from_numpy(pcm).to(dev).contiguous()
+    pipe = FullPipeline(omx, S)
+    up, snaps, st, n_blocks = pipe.step(d_pcm.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    table = gather_stats(pipe.stats(torch, dev, up, snaps, st, n_blocks), S).cpu().numpy()
+    assert table.shape == (S, 10)
+    for s in range(S):
+        lp = LoudnessProcessor(oracle, LoudnessConfig())
+        sp = StereometerProcessor(oracle, StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02,
+                                                            target_sample_count=2000))
+        for k in range(0, frames, 256):
+            blk = AudioBlock(pcm[s, k:k + 256].reshape(-1), 2, 48000.0)
+            ls, ss = lp.process_block(blk), sp.process_block(blk)
+        sg = SpectrogramProcessor(oracle, SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192)).process_block(
+            AudioBlock(pcm[s].reshape(-1), 2, 48000.0))
+        counts = [len(c) for c in sg.new_columns]
+        assert abs(table[s, 0] - ls.momentary_loudness) < 1e-4 and abs(table[s, 1] - ls.short_term_loudness) < 1e-4
+        assert abs(table[s, 2] - ls.true_peak_db[:2].max()) < 1e-4
+        assert np.abs(table[s, 3:7] - ss.correlations).max() < 1e-6 and table[s, 3] < -0.99
+        assert table[s, 7] == len(counts) and abs(table[s, 8] - np.mean(counts)) < 0.5 and abs(table[s, 9] - counts[-1]) <= 4
