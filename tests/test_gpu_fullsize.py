@@ -1,0 +1,156 @@
+"""BASELINE.json's full single-GPU sizes (cfg2 64 streams, cfg3 1024 x 8 ch, cfg4 256 streams), checked through
+size-independent properties — the CPU oracle cannot replay these volumes in seconds, so it only spot-checks.
+
+  shift invariance   stream k carries stream 0's PCM advanced by k hops  =>  column c of stream k is BIT-identical to
+                     column c + k of stream 0 (same samples, same arithmetic, different ring offsets / workgroups / XCDs)
+  partition          one call == the same PCM fed in several calls (frame indexing, ring wrap, carried state), bit-exact
+  replication        identical streams at different bank indices produce identical bits
+  gain               PCM x 0.5 (exact in f32/f64) moves every LUFS / dB field by -6.0206 dB and leaves rho unchanged
+"""
+import numpy as np
+import pytest
+
+from openmeters_amd import banks, capi
+from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, OscilloscopeConfig, OscilloscopeProcessor,
+                                 SpectrogramConfig, SpectrogramProcessor, StereometerConfig, StereometerProcessor)
+from golden_inputs import cfg2_pcm, cfg3_pcm, cfg4_pcm
+from parity import reassigned_column_metrics
+
+pytestmark = pytest.mark.gpu
+FS = 48000.0
+
+
+class View:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def dview(torch, ptr, shape, typestr="<i4"):
+    return torch.as_tensor(View(ptr, shape, typestr), device="cuda:0")
+
+
+def spectrogram_outputs(torch, up):
+    S, cols, stride = int(up.n_streams), int(up.n_columns), int(up.column_stride)
+    counts = dview(torch, up.d_counts, (S, cols)).clone()
+    points = dview(torch, up.d_points, (S, cols, stride, 3)).clone()  # f32 bits as i32: NaN-safe bit comparison
+    valid = torch.arange(stride, device="cuda:0")[None, None, :] < counts[..., None]
+    points[~valid] = 0
+    return counts, points
+
+
+def test_cfg2_full_size_shift_partition_and_oracle_spot_checks(omx, oracle):
+    import torch
+    S, cols, hop = 64, 1024, 256
+    frames = 8192 + hop * (cols - 1)                       # 65 536 STFT frames per call: the bench launch
+    base = cfg2_pcm(5, frames + hop * (S - 1))
+    pcm = np.stack([base[k * hop:k * hop + frames] for k in range(S)])
+    cfg = SpectrogramConfig(fft_size=4096, hop_size=hop, use_reassignment=True, history_length=8192)
+    d_pcm = torch.from_numpy(pcm).to("cuda:0")
+    pos = capi.positions_fallback(2)
+
+    one = banks.SpectrogramBank(omx, cfg, S)
+    up = one.process_device(d_pcm.data_ptr(), frames, 2, FS, pos)
+    assert up.n_columns == cols and up.column_stride == 2049   # ready = (pending - 8192) / hop + 1
+    counts, points = spectrogram_outputs(torch, up)
+    assert int(counts.min()) > 1900                          # sweep + noise: nearly every bin is above the floor
+    for k in (1, 2, 7, 8, 9, 31, 63):                        # across XCDs (k % 8) and far apart
+        assert torch.equal(counts[k, :cols - k], counts[0, k:]), k
+        assert torch.equal(points[k, :cols - k], points[0, k:]), k
+
+    # partition: three uneven calls (the second one is shorter than a window) on a fresh bank
+    parts = banks.SpectrogramBank(omx, cfg, S)
+    got_c, got_p, at = [], [], 0
+    for n in (8192 + hop * 300 + 77, 1000, frames - (8192 + hop * 300 + 77) - 1000):
+        chunk = d_pcm[:, at:at + n].contiguous()
+        u = parts.process_device(chunk.data_ptr(), n, 2, FS, pos)
+        at += n
+        if u is not None:
+            c, p = spectrogram_outputs(torch, u)
+            got_c.append(c)
+            got_p.append(p)
+    assert torch.equal(torch.cat(got_c, 1), counts)
+    assert torch.equal(torch.cat(got_p, 1), points)
+
+    # oracle spot checks: column c of stream k is the first column of a fresh processor fed from frame (k + c) * hop
+    for k, c in ((0, 0), (17, 400), (63, 1023)):
+        at = (k + c) * hop
+        want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(base[at:at + 8192].reshape(-1), 2, FS)).new_columns[0]
+        got = one.fetch_column(k, c, capi.COLUMN_REASSIGNED, 2049)
+        m = reassigned_column_metrics(got, want, FS, hop)
+        assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, m
+
+
+def test_cfg3_full_size_replication_gain_and_oracle_spot_checks(omx, oracle):
+    import torch
+    S, C, blocks = 1024, 8, 80                               # 20 480 frames: the 400 ms momentary window is full
+    frames = 256 * blocks
+    distinct = np.stack([cfg3_pcm(s, frames, C) for s in range(16)])
+    d_pcm = torch.from_numpy(distinct).to("cuda:0").repeat(S // 16, 1, 1).contiguous()   # stream s = distinct[s % 16]
+    bank = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    ptr = bank.process_device(d_pcm.data_ptr(), 256, blocks, C, FS, capi.SURROUND)
+    snaps = dview(torch, ptr, (S, blocks, 30)).clone()
+    assert torch.equal(snaps[:16].repeat(S // 16, 1, 1), snaps)
+
+    half = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    d_half = (d_pcm * 0.5).contiguous()
+    hptr = half.process_device(d_half.data_ptr(), 256, blocks, C, FS, capi.SURROUND)
+    a = dview(torch, ptr, (S, blocks, 30), "<f4")[:, -1]
+    b = dview(torch, hptr, (S, blocks, 30), "<f4")[:, -1]
+    step = 10.0 * np.log10(4.0)
+    for lo, hi in ((0, 2), (2, 2 + C), (10, 10 + C), (18, 18 + C)):   # LUFS pair, rms fast, rms slow, true peak
+        d = (a[:, lo:hi] - b[:, lo:hi]).cpu().numpy()
+        assert np.abs(d - step).max() < 2e-4, (lo, np.abs(d - step).max())
+
+    for s in (0, 9, 1023):
+        p = LoudnessProcessor(oracle, LoudnessConfig())
+        for k in range(0, frames, 256):
+            w = p.process_block(AudioBlock(distinct[s % 16, k:k + 256].reshape(-1), C, FS, capi.SURROUND))
+        g = bank.fetch(s, blocks - 1)
+        assert abs(g.momentary_loudness - w.momentary_loudness) <= 1e-4 and abs(g.short_term_loudness - w.short_term_loudness) <= 1e-4
+        for f in ("rms_fast_db", "rms_slow_db", "true_peak_db"):
+            assert np.abs(getattr(g, f) - getattr(w, f)).max() <= 1e-4, f
+
+
+def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
+    import torch
+    S, blocks = 256, 60
+    frames = 256 * blocks
+    distinct = np.stack([cfg4_pcm(s, frames) for s in range(32)])
+    d_pcm = torch.from_numpy(distinct).to("cuda:0").repeat(S // 32, 1, 1).contiguous()
+    pos = capi.positions_fallback(2)
+    scfg = StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=2000)
+    ocfg = OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2, trigger_source=capi.CH_LEFT,
+                              channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT)
+    st, sc = banks.StereometerBank(omx, scfg, S), banks.OscilloscopeBank(omx, ocfg, S)
+    us = st.process_device(d_pcm.data_ptr(), 256, blocks, 2, FS, pos)
+    uo = sc.process_device(d_pcm.data_ptr(), 256, blocks, 2, FS, pos)
+    corr = dview(torch, us.d_correlations, (S, blocks, 4)).clone()
+    hdr = dview(torch, uo.d_headers, (S, blocks, 8)).clone()
+    smp = dview(torch, uo.d_samples, (S, 2, int(uo.sample_stride))).clone()
+    assert torch.equal(corr[:32].repeat(S // 32, 1, 1), corr)
+    assert torch.equal(hdr[:32].repeat(S // 32, 1, 1), hdr)
+    n = int(hdr[0, -1, 4])                                   # samples_per_channel of the newest snapshot
+    assert torch.equal(smp[:32, :, :n].repeat(S // 32, 1, 1), smp[:, :, :n])
+    assert int(hdr[:, -1, 5].sum()) == S                     # every stream is locked after 320 ms of a periodic tone
+
+    # gain leaves rho untouched (EMA of products scales numerator and denominator alike; x0.5 is exact)
+    st2 = banks.StereometerBank(omx, scfg, S)
+    d_half = (d_pcm * 0.5).contiguous()
+    us2 = st2.process_device(d_half.data_ptr(), 256, blocks, 2, FS, pos)
+    c1 = dview(torch, us.d_correlations, (S, blocks, 4), "<f4")
+    c2 = dview(torch, us2.d_correlations, (S, blocks, 4), "<f4")
+    assert float((c1 - c2).abs().max()) <= 1e-6
+
+    for s in (0, 21, 255):
+        sp, op = StereometerProcessor(oracle, scfg), OscilloscopeProcessor(oracle, ocfg)
+        for k in range(0, frames, 256):
+            blk = AudioBlock(distinct[s % 32, k:k + 256].reshape(-1), 2, FS)
+            ws, wo = sp.process_block(blk), op.process_block(blk)
+        got, produced = st.fetch(s, blocks - 1)
+        assert produced and np.abs(got - ws.correlations).max() <= 1e-6
+        h, samples = sc.fetch(s, blocks - 1, with_samples=True)
+        assert bool(h.locked) == (op.last_cycle_rate() is not None) and h.samples_per_channel == wo.samples_per_channel
+        assert abs(h.period - FS / op.last_cycle_rate()) <= 1e-4 * h.period
+        flat = np.concatenate([samples[c, :h.samples_per_channel] for c in range(h.channels)])
+        assert np.abs(flat - wo.samples).max() <= 2e-3
