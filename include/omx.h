@@ -562,6 +562,55 @@ int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, in
 int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
                                 omx_oscilloscope_block_header* header, float* samples);
 
+/* ===================================================================== *
+ * State-side summary reductions — the small per-snapshot
+ * reductions the reference's visual *states* run on every snapshot and that
+ * feed labels / peak markers; batched here so that per-stream summary rows
+ * can be produced without shipping spectra or snapshots to the host.
+ * ===================================================================== */
+
+/* peak_bin + interpolated_peak, reference src/visuals/spectrum/state.rs:320-356.
+ * `found` = 0 when no interior bin inside [min_f, max_f] has a finite level. */
+typedef struct omx_spectrum_peak {
+    uint32_t found;
+    uint32_t bin;
+    float freq_hz;   /* (center + parabolic offset * bin_hz).max(0) */
+    float level_db;  /* interpolated level, never below the centre bin */
+} omx_spectrum_peak;
+/* rows of dB levels: row r = db[r * row_stride .. + n_bins); one omx_spectrum_peak per row.
+ * on_device = 0: bins/db/out are host pointers (synchronous); 1: device pointers, enqueued on `stream`. */
+int omx_spectrum_peaks(const float* bins, const float* db, int on_device, uint64_t n_bins, uint64_t n_rows,
+                       uint64_t row_stride, float min_f, float max_f, void* stream, omx_spectrum_peak* out);
+
+/* MeterMode, reference src/visuals.rs:89-95 */
+enum {
+    OMX_METER_LUFS_SHORT_TERM = 0,
+    OMX_METER_LUFS_MOMENTARY = 1,
+    OMX_METER_RMS_FAST = 2,
+    OMX_METER_RMS_SLOW = 3,
+    OMX_METER_TRUE_PEAK = 4
+};
+/* PeakHold, reference src/visuals/loudness/state.rs:36-60 (2 s hold, then 60 dB/s); the wall clock
+ * (`Instant`) is replaced by a caller-supplied time in seconds. */
+typedef struct omx_peak_hold {
+    float db;
+    uint32_t _pad;
+    double decay_from;
+} omx_peak_hold;
+/* one applied snapshot: visible_values() (:178-184, channel_side aggregation :222-246) and the three
+ * peak holds after update_peak_holds (:211-217; values clamped to DB_RANGE = [-60, 4]). */
+typedef struct omx_meter_row {
+    float values[3]; /* left bar, right bar (left_mode aggregated per side), right_mode value */
+    float peaks[3];
+} omx_meter_row;
+/* PeakHold::new(DB_RANGE.0, now) for `n` holds (LoudnessState::new / reset_audio / set_modes) */
+int omx_peak_holds_reset(omx_peak_hold* holds, int on_device, uint64_t n, double now, void* stream);
+/* snapshots [n_streams][n_blocks] applied in order, block k at time t0 + k * dt;
+ * holds [n_streams][3] in/out; rows [n_streams][n_blocks] out. */
+int omx_loudness_meters(const omx_loudness_snapshot* snapshots, int on_device, uint64_t n_streams,
+                        uint64_t n_blocks, uint32_t left_mode, uint32_t right_mode, double t0, double dt,
+                        omx_peak_hold* holds, void* stream, omx_meter_row* rows);
+
 #ifdef __cplusplus
 }
 #endif

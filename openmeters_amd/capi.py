@@ -620,3 +620,53 @@ class OscilloscopeProcessor(_Handle):
         n = int(out.n_samples)
         samples = np.ctypeslib.as_array(out.samples, shape=(n,)).copy() if n else np.zeros((0,), np.float32)
         return OscilloscopeSnapshot(out.epoch, out.channels, list(out.slots), samples, out.samples_per_channel)
+
+
+# --------------------------------------------------------------------------- state-side summary reductions
+METER_LUFS_SHORT_TERM, METER_LUFS_MOMENTARY, METER_RMS_FAST, METER_RMS_SLOW, METER_TRUE_PEAK = range(5)
+SPECTRUM_PEAK_DTYPE = np.dtype([("found", "<u4"), ("bin", "<u4"), ("freq_hz", "<f4"), ("level_db", "<f4")])
+PEAK_HOLD_DTYPE = np.dtype([("db", "<f4"), ("_pad", "<u4"), ("decay_from", "<f8")])
+METER_ROW_DTYPE = np.dtype([("values", "<f4", (3,)), ("peaks", "<f4", (3,))])
+
+
+def spectrum_peaks(api: Api, bins: np.ndarray, db: np.ndarray, min_f: float, max_f: float) -> np.ndarray:
+    """peak_bin + interpolated_peak (reference src/visuals/spectrum/state.rs:320-356) for every row of `db` [rows, bins]."""
+    bins = np.ascontiguousarray(bins, np.float32)
+    db = np.ascontiguousarray(np.atleast_2d(db), np.float32)
+    out = np.zeros(db.shape[0], SPECTRUM_PEAK_DTYPE)
+    f = api.fn("spectrum_peaks", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p])
+    api.check(f(bins.ctypes.data, db.ctypes.data, 0, bins.shape[0], db.shape[0], db.shape[1], min_f, max_f, None, out.ctypes.data))
+    return out
+
+
+def peak_holds_reset(api: Api, n: int, now: float) -> np.ndarray:
+    """PeakHold::new(DB_RANGE.0, now) x n (reference src/visuals/loudness/state.rs:42-47)."""
+    holds = np.zeros(n, PEAK_HOLD_DTYPE)
+    api.check(api.fn("peak_holds_reset", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_void_p])(
+        holds.ctypes.data, 0, n, now, None))
+    return holds
+
+
+def loudness_snapshots_to_c(snapshots: Sequence["LoudnessSnapshot"]):
+    arr = (CLoudnessSnapshot * len(snapshots))()
+    for c, s in zip(arr, snapshots):
+        c.short_term_loudness, c.momentary_loudness = s.short_term_loudness, s.momentary_loudness
+        for i in range(MAX_CHANNELS):
+            c.rms_fast_db[i], c.rms_slow_db[i], c.true_peak_db[i] = s.rms_fast_db[i], s.rms_slow_db[i], s.true_peak_db[i]
+            c.positions[i] = s.positions[i]
+        c.channel_count = s.channel_count
+    return arr
+
+
+def loudness_meters(api: Api, snapshots: Sequence["LoudnessSnapshot"], n_streams: int, left_mode: int, right_mode: int,
+                    t0: float, dt: float, holds: np.ndarray) -> np.ndarray:
+    """visible_values + update_peak_holds (reference src/visuals/loudness/state.rs:178-217) for snapshots laid out
+    [n_streams][n_blocks]; `holds` ([n_streams * 3] PEAK_HOLD_DTYPE) is updated in place; returns rows [n_streams, n_blocks]."""
+    n_blocks = len(snapshots) // n_streams
+    arr = loudness_snapshots_to_c(snapshots)
+    rows = np.zeros((n_streams, n_blocks), METER_ROW_DTYPE)
+    f = api.fn("loudness_meters", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double,
+                                            C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])
+    api.check(f(C.byref(arr), 0, n_streams, n_blocks, left_mode, right_mode, t0, dt, holds.ctypes.data, None, rows.ctypes.data))
+    return rows

@@ -1,0 +1,178 @@
+// K9: state-side summary reductions over device-resident snapshots.
+//   spectrum_peaks_kernel   one wavefront per dB row: arg-max over the interior bins inside [min_f, max_f]
+//                           (f32::total_cmp order, the LAST maximum wins like Iterator::max_by), then the
+//                           parabolic interpolation of spectrum/state.rs:326-356.  HBM-bound: 4 B per bin.
+//   loudness_meters_kernel  one lane per stream: visible_values + the three PeakHold recurrences
+//                           (loudness/state.rs:36-60, 121-184, 211-246) over the blocks of a call.
+#include "summary.hpp"
+
+namespace omx {
+
+namespace {
+constexpr float PEAK_EPSILON = 1e-6f;                   // spectrum/state.rs:20
+constexpr float METER_DB_LO = -60.0f, METER_DB_HI = 4.0f;  // loudness/render.rs:11
+constexpr double PEAK_HOLD_SECONDS = 2.0;               // loudness/state.rs:20
+constexpr float PEAK_DECAY_DB_PER_SEC = 60.0f;          // :21
+
+__device__ __forceinline__ bool finite_f(float v) { return fabsf(v) <= 3.4028234663852886e38f; }  // false for NaN / inf
+
+// (total_cmp key, index) packed so that an unsigned 64-bit max picks the larger level and, among equal levels,
+// the larger index
+__device__ __forceinline__ unsigned long long peak_key(float v, uint32_t i) {
+    int32_t b = __float_as_int(v);
+    b ^= (int32_t)((uint32_t)(b >> 31) >> 1);
+    return ((unsigned long long)((uint32_t)b ^ 0x80000000u) << 32) | (unsigned long long)i;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void spectrum_peaks_kernel(const float* __restrict__ bins, const float* __restrict__ db,
+                                                            uint64_t n_bins, uint64_t n_rows, uint64_t row_stride, float min_f,
+                                                            float max_f, omx_spectrum_peak* __restrict__ out) {
+    const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* d = db + row * row_stride;
+    unsigned long long best = 0;  // no finite level maps to key 0 with index 0 (index 0 is never a candidate)
+    for (uint64_t i = 1 + (uint64_t)lane; i + 1 < n_bins; i += 64) {
+        const float f = bins[i], v = d[i];
+        if (f >= min_f && f <= max_f && finite_f(v)) {
+            const unsigned long long k = peak_key(v, (uint32_t)i);
+            best = k > best ? k : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane != 0) return;
+    omx_spectrum_peak p{0u, 0u, 0.0f, 0.0f};
+    const uint32_t bin = (uint32_t)(best & 0xffffffffull);
+    if (best != 0 && n_bins >= 3) {
+        const float bin_hz = bins[1] - bins[0];
+        const float center_freq = bins[bin], center = d[bin];
+        if (finite_f(bin_hz) && bin_hz > 0.0f && finite_f(center_freq)) {
+            const float left = d[bin - 1], right = d[bin + 1];
+            float offset = 0.0f;
+            if (finite_f(left) && finite_f(right)) {
+                const float denom = left - 2.0f * center + right;
+                if (denom < -PEAK_EPSILON) {
+                    offset = 0.5f * (left - right) / denom;
+                    offset = offset < -0.5f ? -0.5f : (offset > 0.5f ? 0.5f : offset);
+                }
+            }
+            float level = center;
+            if (offset != 0.0f) {
+                level = center - 0.25f * (left - right) * offset;
+                level = level > center ? level : center;
+            }
+            const float f = center_freq + offset * bin_hz;
+            p.found = 1u;
+            p.bin = bin;
+            p.freq_hz = f > 0.0f ? f : 0.0f;
+            p.level_db = level;
+        }
+    }
+    out[row] = p;
+}
+
+void launch_spectrum_peaks(const float* bins, const float* db, uint64_t n_bins, uint64_t n_rows, uint64_t row_stride, float min_f,
+                           float max_f, omx_spectrum_peak* out, hipStream_t stream) {
+    if (n_rows == 0) return;
+    hipLaunchKernelGGL(spectrum_peaks_kernel, dim3((uint32_t)((n_rows + 3) / 4)), dim3(256), 0, stream, bins, db, n_bins, n_rows,
+                       row_stride, min_f, max_f, out);
+}
+
+__global__ void peak_holds_reset_kernel(omx_peak_hold* holds, uint64_t n, double now) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) holds[i] = omx_peak_hold{METER_DB_LO, 0u, now};
+}
+void launch_peak_holds_reset(omx_peak_hold* holds, uint64_t n, double now, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(peak_holds_reset_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, holds, n, now);
+}
+
+namespace {
+enum { SIDE_LEFT = 0, SIDE_RIGHT = 1, SIDE_BOTH = 2, SIDE_NEITHER = 3 };
+__device__ __forceinline__ uint32_t fallback_position(uint32_t total, uint32_t index) {  // dsp.rs:36-47
+    if (index >= total) return OMX_POS_UNKNOWN;
+    if (total == 1) return OMX_POS_MONO;
+    if (total == 4 && index >= 2) return index == 2 ? OMX_POS_REAR_LEFT : OMX_POS_REAR_RIGHT;
+    if (total == 5 && index >= 3) return index == 3 ? OMX_POS_REAR_LEFT : OMX_POS_REAR_RIGHT;
+    return index;  // SURROUND order == enum order
+}
+__device__ __forceinline__ int channel_side(uint32_t position, uint32_t index, uint32_t total) {  // loudness/state.rs:222-246
+    if (position >= OMX_POS_AUX0 || position == OMX_POS_UNKNOWN) position = fallback_position(total, index);
+    switch (position) {
+        case OMX_POS_FRONT_LEFT: case OMX_POS_REAR_LEFT: case OMX_POS_SIDE_LEFT: return SIDE_LEFT;
+        case OMX_POS_FRONT_RIGHT: case OMX_POS_REAR_RIGHT: case OMX_POS_SIDE_RIGHT: return SIDE_RIGHT;
+        case OMX_POS_FRONT_CENTER: case OMX_POS_MONO: return SIDE_BOTH;
+        default: return SIDE_NEITHER;
+    }
+}
+__device__ __forceinline__ float meter_value(const omx_loudness_snapshot& s, uint32_t mode, uint32_t ch) {  // :121-131
+    switch (mode) {
+        case OMX_METER_LUFS_SHORT_TERM: return s.short_term_loudness;
+        case OMX_METER_LUFS_MOMENTARY: return s.momentary_loudness;
+        case OMX_METER_RMS_FAST: return s.rms_fast_db[ch];
+        case OMX_METER_RMS_SLOW: return s.rms_slow_db[ch];
+        default: return s.true_peak_db[ch];
+    }
+}
+__device__ __forceinline__ float aggregate(const omx_loudness_snapshot& s, uint32_t mode, int wanted) {  // :153-169
+    if (mode <= OMX_METER_LUFS_MOMENTARY) return meter_value(s, mode, 0);
+    float acc = METER_DB_LO;
+    const uint32_t n = s.channel_count < OMX_MAX_CHANNELS ? s.channel_count : OMX_MAX_CHANNELS;
+    for (uint32_t ch = 0; ch < n; ++ch) {
+        const int side = channel_side(s.positions[ch], ch, n);
+        if (side != SIDE_BOTH && side != wanted) continue;
+        acc = fmaxf(acc, meter_value(s, mode, ch));
+    }
+    return acc;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void loudness_meters_kernel(const omx_loudness_snapshot* __restrict__ snapshots, uint64_t n_streams,
+                                                            uint64_t n_blocks, uint32_t left_mode, uint32_t right_mode, double t0,
+                                                            double dt, omx_peak_hold* __restrict__ holds,
+                                                            omx_meter_row* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_streams) return;
+    omx_peak_hold h[3] = {holds[3 * s], holds[3 * s + 1], holds[3 * s + 2]};
+    for (uint64_t k = 0; k < n_blocks; ++k) {
+        const omx_loudness_snapshot snap = snapshots[s * n_blocks + k];
+        const double now = t0 + (double)k * dt;
+        omx_meter_row r;
+        r.values[0] = aggregate(snap, left_mode, SIDE_LEFT);
+        r.values[1] = aggregate(snap, left_mode, SIDE_RIGHT);
+        r.values[2] = meter_value(snap, right_mode, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float v = r.values[i];
+            v = v < METER_DB_LO ? METER_DB_LO : (v > METER_DB_HI ? METER_DB_HI : v);
+            if (v > h[i].db) {  // PeakHold::update :49-59
+                h[i].db = v;
+                h[i].decay_from = now + PEAK_HOLD_SECONDS;
+            } else if (now > h[i].decay_from) {
+                const float decay_dt = (float)(now - h[i].decay_from);
+                const float d = h[i].db - PEAK_DECAY_DB_PER_SEC * decay_dt;
+                h[i].db = d > v ? d : v;
+                h[i].decay_from = now;
+            }
+            r.peaks[i] = h[i].db;
+        }
+        rows[s * n_blocks + k] = r;
+    }
+    holds[3 * s] = h[0];
+    holds[3 * s + 1] = h[1];
+    holds[3 * s + 2] = h[2];
+}
+
+void launch_loudness_meters(const omx_loudness_snapshot* snapshots, uint64_t n_streams, uint64_t n_blocks, uint32_t left_mode,
+                            uint32_t right_mode, double t0, double dt, omx_peak_hold* holds, omx_meter_row* rows, hipStream_t stream) {
+    if (n_streams == 0) return;
+    hipLaunchKernelGGL(loudness_meters_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, snapshots, n_streams,
+                       n_blocks, left_mode, right_mode, t0, dt, holds, rows);
+}
+
+}  // namespace omx

@@ -29,6 +29,8 @@ class FullPipeline:
         self.spectrogram = banks.SpectrogramBank(api, capi.SpectrogramConfig(sample_rate=sample_rate, fft_size=4096, hop_size=256,
                                                                              history_length=8192, use_reassignment=True), n_streams)
         self.loudness = banks.LoudnessBank(api, capi.LoudnessConfig(sample_rate=sample_rate), n_streams, channels)
+        self._holds = None      # device bytes: omx_peak_hold [n_streams][3], carried across steps (K9)
+        self._clock = 0.0       # sample clock of the next applied snapshot, seconds
         self.stereometer = banks.StereometerBank(api, capi.StereometerConfig(sample_rate=sample_rate, analyze_bands=True,
                                                                              correlation_window=0.05, segment_duration=0.02,
                                                                              target_sample_count=2000), n_streams)
@@ -42,7 +44,8 @@ class FullPipeline:
         return up, snaps, st, frames // 256
 
     def stats(self, torch, device, up, snaps_ptr, st, n_blocks):
-        """[n_streams, 10] float32 summary rows in sharding.STATS_COLUMNS order."""
+        """[n_streams, len(STATS_COLUMNS)] float32 summary rows in sharding.STATS_COLUMNS order."""
+        import ctypes as C
         S = self.n_streams
         out = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
         if snaps_ptr:
@@ -50,6 +53,20 @@ class FullPipeline:
             out[:, 0] = snap[:, 1]                     # momentary LUFS
             out[:, 1] = snap[:, 0]                     # short-term LUFS
             out[:, 2] = snap[:, 18:18 + self.channels].max(dim=1).values  # max true peak dBTP
+            # K9: true-peak bars + their 2 s / 60 dB/s peak holds on the sample clock (loudness/state.rs:36-60, 178-217)
+            api, hs = self.api, torch.cuda.current_stream().cuda_stream
+            if self._holds is None:
+                self._holds = torch.empty(S * 3 * 16, device=device, dtype=torch.uint8)
+                api.check(api.fn("peak_holds_reset", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_void_p])(
+                    self._holds.data_ptr(), 1, S * 3, self._clock, hs))
+            rows = torch.empty((S, n_blocks, 6), device=device, dtype=torch.float32)
+            dt = 256.0 / self.sample_rate
+            api.check(api.fn("loudness_meters", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double,
+                                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])(
+                snaps_ptr, 1, S, n_blocks, capi.METER_TRUE_PEAK, capi.METER_LUFS_SHORT_TERM, self._clock, dt, self._holds.data_ptr(), hs,
+                rows.data_ptr()))
+            self._clock += n_blocks * dt
+            out[:, 10:12] = rows[:, -1, 3:5]
         corr = torch.as_tensor(_DeviceView(st.d_correlations, (S, n_blocks, 4), "<f4"), device=device)[:, -1]
         out[:, 3:7] = corr                             # rho full / low / mid / high
         if up is not None:

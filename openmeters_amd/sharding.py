@@ -1,14 +1,14 @@
 """Multi-GPU layer: independent capture streams shard embarrassingly across ranks (one process per GPU,
 `torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  There is no
 data-path collective — every stream is an independent recurrence / STFT — only a small
-per-stream summary table is all-gathered once per reporting epoch (K8 `stats_gather`, 40 B/stream:
+per-stream summary table is all-gathered once per reporting epoch (K8 `stats_gather`, 48 B/stream:
 latency-bound, so the RCCL default algorithm is used and the call stays out of the per-hop loop)."""
 from __future__ import annotations
 
 from typing import Tuple
 
 STATS_COLUMNS = ("momentary_lufs", "short_term_lufs", "max_true_peak_db", "rho_full", "rho_low", "rho_mid", "rho_high",
-                 "frames_emitted", "mean_points_per_frame", "last_frame_points")
+                 "frames_emitted", "mean_points_per_frame", "last_frame_points", "held_peak_left_db", "held_peak_right_db")
 
 
 def shard_streams(total_streams: int, rank: int, world_size: int) -> Tuple[int, int]:

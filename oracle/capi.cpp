@@ -17,6 +17,7 @@
 #include "spectrogram.hpp"
 #include "spectrum.hpp"
 #include "stereometer.hpp"
+#include "summary.hpp"
 #include "waveform.hpp"
 
 using namespace omxo;
@@ -759,6 +760,27 @@ double omxo_bench_spectrogram(const omx_spectrogram_config* cfg, const float* pc
     for (auto c : cols) total += c;
     if (columns_out) *columns_out = total;
     return secs;
+}
+
+// ---- state-side summary reductions (summary.hpp) ----
+int omxo_spectrum_peaks(const float* bins, const float* db, int, uint64_t n_bins, uint64_t n_rows, uint64_t row_stride,
+                        float min_f, float max_f, void*, omx_spectrum_peak* out) {
+    if (!bins || !db || !out) return OMX_ERR_INVALID;
+    for (uint64_t r = 0; r < n_rows; ++r) out[r] = spectrum_peak(bins, db + r * row_stride, (size_t)n_bins, min_f, max_f);
+    return OMX_PRODUCED;
+}
+int omxo_peak_holds_reset(omx_peak_hold* holds, int, uint64_t n, double now, void*) {
+    if (!holds) return OMX_ERR_INVALID;
+    for (uint64_t i = 0; i < n; ++i) holds[i] = omx_peak_hold{kMeterDbLo, 0, now};
+    return OMX_NONE;
+}
+int omxo_loudness_meters(const omx_loudness_snapshot* snapshots, int, uint64_t n_streams, uint64_t n_blocks, uint32_t left_mode,
+                         uint32_t right_mode, double t0, double dt, omx_peak_hold* holds, void*, omx_meter_row* rows) {
+    if (!snapshots || !holds || !rows || left_mode > OMX_METER_TRUE_PEAK || right_mode > OMX_METER_TRUE_PEAK) return OMX_ERR_INVALID;
+    for (uint64_t s = 0; s < n_streams; ++s)
+        for (uint64_t k = 0; k < n_blocks; ++k)
+            rows[s * n_blocks + k] = apply_meter_snapshot(snapshots[s * n_blocks + k], left_mode, right_mode, t0 + (double)k * dt, holds + 3 * s);
+    return OMX_PRODUCED;
 }
 
 }  // extern "C"

@@ -229,3 +229,55 @@ def test_waveform_blocks_match_oracle(omx, oracle):
             assert np.array_equal(g.preview[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32))
             assert np.abs(g.preview[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-6
     assert total in (319, 320)  # 0.00625 is not exact in f64: the reference phase accumulator lands one column short
+
+
+def test_summary_reductions_on_device_resident_bank_outputs(omx, oracle):
+    """spectrum peaks straight off the spectrum bank's d_traces, loudness bars + peak holds straight off
+    the loudness bank's d_snapshots, compared with the oracle's reductions of the same (fetched) data."""
+    import ctypes as C
+    import torch
+    from openmeters_amd.capi import SpectrumConfig
+    from golden_inputs import cfg2_pcm
+    S, frames = 5, 4096 + 256 * 15
+    pcm = np.stack([cfg2_pcm(s, frames + 30000)[30000:] for s in range(S)])
+    bank = banks.SpectrumBank(omx, SpectrumConfig(fft_size=4096, hop_size=256), S, emit_all_hops=True)
+    up = bank.process_host(pcm, 2, FS)
+    bins, hops = int(up.bins), int(up.n_hops_out)
+    assert hops == 16
+    rows = S * hops
+    d_out = torch.empty((rows, 4), device="cuda:0", dtype=torch.int32)
+    f = omx.fn("spectrum_peaks", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p])
+    fbins = np.arange(bins, dtype=np.float32) * np.float32(FS / 4096)
+    for weighting in (0, 1):   # trace 0, A-weighted / raw: row r starts at d_traces + (r * 4 + weighting) * bins
+        omx.check(f(up.d_frequency_bins, up.d_traces + weighting * bins * 4, 1, bins, rows, 4 * bins, 20.0, float(fbins[-1]), None,
+                    d_out.data_ptr()))
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(capi.SPECTRUM_PEAK_DTYPE).reshape(S, hops)
+        for s in range(S):
+            traces = np.stack([bank.fetch(s, h, bins)[0, weighting] for h in range(hops)])
+            want = capi.spectrum_peaks(oracle, fbins, traces, 20.0, float(fbins[-1]))
+            assert np.array_equal(got[s]["found"], want["found"]) and np.array_equal(got[s]["bin"], want["bin"])
+            assert np.array_equal(got[s]["freq_hz"], want["freq_hz"]) and np.array_equal(got[s]["level_db"], want["level_db"])
+            assert got[s]["found"].all() and (got[s]["freq_hz"] > 20.0).all()
+
+    blocks = 40
+    x = np.stack([cfg3_pcm(s, 256 * blocks, 6) * np.float32(1.0 if s % 2 else 0.05) for s in range(S)])
+    x[:, 256 * 8:] *= np.float32(0.01)      # level drop: the holds keep the early peak
+    lb = banks.LoudnessBank(omx, LoudnessConfig(), S, 6)
+    ptr = lb.process_host(x, 256, 6, FS, capi.positions_fallback(6))
+    holds = torch.empty(S * 3 * 16, device="cuda:0", dtype=torch.uint8)
+    omx.check(omx.fn("peak_holds_reset", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_void_p])(holds.data_ptr(), 1, S * 3, 0.0, None))
+    d_rows = torch.empty((S, blocks, 6), device="cuda:0", dtype=torch.float32)
+    g = omx.fn("loudness_meters", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p])
+    dt = 0.1                                 # coarse clock so that the 2 s hold expires inside the call
+    omx.check(g(ptr, 1, S, blocks, capi.METER_TRUE_PEAK, capi.METER_RMS_FAST, 0.0, dt, holds.data_ptr(), None, d_rows.data_ptr()))
+    torch.cuda.synchronize()
+    got = d_rows.cpu().numpy()
+    snaps = [lb.fetch(s, b) for s in range(S) for b in range(blocks)]
+    oh = capi.peak_holds_reset(oracle, S * 3, 0.0)
+    want = capi.loudness_meters(oracle, snaps, S, capi.METER_TRUE_PEAK, capi.METER_RMS_FAST, 0.0, dt, oh)
+    assert np.array_equal(got[:, :, :3], want["values"]) and np.abs(got[:, :, 3:] - want["peaks"]).max() <= 1e-5
+    assert np.array_equal(holds.cpu().numpy().view(capi.PEAK_HOLD_DTYPE)["db"], oh["db"])
+    assert (want["peaks"][:, 20, 0] > want["values"][:, 20, 0] + 10.0).all() and (want["peaks"][:, -1, 0] < want["peaks"][:, 20, 0]).all()

@@ -23,14 +23,19 @@ def test_full_pipeline_summary_rows_match_oracle(omx, oracle):
     up, snaps, st, n_blocks = pipe.step(d_pcm.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     table = gather_stats(pipe.stats(torch, dev, up, snaps, st, n_blocks), S).cpu().numpy()
-    assert table.shape == (S, 10)
+    assert table.shape == (S, 12)
     for s in range(S):
+        snaps = []
         lp = LoudnessProcessor(oracle, LoudnessConfig())
         sp = StereometerProcessor(oracle, StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02,
                                                             target_sample_count=2000))
         for k in range(0, frames, 256):
             blk = AudioBlock(pcm[s, k:k + 256].reshape(-1), 2, 48000.0)
             ls, ss = lp.process_block(blk), sp.process_block(blk)
+            snaps.append(ls)
+        holds = capi.peak_holds_reset(oracle, 3, 0.0)
+        rows = capi.loudness_meters(oracle, snaps, 1, capi.METER_TRUE_PEAK, capi.METER_LUFS_SHORT_TERM, 0.0, 256.0 / 48000.0, holds)
+        assert np.abs(table[s, 10:12] - rows[0, -1]["peaks"][:2]).max() < 1e-4 and table[s, 10] > -20.0
         sg = SpectrogramProcessor(oracle, SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192)).process_block(
             AudioBlock(pcm[s].reshape(-1), 2, 48000.0))
         counts = [len(c) for c in sg.new_columns]
