@@ -215,6 +215,9 @@ enum {
     OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
     OMX_OPT_FORCE_GENERIC = 2  /* value != 0: route through the generic any-size kernels (A/B checks) */
 };
+/* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the OMX_K2_VARIANT=7 build
+ * (setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store) */
+int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset);
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *

@@ -179,6 +179,16 @@ int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, ui
         return (int)OMX_NONE;
     });
 }
+int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
+    if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        unsigned long long c[K2_PHASES];
+        k2_phase_cycles(c, reset != 0);
+        for (int i = 0; i < K2_PHASES; ++i) out[i] = c[i];
+        return (int)K2_PHASES;
+    });
+}
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value) {
     if (!b) return OMX_ERR_INVALID;
     switch (option) {

@@ -266,7 +266,8 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
     const float latency_hops = (float)center_offset * inv_hop;
 
     timer_.begin(stream);
-    const bool fast = fast4096_ && reassign && !force_generic_;
+    // the fused kernel indexes the ring with 32-bit offsets
+    const bool fast = fast4096_ && reassign && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30);
     if (fast) {
         StftFastArgs fa{};
         fa.ring = ring_.ptr;

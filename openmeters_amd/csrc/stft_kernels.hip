@@ -175,8 +175,12 @@ __device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, fl
 // ================================================================================================
 // Compile-time switches of the fused kernel (A/B-tested on MI355X; see DESIGN.md §4 and profiles/).
 template <uint32_t COLS, bool TW2_LDS_, bool TW3_REGS_, bool DUAL_, bool PINGPONG_, bool ONEBUF_ = false, int MINW = 2,
-          bool RECOMPUTE_S_ = false>
+          bool RECOMPUTE_S_ = false, bool TWIN_CALC_ = false, bool PHASES_ = false,
+          bool EARLY_ = false>
 struct K2Variant {
+    static constexpr bool EARLY = EARLY_;          // table / ring loads issued one transform ahead of their use (needs DUAL)
+    static constexpr bool PHASES = PHASES_;        // tuning build: thread 0 accumulates shader-clock cycles per phase
+    static constexpr bool TWIN_CALC = TWIN_CALC_;  // t*w rebuilt from w in registers (:601-608) instead of a third table
     static constexpr bool RECOMPUTE_S = RECOMPUTE_S_;  // rebuild the analytic slice per windowed FFT instead of holding it
     static constexpr bool ONEBUF = ONEBUF_;        // one 34 KiB FFT buffer + 16 KiB imag[] (53 KiB -> 3 workgroups per CU)
     static constexpr int MIN_WAVES = MINW;         // __launch_bounds__ waves per SIMD
@@ -186,6 +190,9 @@ struct K2Variant {
     static constexpr bool DUAL = DUAL_;            // window and derivative-window FFTs run together
     static constexpr bool PINGPONG = PINGPONG_;    // single transforms alternate between the two LDS buffers
 };
+
+// tuning only (K2Variant::PHASES): cycles spent by thread 0 of every workgroup between phase marks, barrier waits included
+__device__ unsigned long long g_k2_phase_cycles[K2_PHASES];
 
 template <class V>
 __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel(StftFastArgs a) {
@@ -201,8 +208,12 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     uint32_t s, chunk;
     if (!block_to_stream_column(a.n_streams, chunks, s, chunk)) return;
     const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;  // unsigned 32-bit indices let global accesses use the SGPR-base + VGPR-offset form
     const float* ring = a.ring + (uint64_t)s * a.cap;
     const uint64_t mask = a.cap - 1;
+    const uint32_t mask32 = (uint32_t)mask;  // cap <= 2^30 (checked on the host): ring offsets fit 32 bits
+    const uint32_t bytemask = mask32 << 2;   // byte offsets as uint32: SGPR base + VGPR offset addressing
+    const char* ring_bytes = reinterpret_cast<const char*>(ring);
     const long long last_nonzero = a.last_nonzero[s];
     const int lane = j & 63, wave = j >> 6;
     const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
@@ -214,13 +225,24 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     tw.tw2 = V::TW2_LDS ? tw2_lds : a.tw256;
     if constexpr (V::TW3_REGS) {
 #pragma unroll
-        for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[(unsigned)j * (unsigned)t];
+        for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
     }
     if constexpr (V::TW2_LDS) {
-        tw2_lds[j] = a.tw256[j];
+        tw2_lds[j] = a.tw256[ju];
         __syncthreads();
     }
 
+    long long phase_t = 0;
+    if constexpr (V::PHASES) phase_t = clock64();
+    auto mark = [&](int i) {
+        if constexpr (V::PHASES) {
+            if (j == 0) {
+                const long long now = clock64();
+                atomicAdd(&g_k2_phase_cycles[i], (unsigned long long)(now - phase_t));
+                phase_t = now;
+            }
+        }
+    };
     const uint32_t col_end = min(a.n_cols, (chunk + 1) * V::COLS_PER_WG);
     for (uint32_t col = chunk * V::COLS_PER_WG; col < col_end; ++col) {
         const uint64_t p0 = a.tail + (uint64_t)col * a.hop;  // absolute position of this window's first sample
@@ -240,19 +262,28 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
 
         // ---- 1. packed real FFT of the 8192-sample window ----------------------------------------------
         v2f v[16];
+        const uint32_t p32 = (uint32_t)p0;  // (p0 + i) & mask == (p32 + i) & mask32
         if ((p0 & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                v[t] = *reinterpret_cast<const v2f*>(ring + ((p0 + 2u * (uint32_t)(j + 256 * t)) & mask));
+                v[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((p32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const uint64_t q = p0 + 2u * (uint32_t)(j + 256 * t);
-                v[t] = v2f{ring[q & mask], ring[(q + 1) & mask]};
+                const uint32_t q = p32 + 2u * (ju + 256u * (unsigned)t);
+                v[t] = v2f{ring[q & mask32], ring[(q + 1u) & mask32]};
             }
         }
         if constexpr (V::COLS_PER_WG > 1) __syncthreads();  // previous column may still be reading A / B / scan
+        v2f w8[16];  // EARLY: exp(-2 pi i k / 8192), k = j + 256 t, in flight during the forward transform
+        if constexpr (V::EARLY) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) w8[t] = tw8192[ju + 256u * (unsigned)t];
+        }
+        if constexpr (V::PHASES) __syncthreads();
+        mark(0);  // setup + window load
         fft4096t<false, V::PINGPONG>(v, A, B, j, tw);  // v[t] = Zf[j + 256 t]; last read: B (pingpong) or A
+        mark(1);  // forward packed FFT
 
         // ---- 2. Hilbert transform with ONE half-length inverse ----------------------------------------
         // analytic[n] = sum_{k=1..4096} X[k] e^{+2 pi i k n / 8192} (X[0] dropped, no x2, unnormalised; :546-557).
@@ -279,14 +310,27 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             const v2f zr = X[pad16((int)((4096u - k) & 4095u))];
             const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Zf[k] + conj Zf[N-k]) / 2
             const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};  // (Zf[k] - conj Zf[N-k]) / 2
-            const v2f w = tw8192[k];
+            const v2f w = V::EARLY ? w8[t] : tw8192[k];
             y[t] = cmulc(sum, w) - cmul(dif, w);
             if (k == 0) y[t] = v2f{0.0f, 0.0f};
         }
         const float half_x0 = hil[0], half_xn = hil[1];
         if constexpr (V::ONEBUF) __syncthreads();  // partners are read from the buffer the inverse is about to overwrite
         // Y was last read before the barrier above; X is released by pass 1's barrier (ping-pong writes it in pass 2)
+        float pw[16], pdw[16], pxr[16];  // EARLY: window tables and the real part's samples, in flight during the inverse
+        if constexpr (V::EARLY) {
+            static_assert(!V::EARLY || (V::DUAL && !V::RECOMPUTE_S), "EARLY is written for the paired-transform form");
+            const uint32_t qe = p32 + 2048u + ju;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                pw[t] = win[ju + 256u * (unsigned)t];
+                pdw[t] = dwin[ju + 256u * (unsigned)t];
+                pxr[t] = *reinterpret_cast<const float*>(ring_bytes + (((qe + 256u * (unsigned)t) << 2) & bytemask));
+            }
+        }
+        mark(2);  // Hilbert spectrum build
         fft4096t<true, V::PINGPONG>(y, Y, X, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
+        mark(3);  // inverse FFT
 
         // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t ---------------------------------------
         // ping-pong: the inverse read X (= A) last, so Y (= B) is free; in place: it read Y (= A) last, X (= B) is free
@@ -295,12 +339,13 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + 256 * t - 1024)) = y[t];
         __syncthreads();
         const float parity = (j & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of j
-        const uint64_t q0 = p0 + 2048u + (unsigned)j;
+        const uint32_t q0 = p32 + 2048u + ju;
         auto analytic = [&](int t) -> v2f {  // s[j + 256 t]
-            const float xr = ring[(q0 + 256u * (unsigned)t) & mask];
+            const float xr = V::EARLY ? pxr[t] : ring[(q0 + 256u * (unsigned)t) & mask32];
             return v2f{4096.0f * xr - half_x0 + parity, imag[j + 256 * t]};
         };
         v2f bb[9], bd[9], bt[9];
+        float pn[9];  // EARLY: bin normalisation
         if constexpr (V::RECOMPUTE_S) {
             static_assert(V::ONEBUF, "RECOMPUTE_S keeps imag[] alive, which needs the separate imag region");
             v2f vv[16];
@@ -341,27 +386,38 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
 
         // ---- three windowed FFTs; keep bins j + 256 t (t < 8) and bin 2048 (thread 0, t = 8) ----------
         if constexpr (V::DUAL) {
-            v2f vb[16], vd[16];
+            v2f vb[16], vd[16], vt[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float w = win[j + 256 * t], dw = dwin[j + 256 * t];
+                const float w = V::EARLY ? pw[t] : win[j + 256 * t], dw = V::EARLY ? pdw[t] : dwin[j + 256 * t];
                 vb[t] = v2f{sv[t].x * w, sv[t].y * w};
                 vd[t] = v2f{sv[t].x * dw, sv[t].y * dw};
+                if constexpr (V::EARLY) {
+                    const float wt = ((float)(j + 256 * t) - 2047.5f) * w;  // compute_time_weighted (:601-608), same rounding
+                    vt[t] = v2f{sv[t].x * wt, sv[t].y * wt};
+                }
             }
+            mark(4);  // analytic gather + windowing
             fft4096t_dual<false>(vb, vd, A, B, j, tw);
+            mark(5);  // dual FFT
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 bb[t] = vb[t];
                 bd[t] = vd[t];
             }
-            v2f vt[16];
+            if constexpr (!V::EARLY) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float w = twin[j + 256 * t];
-                vt[t] = v2f{sv[t].x * w, sv[t].y * w};
+                for (int t = 0; t < 16; ++t) {
+                    const float w = V::TWIN_CALC ? ((float)(j + 256 * t) - 2047.5f) * win[j + 256 * t] : twin[j + 256 * t];
+                    vt[t] = v2f{sv[t].x * w, sv[t].y * w};
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) pn[t] = bnorm[(t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u];  // in flight during the third transform
             }
             __syncthreads();  // the dual transform's last pass still reads A and B
             fft4096t<false, V::PINGPONG>(vt, A, B, j, tw);
+            mark(6);  // time-weighted FFT
 #pragma unroll
             for (int t = 0; t < 9; ++t) bt[t] = vt[t];
         } else {
@@ -402,7 +458,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         for (int t = 0; t < 9; ++t) {
             const uint32_t bin = (uint32_t)(j + 256 * t);
             bool keep = false;
-            if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], bnorm[bin], rc, pts[t]);
+            if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], V::EARLY ? pn[t] : bnorm[bin], rc, pts[t]);
             masks[t] = __ballot(keep);
             if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
         }
@@ -420,10 +476,12 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             }
             if ((masks[t] >> lane) & 1ull) {
                 const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
-                out[pos] = pts[t];
+                *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
             }
         }
         if (j == 0) *count_out = running;
+        if constexpr (V::PHASES) __syncthreads();
+        mark(7);  // reassignment + compaction + stores
     }
 }
 
@@ -586,6 +644,14 @@ static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds + pad, stream, a);
 }
 
+void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset) {
+    OMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_phase_cycles), K2_PHASES * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[K2_PHASES] = {};
+        OMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_k2_phase_cycles), zero, sizeof(zero)));
+    }
+}
+
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
     // OMX_K2_VARIANT selects an A/B build of the kernel (tuning only; every variant computes the same thing)
@@ -594,7 +660,8 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         return e ? atoi(e) : 0;
     }();
     // Measured on MI355X, 65 536 frames per launch (kernel ms): 100 -> 2.54, 1 -> 2.57, 2 -> 2.43, 3 -> 2.34,
-    // default -> 2.28; persistent multi-column loops (4.5 ms) and 3-workgroup/CU single-buffer forms (2.8-5.6 ms)
+    // 12 -> 2.22, default (12 + loads issued one transform ahead, t*w rebuilt in registers, 32-bit offsets) -> 2.10;
+    // 7 / 9 are the phase-timing builds of 12 / default (tools/k2_phases.py); persistent multi-column loops (4.5 ms) and 3-workgroup/CU single-buffer forms (2.8-5.6 ms)
     // lost to register spills and were removed except variant 13, kept as the documented negative result.
     switch (variant) {                                  //     cols tw2lds tw3reg dual  pingpong onebuf minw recompute
         case 100: launch_k2_variant<K2Variant<1, false, false, true, false>>(a, stream); break;  // round-1 first form
@@ -603,7 +670,10 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 3: launch_k2_variant<K2Variant<1, false, true, true, false>>(a, stream); break;
         case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
         case 20: launch_k2_wave(a, stream); break;  // one wavefront per frame
-        default: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;
+        case 9: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true>>(a, stream); break;
+        case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); break;
+        case 12: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;  // default until the early-load form
+        default: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true>>(a, stream); break;
     }
 }
 

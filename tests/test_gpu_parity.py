@@ -166,7 +166,7 @@ def test_spectrum_bank_all_hops_equal_per_block_snapshots(omx, oracle):
                 check_trace(got[0, wt], snaps[h].traces[0][wt])
 
 
-@pytest.mark.parametrize("variant", ["100", "3", "13", "20"])
+@pytest.mark.parametrize("variant", ["100", "3", "12", "13", "20"])
 def test_k2_alternate_builds_stay_correct(variant):
     """The A/B builds of the fused kernel (OMX_K2_VARIANT: first form, register twiddles, single-buffer form,
     wave-per-frame form) must compute the same columns; run in a subprocess because the variant is latched at first use."""
