@@ -254,7 +254,7 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     pa.tw_fft = reinterpret_cast<const v2f*>(d_tw_fft_.ptr);
     pa.tw256 = reinterpret_cast<const v2f*>(d_tw256_.ptr);
     pa.tw4096 = reinterpret_cast<const v2f*>(d_tw4096_.ptr);
-    const bool fast = fast4096_ && !force_generic_;
+    const bool fast = fast4096_ && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30);  // the fused kernel uses 32-bit ring offsets
     uint64_t wgs = 0;
     if (!fast) {
         wgs = std::min<uint64_t>((uint64_t)n_streams_ * n_traces * hops_launch, 1024);

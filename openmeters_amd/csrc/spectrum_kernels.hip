@@ -32,6 +32,7 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
 
 __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerArgs a) {
     __shared__ v2f A[FFT4096_LDS];
+    __shared__ v2f tw2_lds[256];
     __shared__ float wave_sum[2][4];
     const uint32_t pairs = (a.n_hops + 1) / 2;
     const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * pairs + pair, pair fastest
@@ -40,16 +41,39 @@ __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerA
     const uint32_t h0 = 2 * pr;
     const bool has_b = h0 + 1 < a.n_hops;
     const int j = threadIdx.x;
-    const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
-    const uint64_t mask = a.cap - 1;
-    const uint64_t p0 = a.tail + (uint64_t)(a.first_hop + h0) * a.hop;
-    float xa[16], xb[16];
+    const unsigned ju = threadIdx.x;
+    // every global load of the workgroup is issued up front (unsigned 32-bit offsets: SGPR base + VGPR offset
+    // addressing), so one memory round trip covers the ring, the window, the twiddles and the per-bin tables
+    const char* ring = reinterpret_cast<const char*>(a.ring[tr] + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;  // cap <= 2^30 (host-checked)
+    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)(a.first_hop + h0) * a.hop);
+    float xa[16], xb[16], w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t q = p32 + ju + 256u * (unsigned)t;
+        xa[t] = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
+        xb[t] = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + 256u * (unsigned)t];
+    using TW = TwiddleSource<true, true>;
+    TW tw;
+    tw.j = ju;
+    tw.tw3_global = a.tw4096;
+    tw.tw2 = tw2_lds;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
+    tw2_lds[j] = a.tw256[ju];
+    float norm[9], aw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const unsigned k = (t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u;
+        norm[t] = a.bin_norm[k];
+        aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
+    }
     float sa = 0.0f, sb = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const uint64_t q = p0 + (uint32_t)(j + 256 * t);
-        xa[t] = ring[q & mask];
-        xb[t] = has_b ? ring[(q + a.hop) & mask] : 0.0f;
         sa += xa[t];
         sb += xb[t];
     }
@@ -68,27 +92,50 @@ __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerA
     const float mean_b = (wave_sum[1][0] + wave_sum[1][1] + wave_sum[1][2] + wave_sum[1][3]) / 4096.0f;
     v2f v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float w = a.window[j + 256 * t];
-        v[t] = v2f{(xa[t] - mean_a) * w, (xb[t] - mean_b) * w};
-    }
-    const Fft4096Tables tb{a.tw256, a.tw4096};
-    fft4096<false>(v, A, j, tb);
+    for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    fft4096t<false, false>(v, A, A, j, tw);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
     __syncthreads();
+    float* out0 = nullptr;
+    if (a.fused_db)
+        out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
+    const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (t == 8 && j != 0) break;
-        const uint32_t k = (uint32_t)(j + 256 * t);
+        const uint32_t k = ju + 256u * (unsigned)t;
         const v2f z = v[t];
         const v2f zr = A[pad16((int)((4096u - k) & 4095u))];
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
-        const float norm = a.bin_norm[k];
-        spectrum_store(a, s, tr, h0, k, (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm);
-        if (has_b) spectrum_store(a, s, tr, h0 + 1, k, (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm);
+        const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
+        const float pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t];
+        if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401)
+            float raw_a = a.floor_db, wt_a = a.floor_db, raw_b = a.floor_db, wt_b = a.floor_db;
+            if (!(pa < a.state_floor)) {
+                const float db = logf(pa) * 4.3429448f;
+                raw_a = fmaxf(db, a.floor_db);
+                wt_a = fmaxf(db + aw[t], a.floor_db);
+            }
+            if (!(pb < a.state_floor)) {
+                const float db = logf(pb) * 4.3429448f;
+                raw_b = fmaxf(db, a.floor_db);
+                wt_b = fmaxf(db + aw[t], a.floor_db);
+            }
+            // emit_all == 0: only the newest hop is materialised; the host launches that hop alone (n_hops == 1)
+            out0[k] = wt_a;
+            out0[a.bins + k] = raw_a;
+            if (has_b && a.emit_all) {
+                out0[hop_stride + k] = wt_b;
+                out0[hop_stride + a.bins + k] = raw_b;
+            }
+        } else {
+            float* pw = a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
+            pw[k] = pa;
+            if (has_b) pw[a.bins + k] = pb;
+        }
     }
 }
 
