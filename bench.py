@@ -212,6 +212,21 @@ def main():
     frames_per_launch = S * cols_per_step
     bytes_per_frame = hop * 2 * 4 + 4 + mean_points * 12.0  # PCM once + count + points actually written
     achieved_gbs = frames_per_launch * bytes_per_frame / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside this process): the newest
+    # profiles/*_traffic.json written by tools/profile_bench.sh + tools/summarize_pmc.py for this same workload, else null.
+    traffic, traffic_source = None, None
+    try:
+        import glob
+        here = os.path.dirname(os.path.abspath(__file__))
+        for path in sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json")), reverse=True):
+            with open(path) as fh:
+                rec = json.load(fh)
+            w = rec.get("workload", {})
+            if w.get("streams_per_gpu") == S and w.get("columns_per_step_per_gpu") == frames_per_launch:
+                traffic, traffic_source = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
+                break
+    except Exception:
+        pass
     result = {
         "metric": "STFT frames/s (4096-pt Hann, hop 256, reassignment on)",
         "value": value,
@@ -237,7 +252,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "stft_reassigned_4096_kernel",
             "kernel_ms": kernel_ms,
             "launches_timed": launches,

@@ -614,6 +614,40 @@ int omx_loudness_meters(const omx_loudness_snapshot* snapshots, int on_device, u
                         uint64_t n_blocks, uint32_t left_mode, uint32_t right_mode, double t0, double dt,
                         omx_peak_hold* holds, void* stream, omx_meter_row* rows);
 
+/* ===================================================================== *
+ * Reassigned-splat accumulation + dB resolve — the consumer
+ * immediately after the spectrogram path: reference
+ * src/visuals/render/shaders/spectrogram.wgsl:126-147 (vs_accum_splat),
+ * :215-237 (fs_accum, fs_resolve), src/util/audio/frequency.rs:15-37.
+ * The reference runs this as two raster passes over an Rg16Float target; here the
+ * same per-point math feeds an f32 grid (no half-float saturation channel), and
+ * quad coverage follows the rasteriser's pixel-centre / top-left rule.  Columns are
+ * given oldest -> newest (age = n_columns - 1 - column) instead of through the
+ * renderer's slot ring.
+ * ===================================================================== */
+enum { OMX_FREQ_SCALE_LINEAR = 0, OMX_FREQ_SCALE_LOGARITHMIC = 1, OMX_FREQ_SCALE_ERB = 2 };
+typedef struct omx_splat_view {
+    float extent_x;       /* physical pixels along time (bounds.width * scale_factor), newest column at the right edge */
+    float extent_y;       /* physical pixels along frequency, top = freq_max */
+    float scale_factor;   /* physical pixels per column and per splat side (>= 1) */
+    uint32_t freq_scale;  /* OMX_FREQ_SCALE_* */
+    float freq_min;       /* display_axis(sample_rate): min(1 Hz, nyquist / 2) (spectrogram/state.rs:48-51) */
+    float freq_max;       /* nyquist */
+    float uv_lo, uv_hi;   /* zoom window on the normalised frequency axis ([0, 1] = everything) */
+    float tilt_db;        /* dB / octave around 1 kHz, 0 = off */
+    uint32_t width;       /* out: ceil(max(extent_x, 1)) — filled by omx_splat_view_size */
+    uint32_t height;      /* out: ceil(max(extent_y, 1)) */
+} omx_splat_view;
+void omx_splat_view_size(omx_splat_view* view);
+/* points [n_streams][n_columns][column_stride], counts [n_streams][n_columns] (the spectrogram bank's d_points / d_counts);
+ * accum (power) and db (resolved level, -inf where nothing landed) are f32 [n_streams][width][height]: time-major, one
+ * time column (all frequencies of one x) is contiguous, row 0 = freq_max.
+ * on_device = 0: all four are host pointers (synchronous); 1: device pointers, enqueued on `stream`. */
+int omx_spectrogram_splat(const omx_spectrogram_point* points, const uint32_t* counts, int on_device,
+                          uint64_t n_streams, uint64_t n_columns, uint64_t column_stride,
+                          float reassigned_power_scale, const omx_splat_view* view, void* stream,
+                          float* accum, float* db);
+
 #ifdef __cplusplus
 }
 #endif

@@ -670,3 +670,40 @@ def loudness_meters(api: Api, snapshots: Sequence["LoudnessSnapshot"], n_streams
                                             C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])
     api.check(f(C.byref(arr), 0, n_streams, n_blocks, left_mode, right_mode, t0, dt, holds.ctypes.data, None, rows.ctypes.data))
     return rows
+
+
+# --------------------------------------------------------------------------- reassigned-splat accumulation
+FREQ_SCALE_LINEAR, FREQ_SCALE_LOGARITHMIC, FREQ_SCALE_ERB = range(3)
+
+
+class CSplatView(C.Structure):
+    _fields_ = [("extent_x", C.c_float), ("extent_y", C.c_float), ("scale_factor", C.c_float), ("freq_scale", C.c_uint32),
+                ("freq_min", C.c_float), ("freq_max", C.c_float), ("uv_lo", C.c_float), ("uv_hi", C.c_float), ("tilt_db", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+def splat_view(api: Api, extent_x: float, extent_y: float, sample_rate: float = DEFAULT_SAMPLE_RATE, scale_factor: float = 1.0,
+               freq_scale: int = FREQ_SCALE_LOGARITHMIC, uv=(0.0, 1.0), tilt_db: float = 0.0) -> CSplatView:
+    """display_axis (reference src/visuals/spectrogram/state.rs:48-51) + accumulation-target size (render.rs:523-529)."""
+    nyq = max(sample_rate / 2.0, 1.0)
+    v = CSplatView(extent_x, extent_y, scale_factor, freq_scale, min(1.0, nyq * 0.5), nyq, uv[0], uv[1], tilt_db, 0, 0)
+    api.fn("splat_view_size", None, [C.c_void_p])(C.byref(v))
+    return v
+
+
+def spectrogram_splat(api: Api, columns: Sequence[np.ndarray], view: CSplatView, reassigned_power_scale: float, want_db: bool = True):
+    """Host convenience for one stream: `columns` = reassigned columns oldest -> newest ([n, 3] float32 each).
+    Returns (accum, db) as [height, width] float32."""
+    stride = max(1, max((len(c) for c in columns), default=1))
+    pts = np.zeros((len(columns), stride, 3), np.float32)
+    counts = np.zeros(len(columns), np.uint32)
+    for i, c in enumerate(columns):
+        pts[i, :len(c)] = c
+        counts[i] = len(c)
+    accum = np.zeros((view.width, view.height), np.float32)   # C layout: [width][height]
+    db = np.zeros((view.width, view.height), np.float32)
+    f = api.fn("spectrogram_splat", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p])
+    api.check(f(pts.ctypes.data, counts.ctypes.data, 0, 1, len(columns), stride, reassigned_power_scale, C.byref(view), None,
+                accum.ctypes.data, db.ctypes.data if want_db else None))
+    return accum.T, db.T

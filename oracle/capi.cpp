@@ -17,6 +17,7 @@
 #include "spectrogram.hpp"
 #include "spectrum.hpp"
 #include "stereometer.hpp"
+#include "splat.hpp"
 #include "summary.hpp"
 #include "waveform.hpp"
 
@@ -780,6 +781,19 @@ int omxo_loudness_meters(const omx_loudness_snapshot* snapshots, int, uint64_t n
     for (uint64_t s = 0; s < n_streams; ++s)
         for (uint64_t k = 0; k < n_blocks; ++k)
             rows[s * n_blocks + k] = apply_meter_snapshot(snapshots[s * n_blocks + k], left_mode, right_mode, t0 + (double)k * dt, holds + 3 * s);
+    return OMX_PRODUCED;
+}
+
+// ---- reassigned-splat accumulation + resolve (splat.hpp) ----
+void omxo_splat_view_size(omx_splat_view* view) {
+    if (view) splat_view_size(view);
+}
+int omxo_spectrogram_splat(const omx_spectrogram_point* points, const uint32_t* counts, int, uint64_t n_streams, uint64_t n_columns,
+                           uint64_t column_stride, float reassigned_power_scale, const omx_splat_view* view, void*, float* accum,
+                           float* db) {
+    if (!points || !counts || !view || !accum || view->width == 0 || view->height == 0 || !(view->scale_factor >= 1.0f))
+        return OMX_ERR_INVALID;
+    spectrogram_splat(points, counts, n_streams, n_columns, column_stride, reassigned_power_scale, *view, accum, db);
     return OMX_PRODUCED;
 }
 

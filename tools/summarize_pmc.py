@@ -28,6 +28,26 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for k, cs in agg.items():
         for c, vals in sorted(cs.items()):
             lines.append(f"{k:40s} {c:24s} mean={sum(vals)/len(vals):.6g} n={len(vals)}")
+# HBM traffic of the dominant kernel, per launch, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes:
+# FETCH_SIZE / WRITE_SIZE are in KiB and come from separate passes; on gfx950 FETCH_SIZE reports half of the bytes of a wide
+# coalesced read, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+import json
+traffic = {}
+for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    for f in glob.glob(os.path.join(p, "*counter_collection.csv")):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "stft_reassigned_4096_kernel" in row.get("Kernel_Name", "") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    traffic.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+    fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
+    write = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
+    rec = {"kernel": "stft_reassigned_4096_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
+           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE x2)",
+           "launches": len(traffic["FETCH_SIZE"]), "workload": {"streams_per_gpu": 64, "columns_per_step_per_gpu": 65536}}
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    lines.append(f"== HBM traffic per launch (stft_reassigned_4096_kernel): {rec['hbm_bytes_per_launch'] / 1e9:.3f} GB ==")
 txt = "\n".join(lines)
 print(txt)
 with open(os.path.join(out, "summary.txt"), "w") as fh:
