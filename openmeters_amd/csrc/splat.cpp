@@ -12,6 +12,13 @@ float freq_scale_host(uint32_t scale, float hz) {  // util/audio/frequency.rs:25
         default: return hz;
     }
 }
+int splat_form() {  // OMX_SPLAT_FORM=1|2 pins the kernel form (A/B and tests); default: chosen per image size
+    static const int form = [] {
+        const char* e = getenv("OMX_SPLAT_FORM");
+        return e ? atoi(e) : 0;
+    }();
+    return form;
+}
 }  // namespace
 
 extern "C" {
@@ -53,7 +60,7 @@ int omx_spectrogram_splat(const omx_spectrogram_point* points, const uint32_t* c
             a.points = points;
             a.counts = counts;
             a.accum = accum;
-            launch_splat(a, db, reassigned_power_scale, st);
+            launch_splat(a, db, reassigned_power_scale, st, splat_form());
             OMX_HIP(hipGetLastError());
             return (int)OMX_PRODUCED;
         }
@@ -70,7 +77,7 @@ int omx_spectrogram_splat(const omx_spectrogram_point* points, const uint32_t* c
         a.points = d_points.ptr;
         a.counts = d_counts.ptr;
         a.accum = d_accum.ptr;
-        launch_splat(a, db ? d_db.ptr : nullptr, reassigned_power_scale, st);
+        launch_splat(a, db ? d_db.ptr : nullptr, reassigned_power_scale, st, splat_form());
         OMX_HIP(hipGetLastError());
         OMX_HIP(hipMemcpyAsync(accum, d_accum.ptr, px * sizeof(float), hipMemcpyDeviceToHost, st));
         if (db) OMX_HIP(hipMemcpyAsync(db, d_db.ptr, px * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -14,5 +14,9 @@ struct SplatArgs {
     float tilt_db;
     float* accum;                         // [n_streams][width][height] (frequency fastest: a time column is contiguous)
 };
-void launch_splat(const SplatArgs& a, float* db, float power_scale, hipStream_t stream);
+struct SplatTiling {
+    uint32_t tile_cols, margin_cols, window_width, band_rows;
+};
+// force_form: 0 = choose, 1 = global atomics, 2 = LDS-tiled (OMX_SPLAT_FORM, tuning / tests)
+void launch_splat(const SplatArgs& a, float* db, float power_scale, hipStream_t stream, int force_form = 0);
 }  // namespace omx

@@ -10,8 +10,13 @@ namespace omx {
 namespace {
 __device__ __forceinline__ float freq_scale_value(uint32_t scale, float hz) {
     switch (scale) {
-        case OMX_FREQ_SCALE_LOGARITHMIC: return asinhf(hz / 20.0f);
-        case OMX_FREQ_SCALE_ERB: return 21.4f * logf(1.0f + hz / 228.8f) * 0.4342944819f;
+        // asinh(x) = ln(x + sqrt(x^2 + 1)); x = hz / 20 >= 0 here and the display axis starts at 1 Hz, so the direct form
+        // loses nothing a pixel could see (WGSL leaves asinh's precision to the implementation anyway)
+        case OMX_FREQ_SCALE_LOGARITHMIC: {
+            const float x = hz / 20.0f;
+            return x >= 0.0f ? __logf(x + sqrtf(x * x + 1.0f)) : asinhf(x);
+        }
+        case OMX_FREQ_SCALE_ERB: return 21.4f * __logf(1.0f + hz / 228.8f) * 0.4342944819f;
         default: return hz;
     }
 }
@@ -39,9 +44,16 @@ __device__ __forceinline__ void wave_merged_add(float* acc, bool active, uint32_
     if (active && (lane == 63 || next != key)) unsafeAtomicAdd(acc + key, v);
 }
 
-constexpr uint32_t SPLAT_COLS_PER_WG = 8;  // a workgroup walks 8 columns x ceil(points / 256) chunks: few, fat workgroups
+constexpr uint32_t SPLAT_COLS_PER_WG = 8;  // global-atomic form: a workgroup walks 8 columns x ceil(points / 256) chunks
 
-__device__ __forceinline__ void splat_chunk(const SplatArgs& a, uint32_t s, uint32_t col, uint32_t n, uint32_t i) {
+struct SplatFootprint {
+    bool live;
+    float power;
+    uint32_t i0, i1, j0, j1;  // covered pixels [i0, i1) x [j0, j1)
+};
+// vs_accum_splat + fs_accum for point `i` of column `col` (spectrogram.wgsl:126-147, 215-226)
+__device__ __forceinline__ SplatFootprint splat_footprint(const SplatArgs& a, uint32_t s, uint32_t col, uint32_t n, uint32_t i) {
+    SplatFootprint f{};
     bool live = i < n;
     omx_spectrogram_point p{0.0f, 0.0f, 0.0f};
     if (live) p = a.points[((uint64_t)s * a.n_columns + col) * a.column_stride + i];
@@ -57,36 +69,87 @@ __device__ __forceinline__ void splat_chunk(const SplatArgs& a, uint32_t s, uint
     // pixel (i, j) is covered when its centre lies in [x0, x1) x [y0, y1)
     const float fi0 = ceilf(x0 - 0.5f), fi1 = ceilf(x1 - 0.5f), fj0 = ceilf(y0 - 0.5f), fj1 = ceilf(y1 - 0.5f);
     live = live && fi1 > 0.0f && fj1 > 0.0f && fi0 < (float)a.width && fj0 < (float)a.height;
-    uint32_t i0 = 0, i1 = 0, j0 = 0, j1 = 0;
+    f.live = live;
+    f.power = power;
     if (live) {
-        i0 = (uint32_t)fmaxf(fi0, 0.0f);
-        i1 = (uint32_t)fminf(fi1, (float)a.width);
-        j0 = (uint32_t)fmaxf(fj0, 0.0f);
-        j1 = (uint32_t)fminf(fj1, (float)a.height);
+        f.i0 = (uint32_t)fmaxf(fi0, 0.0f);
+        f.i1 = (uint32_t)fminf(fi1, (float)a.width);
+        f.j0 = (uint32_t)fmaxf(fj0, 0.0f);
+        f.j1 = (uint32_t)fminf(fj1, (float)a.height);
     }
-    float* acc = a.accum + (uint64_t)s * a.width * a.height;
-    // footprint offsets are walked in lock-step by the whole wave (a footprint is at most ceil(scale_factor) + 1 wide)
-    const uint32_t reach = (uint32_t)ceilf(sf) + 1u;
-    for (uint32_t dx = 0; dx < reach; ++dx) {
-        for (uint32_t dy = 0; dy < reach; ++dy) {
-            const bool on = live && i0 + dx < i1 && j0 + dy < j1;
-            if (__ballot(on) == 0ull) continue;
-            // [width][height]: neighbouring bins of one column are neighbouring addresses
-            wave_merged_add(acc, on, (i0 + dx) * a.height + (j0 + dy), power);
-        }
-    }
+    return f;
 }
 
+// ---- form 1: straight to the image with global atomics (any image size) ---------------------------------------------
 __global__ __launch_bounds__(256) void splat_accumulate_kernel(SplatArgs a) {
     // grid: x = ceil(n_columns / SPLAT_COLS_PER_WG), y = stream
     const uint32_t s = blockIdx.y;
     const uint32_t col_end = min(a.n_columns, (blockIdx.x + 1u) * SPLAT_COLS_PER_WG);
+    float* acc = a.accum + (uint64_t)s * a.width * a.height;
+    const uint32_t reach = (uint32_t)ceilf(a.scale_factor) + 1u;  // a footprint is at most ceil(scale_factor) + 1 wide
     for (uint32_t col = blockIdx.x * SPLAT_COLS_PER_WG; col < col_end; ++col) {
         const uint32_t n = min(a.counts[(uint64_t)s * a.n_columns + col], a.column_stride);
         for (uint32_t base = 0; base < n; base += 256u) {
             if (base + (threadIdx.x & ~63u) >= n) continue;  // whole wave past the end of the column
-            splat_chunk(a, s, col, n, base + threadIdx.x);
+            const SplatFootprint f = splat_footprint(a, s, col, n, base + threadIdx.x);
+            // footprint offsets are walked in lock-step by the whole wave
+            for (uint32_t dx = 0; dx < reach; ++dx) {
+                for (uint32_t dy = 0; dy < reach; ++dy) {
+                    const bool on = f.live && f.i0 + dx < f.i1 && f.j0 + dy < f.j1;
+                    if (__ballot(on) == 0ull) continue;
+                    // [width][height]: neighbouring bins of one column are neighbouring addresses
+                    wave_merged_add(acc, on, (f.i0 + dx) * a.height + (f.j0 + dy), f.power);
+                }
+            }
         }
+    }
+}
+
+// ---- form 2: LDS-tiled.  The global form is bound by the L2's atomic transaction rate (one transaction per scattered
+// pixel).  Here a workgroup owns a tile of consecutive columns and a band of rows: it accumulates every footprint pixel that
+// falls into its [x window] x [row band] with LDS atomics, then flushes the window to the image with coalesced atomics (the
+// windows of neighbouring tiles overlap by the time-reassignment margin).  Pixels are partitioned by ROW BAND, so every
+// (point, pixel) pair is added exactly once; pixels of the band outside the x window go straight to the image.
+__global__ __launch_bounds__(1024) void splat_tiled_kernel(SplatArgs a, SplatTiling t) {
+    extern __shared__ float tile[];  // [window_width][band_rows + 1]: the odd stride spreads one row of many columns over the banks
+    const uint32_t s = blockIdx.z, band = blockIdx.y;
+    const uint32_t c0 = blockIdx.x * t.tile_cols, c1 = min(a.n_columns, c0 + t.tile_cols);
+    const uint32_t j_lo = band * t.band_rows, j_hi = min(a.height, j_lo + t.band_rows);
+    // x window: from margin_cols behind the tile's oldest column to 2 columns ahead of its newest one
+    const float sf = a.scale_factor;
+    const float x_old = a.extent_x - ((float)(a.n_columns - 1u - c0) + (float)t.margin_cols) * sf;
+    const float x_new = a.extent_x - ((float)(a.n_columns - c1) - 2.5f) * sf;
+    const int xl = max(0, (int)floorf(x_old) - 1);
+    const int xh = min((int)a.width, min(xl + (int)t.window_width, (int)ceilf(x_new) + 1));
+    const uint32_t x_lo = (uint32_t)xl, x_hi = (uint32_t)max(xh, xl);
+    const uint32_t rows = j_hi - j_lo, stride = t.band_rows + 1u, cells = (x_hi - x_lo) * stride;
+    for (uint32_t k = threadIdx.x; k < cells; k += 1024u) tile[k] = 0.0f;
+    __syncthreads();
+    float* acc = a.accum + (uint64_t)s * a.width * a.height;
+    const uint32_t reach = (uint32_t)ceilf(sf) + 1u;
+    for (uint32_t col = c0; col < c1; ++col) {
+        const uint32_t n = min(a.counts[(uint64_t)s * a.n_columns + col], a.column_stride);
+        for (uint32_t base = 0; base < n; base += 1024u) {
+            const SplatFootprint f = splat_footprint(a, s, col, n, base + threadIdx.x);
+            if (!f.live || f.j1 <= j_lo || f.j0 >= j_hi) continue;
+            for (uint32_t dx = 0; dx < reach && f.i0 + dx < f.i1; ++dx) {
+                const uint32_t ix = f.i0 + dx;
+                for (uint32_t dy = 0; dy < reach && f.j0 + dy < f.j1; ++dy) {
+                    const uint32_t jy = f.j0 + dy;
+                    if (jy < j_lo || jy >= j_hi) continue;  // another band's pixel
+                    if (ix >= x_lo && ix < x_hi)
+                        atomicAdd(&tile[(ix - x_lo) * stride + (jy - j_lo)], f.power);
+                    else
+                        unsafeAtomicAdd(acc + (uint64_t)ix * a.height + jy, f.power);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < cells; k += 1024u) {
+        const uint32_t r = k % stride;
+        const float v = tile[k];
+        if (r < rows && v != 0.0f) unsafeAtomicAdd(acc + (uint64_t)(x_lo + k / stride) * a.height + j_lo + r, v);
     }
 }
 
@@ -100,13 +163,35 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(const float* __restr
     db[i] = out;
 }
 
-void launch_splat(const SplatArgs& a, float* db, float power_scale, hipStream_t stream) {
+void launch_splat(const SplatArgs& a, float* db, float power_scale, hipStream_t stream, int force_form) {
     const uint64_t px = (uint64_t)a.n_streams * a.width * a.height;
     if (px == 0) return;
     OMX_HIP(hipMemsetAsync(a.accum, 0, px * sizeof(float), stream));
-    if (a.n_columns && a.column_stride)
-        hipLaunchKernelGGL(splat_accumulate_kernel, dim3((a.n_columns + SPLAT_COLS_PER_WG - 1) / SPLAT_COLS_PER_WG, a.n_streams), dim3(256),
-                           0, stream, a);
+    if (a.n_columns && a.column_stride) {
+        // tiling: 32 columns per workgroup, window = tile + 17 columns behind (time reassignment reaches back by up to
+        // window/hop columns; anything further falls back to global atomics) + 3 ahead, rows banded to fit 128 KiB of LDS
+        SplatTiling t{};
+        t.tile_cols = 32;
+        t.margin_cols = 17;
+        t.window_width = (uint32_t)std::ceil((float)(t.tile_cols + t.margin_cols + 3) * a.scale_factor) + 3u;
+        constexpr uint32_t lds_floats = 32768;
+        t.band_rows = std::min<uint32_t>(lds_floats / t.window_width - 1u, a.height);
+        const uint32_t bands = t.band_rows ? (a.height + t.band_rows - 1) / t.band_rows : 0;
+        const bool tiled = force_form == 2 || (force_form != 1 && t.band_rows >= 64 && bands <= 8);
+        if (tiled && t.band_rows) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(lds_floats * sizeof(float)));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(splat_tiled_kernel, dim3((a.n_columns + t.tile_cols - 1) / t.tile_cols, bands, a.n_streams), dim3(1024),
+                               (size_t)t.window_width * (t.band_rows + 1u) * sizeof(float), stream, a, t);
+        } else {
+            hipLaunchKernelGGL(splat_accumulate_kernel, dim3((a.n_columns + SPLAT_COLS_PER_WG - 1) / SPLAT_COLS_PER_WG, a.n_streams),
+                               dim3(256), 0, stream, a);
+        }
+    }
     if (db) hipLaunchKernelGGL(splat_resolve_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, stream, a.accum, db, px, power_scale);
 }
 

@@ -217,3 +217,17 @@ def test_splat_accumulation_of_device_resident_columns_matches_oracle(omx, oracl
             assert strong.sum() > 30, strong.sum()
             worst = np.abs(db[s][strong] - want_db[strong]).max()
             assert worst <= 0.05, worst
+
+
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_splat_kernel_forms_stay_correct(form):
+    """OMX_SPLAT_FORM pins the global-atomic (1) or the LDS-tiled (2) accumulation kernel: both must pass the behavioural
+    cases and the device-parity case."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, OMX_SPLAT_FORM=form)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", "splat and not forms", os.path.join(here, "test_kat_splat.py"),
+                        os.path.join(here, "test_gpu_parity.py")], env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and "10 passed" in r.stdout, r.stdout[-2000:]
