@@ -1,0 +1,80 @@
+"""Configuration matrix for the spectrogram / spectrum parity (`-m gpu`): every WindowKind, several sample rates and
+channel layouts, through the fused 4096 kernels and the generic ones.  Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from openmeters_amd import capi
+from openmeters_amd.capi import (AudioBlock, SpectrogramConfig, SpectrogramProcessor, SpectrumConfig, SpectrumProcessor)
+from test_gpu_parity import check_reassigned, check_trace, stream_pcm
+from parity import classic_column_metrics
+
+pytestmark = pytest.mark.gpu
+WINDOWS = [capi.WINDOW_RECTANGULAR, capi.WINDOW_HANN, capi.WINDOW_HAMMING, capi.WINDOW_BLACKMAN, capi.WINDOW_BLACKMAN_HARRIS]
+
+
+def multichannel(s, frames, channels):
+    base = stream_pcm(s, frames)[:, 0]
+    out = np.zeros((frames, channels), np.float32)
+    for c in range(channels):
+        out[:, c] = np.roll(base, 37 * c) * np.float32(1.0 - 0.1 * c)
+    return out
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+@pytest.mark.parametrize("W", [4096, 1024])
+def test_reassigned_every_window_kind(omx, oracle, window, W):
+    """derivative window (spectral derivative, on the device), time-weighted window (rebuilt in registers in the fused kernel)
+    and the bin normalisation all depend on the window kind"""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=256, window=window, use_reassignment=True, history_length=64)
+    pcm = stream_pcm(3, 2 * W + 256 * 5)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert len(g.new_columns) == len(w.new_columns) == 6 and g.reassigned_power_scale == w.reassigned_power_scale
+    check_reassigned(g.new_columns, w.new_columns, 256)
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+def test_classic_and_spectrum_every_window_kind(omx, oracle, window):
+    pcm = stream_pcm(4, 4096 + 256 * 7)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    cfg = SpectrogramConfig(fft_size=2048, hop_size=256, window=window, use_reassignment=False, history_length=64)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert len(g.new_columns) == len(w.new_columns) > 0
+    for h, o in zip(g.new_columns, w.new_columns):
+        m = classic_column_metrics(h, o)
+        assert m["max_code_diff"] <= 1 and m["n_diff"] <= max(4, m["n"] // 50), m
+    for N in (4096, 512):
+        sc = SpectrumConfig(fft_size=N, hop_size=N // 4, window=window, source=capi.CH_LEFT, secondary_source=capi.CH_SIDE)
+        gs, ws = SpectrumProcessor(omx, sc).process_block(blk), SpectrumProcessor(oracle, sc).process_block(blk)
+        assert np.array_equal(gs.frequency_bins, ws.frequency_bins)
+        for tr in range(2):
+            for k in range(2):
+                check_trace(gs.traces[tr][k], ws.traces[tr][k])
+
+
+@pytest.mark.parametrize("rate,channels,positions", [(44100.0, 1, None), (96000.0, 6, None), (192000.0, 8, capi.SURROUND),
+                                                     (48000.0, 4, [capi.POS_FC, capi.POS_LFE, capi.POS_SL, capi.POS_SR]),
+                                                     (22050.0, 3, [capi.POS_AUX0, capi.POS_AUX0 + 1, capi.POS_UNKNOWN])])
+def test_sample_rates_and_channel_layouts(omx, oracle, rate, channels, positions):
+    """the stereo fold (dsp.rs:117-176) and every rate-derived constant (bin_hz, latency, max_hz) feed the fused kernel"""
+    frames = 8192 + 256 * 4
+    pcm = multichannel(6, frames, channels)
+    if positions is not None:
+        positions = list(positions) + [capi.POS_UNKNOWN] * (8 - len(positions))
+    blk = AudioBlock(pcm.reshape(-1), channels, rate, positions)
+    cfg = SpectrogramConfig(sample_rate=rate, fft_size=4096, hop_size=256, use_reassignment=True, history_length=64)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert (g is None) == (w is None)
+    if w is not None:
+        assert len(g.new_columns) == len(w.new_columns) == 5
+        for h, o in zip(g.new_columns, w.new_columns):
+            from parity import reassigned_column_metrics
+            m = reassigned_column_metrics(h, o, rate, 256)
+            assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, m
+    sc = SpectrumConfig(sample_rate=rate, fft_size=4096, hop_size=512, source=capi.CH_MID, secondary_source=capi.CH_RIGHT)
+    gs, ws = SpectrumProcessor(omx, sc).process_block(blk), SpectrumProcessor(oracle, sc).process_block(blk)
+    assert (gs is None) == (ws is None)
+    if ws is not None:
+        for tr in range(2):
+            for k in range(2):
+                check_trace(gs.traces[tr][k], ws.traces[tr][k])
