@@ -1,0 +1,171 @@
+// Size-templated variant of the register / LDS FFT of fft_device.hpp for N = 1024, 2048, 4096 complex points.
+// One transform is carried by T = N / 16 threads (64, 128, 256), 16 complex values per thread, so a 256-thread
+// workgroup runs 4, 2 or 1 transforms side by side.  Three Stockham passes: radix 16, radix 16, radix R3 = N / 256
+// (4, 8, 16); in the last pass a thread does 16 / R3 butterflies.  Same padded LDS layout, same element convention as
+// the 4096-point code: thread jf holds x[jf + T u] in v[u] on entry and X[jf + T u] in v[u] on return.
+#pragma once
+#include "fft_device.hpp"
+
+namespace omx {
+
+template <int LOGN>
+struct FftGeom {
+    static_assert(LOGN >= 10 && LOGN <= 12, "N = 1024, 2048 or 4096");
+    static constexpr int N = 1 << LOGN;
+    static constexpr int T = N / 16;       // threads per transform
+    static constexpr int R3 = N / 256;     // radix of the last pass
+    static constexpr int M = 16 / R3;      // butterflies per thread in the last pass
+    static constexpr int LDS = N + N / 16; // padded complex slots per buffer
+    static constexpr int FRAMES = 256 / T; // transforms per 256-thread workgroup
+};
+
+// natural-order 8-point DFT in place (radix-2 over two dft4)
+template <bool INV>
+__device__ __forceinline__ void dft8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7) {
+    constexpr float H = 0.70710678118654752440f;
+    const v2f hh{H, H}, nh{-H, -H};
+    dft4<INV>(a0, a2, a4, a6);  // E[0..3]
+    dft4<INV>(a1, a3, a5, a7);  // O[0..3]
+    const v2f o1 = add_rot<INV>(a3, a3) * hh;  // w8^1 O1 = H (1 -+ i) O1
+    const v2f o3 = sub_rot<INV>(a7, a7) * nh;  // w8^3 O3 = -H (1 +- i) O3
+    const v2f e0 = a0, e1 = a2, e2 = a4, e3 = a6, o0 = a1, o2 = a5;
+    a0 = e0 + o0;
+    a4 = e0 - o0;
+    a1 = e1 + o1;
+    a5 = e1 - o1;
+    a2 = add_rot<INV>(e2, o2);  // w8^2 = -+ i
+    a6 = sub_rot<INV>(e2, o2);
+    a3 = e3 + o3;
+    a7 = e3 - o3;
+}
+
+// Twiddles: pass 2 from a 256-entry table (LDS copy), pass 3 resident in VGPRs.
+template <int LOGN>
+struct TwiddlesPow2 {
+    using G = FftGeom<LOGN>;
+    const v2f* tw2;  // exp(-2 pi i k / 256), k < 256
+    v2f tw3[15];     // tw3[u - 1] = exp(-2 pi i t b / N), u = m + M t, b = jf + T m  (unused while t == 0)
+    __device__ __forceinline__ void load(const v2f* twN, unsigned jf) {
+#pragma unroll
+        for (int u = 1; u < 16; ++u) {
+            const unsigned t = (unsigned)(u / G::M), m = (unsigned)(u % G::M);
+            tw3[u - 1] = t ? twN[t * (jf + (unsigned)G::T * m)] : v2f{1.0f, 0.0f};
+        }
+    }
+};
+
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_pass1(v2f (&v)[16], v2f* lds, int jf) {
+    dft16<INV>(v);
+    const int base = 17 * jf;  // pad16(16 jf + t)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lds[base + t] = v[DFT16_OUT(t)];
+}
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_pass2(const v2f* src, v2f* dst, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[pad16(jf + G::T * t)];
+    const unsigned k = (unsigned)jf & 15u;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw.tw2[k * (unsigned)t]);
+    dft16<INV>(v);
+    const int base = (jf >> 4) * 272 + (int)k;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dst[base + 17 * t] = v[DFT16_OUT(t)];
+}
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    v2f v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = lds[pad16(jf + G::T * u)];
+#pragma unroll
+    for (int u = G::M; u < 16; ++u) v[u] = twmul<INV>(v[u], tw.tw3[u - 1]);
+    if constexpr (G::R3 == 16) {
+        dft16<INV>(v);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[t] = v[DFT16_OUT(t)];
+    } else if constexpr (G::R3 == 8) {
+        dft8<INV>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14]);
+        dft8<INV>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) out[u] = v[u];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dft4<INV>(v[m], v[m + 4], v[m + 8], v[m + 12]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) out[u] = v[u];
+    }
+}
+// x[jf + T u] in v[u] -> X[jf + T u] in v[u].  Writes `first`, then `second`, reads `second` last (ping-pong); the caller
+// guarantees nobody still reads `first` and that `second` is free.  All 256 threads of the workgroup must call it together.
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp(v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw) {
+    fftp_pass1<INV, LOGN>(v, first, jf);
+    __syncthreads();
+    fftp_pass2<INV, LOGN>(first, second, jf, tw);
+    __syncthreads();
+    fftp_pass3<INV, LOGN>(v, second, jf, tw);
+}
+// In place in one buffer (one extra barrier in pass 2): half the LDS of the ping-pong form, for kernels that run a single
+// transform per frame slot (classic columns, spectrum).
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    fftp_pass1<INV, LOGN>(v, buf, jf);
+    __syncthreads();
+    {
+        v2f a[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a[t] = buf[pad16(jf + G::T * t)];
+        const unsigned k = (unsigned)jf & 15u;
+#pragma unroll
+        for (int t = 1; t < 16; ++t) a[t] = twmul<INV>(a[t], tw.tw2[k * (unsigned)t]);
+        dft16<INV>(a);
+        __syncthreads();
+        const int base = (jf >> 4) * 272 + (int)k;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) buf[base + 17 * t] = a[DFT16_OUT(t)];
+    }
+    __syncthreads();
+    fftp_pass3<INV, LOGN>(v, buf, jf, tw);
+}
+// Two transforms at once, in place on their own buffers (shared barriers).
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    fftp_pass1<INV, LOGN>(v0, A, jf);
+    fftp_pass1<INV, LOGN>(v1, B, jf);
+    __syncthreads();
+    {
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(jf + G::T * t)];
+            b[t] = B[pad16(jf + G::T * t)];
+        }
+        const unsigned k = (unsigned)jf & 15u;
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tw.tw2[k * (unsigned)t];
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+        __syncthreads();
+        const int base = (jf >> 4) * 272 + (int)k;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            A[base + 17 * t] = a[DFT16_OUT(t)];
+            B[base + 17 * t] = b[DFT16_OUT(t)];
+        }
+    }
+    __syncthreads();
+    fftp_pass3<INV, LOGN>(v0, A, jf, tw);
+    fftp_pass3<INV, LOGN>(v1, B, jf, tw);
+}
+
+}  // namespace omx

@@ -145,15 +145,15 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
             squares = squares + x * x;
         }
         power_scale_ = (float)(sum * sum / ((double)fft_size_ * squares));
-        fast4096_ = (W == 4096 && fft_size_ == 4096);
-        if (fast4096_) {
-            d_tw256_.upload(twiddle_table(256, 256), stream);
-            d_tw4096_.upload(twiddle_table(4096, 4096), stream);
-            d_tw8192_.upload(twiddle_table(8192, 4096), stream);
-        }
     } else {
         power_scale_ = 1.0f;
-        fast4096_ = false;
+    }
+    // fused kernels: W = F in {1024, 2048, 4096} (the tuned 4096 kernel / the size-templated ones; classic and reassigned)
+    fast4096_ = (W == fft_size_ && (W == 4096 || W == 2048 || W == 1024));
+    if (fast4096_) {
+        d_tw256_.upload(twiddle_table(256, 256), stream);
+        d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / N)
+        d_tw8192_.upload(twiddle_table(2 * W, W), stream);  // exp(-2 pi i k / 2N)
     }
     d_bin_norm_.upload(bin_norm, stream);
     OMX_HIP(hipStreamSynchronize(stream));  // host vectors above go out of scope
@@ -267,7 +267,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
 
     timer_.begin(stream);
     // the fused kernel indexes the ring with 32-bit offsets
-    const bool fast = fast4096_ && reassign && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30);
+    const bool fast = fast4096_ && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30) && hop <= 0xFFFFFFFFull;
     if (fast) {
         StftFastArgs fa{};
         fa.ring = ring_.ptr;
@@ -292,7 +292,16 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         fa.latency_hops = latency_hops;
         fa.points = d_points_.ptr;
         fa.counts = d_counts_.ptr;
-        launch_stft_reassigned_4096(fa, stream);
+        static const bool cross_check = [] {  // OMX_K2_VARIANT=30: run 4096 through the size-templated kernel as well
+            const char* e = getenv("OMX_K2_VARIANT");
+            return e && atoi(e) == 30;
+        }();
+        if (!reassign)
+            launch_stft_classic_pow2(fa, d_codes_.ptr, (uint32_t)fft_size_, stream);
+        else if (fft_size_ == 4096 && !cross_check)
+            launch_stft_reassigned_4096(fa, stream);
+        else
+            launch_stft_reassigned_pow2(fa, (uint32_t)fft_size_, stream);
     } else {
         if (hop > 0xFFFFFFFFull) unsupported("hop_size beyond 2^32");
         const uint64_t per_wg = reassign ? hilbert_len_ + 3 * fft_size_ : fft_size_;

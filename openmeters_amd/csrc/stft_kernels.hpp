@@ -54,6 +54,10 @@ constexpr int K2_PHASES = 8;
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning builds only (OMX_K2_VARIANT=7)
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream);
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
+// size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
+void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);
+// fused classic columns (u16 dB codes, two columns per complex FFT) for the same sizes
+void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t fft_size, hipStream_t stream);
 
 // ---------------------------------------------------------------- K1/K2 generic spectrogram
 struct StftGenericArgs {

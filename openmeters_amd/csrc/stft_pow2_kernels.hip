@@ -1,0 +1,337 @@
+// K2p: the fused reassigned STFT of stft_kernels.hip, templated on the window length W = N = 1024, 2048 (and 4096, kept as a
+// cross-check of the tuned 4096 kernel).  A frame is carried by T = N / 16 threads, so a 256-thread workgroup processes
+// 256 / T consecutive columns of one stream side by side, each with its own pair of LDS buffers.  Same algorithm, same
+// operation order per bin (reference src/visuals/spectrogram/processor.rs:318-348, 439-488, 546-567):
+//   packed real FFT of the 2N-sample window -> Hilbert with one half-length inverse -> analytic slice ->
+//   three windowed FFTs (w, w', t w) -> per-bin reassignment -> ordered compaction.
+#include "fft_pow2_device.hpp"
+#include "stft_kernels.hpp"
+
+namespace omx {
+
+namespace {
+struct ReassignConstsP {
+    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
+};
+// spectrogram/processor.rs:459-485 for one bin; returns keep flag (same statement order as reassign_bin in stft_kernels.hip)
+__device__ __forceinline__ bool reassign_bin_p(uint32_t i, v2f b, v2f d, v2f t, float norm, const ReassignConstsP& c,
+                                               omx_spectrogram_point& p) {
+    const float pow = b.x * b.x + b.y * b.y;
+    const float scaled_power = pow * norm;
+    if (scaled_power < 1e-14f) return false;
+    const float inv_pow = 1.0f / pow;
+    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
+    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
+    if (!(freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f)) return false;
+    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
+    p.freq_hz = freq_hz;
+    p.power = scaled_power;
+    return true;
+}
+}  // namespace
+
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastArgs a) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // waves per frame
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* lds = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = lds + 2 * F * G::LDS;                              // [256]
+    uint32_t* scan_all = reinterpret_cast<uint32_t*>(tw2_lds + 256);  // [F][9][WPF]
+    float* hil_all = reinterpret_cast<float*>(scan_all + F * 9 * WPF);  // [F][2]
+
+    const uint32_t chunks = (a.n_cols + F - 1) / F;
+    // XCD-aware block -> (stream, chunk) map (see block_to_stream_column in stft_kernels.hip)
+    const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
+    const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
+    if (s >= a.n_streams) return;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    const unsigned ju = (unsigned)jf;
+    const int lane = threadIdx.x & 63, wf = jf >> 6;
+    v2f* A = lds + (2 * fs) * G::LDS;
+    v2f* B = A + G::LDS;
+    uint32_t* scan = scan_all + fs * 9 * WPF;
+    float* hil = hil_all + fs * 2;
+    const uint32_t col_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = col_raw < a.n_cols;
+    const uint32_t col = in_range ? col_raw : a.n_cols - 1u;  // idle frame slots shadow the last column (barriers stay uniform)
+
+    const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
+    const long long last_nonzero = a.last_nonzero[s];
+    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    const uint32_t p32 = (uint32_t)p0;
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+    // silent fast path (:307-316).  The first frame slot has the smallest p0: if it is silent, all of them are.
+    const uint64_t p0_first = a.tail + (uint64_t)(chunk * F) * a.hop;
+    if (last_nonzero < (long long)p0_first) {
+        if (jf == 0 && in_range) *count_out = 0;
+        return;
+    }
+    const bool silent = last_nonzero < (long long)p0;  // this slot only: computed anyway, emitted empty
+
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);  // `tw4096` carries exp(-2 pi i k / N) for this N
+    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+
+    // ---- 1. packed real FFT of the 2N-sample window (loads for the Hilbert build issued alongside) -----------------
+    v2f v[16], w2n[16];
+    if ((p0 & 1ull) == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            v[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((p32 + 2u * (ju + (unsigned)T * (unsigned)t)) << 2) & bytemask));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qq = p32 + 2u * (ju + (unsigned)T * (unsigned)t);
+            v[t] = v2f{*reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask)),
+                       *reinterpret_cast<const float*>(ring_bytes + (((qq + 1u) << 2) & bytemask))};
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w2n[t] = a.tw8192[ju + (unsigned)T * (unsigned)t];  // exp(-2 pi i k / 2N)
+    __syncthreads();  // tw2_lds
+    fftp<false, LOGN>(v, A, B, jf, tw);  // v[t] = Zf[jf + T t]; last read: B
+
+    // ---- 2. Hilbert transform with one half-length inverse (see stft_kernels.hip for the derivation) ------------------
+    //   Re analytic[n] = N x[n] - X[0]/2 + X[N](-1)^n / 2 ;  Im analytic = inverse REAL FFT of -i X[k]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) A[pad16(jf + T * t)] = v[t];
+    if (jf == 0) {
+        hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[N] / 2   (N = the half-length: the real transform has 2N points)
+    }
+    __syncthreads();
+    v2f y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned k = ju + (unsigned)T * (unsigned)t;
+        const v2f z = v[t];
+        const v2f zr = A[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
+        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
+        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+        y[t] = cmulc(sum, w2n[t]) - cmul(dif, w2n[t]);
+        if (k == 0) y[t] = v2f{0.0f, 0.0f};
+    }
+    const float half_x0 = hil[0], half_xn = hil[1];
+    float pw[16], pdw[16], pxr[16];
+    {
+        const uint32_t qe = p32 + (uint32_t)(N / 2) + ju;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            pw[t] = a.window[ju + (unsigned)T * (unsigned)t];
+            pdw[t] = a.dwindow[ju + (unsigned)T * (unsigned)t];
+            pxr[t] = *reinterpret_cast<const float*>(ring_bytes + (((qe + (unsigned)T * (unsigned)t) << 2) & bytemask));
+        }
+    }
+    // B was last read before the barrier above; A is released by pass 1's barrier (pass 2 writes it)
+    fftp<true, LOGN>(y, B, A, jf, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = jf + T t; last read: A
+
+    // ---- 3. analytic slice s[i] = analytic[N/2 + i], i = jf + T t ---------------------------------------------------------
+    float* imag = reinterpret_cast<float*>(B);  // N floats: Im analytic[N/2 .. 3N/2)
+#pragma unroll
+    for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (jf + T * t - N / 4)) = y[t];
+    __syncthreads();
+    const float parity = (jf & 1) ? -half_xn : half_xn;  // n = N/2 + i has the parity of jf (N/2 and T are even)
+    v2f vb[16], vd[16], vt[16];
+    constexpr float CENTER = (float)(N - 1) * 0.5f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const v2f sv{(float)N * pxr[t] - half_x0 + parity, imag[jf + T * t]};
+        const float w = pw[t], dw = pdw[t];
+        const float wt = ((float)(jf + T * t) - CENTER) * w;  // compute_time_weighted (:601-608)
+        vb[t] = v2f{sv.x * w, sv.y * w};
+        vd[t] = v2f{sv.x * dw, sv.y * dw};
+        vt[t] = v2f{sv.x * wt, sv.y * wt};
+    }
+    __syncthreads();  // imag[] (in B) is consumed
+    fftp_dual<false, LOGN>(vb, vd, A, B, jf, tw);
+    v2f bb[9], bd[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        bb[t] = vb[t];
+        bd[t] = vd[t];
+    }
+    float pn[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+    __syncthreads();  // the paired transform's last pass still reads A and B
+    fftp<false, LOGN>(vt, A, B, jf, tw);
+
+    // ---- 4. reassignment + ordered compaction (bins jf + T t, t < 8, and bin N/2 on thread 0) ----------------------------
+    omx_spectrogram_point pts[9];
+    unsigned long long masks[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+        bool keep = false;
+        if ((t < 8 || jf == 0) && !silent) keep = reassign_bin_p(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]);
+        masks[t] = __ballot(keep);
+        if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
+    }
+    __syncthreads();
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t before = running;
+#pragma unroll
+        for (int w = 0; w < WPF; ++w) {
+            const uint32_t c = scan[t * WPF + w];
+            if (w < wf) before += c;
+            running += c;
+        }
+        if (in_range && ((masks[t] >> lane) & 1ull)) {
+            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
+        }
+    }
+    if (jf == 0 && in_range) *count_out = running;
+}
+
+// ================================================================================================
+// K1p: fused classic column (reference spectrogram/processor.rs:350-380, window.rs:66-88) for W = F = 1024 / 2048 / 4096.
+// Two consecutive columns share one complex FFT (column 2p in the real part, 2p+1 in the imaginary part); a frame slot is
+// T = N/16 threads, so a workgroup emits 2 * 256/T columns.  One LDS buffer per slot (in-place transform) -> 4 workgroups
+// per CU.  HBM-bound by design: hop*C*4 B in, (N/2+1)*2 B out per column.
+// ================================================================================================
+__device__ __forceinline__ uint16_t classic_code(float power) {  // level.rs:28-34 + processor.rs:103-108
+    const float db = power > 0.0f ? fmaxf(logf(power) * 4.3429448f, -140.0f) : -140.0f;
+    float v = roundf((db + 144.0f) * (65535.0f / 156.0f));
+    v = v < 0.0f ? 0.0f : (v > 65535.0f ? 65535.0f : v);
+    return (v == v) ? (uint16_t)v : (uint16_t)0;
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, uint16_t* __restrict__ codes) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;
+    __shared__ v2f lds[F * G::LDS];
+    __shared__ v2f tw2_lds[256];
+    __shared__ float wave_sum[F][2][WPF];
+    const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
+    const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
+    const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
+    if (s >= a.n_streams) return;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    const unsigned ju = (unsigned)jf;
+    const int wf = jf >> 6;
+    v2f* buf = lds + fs * G::LDS;
+    const uint32_t pair_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = pair_raw < pairs;
+    const uint32_t pair = in_range ? pair_raw : pairs - 1u;
+    const uint32_t col_a = 2u * pair;
+    const bool has_b = col_a + 1u < a.n_cols;
+
+    const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
+    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)col_a * a.hop);
+    float xa[16], xb[16], w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t qq = p32 + ju + (unsigned)T * (unsigned)t;
+        xa[t] = *reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask));
+        xb[t] = has_b ? *reinterpret_cast<const float*>(ring_bytes + (((qq + a.hop) << 2) & bytemask)) : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);
+    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    float norm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) norm[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+    // window.rs:80-84 mean (tree order; the generic kernel keeps the reference's sequential order)
+    float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        sa += xa[t];
+        sb += xb[t];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+    }
+    if ((jf & 63) == 0) {
+        wave_sum[fs][0][wf] = sa;
+        wave_sum[fs][1][wf] = sb;
+    }
+    __syncthreads();
+    float ta = 0.0f, tb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+        ta += wave_sum[fs][0][i];
+        tb += wave_sum[fs][1][i];
+    }
+    const float mean_a = ta / (float)N, mean_b = tb / (float)N;
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    fftp_inplace<false, LOGN>(v, buf, jf, tw);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) buf[pad16(jf + T * t)] = v[t];
+    __syncthreads();
+    if (!in_range) return;
+    uint16_t* out_a = codes + ((uint64_t)s * a.n_cols + col_a) * a.column_stride;
+    uint16_t* out_b = out_a + a.column_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t == 8 && jf != 0) break;
+        const uint32_t k = ju + (unsigned)T * (unsigned)t;
+        const v2f z = v[t];
+        const v2f zr = buf[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
+        const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr) / 2
+        const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr) / (2i)
+        out_a[k] = classic_code((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t]);
+        if (has_b) out_b[k] = classic_code((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t]);
+    }
+}
+
+template <int LOGN>
+static void launch_classic(const StftFastArgs& a, uint16_t* codes, hipStream_t stream) {
+    constexpr int F = FftGeom<LOGN>::FRAMES;
+    const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
+    hipLaunchKernelGGL(stft_classic_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), 0, stream, a, codes);
+}
+void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t fft_size, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    switch (fft_size) {
+        case 1024: launch_classic<10>(a, codes, stream); break;
+        case 2048: launch_classic<11>(a, codes, stream); break;
+        case 4096: launch_classic<12>(a, codes, stream); break;
+        default: break;
+    }
+}
+
+template <int LOGN>
+static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)(2 * F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) + (size_t)F * 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_kernel<LOGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const uint32_t chunks = (a.n_cols + F - 1) / F;
+    hipLaunchKernelGGL(stft_reassigned_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
+}
+
+// fft_size = 1024, 2048 or 4096 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
+void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    switch (fft_size) {
+        case 1024: launch_pow2<10>(a, stream); break;
+        case 2048: launch_pow2<11>(a, stream); break;
+        case 4096: launch_pow2<12>(a, stream); break;
+        default: break;
+    }
+}
+
+}  // namespace omx

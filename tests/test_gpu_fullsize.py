@@ -154,3 +154,46 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
         assert abs(h.period - FS / op.last_cycle_rate()) <= 1e-4 * h.period
         flat = np.concatenate([samples[c, :h.samples_per_channel] for c in range(h.channels)])
         assert np.abs(flat - wo.samples).max() <= 2e-3
+
+
+@pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256)])
+def test_fused_small_windows_full_size_shift_partition_and_oracle(omx, oracle, W, hop):
+    """The reference's DEFAULT spectrogram shape (2048 / hop 64, processor.rs:58-59) and 1024 / 256 go through the size-templated
+    fused kernel (several columns per workgroup): shift invariance across frame slots / workgroups / XCDs, partition
+    invariance, the generic kernel and the oracle as cross-checks."""
+    import torch
+    S, cols = 64, 1026                                        # not a multiple of the 2 / 4 columns a workgroup carries
+    frames = 2 * W + hop * (cols - 1)
+    base = cfg2_pcm(11, frames + hop * (S - 1))
+    pcm = np.stack([base[k * hop:k * hop + frames] for k in range(S)])
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=True, history_length=8192)
+    d_pcm = torch.from_numpy(pcm).to("cuda:0")
+    pos = capi.positions_fallback(2)
+    one = banks.SpectrogramBank(omx, cfg, S)
+    up = one.process_device(d_pcm.data_ptr(), frames, 2, FS, pos)
+    assert up.n_columns == cols and up.column_stride == W // 2 + 1
+    counts, points = spectrogram_outputs(torch, up)
+    for k in (1, 2, 3, 5, 8, 63):
+        assert torch.equal(counts[k, :cols - k], counts[0, k:]), k
+        assert torch.equal(points[k, :cols - k], points[0, k:]), k
+    parts = banks.SpectrogramBank(omx, cfg, S)
+    got_c, got_p, at = [], [], 0
+    for n in (2 * W + hop * 301 + 13, hop // 2, frames - (2 * W + hop * 301 + 13) - hop // 2):
+        chunk = d_pcm[:, at:at + n].contiguous()
+        u = parts.process_device(chunk.data_ptr(), n, 2, FS, pos)
+        at += n
+        if u is not None:
+            c, p = spectrogram_outputs(torch, u)
+            got_c.append(c)
+            got_p.append(p)
+    assert torch.equal(torch.cat(got_c, 1), counts) and torch.equal(torch.cat(got_p, 1), points)
+    gen = banks.SpectrogramBank(omx, cfg, 2)
+    gen.set_option(capi.OPT_FORCE_GENERIC, 1)
+    gen.process_device(d_pcm[:2].contiguous().data_ptr(), frames, 2, FS, pos)
+    for k, c in ((0, 0), (1, 517), (1, cols - 1)):
+        at = (k + c) * hop
+        want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(base[at:at + 2 * W].reshape(-1), 2, FS)).new_columns[0]
+        for bank in (one, gen):
+            got = bank.fetch_column(k, c, capi.COLUMN_REASSIGNED, W // 2 + 1)
+            m = reassigned_column_metrics(got, want, FS, hop)
+            assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, (m, bank is gen)

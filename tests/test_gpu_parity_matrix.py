@@ -6,7 +6,7 @@ import pytest
 from openmeters_amd import capi
 from openmeters_amd.capi import (AudioBlock, SpectrogramConfig, SpectrogramProcessor, SpectrumConfig, SpectrumProcessor)
 from test_gpu_parity import check_reassigned, check_trace, stream_pcm
-from parity import classic_column_metrics
+from parity import check_classic
 
 pytestmark = pytest.mark.gpu
 WINDOWS = [capi.WINDOW_RECTANGULAR, capi.WINDOW_HANN, capi.WINDOW_HAMMING, capi.WINDOW_BLACKMAN, capi.WINDOW_BLACKMAN_HARRIS]
@@ -40,9 +40,7 @@ def test_classic_and_spectrum_every_window_kind(omx, oracle, window):
     cfg = SpectrogramConfig(fft_size=2048, hop_size=256, window=window, use_reassignment=False, history_length=64)
     g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
     assert len(g.new_columns) == len(w.new_columns) > 0
-    for h, o in zip(g.new_columns, w.new_columns):
-        m = classic_column_metrics(h, o)
-        assert m["max_code_diff"] <= 1 and m["n_diff"] <= max(4, m["n"] // 50), m
+    check_classic(g.new_columns, w.new_columns)
     for N in (4096, 512):
         sc = SpectrumConfig(fft_size=N, hop_size=N // 4, window=window, source=capi.CH_LEFT, secondary_source=capi.CH_SIDE)
         gs, ws = SpectrumProcessor(omx, sc).process_block(blk), SpectrumProcessor(oracle, sc).process_block(blk)
