@@ -3,12 +3,12 @@
 //                          (reference src/util/audio/window.rs:66-88, src/visuals/spectrum/processor.rs:215-244)
 //   K3b spectrum_levels    per-bin None / Exponential / PeakHold recurrence over hops + raw and
 //                          A-weighted dB (reference spectrum/processor.rs:349-402)
-#include "fft_device.hpp"
+#include "fft_pow2_device.hpp"
 #include "stft_kernels.hpp"
 
 namespace omx {
 
-// ---- K3a fast: N = 4096.  Two consecutive hops of one (stream, trace) share one complex FFT: hop 2p is
+// ---- K3a fast: N = 1024 / 2048 / 4096 (size-templated FFT, 4 / 2 / 1 transforms per workgroup).  Two consecutive hops of one (stream, trace) share one complex FFT: hop 2p is
 // the real part, hop 2p+1 the imaginary part, X_a = (Z[k] + conj Z[N-k])/2, X_b = (Z[k] - conj Z[N-k])/(2i).
 // With AveragingMode::None the dB conversion (:391-401) is fused here and the traces are written directly;
 // otherwise the per-hop power goes to the scratch buffer for spectrum_levels_kernel.
@@ -30,18 +30,25 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
     }
 }
 
-__global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerArgs a) {
-    __shared__ v2f A[FFT4096_LDS];
+template <int LOGN>
+__global__ __launch_bounds__(256) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
+    __shared__ v2f lds[F * G::LDS];
     __shared__ v2f tw2_lds[256];
-    __shared__ float wave_sum[2][4];
-    const uint32_t pairs = (a.n_hops + 1) / 2;
-    const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * pairs + pair, pair fastest
-    const uint32_t pr = item % pairs, st = item / pairs;
+    __shared__ float wave_sum[F][2][WPF];
+    const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F;
+    const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * chunks + chunk, chunk fastest
+    const uint32_t chunk = item % chunks, st = item / chunks;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T, wf = jf >> 6;
+    const unsigned ju = (unsigned)jf;
+    v2f* A = lds + fs * G::LDS;
+    const uint32_t pair_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = pair_raw < pairs;
+    const uint32_t pr = in_range ? pair_raw : pairs - 1u;  // idle slots shadow the last pair (barriers stay uniform)
     const uint32_t h0 = 2 * pr;
     const bool has_b = h0 + 1 < a.n_hops;
-    const int j = threadIdx.x;
-    const unsigned ju = threadIdx.x;
     // every global load of the workgroup is issued up front (unsigned 32-bit offsets: SGPR base + VGPR offset
     // addressing), so one memory round trip covers the ring, the window, the twiddles and the per-bin tables
     const char* ring = reinterpret_cast<const char*>(a.ring[tr] + (uint64_t)s * a.cap);
@@ -50,24 +57,20 @@ __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerA
     float xa[16], xb[16], w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const uint32_t q = p32 + ju + 256u * (unsigned)t;
+        const uint32_t q = p32 + ju + (unsigned)T * (unsigned)t;
         xa[t] = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
         xb[t] = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + 256u * (unsigned)t];
-    using TW = TwiddleSource<true, true>;
-    TW tw;
-    tw.j = ju;
-    tw.tw3_global = a.tw4096;
+    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
+    TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
-#pragma unroll
-    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
-    tw2_lds[j] = a.tw256[ju];
+    tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N
+    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
     float norm[9], aw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const unsigned k = (t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u;
+        const unsigned k = (t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
         norm[t] = a.bin_norm[k];
         aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
     }
@@ -83,31 +86,37 @@ __global__ __launch_bounds__(256) void spectrum_power_4096_kernel(SpectrumPowerA
         sa += __shfl_xor(sa, off);
         sb += __shfl_xor(sb, off);
     }
-    if ((j & 63) == 0) {
-        wave_sum[0][j >> 6] = sa;
-        wave_sum[1][j >> 6] = sb;
+    if ((jf & 63) == 0) {
+        wave_sum[fs][0][wf] = sa;
+        wave_sum[fs][1][wf] = sb;
     }
     __syncthreads();
-    const float mean_a = (wave_sum[0][0] + wave_sum[0][1] + wave_sum[0][2] + wave_sum[0][3]) / 4096.0f;
-    const float mean_b = (wave_sum[1][0] + wave_sum[1][1] + wave_sum[1][2] + wave_sum[1][3]) / 4096.0f;
+    float ta = 0.0f, tb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+        ta += wave_sum[fs][0][i];
+        tb += wave_sum[fs][1][i];
+    }
+    const float mean_a = ta / (float)N, mean_b = tb / (float)N;
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
-    fft4096t<false, false>(v, A, A, j, tw);
+    fftp_inplace<false, LOGN>(v, A, jf, tw);
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 16; ++t) A[pad16(j + 256 * t)] = v[t];
+    for (int t = 0; t < 16; ++t) A[pad16(jf + T * t)] = v[t];
     __syncthreads();
+    if (!in_range) return;
     float* out0 = nullptr;
     if (a.fused_db)
         out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
     const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        if (t == 8 && j != 0) break;
-        const uint32_t k = ju + 256u * (unsigned)t;
+        if (t == 8 && jf != 0) break;
+        const uint32_t k = ju + (unsigned)T * (unsigned)t;
         const v2f z = v[t];
-        const v2f zr = A[pad16((int)((4096u - k) & 4095u))];
+        const v2f zr = A[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
         const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
@@ -172,8 +181,16 @@ void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t g
     const uint64_t total = (uint64_t)a.n_streams * a.n_traces * a.n_hops;
     if (total == 0) return;
     const uint64_t pairs = (uint64_t)a.n_streams * a.n_traces * ((a.n_hops + 1) / 2);
-    if (fast4096) hipLaunchKernelGGL(spectrum_power_4096_kernel, dim3((uint32_t)pairs), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(spectrum_power_generic_kernel, dim3(generic_wgs), dim3(256), 0, stream, a);
+    const uint32_t hop_pairs = (a.n_hops + 1) / 2, st = a.n_streams * a.n_traces;
+    (void)pairs;
+    if (fast4096 && a.fft_size == 4096)
+        hipLaunchKernelGGL(spectrum_power_pow2_kernel<12>, dim3(st * hop_pairs), dim3(256), 0, stream, a);
+    else if (fast4096 && a.fft_size == 2048)
+        hipLaunchKernelGGL(spectrum_power_pow2_kernel<11>, dim3(st * ((hop_pairs + 1) / 2)), dim3(256), 0, stream, a);
+    else if (fast4096 && a.fft_size == 1024)
+        hipLaunchKernelGGL(spectrum_power_pow2_kernel<10>, dim3(st * ((hop_pairs + 3) / 4)), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(spectrum_power_generic_kernel, dim3(generic_wgs), dim3(256), 0, stream, a);
 }
 
 // ---- K3b: per-bin recurrences + dB ------------------------------------------------------------------

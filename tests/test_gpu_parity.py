@@ -154,7 +154,7 @@ def check_trace(x, y, floor=-100.0):
 
 
 @pytest.mark.parametrize("mode,param", [(capi.AVG_NONE, 0.0), (capi.AVG_EXPONENTIAL, 0.5), (capi.AVG_PEAK_HOLD, 12.0)])
-@pytest.mark.parametrize("N,hop", [(4096, 256), (1024, 512)])
+@pytest.mark.parametrize("N,hop", [(4096, 256), (1024, 512), (2048, 128), (512, 128)])
 def test_spectrum_matches_oracle(omx, oracle, mode, param, N, hop):
     cfg = SpectrumConfig(fft_size=N, hop_size=hop, averaging_mode=mode, averaging_param=param, source=capi.CH_MID,
                          secondary_source=capi.CH_SIDE, floor_db=-100.0)
