@@ -1,0 +1,137 @@
+"""Randomised operation sequences (seeded) against the oracle: block partition, config changes, resets, sample-rate and channel
+changes, silence — the host-side state machines of the HIP processors must make the same decisions as the reference
+restatement at every step (column counts, `reset` flags, None vs Some), and the emitted data must stay within tolerance."""
+import numpy as np
+import pytest
+
+from openmeters_amd import capi
+from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
+                                 SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
+                                 WaveformProcessor)
+from parity import check_classic, classic_column_metrics, reassigned_column_metrics
+from test_gpu_parity import check_trace
+
+pytestmark = pytest.mark.gpu
+
+
+def signal(rng, frames, channels, t0, rate, silent):
+    if silent:
+        return np.zeros((frames, channels), np.float32)
+    t = (t0 + np.arange(frames)) / rate
+    x = 0.4 * np.sin(2 * np.pi * (300.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t)) * t) + 0.002 * rng.standard_normal(frames)
+    out = np.stack([x * (1.0 - 0.13 * c) for c in range(channels)], 1)
+    return out.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_spectrogram_random_operation_sequences(omx, oracle, seed):
+    rng = np.random.default_rng(seed)
+    sizes = [256, 512, 1024, 2048, 4096]
+    cfg = SpectrogramConfig(fft_size=int(rng.choice(sizes)), hop_size=int(rng.choice([64, 100, 256, 777])),
+                            use_reassignment=bool(rng.integers(2)), history_length=int(rng.choice([3, 64, 8192])))
+    a, b = SpectrogramProcessor(omx, cfg), SpectrogramProcessor(oracle, cfg)
+    rate, channels, t0, produced = 48000.0, 2, 0, 0
+    for step in range(45):
+        op = rng.random()
+        if op < 0.08:
+            cfg = SpectrogramConfig(sample_rate=rate, fft_size=int(rng.choice(sizes)), hop_size=int(rng.choice([64, 100, 256, 777])),
+                                    window=int(rng.integers(5)), use_reassignment=bool(rng.integers(2)),
+                                    zero_padding_factor=int(rng.choice([1, 1, 1, 2])), history_length=int(rng.choice([3, 64, 8192])))
+            a.update_config(cfg)
+            b.update_config(cfg)
+            ca, cb = a.config(), b.config()
+            assert (ca.fft_size, ca.hop_size, ca.use_reassignment, ca.zero_padding_factor) == (cb.fft_size, cb.hop_size,
+                                                                                                 cb.use_reassignment, cb.zero_padding_factor)
+            continue
+        if op < 0.12:
+            a.reset_audio()
+            b.reset_audio()
+            continue
+        if op < 0.16:
+            rate = float(rng.choice([44100.0, 48000.0, 96000.0]))
+        if op < 0.20:
+            channels = int(rng.choice([1, 2, 6]))
+        frames = int(rng.choice([0, 1, 37, 256, 256, 1024, 3000, 9000]))
+        pcm = signal(rng, frames, channels, t0, rate, silent=rng.random() < 0.15)
+        t0 += frames
+        blk = AudioBlock(pcm.reshape(-1), channels, rate)
+        g, w = a.process_block(blk), b.process_block(blk)
+        assert (g is None) == (w is None), step
+        if w is None:
+            continue
+        assert len(g.new_columns) == len(w.new_columns) and g.reset == w.reset and g.fft_size == w.fft_size, step
+        assert g.hop_size == w.hop_size and g.history_length == w.history_length and g.sample_rate == w.sample_rate
+        produced += len(w.new_columns)
+        if not w.new_columns:
+            continue
+        if w.new_columns[0].ndim == 2:   # reassigned
+            assert g.reassigned_power_scale == w.reassigned_power_scale
+            for h, o in zip(g.new_columns, w.new_columns):
+                if len(o) == 0 or len(h) == 0:
+                    assert len(o) < 8 and len(h) < 8   # silent / floor-level column on both sides
+                    continue
+                if o[:, 2].max() < 1e-10:   # strongest bin within 40 dB of the 1e-14 floor: which floor-level bins survive
+                    assert abs(len(o) - len(h)) <= max(4, len(o) // 4)   # is rounding noise on both sides
+                    continue
+                m = reassigned_column_metrics(h, o, rate, w.hop_size)
+                assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4, (step, m)
+                # a bin present on one side only must sit on the 1e-14 keep-floor (relative to a weak column that is > 1e-8)
+                assert m["orphan"] < 1e-8 or m["orphan"] * float(o[:, 2].max()) < 1e-12, (step, m)
+        elif w.fft_size in (1024, 2048, 4096):
+            check_classic(g.new_columns, w.new_columns)
+        else:
+            for h, o in zip(g.new_columns, w.new_columns):
+                assert classic_column_metrics(h, o)["max_code_diff"] <= 1
+    assert produced > 0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_meter_processors_random_block_sequences(omx, oracle, seed):
+    """spectrum / loudness / stereometer / waveform fed the same irregular block sequence with format changes"""
+    rng = np.random.default_rng(seed)
+    sc = SpectrumConfig(fft_size=int(rng.choice([512, 1024, 4096])), hop_size=int(rng.choice([128, 256, 1000])),
+                        averaging_mode=int(rng.integers(3)), averaging_param=float(rng.choice([0.5, 0.9, 12.0])),
+                        source=capi.CH_LEFT, secondary_source=capi.CH_SIDE)
+    if sc.averaging_mode == capi.AVG_EXPONENTIAL:
+        sc.averaging_param = 0.7
+    pairs = [(SpectrumProcessor(omx, sc), SpectrumProcessor(oracle, sc)),
+             (LoudnessProcessor(omx, LoudnessConfig()), LoudnessProcessor(oracle, LoudnessConfig())),
+             (StereometerProcessor(omx, StereometerConfig(analyze_bands=True)), StereometerProcessor(oracle, StereometerConfig(analyze_bands=True))),
+             (WaveformProcessor(omx, WaveformConfig(scroll_speed=200.0, analyze_bands=True, track_history=True)),
+              WaveformProcessor(oracle, WaveformConfig(scroll_speed=200.0, analyze_bands=True, track_history=True)))]
+    rate, channels, t0 = 48000.0, 2, 0
+    for step in range(40):
+        op = rng.random()
+        if op < 0.06:
+            for g, w in pairs:
+                g.reset_audio()
+                w.reset_audio()
+            continue
+        if op < 0.10:
+            rate = float(rng.choice([44100.0, 48000.0, 96000.0]))
+        if op < 0.14:
+            channels = int(rng.choice([1, 2, 6]))
+        frames = int(rng.choice([0, 1, 100, 256, 256, 960, 2048, 5000]))
+        pcm = signal(rng, frames, channels, t0, rate, silent=rng.random() < 0.15)
+        t0 += frames
+        blk = AudioBlock(pcm.reshape(-1), channels, rate)
+        (sg, sw), (lg, lw), (tg, tw), (wg, ww) = [(g.process_block(blk), w.process_block(blk)) for g, w in pairs]
+        assert (sg is None) == (sw is None) and (lg is None) == (lw is None) and (tg is None) == (tw is None), step
+        if sw is not None:
+            assert np.array_equal(sg.frequency_bins, sw.frequency_bins)
+            for tr in range(2):
+                for k in range(2):
+                    if len(sw.traces[tr][k]):
+                        check_trace(sg.traces[tr][k], sw.traces[tr][k])
+        if lw is not None:
+            assert lg.channel_count == lw.channel_count and lg.positions == lw.positions
+            assert abs(lg.momentary_loudness - lw.momentary_loudness) <= 1e-4 and abs(lg.short_term_loudness - lw.short_term_loudness) <= 1e-4
+            assert np.abs(lg.true_peak_db - lw.true_peak_db).max() <= 1e-4 and np.abs(lg.rms_fast_db - lw.rms_fast_db).max() <= 1e-4
+        if tw is not None:
+            assert np.abs(tg.correlations - tw.correlations).max() <= 1e-6
+            assert all(x.shape == y.shape for x, y in zip(tg.points, tw.points))
+        assert (wg is None) == (ww is None)
+        if ww is not None:
+            assert wg.reset == ww.reset and wg.columns.shape == ww.columns.shape, step
+            if len(ww.columns):
+                assert np.array_equal(wg.columns[:, :, :2].view(np.uint32), ww.columns[:, :, :2].view(np.uint32))
