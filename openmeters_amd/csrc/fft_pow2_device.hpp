@@ -19,6 +19,20 @@ struct FftGeom {
     static constexpr int FRAMES = 256 / T; // transforms per 256-thread workgroup
 };
 
+// Barrier between the threads of ONE transform.  With T = 64 a transform lives in a single wavefront, whose LDS
+// instructions execute in order: no s_barrier is needed, only a fence that keeps the compiler from reordering the LDS
+// accesses — the 4 transforms of a workgroup then run free of each other.
+template <int LOGN>
+__device__ __forceinline__ void frame_sync() {
+    if constexpr (FftGeom<LOGN>::T == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // natural-order 8-point DFT in place (radix-2 over two dft4)
 template <bool INV>
 __device__ __forceinline__ void dft8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4, v2f& a5, v2f& a6, v2f& a7) {
@@ -104,9 +118,9 @@ __device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int j
 template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp(v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw) {
     fftp_pass1<INV, LOGN>(v, first, jf);
-    __syncthreads();
+    frame_sync<LOGN>();
     fftp_pass2<INV, LOGN>(first, second, jf, tw);
-    __syncthreads();
+    frame_sync<LOGN>();
     fftp_pass3<INV, LOGN>(v, second, jf, tw);
 }
 // In place in one buffer (one extra barrier in pass 2): half the LDS of the ping-pong form, for kernels that run a single
@@ -115,7 +129,7 @@ template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, const TwiddlesPow2<LOGN>& tw) {
     using G = FftGeom<LOGN>;
     fftp_pass1<INV, LOGN>(v, buf, jf);
-    __syncthreads();
+    frame_sync<LOGN>();
     {
         v2f a[16];
 #pragma unroll
@@ -124,12 +138,12 @@ __device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, con
 #pragma unroll
         for (int t = 1; t < 16; ++t) a[t] = twmul<INV>(a[t], tw.tw2[k * (unsigned)t]);
         dft16<INV>(a);
-        __syncthreads();
+        frame_sync<LOGN>();
         const int base = (jf >> 4) * 272 + (int)k;
 #pragma unroll
         for (int t = 0; t < 16; ++t) buf[base + 17 * t] = a[DFT16_OUT(t)];
     }
-    __syncthreads();
+    frame_sync<LOGN>();
     fftp_pass3<INV, LOGN>(v, buf, jf, tw);
 }
 // Two transforms at once, in place on their own buffers (shared barriers).
@@ -138,7 +152,7 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
     using G = FftGeom<LOGN>;
     fftp_pass1<INV, LOGN>(v0, A, jf);
     fftp_pass1<INV, LOGN>(v1, B, jf);
-    __syncthreads();
+    frame_sync<LOGN>();
     {
         v2f a[16], b[16];
 #pragma unroll
@@ -155,7 +169,7 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
         }
         dft16<INV>(a);
         dft16<INV>(b);
-        __syncthreads();
+        frame_sync<LOGN>();
         const int base = (jf >> 4) * 272 + (int)k;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -163,7 +177,7 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
             B[base + 17 * t] = b[DFT16_OUT(t)];
         }
     }
-    __syncthreads();
+    frame_sync<LOGN>();
     fftp_pass3<INV, LOGN>(v0, A, jf, tw);
     fftp_pass3<INV, LOGN>(v1, B, jf, tw);
 }

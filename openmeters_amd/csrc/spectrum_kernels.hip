@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void spectrum_power_pow2_kernel(SpectrumPowerA
         wave_sum[fs][0][wf] = sa;
         wave_sum[fs][1][wf] = sb;
     }
-    __syncthreads();
+    __syncthreads();  // wave sums and tw2_lds (shared by every frame slot)
     float ta = 0.0f, tb = 0.0f;
 #pragma unroll
     for (int i = 0; i < WPF; ++i) {
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void spectrum_power_pow2_kernel(SpectrumPowerA
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
     fftp_inplace<false, LOGN>(v, A, jf, tw);
-    __syncthreads();
+    frame_sync<LOGN>();
 #pragma unroll
     for (int t = 0; t < 16; ++t) A[pad16(jf + T * t)] = v[t];
-    __syncthreads();
+    frame_sync<LOGN>();
     if (!in_range) return;
     float* out0 = nullptr;
     if (a.fused_db)

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) w2n[t] = a.tw8192[ju + (unsigned)T * (unsigned)t];  // exp(-2 pi i k / 2N)
-    __syncthreads();  // tw2_lds
+    __syncthreads();  // tw2_lds (shared by every frame slot)
     fftp<false, LOGN>(v, A, B, jf, tw);  // v[t] = Zf[jf + T t]; last read: B
 
     // ---- 2. Hilbert transform with one half-length inverse (see stft_kernels.hip for the derivation) ------------------
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
         hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
         hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[N] / 2   (N = the half-length: the real transform has 2N points)
     }
-    __syncthreads();
+    frame_sync<LOGN>();
     v2f y[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
     float* imag = reinterpret_cast<float*>(B);  // N floats: Im analytic[N/2 .. 3N/2)
 #pragma unroll
     for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (jf + T * t - N / 4)) = y[t];
-    __syncthreads();
+    frame_sync<LOGN>();
     const float parity = (jf & 1) ? -half_xn : half_xn;  // n = N/2 + i has the parity of jf (N/2 and T are even)
     v2f vb[16], vd[16], vt[16];
     constexpr float CENTER = (float)(N - 1) * 0.5f;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
         vd[t] = v2f{sv.x * dw, sv.y * dw};
         vt[t] = v2f{sv.x * wt, sv.y * wt};
     }
-    __syncthreads();  // imag[] (in B) is consumed
+    frame_sync<LOGN>();  // imag[] (in B) is consumed
     fftp_dual<false, LOGN>(vb, vd, A, B, jf, tw);
     v2f bb[9], bd[9];
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
     float pn[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
-    __syncthreads();  // the paired transform's last pass still reads A and B
+    frame_sync<LOGN>();  // the paired transform's last pass still reads A and B
     fftp<false, LOGN>(vt, A, B, jf, tw);
 
     // ---- 4. reassignment + ordered compaction (bins jf + T t, t < 8, and bin N/2 on thread 0) ----------------------------
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
         masks[t] = __ballot(keep);
         if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
     }
-    __syncthreads();
+    frame_sync<LOGN>();
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
     uint32_t running = 0;
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, 
         wave_sum[fs][0][wf] = sa;
         wave_sum[fs][1][wf] = sb;
     }
-    __syncthreads();
+    __syncthreads();  // wave sums and tw2_lds (shared by every frame slot)
     float ta = 0.0f, tb = 0.0f;
 #pragma unroll
     for (int i = 0; i < WPF; ++i) {
@@ -272,10 +272,10 @@ __global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, 
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
     fftp_inplace<false, LOGN>(v, buf, jf, tw);
-    __syncthreads();
+    frame_sync<LOGN>();
 #pragma unroll
     for (int t = 0; t < 16; ++t) buf[pad16(jf + T * t)] = v[t];
-    __syncthreads();
+    frame_sync<LOGN>();
     if (!in_range) return;
     uint16_t* out_a = codes + ((uint64_t)s * a.n_cols + col_a) * a.column_stride;
     uint16_t* out_b = out_a + a.column_stride;
