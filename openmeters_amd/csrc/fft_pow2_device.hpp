@@ -1,7 +1,8 @@
-// Size-templated variant of the register / LDS FFT of fft_device.hpp for N = 1024, 2048, 4096 complex points.
-// One transform is carried by T = N / 16 threads (64, 128, 256), 16 complex values per thread, so a 256-thread
-// workgroup runs 4, 2 or 1 transforms side by side.  Three Stockham passes: radix 16, radix 16, radix R3 = N / 256
-// (4, 8, 16); in the last pass a thread does 16 / R3 butterflies.  Same padded LDS layout, same element convention as
+// Size-templated variant of the register / LDS FFT of fft_device.hpp for N = 1024 ... 16384 complex points.
+// One transform is carried by T = N / 16 threads, 16 complex values per thread: a 256-thread workgroup runs 4, 2 or 1
+// transforms of 1024 / 2048 / 4096 points side by side; 8192 and 16384 points take a 512- / 1024-thread workgroup.
+// Stockham passes: radix 16, 16, R3 = N / 256 (4, 8, 16) up to 4096 points; radix 16, 16, 16, R3 = N / 4096 (2, 4) above.
+// In the last pass a thread does 16 / R3 butterflies.  Same padded LDS layout, same element convention as
 // the 4096-point code: thread jf holds x[jf + T u] in v[u] on entry and X[jf + T u] in v[u] on return.
 #pragma once
 #include "fft_device.hpp"
@@ -10,13 +11,15 @@ namespace omx {
 
 template <int LOGN>
 struct FftGeom {
-    static_assert(LOGN >= 10 && LOGN <= 12, "N = 1024, 2048 or 4096");
+    static_assert(LOGN >= 10 && LOGN <= 14, "N = 1024 ... 16384");
     static constexpr int N = 1 << LOGN;
-    static constexpr int T = N / 16;       // threads per transform
-    static constexpr int R3 = N / 256;     // radix of the last pass
-    static constexpr int M = 16 / R3;      // butterflies per thread in the last pass
-    static constexpr int LDS = N + N / 16; // padded complex slots per buffer
-    static constexpr int FRAMES = 256 / T; // transforms per 256-thread workgroup
+    static constexpr int T = N / 16;                 // threads per transform
+    static constexpr int PASSES = LOGN <= 12 ? 3 : 4;  // radix 16 . 16 . R3   or   16 . 16 . 16 . R3
+    static constexpr int R3 = PASSES == 3 ? N / 256 : N / 4096;  // radix of the LAST pass (2, 4, 8 or 16)
+    static constexpr int M = 16 / R3;                // butterflies per thread in the last pass
+    static constexpr int LDS = N + N / 16;           // padded complex slots per buffer
+    static constexpr int WG = T > 256 ? T : 256;     // threads per workgroup (N = 8192: 512, N = 16384: 1024)
+    static constexpr int FRAMES = WG / T;            // transforms per workgroup
 };
 
 // Barrier between the threads of ONE transform.  With T = 64 a transform lives in a single wavefront, whose LDS
@@ -58,12 +61,14 @@ template <int LOGN>
 struct TwiddlesPow2 {
     using G = FftGeom<LOGN>;
     const v2f* tw2;  // exp(-2 pi i k / 256), k < 256
-    v2f tw3[15];     // tw3[u - 1] = exp(-2 pi i t b / N), u = m + M t, b = jf + T m  (unused while t == 0)
-    __device__ __forceinline__ void load(const v2f* twN, unsigned jf) {
+    const v2f* twN;  // exp(-2 pi i k / N), k < N (global): pass-3 twiddles of the four-pass sizes are read from it at use
+    v2f tw3[15];     // last pass: tw3[u - 1] = exp(-2 pi i t b / N), u = m + M t, b = jf + T m  (unused while t == 0)
+    __device__ __forceinline__ void load(const v2f* table, unsigned jf) {
+        twN = table;
 #pragma unroll
         for (int u = 1; u < 16; ++u) {
             const unsigned t = (unsigned)(u / G::M), m = (unsigned)(u % G::M);
-            tw3[u - 1] = t ? twN[t * (jf + (unsigned)G::T * m)] : v2f{1.0f, 0.0f};
+            tw3[u - 1] = t ? table[t * (jf + (unsigned)G::T * m)] : v2f{1.0f, 0.0f};
         }
     }
 };
@@ -106,6 +111,12 @@ __device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int j
         dft8<INV>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]);
 #pragma unroll
         for (int u = 0; u < 16; ++u) out[u] = v[u];
+    } else if constexpr (G::R3 == 2) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            out[m] = v[m] + v[m + 8];
+            out[m + 8] = v[m] - v[m + 8];
+        }
     } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) dft4<INV>(v[m], v[m + 4], v[m + 8], v[m + 12]);
@@ -117,11 +128,29 @@ __device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int j
 // guarantees nobody still reads `first` and that `second` is free.  All 256 threads of the workgroup must call it together.
 template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp(v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw) {
+    static_assert(FftGeom<LOGN>::PASSES == 3, "ping-pong form: three-pass sizes only");
     fftp_pass1<INV, LOGN>(v, first, jf);
     frame_sync<LOGN>();
     fftp_pass2<INV, LOGN>(first, second, jf, tw);
     frame_sync<LOGN>();
     fftp_pass3<INV, LOGN>(v, second, jf, tw);
+}
+// Third pass of the four-pass sizes (Ns = 256, radix 16): reads y[jf + T t], twiddle exp(-+2 pi i t (jf % 256) / 4096), writes
+// z[(jf / 256) * 4096 + jf % 256 + 256 t] in place (barrier between the loads and the stores).
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_mid3_inplace(v2f* buf, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    v2f a[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a[t] = buf[pad16(jf + G::T * t)];
+    const unsigned k = (unsigned)jf & 255u;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) a[t] = twmul<INV>(a[t], tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)]);
+    dft16<INV>(a);
+    frame_sync<LOGN>();
+    const int base = (jf >> 8) * 4352 + (int)k + (int)(k >> 4);  // pad16(4096 q + k + 256 t) = 4352 q + k + k/16 + 272 t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) buf[base + 272 * t] = a[DFT16_OUT(t)];
 }
 // In place in one buffer (one extra barrier in pass 2): half the LDS of the ping-pong form, for kernels that run a single
 // transform per frame slot (classic columns, spectrum).
@@ -144,12 +173,17 @@ __device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, con
         for (int t = 0; t < 16; ++t) buf[base + 17 * t] = a[DFT16_OUT(t)];
     }
     frame_sync<LOGN>();
+    if constexpr (G::PASSES == 4) {
+        fftp_mid3_inplace<INV, LOGN>(buf, jf, tw);
+        frame_sync<LOGN>();
+    }
     fftp_pass3<INV, LOGN>(v, buf, jf, tw);
 }
 // Two transforms at once, in place on their own buffers (shared barriers).
 template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int jf, const TwiddlesPow2<LOGN>& tw) {
     using G = FftGeom<LOGN>;
+    static_assert(G::PASSES == 3, "paired form: three-pass sizes only");
     fftp_pass1<INV, LOGN>(v0, A, jf);
     fftp_pass1<INV, LOGN>(v1, B, jf);
     frame_sync<LOGN>();

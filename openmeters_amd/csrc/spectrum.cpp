@@ -69,7 +69,7 @@ void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
     d_window_.upload(window, stream);
     d_bin_norm_.upload(fft_bin_normalization(window, N), stream);
     d_tw_fft_.upload(twiddle_table(N, std::max<size_t>(N / 2, 1)), stream);
-    fast4096_ = N == 4096 || N == 2048 || N == 1024;  // fused kernel sizes
+    fast4096_ = N == 16384 || N == 8192 || N == 4096 || N == 2048 || N == 1024;  // fused kernel sizes (every FFT size the GUI offers)
     if (fast4096_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
         d_tw4096_.upload(twiddle_table(N, N), stream);  // exp(-2 pi i k / N)

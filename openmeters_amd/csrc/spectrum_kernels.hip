@@ -31,12 +31,13 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
+__global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
-    __shared__ v2f lds[F * G::LDS];
-    __shared__ v2f tw2_lds[256];
-    __shared__ float wave_sum[F][2][WPF];
+    extern __shared__ __attribute__((aligned(16))) unsigned char spectrum_smem[];
+    v2f* lds = reinterpret_cast<v2f*>(spectrum_smem);                 // [F][G::LDS]
+    v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
+    float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
     const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F;
     const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * chunks + chunk, chunk fastest
     const uint32_t chunk = item % chunks, st = item / chunks;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void spectrum_power_pow2_kernel(SpectrumPowerA
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N
-    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
     float norm[9], aw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -177,20 +178,32 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
     }
 }
 
+template <int LOGN>
+static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 2 * WPF * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_traces * ((hop_pairs + F - 1) / F)), dim3(G::WG), lds, stream, a);
+}
+
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream) {
     const uint64_t total = (uint64_t)a.n_streams * a.n_traces * a.n_hops;
     if (total == 0) return;
     const uint64_t pairs = (uint64_t)a.n_streams * a.n_traces * ((a.n_hops + 1) / 2);
     const uint32_t hop_pairs = (a.n_hops + 1) / 2, st = a.n_streams * a.n_traces;
     (void)pairs;
-    if (fast4096 && a.fft_size == 4096)
-        hipLaunchKernelGGL(spectrum_power_pow2_kernel<12>, dim3(st * hop_pairs), dim3(256), 0, stream, a);
-    else if (fast4096 && a.fft_size == 2048)
-        hipLaunchKernelGGL(spectrum_power_pow2_kernel<11>, dim3(st * ((hop_pairs + 1) / 2)), dim3(256), 0, stream, a);
-    else if (fast4096 && a.fft_size == 1024)
-        hipLaunchKernelGGL(spectrum_power_pow2_kernel<10>, dim3(st * ((hop_pairs + 3) / 4)), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(spectrum_power_generic_kernel, dim3(generic_wgs), dim3(256), 0, stream, a);
+    if (fast4096 && a.fft_size == 16384) launch_spectrum_pow2<14>(a, st, hop_pairs, stream);
+    else if (fast4096 && a.fft_size == 8192) launch_spectrum_pow2<13>(a, st, hop_pairs, stream);
+    else if (fast4096 && a.fft_size == 4096) launch_spectrum_pow2<12>(a, st, hop_pairs, stream);
+    else if (fast4096 && a.fft_size == 2048) launch_spectrum_pow2<11>(a, st, hop_pairs, stream);
+    else if (fast4096 && a.fft_size == 1024) launch_spectrum_pow2<10>(a, st, hop_pairs, stream);
+    else hipLaunchKernelGGL(spectrum_power_generic_kernel, dim3(generic_wgs), dim3(256), 0, stream, a);
 }
 
 // ---- K3b: per-bin recurrences + dB ------------------------------------------------------------------

@@ -205,12 +205,13 @@ __device__ __forceinline__ uint16_t classic_code(float power) {  // level.rs:28-
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, uint16_t* __restrict__ codes) {
+__global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(StftFastArgs a, uint16_t* __restrict__ codes) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;
-    __shared__ v2f lds[F * G::LDS];
-    __shared__ v2f tw2_lds[256];
-    __shared__ float wave_sum[F][2][WPF];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* lds = reinterpret_cast<v2f*>(smem_raw);                      // [F][G::LDS]
+    v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
+    float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
     const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
     const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
     const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, 
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);
-    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
     float norm[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) norm[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
@@ -294,9 +295,17 @@ __global__ __launch_bounds__(256) void stft_classic_pow2_kernel(StftFastArgs a, 
 
 template <int LOGN>
 static void launch_classic(const StftFastArgs& a, uint16_t* codes, hipStream_t stream) {
-    constexpr int F = FftGeom<LOGN>::FRAMES;
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 2 * WPF * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_classic_pow2_kernel<LOGN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
-    hipLaunchKernelGGL(stft_classic_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), 0, stream, a, codes);
+    hipLaunchKernelGGL(stft_classic_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a, codes);
 }
 void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
@@ -304,6 +313,8 @@ void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t f
         case 1024: launch_classic<10>(a, codes, stream); break;
         case 2048: launch_classic<11>(a, codes, stream); break;
         case 4096: launch_classic<12>(a, codes, stream); break;
+        case 8192: launch_classic<13>(a, codes, stream); break;
+        case 16384: launch_classic<14>(a, codes, stream); break;
         default: break;
     }
 }

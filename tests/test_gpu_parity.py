@@ -51,7 +51,7 @@ def test_reassigned_columns_match_oracle(omx, oracle, W, hop, zp):
     check_reassigned(got.new_columns, want.new_columns, hop)
 
 
-@pytest.mark.parametrize("W,hop", [(1024, 256), (2048, 64), (4096, 256), (64, 16), (512, 128)])
+@pytest.mark.parametrize("W,hop", [(1024, 256), (2048, 64), (4096, 256), (64, 16), (512, 128), (8192, 1024), (16384, 1024)])
 def test_classic_columns_match_oracle(omx, oracle, W, hop):
     """W in {1024, 2048, 4096} runs the fused two-columns-per-FFT kernel (radix-16 passes: a different, equally valid f32
     rounding pattern -> level-aware bar, see parity.check_classic); other sizes run the generic kernel, which repeats the
@@ -61,7 +61,7 @@ def test_classic_columns_match_oracle(omx, oracle, W, hop):
     got = SpectrogramProcessor(omx, cfg).process_block(AudioBlock(pcm, 2, 48000.0))
     want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(pcm, 2, 48000.0))
     assert len(got.new_columns) == len(want.new_columns) == 16
-    if W in (1024, 2048, 4096):
+    if W in (1024, 2048, 4096, 8192, 16384):
         check_classic(got.new_columns, want.new_columns)
     else:
         for h, o in zip(got.new_columns, want.new_columns):
@@ -154,7 +154,7 @@ def check_trace(x, y, floor=-100.0):
 
 
 @pytest.mark.parametrize("mode,param", [(capi.AVG_NONE, 0.0), (capi.AVG_EXPONENTIAL, 0.5), (capi.AVG_PEAK_HOLD, 12.0)])
-@pytest.mark.parametrize("N,hop", [(4096, 256), (1024, 512), (2048, 128), (512, 128)])
+@pytest.mark.parametrize("N,hop", [(4096, 256), (1024, 512), (2048, 128), (512, 128), (8192, 512), (16384, 1024)])
 def test_spectrum_matches_oracle(omx, oracle, mode, param, N, hop):
     cfg = SpectrumConfig(fft_size=N, hop_size=hop, averaging_mode=mode, averaging_param=param, source=capi.CH_MID,
                          secondary_source=capi.CH_SIDE, floor_db=-100.0)
