@@ -1,0 +1,49 @@
+"""The boundary is a C ABI: a plain C99 program (tests/c_abi/abi_demo.c) must compile against include/omx.h alone, link the
+shared library, and — on the GPU box — produce the same numbers from the HIP product as from the oracle."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "c_abi", "abi_demo.c")
+
+
+def build(tmp_path, oracle_lib):
+    out = str(tmp_path / ("demo_oracle" if oracle_lib else "demo_hip"))
+    libdir = os.path.join(ROOT, "oracle") if oracle_lib else os.path.join(ROOT, "openmeters_amd", "csrc")
+    lib = "omx_oracle" if oracle_lib else "omx_hip"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", out,
+           "-L", libdir, "-l" + lib, "-lm", "-Wl,-rpath," + libdir]
+    if oracle_lib:
+        cmd.insert(1, "-DOMX_PREFIX_ORACLE")
+    else:
+        cmd += ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
+def parse(line):
+    tok = line.split()
+    return {tok[i]: float(tok[i + 1]) for i in range(0, len(tok), 2)}
+
+
+def test_c99_program_builds_against_the_header_and_runs_on_the_oracle(tmp_path, oracle):
+    for lib in (True, False):          # linking the product needs no GPU
+        exe = build(tmp_path, lib)
+    r = subprocess.run([build(tmp_path, True)], capture_output=True, text=True, check=True)
+    v = parse(r.stdout.strip())
+    assert v["columns"] == 200 - 31 and abs(v["peak_freq"] - 1000.0) < 0.5 and abs(v["spectrum_peak_hz"] - 996.09) < 12.0
+    assert abs(v["true_peak"] - 20 * 0.30103 * -1) < 0.05  # 0.5 amplitude = -6.02 dBTP
+
+
+@pytest.mark.gpu
+def test_c99_program_gets_the_same_numbers_from_the_hip_library(tmp_path, oracle):
+    ro = subprocess.run([build(tmp_path, True)], capture_output=True, text=True, check=True)
+    rh = subprocess.run([build(tmp_path, False)], capture_output=True, text=True)
+    assert rh.returncode == 0, rh.stderr
+    a, b = parse(rh.stdout.strip()), parse(ro.stdout.strip())
+    assert a["columns"] == b["columns"] and abs(a["points"] - b["points"]) <= 4 * a["columns"]
+    assert abs(a["peak_freq"] - b["peak_freq"]) < 1e-3 and abs(a["peak_power"] - b["peak_power"]) <= 1e-5 * b["peak_power"]
+    assert a["spectrum_peak_hz"] == b["spectrum_peak_hz"] and abs(a["spectrum_peak_db"] - b["spectrum_peak_db"]) < 0.01
+    assert abs(a["momentary"] - b["momentary"]) < 1e-4 and abs(a["true_peak"] - b["true_peak"]) < 1e-4
