@@ -167,18 +167,29 @@ def main():
                                                          secondary_source=capi.CH_NONE, floor_db=-100.0), S, emit_all_hops=True)
     positions = capi.positions_fallback(2)
 
+    # K8 runs beside the data path: the per-stream counts are snapshotted on the compute stream (the bank reuses its output
+    # buffers every call), then the summary rows are assembled and all-gathered over RCCL/xGMI on a second HIP stream while
+    # the next step's kernels run (48 B/stream: latency-bound, must not sit between two K2 launches)
+    side = torch.cuda.Stream(device=device) if world > 1 else None
+
     def step():
         up = bank.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
         if spectrum is not None:
             spectrum.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
         if world > 1 and up is not None:
-            # K8: per-stream summary rows all-gathered over RCCL/xGMI once per step (40 B/stream: latency-bound)
-            counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).to(torch.float32)
-            stats = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
-            stats[:, 7] = float(up.n_columns)
-            stats[:, 8] = counts.mean(dim=1)
-            stats[:, 9] = counts[:, -1]
-            gather_stats(stats if backend == "nccl" else stats.cpu(), world * S)
+            counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).clone()
+            n_columns = float(up.n_columns)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                cf = counts.to(torch.float32)
+                stats = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
+                stats[:, 7] = n_columns
+                stats[:, 8] = cf.mean(dim=1)
+                stats[:, 9] = cf[:, -1]
+                gather_stats(stats if backend == "nccl" else stats.cpu(), world * S)
+                counts.record_stream(side)
         return up
 
     for _ in range(args.warmup):
