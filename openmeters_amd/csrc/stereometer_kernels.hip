@@ -1,12 +1,12 @@
 // K5 threeband_correlator: per stereo frame 16 f32 biquads (LR4 three-band split of L and R) and four
 // f64 EMA correlators.  reference src/dsp.rs:422-432, :489-495 and
 // src/visuals/stereometer/processor.rs:40-61, :115-140.
-// Four lanes per stream run the same straight-line code with per-lane coefficient sets:
-//   lane 0  full band      (no filter)
-//   lane 1  low   = LP_low(x)
-//   lane 2  mid   = LP_high(HP_low(x))
-//   lane 3  high  = HP_high(HP_low(x))      (CASCADE_HIGH = true)
-// HP_low is evaluated by lanes 2 and 3 on identical inputs, so both see bit-identical `above_low`.
+// Four lanes per stream (one per wavefront of the workgroup) run the same code with per-band coefficient sets:
+//   band 0  full band      (no filter)
+//   band 1  low   = LP_low(x)
+//   band 2  mid   = LP_high(HP_low(x))
+//   band 3  high  = HP_high(HP_low(x))      (CASCADE_HIGH = true)
+// HP_low is evaluated by bands 2 and 3 on identical inputs, so both see bit-identical `above_low`.
 #include "stereometer.hpp"
 
 namespace omx {
@@ -21,81 +21,170 @@ __device__ __forceinline__ float biquad_step(const BiquadCoef& c, float (&z)[2],
     return 0.0f;
 }
 
-__global__ __launch_bounds__(64) void stereometer_kernel(StereometerArgs a) {
-    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;  // stream * 4 + lane
-    const uint32_t s = gid >> 2, band = gid & 3;
+typedef float v2f __attribute__((ext_vector_type(2)));  // (left, right): both channels of a cascade element in one packed op
+
+// Biquad::process (dsp.rs:422-432) for the L and R filters of one cascade element at once; each component follows the
+// reference's statement order (no fused multiply-add), the non-finite reset is per channel.
+__device__ __forceinline__ v2f biquad_step2(const BiquadCoef& c, v2f& z0, v2f& z1, v2f x) {
+    const v2f out = c.b[0] * x + z0;
+    z0 = c.b[1] * x - c.a[0] * out + z1;
+    z1 = c.b[2] * x - c.a[1] * out;
+    const bool okl = isfinite(out.x), okr = isfinite(out.y);
+    if (__builtin_expect(__ballot(!(okl && okr)) != 0ull, 0)) {  // rare: keep the selects off the straight path
+        z0 = v2f{okl ? z0.x : 0.0f, okr ? z0.y : 0.0f};
+        z1 = v2f{okl ? z1.x : 0.0f, okr ? z1.y : 0.0f};
+        return v2f{okl ? out.x : 0.0f, okr ? out.y : 0.0f};
+    }
+    return out;
+}
+
+struct StereoRegs {  // StereoLaneState with the two channels of every delay element paired
+    v2f z0[2][2], z1[2][2];  // [stage A/B][cascade element]
+    double m[3];
+};
+__device__ __forceinline__ StereoRegs load_regs(const StereoLaneState& st) {
+    StereoRegs r;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            r.z0[g][e] = v2f{st.z[g][e][0][0], st.z[g][e][1][0]};
+            r.z1[g][e] = v2f{st.z[g][e][0][1], st.z[g][e][1][1]};
+        }
+    r.m[0] = st.moments[0];
+    r.m[1] = st.moments[1];
+    r.m[2] = st.moments[2];
+    return r;
+}
+__device__ __forceinline__ void store_regs(const StereoRegs& r, StereoLaneState& st) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            st.z[g][e][0][0] = r.z0[g][e].x;
+            st.z[g][e][1][0] = r.z0[g][e].y;
+            st.z[g][e][0][1] = r.z1[g][e].x;
+            st.z[g][e][1][1] = r.z1[g][e].y;
+        }
+    st.moments[0] = r.m[0];
+    st.moments[1] = r.m[1];
+    st.moments[2] = r.m[2];
+}
+
+// One frame of one (stream, band): stereo fold already done.
+__device__ __forceinline__ v2f stereo_frame(const BiquadCoef& ca, const BiquadCoef& cb, bool use_a, bool use_b, StereoRegs& st,
+                                            double alpha, v2f x) {
+    if (use_a) {  // Cascade<Biquad,2> per channel (dsp.rs:447-451)
+        x = biquad_step2(ca, st.z0[0][0], st.z1[0][0], x);
+        x = biquad_step2(ca, st.z0[0][1], st.z1[0][1], x);
+    }
+    if (use_b) {
+        x = biquad_step2(cb, st.z0[1][0], st.z1[1][0], x);
+        x = biquad_step2(cb, st.z0[1][1], st.z1[1][1], x);
+    }
+    const double ld = (double)x.x, rd = (double)x.y;  // Correlator::update (:40-46)
+    st.m[0] += alpha * (ld * rd - st.m[0]);
+    st.m[1] += alpha * (ld * ld - st.m[1]);
+    st.m[2] += alpha * (rd * rd - st.m[2]);
+    return x;
+}
+
+// CH = 2: compile-time fold (dsp.rs:234-239 has the same specialisation); CH = 0: any channel count.
+// Workgroup = 4 wavefronts, wavefront w = band w of 64 consecutive streams (lane = stream): which filters run, whether
+// the history is written and whether the band is active at all are wave-uniform, so the per-frame code has no divergent
+// branches (the first layout — 4 lanes per stream — spent half of its instructions on exec-mask bookkeeping).
+template <int CH>
+__global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
+    const uint32_t band = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, in an SGPR
+    const uint32_t s = blockIdx.x * 64 + (threadIdx.x & 63);
     if (s >= a.n_streams) return;
+    const uint32_t gid = s * 4 + band;  // state / history / output slot of this (stream, band)
     const bool active = band == 0 || a.analyze_bands != 0;
-    StereoLaneState st = a.state[gid];
+    StereoLaneState st_mem = a.state[gid];
+    StereoRegs st = load_regs(st_mem);
     const BiquadCoef ca = a.stage_a[band], cb = a.stage_b[band];
     const bool use_a = a.use_a[band] != 0, use_b = a.use_b[band] != 0;
     const bool push_history = band == 0 || a.emit_band_points != 0;
-    const float* pcm = a.pcm + (uint64_t)s * a.frames_total * a.fmt.channels;
+    const uint32_t channels = CH ? (uint32_t)CH : a.fmt.channels;
+    const float* pcm = a.pcm + (uint64_t)s * a.frames_total * channels;
     float* hist = a.history + ((uint64_t)s * 4 + band) * a.hist_frames * 2;
-    uint64_t pos = a.hist_pos[band];
+    uint32_t slot = (uint32_t)(a.hist_pos[band] % a.hist_frames);  // ring slot advanced with a 32-bit compare, not a 64-bit modulo
+    const double alpha = a.alpha;
+    constexpr int BATCH = 8;  // frames whose loads are issued together
 
     for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
         if (active) {
-            for (uint32_t f = 0; f < a.block_frames; ++f) {
-                const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
+            const float* base = pcm + (uint64_t)blk * a.block_frames * channels;
+            uint32_t f = 0;
+            if constexpr (CH == 2) {
+                for (; f + BATCH <= a.block_frames; f += BATCH) {
+                    float2 x[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) x[i] = *reinterpret_cast<const float2*>(base + 2u * (f + i));
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        // two channels: the fold is the identity on bits (dsp.rs:232-236) with the default matrix, else weights
+                        const float left = 0.0f + x[i].x * a.fmt.m[0][0] + x[i].y * a.fmt.m[1][0];
+                        const float right = 0.0f + x[i].x * a.fmt.m[0][1] + x[i].y * a.fmt.m[1][1];
+                        const v2f y = stereo_frame(ca, cb, use_a, use_b, st, alpha, v2f{left, right});
+                        if (push_history) {
+                            *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
+                            slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
+                        }
+                    }
+                }
+            }
+            for (; f < a.block_frames; ++f) {
+                const float* frame = base + (uint64_t)f * channels;
                 float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
-                for (uint32_t c = 0; c < a.fmt.channels; ++c) {
+                for (uint32_t c = 0; c < channels; ++c) {
                     const float v = frame[c];
                     left = left + v * a.fmt.m[c][0];
                     right = right + v * a.fmt.m[c][1];
                 }
-                float l = left, r = right;
-                if (use_a) {  // Cascade<Biquad,2> per channel (dsp.rs:447-451)
-                    l = biquad_step(ca, st.z[0][0][0], l);
-                    l = biquad_step(ca, st.z[0][1][0], l);
-                    r = biquad_step(ca, st.z[0][0][1], r);
-                    r = biquad_step(ca, st.z[0][1][1], r);
-                }
-                if (use_b) {
-                    l = biquad_step(cb, st.z[1][0][0], l);
-                    l = biquad_step(cb, st.z[1][1][0], l);
-                    r = biquad_step(cb, st.z[1][0][1], r);
-                    r = biquad_step(cb, st.z[1][1][1], r);
-                }
-                const double ld = (double)l, rd = (double)r;  // Correlator::update (:40-46)
-                st.moments[0] += a.alpha * (ld * rd - st.moments[0]);
-                st.moments[1] += a.alpha * (ld * ld - st.moments[1]);
-                st.moments[2] += a.alpha * (rd * rd - st.moments[2]);
+                const v2f y = stereo_frame(ca, cb, use_a, use_b, st, alpha, v2f{left, right});
                 if (push_history) {
-                    const uint64_t slot = pos % a.hist_frames;
-                    hist[slot * 2] = l;
-                    hist[slot * 2 + 1] = r;
-                    ++pos;
+                    *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
+                    slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
                 }
             }
             // flush_denormals once per block (:134-140)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (fabs(st.moments[i]) < 1.0e-30) st.moments[i] = 0.0;
+                if (fabs(st.m[i]) < 1.0e-30) st.m[i] = 0.0;
             if (band != 0) {
-                float* z = &st.z[0][0][0][0];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (fabsf(z[i]) < 1.0e-20f) z[i] = 0.0f;
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        v2f& p = st.z0[g][e];
+                        v2f& q = st.z1[g][e];
+                        p = v2f{fabsf(p.x) < 1.0e-20f ? 0.0f : p.x, fabsf(p.y) < 1.0e-20f ? 0.0f : p.y};
+                        q = v2f{fabsf(q.x) < 1.0e-20f ? 0.0f : q.x, fabsf(q.y) < 1.0e-20f ? 0.0f : q.y};
+                    }
             }
         }
         float value = 0.0f;  // Correlator::value (:48-56)
         if (active) {
-            const double denom = sqrt(st.moments[1] * st.moments[2]);
+            const double denom = sqrt(st.m[1] * st.m[2]);
             if (denom > 1e-12) {
-                const double v = st.moments[0] / denom;
+                const double v = st.m[0] / denom;
                 if (isfinite(v)) value = (float)fmin(fmax(v, -1.0), 1.0);
             }
         }
         a.correlations[((uint64_t)s * a.n_blocks + blk) * 4 + band] = value;
     }
-    a.state[gid] = st;
+    store_regs(st, st_mem);
+    a.state[gid] = st_mem;
 }
 
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
-    const uint32_t threads = a.n_streams * 4;
-    hipLaunchKernelGGL(stereometer_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, a);
+    const uint32_t groups = (a.n_streams + 63) / 64;
+    if (a.fmt.channels == 2)
+        hipLaunchKernelGGL(stereometer_kernel<2>, dim3(groups), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(stereometer_kernel<0>, dim3(groups), dim3(256), 0, stream, a);
 }
 
 struct PointsArgs {

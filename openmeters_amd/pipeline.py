@@ -43,6 +43,27 @@ class FullPipeline:
         st = self.stereometer.process_device(device_ptr, 256, frames // 256, self.channels, self.sample_rate, self.positions, stream)
         return up, snaps, st, frames // 256
 
+    def step_concurrent(self, torch, device_ptr: int, frames: int):
+        """Same as `step` on torch's current stream, but the loudness and stereometer banks (register-pipeline kernels: a few
+        waves per CU, latency-bound) run on two side streams beside the FFT-bound spectrogram kernel; joined before returning
+        to the caller's stream order."""
+        assert frames % 256 == 0
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        up = self.spectrogram.process_device(device_ptr, frames, self.channels, self.sample_rate, self.positions, main.cuda_stream)
+        results = []
+        for side, bank in zip(self._side, (self.loudness, self.stereometer)):
+            side.wait_event(fork)
+            results.append(bank.process_device(device_ptr, 256, frames // 256, self.channels, self.sample_rate, self.positions,
+                                               side.cuda_stream))
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+        return up, results[0], results[1], frames // 256
+
     def stats(self, torch, device, up, snaps_ptr, st, n_blocks):
         """[n_streams, len(STATS_COLUMNS)] float32 summary rows in sharding.STATS_COLUMNS order."""
         import ctypes as C

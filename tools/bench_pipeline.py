@@ -1,0 +1,36 @@
+"""cfg5 per-GPU shard: 1024 independent 2-ch streams through the full pipeline (reassigned STFT + LUFS + correlation), one
+step = 16384 new frames per stream (64 STFT columns, 64 blocks of 256).  Run on the GPU box."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import openmeters_amd
+from openmeters_amd.pipeline import FullPipeline
+
+api = openmeters_amd.api()
+dev = torch.device("cuda", 0)
+S, frames = 1024, 16384
+t = torch.arange(frames * 6, device=dev, dtype=torch.float32)
+base = 0.4 * torch.sin(t * 0.05 + 1e-7 * t * t)
+pcm = (base[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :] + 0.001 * torch.randn((S, frames * 6, 2), device=dev)).contiguous()
+for mode in ("serial", "concurrent"):
+    pipe = FullPipeline(api, S)
+    chunks = [pcm[:, k * frames:(k + 1) * frames].contiguous() for k in range(6)]
+    run = (lambda c: pipe.step(c.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)) if mode == "serial" else \
+          (lambda c: pipe.step_concurrent(torch, c.data_ptr(), frames))
+    run(chunks[0])
+    run(chunks[1])
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for c in chunks[2:]:
+        out = run(c)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / 4
+    table = pipe.stats(torch, dev, *out)
+    print(f"{mode}: {ms:.3f} ms per step of {S} streams x {frames} frames -> {S * frames / ms / 1e6:.2f} G stream-frames/s, "
+          f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
+          f"rho mean {float(table[:, 3].mean()):.3f}")
