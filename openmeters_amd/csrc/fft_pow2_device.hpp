@@ -127,8 +127,19 @@ __device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int j
 // x[jf + T u] in v[u] -> X[jf + T u] in v[u].  Writes `first`, then `second`, reads `second` last (ping-pong); the caller
 // guarantees nobody still reads `first` and that `second` is free.  All 256 threads of the workgroup must call it together.
 template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp(v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw);
+template <bool INV, int LOGN>
+__device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, const TwiddlesPow2<LOGN>& tw);
+
+template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp(v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw) {
-    static_assert(FftGeom<LOGN>::PASSES == 3, "ping-pong form: three-pass sizes only");
+    if constexpr (FftGeom<LOGN>::PASSES == 4) {
+        // four passes would end on `first`: run in place on `second` instead, so `second` is still the buffer read last.
+        // The ping-pong contract only frees `second` one barrier into the transform, hence the barrier up front.
+        frame_sync<LOGN>();
+        fftp_inplace<INV, LOGN>(v, second, jf, tw);
+        return;
+    }
     fftp_pass1<INV, LOGN>(v, first, jf);
     frame_sync<LOGN>();
     fftp_pass2<INV, LOGN>(first, second, jf, tw);
@@ -183,7 +194,6 @@ __device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, con
 template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int jf, const TwiddlesPow2<LOGN>& tw) {
     using G = FftGeom<LOGN>;
-    static_assert(G::PASSES == 3, "paired form: three-pass sizes only");
     fftp_pass1<INV, LOGN>(v0, A, jf);
     fftp_pass1<INV, LOGN>(v1, B, jf);
     frame_sync<LOGN>();
@@ -212,6 +222,31 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
         }
     }
     frame_sync<LOGN>();
+    if constexpr (G::PASSES == 4) {
+        v2f a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            a[t] = A[pad16(jf + G::T * t)];
+            b[t] = B[pad16(jf + G::T * t)];
+        }
+        const unsigned k = (unsigned)jf & 255u;
+#pragma unroll
+        for (int t = 1; t < 16; ++t) {
+            const v2f w = tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)];
+            a[t] = twmul<INV>(a[t], w);
+            b[t] = twmul<INV>(b[t], w);
+        }
+        dft16<INV>(a);
+        dft16<INV>(b);
+        frame_sync<LOGN>();
+        const int base = (jf >> 8) * 4352 + (int)k + (int)(k >> 4);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            A[base + 272 * t] = a[DFT16_OUT(t)];
+            B[base + 272 * t] = b[DFT16_OUT(t)];
+        }
+        frame_sync<LOGN>();
+    }
     fftp_pass3<INV, LOGN>(v0, A, jf, tw);
     fftp_pass3<INV, LOGN>(v1, B, jf, tw);
 }

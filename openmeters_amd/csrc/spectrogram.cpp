@@ -149,8 +149,8 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
         power_scale_ = 1.0f;
     }
     // fused kernels: W = F in {1024, 2048, 4096} (the tuned 4096 kernel / the size-templated ones; classic and reassigned)
-    // (classic only for 8192 / 16384: the reassigned form of those sizes does not fit the LDS / register budget of one CU)
-    fast4096_ = (W == fft_size_ && (W == 4096 || W == 2048 || W == 1024 || (!reassign && (W == 8192 || W == 16384))));
+    // (16384 classic only: its reassigned form needs two 139 KiB LDS buffers, or 1024 threads under a 128-VGPR cap)
+    fast4096_ = (W == fft_size_ && (W == 8192 || W == 4096 || W == 2048 || W == 1024 || (!reassign && W == 16384)));
     if (fast4096_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
         d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / N)

@@ -31,7 +31,7 @@ __device__ __forceinline__ bool reassign_bin_p(uint32_t i, v2f b, v2f d, v2f t, 
 }  // namespace
 
 template <int LOGN>
-__global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastArgs a) {
+__global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1) void stft_reassigned_pow2_kernel(StftFastArgs a) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // waves per frame
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_kernel(StftFastAr
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);  // `tw4096` carries exp(-2 pi i k / N) for this N
-    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
 
     // ---- 1. packed real FFT of the 2N-sample window (loads for the Hilbert build issued alongside) -----------------
     v2f v[16], w2n[16];
@@ -331,16 +331,17 @@ static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     const uint32_t chunks = (a.n_cols + F - 1) / F;
-    hipLaunchKernelGGL(stft_reassigned_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(stft_reassigned_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
 }
 
-// fft_size = 1024, 2048 or 4096 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
+// fft_size = 1024, 2048, 4096 or 8192 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
     switch (fft_size) {
         case 1024: launch_pow2<10>(a, stream); break;
         case 2048: launch_pow2<11>(a, stream); break;
         case 4096: launch_pow2<12>(a, stream); break;
+        case 8192: launch_pow2<13>(a, stream); break;
         default: break;
     }
 }

@@ -156,7 +156,7 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
         assert np.abs(flat - wo.samples).max() <= 2e-3
 
 
-@pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256)])
+@pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256), (8192, 512)])
 def test_fused_small_windows_full_size_shift_partition_and_oracle(omx, oracle, W, hop):
     """The reference's DEFAULT spectrogram shape (2048 / hop 64, processor.rs:58-59) and 1024 / 256 go through the size-templated
     fused kernel (several columns per workgroup): shift invariance across frame slots / workgroups / XCDs, partition

@@ -10,8 +10,8 @@ from openmeters_amd import banks, capi
 
 api = openmeters_amd.api()
 S = 64
-for W, hop in ((1024, 256), (2048, 64), (2048, 256), (4096, 256)):
-    cols = 65536 // S
+for W, hop in ((1024, 256), (2048, 64), (2048, 256), (4096, 256), (8192, 512), (16384, 1024)):
+    cols = (65536 if W <= 8192 else 4096) // S   # 16384 reassigned runs the generic kernel
     frames = 2 * W + hop * (cols - 1)
     pcm = (torch.rand((S, frames + hop * cols * 4, 2), device="cuda:0") - 0.5).contiguous()
     bank = banks.SpectrogramBank(api, capi.SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=True, history_length=8192), S)
