@@ -218,6 +218,8 @@ enum {
 /* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the OMX_K2_VARIANT=7 build
  * (setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store) */
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset);
+/* same for the oscilloscope kernel with OMX_SCOPE_PHASES=1 (ring push, pre-FFT, FFTs, NSDF + peak, locate, snapshot) */
+int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset);
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *

@@ -179,6 +179,16 @@ int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, ui
         return (int)OMX_NONE;
     });
 }
+int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset) {
+    if (!out || n < (uint32_t)SCOPE_PHASES) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        unsigned long long c[SCOPE_PHASES];
+        scope_phase_cycles(c, reset != 0);
+        for (int i = 0; i < SCOPE_PHASES; ++i) out[i] = c[i];
+        return (int)SCOPE_PHASES;
+    });
+}
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;
     REQUIRE_DEVICE();

@@ -127,6 +127,10 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
     if (fft_size != fft_size_) {
         fft_size_ = fft_size;
         tw_fft_.upload(twiddle_table(fft_size, fft_size / 2), stream);
+        if (fft_size == 8192) {
+            tw256_.upload(twiddle_table(256, 256), stream);
+            tw4096_.upload(twiddle_table(4096, 4096), stream);
+        }
     }
     const uint64_t scratch_stride = scope_scratch_floats(max_kernel, 0, probe_frames, max_period);
     scratch_.reserve((size_t)(scratch_stride * n_streams_));
@@ -181,8 +185,17 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
     sa.log_fft = log2_exact(fft_size);
     sa.tw_fft = reinterpret_cast<const v2f*>(tw_fft_.ptr);
     sa.fft_global = fft_in_lds ? nullptr : reinterpret_cast<v2f*>(fft_global_.ptr);
+    const bool fast_acf = fft_size_ == 8192 && fft_in_lds && tw4096_.ptr;
+    sa.tw256 = fast_acf ? reinterpret_cast<const v2f*>(tw256_.ptr) : nullptr;
+    sa.tw4096 = fast_acf ? reinterpret_cast<const v2f*>(tw4096_.ptr) : nullptr;
+    sa.lds_scratch = (fast_acf && scope_lds_scratch_bytes(max_kernel, sa.max_period, sa.probe_frames) <= 150 * 1024) ? 1u : 0u;
     sa.headers = headers_.ptr;
     sa.samples = samples_.ptr;
+    static const bool phase_timing = [] {
+        const char* e = getenv("OMX_SCOPE_PHASES");
+        return e && atoi(e) != 0;
+    }();
+    sa.phase_timing = phase_timing ? 1u : 0u;
     launch_oscilloscope(sa, stream);
     OMX_HIP(hipGetLastError());
 

@@ -56,9 +56,16 @@ struct ScopeArgs {
     uint32_t fft_size, log_fft;  // NSDF FFT (next_pow2(probe + max_lag))
     const v2f* tw_fft;      // exp(-2*pi*i*k/fft_size), k < fft_size/2
     v2f* fft_global;        // [n_streams][fft_size] when the FFT does not fit the LDS budget, else nullptr
+    const v2f* tw256;       // exp(-2 pi i k / 256), exp(-2 pi i k / 4096): tables of the register/LDS 4096-point transform that
+    const v2f* tw4096;      // carries the 8192-point autocorrelation (nullptr unless fft_size == 8192)
     ScopeBlockHeader* headers;   // [n_streams][n_blocks]
     float* samples;         // [n_streams][2][kScopeTarget] snapshot of the newest block
+    uint32_t phase_timing;  // tuning aid: accumulate per-phase cycles (OMX_SCOPE_PHASES=1)
+    uint32_t lds_scratch;   // hot scratch arrays in LDS (fast 8192 configuration whose two phase layouts fit 150 KiB)
 };
+uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
+constexpr int SCOPE_PHASES = 6;
+void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
 uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search, uint32_t probe_frames, uint32_t max_period);
 
@@ -95,7 +102,7 @@ private:
     uint64_t cap_ = 0, last_blocks_ = 0;
     bool pending_unlock_ = true;
     uint32_t max_kernel_ = 0, fft_size_ = 0;
-    DeviceBuffer<float> rings_, reference_, scratch_, samples_, staging_, tw_fft_, fft_global_;
+    DeviceBuffer<float> rings_, reference_, scratch_, samples_, staging_, tw_fft_, fft_global_, tw256_, tw4096_;
     DeviceBuffer<ScopeTriggerState> trig_;
     DeviceBuffer<ScopeBlockHeader> headers_;
     hipStream_t last_stream_ = nullptr;

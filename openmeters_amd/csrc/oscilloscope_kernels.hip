@@ -131,11 +131,30 @@ struct Scratch {
     float* nsdf;        // [max_period + 2]
     float* scores;      // [max_search + 2]
     float* energy;      // [probe_frames + 1]
+    float* partials;    // [256] block-scan partials of estimate_period
+};
+
+// tuning aid (ScopeArgs::phase_timing): cycles thread 0 spends between marks, summed over workgroups and blocks
+__device__ unsigned long long g_scope_phase_cycles[SCOPE_PHASES];
+struct PhaseClock {
+    long long t;
+    bool on;
+    __device__ __forceinline__ void start(bool enabled) {
+        on = enabled && threadIdx.x == 0;
+        if (on) t = clock64();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        if (on) {
+            const long long now = clock64();
+            atomicAdd(&g_scope_phase_cycles[i], (unsigned long long)(now - t));
+            t = now;
+        }
+    }
 };
 
 // ---------------------------------------------------------------- PeriodEstimator::estimate_period (:93-181)
 __device__ Estimate estimate_period(const View& x, float rate, float& last_peak, const ScopeArgs& a, v2f* fft, Scratch& sc,
-                                    Shared& sh) {
+                                    Shared& sh, PhaseClock& pc) {
     const unsigned tid = threadIdx.x;
     Estimate none{0, 0.0f, 0.0f};
     last_peak = 0.0f;
@@ -161,48 +180,110 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
     }
     const uint32_t tw_step = a.fft_size / fft_size;  // a.fft_size is the largest size this config can need
     const uint32_t chunk = (n + 255) / 256;
+    const bool fast = fft_size == 8192 && a.tw4096 != nullptr;  // steady state at 44.1 / 48 kHz
     {  // centred copy + prefix energy (block scan: per-thread chunk sums, serial scan of 256 partials)
         const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
         float local = 0.0f;
         for (uint32_t i = lo; i < hi; ++i) {
             const float c = x.at(i) - mean;
-            fft[i] = v2f{c, 0.0f};
+            if (!fast) fft[i] = v2f{c, 0.0f};
             local = c * c + local;
         }
-        for (uint32_t i = n + tid; i < fft_size; i += 256) fft[i] = v2f{0.0f, 0.0f};
+        if (!fast)
+            for (uint32_t i = n + tid; i < fft_size; i += 256) fft[i] = v2f{0.0f, 0.0f};
         __syncthreads();
-        sc.scores[tid] = local;  // scores doubles as the 256-entry partials buffer here
+        sc.partials[tid] = local;
         __syncthreads();
         if (tid == 0) {
             float run = 0.0f;
             for (int t = 0; t < 256; ++t) {
-                const float v = sc.scores[t];
-                sc.scores[t] = run;
+                const float v = sc.partials[t];
+                sc.partials[t] = run;
                 run += v;
             }
             sc.energy[0] = 0.0f;
         }
         __syncthreads();
-        float run = sc.scores[tid];
+        float run = sc.partials[tid];
         for (uint32_t i = lo; i < hi; ++i) {
-            const float c = fft[i].x;
+            const float c = x.at(i) - mean;
             run = c * c + run;
             sc.energy[i + 1] = run;
         }
     }
-    fft_radix2(fft, fft_size, logn, a.tw_fft, false, tid, 256, tw_step);
-    for (uint32_t k = tid; k < fft_size; k += 256) {
-        const v2f b = fft[k];
-        fft[k] = v2f{b.x * b.x + b.y * b.y, 0.0f};
-    }
-    fft_radix2(fft, fft_size, logn, a.tw_fft, true, tid, 256, tw_step);
+    pc.mark(1);  // mean / peak / centred copy / prefix energy
     const float norm = 1.0f / (float)fft_size;
-    const float total_energy = sc.energy[n];
-    if (total_energy <= F32_EPS) return none;
-    for (uint32_t tau = tid; tau <= max_lag; tau += 256) {
-        const float left = sc.energy[n - tau], right = total_energy - sc.energy[tau];
-        const float denom = left + right;
-        sc.nsdf[tau] = denom > F32_EPS ? 2.0f * fft[tau].x * norm / denom : 0.0f;
+    if (fast) {
+        // Autocorrelation of the zero-padded real probe through two 4096-point register/LDS transforms instead of two
+        // 8192-point complex radix-2 transforms in LDS (:147-160 computes FFT_8192(x + 0i), |.|^2, IFFT_8192, real part):
+        //   z[m] = x[2m] + i x[2m+1];  Z = FFT_4096(z);  E, O = even / odd sample spectra;  X[k] = E + w^k O, X[k+N] = E - w^k O
+        //   P = |X|^2 (real, P[2N-k] = P[k]);  acf[2m] + i acf[2m+1] = IFFT_4096( (P[k] + P[k+N]) + i (P[k] - P[k+N]) conj(w^k) )
+        constexpr uint32_t N = 4096;
+        const int j = (int)tid;
+        const Fft4096Tables tb{a.tw256, a.tw4096};
+        v2f v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t m = (uint32_t)(j + 256 * t);
+            const float re = 2u * m < n ? x.at(2u * m) - mean : 0.0f;
+            const float im = 2u * m + 1u < n ? x.at(2u * m + 1u) - mean : 0.0f;
+            v[t] = v2f{re, im};
+        }
+        fft4096<false>(v, fft, j, tb);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fft[pad16(j + 256 * t)] = v[t];
+        __syncthreads();
+        v2f y[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t k = (uint32_t)(j + 256 * t);
+            const v2f z = v[t];
+            const v2f zr = fft[pad16((int)((N - k) & (N - 1)))];
+            const v2f e{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr) / 2
+            const v2f o{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr) / (2i)
+            const v2f w = a.tw_fft[k];                               // exp(-2 pi i k / 8192)
+            const v2f wo{o.x * w.x - o.y * w.y, o.x * w.y + o.y * w.x};
+            const v2f xp{e.x + wo.x, e.y + wo.y}, xm{e.x - wo.x, e.y - wo.y};
+            const float p0 = xp.x * xp.x + xp.y * xp.y, p1 = xm.x * xm.x + xm.y * xm.y;  // P[k], P[k + N]
+            const float sum = p0 + p1, dif = p0 - p1;
+            y[t] = v2f{sum + dif * w.y, dif * w.x};  // (P[k] + P[k+N]) + i (P[k] - P[k+N]) conj(w^k)
+        }
+        __syncthreads();
+        fft4096<true>(y, fft, j, tb);  // y[t] = (acf[2m], acf[2m + 1]), m = j + 256 t
+        const float total_energy_f = sc.energy[n];
+        if (total_energy_f > F32_EPS) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t m = (uint32_t)(j + 256 * t);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t tau = 2u * m + (uint32_t)h;
+                    if (tau > max_lag) continue;
+                    const float acf = h ? y[t].y : y[t].x;
+                    const float left = sc.energy[n - tau], right = total_energy_f - sc.energy[tau];
+                    const float denom = left + right;
+                    sc.nsdf[tau] = denom > F32_EPS ? 2.0f * acf * norm / denom : 0.0f;
+                }
+            }
+        }
+        pc.mark(2);  // two FFTs (+ NSDF fill)
+        if (total_energy_f <= F32_EPS) return none;
+    } else {
+        fft_radix2(fft, fft_size, logn, a.tw_fft, false, tid, 256, tw_step);
+        for (uint32_t k = tid; k < fft_size; k += 256) {
+            const v2f b = fft[k];
+            fft[k] = v2f{b.x * b.x + b.y * b.y, 0.0f};
+        }
+        fft_radix2(fft, fft_size, logn, a.tw_fft, true, tid, 256, tw_step);
+        pc.mark(2);  // two FFTs
+        const float total_energy = sc.energy[n];
+        if (total_energy <= F32_EPS) return none;
+        for (uint32_t tau = tid; tau <= max_lag; tau += 256) {
+            const float left = sc.energy[n - tau], right = total_energy - sc.energy[tau];
+            const float denom = left + right;
+            sc.nsdf[tau] = denom > F32_EPS ? 2.0f * fft[tau].x * norm / denom : 0.0f;
+        }
     }
     __syncthreads();
     const float* nsdf = sc.nsdf;
@@ -533,16 +614,18 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
 
 // StableTrigger::capture (:306-334)
 __device__ Capture stable_capture(ScopeTriggerState& t, float* reference, const View& trace, const ScopeArgs& a, v2f* fft,
-                                  Scratch& sc, Shared& sh) {
+                                  Scratch& sc, Shared& sh, PhaseClock& pc) {
     const uint32_t n = trace.n;
     const uint32_t probe_len = min(a.probe_frames, n);
     float last_peak = 0.0f;
     Estimate detected{0, 0.0f, 0.0f};
-    if (probe_len >= 3) detected = estimate_period(trace.sub(n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh);
+    if (probe_len >= 3) detected = estimate_period(trace.sub(n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh, pc);
+    pc.mark(3);  // NSDF + peak picking
     if (probe_len > 0 && last_peak < MIN_SIGNAL_PEAK) trigger_unlock(t);
     const Estimate est = stabilize(t, detected);
     if (est.some) {
         const Capture c = locate(t, reference, trace, est, a.num_cycles, a.sample_rate, sc, sh);
+        pc.mark(4);  // locate (template correlation search)
         if (c.some) return c;
     }
     Capture c;
@@ -595,6 +678,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     const uint32_t s = blockIdx.x;
     v2f* fft = a.fft_global ? a.fft_global + (uint64_t)s * a.fft_size : reinterpret_cast<v2f*>(smem_raw);
     float* scratch = a.scratch + (uint64_t)s * a.scratch_stride;
+    __shared__ float partials[256];
     Scratch sc;
     {
         // layout mirrors scope_scratch_floats()
@@ -606,6 +690,18 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         sc.nsdf = scratch + off;       off += (uint64_t)a.max_period + 8;
         sc.scores = scratch + off;     off += (uint64_t)max(ms, 256u) + 8;
         sc.energy = scratch + off;
+        sc.partials = partials;
+        if (a.lds_scratch) {
+            // The hot arrays live in LDS (the global copies above stay allocated as the fallback layout).  Two phases alias the
+            // same dynamic region:  estimate_period  [ 4096-point FFT buffer | nsdf | energy ]
+            //                       locate           [ work | candidate | scores ]
+            float* lds_f = reinterpret_cast<float*>(smem_raw);
+            sc.nsdf = lds_f + 2 * FFT4096_LDS;
+            sc.energy = sc.nsdf + a.max_period + 8;
+            sc.work = lds_f;
+            sc.candidate = sc.work + a.max_kernel + ms + 8;
+            sc.scores = sc.candidate + a.max_kernel + 8;
+        }
     }
     if (tid < kScopeTraces) trig[tid] = a.trig[(uint64_t)s * kScopeTraces + tid];
     __syncthreads();
@@ -619,6 +715,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     }
     const bool active[2] = {a.trace_channel[0] != OMX_CHANNEL_NONE, a.trace_channel[1] != OMX_CHANNEL_NONE};
 
+    PhaseClock pc;
+    pc.start(a.phase_timing != 0);
     for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
         // ---- push projected frames (:657-681)
         for (uint32_t f = tid; f < a.block_frames; f += 256) {
@@ -654,6 +752,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
             }
         }
         __syncthreads();
+        pc.mark(0);  // ring push
         View views[kScopeTraces];
         for (int t = 0; t < kScopeTraces; ++t)
             views[t] = View{rings + (uint64_t)t * a.cap, head[t] - len[t], mask, (uint32_t)len[t]};
@@ -665,7 +764,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
                 float* reference = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
                 // the trigger state lives in LDS; thread-uniform updates are done redundantly by every thread
                 ScopeTriggerState local = trig[trig_index];
-                const Capture c = stable_capture(local, reference, trace, a, fft, sc, sh);
+                const Capture c = stable_capture(local, reference, trace, a, fft, sc, sh, pc);
                 __syncthreads();
                 if (tid == 0) trig[trig_index] = local;
                 __syncthreads();
@@ -729,6 +828,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         }
         if (tid == 0) a.headers[(uint64_t)s * a.n_blocks + blk] = hdr;
         __syncthreads();
+        pc.mark(5);  // snapshot
     }
     if (tid < kScopeTraces) a.trig[(uint64_t)s * kScopeTraces + tid] = trig[tid];
 }
@@ -746,9 +846,26 @@ uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search_unused, u
     return off;
 }
 
+// bytes of the two aliased LDS layouts of the fast configuration (see oscilloscope_kernel)
+uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames) {
+    const uint32_t ms = (uint32_t)std::ceil((float)max_period * 1.5f) + 2;
+    const uint64_t estimate = 2ull * FFT4096_LDS + (max_period + 8ull) + (probe_frames + 8ull);
+    const uint64_t locate = (max_kernel + ms + 8ull) + (max_kernel + 8ull) + (std::max(ms, 256u) + 8ull);
+    return std::max(estimate, locate) * sizeof(float);
+}
+
+void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset) {
+    OMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scope_phase_cycles), SCOPE_PHASES * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[SCOPE_PHASES] = {};
+        OMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scope_phase_cycles), zero, sizeof(zero)));
+    }
+}
+
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
-    const size_t lds = a.fft_global ? 0 : (size_t)a.fft_size * sizeof(v2f);
+    size_t lds = a.fft_global ? 0 : (size_t)a.fft_size * sizeof(v2f);
+    if (a.lds_scratch) lds = std::max(lds, (size_t)scope_lds_scratch_bytes(a.max_kernel, a.max_period, a.probe_frames));
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(oscilloscope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
