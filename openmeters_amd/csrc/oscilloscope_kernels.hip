@@ -153,8 +153,10 @@ struct PhaseClock {
 };
 
 // ---------------------------------------------------------------- PeriodEstimator::estimate_period (:93-181)
+using ScopeTwiddles = TwiddleSource<true, true>;  // pass-2 table in LDS, pass-3 twiddles in VGPRs, loaded once per kernel
+
 __device__ Estimate estimate_period(const View& x, float rate, float& last_peak, const ScopeArgs& a, v2f* fft, Scratch& sc,
-                                    Shared& sh, PhaseClock& pc) {
+                                    Shared& sh, PhaseClock& pc, const ScopeTwiddles& tw) {
     const unsigned tid = threadIdx.x;
     Estimate none{0, 0.0f, 0.0f};
     last_peak = 0.0f;
@@ -220,7 +222,6 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
         //   P = |X|^2 (real, P[2N-k] = P[k]);  acf[2m] + i acf[2m+1] = IFFT_4096( (P[k] + P[k+N]) + i (P[k] - P[k+N]) conj(w^k) )
         constexpr uint32_t N = 4096;
         const int j = (int)tid;
-        const Fft4096Tables tb{a.tw256, a.tw4096};
         v2f v[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -229,7 +230,7 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
             const float im = 2u * m + 1u < n ? x.at(2u * m + 1u) - mean : 0.0f;
             v[t] = v2f{re, im};
         }
-        fft4096<false>(v, fft, j, tb);
+        fft4096t<false, false>(v, fft, fft, j, tw);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 16; ++t) fft[pad16(j + 256 * t)] = v[t];
@@ -250,7 +251,7 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
             y[t] = v2f{sum + dif * w.y, dif * w.x};  // (P[k] + P[k+N]) + i (P[k] - P[k+N]) conj(w^k)
         }
         __syncthreads();
-        fft4096<true>(y, fft, j, tb);  // y[t] = (acf[2m], acf[2m + 1]), m = j + 256 t
+        fft4096t<true, false>(y, fft, fft, j, tw);  // y[t] = (acf[2m], acf[2m + 1]), m = j + 256 t
         const float total_energy_f = sc.energy[n];
         if (total_energy_f > F32_EPS) {
 #pragma unroll
@@ -614,12 +615,12 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
 
 // StableTrigger::capture (:306-334)
 __device__ Capture stable_capture(ScopeTriggerState& t, float* reference, const View& trace, const ScopeArgs& a, v2f* fft,
-                                  Scratch& sc, Shared& sh, PhaseClock& pc) {
+                                  Scratch& sc, Shared& sh, PhaseClock& pc, const ScopeTwiddles& tw) {
     const uint32_t n = trace.n;
     const uint32_t probe_len = min(a.probe_frames, n);
     float last_peak = 0.0f;
     Estimate detected{0, 0.0f, 0.0f};
-    if (probe_len >= 3) detected = estimate_period(trace.sub(n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh, pc);
+    if (probe_len >= 3) detected = estimate_period(trace.sub(n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh, pc, tw);
     pc.mark(3);  // NSDF + peak picking
     if (probe_len > 0 && last_peak < MIN_SIGNAL_PEAK) trigger_unlock(t);
     const Estimate est = stabilize(t, detected);
@@ -703,6 +704,16 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
             sc.scores = sc.candidate + a.max_kernel + 8;
         }
     }
+    __shared__ v2f tw2_lds[256];
+    ScopeTwiddles tw;
+    tw.j = tid;
+    tw.tw3_global = a.tw4096;
+    tw.tw2 = tw2_lds;
+    if (a.tw4096) {  // fast autocorrelation configuration: twiddles resident for every block of the call
+#pragma unroll
+        for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[tid * (unsigned)t];
+        tw2_lds[tid] = a.tw256[tid];
+    }
     if (tid < kScopeTraces) trig[tid] = a.trig[(uint64_t)s * kScopeTraces + tid];
     __syncthreads();
     const uint64_t mask = a.cap - 1;
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
                 float* reference = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
                 // the trigger state lives in LDS; thread-uniform updates are done redundantly by every thread
                 ScopeTriggerState local = trig[trig_index];
-                const Capture c = stable_capture(local, reference, trace, a, fft, sc, sh, pc);
+                const Capture c = stable_capture(local, reference, trace, a, fft, sc, sh, pc, tw);
                 __syncthreads();
                 if (tid == 0) trig[trig_index] = local;
                 __syncthreads();
