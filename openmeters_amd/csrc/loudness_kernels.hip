@@ -41,9 +41,19 @@ struct LoudLane {
 };
 
 // Processes NB consecutive samples (x) with their expiring ring values (old, 0.0 while the window is not full).
-template <int NB, int DL>
-__device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&x)[NB], const double (&old)[NB], const LoudnessArgs& a,
-                                              double* ring_col, uint32_t row, uint32_t len, uint32_t cap, bool store_lane) {
+// MODE 0: everything in one lane (K-weighting + window + true-peak phase);  MODE 1: K-weighting + window only (the true
+// peak of the call is computed by the true-peak workgroups of the same launch);  MODE 2: true peak only.
+template <int NB, int DL, int MODE>
+__device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)[NB], const double (&oldr)[NB], uint32_t unf, bool live,
+                                              const LoudnessArgs& a, double* ring_col, uint32_t row, uint32_t len, uint32_t cap,
+                                              bool store_lane) {
+    float x[NB];
+    double old[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {  // the selects that loudness_fetch left out
+        x[k] = live ? xr[k] : 0.0f;
+        old[k] = (live && (uint32_t)k >= unf) ? oldr[k] : 0.0;
+    }
     float ext[NB + (DL > 0 ? DL - 1 : 0)];  // ext[NB-1-k] = x[k]; ext[NB + i] = hist[i]
 #pragma unroll
     for (int k = 0; k < NB; ++k) ext[NB - 1 - k] = x[k];
@@ -54,6 +64,7 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&x)[
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const float sample = x[k];
+        if constexpr (MODE != 2) {
         // ---- k_weighted (:153-162)
         const double xd = (double)sample;
         const double y = a.b[0] * xd + L.filt[0];
@@ -78,9 +89,10 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&x)[
         }
         if (store_lane) ring_col[(uint64_t)L.head * row] = value;
         L.head = L.head + 1 == len ? 0 : L.head + 1;
+        }
         // ---- TruePeakMeter::process (:123-150): window newest-first = ext[NB-1-k + i]
-        L.peak = fmaxf(L.peak, fabsf(sample));
-        if constexpr (DL > 0) {
+        if constexpr (MODE != 1) L.peak = fmaxf(L.peak, fabsf(sample));
+        if constexpr (DL > 0 && MODE != 1) {
             float o = 0.0f;
 #pragma unroll
             for (int i = 0; i < DL; ++i) o += ext[NB - 1 - k + i] * L.taps[i];
@@ -93,33 +105,33 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&x)[
     }
 }
 
-template <int NB, int DL>
-__device__ __forceinline__ void loudness_fetch(const LoudLane<DL>& L, float (&x)[NB], double (&old)[NB], const float* pcm,
+template <int NB, int DL, int MODE>
+__device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float (&x)[NB], double (&old)[NB], const float* pcm,
                                                uint64_t frame0, uint32_t channels, const double* ring_col, uint32_t row, uint32_t len,
                                                uint32_t cap, uint32_t ahead, bool live) {
     // `ahead` = samples between the lane's cursor (head, unfilled) and the first sample fetched here
     uint32_t h = L.head + ahead;
     h = h >= len ? h - len : h;
     const uint32_t unf = L.unfilled > ahead ? L.unfilled - ahead : 0u;
+    // Branch-free on purpose: a conditional load sits in its own basic block and the compiler drains vmcnt at every join,
+    // which serialises the whole prefetch.  Non-live lanes point at stream 0 / column 0 (always valid), the ring index is
+    // always inside the ring; what must not be used is discarded by the selects.
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        x[k] = 0.0f;
-        old[k] = 0.0;
-        if (live) {
-            x[k] = pcm[(frame0 + k) * channels];
-            if ((uint32_t)k >= unf) {  // dsp.rs:336-338: the value pushed `cap` samples ago, read before this sample's store
-                uint32_t pos = h + (uint32_t)k;
-                pos = pos >= len ? pos - len : pos;
-                const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
-                old[k] = ring_col[(uint64_t)idx * row];
-            }
-        }
+        const float xv = pcm[(frame0 + k) * channels];
+        uint32_t pos = h + (uint32_t)k;
+        pos = pos >= len ? pos - len : pos;
+        const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
+        double ov = 0.0;
+        if constexpr (MODE != 2) ov = ring_col[(uint64_t)idx * row];
+        x[k] = xv;   // raw: the selects happen where the values are consumed (a select here would wait for the load)
+        old[k] = ov;
     }
+    return unf;  // samples of this batch that precede the first expiring value (dsp.rs:336-338)
 }
 
-template <int B, int DL>  // B = samples per prefetch batch, DL = true-peak delay length (12: 4x, 24: 2x, 0: off)
-__global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
-    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+template <int B, int DL, int MODE>
+__device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gid) {
     const uint32_t r = gid & 3, chan = gid >> 2;      // chan = stream * 8 + channel
     const uint32_t s = chan >> 3, c = chan & 7;
     const bool live = s < a.n_streams && c < a.channels;
@@ -132,13 +144,15 @@ __global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
     for (int i = 0; i < (DL > 1 ? DL - 1 : 1); ++i) L.hist[i] = 0.0f;
     if (live) {
         const LoudnessChannelState& st = a.state[chan];
-        L.sum0 = st.sums[r][0];
-        L.sum1 = st.sums[r][1];
-        L.cor0 = st.corrections[r][0];
-        L.cor1 = st.corrections[r][1];
+        if constexpr (MODE != 2) {
+            L.sum0 = st.sums[r][0];
+            L.sum1 = st.sums[r][1];
+            L.cor0 = st.corrections[r][0];
+            L.cor1 = st.corrections[r][1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) L.filt[i] = st.filter[i];
-        if constexpr (DL > 1) {
+            for (int i = 0; i < 4; ++i) L.filt[i] = st.filter[i];
+        }
+        if constexpr (DL > 1 && MODE != 1) {
 #pragma unroll
             for (int i = 0; i < DL - 1; ++i) L.hist[i] = st.delay[i];
         }
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
     L.refresh = (uint32_t)(a.frames_seen % a.capacities[r]);                                             // dsp.rs:363
     L.unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);  // pushes until count >= cap
     uint64_t seen = a.frames_seen;
-    double* ring_col = a.ring + chan;
+    double* ring_col = a.ring + (live ? chan : 0);  // dead lanes read column 0 (discarded) and never store
     const bool store_lane = live && r == 0;
     const uint32_t full = a.block_frames / B, tail = a.block_frames % B;
 
@@ -167,99 +181,342 @@ __global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
         // batch n+1 are issued before batch n is computed (HBM round trip hidden behind ~8 samples of f64 work)
         float xa[B], xb[B];
         double oa[B], ob[B];
-        if (full > 0) loudness_fetch<B, DL>(L, xa, oa, pcm, f_blk, a.channels, ring_col, row, len, cap, 0, live);
+        uint32_t ua = 0, ub = 0;
+        if (full > 0) ua = loudness_fetch<B, DL, MODE>(L, xa, oa, pcm, f_blk, a.channels, ring_col, row, len, cap, 0, live);
         uint32_t q = 0;
         for (; q + 2 <= full; q += 2) {
-            loudness_fetch<B, DL>(L, xb, ob, pcm, f_blk + (uint64_t)(q + 1) * B, a.channels, ring_col, row, len, cap, B, live);
-            loudness_step<B, DL>(L, xa, oa, a, ring_col, row, len, cap, store_lane);
+            ub = loudness_fetch<B, DL, MODE>(L, xb, ob, pcm, f_blk + (uint64_t)(q + 1) * B, a.channels, ring_col, row, len, cap, B, live);
+            loudness_step<B, DL, MODE>(L, xa, oa, ua, live, a, ring_col, row, len, cap, store_lane);
             if (q + 2 < full)
-                loudness_fetch<B, DL>(L, xa, oa, pcm, f_blk + (uint64_t)(q + 2) * B, a.channels, ring_col, row, len, cap, B, live);
-            loudness_step<B, DL>(L, xb, ob, a, ring_col, row, len, cap, store_lane);
+                ua = loudness_fetch<B, DL, MODE>(L, xa, oa, pcm, f_blk + (uint64_t)(q + 2) * B, a.channels, ring_col, row, len, cap, B, live);
+            loudness_step<B, DL, MODE>(L, xb, ob, ub, live, a, ring_col, row, len, cap, store_lane);
         }
-        if (q < full) loudness_step<B, DL>(L, xa, oa, a, ring_col, row, len, cap, store_lane);
+        if (q < full) loudness_step<B, DL, MODE>(L, xa, oa, ua, live, a, ring_col, row, len, cap, store_lane);
         for (uint32_t k = 0; k < tail; ++k) {  // block_frames % B leftover samples, one at a time
             float x1[1];
             double o1[1];
-            loudness_fetch<1, DL>(L, x1, o1, pcm, f_blk + (uint64_t)full * B + k, a.channels, ring_col, row, len, cap, 0, live);
-            loudness_step<1, DL>(L, x1, o1, a, ring_col, row, len, cap, store_lane);
+            const uint32_t u1 = loudness_fetch<1, DL, MODE>(L, x1, o1, pcm, f_blk + (uint64_t)full * B + k, a.channels, ring_col, row, len,
+                                                            cap, 0, live);
+            loudness_step<1, DL, MODE>(L, x1, o1, u1, live, a, ring_col, row, len, cap, store_lane);
         }
         seen += a.block_frames;
 
         // ---- end of block: denormal flush (:281-285) and snapshot (:287-310)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (fabs(L.filt[i]) < 1.0e-30) L.filt[i] = 0.0;
-        const uint64_t cnt = max(min(min(seen, a.ring_len), a.capacities[r]), (uint64_t)1);  // dsp.rs:367-370
-        const double mean_r = (L.sum0 + L.cor0) / (double)cnt;
-        // channel-level values: means of the four windows (lanes 4q..4q+3) and the max of the lane peaks
-        const int lane = threadIdx.x, chan_lane0 = lane & ~3;
-        const double mean_fast = __shfl(mean_r, chan_lane0 + 2), mean_slow = __shfl(mean_r, chan_lane0 + 3);
-        float pk = fmaxf(L.peak, __shfl_xor(L.peak, 1));
-        pk = fmaxf(pk, __shfl_xor(pk, 2));
-        L.peak = 0.0f;  // std::mem::take (:301)
-        // position-weighted channel sums in channel order (:292-296): lane (stream_lane0 + 4k + w) holds window w of channel k
-        double short_term = 0.0, momentary = 0.0;
-        const int stream_lane0 = lane & ~31;
-        for (uint32_t k = 0; k < a.channels; ++k) {
-            const double ms = __shfl(mean_r, stream_lane0 + 4 * (int)k + 0);
-            const double mm = __shfl(mean_r, stream_lane0 + 4 * (int)k + 1);
-            short_term += ms * a.weights[k];
-            momentary += mm * a.weights[k];
+        const int lane = threadIdx.x;
+        if constexpr (MODE != 1) {  // true peak: max over the lanes (phases) of the channel, taken at every block (:301)
+            float pk = fmaxf(L.peak, __shfl_xor(L.peak, 1));
+            pk = fmaxf(pk, __shfl_xor(pk, 2));
+            L.peak = 0.0f;  // std::mem::take (:301)
+            if (live && r == 0) {
+                omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + blk;
+                snap->true_peak_db[c] = power_to_db_f(pk * pk, a.floor_db);
+                if (c == 0)
+                    for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) snap->true_peak_db[i] = a.floor_db;  // with_floor (:197-207)
+            }
         }
-        if (live && r == 0) {
-            omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + blk;
-            snap->rms_fast_db[c] = power_to_db_f((float)mean_fast, a.floor_db);
-            snap->rms_slow_db[c] = power_to_db_f((float)mean_slow, a.floor_db);
-            snap->true_peak_db[c] = power_to_db_f(pk * pk, a.floor_db);
-            if (c == 0) {
-                snap->short_term_loudness = mean_square_to_lufs(short_term, a.floor_db);
-                snap->momentary_loudness = mean_square_to_lufs(momentary, a.floor_db);
-                snap->channel_count = a.channels;
-                snap->_pad = 0;
-                for (int i = 0; i < OMX_MAX_CHANNELS; ++i) snap->positions[i] = a.positions[i];
-                for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) {  // LoudnessSnapshot::with_floor (:197-207)
-                    snap->rms_fast_db[i] = a.floor_db;
-                    snap->rms_slow_db[i] = a.floor_db;
-                    snap->true_peak_db[i] = a.floor_db;
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (fabs(L.filt[i]) < 1.0e-30) L.filt[i] = 0.0;
+            const uint64_t cnt = max(min(min(seen, a.ring_len), a.capacities[r]), (uint64_t)1);  // dsp.rs:367-370
+            const double mean_r = (L.sum0 + L.cor0) / (double)cnt;
+            // channel-level values: means of the four windows (lanes 4q..4q+3)
+            const int chan_lane0 = lane & ~3;
+            const double mean_fast = __shfl(mean_r, chan_lane0 + 2), mean_slow = __shfl(mean_r, chan_lane0 + 3);
+            // position-weighted channel sums in channel order (:292-296): lane (stream_lane0 + 4k + w) holds window w of channel k
+            double short_term = 0.0, momentary = 0.0;
+            const int stream_lane0 = lane & ~31;
+            for (uint32_t k = 0; k < a.channels; ++k) {
+                const double ms = __shfl(mean_r, stream_lane0 + 4 * (int)k + 0);
+                const double mm = __shfl(mean_r, stream_lane0 + 4 * (int)k + 1);
+                short_term += ms * a.weights[k];
+                momentary += mm * a.weights[k];
+            }
+            if (live && r == 0) {
+                omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + blk;
+                snap->rms_fast_db[c] = power_to_db_f((float)mean_fast, a.floor_db);
+                snap->rms_slow_db[c] = power_to_db_f((float)mean_slow, a.floor_db);
+                if (c == 0) {
+                    snap->short_term_loudness = mean_square_to_lufs(short_term, a.floor_db);
+                    snap->momentary_loudness = mean_square_to_lufs(momentary, a.floor_db);
+                    snap->channel_count = a.channels;
+                    snap->_pad = 0;
+                    for (int i = 0; i < OMX_MAX_CHANNELS; ++i) snap->positions[i] = a.positions[i];
+                    for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) {  // LoudnessSnapshot::with_floor (:197-207)
+                        snap->rms_fast_db[i] = a.floor_db;
+                        snap->rms_slow_db[i] = a.floor_db;
+                    }
                 }
             }
         }
     }
     if (live) {
         LoudnessChannelState& st = a.state[chan];
-        st.sums[r][0] = L.sum0;
-        st.sums[r][1] = L.sum1;
-        st.corrections[r][0] = L.cor0;
-        st.corrections[r][1] = L.cor1;
-        if (r == 0) {
+        if constexpr (MODE != 2) {
+            st.sums[r][0] = L.sum0;
+            st.sums[r][1] = L.sum1;
+            st.corrections[r][0] = L.cor0;
+            st.corrections[r][1] = L.cor1;
+            if (r == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st.filter[i] = L.filt[i];
-            if constexpr (DL > 1) {
-#pragma unroll
-                for (int i = 0; i < DL - 1; ++i) st.delay[i] = L.hist[i];
+                for (int i = 0; i < 4; ++i) st.filter[i] = L.filt[i];
             }
-            st.peak = 0.0f;
+        }
+        if constexpr (MODE != 1) {
+            if (r == 0) {
+                if constexpr (DL > 1) {
+#pragma unroll
+                    for (int i = 0; i < DL - 1; ++i) st.delay[i] = L.hist[i];
+                }
+                st.peak = 0.0f;
+            }
         }
     }
 }
 
+template <int B, int DL, bool SPLIT>
+__global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
+    if constexpr (!SPLIT) {
+        loudness_body<B, DL, 0>(a, blockIdx.x * 64 + threadIdx.x);
+    } else {
+        if (blockIdx.x < a.n_meter_blocks) loudness_body<B, DL, 1>(a, blockIdx.x * 64 + threadIdx.x);
+        else loudness_body<B, DL, 2>(a, (blockIdx.x - a.n_meter_blocks) * 64 + threadIdx.x);
+    }
+}
+
+// ---- role-per-wavefront form -------------------------------------------------------------------------------------------
+// Meter workgroup = 5 wavefronts over 64 (stream, channel) slots (lane = slot): wavefront 0 runs the K-weighting filter and
+// hands (f32-rounded y)^2 to the others through a double-buffered LDS batch; wavefronts 1..4 each own one sliding window
+// (its KBN pair, its expiring-value reads, its fields of the snapshot); window 0 — the longest, cap == ring length — also
+// stores the new values to the ring right after it has read the expiring ones, exactly like lane 0 of the lane-quad form.
+// No wavefront executes another role's instructions, so the per-sample cost is the window's (3 KBN adds), not the sum of
+// filter + window + interpolator.  True peak runs in separate workgroups (MODE 2 of loudness_body).  Every per-window
+// recurrence is still strictly sequential in time: results are bit-identical to the lane-quad form.
+// Workgroup barrier for data handed over through LDS only: waits for this wavefront's LDS traffic, not for its outstanding
+// global loads (__syncthreads would drain the expiring-value prefetches of the window wavefronts at every round).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int B, int NSUB, int DL>  // B samples per prefetch batch, NSUB batches per barrier round (= prefetch depth of the windows)
+__global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
+    static_assert(NSUB == 4, "four rotating prefetch buffers");
+    if (blockIdx.x >= a.n_meter_blocks) {  // true-peak workgroups: 80 channels x 4 phase lanes
+        loudness_body<8, DL, 2>(a, (blockIdx.x - a.n_meter_blocks) * 320 + threadIdx.x);
+        return;
+    }
+    __shared__ double vals[2][NSUB * B][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t chan = blockIdx.x * 64 + lane;  // stream * 8 + channel
+    const uint32_t s = chan >> 3, c = chan & 7;
+    const bool live = s < a.n_streams && c < a.channels;
+    const uint32_t row = a.n_streams * 8;
+    const uint32_t full = a.block_frames / B;           // batches per block (block_frames % (B * NSUB) == 0, host-checked)
+    const uint64_t total = (uint64_t)a.n_blocks * full;   // batches of the call
+    const uint64_t rounds = total / NSUB;                 // barrier rounds carrying data
+    const float* pcm = a.pcm + ((uint64_t)(live ? s : 0) * a.frames_total) * a.channels + (live ? c : 0);
+    double* ring_col = a.ring + (live ? chan : 0);  // dead lanes read column 0 (discarded) and never store
+    const uint32_t len = (uint32_t)a.ring_len;
+
+    if (wave == 0) {
+        // ---------------- K-weighting wavefront ----------------
+        double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+        if (live) {
+            const LoudnessChannelState& st = a.state[chan];
+            f0 = st.filter[0];
+            f1 = st.filter[1];
+            f2 = st.filter[2];
+            f3 = st.filter[3];
+        }
+        float xa[B], xb[B];
+        auto fetch = [&](float (&x)[B], uint64_t batch) {
+#pragma unroll
+            for (int k = 0; k < B; ++k)  // unconditional raw loads (see loudness_fetch); past the end of the call: batch 0 again
+                x[k] = pcm[((batch < total ? batch : 0) * B + k) * a.channels];
+        };
+        auto produce = [&](const float (&x)[B], uint32_t buf, uint32_t sub, uint64_t batch) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) {  // k_weighted (:153-162)
+                const double xd = (double)(live ? x[k] : 0.0f);
+                const double y = a.b[0] * xd + f0;
+                f0 = a.b[1] * xd + f1 - a.a[1] * y;
+                f1 = a.b[2] * xd + f2 - a.a[2] * y;
+                f2 = a.b[3] * xd + f3 - a.a[3] * y;
+                f3 = a.b[4] * xd - a.a[4] * y;
+                const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
+                double value = filtered * filtered;
+                value = isfinite(value) ? value : 0.0;     // WindowedMeans::push (dsp.rs:325)
+                vals[buf][sub * B + k][lane] = value;
+            }
+            if ((batch + 1) % full == 0) {  // denormal flush after a block's last sample (:281-285)
+                if (fabs(f0) < 1.0e-30) f0 = 0.0;
+                if (fabs(f1) < 1.0e-30) f1 = 0.0;
+                if (fabs(f2) < 1.0e-30) f2 = 0.0;
+                if (fabs(f3) < 1.0e-30) f3 = 0.0;
+            }
+        };
+        fetch(xa, 0);
+        // round i: this wavefront fills buffer i & 1 with batches [i NSUB, (i + 1) NSUB) while the window wavefronts consume
+        // round i - 1 from the other buffer; one barrier per round
+        for (uint64_t i = 0; i <= rounds; ++i) {
+            if (i < rounds) {
+                const uint64_t b0 = i * NSUB;
+#pragma unroll
+                for (int sb = 0; sb < NSUB; sb += 2) {
+                    fetch(xb, b0 + sb + 1);
+                    produce(xa, (uint32_t)(i & 1), sb, b0 + sb);
+                    fetch(xa, b0 + sb + 2);
+                    produce(xb, (uint32_t)(i & 1), sb + 1, b0 + sb + 1);
+                }
+            }
+            lds_barrier();
+        }
+        if (live) {
+            LoudnessChannelState& st = a.state[chan];
+            st.filter[0] = f0;
+            st.filter[1] = f1;
+            st.filter[2] = f2;
+            st.filter[3] = f3;
+        }
+        return;
+    }
+
+    // ---------------- window wavefronts ----------------
+    const uint32_t r = wave - 1;
+    const uint32_t cap = (uint32_t)a.capacities[r];
+    double sum0 = 0.0, sum1 = 0.0, cor0 = 0.0, cor1 = 0.0;
+    if (live) {
+        const LoudnessChannelState& st = a.state[chan];
+        sum0 = st.sums[r][0];
+        sum1 = st.sums[r][1];
+        cor0 = st.corrections[r][0];
+        cor1 = st.corrections[r][1];
+    }
+    uint32_t head = (uint32_t)(a.frames_seen % a.ring_len);
+    uint32_t refresh = (uint32_t)(a.frames_seen % a.capacities[r]);
+    uint32_t unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);
+    uint64_t seen = a.frames_seen;
+    const bool store_lane = live && r == 0;
+    double o0[B], o1[B], o2[B], o3[B];  // expiring values, fetched four batches (32 samples, several HBM round trips) ahead
+    // expiring values of the batch that starts `ahead` samples from the cursor (dsp.rs:336-338); `batch` only gates the tail
+    auto fetch_old = [&](double (&old)[B], uint32_t ahead, uint64_t batch) -> uint32_t {
+        uint32_t h = head + ahead;
+        h = h >= len ? h - len : h;
+        const uint32_t unf = unfilled > ahead ? unfilled - ahead : 0u;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {  // unconditional raw loads (see loudness_fetch): the selects happen in consume()
+            uint32_t pos = h + (uint32_t)k;
+            pos = pos >= len ? pos - len : pos;
+            const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
+            old[k] = ring_col[(uint64_t)idx * row];
+        }
+        return batch < total ? unf : (uint32_t)B;  // first sample of the batch that has an expiring value
+    };
+    auto snapshot = [&](uint32_t blk) {
+        const uint64_t cnt = max(min(min(seen, a.ring_len), a.capacities[r]), (uint64_t)1);  // dsp.rs:367-370
+        const double mean_r = (sum0 + cor0) / (double)cnt;
+        omx_loudness_snapshot* snap = a.snapshots + (uint64_t)(live ? s : 0) * a.n_blocks + blk;
+        if (r < 2) {  // position-weighted channel sum in channel order (:292-296): the 8 lanes of a stream
+            double acc = 0.0;
+            const int stream_lane0 = (int)(lane & ~7u);
+            for (uint32_t k = 0; k < a.channels; ++k) acc += __shfl(mean_r, stream_lane0 + (int)k) * a.weights[k];
+            if (live && c == 0) {
+                const float lufs = mean_square_to_lufs(acc, a.floor_db);
+                if (r == 0) {
+                    snap->short_term_loudness = lufs;
+                    snap->channel_count = a.channels;
+                    snap->_pad = 0;
+                    for (int i = 0; i < OMX_MAX_CHANNELS; ++i) snap->positions[i] = a.positions[i];
+                } else {
+                    snap->momentary_loudness = lufs;
+                }
+            }
+        } else if (live) {
+            float* field = r == 2 ? snap->rms_fast_db : snap->rms_slow_db;
+            field[c] = power_to_db_f((float)mean_r, a.floor_db);
+            if (c == 0)
+                for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) field[i] = a.floor_db;  // with_floor (:197-207)
+        }
+    };
+    auto consume = [&](const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const double value = vals[buf][sub * B + k][lane];
+            const double expiring = (live && (uint32_t)k >= first_valid) ? old[k] : 0.0;
+            kbn_add(sum0, cor0, value);
+            kbn_add(sum1, cor1, value);
+            kbn_add(sum0, cor0, -expiring);
+            unfilled -= (unfilled != 0u) ? 1u : 0u;
+            if (++refresh == cap) {  // CompensatedPair::refresh (dsp.rs:287-289)
+                sum0 = sum1;
+                sum1 = 0.0;
+                cor0 = cor1;
+                cor1 = 0.0;
+                refresh = 0;
+            }
+            if (store_lane) ring_col[(uint64_t)head * row] = value;
+            head = head + 1 == len ? 0 : head + 1;
+        }
+        seen += B;
+        if ((batch + 1) % full == 0) snapshot((uint32_t)((batch + 1) / full - 1));
+    };
+    uint32_t u0 = fetch_old(o0, 0, 0), u1 = fetch_old(o1, B, 1), u2 = fetch_old(o2, 2 * B, 2), u3 = fetch_old(o3, 3 * B, 3);
+    for (uint64_t i = 0; i <= rounds; ++i) {
+        if (i >= 1) {  // consume round i - 1 (buffer (i - 1) & 1); after a batch is consumed its registers take the batch 4 ahead
+            const uint64_t b0 = (i - 1) * NSUB;
+            const uint32_t buf = (uint32_t)((i - 1) & 1);
+            consume(o0, u0, buf, 0, b0);
+            u0 = fetch_old(o0, 3 * B, b0 + 4);
+            consume(o1, u1, buf, 1, b0 + 1);
+            u1 = fetch_old(o1, 3 * B, b0 + 5);
+            consume(o2, u2, buf, 2, b0 + 2);
+            u2 = fetch_old(o2, 3 * B, b0 + 6);
+            consume(o3, u3, buf, 3, b0 + 3);
+            u3 = fetch_old(o3, 3 * B, b0 + 7);
+        }
+        lds_barrier();
+    }
+    if (live) {
+        LoudnessChannelState& st = a.state[chan];
+        st.sums[r][0] = sum0;
+        st.sums[r][1] = sum1;
+        st.corrections[r][0] = cor0;
+        st.corrections[r][1] = cor1;
+    }
+}
+
 template <int DL>
-static void launch_loudness_dl(const LoudnessArgs& a, dim3 grid, bool batched, hipStream_t stream) {
-    if (batched) hipLaunchKernelGGL((loudness_kernel<8, DL>), grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((loudness_kernel<1, DL>), grid, dim3(64), 0, stream, a);
+static void launch_loudness_dl(LoudnessArgs a, uint32_t blocks, bool batched, bool split, hipStream_t stream) {
+    a.n_meter_blocks = blocks;
+    if (batched && split) hipLaunchKernelGGL((loudness_kernel<8, DL, true>), dim3(2 * blocks), dim3(64), 0, stream, a);
+    else if (batched) hipLaunchKernelGGL((loudness_kernel<8, DL, false>), dim3(blocks), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((loudness_kernel<1, DL, false>), dim3(blocks), dim3(64), 0, stream, a);
 }
 
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     const uint32_t threads = a.n_streams * 32;  // 8 channels x 4 lanes per stream
-    const dim3 grid((threads + 63) / 64);
+    const uint32_t grid = (threads + 63) / 64;
     uint64_t min_cap = a.capacities[0];
     for (int w = 1; w < kLoudnessWindows; ++w) min_cap = std::min(min_cap, a.capacities[w]);
     // prefetching two batches of expiring values is only valid when no window is shorter than two batches
     const bool batched = min_cap >= 16;
-    if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, stream);
-    else if (a.delay_len == 24) launch_loudness_dl<24>(a, grid, batched, stream);
-    else launch_loudness_dl<0>(a, grid, batched, stream);
+    // split roles while the single-role launch would leave SIMDs idle (one 64-lane workgroup per SIMD fills 1024 of them)
+    static const int force = [] {
+        const char* e = getenv("OMX_LOUDNESS_SPLIT");  // 0 / 1 pins the form (A/B and tests)
+        return e ? atoi(e) : -1;
+    }();
+    const bool split = force >= 0 ? force != 0 : (a.delay_len != 0 && grid <= 4096);
+    // role-per-wavefront form (OMX_LOUDNESS_SPLIT=2 pins it, default when it applies): whole batches per block, 4x interpolator
+    const bool roles = (force == 2 || (force < 0 && grid <= 4096)) && min_cap >= 64 && a.block_frames % 32 == 0 && a.delay_len == 12;
+    if (roles) {
+        LoudnessArgs r = a;
+        r.n_meter_blocks = (a.n_streams * 8 + 63) / 64;
+        const uint32_t peak_blocks = (a.n_streams * 32 + 319) / 320;
+        hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12>), dim3(r.n_meter_blocks + peak_blocks), dim3(320), 0, stream, r);
+        return;
+    }
+    if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, split, stream);
+    else if (a.delay_len == 24) launch_loudness_dl<24>(a, grid, batched, split, stream);
+    else launch_loudness_dl<0>(a, grid, batched, false, stream);
 }
 
 }  // namespace omx
