@@ -284,3 +284,35 @@ class OscilloscopeBank(_BlockBank):
         self.api.check(self.api.fn("oscilloscope_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p])(
             self._h, stream_index, block, C.byref(hdr), buf.ctypes.data if with_samples else None))
         return hdr, buf
+
+
+class WaveformBank(_BlockBank):
+    """reference src/visuals/waveform/processor.rs:135-353, S streams in lock-step; one block per call (the column phase is
+    advanced on the host)."""
+    _family = "waveform"
+
+    def __init__(self, api: Api, config: capi.WaveformConfig, n_streams: int):
+        super().__init__(api, config.to_c(), n_streams)
+
+    def _process(self, ptr, on_device, frames, channels, sample_rate, positions, stream):
+        out = capi.CWaveformBankUpdate()
+        f = self.api.fn("waveform_bank_process", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_float, _u8x8,
+                                                           C.c_void_p, C.c_void_p])
+        rc = self.api.check(f(self._h, C.c_void_p(ptr), int(on_device), frames, channels, sample_rate, _u8x8(*positions),
+                              C.c_void_p(stream or 0), C.byref(out)))
+        return out if rc == capi.PRODUCED else None
+
+    def process_device(self, device_ptr, frames, channels, sample_rate, positions, stream=0):
+        return self._process(device_ptr, True, frames, channels, sample_rate, positions, stream)
+
+    def process_host(self, pcm, channels, sample_rate, positions=None):
+        pcm = self._pcm(pcm, channels)
+        positions = positions if positions is not None else capi.positions_fallback(channels)
+        return self._process(pcm.ctypes.data, False, pcm.shape[1], channels, sample_rate, positions, 0)
+
+    def fetch(self, stream_index, n_columns, with_preview=False):
+        cols = np.zeros((max(n_columns, 1), 4, 11), np.float32)
+        prev = np.zeros((4, 11), np.float32) if with_preview else None
+        self.api.check(self.api.fn("waveform_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p])(
+            self._h, stream_index, cols.ctypes.data, prev.ctypes.data if with_preview else None))
+        return cols[:n_columns], prev

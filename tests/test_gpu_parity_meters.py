@@ -281,3 +281,33 @@ def test_summary_reductions_on_device_resident_bank_outputs(omx, oracle):
     assert np.array_equal(got[:, :, :3], want["values"]) and np.abs(got[:, :, 3:] - want["peaks"]).max() <= 1e-5
     assert np.array_equal(holds.cpu().numpy().view(capi.PEAK_HOLD_DTYPE)["db"], oh["db"])
     assert (want["peaks"][:, 20, 0] > want["values"][:, 20, 0] + 10.0).all() and (want["peaks"][:, -1, 0] < want["peaks"][:, 20, 0]).all()
+
+
+def test_waveform_bank_matches_per_stream_oracle(omx, oracle):
+    """bank of 7 streams, irregular block sizes: column counts / reset flags in lock-step, min / max bit-exact per stream"""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    S = 7
+    cfg = WaveformConfig(scroll_speed=240.0, max_columns=256, analyze_bands=True, track_history=True)
+    pcm = np.stack([cfg4_pcm(s, 256 * 90) for s in range(S)])
+    bank = banks.WaveformBank(omx, cfg, S)
+    refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
+    at, total = 0, 0
+    for n in [256, 256, 1000, 37, 4096, 256, 2048, 9000, 256]:
+        chunk = pcm[:, at:at + n]
+        at += n
+        up = bank.process_host(chunk, 2, FS)
+        wants = [r.process_block(AudioBlock(chunk[s].reshape(-1), 2, FS)) for s, r in enumerate(refs)]
+        assert (up is None) == (wants[0] is None)
+        if up is None:
+            continue
+        for s in (0, 3, 6):
+            w = wants[s]
+            assert up.n_columns == len(w.columns) and bool(up.reset) == w.reset and bool(up.preview_some) == (w.preview is not None)
+            got, prev = bank.fetch(s, int(up.n_columns), with_preview=True)
+            assert np.array_equal(got[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32))
+            if len(got):
+                assert np.abs(got[:, :, 2:5] - w.columns[:, :, 2:5]).max() <= 1e-6 * max(1.0, np.abs(w.columns[:, :, 2:5]).max())
+            if w.preview is not None:
+                assert np.array_equal(prev[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32))
+        total += int(up.n_columns)
+    assert total > 50
