@@ -116,3 +116,26 @@ def test_sharded_streams_gather_over_gloo_world_size_2(oracle, tmp_path):
                         "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_generated_rust_ffi_layer_covers_the_header():
+    """bindings/rust/omx_sys.rs (tools/gen_rust_ffi.py) is what the reference — a Rust crate — would link against: every
+    function of include/omx.h must be there, with the header's parameter count; every struct with the header's field count."""
+    import re
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], check=True, capture_output=True)
+    rs = open(os.path.join(ROOT, "bindings", "rust", "omx_sys.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "omx.h")).read(), flags=re.S)
+    header = "\n".join(l for l in header.split("\n") if not l.lstrip().startswith("#"))
+    fns = dict(re.findall(r"pub fn (omx_\w+)\((.*?)\)", rs))
+    for s in declared_symbols():
+        assert s in fns, s
+        m = re.search(r"\b" + s + r"\s*\(([^;{}]*?)\)\s*;", header, flags=re.S)
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len([p for p in fns[s].split(",") if p.strip()]) == len(params), s
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", header, flags=re.S):
+        n_fields = len([f for f in m.group(2).split(";") if f.strip()])
+        body = re.search(r"pub struct " + m.group(3) + r" \{\n(.*?)\n\}", rs, flags=re.S).group(1)
+        assert body.count("pub ") == n_fields, m.group(3)
+    assert "define" not in rs and rs.count("#[repr(C)]") >= 30
