@@ -163,6 +163,18 @@ __device__ __forceinline__ void fftp_mid3_inplace(v2f* buf, int jf, const Twiddl
 #pragma unroll
     for (int t = 0; t < 16; ++t) buf[base + 272 * t] = a[DFT16_OUT(t)];
 }
+// Ping-pong transform of a SUBSET of a frame's threads (`act`), inside a frame whose barriers are sized by LOGSYNC: every
+// thread of the frame reaches the barriers, only the active ones touch data.  Used by the zero-padded kernel, whose Hilbert
+// transforms (window length W) are smaller than its windowed transforms (F = zp W).  Three-pass sizes only.
+template <bool INV, int LOGN, int LOGSYNC>
+__device__ __forceinline__ void fftp_masked(bool act, v2f (&v)[16], v2f* first, v2f* second, int jf, const TwiddlesPow2<LOGN>& tw) {
+    static_assert(FftGeom<LOGN>::PASSES == 3, "three-pass sizes only");
+    if (act) fftp_pass1<INV, LOGN>(v, first, jf);
+    frame_sync<LOGSYNC>();
+    if (act) fftp_pass2<INV, LOGN>(first, second, jf, tw);
+    frame_sync<LOGSYNC>();
+    if (act) fftp_pass3<INV, LOGN>(v, second, jf, tw);
+}
 // In place in one buffer (one extra barrier in pass 2): half the LDS of the ping-pong form, for kernels that run a single
 // transform per frame slot (classic columns, spectrum).
 template <bool INV, int LOGN>

@@ -151,10 +151,13 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     // fused kernels: W = F in {1024, 2048, 4096} (the tuned 4096 kernel / the size-templated ones; classic and reassigned)
     // (16384 classic only: its reassigned form needs two 139 KiB LDS buffers, or 1024 threads under a 128-VGPR cap)
     fast4096_ = (W == fft_size_ && (W == 8192 || W == 4096 || W == 2048 || W == 1024 || (!reassign && W == 16384)));
-    if (fast4096_) {
+    // zero-padded reassigned shapes with a fused kernel: window 1024 / 2048 padded to 2048 / 4096
+    fast_zp_ = reassign && ((W == 1024 && (fft_size_ == 2048 || fft_size_ == 4096)) || (W == 2048 && fft_size_ == 4096));
+    if (fast4096_ || fast_zp_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
-        d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / N)
-        d_tw8192_.upload(twiddle_table(2 * W, W), stream);  // exp(-2 pi i k / 2N)
+        d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / W)
+        d_tw8192_.upload(twiddle_table(2 * W, W), stream);  // exp(-2 pi i k / 2W)
+        if (fast_zp_) d_twF_.upload(twiddle_table(fft_size_, fft_size_), stream);  // exp(-2 pi i k / F)
     }
     d_bin_norm_.upload(bin_norm, stream);
     OMX_HIP(hipStreamSynchronize(stream));  // host vectors above go out of scope
@@ -268,7 +271,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
 
     timer_.begin(stream);
     // the fused kernel indexes the ring with 32-bit offsets
-    const bool fast = fast4096_ && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30) && hop <= 0xFFFFFFFFull;
+    const bool fast = (fast4096_ || fast_zp_) && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30) && hop <= 0xFFFFFFFFull;
     if (fast) {
         StftFastArgs fa{};
         fa.ring = ring_.ptr;
@@ -297,7 +300,9 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
             const char* e = getenv("OMX_K2_VARIANT");
             return e && atoi(e) == 30;
         }();
-        if (!reassign)
+        if (fast_zp_)
+            (void)launch_stft_reassigned_zp(fa, (uint32_t)W, (uint32_t)fft_size_, reinterpret_cast<const v2f*>(d_twF_.ptr), stream);
+        else if (!reassign)
             launch_stft_classic_pow2(fa, d_codes_.ptr, (uint32_t)fft_size_, stream);
         else if (fft_size_ == 4096 && !cross_check)
             launch_stft_reassigned_4096(fa, stream);
@@ -307,10 +312,13 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         if (hop > 0xFFFFFFFFull) unsupported("hop_size beyond 2^32");
         const uint64_t per_wg = reassign ? hilbert_len_ + 3 * fft_size_ : fft_size_;
         const uint64_t total = (uint64_t)n_streams_ * n_cols;
-        // bound the workspace to ~1 GiB
-        uint64_t wgs = std::min<uint64_t>(total, 1024);
-        while (wgs > 1 && wgs * per_wg * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
-        d_workspace_.reserve((size_t)(wgs * per_wg * 2));
+        // working set in LDS when it fits one CU (<= 144 KiB), else a global workspace bounded to ~1 GiB
+        const bool ws_in_lds = per_wg * sizeof(v2f) <= 144 * 1024;
+        uint64_t wgs = std::min<uint64_t>(total, ws_in_lds ? 4096 : 1024);
+        if (!ws_in_lds) {
+            while (wgs > 1 && wgs * per_wg * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
+            d_workspace_.reserve((size_t)(wgs * per_wg * 2));
+        }
         StftGenericArgs ga{};
         ga.ring = ring_.ptr;
         ga.cap = ring_cap_;
@@ -337,7 +345,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         ga.inv_2pi = inv_2pi;
         ga.inv_hop = inv_hop;
         ga.latency_hops = latency_hops;
-        ga.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
+        ga.workspace = ws_in_lds ? nullptr : reinterpret_cast<v2f*>(d_workspace_.ptr);
         ga.workspace_stride = per_wg;
         ga.points = d_points_.ptr;
         ga.counts = d_counts_.ptr;

@@ -33,7 +33,7 @@ private:
 
     omx_spectrogram_config cfg_{};
     uint32_t n_streams_;
-    bool prepared_ = false, reset_ = true, fast4096_ = false, force_generic_ = false;
+    bool prepared_ = false, reset_ = true, fast4096_ = false, fast_zp_ = false, force_generic_ = false;
     size_t fft_size_ = 0, hilbert_len_ = 0;
     float power_scale_ = 1.0f;
     // pending audio: absolute sample counters shared by all streams (lock-step pushes)
@@ -41,7 +41,7 @@ private:
     DeviceBuffer<float> ring_, staging_;
     DeviceBuffer<long long> last_nonzero_, partial_nonzero_;
     DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
-    DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_workspace_;
+    DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_twF_, d_workspace_;
     DeviceBuffer<omx_spectrogram_point> d_points_;
     DeviceBuffer<uint32_t> d_counts_;
     DeviceBuffer<uint16_t> d_codes_;

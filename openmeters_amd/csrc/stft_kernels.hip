@@ -685,9 +685,12 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
     __shared__ uint32_t scan[4];
     __shared__ uint32_t running_sh;
     __shared__ float mean_sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char generic_smem[];
     const unsigned tid = threadIdx.x, nt = blockDim.x;
     const uint64_t total = (uint64_t)a.n_streams * a.n_cols;
-    v2f* ws = a.workspace + (uint64_t)blockIdx.x * a.workspace_stride;
+    // the working set (H + 3F complex values, or F for classic columns) lives in LDS when it fits one CU — same radix-2
+    // butterflies in the same order, so the output stays bit-identical to the global-workspace form
+    v2f* ws = a.workspace ? a.workspace + (uint64_t)blockIdx.x * a.workspace_stride : reinterpret_cast<v2f*>(generic_smem);
     const uint32_t bins = a.fft_size / 2 + 1;
     const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
 
@@ -783,7 +786,11 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
 
 void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_workgroups), dim3(256), 0, stream, a);
+    const size_t lds = a.workspace ? 0 : (size_t)a.workspace_stride * sizeof(v2f);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_workgroups), dim3(256), lds, stream, a);
 }
 
 // ================================================================================================

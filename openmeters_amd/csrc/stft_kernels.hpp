@@ -56,6 +56,8 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream);
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
 // size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);
+// zero-padded fused kernel: window 1024 / 2048, transform 2048 / 4096 (false: combination not covered)
+bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t fft_size, const v2f* twF, hipStream_t stream);
 // fused classic columns (u16 dB codes, two columns per complex FFT) for the same sizes
 void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t fft_size, hipStream_t stream);
 

@@ -319,6 +319,217 @@ void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t f
     }
 }
 
+// ================================================================================================
+// K2z: the same fused reassigned STFT with zero padding (the GUI offers 2 ... 32x, `ui/settings/spectrogram.rs:13`): window
+// length W = 2^LOGW, transform length F = 2^LOGF = zp W.  The Hilbert pair works on 2W samples (a W-point complex packing,
+// `processor.rs:546-557` with H = next_pow2(2W)) and is carried by the first W/16 threads of the frame; the analytic slice
+// (W values) is then spread over all F/16 threads, zero-extended to F (`apply_complex_window`, :559-567) and the three
+// windowed transforms, the reassignment and the compaction run exactly as in the unpadded kernel, over F/2 + 1 bins.
+// ================================================================================================
+template <int LOGW, int LOGF>
+__global__ __launch_bounds__(256, 2) void stft_reassigned_zp_kernel(StftFastArgs a, const v2f* __restrict__ twF) {
+    using GW = FftGeom<LOGW>;
+    using G = FftGeom<LOGF>;
+    static_assert(LOGF > LOGW && G::PASSES == 3 && GW::PASSES == 3 && G::WG == 256, "W < F <= 4096");
+    constexpr int W = GW::N, TW = GW::T, N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* lds = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = lds + 2 * F * G::LDS;                              // [256]
+    uint32_t* scan_all = reinterpret_cast<uint32_t*>(tw2_lds + 256);  // [F][9][WPF]
+    float* hil_all = reinterpret_cast<float*>(scan_all + F * 9 * WPF);  // [F][2]
+
+    const uint32_t chunks = (a.n_cols + F - 1) / F;
+    const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
+    const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
+    if (s >= a.n_streams) return;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    const unsigned ju = (unsigned)jf;
+    const int lane = threadIdx.x & 63, wf = jf >> 6;
+    const bool hact = jf < TW;  // the threads that carry the W-point Hilbert transforms
+    v2f* A = lds + (2 * fs) * G::LDS;
+    v2f* B = A + G::LDS;
+    uint32_t* scan = scan_all + fs * 9 * WPF;
+    float* hil = hil_all + fs * 2;
+    const uint32_t col_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = col_raw < a.n_cols;
+    const uint32_t col = in_range ? col_raw : a.n_cols - 1u;
+
+    const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
+    const long long last_nonzero = a.last_nonzero[s];
+    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    const uint32_t p32 = (uint32_t)p0;
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+    const uint64_t p0_first = a.tail + (uint64_t)(chunk * F) * a.hop;
+    if (last_nonzero < (long long)p0_first) {  // silent fast path (:307-316): the first slot has the smallest p0
+        if (jf == 0 && in_range) *count_out = 0;
+        return;
+    }
+    const bool silent = last_nonzero < (long long)p0;
+
+    TwiddlesPow2<LOGW> twh;  // Hilbert transforms (size W): `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W)
+    twh.tw2 = tw2_lds;
+    twh.load(a.tw4096, hact ? ju : 0u);
+    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+
+    // ---- 1. packed real FFT of the 2W-sample window (W/16 threads) -----------------------------------------------------------
+    const unsigned jh = hact ? ju : 0u;  // idle threads shadow thread 0's addresses (loads stay unconditional and in range)
+    v2f v[16], w2n[16];
+    if ((p0 & 1ull) == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            v[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((p32 + 2u * (jh + (unsigned)TW * (unsigned)t)) << 2) & bytemask));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qq = p32 + 2u * (jh + (unsigned)TW * (unsigned)t);
+            v[t] = v2f{*reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask)),
+                       *reinterpret_cast<const float*>(ring_bytes + (((qq + 1u) << 2) & bytemask))};
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w2n[t] = a.tw8192[jh + (unsigned)TW * (unsigned)t];
+    __syncthreads();  // tw2_lds (shared by every frame slot)
+    fftp_masked<false, LOGW, LOGF>(hact, v, A, B, jf, twh);
+
+    // ---- 2. Hilbert transform with one half-length inverse ---------------------------------------------------------------------
+    if (hact) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) A[pad16(jf + TW * t)] = v[t];
+        if (jf == 0) {
+            hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
+            hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[W] / 2
+        }
+    }
+    frame_sync<LOGF>();
+    v2f y[16];
+    if (hact) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned k = ju + (unsigned)TW * (unsigned)t;
+            const v2f z = v[t];
+            const v2f zr = A[pad16((int)(((unsigned)W - k) & (unsigned)(W - 1)))];
+            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
+            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+            y[t] = cmulc(sum, w2n[t]) - cmul(dif, w2n[t]);
+            if (k == 0) y[t] = v2f{0.0f, 0.0f};
+        }
+    }
+    const float half_x0 = hil[0], half_xn = hil[1];
+    // window tables and the real part's samples for THIS thread's slice elements i = jf + T u (i < W), in flight during the inverse
+    float pw[16], pdw[16], pxr[16];
+    {
+        const uint32_t qe = p32 + (uint32_t)(W / 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned i = ju + (unsigned)T * (unsigned)u;
+            const unsigned ic = i < (unsigned)W ? i : 0u;  // clamped: the value is discarded below when i >= W
+            pw[u] = a.window[ic];
+            pdw[u] = a.dwindow[ic];
+            pxr[u] = *reinterpret_cast<const float*>(ring_bytes + (((qe + ic) << 2) & bytemask));
+        }
+    }
+    fftp_masked<true, LOGW, LOGF>(hact, y, B, A, jf, twh);  // y[t] = (Im a[2m], Im a[2m+1]), m = jf + TW t
+
+    // ---- 3. analytic slice s[i] = analytic[W/2 + i], i < W, spread over the F/16 threads of the frame ---------------------
+    float* imag = reinterpret_cast<float*>(B);  // W floats
+    if (hact) {
+#pragma unroll
+        for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (jf + TW * t - W / 4)) = y[t];
+    }
+    TwiddlesPow2<LOGF> tw;  // windowed transforms (size F)
+    tw.tw2 = tw2_lds;
+    tw.load(twF, ju);
+    frame_sync<LOGF>();
+    const float parity = (jf & 1) ? -half_xn : half_xn;  // n = W/2 + i has the parity of jf (W/2 and T are even)
+    v2f vb[16], vd[16], vt[16];
+    constexpr float CENTER = (float)(W - 1) * 0.5f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = jf + T * u;
+        v2f sv{0.0f, 0.0f};
+        float w = 0.0f, dw = 0.0f, wt = 0.0f;
+        if (i < W) {  // compile-time for most u: i < W  <=>  u < 16 / zp (T u is a multiple of T, jf < T)
+            sv = v2f{(float)W * pxr[u] - half_x0 + parity, imag[i]};
+            w = pw[u];
+            dw = pdw[u];
+            wt = ((float)i - CENTER) * w;  // compute_time_weighted (:601-608)
+        }
+        vb[u] = v2f{sv.x * w, sv.y * w};   // zero beyond the window (:563-566)
+        vd[u] = v2f{sv.x * dw, sv.y * dw};
+        vt[u] = v2f{sv.x * wt, sv.y * wt};
+    }
+    frame_sync<LOGF>();  // imag[] (in B) is consumed
+    fftp_dual<false, LOGF>(vb, vd, A, B, jf, tw);
+    v2f bb[9], bd[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        bb[t] = vb[t];
+        bd[t] = vd[t];
+    }
+    float pn[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+    frame_sync<LOGF>();  // the paired transform's last pass still reads A and B
+    fftp<false, LOGF>(vt, A, B, jf, tw);
+
+    // ---- 4. reassignment + ordered compaction (bins jf + T t, t < 8, and bin F/2 on thread 0) ----------------------------
+    omx_spectrogram_point pts[9];
+    unsigned long long masks[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+        bool keep = false;
+        if ((t < 8 || jf == 0) && !silent) keep = reassign_bin_p(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]);
+        masks[t] = __ballot(keep);
+        if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
+    }
+    frame_sync<LOGF>();
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t before = running;
+#pragma unroll
+        for (int w = 0; w < WPF; ++w) {
+            const uint32_t c = scan[t * WPF + w];
+            if (w < wf) before += c;
+            running += c;
+        }
+        if (in_range && ((masks[t] >> lane) & 1ull)) {
+            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
+        }
+    }
+    if (jf == 0 && in_range) *count_out = running;
+}
+
+template <int LOGW, int LOGF>
+static void launch_zp(const StftFastArgs& a, const v2f* twF, hipStream_t stream) {
+    using G = FftGeom<LOGF>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)(2 * F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) + (size_t)F * 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_zp_kernel<LOGW, LOGF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const uint32_t chunks = (a.n_cols + F - 1) / F;
+    hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a, twF);
+}
+
+// window 1024 / 2048 zero-padded to 2048 / 4096: `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W), twF = exp(-2 pi i k / F)
+bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t fft_size, const v2f* twF, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return true;
+    if (window == 1024 && fft_size == 2048) launch_zp<10, 11>(a, twF, stream);
+    else if (window == 1024 && fft_size == 4096) launch_zp<10, 12>(a, twF, stream);
+    else if (window == 2048 && fft_size == 4096) launch_zp<11, 12>(a, twF, stream);
+    else return false;
+    return true;
+}
+
 template <int LOGN>
 static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
     using G = FftGeom<LOGN>;
