@@ -151,9 +151,18 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     // fused kernels: W = F in {1024, 2048, 4096} (the tuned 4096 kernel / the size-templated ones; classic and reassigned)
     // (16384 classic only: its reassigned form needs two 139 KiB LDS buffers, or 1024 threads under a 128-VGPR cap)
     fast4096_ = (W == fft_size_ && (W == 8192 || W == 4096 || W == 2048 || W == 1024 || (!reassign && W == 16384)));
+    // classic columns: any window that is zero-padded to one of the fused transform sizes
+    // (windows shorter than 256 samples stay on the generic kernel: DC removal over so few samples is all cancellation, and
+    // the generic kernel keeps the reference's sequential mean)
+    const bool fast_classic_zp = !reassign && W < fft_size_ && W >= 256 &&
+                                 (fft_size_ == 1024 || fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192 || fft_size_ == 16384);
     // zero-padded reassigned shapes with a fused kernel: window 1024 / 2048 padded to 2048 / 4096
     fast_zp_ = reassign && ((W == 1024 && (fft_size_ == 2048 || fft_size_ == 4096)) || (W == 2048 && fft_size_ == 4096));
-    if (fast4096_ || fast_zp_) {
+    if (fast_classic_zp) {
+        fast4096_ = true;
+        d_tw256_.upload(twiddle_table(256, 256), stream);
+        d_tw4096_.upload(twiddle_table(fft_size_, fft_size_), stream);  // exp(-2 pi i k / F): the only transform of the classic path
+    } else if (fast4096_ || fast_zp_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
         d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / W)
         d_tw8192_.upload(twiddle_table(2 * W, W), stream);  // exp(-2 pi i k / 2W)
@@ -281,6 +290,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         fa.n_streams = n_streams_;
         fa.n_cols = (uint32_t)n_cols;
         fa.column_stride = (uint32_t)stride;
+        fa.window_size = (uint32_t)W;
         fa.last_nonzero = last_nonzero_.ptr;
         fa.window = d_window_.ptr;
         fa.dwindow = d_dwindow_.ptr;

@@ -38,6 +38,7 @@ struct StftFastArgs {
     uint32_t n_streams;
     uint32_t n_cols;
     uint32_t column_stride;  // points per column slot
+    uint32_t window_size;    // classic columns: window length W <= transform length (0 = same as the transform)
     const long long* last_nonzero;
     const float* window;     // [4096]
     const float* dwindow;    // [4096] derivative window

@@ -229,15 +229,22 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)col_a * a.hop);
+    // zero padding (window W < transform N, `processor.rs:350-368`): element i = jf + T t of the frame is sample i of the window
+    // for i < W and 0 beyond; loads use a clamped index and the selects sit where the values are consumed
+    const uint32_t Wn = a.window_size ? a.window_size : (uint32_t)N;
     float xa[16], xb[16], w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const uint32_t qq = p32 + ju + (unsigned)T * (unsigned)t;
+        const uint32_t i = ju + (unsigned)T * (unsigned)t;
+        const uint32_t qq = p32 + (i < Wn ? i : 0u);
         xa[t] = *reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask));
-        xb[t] = has_b ? *reinterpret_cast<const float*>(ring_bytes + (((qq + a.hop) << 2) & bytemask)) : 0.0f;
+        xb[t] = *reinterpret_cast<const float*>(ring_bytes + (((qq + (has_b ? a.hop : 0u)) << 2) & bytemask));
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t i = ju + (unsigned)T * (unsigned)t;
+        w[t] = a.window[i < Wn ? i : 0u];
+    }
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);
@@ -249,8 +256,9 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
     float sa = 0.0f, sb = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        sa += xa[t];
-        sb += xb[t];
+        const bool inside = ju + (unsigned)T * (unsigned)t < Wn;
+        sa += inside ? xa[t] : 0.0f;
+        sb += (inside && has_b) ? xb[t] : 0.0f;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -268,10 +276,13 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
         ta += wave_sum[fs][0][i];
         tb += wave_sum[fs][1][i];
     }
-    const float mean_a = ta / (float)N, mean_b = tb / (float)N;
+    const float mean_a = ta / (float)Wn, mean_b = tb / (float)Wn;  // mean over the window (window.rs:80-84)
     v2f v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    for (int t = 0; t < 16; ++t) {
+        const bool inside = ju + (unsigned)T * (unsigned)t < Wn;
+        v[t] = v2f{inside ? (xa[t] - mean_a) * w[t] : 0.0f, (inside && has_b) ? (xb[t] - mean_b) * w[t] : 0.0f};
+    }
     fftp_inplace<false, LOGN>(v, buf, jf, tw);
     frame_sync<LOGN>();
 #pragma unroll

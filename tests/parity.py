@@ -78,11 +78,12 @@ def classic_column_metrics(hip, ora):
     max_code_diff / n_diff: over every bin.  An f32 FFT carries a noise floor of ~1e-7 of the column's largest amplitude,
     so bins far below the maximum legitimately differ between two correct FFTs (the generic kernel repeats the oracle's
     radix-2 order and is code-identical; the fused radix-16 kernels are not).  Hence also:
-    power: max |dP| / max P in linear power;  loud_code_diff: max |d code| over the bins within 50 dB of the column maximum."""
+    power: max |dP| / max P in linear power;  loud_code_diff: max |d code| over the bins within 40 dB of the column maximum
+    (one code at -40 dB is 5.5e-8 of the maximum: the weak-bin bound of check_classic, so the two criteria meet there)."""
     d = np.abs(hip.astype(np.int64) - ora.astype(np.int64))
     db_h, db_o = hip.astype(np.float64) * (156.0 / 65535.0) - 144.0, ora.astype(np.float64) * (156.0 / 65535.0) - 144.0
     p_h, p_o = 10.0 ** (db_h / 10.0), 10.0 ** (db_o / 10.0)
-    loud = db_o >= db_o.max() - 50.0 if len(d) else np.zeros(0, bool)
+    loud = db_o >= db_o.max() - 40.0 if len(d) else np.zeros(0, bool)
     weak = ~loud
     return dict(max_code_diff=int(d.max()) if len(d) else 0, n_diff=int((d > 0).sum()), n=len(d),
                 power=float(np.abs(p_h - p_o).max() / max(p_o.max(), 1e-300)) if len(d) else 0.0,
@@ -91,10 +92,10 @@ def classic_column_metrics(hip, ora):
 
 
 def check_classic(got, want):
-    """fused-kernel bar: codes within 1 for every bin within 50 dB of the column maximum; below that, linear power within
-    1e-8 of the column maximum (an f32 FFT's own noise floor: the codes of bins 100 dB down are not reproducible between two
+    """fused-kernel bar: codes within 1 for every bin within 40 dB of the column maximum; below that, linear power within
+    6e-8 of the column maximum (= one code at -40 dB, where the two criteria meet) (an f32 FFT's own noise floor: the codes of bins 100 dB down are not reproducible between two
     correct transforms, and the two-columns-per-FFT packing lets each column see the other's rounding noise)"""
     assert len(got) == len(want)
     for h, o in zip(got, want):
         m = classic_column_metrics(h, o)
-        assert m["loud_code_diff"] <= 1 and m["weak_power"] <= 1e-8, m
+        assert m["loud_code_diff"] <= 1 and m["weak_power"] <= 6e-8, m   # 6e-8 = one code at -40 dB

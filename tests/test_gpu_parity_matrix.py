@@ -76,3 +76,15 @@ def test_sample_rates_and_channel_layouts(omx, oracle, rate, channels, positions
         for tr in range(2):
             for k in range(2):
                 check_trace(gs.traces[tr][k], ws.traces[tr][k])
+
+
+@pytest.mark.parametrize("W,zp,hop", [(1024, 2, 256), (512, 4, 100), (2048, 2, 64), (256, 16, 64), (4096, 4, 1024), (64, 32, 16)])
+def test_zero_padded_classic_columns(omx, oracle, W, zp, hop):
+    """window W zero-padded to F = zp W in {1024 ... 16384}: fused two-columns-per-FFT kernel (mean over the W window samples,
+    zeros beyond, window.rs:66-88 + processor.rs:350-368); 64 x 32 = 2048"""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, use_reassignment=False, history_length=64)
+    pcm = stream_pcm(8, W + hop * 10)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert len(g.new_columns) == len(w.new_columns) == 11 and g.fft_size == w.fft_size == W * zp
+    check_classic(g.new_columns, w.new_columns)
