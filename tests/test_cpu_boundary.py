@@ -109,11 +109,15 @@ print("rank", rank, "ok")
 
 
 def test_sharded_streams_gather_over_gloo_world_size_2(oracle, tmp_path):
+    import socket
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    with socket.socket() as sock:   # a free port: a fixed one may still sit in TIME_WAIT from the previous run
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
+                        "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
