@@ -156,8 +156,9 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     // the generic kernel keeps the reference's sequential mean)
     const bool fast_classic_zp = !reassign && W < fft_size_ && W >= 256 &&
                                  (fft_size_ == 1024 || fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192 || fft_size_ == 16384);
-    // zero-padded reassigned shapes with a fused kernel: window 1024 / 2048 padded to 2048 / 4096
-    fast_zp_ = reassign && ((W == 1024 && (fft_size_ == 2048 || fft_size_ == 4096)) || (W == 2048 && fft_size_ == 4096));
+    // zero-padded reassigned shapes with a fused kernel: window 1024 / 2048 / 4096 padded to 2048 / 4096 / 8192
+    fast_zp_ = reassign && W < fft_size_ && (W == 1024 || W == 2048 || W == 4096) &&
+               (fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192);
     if (fast_classic_zp) {
         fast4096_ = true;
         d_tw256_.upload(twiddle_table(256, 256), stream);

@@ -338,10 +338,11 @@ void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t f
 // windowed transforms, the reassignment and the compaction run exactly as in the unpadded kernel, over F/2 + 1 bins.
 // ================================================================================================
 template <int LOGW, int LOGF>
-__global__ __launch_bounds__(256, 2) void stft_reassigned_zp_kernel(StftFastArgs a, const v2f* __restrict__ twF) {
+__global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1) void stft_reassigned_zp_kernel(
+    StftFastArgs a, const v2f* __restrict__ twF) {
     using GW = FftGeom<LOGW>;
     using G = FftGeom<LOGF>;
-    static_assert(LOGF > LOGW && G::PASSES == 3 && GW::PASSES == 3 && G::WG == 256, "W < F <= 4096");
+    static_assert(LOGF > LOGW && LOGF <= 13 && GW::PASSES == 3, "W <= 4096 < F <= 8192, or W < F <= 4096");
     constexpr int W = GW::N, TW = GW::T, N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* lds = reinterpret_cast<v2f*>(smem_raw);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_zp_kernel(StftFastArgs
     TwiddlesPow2<LOGW> twh;  // Hilbert transforms (size W): `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W)
     twh.tw2 = tw2_lds;
     twh.load(a.tw4096, hact ? ju : 0u);
-    tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
 
     // ---- 1. packed real FFT of the 2W-sample window (W/16 threads) -----------------------------------------------------------
     const unsigned jh = hact ? ju : 0u;  // idle threads shadow thread 0's addresses (loads stay unconditional and in range)
@@ -528,15 +529,19 @@ static void launch_zp(const StftFastArgs& a, const v2f* twF, hipStream_t stream)
         attr_set = true;
     }
     const uint32_t chunks = (a.n_cols + F - 1) / F;
-    hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a, twF);
+    hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a,
+                       twF);
 }
 
-// window 1024 / 2048 zero-padded to 2048 / 4096: `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W), twF = exp(-2 pi i k / F)
+// window 1024 / 2048 / 4096 zero-padded to 2048 / 4096 / 8192: `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W), twF = exp(-2 pi i k / F)
 bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t fft_size, const v2f* twF, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return true;
     if (window == 1024 && fft_size == 2048) launch_zp<10, 11>(a, twF, stream);
     else if (window == 1024 && fft_size == 4096) launch_zp<10, 12>(a, twF, stream);
     else if (window == 2048 && fft_size == 4096) launch_zp<11, 12>(a, twF, stream);
+    else if (window == 1024 && fft_size == 8192) launch_zp<10, 13>(a, twF, stream);
+    else if (window == 2048 && fft_size == 8192) launch_zp<11, 13>(a, twF, stream);
+    else if (window == 4096 && fft_size == 8192) launch_zp<12, 13>(a, twF, stream);
     else return false;
     return true;
 }
