@@ -149,8 +149,8 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
         power_scale_ = 1.0f;
     }
     // fused kernels: W = F in {1024, 2048, 4096} (the tuned 4096 kernel / the size-templated ones; classic and reassigned)
-    // (16384 classic only: its reassigned form needs two 139 KiB LDS buffers, or 1024 threads under a 128-VGPR cap)
-    fast4096_ = (W == fft_size_ && (W == 8192 || W == 4096 || W == 2048 || W == 1024 || (!reassign && W == 16384)));
+    // (reassigned 16384 runs as three kernels through an HBM scratch: its fused form does not fit one CU)
+    fast4096_ = (W == fft_size_ && (W == 16384 || W == 8192 || W == 4096 || W == 2048 || W == 1024));
     // classic columns: any window that is zero-padded to one of the fused transform sizes
     // (windows shorter than 256 samples stay on the generic kernel: DC removal over so few samples is all cancellation, and
     // the generic kernel keeps the reference's sequential mean)
@@ -311,7 +311,12 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
             const char* e = getenv("OMX_K2_VARIANT");
             return e && atoi(e) == 30;
         }();
-        if (fast_zp_)
+        if (reassign && fft_size_ == 16384 && !fast_zp_) {
+            const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 1024);
+            d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
+            for (uint64_t first = 0; first < total; first += chunk)
+                launch_stft_reassigned_16384(fa, d_workspace_.ptr, (uint32_t)first, (uint32_t)std::min(chunk, total - first), stream);
+        } else if (fast_zp_)
             (void)launch_stft_reassigned_zp(fa, (uint32_t)W, (uint32_t)fft_size_, reinterpret_cast<const v2f*>(d_twF_.ptr), stream);
         else if (!reassign)
             launch_stft_classic_pow2(fa, d_codes_.ptr, (uint32_t)fft_size_, stream);

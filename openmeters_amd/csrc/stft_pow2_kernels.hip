@@ -546,6 +546,197 @@ bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t 
     return true;
 }
 
+// ================================================================================================
+// K2b: reassigned columns for W = F = 16384 — the one GUI size whose fused form does not fit a CU (two 139 KiB LDS buffers, or
+// 1024 threads under a 128-VGPR cap).  Same arithmetic as the fused kernels, cut into three kernels that hand the analytic
+// slice and the three spectra over through an HBM scratch (0.45 MB per frame), processed in chunks of frames:
+//   hilbert_big_kernel     packed real FFT of the 2N-sample window, single-IFFT Hilbert, analytic slice -> sv[frame][N]
+//   windowed_big_kernel    (frame, q): FFT_N(sv * {w, w', t w}[q]) -> spec[q][frame][N/2 + 1]
+//   reassign_big_kernel    per-bin reassignment + ordered compaction
+// One frame per 1024-thread workgroup, one in-place 16384-point transform at a time.
+// ================================================================================================
+struct BigScratch {
+    v2f* sv;          // [chunk][N]
+    v2f* spec;        // [3][chunk][N/2 + 1]
+    uint32_t first;   // first frame (item = stream * n_cols + column) of this chunk
+    uint32_t count;   // frames in this chunk
+};
+
+template <int LOGN>
+__global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFastArgs a, BigScratch sc) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* buf = reinterpret_cast<v2f*>(smem_raw);         // [G::LDS]
+    v2f* tw2_lds = buf + G::LDS;                          // [256]
+    float* hil = reinterpret_cast<float*>(tw2_lds + 256);  // [2]
+    const uint32_t item = sc.first + blockIdx.x;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    if (a.last_nonzero[s] < (long long)p0) return;  // silent column (:307-316): reassign_big_kernel emits it empty
+    const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
+    const uint32_t p32 = (uint32_t)p0;
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t qq = p32 + 2u * (ju + (unsigned)T * (unsigned)t);
+        v[t] = v2f{*reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask)),
+                   *reinterpret_cast<const float*>(ring_bytes + (((qq + 1u) << 2) & bytemask))};
+    }
+    __syncthreads();  // tw2_lds
+    fftp_inplace<false, LOGN>(v, buf, j, tw);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) buf[pad16(j + T * t)] = v[t];
+    if (j == 0) {
+        hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[N] / 2
+    }
+    __syncthreads();
+    v2f y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned k = ju + (unsigned)T * (unsigned)t;
+        const v2f z = v[t];
+        const v2f zr = buf[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
+        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
+        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+        const v2f w = a.tw8192[k];  // exp(-2 pi i k / 2N)
+        y[t] = cmulc(sum, w) - cmul(dif, w);
+        if (k == 0) y[t] = v2f{0.0f, 0.0f};
+    }
+    const float half_x0 = hil[0], half_xn = hil[1];
+    __syncthreads();  // partners are read from the buffer the inverse is about to overwrite
+    fftp_inplace<true, LOGN>(y, buf, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + T t
+    __syncthreads();
+    float* imag = reinterpret_cast<float*>(buf);  // N floats: Im analytic[N/2 .. 3N/2)
+#pragma unroll
+    for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + T * t - N / 4)) = y[t];
+    __syncthreads();
+    const float parity = (j & 1) ? -half_xn : half_xn;
+    v2f* out = sc.sv + (uint64_t)blockIdx.x * N;
+    const uint32_t qe = p32 + (uint32_t)(N / 2) + ju;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float xr = *reinterpret_cast<const float*>(ring_bytes + (((qe + (unsigned)T * (unsigned)u) << 2) & bytemask));
+        out[j + T * u] = v2f{(float)N * xr - half_x0 + parity, imag[j + T * u]};
+    }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFastArgs a, BigScratch sc) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* buf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = buf + G::LDS;
+    const uint32_t item = sc.first + blockIdx.x, q = blockIdx.y;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    if (a.last_nonzero[s] < (long long)(a.tail + (uint64_t)col * a.hop)) return;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    const v2f* sv = sc.sv + (uint64_t)blockIdx.x * N;
+    const float* win = q == 1 ? a.dwindow : a.window;
+    constexpr float CENTER = (float)(N - 1) * 0.5f;
+    v2f v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = j + T * u;
+        const v2f x = sv[i];
+        float w = win[i];
+        if (q == 2) w = ((float)i - CENTER) * w;  // compute_time_weighted (:601-608)
+        v[u] = v2f{x.x * w, x.y * w};
+    }
+    __syncthreads();  // tw2_lds
+    fftp_inplace<false, LOGN>(v, buf, j, tw);
+    v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * (N / 2 + 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out[j + T * u] = v[u];
+    if (j == 0) out[N / 2] = v[8];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFastArgs a, BigScratch sc) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, WPF = T / 64;
+    __shared__ uint32_t scan[9 * WPF];
+    const uint32_t item = sc.first + blockIdx.x;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    const int lane = j & 63, wf = j >> 6;
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+    if (a.last_nonzero[s] < (long long)(a.tail + (uint64_t)col * a.hop)) {
+        if (j == 0) *count_out = 0;
+        return;
+    }
+    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t per = (uint64_t)sc.count * (N / 2 + 1);
+    const v2f* sb = sc.spec + (uint64_t)blockIdx.x * (N / 2 + 1);
+    omx_spectrogram_point pts[9];
+    unsigned long long masks[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t bin = (t < 8 || j == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
+        const v2f b = sb[bin], d = sb[per + bin], tt = sb[2 * per + bin];
+        const float norm = a.bin_norm[bin];
+        bool keep = false;
+        if (t < 8 || j == 0) keep = reassign_bin_p(bin, b, d, tt, norm, rc, pts[t]);
+        masks[t] = __ballot(keep);
+        if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
+    }
+    __syncthreads();
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        uint32_t before = running;
+        for (int w = 0; w < WPF; ++w) {
+            const uint32_t c = scan[t * WPF + w];
+            if (w < wf) before += c;
+            running += c;
+        }
+        if ((masks[t] >> lane) & 1ull) {
+            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
+        }
+    }
+    if (j == 0) *count_out = running;
+}
+
+// bytes of scratch per frame of a chunk, and the launcher (frames [first, first + count) of the call)
+uint64_t stft_big_scratch_bytes_per_frame() { return (uint64_t)(16384 + 3 * 8193) * sizeof(v2f); }
+void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    if (count == 0) return;
+    using G = FftGeom<14>;
+    BigScratch sc{};
+    sc.sv = reinterpret_cast<v2f*>(scratch);
+    sc.spec = sc.sv + (uint64_t)count * G::N;
+    sc.first = first;
+    sc.count = count;
+    const size_t lds = (size_t)(G::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_big_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(hilbert_big_kernel<14>, dim3(count), dim3(G::WG), lds, stream, a, sc);
+    hipLaunchKernelGGL(windowed_big_kernel<14>, dim3(count, 3), dim3(G::WG), lds, stream, a, sc);
+    hipLaunchKernelGGL(reassign_big_kernel<14>, dim3(count), dim3(G::WG), 0, stream, a, sc);
+}
+
 template <int LOGN>
 static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
     using G = FftGeom<LOGN>;

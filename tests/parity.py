@@ -14,12 +14,33 @@ def align_points(a, b, max_power):
     i = j = 0
     pairs, oa, ob = [], [], []
     tol_abs = 1e-5 * max_power
+
+    def shifted_pairing_is_clearly_better(i, j):
+        """Weak points all 'agree' in power, so a floor-level orphan can slip the merge by one bin without being noticed
+        (bins are 3 Hz apart at 16384 points).  If skipping one entry on either side brings the frequencies at least 4x
+        closer, the current pair is a slip."""
+        d0 = abs(a[i, 1] - b[j, 1])
+        if d0 == 0.0 or (len(a) - i) == (len(b) - j):   # nothing left to re-synchronise: the rest pairs one to one
+            return None
+        if len(b) - j > len(a) - i and j + 1 < len(b) and abs(a[i, 1] - b[j + 1, 1]) < 0.25 * d0 and abs(a[i, 2] - b[j + 1, 2]) <= tol_abs + 2e-3 * min(a[i, 2], b[j + 1, 2]):
+            return (0, 1)
+        if len(a) - i > len(b) - j and i + 1 < len(a) and abs(a[i + 1, 1] - b[j, 1]) < 0.25 * d0 and abs(a[i + 1, 2] - b[j, 2]) <= tol_abs + 2e-3 * min(a[i + 1, 2], b[j, 2]):
+            return (1, 0)
+        return None
+
     while i < len(a) and j < len(b):
         pa, pb = a[i, 2], b[j, 2]
         if abs(pa - pb) <= tol_abs + 2e-3 * min(pa, pb) and abs(a[i, 1] - b[j, 1]) <= max(50.0, 0.02 * abs(b[j, 1])):
-            pairs.append((i, j))
-            i += 1
-            j += 1
+            slip = shifted_pairing_is_clearly_better(i, j) if max(pa, pb) < 1e-6 * max_power else None
+            if slip is None:
+                pairs.append((i, j))
+                i += 1
+                j += 1
+            else:
+                oa.extend(range(i, i + slip[0]))
+                ob.extend(range(j, j + slip[1]))
+                i += slip[0]
+                j += slip[1]
             continue
         # look ahead a few entries for a re-synchronisation point
         found = None
