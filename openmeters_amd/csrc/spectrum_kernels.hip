@@ -68,13 +68,6 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N
     if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
-    float norm[9], aw[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const unsigned k = (t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
-        norm[t] = a.bin_norm[k];
-        aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
-    }
     float sa = 0.0f, sb = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -102,7 +95,16 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    // per-bin tables: issued before the last pass's butterflies would be ideal, but holding 18 more registers through the
+    // transform costs the fourth resident workgroup (128-VGPR line); here they overlap the exchange below
+    float norm[9], aw[9];
     fftp_inplace<false, LOGN>(v, A, jf, tw);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const unsigned k = (t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
+        norm[t] = a.bin_norm[k];
+        aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
+    }
     frame_sync<LOGN>();
 #pragma unroll
     for (int t = 0; t < 16; ++t) A[pad16(jf + T * t)] = v[t];
