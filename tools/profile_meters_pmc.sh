@@ -1,0 +1,28 @@
+#!/bin/bash
+# HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the cfg3 / cfg4 meter kernels; outputs under gpurun_out/$1
+set -u
+TAG=${1:-meters_pmc}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py > $OUT/write.log 2>&1
+python3 - <<PY
+import csv, glob, os
+from collections import defaultdict
+out = "$OUT"
+agg = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row.get("Kernel_Name", "")
+            if "omx::" in k:
+                agg[k.split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+lines = []
+for k, cs in agg.items():
+    fe = sum(cs.get("FETCH_SIZE", [0])) / max(len(cs.get("FETCH_SIZE", [1])), 1)
+    wr = sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [1])), 1)
+    lines.append(f"{k:60s} FETCH_SIZE {fe:12.0f} KiB  WRITE_SIZE {wr:12.0f} KiB  -> HBM bytes per launch (2*F + W)*1024 = {(2 * fe + wr) * 1024 / 1e9:.3f} GB")
+open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
