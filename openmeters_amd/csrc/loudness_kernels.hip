@@ -13,8 +13,12 @@
 namespace omx {
 
 __device__ __forceinline__ void kbn_add(double& sum, double& corr, double v) {  // dsp.rs:277-285
+    // corr += |sum| >= |v| ? (sum - next) + v : (v - next) + sum;  picking (big, small) first evaluates one branch's two f64
+    // operations instead of both branches' four (f64 issues at half rate): same operands, same order, same bits
     const double next = sum + v;
-    corr += (fabs(sum) >= fabs(v)) ? (sum - next) + v : (v - next) + sum;
+    const bool sum_is_big = fabs(sum) >= fabs(v);
+    const double big = sum_is_big ? sum : v, small = sum_is_big ? v : sum;
+    corr += (big - next) + small;
     sum = next;
 }
 __device__ __forceinline__ float power_to_db_f(float power, float floor) {  // level.rs:28-34
@@ -437,6 +441,9 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
         }
     };
     auto consume = [&](const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
+        // CompensatedPair::refresh (dsp.rs:287-289) fires once per `cap` pushes (>= 14 400): a batch that cannot reach it runs
+        // as straight-line code, the rare one that can keeps the per-sample test
+        const bool may_refresh = refresh + (uint32_t)B >= cap;
 #pragma unroll
         for (int k = 0; k < B; ++k) {
             const double value = vals[buf][sub * B + k][lane];
@@ -444,17 +451,19 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
             kbn_add(sum0, cor0, value);
             kbn_add(sum1, cor1, value);
             kbn_add(sum0, cor0, -expiring);
-            unfilled -= (unfilled != 0u) ? 1u : 0u;
-            if (++refresh == cap) {  // CompensatedPair::refresh (dsp.rs:287-289)
+            if (may_refresh && refresh + (uint32_t)k + 1u == cap) {
                 sum0 = sum1;
                 sum1 = 0.0;
                 cor0 = cor1;
                 cor1 = 0.0;
-                refresh = 0;
             }
-            if (store_lane) ring_col[(uint64_t)head * row] = value;
-            head = head + 1 == len ? 0 : head + 1;
+            if (store_lane) ring_col[(uint64_t)(head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * row] = value;
         }
+        refresh += (uint32_t)B;
+        refresh = refresh >= cap ? refresh - cap : refresh;
+        unfilled = unfilled > (uint32_t)B ? unfilled - (uint32_t)B : 0u;
+        head += (uint32_t)B;
+        head = head >= len ? head - len : head;
         seen += B;
         if ((batch + 1) % full == 0) snapshot((uint32_t)((batch + 1) / full - 1));
     };
