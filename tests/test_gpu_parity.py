@@ -146,13 +146,21 @@ def test_silent_and_mixed_streams_in_one_bank(omx):
 
 
 def check_trace(x, y, floor=-100.0):
+    """dB traces.  The bound that always holds is the linear-power one (relative to the trace maximum, but not below -60 dB:
+    a trace of near-silence is all f32 FFT noise).  dB differences are only meaningful away from (a) the f32 noise floor
+    60 / 80 dB under the maximum and (b) the display / state floor, where `update_outputs` flushes a smoothed state to zero
+    (spectrum/processor.rs:366-389) — a discontinuity of a few dB that a last-bit difference can trip on either side."""
     x, y = x.astype(np.float64), y.astype(np.float64)
     px, py = 10.0 ** (x / 10.0), 10.0 ** (y / 10.0)
-    assert np.abs(px - py).max() <= 1e-5 * py.max(), np.abs(px - py).max() / py.max()
-    loud = y > floor + 1.0
+    ref = max(py.max(), 1e-6)
+    assert np.abs(px - py).max() <= 1e-5 * ref, np.abs(px - py).max() / ref
+    clear = (y > floor + 12.0) & (x > floor + 12.0)   # a flushed state re-seeds (:366-369): its bin needs a few hops to re-converge
+    loud = clear & (y > y.max() - 60.0)
     if loud.any():
         assert np.abs(x[loud] - y[loud]).max() <= 0.05, np.abs(x[loud] - y[loud]).max()
-    assert np.abs(x - y).max() <= 0.1  # a bin sitting at the floor in one backend only
+    near = clear & (y > y.max() - 80.0)
+    if near.any():
+        assert np.abs(x - y)[near].max() <= 0.1
 
 
 @pytest.mark.parametrize("mode,param", [(capi.AVG_NONE, 0.0), (capi.AVG_EXPONENTIAL, 0.5), (capi.AVG_PEAK_HOLD, 12.0)])
