@@ -101,14 +101,24 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
         history_channels_ = channels;
     }
     const uint32_t frames = segment_frames();
-    if (frames != hist_frames_ || !history_.ptr) {  // ring geometry changed: old pairs cannot be re-homed
+    if (!history_.ptr) {
         hist_frames_ = frames;
         history_.reserve((size_t)n_streams_ * 4 * frames * 2);
         OMX_HIP(hipMemsetAsync(history_.ptr, 0, history_.count * sizeof(float), stream));
-        for (int b = 0; b < 4; ++b) {
-            hist_len_[b] = 0;
-            hist_pos_[b] = 0;
-        }
+        for (int b = 0; b < 4; ++b) hist_len_[b] = hist_pos_[b] = 0;
+    } else if (frames != hist_frames_) {
+        // the deques survive a segment-length change (:183-207) and are trimmed to the new length (:146-150): carry the newest
+        // min(len, frames) pairs of every band into a ring of the new length
+        uint64_t keep[4];
+        for (int b = 0; b < 4; ++b) keep[b] = std::min<uint64_t>(hist_len_[b], frames);
+        history_next_.reserve((size_t)n_streams_ * 4 * frames * 2);
+        OMX_HIP(hipMemsetAsync(history_next_.ptr, 0, (size_t)n_streams_ * 4 * frames * 2 * sizeof(float), stream));
+        launch_stereometer_rehome(history_.ptr, history_next_.ptr, n_streams_, hist_frames_, frames, hist_pos_, keep, stream);
+        OMX_HIP(hipGetLastError());
+        std::swap(history_.ptr, history_next_.ptr);
+        std::swap(history_.count, history_next_.count);
+        hist_frames_ = frames;
+        for (int b = 0; b < 4; ++b) hist_len_[b] = keep[b];
     }
     if (pending_full_reset_) {
         OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(StereoLaneState), stream));

@@ -230,4 +230,42 @@ void launch_stereometer_points(const float* history, uint32_t n_streams, uint32_
     hipLaunchKernelGGL(stereometer_points_kernel, dim3((target + 255) / 256, 4, n_streams), dim3(256), 0, stream, a);
 }
 
+struct RehomeArgs {
+    const float* from;
+    float* to;
+    uint32_t n_streams, from_frames, to_frames;
+    uint64_t hist_pos[4];
+    uint64_t keep[4];  // newest pairs carried over per band (<= both ring lengths)
+};
+// segment length changed (update_config, :183-207 keeps the deques; :142-150 trims them to the new length on the next block):
+// the newest keep[band] pairs move to the slots their absolute positions have in the new ring
+__global__ __launch_bounds__(256) void stereometer_rehome_kernel(RehomeArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t band = blockIdx.y, s = blockIdx.z;
+    if (i >= a.keep[band]) return;
+    const uint64_t at = a.hist_pos[band] - a.keep[band] + i;
+    const float* src = a.from + (((uint64_t)s * 4 + band) * a.from_frames + at % a.from_frames) * 2;
+    float* dst = a.to + (((uint64_t)s * 4 + band) * a.to_frames + at % a.to_frames) * 2;
+    dst[0] = src[0];
+    dst[1] = src[1];
+}
+
+void launch_stereometer_rehome(const float* from, float* to, uint32_t n_streams, uint32_t from_frames, uint32_t to_frames,
+                               const uint64_t hist_pos[4], const uint64_t keep[4], hipStream_t stream) {
+    uint64_t most = 0;
+    RehomeArgs a{};
+    a.from = from;
+    a.to = to;
+    a.n_streams = n_streams;
+    a.from_frames = from_frames;
+    a.to_frames = to_frames;
+    for (int b = 0; b < 4; ++b) {
+        a.hist_pos[b] = hist_pos[b];
+        a.keep[b] = keep[b];
+        most = most > keep[b] ? most : keep[b];
+    }
+    if (n_streams == 0 || most == 0) return;
+    hipLaunchKernelGGL(stereometer_rehome_kernel, dim3((uint32_t)((most + 255) / 256), 4, n_streams), dim3(256), 0, stream, a);
+}
+
 }  // namespace omx

@@ -152,3 +152,51 @@ def test_meter_processors_random_block_sequences(omx, oracle, seed):
             assert wg.reset == ww.reset and wg.columns.shape == ww.columns.shape, step
             if len(ww.columns):
                 assert np.array_equal(wg.columns[:, :, :2].view(np.uint32), ww.columns[:, :, :2].view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26])
+def test_stereometer_config_change_sequences(omx, oracle, seed):
+    """update_config between blocks: a new segment length keeps the pairs already collected (shorter: Some at once from the
+    newest pairs; longer: None until the deque has grown), band analysis / band points toggled, window changed
+    (stereometer/processor.rs:142-150, :183-207)"""
+    rng = np.random.default_rng(seed)
+
+    def rand_cfg():
+        return StereometerConfig(analyze_bands=bool(rng.integers(2)), emit_band_points=bool(rng.integers(2)),
+                                 segment_duration=float(rng.choice([0.005, 0.01, 0.02, 0.04])),
+                                 target_sample_count=int(rng.choice([1, 100, 2000])), correlation_window=float(rng.choice([0.05, 0.2])))
+    cfg = rand_cfg()
+    a, b = StereometerProcessor(omx, cfg), StereometerProcessor(oracle, cfg)
+    rate, channels, t0, some, changes_with_history = 48000.0, 2, 0, 0, 0
+    for step in range(70):
+        op = rng.random()
+        if op < 0.2:
+            cfg = rand_cfg()
+            cfg.sample_rate = rate
+            a.update_config(cfg)
+            b.update_config(cfg)
+            changes_with_history += some > 0
+            continue
+        if op < 0.23:
+            a.reset_audio()
+            b.reset_audio()
+            continue
+        if op < 0.26:
+            rate = float(rng.choice([44100.0, 48000.0]))
+        if op < 0.29:
+            channels = int(rng.choice([1, 2, 6]))
+        frames = int(rng.choice([1, 100, 256, 256, 512, 1500]))
+        pcm = signal(rng, frames, channels, t0, rate, silent=False)
+        t0 += frames
+        blk = AudioBlock(pcm.reshape(-1), channels, rate)
+        g, w = a.process_block(blk), b.process_block(blk)
+        assert (g is None) == (w is None), step
+        if w is None:
+            continue
+        some += 1
+        assert np.abs(g.correlations - w.correlations).max() <= 1e-6, step
+        for x, y in zip(g.points, w.points):
+            assert x.shape == y.shape, step
+            if len(y):
+                assert np.abs(x - y).max() <= 1e-6, step   # the full band is a copy of the input; bands go through the LR4 split
+    assert some > 5 and changes_with_history > 0
