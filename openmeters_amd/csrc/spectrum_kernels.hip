@@ -12,6 +12,10 @@ namespace omx {
 // the real part, hop 2p+1 the imaginary part, X_a = (Z[k] + conj Z[N-k])/2, X_b = (Z[k] - conj Z[N-k])/(2i).
 // With AveragingMode::None the dB conversion (:391-401) is fused here and the traces are written directly;
 // otherwise the per-hop power goes to the scratch buffer for spectrum_levels_kernel.
+// ln(p) * LN_TO_DB for p at or above the state floor (>= f32::MIN_POSITIVE, :332-336, so never a denormal): one v_log_f32
+// and one multiply instead of libm's 14-instruction denormal-safe logf — the two differ by < 1e-5 dB
+__device__ __forceinline__ float fast_power_db(float p) { return __builtin_amdgcn_logf(p) * 3.0102999566f; }
+
 __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint32_t s, uint32_t tr, uint32_t h, uint32_t k,
                                                float power) {
     if (a.fused_db) {
@@ -124,18 +128,11 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
         const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
         const float pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t];
-        if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401)
-            float raw_a = a.floor_db, wt_a = a.floor_db, raw_b = a.floor_db, wt_b = a.floor_db;
-            if (!(pa < a.state_floor)) {
-                const float db = logf(pa) * 4.3429448f;
-                raw_a = fmaxf(db, a.floor_db);
-                wt_a = fmaxf(db + aw[t], a.floor_db);
-            }
-            if (!(pb < a.state_floor)) {
-                const float db = logf(pb) * 4.3429448f;
-                raw_b = fmaxf(db, a.floor_db);
-                wt_b = fmaxf(db + aw[t], a.floor_db);
-            }
+        if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
+            const float db_a = fast_power_db(pa), db_b = fast_power_db(pb);
+            const bool low_a = pa < a.state_floor, low_b = pb < a.state_floor;
+            const float raw_a = low_a ? a.floor_db : fmaxf(db_a, a.floor_db), wt_a = low_a ? a.floor_db : fmaxf(db_a + aw[t], a.floor_db);
+            const float raw_b = low_b ? a.floor_db : fmaxf(db_b, a.floor_db), wt_b = low_b ? a.floor_db : fmaxf(db_b + aw[t], a.floor_db);
             // emit_all == 0: only the newest hop is materialised; the host launches that hop alone (n_hops == 1)
             out0[k] = wt_a;
             out0[a.bins + k] = raw_a;

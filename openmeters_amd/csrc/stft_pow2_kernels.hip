@@ -197,11 +197,13 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
 // T = N/16 threads, so a workgroup emits 2 * 256/T columns.  One LDS buffer per slot (in-place transform) -> 4 workgroups
 // per CU.  HBM-bound by design: hop*C*4 B in, (N/2+1)*2 B out per column.
 // ================================================================================================
+// Hardware log2 (v_log_f32, 1 ulp) instead of libm's denormal-safe logf: zero / denormal / NaN power all land on the -140 dB
+// clamp exactly as `power > 0 ? max(ln p * LN_TO_DB, floor) : floor` does, and since db >= -140 the rounded value is >= 1680,
+// where floor(x + 0.5) is exactly round-half-away (x + 0.5 is representable): 6 VALU per bin instead of ~30.
 __device__ __forceinline__ uint16_t classic_code(float power) {  // level.rs:28-34 + processor.rs:103-108
-    const float db = power > 0.0f ? fmaxf(logf(power) * 4.3429448f, -140.0f) : -140.0f;
-    float v = roundf((db + 144.0f) * (65535.0f / 156.0f));
-    v = v < 0.0f ? 0.0f : (v > 65535.0f ? 65535.0f : v);
-    return (v == v) ? (uint16_t)v : (uint16_t)0;
+    const float db = fmaxf(__builtin_amdgcn_logf(power) * 3.0102999566f, -140.0f);
+    const float v = fminf(floorf((db + 144.0f) * (65535.0f / 156.0f) + 0.5f), 65535.0f);
+    return (uint16_t)v;
 }
 
 template <int LOGN>
