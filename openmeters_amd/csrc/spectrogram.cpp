@@ -166,7 +166,9 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     } else if (fast4096_ || fast_zp_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
         d_tw4096_.upload(twiddle_table(W, W), stream);      // exp(-2 pi i k / W)
-        d_tw8192_.upload(twiddle_table(2 * W, W), stream);  // exp(-2 pi i k / 2W)
+        std::vector<float> half_tw = twiddle_table(2 * W, W);  // exp(-2 pi i k / 2W) / 2: the real-FFT split's 1/2 folded in (exact)
+        for (float& x : half_tw) x *= 0.5f;
+        d_tw8192_.upload(half_tw, stream);
         if (fast_zp_) d_twF_.upload(twiddle_table(fft_size_, fft_size_), stream);  // exp(-2 pi i k / F)
     }
     d_bin_norm_.upload(bin_norm, stream);

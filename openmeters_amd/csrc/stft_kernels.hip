@@ -164,6 +164,24 @@ __device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, fl
     return true;
 }
 
+// Branch-free form for the fused kernels: the nine bins of a thread become nine independent dependency chains the scheduler
+// can interleave (the early returns above compile to exec-mask regions that serialise them), and 1/pow is one v_rcp_f32
+// (1 ulp) instead of the 10-instruction IEEE sequence.  pow only scales the two CORRECTION terms (|d_omega| <~ a few bins,
+// |t_hat| <~ W/2 samples), so a 1-ulp reciprocal moves freq_hz by < 1e-9 of Nyquist and time_offset by < 1e-6 hop.
+// A dropped bin (power under the floor, pow == 0 included) may carry NaN in `p`; the caller only stores kept points.
+__device__ __forceinline__ bool reassign_bin_fast(uint32_t i, v2f b, v2f d, v2f t, float norm, const ReassignConsts& c,
+                                                  omx_spectrogram_point& p) {
+    const float pow = b.x * b.x + b.y * b.y;
+    const float scaled_power = pow * norm;
+    const float inv_pow = __builtin_amdgcn_rcpf(pow);
+    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
+    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
+    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
+    p.freq_hz = freq_hz;
+    p.power = scaled_power;
+    return !(scaled_power < 1e-14f) && (freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f);
+}
+
 // ================================================================================================
 // K2: fused reassigned STFT, W = F = 4096, H = 8192.  256 threads, two padded 4096-complex LDS
 // buffers (68 KiB) -> two workgroups per CU.  Algorithm (all f32):
@@ -176,8 +194,10 @@ __device__ __forceinline__ bool reassign_bin(uint32_t i, v2f b, v2f d, v2f t, fl
 // Compile-time switches of the fused kernel (A/B-tested on MI355X; see DESIGN.md §4 and profiles/).
 template <uint32_t COLS, bool TW2_LDS_, bool TW3_REGS_, bool DUAL_, bool PINGPONG_, bool ONEBUF_ = false, int MINW = 2,
           bool RECOMPUTE_S_ = false, bool TWIN_CALC_ = false, bool PHASES_ = false,
-          bool EARLY_ = false>
+          bool EARLY_ = false, bool PHASE_WAIT_ = false, bool FAST_REASSIGN_ = false>
 struct K2Variant {
+    static constexpr bool FAST_REASSIGN = FAST_REASSIGN_;  // branch-free reassignment with v_rcp_f32
+    static constexpr bool PHASE_WAIT = PHASE_WAIT_;  // tuning build: every phase mark drains vmcnt / lgkmcnt first
     static constexpr bool EARLY = EARLY_;          // table / ring loads issued one transform ahead of their use (needs DUAL)
     static constexpr bool PHASES = PHASES_;        // tuning build: thread 0 accumulates shader-clock cycles per phase
     static constexpr bool TWIN_CALC = TWIN_CALC_;  // t*w rebuilt from w in registers (:601-608) instead of a third table
@@ -236,6 +256,11 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     if constexpr (V::PHASES) phase_t = clock64();
     auto mark = [&](int i) {
         if constexpr (V::PHASES) {
+            if constexpr (V::PHASE_WAIT) {  // charge every outstanding load to the phase that issued it
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (j == 0) {
                 const long long now = clock64();
                 atomicAdd(&g_k2_phase_cycles[i], (unsigned long long)(now - phase_t));
@@ -308,11 +333,11 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             const unsigned k = (unsigned)(j + 256 * t);
             const v2f z = v[t];
             const v2f zr = X[pad16((int)((4096u - k) & 4095u))];
-            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Zf[k] + conj Zf[N-k]) / 2
-            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};  // (Zf[k] - conj Zf[N-k]) / 2
+            const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
+            const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
             const v2f w = V::EARLY ? w8[t] : tw8192[k];
             y[t] = cmulc(sum, w) - cmul(dif, w);
-            if (k == 0) y[t] = v2f{0.0f, 0.0f};
+            if (t == 0 && k == 0) y[t] = v2f{0.0f, 0.0f};
         }
         const float half_x0 = hil[0], half_xn = hil[1];
         if constexpr (V::ONEBUF) __syncthreads();  // partners are read from the buffer the inverse is about to overwrite
@@ -458,21 +483,30 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         for (int t = 0; t < 9; ++t) {
             const uint32_t bin = (uint32_t)(j + 256 * t);
             bool keep = false;
-            if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], V::EARLY ? pn[t] : bnorm[bin], rc, pts[t]);
+            if constexpr (V::FAST_REASSIGN) {
+                keep = reassign_bin_fast(bin, bb[t], bd[t], bt[t], pn[t], rc, pts[t]) && (t < 8 || j == 0);
+            } else {
+                if (t < 8 || j == 0) keep = reassign_bin(bin, bb[t], bd[t], bt[t], V::EARLY ? pn[t] : bnorm[bin], rc, pts[t]);
+            }
             masks[t] = __ballot(keep);
             if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
         }
         __syncthreads();
         omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        // all 36 wave counts first (nine 16-byte LDS reads in flight together), then the stores: read-wait-store per bin row
+        // exposed the LDS latency nine times
+        uint4 counts4[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) counts4[t] = *reinterpret_cast<const uint4*>(scan + t * 4);
         uint32_t running = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            const uint32_t c[4] = {counts4[t].x, counts4[t].y, counts4[t].z, counts4[t].w};
             uint32_t before = running;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const uint32_t c = scan[t * 4 + w];
-                if (w < wave) before += c;
-                running += c;
+                if (w < wave) before += c[w];
+                running += c[w];
             }
             if ((masks[t] >> lane) & 1ull) {
                 const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
@@ -542,8 +576,8 @@ __global__ __launch_bounds__(256, 1) void stft_reassigned_4096_wave_kernel(StftF
             const v2f z = buf[lane + 65 * t];
             const unsigned kr = (4096u - k) & 4095u;
             const v2f zr = buf[kr + (kr >> 6)];
-            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
-            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+            const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
+            const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
             const v2f w = a.tw8192[k];
             const v2f y = cmulc(sum, w) - cmul(dif, w);
             v[t] = (k == 0) ? v2f{0.0f, 0.0f} : v2f{y.x, -y.y};  // conj(Z'[k])
@@ -671,6 +705,8 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
         case 20: launch_k2_wave(a, stream); break;  // one wavefront per frame
         case 9: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true>>(a, stream); break;
+        case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); break;
+        case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); break;
         case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); break;
         case 12: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;  // default until the early-load form
         default: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true>>(a, stream); break;

@@ -46,7 +46,7 @@ struct StftFastArgs {
     const float* bin_norm;   // [2049]
     const v2f* tw256;        // exp(-2*pi*i*k/256),  k < 256
     const v2f* tw4096;       // exp(-2*pi*i*k/4096), k < 4096
-    const v2f* tw8192;       // exp(-2*pi*i*k/8192), k < 4096
+    const v2f* tw8192;       // exp(-2*pi*i*k/8192) / 2, k < 4096 (2W-point twiddles carrying the real-FFT split's 1/2)
     float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
     omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
     uint32_t* counts;               // [n_streams][n_cols]

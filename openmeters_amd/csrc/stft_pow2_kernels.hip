@@ -110,8 +110,8 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
         const unsigned k = ju + (unsigned)T * (unsigned)t;
         const v2f z = v[t];
         const v2f zr = A[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
-        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
-        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+        const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
+        const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
         y[t] = cmulc(sum, w2n[t]) - cmul(dif, w2n[t]);
         if (k == 0) y[t] = v2f{0.0f, 0.0f};
     }
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
             const unsigned k = ju + (unsigned)TW * (unsigned)t;
             const v2f z = v[t];
             const v2f zr = A[pad16((int)(((unsigned)W - k) & (unsigned)(W - 1)))];
-            const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
-            const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+            const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
+            const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
             y[t] = cmulc(sum, w2n[t]) - cmul(dif, w2n[t]);
             if (k == 0) y[t] = v2f{0.0f, 0.0f};
         }
@@ -608,8 +608,8 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFast
         const unsigned k = ju + (unsigned)T * (unsigned)t;
         const v2f z = v[t];
         const v2f zr = buf[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
-        const v2f sum{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};
-        const v2f dif{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+        const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
+        const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
         const v2f w = a.tw8192[k];  // exp(-2 pi i k / 2N)
         y[t] = cmulc(sum, w) - cmul(dif, w);
         if (k == 0) y[t] = v2f{0.0f, 0.0f};
