@@ -7,6 +7,8 @@
 //   band 2  mid   = LP_high(HP_low(x))
 //   band 3  high  = HP_high(HP_low(x))      (CASCADE_HIGH = true)
 // HP_low is evaluated by bands 2 and 3 on identical inputs, so both see bit-identical `above_low`.
+#include <type_traits>
+
 #include "stereometer.hpp"
 
 namespace omx {
@@ -89,6 +91,21 @@ __device__ __forceinline__ v2f stereo_frame(const BiquadCoef& ca, const BiquadCo
     return x;
 }
 
+// ---- branch-free batch path ---------------------------------------------------------------------------------------------
+// The per-frame non-finite test of Biquad::process (dsp.rs:428-431) costs a wave-level branch per cascade element, and the
+// branches keep the scheduler from overlapping the elements, the correlator and the history store.  A non-finite output is
+// sticky (it poisons z0 / z1 of that element for good), so the fast path runs BATCH frames without the test while accumulating
+// `poison += out * 0` per element (NaN as soon as any output was inf / NaN); a clean poison means the batch was exact, otherwise
+// the lane state is rolled back and the batch replayed through the per-frame reference path.  (A stage-skewed software
+// pipeline of the same batch — element k on frame i - k — was slower: 3.99 vs 2.84 ms; 16-byte loads / stores changed nothing.)
+__device__ __forceinline__ v2f biquad_core2(const BiquadCoef& c, v2f& z0, v2f& z1, v2f x, v2f& poison) {
+    const v2f out = c.b[0] * x + z0;
+    z0 = c.b[1] * x - c.a[0] * out + z1;
+    z1 = c.b[2] * x - c.a[1] * out;
+    poison = __builtin_elementwise_fma(out, v2f{0.0f, 0.0f}, poison);
+    return out;
+}
+
 // CH = 2: compile-time fold (dsp.rs:234-239 has the same specialisation); CH = 0: any channel count.
 // Workgroup = 4 wavefronts, wavefront w = band w of 64 consecutive streams (lane = stream): which filters run, whether
 // the history is written and whether the band is active at all are wave-uniform, so the per-frame code has no divergent
@@ -117,22 +134,63 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
             const float* base = pcm + (uint64_t)blk * a.block_frames * channels;
             uint32_t f = 0;
             if constexpr (CH == 2) {
-                for (; f + BATCH <= a.block_frames; f += BATCH) {
-                    float2 x[BATCH];
+                auto batches = [&](auto use_a_c, auto use_b_c, auto push_c) {
+                    constexpr bool UA = decltype(use_a_c)::value, UB = decltype(use_b_c)::value, PUSH = decltype(push_c)::value;
+                    for (; f + BATCH <= a.block_frames; f += BATCH) {
+                        float2 x[BATCH];
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i) x[i] = *reinterpret_cast<const float2*>(base + 2u * (f + i));
+                        for (int i = 0; i < BATCH; ++i) x[i] = *reinterpret_cast<const float2*>(base + 2u * (f + i));
+                        const StereoRegs saved = st;
+                        const uint32_t slot0 = slot;
+                        v2f poison[4] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
 #pragma unroll
-                    for (int i = 0; i < BATCH; ++i) {
-                        // two channels: the fold is the identity on bits (dsp.rs:232-236) with the default matrix, else weights
-                        const float left = 0.0f + x[i].x * a.fmt.m[0][0] + x[i].y * a.fmt.m[1][0];
-                        const float right = 0.0f + x[i].x * a.fmt.m[0][1] + x[i].y * a.fmt.m[1][1];
-                        const v2f y = stereo_frame(ca, cb, use_a, use_b, st, alpha, v2f{left, right});
-                        if (push_history) {
-                            *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
-                            slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
+                        for (int i = 0; i < BATCH; ++i) {
+                            // two channels: the fold is the identity on bits (dsp.rs:232-236) with the default matrix, else weights
+                            const float left = 0.0f + x[i].x * a.fmt.m[0][0] + x[i].y * a.fmt.m[1][0];
+                            const float right = 0.0f + x[i].x * a.fmt.m[0][1] + x[i].y * a.fmt.m[1][1];
+                            v2f y{left, right};
+                            if constexpr (UA) {  // Cascade<Biquad,2> per channel (dsp.rs:447-451)
+                                y = biquad_core2(ca, st.z0[0][0], st.z1[0][0], y, poison[0]);
+                                y = biquad_core2(ca, st.z0[0][1], st.z1[0][1], y, poison[1]);
+                            }
+                            if constexpr (UB) {
+                                y = biquad_core2(cb, st.z0[1][0], st.z1[1][0], y, poison[2]);
+                                y = biquad_core2(cb, st.z0[1][1], st.z1[1][1], y, poison[3]);
+                            }
+                            const double ld = (double)y.x, rd = (double)y.y;  // Correlator::update (:40-46)
+                            st.m[0] += alpha * (ld * rd - st.m[0]);
+                            st.m[1] += alpha * (ld * ld - st.m[1]);
+                            st.m[2] += alpha * (rd * rd - st.m[2]);
+                            if constexpr (PUSH) {
+                                *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
+                                slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
+                            }
+                        }
+                        const v2f taint2 = (poison[0] + poison[1]) + (poison[2] + poison[3]);
+                        const float taint = taint2.x + taint2.y;
+                        if (__builtin_expect(__ballot(!(taint == 0.0f)) != 0ull, 0)) {  // some output was inf / NaN: exact replay
+                            st = saved;
+                            slot = slot0;
+#pragma unroll 1
+                            for (int i = 0; i < BATCH; ++i) {  // frames re-read from memory: a dynamically indexed x[] would live in scratch
+                                const float2 xi = *reinterpret_cast<const float2*>(base + 2u * (f + (uint32_t)i));
+                                const float left = 0.0f + xi.x * a.fmt.m[0][0] + xi.y * a.fmt.m[1][0];
+                                const float right = 0.0f + xi.x * a.fmt.m[0][1] + xi.y * a.fmt.m[1][1];
+                                const v2f y = stereo_frame(ca, cb, UA, UB, st, alpha, v2f{left, right});
+                                if constexpr (PUSH) {
+                                    *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
+                                    slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
+                                }
+                            }
                         }
                     }
-                }
+                };
+                using T = std::true_type;
+                using F = std::false_type;
+                // wave-uniform role: full band (no filter), low (stage A), mid / high (A then B)
+                if (use_a && use_b) push_history ? batches(T{}, T{}, T{}) : batches(T{}, T{}, F{});
+                else if (use_a) push_history ? batches(T{}, F{}, T{}) : batches(T{}, F{}, F{});
+                else if (!use_b) push_history ? batches(F{}, F{}, T{}) : batches(F{}, F{}, F{});
             }
             for (; f < a.block_frames; ++f) {
                 const float* frame = base + (uint64_t)f * channels;

@@ -311,3 +311,36 @@ def test_waveform_bank_matches_per_stream_oracle(omx, oracle):
                 assert np.array_equal(prev[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32))
         total += int(up.n_columns)
     assert total > 50
+
+
+def test_stereometer_non_finite_samples_reset_the_filters_like_the_reference(omx, oracle):
+    """Biquad::process zeroes its state and output when the output is not finite (dsp.rs:428-431).  The HIP kernel runs 8-frame
+    batches without that test and replays a batch frame by frame when its poison accumulator trips: inf / NaN / overflowing
+    samples at scattered positions must give bit-identical band points and the same correlations as the frame-by-frame oracle."""
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.01,
+                            target_sample_count=480)
+    pcm = cfg4_pcm(7, 256 * 16).copy()
+    pcm[300, 0] = np.inf
+    pcm[301, 1] = -np.inf
+    pcm[777, 0] = np.nan
+    pcm[1500:1503, :] = np.float32(3.0e38)    # finite input, overflows inside the cascades
+    pcm[2300, 1] = np.float32(-3.4e38)
+    pcm[3071, 0] = np.nan                     # last frame of a block
+    pcm[3072, 1] = np.inf                     # first frame of the next
+    a, b = StereometerProcessor(omx, cfg), StereometerProcessor(oracle, cfg)
+    seen = 0
+    for k in range(0, pcm.shape[0], 256):
+        g = a.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        w = b.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        assert (g is None) == (w is None)
+        if g is None:
+            continue
+        seen += 1
+        assert np.array_equal(np.isnan(g.correlations), np.isnan(w.correlations))
+        assert np.nanmax(np.abs(g.correlations - w.correlations), initial=0.0) <= 1e-6, k
+        for band in range(4):
+            assert g.points[band].shape == w.points[band].shape
+            gp, wp = g.points[band], w.points[band]
+            both_nan = np.isnan(gp) & np.isnan(wp)
+            assert np.array_equal(gp.view(np.uint32)[~both_nan], wp.view(np.uint32)[~both_nan]), (k, band)
+    assert seen >= 10
