@@ -8,6 +8,8 @@
 // (lazy activation with leading zeros == eager state fed zeros, loudness/processor.rs:400-417), so
 // each expiring-value read and each ring write is one coalesced f64 row per wave.
 // Built with -ffp-contract=off: the f64 filter and the KBN sums round exactly like the scalar code.
+#include <type_traits>
+
 #include "loudness.hpp"
 
 namespace omx {
@@ -398,7 +400,6 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
     uint32_t refresh = (uint32_t)(a.frames_seen % a.capacities[r]);
     uint32_t unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);
     uint64_t seen = a.frames_seen;
-    const bool store_lane = live && r == 0;
     double o0[B], o1[B], o2[B], o3[B];  // expiring values, fetched four batches (32 samples, several HBM round trips) ahead
     // expiring values of the batch that starts `ahead` samples from the cursor (dsp.rs:336-338); `batch` only gates the tail
     auto fetch_old = [&](double (&old)[B], uint32_t ahead, uint64_t batch) -> uint32_t {
@@ -440,10 +441,13 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
                 for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) field[i] = a.floor_db;  // with_floor (:197-207)
         }
     };
-    auto consume = [&](const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
-        // CompensatedPair::refresh (dsp.rs:287-289) fires once per `cap` pushes (>= 14 400): a batch that cannot reach it runs
-        // as straight-line code, the rare one that can keeps the per-sample test
-        const bool may_refresh = refresh + (uint32_t)B >= cap;
+    // Window 0 (cap == ring length) also writes the ring.  The role is wave-uniform: the per-sample `if (store_lane)` of the
+    // first form cost every other window wavefront a taken branch per sample, so the batch body is instantiated per role
+    // (STORE) and per "can CompensatedPair::refresh fire in this batch" (REFRESH; once per `cap` >= 14 400 pushes) — the common
+    // instantiation is straight-line code.
+    const bool store_wave = __builtin_amdgcn_readfirstlane((int)(r == 0)) != 0;
+    auto consume_as = [&](auto store_c, auto refresh_c, const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub) {
+        constexpr bool STORE = decltype(store_c)::value, REFRESH = decltype(refresh_c)::value;
 #pragma unroll
         for (int k = 0; k < B; ++k) {
             const double value = vals[buf][sub * B + k][lane];
@@ -451,13 +455,29 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
             kbn_add(sum0, cor0, value);
             kbn_add(sum1, cor1, value);
             kbn_add(sum0, cor0, -expiring);
-            if (may_refresh && refresh + (uint32_t)k + 1u == cap) {
-                sum0 = sum1;
-                sum1 = 0.0;
-                cor0 = cor1;
-                cor1 = 0.0;
+            if constexpr (REFRESH) {
+                if (refresh + (uint32_t)k + 1u == cap) {  // CompensatedPair::refresh (dsp.rs:287-289)
+                    sum0 = sum1;
+                    sum1 = 0.0;
+                    cor0 = cor1;
+                    cor1 = 0.0;
+                }
             }
-            if (store_lane) ring_col[(uint64_t)(head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * row] = value;
+            if constexpr (STORE) {
+                if (live) ring_col[(uint64_t)(head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * row] = value;
+            }
+        }
+    };
+    auto consume = [&](const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool may_refresh = refresh + (uint32_t)B >= cap;
+        if (store_wave) {
+            if (may_refresh) consume_as(T{}, T{}, old, first_valid, buf, sub);
+            else consume_as(T{}, F{}, old, first_valid, buf, sub);
+        } else {
+            if (may_refresh) consume_as(F{}, T{}, old, first_valid, buf, sub);
+            else consume_as(F{}, F{}, old, first_valid, buf, sub);
         }
         refresh += (uint32_t)B;
         refresh = refresh >= cap ? refresh - cap : refresh;

@@ -98,6 +98,9 @@ __device__ __forceinline__ v2f stereo_frame(const BiquadCoef& ca, const BiquadCo
 // `poison += out * 0` per element (NaN as soon as any output was inf / NaN); a clean poison means the batch was exact, otherwise
 // the lane state is rolled back and the batch replayed through the per-frame reference path.  (A stage-skewed software
 // pipeline of the same batch — element k on frame i - k — was slower: 3.99 vs 2.84 ms; 16-byte loads / stores changed nothing.)
+// A dependent v_pk_*_f32 issues every 8 cycles on gfx950, an independent one every 4 (tools/microbench/issue_rate.hip), and the
+// wavefront issues in order: the file is built with -amdgpu-sched-strategy=max-ilp so that the four cascade elements, the
+// correlator and the neighbouring frames of a batch are interleaved instead of laid out chain after chain.
 __device__ __forceinline__ v2f biquad_core2(const BiquadCoef& c, v2f& z0, v2f& z1, v2f x, v2f& poison) {
     const v2f out = c.b[0] * x + z0;
     z0 = c.b[1] * x - c.a[0] * out + z1;
@@ -129,6 +132,26 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     const double alpha = a.alpha;
     constexpr int BATCH = 8;  // frames whose loads are issued together
 
+    float2 xnext[BATCH];      // CH == 2 fast path: the prefetched batch
+    bool have_next = false;   // xnext holds the batch the loop is about to process
+    // History pairs of a batch are stored at the START of the next batch, ahead of its prefetch loads: loads and stores share
+    // vmcnt on gfx950, so the wait for the prefetched frames at the top of a batch also waits for every store still in flight —
+    // stores issued at the end of the previous batch exposed a full write round trip per 8 frames (the whole kernel time).
+    v2f pend[BATCH];
+    uint32_t pend_slot = 0;
+    bool has_pend = false;
+    auto flush_pending = [&]() {
+        if (has_pend) {
+            uint32_t sl = pend_slot;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                *reinterpret_cast<v2f*>(hist + 2u * sl) = pend[i];
+                sl = sl + 1u == a.hist_frames ? 0u : sl + 1u;
+            }
+            has_pend = false;
+        }
+    };
+    const bool contiguous_batches = a.block_frames % BATCH == 0;
     for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
         if (active) {
             const float* base = pcm + (uint64_t)blk * a.block_frames * channels;
@@ -138,8 +161,21 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
                     constexpr bool UA = decltype(use_a_c)::value, UB = decltype(use_b_c)::value, PUSH = decltype(push_c)::value;
                     for (; f + BATCH <= a.block_frames; f += BATCH) {
                         float2 x[BATCH];
+                        if (!have_next) {
 #pragma unroll
-                        for (int i = 0; i < BATCH; ++i) x[i] = *reinterpret_cast<const float2*>(base + 2u * (f + i));
+                            for (int i = 0; i < BATCH; ++i) xnext[i] = *reinterpret_cast<const float2*>(base + 2u * (f + i));
+                        }
+#pragma unroll
+                        for (int i = 0; i < BATCH; ++i) x[i] = xnext[i];
+                        flush_pending();
+                        // the next batch's frames are requested before this batch is computed (one wavefront per SIMD: nothing
+                        // else hides the round trip).  Blocks are contiguous, so the prefetch runs across block boundaries; past
+                        // the end of the call it re-reads the current batch (unconditional load, selected address).
+                        const uint64_t g = (uint64_t)blk * a.block_frames + f + BATCH;
+                        have_next = contiguous_batches && g + BATCH <= a.frames_total;
+                        const float* nxt = pcm + 2u * (have_next ? g : g - BATCH);
+#pragma unroll
+                        for (int i = 0; i < BATCH; ++i) xnext[i] = *reinterpret_cast<const float2*>(nxt + 2 * i);
                         const StereoRegs saved = st;
                         const uint32_t slot0 = slot;
                         v2f poison[4] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
@@ -162,15 +198,18 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
                             st.m[1] += alpha * (ld * ld - st.m[1]);
                             st.m[2] += alpha * (rd * rd - st.m[2]);
                             if constexpr (PUSH) {
-                                *reinterpret_cast<v2f*>(hist + 2u * slot) = y;
+                                pend[i] = y;
                                 slot = slot + 1u == a.hist_frames ? 0u : slot + 1u;
                             }
                         }
+                        pend_slot = slot0;
+                        has_pend = PUSH;
                         const v2f taint2 = (poison[0] + poison[1]) + (poison[2] + poison[3]);
                         const float taint = taint2.x + taint2.y;
                         if (__builtin_expect(__ballot(!(taint == 0.0f)) != 0ull, 0)) {  // some output was inf / NaN: exact replay
                             st = saved;
                             slot = slot0;
+                            has_pend = false;  // the replay stores its pairs itself
 #pragma unroll 1
                             for (int i = 0; i < BATCH; ++i) {  // frames re-read from memory: a dynamically indexed x[] would live in scratch
                                 const float2 xi = *reinterpret_cast<const float2*>(base + 2u * (f + (uint32_t)i));
@@ -192,6 +231,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
                 else if (use_a) push_history ? batches(T{}, F{}, T{}) : batches(T{}, F{}, F{});
                 else if (!use_b) push_history ? batches(F{}, F{}, T{}) : batches(F{}, F{}, F{});
             }
+            if (f < a.block_frames) flush_pending();
             for (; f < a.block_frames; ++f) {
                 const float* frame = base + (uint64_t)f * channels;
                 float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
@@ -232,6 +272,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
         }
         a.correlations[((uint64_t)s * a.n_blocks + blk) * 4 + band] = value;
     }
+    flush_pending();
     store_regs(st, st_mem);
     a.state[gid] = st_mem;
 }
