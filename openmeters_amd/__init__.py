@@ -17,7 +17,7 @@ from .capi import (  # noqa: F401  (re-exported: the reference's config / snapsh
 )
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libomx_hip.so")
+LIB_PATH = os.environ.get("OMX_HIP_LIB") or os.path.join(_HERE, "csrc", "libomx_hip.so")  # OMX_HIP_LIB: A/B builds (tuning)
 _API = None
 
 
