@@ -162,11 +162,25 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
     last_peak = 0.0f;
     const uint32_t n = x.n;
     if (n < 3) return none;
+    // Steady state (8192-point autocorrelation, transform buffer in LDS): the probe is read from the trace ring ONCE, into the
+    // still unused transform buffer; mean, peak, prefix energy and the transform's input all come from that LDS copy (four more
+    // passes over the global ring before, each exposing an L2 round trip to the one workgroup a CU holds).
+    const bool staged = a.tw4096 != nullptr && !a.fft_global && n <= 2u * FFT4096_LDS;
+    float* stage = reinterpret_cast<float*>(fft);
     float part = 0.0f;
-    for (uint32_t i = tid; i < n; i += 256) part += x.at(i);
-    const float mean = block_sum(part, sh) / (float)n;
+    if (staged) {
+        for (uint32_t i = tid; i < n; i += 256) {
+            const float v = x.at(i);
+            stage[i] = v;
+            part += v;
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += 256) part += x.at(i);
+    }
+    const float mean = block_sum(part, sh) / (float)n;  // its barriers also publish `stage`
+    auto xs = [&](uint32_t i) { return staged ? stage[i] : x.at(i); };
     float pk = 0.0f;
-    for (uint32_t i = tid; i < n; i += 256) pk = fmaxf(pk, fabsf(x.at(i) - mean));
+    for (uint32_t i = tid; i < n; i += 256) pk = fmaxf(pk, fabsf(xs(i) - mean));
     last_peak = block_max(pk, sh);
     if (last_peak < MIN_SIGNAL_PEAK) return none;
     const uint32_t min_period = f2u(fmaxf(roundf(rate / MAX_HZ), 2.0f));
@@ -183,34 +197,66 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
     const uint32_t tw_step = a.fft_size / fft_size;  // a.fft_size is the largest size this config can need
     const uint32_t chunk = (n + 255) / 256;
     const bool fast = fft_size == 8192 && a.tw4096 != nullptr;  // steady state at 44.1 / 48 kHz
-    {  // centred copy + prefix energy (block scan: per-thread chunk sums, serial scan of 256 partials)
+    {  // centred copy + prefix energy: per-thread chunk sums, then a wave-level scan of the 256 chunk sums
         const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
         float local = 0.0f;
-        for (uint32_t i = lo; i < hi; ++i) {
-            const float c = x.at(i) - mean;
-            if (!fast) fft[i] = v2f{c, 0.0f};
-            local = c * c + local;
-        }
-        if (!fast)
-            for (uint32_t i = n + tid; i < fft_size; i += 256) fft[i] = v2f{0.0f, 0.0f};
-        __syncthreads();
-        sc.partials[tid] = local;
-        __syncthreads();
-        if (tid == 0) {
-            float run = 0.0f;
-            for (int t = 0; t < 256; ++t) {
-                const float v = sc.partials[t];
-                sc.partials[t] = run;
-                run += v;
+        if (staged && !fast) __syncthreads();  // (never in practice) the radix-2 path overwrites the staging area below
+        float cached[24];                      // chunk <= 24 whenever the probe is staged (n <= 6144)
+        const bool keep = staged && chunk <= 24;
+        if (keep) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                cached[q] = i < hi ? stage[i] - mean : 0.0f;
+                local = i < hi ? cached[q] * cached[q] + local : local;
             }
-            sc.energy[0] = 0.0f;
+        } else {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const float c = x.at(i) - mean;
+                if (!fast) fft[i] = v2f{c, 0.0f};
+                local = c * c + local;
+            }
         }
+        if (!fast) {
+            if (keep) {
+                __syncthreads();
+                for (uint32_t i = lo; i < hi; ++i) fft[i] = v2f{x.at(i) - mean, 0.0f};
+            }
+            for (uint32_t i = n + tid; i < fft_size; i += 256) fft[i] = v2f{0.0f, 0.0f};
+        }
+        // exclusive scan of the chunk sums (the first form scanned the 256 partials serially on thread 0: 256 dependent
+        // LDS round trips, a tenth of the whole block time)
+        const unsigned lane = tid & 63u, wave = tid >> 6;
+        float incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float up = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += up;
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 0.0f;
         __syncthreads();
-        float run = sc.partials[tid];
-        for (uint32_t i = lo; i < hi; ++i) {
-            const float c = x.at(i) - mean;
-            run = c * c + run;
-            sc.energy[i + 1] = run;
+        if (lane == 63) sh.redf[wave] = incl;
+        if (tid == 0) sc.energy[0] = 0.0f;
+        __syncthreads();
+        float run = 0.0f;
+        for (unsigned w = 0; w < wave; ++w) run += sh.redf[w];
+        run += excl;
+        if (keep) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                if (i < hi) {
+                    run = cached[q] * cached[q] + run;
+                    sc.energy[i + 1] = run;
+                }
+            }
+        } else {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const float c = x.at(i) - mean;
+                run = c * c + run;
+                sc.energy[i + 1] = run;
+            }
         }
     }
     pc.mark(1);  // mean / peak / centred copy / prefix energy
@@ -226,10 +272,11 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const uint32_t m = (uint32_t)(j + 256 * t);
-            const float re = 2u * m < n ? x.at(2u * m) - mean : 0.0f;
-            const float im = 2u * m + 1u < n ? x.at(2u * m + 1u) - mean : 0.0f;
+            const float re = 2u * m < n ? xs(2u * m) - mean : 0.0f;
+            const float im = 2u * m + 1u < n ? xs(2u * m + 1u) - mean : 0.0f;
             v[t] = v2f{re, im};
         }
+        if (staged) __syncthreads();  // every thread has taken its samples out of the staging area the first pass overwrites
         fft4096t<false, false>(v, fft, fft, j, tw);
         __syncthreads();
 #pragma unroll

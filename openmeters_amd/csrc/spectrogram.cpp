@@ -313,7 +313,16 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
             const char* e = getenv("OMX_K2_VARIANT");
             return e && atoi(e) == 30;
         }();
-        if (reassign && fft_size_ == 16384 && !fast_zp_) {
+        static const bool split_check = [] {  // OMX_K2_VARIANT=31: 4096 through the three-kernel form (tuning)
+            const char* e = getenv("OMX_K2_VARIANT");
+            return e && atoi(e) == 31;
+        }();
+        if (reassign && fft_size_ == 4096 && !fast_zp_ && split_check) {
+            const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 4096);
+            d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
+            for (uint64_t first = 0; first < total; first += chunk)
+                launch_stft_reassigned_4096_split(fa, d_workspace_.ptr, (uint32_t)first, (uint32_t)std::min(chunk, total - first), stream);
+        } else if (reassign && fft_size_ == 16384 && !fast_zp_) {
             const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 1024);
             d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
             for (uint64_t first = 0; first < total; first += chunk)

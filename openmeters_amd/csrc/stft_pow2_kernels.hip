@@ -719,9 +719,9 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
 
 // bytes of scratch per frame of a chunk, and the launcher (frames [first, first + count) of the call)
 uint64_t stft_big_scratch_bytes_per_frame() { return (uint64_t)(16384 + 3 * 8193) * sizeof(v2f); }
-void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
-    if (count == 0) return;
-    using G = FftGeom<14>;
+template <int LOGN>
+static void launch_big(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    using G = FftGeom<LOGN>;
     BigScratch sc{};
     sc.sv = reinterpret_cast<v2f*>(scratch);
     sc.spec = sc.sv + (uint64_t)count * G::N;
@@ -730,13 +730,23 @@ void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t
     const size_t lds = (size_t)(G::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_big_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_big_kernel<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(hilbert_big_kernel<14>, dim3(count), dim3(G::WG), lds, stream, a, sc);
-    hipLaunchKernelGGL(windowed_big_kernel<14>, dim3(count, 3), dim3(G::WG), lds, stream, a, sc);
-    hipLaunchKernelGGL(reassign_big_kernel<14>, dim3(count), dim3(G::WG), 0, stream, a, sc);
+    hipLaunchKernelGGL(hilbert_big_kernel<LOGN>, dim3(count), dim3(G::WG), lds, stream, a, sc);
+    hipLaunchKernelGGL(windowed_big_kernel<LOGN>, dim3(count, 3), dim3(G::WG), lds, stream, a, sc);
+    hipLaunchKernelGGL(reassign_big_kernel<LOGN>, dim3(count), dim3(G::WG), 0, stream, a, sc);
+}
+void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    if (count == 0) return;
+    launch_big<14>(a, scratch, first, count, stream);
+}
+// tuning only (OMX_K2_VARIANT=31): the 4096-point shape through the same three kernels, to price the fused kernel against
+// simple high-occupancy ones
+void launch_stft_reassigned_4096_split(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    if (count == 0) return;
+    launch_big<12>(a, scratch, first, count, stream);
 }
 
 template <int LOGN>
