@@ -157,8 +157,10 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     const bool fast_classic_zp = !reassign && W < fft_size_ && W >= 256 &&
                                  (fft_size_ == 1024 || fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192 || fft_size_ == 16384);
     // zero-padded reassigned shapes with a fused kernel: window 1024 / 2048 / 4096 padded to 2048 / 4096 / 8192
-    fast_zp_ = reassign && W < fft_size_ && (W == 1024 || W == 2048 || W == 4096) &&
-               (fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192);
+    // ... or, through the three-kernel form, window 1024 ... 8192 padded to 16384
+    fast_zp_ = reassign && W < fft_size_ &&
+               (((W == 1024 || W == 2048 || W == 4096) && (fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192)) ||
+                ((W == 1024 || W == 2048 || W == 4096 || W == 8192) && fft_size_ == 16384));
     if (fast_classic_zp) {
         fast4096_ = true;
         d_tw256_.upload(twiddle_table(256, 256), stream);
@@ -327,6 +329,12 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
             d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
             for (uint64_t first = 0; first < total; first += chunk)
                 launch_stft_reassigned_16384(fa, d_workspace_.ptr, (uint32_t)first, (uint32_t)std::min(chunk, total - first), stream);
+        } else if (fast_zp_ && fft_size_ == 16384) {
+            const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 1024);
+            d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
+            for (uint64_t first = 0; first < total; first += chunk)
+                (void)launch_stft_reassigned_zp_16384(fa, (uint32_t)W, reinterpret_cast<const v2f*>(d_twF_.ptr), d_workspace_.ptr,
+                                                      (uint32_t)first, (uint32_t)std::min(chunk, total - first), stream);
         } else if (fast_zp_)
             (void)launch_stft_reassigned_zp(fa, (uint32_t)W, (uint32_t)fft_size_, reinterpret_cast<const v2f*>(d_twF_.ptr), stream);
         else if (!reassign)

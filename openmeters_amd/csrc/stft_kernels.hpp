@@ -60,6 +60,8 @@ void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipSt
 // reassigned 16384: three kernels through an HBM scratch, frames [first, first + count) of the call per launch
 uint64_t stft_big_scratch_bytes_per_frame();
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream);
+bool launch_stft_reassigned_zp_16384(const StftFastArgs& a, uint32_t window, const v2f* twF, void* scratch, uint32_t first, uint32_t count,
+                                     hipStream_t stream);
 void launch_stft_reassigned_4096_split(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream);
 // zero-padded fused kernel: window 1024 / 2048, transform 2048 / 4096 (false: combination not covered)
 bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t fft_size, const v2f* twF, hipStream_t stream);

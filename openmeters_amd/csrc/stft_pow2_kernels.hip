@@ -584,7 +584,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFast
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);
-    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    for (unsigned i = threadIdx.x; i < 256u; i += (unsigned)T) tw2_lds[i] = a.tw256[i];  // launched with T threads (T >= 64)
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -648,17 +648,19 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFas
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);
     if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
-    const v2f* sv = sc.sv + (uint64_t)blockIdx.x * N;
+    const uint32_t W = a.window_size;  // == N unless the window is zero-padded to the transform (:334-342)
+    const v2f* sv = sc.sv + (uint64_t)blockIdx.x * W;
     const float* win = q == 1 ? a.dwindow : a.window;
-    constexpr float CENTER = (float)(N - 1) * 0.5f;
+    const float center = (float)(W - 1u) * 0.5f;
     v2f v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int i = j + T * u;
-        const v2f x = sv[i];
-        float w = win[i];
-        if (q == 2) w = ((float)i - CENTER) * w;  // compute_time_weighted (:601-608)
-        v[u] = v2f{x.x * w, x.y * w};
+        const uint32_t i = ju + (unsigned)T * (unsigned)u;
+        const uint32_t ic = i < W ? i : 0u;  // unconditional loads, selected afterwards
+        const v2f x = sv[ic];
+        float w = win[ic];
+        if (q == 2) w = ((float)ic - center) * w;  // compute_time_weighted (:601-608)
+        v[u] = i < W ? v2f{x.x * w, x.y * w} : v2f{0.0f, 0.0f};
     }
     __syncthreads();  // tw2_lds
     fftp_inplace<false, LOGN>(v, buf, j, tw);
@@ -719,34 +721,51 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
 
 // bytes of scratch per frame of a chunk, and the launcher (frames [first, first + count) of the call)
 uint64_t stft_big_scratch_bytes_per_frame() { return (uint64_t)(16384 + 3 * 8193) * sizeof(v2f); }
-template <int LOGN>
-static void launch_big(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
-    using G = FftGeom<LOGN>;
+// LOGW = window (Hilbert pair on 2W samples), LOGF = transform; W == F unless zero-padded
+template <int LOGW, int LOGF>
+static void launch_big(const StftFastArgs& a, const v2f* twF, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    using GW = FftGeom<LOGW>;
+    using GF = FftGeom<LOGF>;
     BigScratch sc{};
     sc.sv = reinterpret_cast<v2f*>(scratch);
-    sc.spec = sc.sv + (uint64_t)count * G::N;
+    sc.spec = sc.sv + (uint64_t)count * GW::N;
     sc.first = first;
     sc.count = count;
-    const size_t lds = (size_t)(G::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
+    const size_t lds_w = (size_t)(GW::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
+    const size_t lds_f = (size_t)(GF::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_big_kernel<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<LOGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_big_kernel<LOGF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
         attr_set = true;
     }
-    hipLaunchKernelGGL(hilbert_big_kernel<LOGN>, dim3(count), dim3(G::WG), lds, stream, a, sc);
-    hipLaunchKernelGGL(windowed_big_kernel<LOGN>, dim3(count, 3), dim3(G::WG), lds, stream, a, sc);
-    hipLaunchKernelGGL(reassign_big_kernel<LOGN>, dim3(count), dim3(G::WG), 0, stream, a, sc);
+    StftFastArgs af = a;  // the windowed transforms run at F points: their twiddles are exp(-2 pi i k / F)
+    if (twF) af.tw4096 = twF;
+    hipLaunchKernelGGL(hilbert_big_kernel<LOGW>, dim3(count), dim3(GW::T), lds_w, stream, a, sc);
+    hipLaunchKernelGGL(windowed_big_kernel<LOGF>, dim3(count, 3), dim3(GF::T), lds_f, stream, af, sc);
+    hipLaunchKernelGGL(reassign_big_kernel<LOGF>, dim3(count), dim3(GF::T), 0, stream, af, sc);
 }
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
     if (count == 0) return;
-    launch_big<14>(a, scratch, first, count, stream);
+    launch_big<14, 14>(a, nullptr, scratch, first, count, stream);
+}
+// window 1024 ... 8192 zero-padded to a 16384-point transform (zero padding 16 / 8 / 4 / 2 of the GUI): same three kernels
+bool launch_stft_reassigned_zp_16384(const StftFastArgs& a, uint32_t window, const v2f* twF, void* scratch, uint32_t first, uint32_t count,
+                                     hipStream_t stream) {
+    if (count == 0) return true;
+    switch (window) {
+        case 1024: launch_big<10, 14>(a, twF, scratch, first, count, stream); return true;
+        case 2048: launch_big<11, 14>(a, twF, scratch, first, count, stream); return true;
+        case 4096: launch_big<12, 14>(a, twF, scratch, first, count, stream); return true;
+        case 8192: launch_big<13, 14>(a, twF, scratch, first, count, stream); return true;
+        default: return false;
+    }
 }
 // tuning only (OMX_K2_VARIANT=31): the 4096-point shape through the same three kernels, to price the fused kernel against
 // simple high-occupancy ones
 void launch_stft_reassigned_4096_split(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
     if (count == 0) return;
-    launch_big<12>(a, scratch, first, count, stream);
+    launch_big<12, 12>(a, nullptr, scratch, first, count, stream);
 }
 
 template <int LOGN>

@@ -39,7 +39,7 @@ def check_reassigned(got, want, hop):
 
 @pytest.mark.parametrize("W,hop,zp", [(4096, 256, 1), (1024, 256, 1), (2048, 64, 1), (2048, 512, 4), (256, 32, 1), (8192, 512, 1),
                                       (16384, 2048, 1), (1024, 256, 2), (1024, 100, 4), (2048, 64, 2), (2048, 256, 8),
-                                      (4096, 256, 2), (2048, 128, 4), (1024, 64, 8)])
+                                      (4096, 256, 2), (2048, 128, 4), (1024, 64, 8), (1024, 128, 16), (4096, 512, 4), (8192, 1024, 2)])
 def test_reassigned_columns_match_oracle(omx, oracle, W, hop, zp):
     assert openmeters_amd.device_available()
     cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, use_reassignment=True, history_length=8192)
