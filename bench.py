@@ -42,9 +42,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
     ap.add_argument("--frames-per-step", type=int, default=256 * 1024, help="new PCM frames per stream per step")
-    ap.add_argument("--cpu-columns", type=int, default=2048, help="columns per stream in the cpu_baseline sample")
+    ap.add_argument("--cpu-columns", type=int, default=8192, help="columns per stream in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spectrum", action="store_true", help="leave the A-weighted spectrum bank out of the step")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 side measurements (N = 1 only)")
     return ap.parse_args()
 
 
@@ -278,6 +279,21 @@ def main():
         },
     }
     if rank == 0:
+        if world == 1 and not args.no_secondary:
+            # BASELINE.json's other single-GPU configurations, measured after the timed region (a few seconds; never part of
+            # `value`): cfg3 loudness, cfg4 oscilloscope + stereometer, cfg5's per-GPU shard of the full pipeline
+            try:
+                del pcm, bank, spectrum
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_meters
+                import bench_pipeline
+                side = {"cfg3_loudness": bench_meters.loudness(out=sys.stderr)}
+                side.update({"cfg4_" + k: v for k, v in bench_meters.scope_stereo(out=sys.stderr).items()})
+                side["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
+                result["secondary"] = side
+            except Exception as e:  # the headline line must survive a failure here
+                result["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_columns, log)
         print(json.dumps(result), flush=True)

@@ -29,7 +29,7 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def loudness(S=1024, C=8, blocks=64, reps=5):
+def loudness(S=1024, C=8, blocks=64, reps=5, out=sys.stdout):
     frames = 256 * blocks
     n = torch.arange(frames, device=dev, dtype=torch.float64)
     pcm = torch.empty((S, frames, C), device=dev, dtype=torch.float32)
@@ -46,12 +46,15 @@ def loudness(S=1024, C=8, blocks=64, reps=5):
     kms, _ = bank.kernel_time()
     cs = S * C * frames
     print(f"cfg3 loudness: {S}x{C}ch, {blocks} blocks/call: {dt*1e3:.2f} ms/call (kernel {kms:.2f} ms) -> {cs/dt/1e9:.2f} G channel-samples/s, "
-          f"{cs/dt/(S*C*FS):.0f}x real time, algorithmic {cs*44/ (kms*1e-3)/1e9:.0f} GB/s = {cs*44/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s")
+          f"{cs/dt/(S*C*FS):.0f}x real time, algorithmic {cs*44/ (kms*1e-3)/1e9:.0f} GB/s = {cs*44/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s", file=out)
     snap = bank.fetch(0, blocks - 1)
-    print("   stream0 last snapshot:", snap.short_term_loudness, snap.momentary_loudness, snap.true_peak_db[:3])
+    print("   stream0 last snapshot:", snap.short_term_loudness, snap.momentary_loudness, snap.true_peak_db[:3], file=out)
+    return {"workload": f"{S} streams x {C} ch, {blocks} blocks of 256 per call", "channel_samples_per_s": cs / dt, "x_real_time": cs / dt / (S * C * FS),
+            "ms_per_call": dt * 1e3, "kernel_ms": kms, "hbm_frac_algorithmic_44B": cs * 44 / (kms * 1e-3) / 8e12,
+            "momentary_lufs_stream0": float(snap.momentary_loudness)}
 
 
-def scope_stereo(S=256, blocks=64, reps=5):
+def scope_stereo(S=256, blocks=64, reps=5, out=sys.stdout):
     frames = 256 * blocks
     n = torch.arange(frames, device=dev, dtype=torch.float64)
     pcm = torch.empty((S, frames, 2), device=dev, dtype=torch.float32)
@@ -65,13 +68,19 @@ def scope_stereo(S=256, blocks=64, reps=5):
                                                            target_sample_count=2000), S)
     dt = timed(lambda: st.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
     print(f"cfg4 stereometer: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
-          f"{S*frames/dt/(S*FS):.0f}x real time")
+          f"{S*frames/dt/(S*FS):.0f}x real time", file=out)
+    res = {"stereometer": {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
+                           "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3}}
     sc = banks.OscilloscopeBank(api, capi.OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2,
                                                              trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT), S)
     dt = timed(lambda: sc.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
     hdr, _ = sc.fetch(0, blocks - 1)
     print(f"cfg4 oscilloscope: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.1f} k blocks/s, "
-          f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel}")
+          f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel}", file=out)
+    res["oscilloscope"] = {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
+                           "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3, "stream0_locked": int(hdr.locked),
+                           "stream0_period": float(hdr.period)}
+    return res
 
 
 if __name__ == "__main__":

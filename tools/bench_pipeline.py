@@ -9,28 +9,36 @@ import torch
 import openmeters_amd
 from openmeters_amd.pipeline import FullPipeline
 
-api = openmeters_amd.api()
-dev = torch.device("cuda", 0)
-S, frames = 1024, 16384
-t = torch.arange(frames * 6, device=dev, dtype=torch.float32)
-base = 0.4 * torch.sin(t * 0.05 + 1e-7 * t * t)
-pcm = (base[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :] + 0.001 * torch.randn((S, frames * 6, 2), device=dev)).contiguous()
-for mode in ("serial", "concurrent"):
-    pipe = FullPipeline(api, S)
-    chunks = [pcm[:, k * frames:(k + 1) * frames].contiguous() for k in range(6)]
-    run = (lambda c: pipe.step(c.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)) if mode == "serial" else \
-          (lambda c: pipe.step_concurrent(torch, c.data_ptr(), frames))
-    run(chunks[0])
-    run(chunks[1])
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ev[0].record()
-    for c in chunks[2:]:
-        out = run(c)
-    ev[1].record()
-    torch.cuda.synchronize()
-    ms = ev[0].elapsed_time(ev[1]) / 4
-    table = pipe.stats(torch, dev, *out)
-    print(f"{mode}: {ms:.3f} ms per step of {S} streams x {frames} frames -> {S * frames / ms / 1e6:.2f} G stream-frames/s, "
-          f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
-          f"rho mean {float(table[:, 3].mean()):.3f}")
+
+def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
+    api = openmeters_amd.api()
+    dev = torch.device("cuda", 0)
+    t = torch.arange(frames * 6, device=dev, dtype=torch.float32)
+    base = 0.4 * torch.sin(t * 0.05 + 1e-7 * t * t)
+    pcm = (base[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :] + 0.001 * torch.randn((S, frames * 6, 2), device=dev)).contiguous()
+    res = {"workload": f"{S} streams x 2 ch: reassigned STFT 4096/256 + LUFS + band correlation, {frames} frames per step"}
+    for mode in ("serial", "concurrent"):
+        pipe = FullPipeline(api, S)
+        chunks = [pcm[:, k * frames:(k + 1) * frames].contiguous() for k in range(6)]
+        run = (lambda c: pipe.step(c.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)) if mode == "serial" else \
+              (lambda c: pipe.step_concurrent(torch, c.data_ptr(), frames))
+        run(chunks[0])
+        run(chunks[1])
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for c in chunks[2:]:
+            result = run(c)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 4
+        table = pipe.stats(torch, dev, *result)
+        print(f"{mode}: {ms:.3f} ms per step of {S} streams x {frames} frames -> {S * frames / ms / 1e6:.2f} G stream-frames/s, "
+              f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
+              f"rho mean {float(table[:, 3].mean()):.3f}", file=out)
+        res[mode] = {"ms_per_step": ms, "stft_frames_per_s": S * (frames // 256) / (ms * 1e-3), "x_real_time": frames / 48000.0 / (ms * 1e-3)}
+    return res
+
+
+if __name__ == "__main__":
+    shard_pipeline()
