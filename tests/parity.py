@@ -9,60 +9,85 @@ way SURVEY §7 defines "1e-5 relative": against the column's maximum, not per-bi
 import numpy as np
 
 
-def align_points(a, b, max_power):
-    """Returns (pairs, orphans_a, orphans_b); pairs index into a / b."""
-    i = j = 0
+def align_points(a, b, max_power, band_extra=8):
+    """Returns (pairs, orphans_a, orphans_b); pairs index into a / b.
+
+    Minimum-cost monotone alignment (banded Needleman-Wunsch).  Both lists are in ascending-bin order, so the true alignment
+    is monotone; a point present on one side only (a bin on the 1e-14 keep-floor or on the 0 < f < fs/2 edge) is a gap.
+      pair cost = |dP| / max P  +  1e-3 r |df| / 24 kHz     (r = sqrt(P / max P): the reassigned frequency of a weak bin is noise;
+                                                             the term only breaks ties between otherwise equal alignments)
+      gap cost  = P / max P + 1e-9   (the constant keeps floor-level bins with noisy frequencies paired rather than dropped)
+    Exact pairs cost ~0, so whenever the lists agree up to a few floor-level orphans that alignment wins; a greedy merge
+    (the first version) could slip by one entry behind such an orphan and then "pair" neighbours whose powers happen to lie
+    within the tolerance of each other."""
+    n, m = len(a), len(b)
+    if n == 0 or m == 0:
+        return [], list(range(n)), list(range(m))
+    inv = 1.0 / max_power
+    pa = [float(x) * inv for x in a[:, 2]]
+    pb = [float(x) * inv for x in b[:, 2]]
+    fa = [float(x) / 24000.0 for x in a[:, 1]]
+    fb = [float(x) / 24000.0 for x in b[:, 1]]
+    band = abs(n - m) + band_extra
+    INF = float("inf")
+    width = 2 * band + 1
+    # dp[i][k]: best cost aligning a[:i] with b[:j], j = i + k - band
+    prev = [INF] * width
+    back = []
+    for k in range(width):
+        j = k - band
+        if 0 <= j <= m:
+            prev[k] = sum(pb[:j]) + 1e-9 * j
+    back.append([2] * width)  # row 0: only gaps in b
+    for i in range(1, n + 1):
+        cur = [INF] * width
+        bk = [0] * width
+        ai_p, ai_f = pa[i - 1], fa[i - 1]
+        gap_a = ai_p + 1e-9
+        for k in range(width):
+            j = i + k - band
+            if j < 0 or j > m:
+                continue
+            best, how = INF, 0
+            # gap in b's favour: a[i-1] unmatched -> from (i-1, j): k + 1 in the previous row
+            if k + 1 < width and prev[k + 1] < INF:
+                c = prev[k + 1] + gap_a
+                if c < best:
+                    best, how = c, 1
+            if j >= 1:
+                # pair a[i-1], b[j-1]: from (i-1, j-1): same k in the previous row
+                if prev[k] < INF:
+                    bp = pb[j - 1]
+                    r = (ai_p if ai_p > bp else bp) ** 0.5
+                    c = prev[k] + abs(ai_p - bp) + 1e-3 * r * abs(ai_f - fb[j - 1])
+                    if c < best:
+                        best, how = c, 3
+                # b[j-1] unmatched: from (i, j-1): k - 1 in the current row
+                if k >= 1 and cur[k - 1] < INF:
+                    c = cur[k - 1] + pb[j - 1] + 1e-9
+                    if c < best:
+                        best, how = c, 2
+            cur[k], bk[k] = best, how
+        back.append(bk)
+        prev = cur
     pairs, oa, ob = [], [], []
-    tol_abs = 1e-5 * max_power
-
-    def shifted_pairing_is_clearly_better(i, j):
-        """Weak points all 'agree' in power, so a floor-level orphan can slip the merge by one bin without being noticed
-        (bins are 3 Hz apart at 16384 points).  If skipping one entry on either side brings the frequencies at least 4x
-        closer, the current pair is a slip."""
-        d0 = abs(a[i, 1] - b[j, 1])
-        if d0 == 0.0 or (len(a) - i) == (len(b) - j):   # nothing left to re-synchronise: the rest pairs one to one
-            return None
-        if len(b) - j > len(a) - i and j + 1 < len(b) and abs(a[i, 1] - b[j + 1, 1]) < 0.25 * d0 and abs(a[i, 2] - b[j + 1, 2]) <= tol_abs + 2e-3 * min(a[i, 2], b[j + 1, 2]):
-            return (0, 1)
-        if len(a) - i > len(b) - j and i + 1 < len(a) and abs(a[i + 1, 1] - b[j, 1]) < 0.25 * d0 and abs(a[i + 1, 2] - b[j, 2]) <= tol_abs + 2e-3 * min(a[i + 1, 2], b[j, 2]):
-            return (1, 0)
-        return None
-
-    while i < len(a) and j < len(b):
-        pa, pb = a[i, 2], b[j, 2]
-        if abs(pa - pb) <= tol_abs + 2e-3 * min(pa, pb) and abs(a[i, 1] - b[j, 1]) <= max(50.0, 0.02 * abs(b[j, 1])):
-            slip = shifted_pairing_is_clearly_better(i, j) if max(pa, pb) < 1e-6 * max_power else None
-            if slip is None:
-                pairs.append((i, j))
-                i += 1
-                j += 1
-            else:
-                oa.extend(range(i, i + slip[0]))
-                ob.extend(range(j, j + slip[1]))
-                i += slip[0]
-                j += slip[1]
-            continue
-        # look ahead a few entries for a re-synchronisation point
-        found = None
-        for da in range(0, 4):
-            for db in range(0, 4):
-                if da == db == 0 or i + da >= len(a) or j + db >= len(b):
-                    continue
-                qa, qb = a[i + da, 2], b[j + db, 2]
-                if abs(qa - qb) <= tol_abs + 2e-3 * min(qa, qb) and abs(a[i + da, 1] - b[j + db, 1]) <= max(
-                        50.0, 0.02 * abs(b[j + db, 1])):
-                    found = (da, db)
-                    break
-            if found:
-                break
-        if not found:
-            found = (1, 1)
-        oa.extend(range(i, i + found[0]))
-        ob.extend(range(j, j + found[1]))
-        i += found[0]
-        j += found[1]
-    oa.extend(range(i, len(a)))
-    ob.extend(range(j, len(b)))
+    i, j = n, m
+    while i > 0 or j > 0:
+        k = j - i + band
+        how = back[i][k] if i > 0 else 2
+        if how == 3:
+            pairs.append((i - 1, j - 1))
+            i -= 1
+            j -= 1
+        elif how == 1:
+            oa.append(i - 1)
+            i -= 1
+        else:
+            ob.append(j - 1)
+            j -= 1
+    pairs.reverse()
+    oa.reverse()
+    ob.reverse()
     return pairs, oa, ob
 
 
