@@ -2,7 +2,7 @@
 
 Reassigned columns are variable-length, ascending-bin lists of (time_offset, freq_hz, power) with no
 bin index, and a bin sitting on the 1e-14 analysis floor or on the 0 < f < fs/2 edge may appear in
-one list only.  `align_points` walks both lists like a merge: points whose power agrees are paired;
+one list only.  `align_points` finds the minimum-cost monotone alignment of the two lists: points whose power agrees are paired;
 anything else is an orphan and must be weak (checked by the caller).  All errors are normalised the
 way SURVEY §7 defines "1e-5 relative": against the column's maximum, not per-bin.
 """
