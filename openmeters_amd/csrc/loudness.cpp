@@ -111,6 +111,7 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
         const size_t n = (size_t)n_streams_ * frames * channels;
         staging_.reserve(n);
         OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
         d_pcm = staging_.ptr;
     }
     snapshots_.reserve((size_t)(n_streams_ * n_blocks));

@@ -134,6 +134,7 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
         const size_t n = (size_t)n_streams_ * total * channels;
         staging_.reserve(n);
         OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
         d_pcm = staging_.ptr;
     }
     correlations_.reserve((size_t)(n_streams_ * n_blocks * 4));
@@ -166,6 +167,7 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
 
     // deque lengths per block (:116, :129, :146-150): produced iff the full-band history is full
     produced_host_.assign((size_t)n_blocks, 0);
+    const uint64_t len_before = hist_len_[0];
     for (uint64_t blk = 0; blk < n_blocks; ++blk) {
         hist_len_[0] = std::min<uint64_t>(hist_len_[0] + block_frames, frames);
         if (cfg_.analyze_bands && cfg_.emit_band_points)
@@ -175,12 +177,11 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
     hist_pos_[0] += total;
     if (cfg_.analyze_bands && cfg_.emit_band_points)
         for (int b = 1; b < 4; ++b) hist_pos_[b] += total;
-    std::vector<uint32_t> flat((size_t)(n_streams_ * n_blocks));
-    for (uint32_t s = 0; s < n_streams_; ++s)
-        for (uint64_t blk = 0; blk < n_blocks; ++blk) flat[s * n_blocks + blk] = produced_host_[blk];
-    produced_.reserve(flat.size());
-    OMX_HIP(hipMemcpyAsync(produced_.ptr, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    OMX_HIP(hipStreamSynchronize(stream));  // `flat` is a stack temporary
+    produced_.reserve((size_t)(n_streams_ * n_blocks));
+    // the per-block "history full" flags follow from three scalars: written by a kernel, so the call stays asynchronous (a host
+    // staging copy had to be synchronised before returning, which serialised the caller's other streams behind this bank)
+    launch_stereometer_produced(produced_.ptr, n_streams_, (uint32_t)n_blocks, len_before, (uint32_t)block_frames, frames, stream);
+    OMX_HIP(hipGetLastError());
 
     const uint32_t target = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cfg_.target_sample_count, 1), frames);  // :152
     last_target_ = target;

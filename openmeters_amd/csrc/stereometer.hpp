@@ -36,6 +36,8 @@ void launch_stereometer(const StereometerArgs& a, hipStream_t stream);
 // points[s][band][i] = history pair (oldest + i*frames/target), band points scaled by 0.8 (:152-170)
 void launch_stereometer_rehome(const float* from, float* to, uint32_t n_streams, uint32_t from_frames, uint32_t to_frames,
                                const uint64_t hist_pos[4], const uint64_t keep[4], hipStream_t stream);
+void launch_stereometer_produced(uint32_t* out, uint32_t n_streams, uint32_t n_blocks, uint64_t len_before, uint32_t block_frames,
+                                 uint32_t frames, hipStream_t stream);
 void launch_stereometer_points(const float* history, uint32_t n_streams, uint32_t hist_frames, const uint64_t hist_pos[4],
                                const uint32_t band_valid[4], uint32_t target, float* points, hipStream_t stream);
 

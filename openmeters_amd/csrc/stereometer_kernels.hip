@@ -367,4 +367,21 @@ void launch_stereometer_rehome(const float* from, float* to, uint32_t n_streams,
     hipLaunchKernelGGL(stereometer_rehome_kernel, dim3((uint32_t)((most + 255) / 256), 4, n_streams), dim3(256), 0, stream, a);
 }
 
+// produced[s][blk] = the full-band deque holds `frames` pairs after block blk (:116, :129, :146-150); identical for every stream
+__global__ void stereometer_produced_kernel(uint32_t* out, uint32_t n_streams, uint32_t n_blocks, uint64_t len_before,
+                                            uint32_t block_frames, uint32_t frames) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)n_streams * n_blocks) return;
+    const uint64_t blk = i % n_blocks;
+    const uint64_t len = len_before + (blk + 1) * (uint64_t)block_frames;  // the deque is trimmed to `frames`, never below it
+    out[i] = len >= frames ? 1u : 0u;
+}
+void launch_stereometer_produced(uint32_t* out, uint32_t n_streams, uint32_t n_blocks, uint64_t len_before, uint32_t block_frames,
+                                 uint32_t frames, hipStream_t stream) {
+    const uint64_t n = (uint64_t)n_streams * n_blocks;
+    if (n == 0) return;
+    hipLaunchKernelGGL(stereometer_produced_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, out, n_streams, n_blocks,
+                       len_before, block_frames, frames);
+}
+
 }  // namespace omx

@@ -127,6 +127,7 @@ int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         const size_t n = (size_t)n_streams_ * frames * channels;
         staging_.reserve(n);
         OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
         d_pcm = staging_.ptr;
     }
     const float progress = (float)std::min(std::max(phase, 0.0), 1.0);  // preview (:300-306)
