@@ -296,7 +296,10 @@ __global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
 // (its KBN pair, its expiring-value reads, its fields of the snapshot); window 0 — the longest, cap == ring length — also
 // stores the new values to the ring right after it has read the expiring ones, exactly like lane 0 of the lane-quad form.
 // No wavefront executes another role's instructions, so the per-sample cost is the window's (3 KBN adds), not the sum of
-// filter + window + interpolator.  True peak runs in separate workgroups (MODE 2 of loudness_body).  Every per-window
+// filter + window + interpolator.  (Five wavefronts on a CU's four SIMDs: one SIMD carries two of them, K-weighting 28 + a
+// window's 34 VALU per sample, and paces the workgroup — the meter workgroups alone take the whole 2.5 ms of the launch, the
+// true-peak ones 1.2 ms.  Packing two channel groups into one workgroup makes that worse (3.6 ms): the 128 workgroups already
+// have a CU each.)  True peak runs in separate workgroups (MODE 2 of loudness_body).  Every per-window
 // recurrence is still strictly sequential in time: results are bit-identical to the lane-quad form.
 // Workgroup barrier for data handed over through LDS only: waits for this wavefront's LDS traffic, not for its outstanding
 // global loads (__syncthreads would drain the expiring-value prefetches of the window wavefronts at every round).
@@ -448,9 +451,14 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
     const bool store_wave = __builtin_amdgcn_readfirstlane((int)(r == 0)) != 0;
     auto consume_as = [&](auto store_c, auto refresh_c, const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub) {
         constexpr bool STORE = decltype(store_c)::value, REFRESH = decltype(refresh_c)::value;
+        // all B values of the batch in one burst of LDS reads (read-per-sample exposed the LDS latency at every sample)
+        double batch[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) batch[k] = vals[buf][sub * B + k][lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-            const double value = vals[buf][sub * B + k][lane];
+            const double value = batch[k];
             const double expiring = (live && (uint32_t)k >= first_valid) ? old[k] : 0.0;
             kbn_add(sum0, cor0, value);
             kbn_add(sum1, cor1, value);
