@@ -34,6 +34,7 @@ struct View {  // a contiguous logical slice of a trace ring
 };
 
 struct Shared {
+    float redn[4][6];  // block_sum_n: [wave][component]
     float redf[8];
     unsigned long long redu[8];
     float f[8];
@@ -59,6 +60,30 @@ __device__ float block_max(float v, Shared& sh) {
     if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmaxf(fmaxf(sh.redf[0], sh.redf[1]), fmaxf(sh.redf[2], sh.redf[3]));
+}
+// K sums in one barrier pair; every component is reduced exactly like block_sum (same shuffle tree, same wave order), so
+// fusing several block_sum calls into one changes no bit.  MAX_LAST: the last component is a maximum instead of a sum.
+template <int K, bool MAX_LAST = false>
+__device__ void block_sum_n(float (&v)[K], Shared& sh) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_xor(v[k], off);
+            v[k] = (MAX_LAST && k == K - 1) ? fmaxf(v[k], o) : v[k] + o;
+        }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sh.redn[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (MAX_LAST && k == K - 1) v[k] = fmaxf(fmaxf(sh.redn[0][k], sh.redn[1][k]), fmaxf(sh.redn[2][k], sh.redn[3][k]));
+        else v[k] = ((sh.redn[0][k] + sh.redn[1][k]) + sh.redn[2][k]) + sh.redn[3][k];
+    }
 }
 __device__ unsigned long long block_max_u64(unsigned long long v, Shared& sh) {
 #pragma unroll
@@ -272,8 +297,15 @@ __device__ Estimate estimate_period(const View& x, float rate, float& last_peak,
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const uint32_t m = (uint32_t)(j + 256 * t);
-            const float re = 2u * m < n ? xs(2u * m) - mean : 0.0f;
-            const float im = 2u * m + 1u < n ? xs(2u * m + 1u) - mean : 0.0f;
+            float re, im;
+            if (staged) {  // one 8-byte LDS read (the staging area covers 2m + 1 <= 8191; what lies beyond n is selected away)
+                const v2f pair = *reinterpret_cast<const v2f*>(stage + 2u * m);
+                re = 2u * m < n ? pair.x - mean : 0.0f;
+                im = 2u * m + 1u < n ? pair.y - mean : 0.0f;
+            } else {
+                re = 2u * m < n ? x.at(2u * m) - mean : 0.0f;
+                im = 2u * m + 1u < n ? x.at(2u * m + 1u) - mean : 0.0f;
+            }
             v[t] = v2f{re, im};
         }
         if (staged) __syncthreads();  // every thread has taken its samples out of the staging area the first pass overwrites
@@ -430,17 +462,10 @@ __device__ void correlation_stats(const float* y, uint32_t n, float& sum, float&
         s += y[i];
         q += y[i] * y[i];
     }
-    sum = block_sum(s, sh);
-    squares = block_sum(q, sh);
-}
-
-__device__ void normalize_peak(float* data, uint32_t n, Shared& sh) {  // :191-197
-    float pk = 0.0f;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) pk = fmaxf(pk, fabsf(data[i]));
-    pk = block_max(pk, sh);
-    const float scale = 1.0f / fmaxf(pk, NORMALIZE_FLOOR);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) data[i] *= scale;
-    __syncthreads();
+    float v[2] = {s, q};
+    block_sum_n<2>(v, sh);
+    sum = v[0];
+    squares = v[1];
 }
 
 // prepare_template (:422-439)
@@ -448,15 +473,16 @@ __device__ void prepare_template(float* candidate, const float* reference, uint3
     const uint32_t midpoint = len / 2;
     const float max_width = fmaxf((float)max(midpoint, 1u) / 3.0f, 1.0f);
     const float width = rclamp(SLOPE_WIDTH_PERIODS * period, 1.0f, max_width);
-    for (uint32_t i = threadIdx.x; i < (len + 1) / 2; i += 256) {
-        const uint32_t mirror = len - 1 - i;
-        const float weight = gaussian(len, i, width);
-        candidate[i] = -0.5f * EDGE_STRENGTH * 2.0f * weight;
-        candidate[mirror] = 0.5f * EDGE_STRENGTH * 2.0f * weight;
+    // the reference writes -g(i) at i and +g(i) at the mirror index for i < (len + 1) / 2 (the middle element of an odd length
+    // ends up +g), then adds the learnt reference: element-wise here, one pass
+    for (uint32_t e = threadIdx.x; e < len; e += 256) {
+        const uint32_t mirror = len - 1 - e;
+        const bool lower = e < (len + 1) / 2 && mirror != e;
+        const float weight = gaussian(len, lower ? e : mirror, width);
+        float v = lower ? -0.5f * EDGE_STRENGTH * 2.0f * weight : 0.5f * EDGE_STRENGTH * 2.0f * weight;
+        if (use_reference) v += reference[e];
+        candidate[e] = v;
     }
-    __syncthreads();
-    if (use_reference)
-        for (uint32_t i = threadIdx.x; i < len; i += 256) candidate[i] += reference[i];
     __syncthreads();
 }
 
@@ -538,35 +564,38 @@ __device__ void find_best(float* scores, const float* work, const float* tmpl, u
 // write_candidate (:509-527): candidate = windowed, peak-normalised, mean-removed segment; returns the
 // correlation with the reference.
 __device__ float write_candidate(float* candidate, const float* reference, const View& seg, float period, Shared& sh) {
+    // same arithmetic per element as mean-remove / normalize_peak / window / correlation_stats / normalized_correlation run one
+    // after the other (seven workgroup reductions and as many passes): fused into three passes and three reductions
     const uint32_t n = seg.n;
     float part = 0.0f;
     for (uint32_t i = threadIdx.x; i < n; i += 256) part += seg.at(i);
     const float mean = block_sum(part, sh) / (float)max(n, 1u);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) candidate[i] = seg.at(i) - mean;
-    __syncthreads();
-    normalize_peak(candidate, n, sh);
-    const float std_ = fmaxf(period * BUFFER_FALLOFF_PERIODS, 1.0f);
-    for (uint32_t i = threadIdx.x; i < (n + 1) / 2; i += 256) {
-        const uint32_t mirror = n - 1 - i;
-        const float weight = gaussian(n, i, std_);
-        candidate[i] *= weight;
-        if (mirror != i) candidate[mirror] *= weight;
-    }
-    __syncthreads();
-    float sum_y, sum_yy;
-    correlation_stats(candidate, n, sum_y, sum_yy, sh);
-    // normalized_correlation(reference, candidate) across the whole workgroup
-    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
+    float pk = 0.0f;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const float xv = reference[i], yv = candidate[i];
-        sx += xv;
-        sxx += xv * xv;
-        sxy += xv * yv;
+        const float c = seg.at(i) - mean;
+        candidate[i] = c;
+        pk = fmaxf(pk, fabsf(c));
     }
-    sx = block_sum(sx, sh);
-    sxx = block_sum(sxx, sh);
-    sxy = block_sum(sxy, sh);
+    pk = block_max(pk, sh);
+    const float scale = 1.0f / fmaxf(pk, NORMALIZE_FLOOR);  // normalize_peak (:191-197)
+    const float std_ = fmaxf(period * BUFFER_FALLOFF_PERIODS, 1.0f);
+    float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // sum y, sum y^2, sum x, sum x^2, sum x y
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t mirror = n - 1 - i;
+        const float weight = gaussian(n, i < (n + 1) / 2 ? i : mirror, std_);
+        float yv = candidate[i] * scale;
+        yv *= weight;
+        candidate[i] = yv;
+        const float xv = reference[i];
+        acc[0] += yv;
+        acc[1] += yv * yv;
+        acc[2] += xv;
+        acc[3] += xv * xv;
+        acc[4] += xv * yv;
+    }
+    block_sum_n<5>(acc, sh);  // its barriers also publish candidate[]
     if (n == 0) return 0.0f;
+    const float sum_y = acc[0], sum_yy = acc[1], sx = acc[2], sxx = acc[3], sxy = acc[4];
     const float nf = (float)n;
     const float dot = sxy - sx * sum_y / nf;
     const float ex = fmaxf(sxx - sx * sx / nf, 0.0f);
@@ -615,17 +644,15 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
         }
     }
     __syncthreads();
-    float part = 0.0f;
-    for (uint32_t i = threadIdx.x; i < data.n; i += 256) part += data.at(i);
-    const float mean = block_sum(part, sh) / (float)max(data.n, 1u);
+    float red[2] = {0.0f, 0.0f};  // sum of the search span, peak of the reference: one reduction
+    for (uint32_t i = threadIdx.x; i < data.n; i += 256) red[0] += data.at(i);
+    for (uint32_t i = threadIdx.x; i < len; i += 256) red[1] = fmaxf(red[1], fabsf(reference[i]));
+    block_sum_n<2, true>(red, sh);
+    const float mean = red[0] / (float)max(data.n, 1u);
     t.mean += MEAN_RESPONSIVENESS * (mean - t.mean);
     for (uint32_t i = threadIdx.x; i < data.n; i += 256) sc.work[i] = data.at(i) - t.mean;
-    __syncthreads();
-
-    float refpk = 0.0f;
-    for (uint32_t i = threadIdx.x; i < len; i += 256) refpk = fmaxf(refpk, fabsf(reference[i]));
-    const bool use_reference = block_max(refpk, sh) > 1.0e-3f;  // any(|sample| > 1e-3) (:381)
-    prepare_template(sc.candidate, reference, len, period, use_reference);
+    const bool use_reference = red[1] > 1.0e-3f;  // any(|sample| > 1e-3) (:381)
+    prepare_template(sc.candidate, reference, len, period, use_reference);  // ends with the barrier that also publishes work[]
     uint32_t offset;
     float frac_offset;
     find_best(sc.scores, sc.work, sc.candidate, len, search, period, offset, frac_offset, sh);
@@ -647,8 +674,15 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
         if (!use_reference || reset || !candidate_written)
             write_candidate(sc.candidate, reference, trace.sub(left + offset - before, len), period, sh);
         // update_reference (:500-507)
-        normalize_peak(reference, len, sh);
-        for (uint32_t i = threadIdx.x; i < len; i += 256) reference[i] += BUFFER_RESPONSIVENESS * (sc.candidate[i] - reference[i]);
+        float rpk = 0.0f;
+        for (uint32_t i = threadIdx.x; i < len; i += 256) rpk = fmaxf(rpk, fabsf(reference[i]));
+        rpk = block_max(rpk, sh);
+        const float rscale = 1.0f / fmaxf(rpk, NORMALIZE_FLOOR);  // normalize_peak (:191-197), then the EMA, in one pass
+        for (uint32_t i = threadIdx.x; i < len; i += 256) {
+            float rv = reference[i] * rscale;
+            rv += BUFFER_RESPONSIVENESS * (sc.candidate[i] - rv);
+            reference[i] = rv;
+        }
         t.reference_period += BUFFER_RESPONSIVENESS * (period - t.reference_period);
         __syncthreads();
     }
