@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     }
     if constexpr (V::TW2_LDS) {
         tw2_lds[j] = a.tw256[ju];
-        __syncthreads();
+        // no barrier of its own: the table is first read in pass 2 of the first transform, behind that transform's pass-1
+        // barrier — a barrier here would put the twiddle loads and the ring loads of the window in two serial round trips
+        if constexpr (V::COLS_PER_WG > 1 || !V::PINGPONG) __syncthreads();
     }
 
     long long phase_t = 0;
