@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[4096] / 2
         }
         __syncthreads();
+        mark(8);  // (sub-phase) natural-order write of the forward spectrum + barrier
         v2f y[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -493,7 +494,9 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             masks[t] = __ballot(keep);
             if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
         }
+        mark(9);   // (sub-phase) reassignment arithmetic + ballots
         __syncthreads();
+        mark(10);  // (sub-phase) barrier behind the wave counts
         omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
         // all 36 wave counts first (nine 16-byte LDS reads in flight together), then the stores: read-wait-store per bin row
         // exposed the LDS latency nine times

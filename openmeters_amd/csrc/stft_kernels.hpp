@@ -51,7 +51,7 @@ struct StftFastArgs {
     omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
     uint32_t* counts;               // [n_streams][n_cols]
 };
-constexpr int K2_PHASES = 8;
+constexpr int K2_PHASES = 12;
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning builds only (OMX_K2_VARIANT=7)
 void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream);
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
