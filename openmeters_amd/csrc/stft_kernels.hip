@@ -194,8 +194,12 @@ __device__ __forceinline__ bool reassign_bin_fast(uint32_t i, v2f b, v2f d, v2f 
 // Compile-time switches of the fused kernel (A/B-tested on MI355X; see DESIGN.md §4 and profiles/).
 template <uint32_t COLS, bool TW2_LDS_, bool TW3_REGS_, bool DUAL_, bool PINGPONG_, bool ONEBUF_ = false, int MINW = 2,
           bool RECOMPUTE_S_ = false, bool TWIN_CALC_ = false, bool PHASES_ = false,
-          bool EARLY_ = false, bool PHASE_WAIT_ = false, bool FAST_REASSIGN_ = false>
+          bool EARLY_ = false, bool PHASE_WAIT_ = false, bool FAST_REASSIGN_ = false,
+          int KNOCK_ = 0>
 struct K2Variant {
+    // tuning only, WRONG results: leave one stage out to price it by the kernel time that disappears (1 reassignment +
+    // compaction + stores, 2 third transform, 3 paired transforms, 4 inverse transform, 5 forward transform)
+    static constexpr int KNOCK = KNOCK_;
     static constexpr bool FAST_REASSIGN = FAST_REASSIGN_;  // branch-free reassignment with v_rcp_f32
     static constexpr bool PHASE_WAIT = PHASE_WAIT_;  // tuning build: every phase mark drains vmcnt / lgkmcnt first
     static constexpr bool EARLY = EARLY_;          // table / ring loads issued one transform ahead of their use (needs DUAL)
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         }
         if constexpr (V::PHASES) __syncthreads();
         mark(0);  // setup + window load
-        fft4096t<false, V::PINGPONG>(v, A, B, j, tw);  // v[t] = Zf[j + 256 t]; last read: B (pingpong) or A
+        if constexpr (V::KNOCK != 5) fft4096t<false, V::PINGPONG>(v, A, B, j, tw);  // v[t] = Zf[j + 256 t]; last read: B (pingpong) or A
         mark(1);  // forward packed FFT
 
         // ---- 2. Hilbert transform with ONE half-length inverse ----------------------------------------
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             }
         }
         mark(2);  // Hilbert spectrum build
-        fft4096t<true, V::PINGPONG>(y, Y, X, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
+        if constexpr (V::KNOCK != 4) fft4096t<true, V::PINGPONG>(y, Y, X, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
         mark(3);  // inverse FFT
 
         // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t ---------------------------------------
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
                 }
             }
             mark(4);  // analytic gather + windowing
-            fft4096t_dual<false>(vb, vd, A, B, j, tw);
+            if constexpr (V::KNOCK != 3) fft4096t_dual<false>(vb, vd, A, B, j, tw);
             mark(5);  // dual FFT
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
                 for (int t = 0; t < 9; ++t) pn[t] = bnorm[(t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u];  // in flight during the third transform
             }
             __syncthreads();  // the dual transform's last pass still reads A and B
-            fft4096t<false, V::PINGPONG>(vt, A, B, j, tw);
+            if constexpr (V::KNOCK != 2) fft4096t<false, V::PINGPONG>(vt, A, B, j, tw);
             mark(6);  // time-weighted FFT
 #pragma unroll
             for (int t = 0; t < 9; ++t) bt[t] = vt[t];
@@ -480,6 +484,14 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         }
 
         // ---- 4. reassignment + ordered compaction -------------------------------------------------------
+        if constexpr (V::KNOCK == 1) {  // keep the transforms alive: one checksum word per thread instead of the points
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += bb[t].x + bd[t].y + bt[t].x + pn[t];
+            reinterpret_cast<float*>(a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride)[j] = acc;
+            if (j == 0) *count_out = 0;
+            continue;
+        }
         omx_spectrogram_point pts[9];
         unsigned long long masks[9];
 #pragma unroll
@@ -710,6 +722,11 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
         case 20: launch_k2_wave(a, stream); break;  // one wavefront per frame
         case 9: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true>>(a, stream); break;
+        case 41: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 1>>(a, stream); break;
+        case 42: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 2>>(a, stream); break;
+        case 43: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 3>>(a, stream); break;
+        case 44: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 4>>(a, stream); break;
+        case 45: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 5>>(a, stream); break;
         case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); break;
         case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); break;
         case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); break;
