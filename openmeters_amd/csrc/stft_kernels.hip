@@ -231,6 +231,10 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     const uint32_t chunks = (a.n_cols + V::COLS_PER_WG - 1) / V::COLS_PER_WG;
     uint32_t s, chunk;
     if (!block_to_stream_column(a.n_streams, chunks, s, chunk)) return;
+    if constexpr (V::KNOCK == 6) {  // empty workgroups: dispatch + LDS / register allocation cost of the launch shape
+        if (threadIdx.x == 0 && s == 0xFFFFFFFFu) a.counts[0] = 0;
+        return;
+    }
     const int j = threadIdx.x;
     const unsigned ju = threadIdx.x;  // unsigned 32-bit indices let global accesses use the SGPR-base + VGPR-offset form
     const float* ring = a.ring + (uint64_t)s * a.cap;
@@ -727,6 +731,7 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 43: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 3>>(a, stream); break;
         case 44: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 4>>(a, stream); break;
         case 45: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 5>>(a, stream); break;
+        case 46: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 6>>(a, stream); break;
         case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); break;
         case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); break;
         case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); break;
