@@ -330,8 +330,10 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         v2f* X = (V::PINGPONG || V::ONEBUF) ? A : B;  // exchange buffer
         v2f* Y = V::PINGPONG ? B : A;
         if constexpr (!V::PINGPONG) __syncthreads();
+        if constexpr (V::KNOCK != 7) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = v[t];
+        }
         if (j == 0) {
             hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
             hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[4096] / 2
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         for (int t = 0; t < 16; ++t) {
             const unsigned k = (unsigned)(j + 256 * t);
             const v2f z = v[t];
-            const v2f zr = X[pad16((int)((4096u - k) & 4095u))];
+            const v2f zr = V::KNOCK == 7 ? z : X[pad16((int)((4096u - k) & 4095u))];
             const v2f sum{z.x + zr.x, z.y - zr.y};   // Zf[k] + conj Zf[N-k]  (the 1/2 lives in the twiddle table)
             const v2f dif{z.x - zr.x, z.y + zr.y};   // Zf[k] - conj Zf[N-k]
             const v2f w = V::EARLY ? w8[t] : tw8192[k];
@@ -359,6 +361,12 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             const uint32_t qe = p32 + 2048u + ju;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
+                if constexpr (V::KNOCK == 9) {
+                    pw[t] = 0.5f + (float)t;
+                    pdw[t] = 0.25f - (float)t;
+                    pxr[t] = v[t].x;
+                    continue;
+                }
                 pw[t] = win[ju + 256u * (unsigned)t];
                 pdw[t] = dwin[ju + 256u * (unsigned)t];
                 pxr[t] = *reinterpret_cast<const float*>(ring_bytes + (((qe + 256u * (unsigned)t) << 2) & bytemask));
@@ -371,14 +379,16 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
         // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t ---------------------------------------
         // ping-pong: the inverse read X (= A) last, so Y (= B) is free; in place: it read Y (= A) last, X (= B) is free
         float* imag = reinterpret_cast<float*>(B);
+        if constexpr (V::KNOCK != 8) {
 #pragma unroll
         for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + 256 * t - 1024)) = y[t];
         __syncthreads();
+        }
         const float parity = (j & 1) ? -half_xn : half_xn;  // (-1)^n, n = 2048 + i has the parity of j
         const uint32_t q0 = p32 + 2048u + ju;
         auto analytic = [&](int t) -> v2f {  // s[j + 256 t]
             const float xr = V::EARLY ? pxr[t] : ring[(q0 + 256u * (unsigned)t) & mask32];
-            return v2f{4096.0f * xr - half_x0 + parity, imag[j + 256 * t]};
+            return v2f{4096.0f * xr - half_x0 + parity, V::KNOCK == 8 ? y[t].x + y[t].y : imag[j + 256 * t]};
         };
         v2f bb[9], bd[9], bt[9];
         float pn[9];  // EARLY: bin normalisation
@@ -731,6 +741,9 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
         case 43: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 3>>(a, stream); break;
         case 44: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 4>>(a, stream); break;
         case 45: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 5>>(a, stream); break;
+        case 47: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 7>>(a, stream); break;
+        case 48: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 8>>(a, stream); break;
+        case 49: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 9>>(a, stream); break;
         case 46: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 6>>(a, stream); break;
         case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); break;
         case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); break;
