@@ -93,7 +93,12 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
     if (cfg_.trigger_source == OMX_CHANNEL_NONE) len_[2] = 0;
 
     // ---- device buffers
-    const uint64_t cap = next_pow2((uint64_t)history_frames + std::max<uint64_t>(block_frames, 4096));
+    // two-pass form (period estimates of every block in parallel, see oscilloscope.hpp): several blocks per call in the
+    // stable-trigger steady state; the rings then hold the history plus the whole call
+    const uint64_t total_frames = block_frames * n_blocks;
+    const bool two_pass_shape = n_blocks >= 4 && cfg_.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && total_frames <= (1ull << 22);
+    const uint64_t cap = std::max<uint64_t>(  // never shrinks: call shapes may alternate
+        cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(two_pass_shape ? total_frames : block_frames, 4096)));
     if (cap != cap_ || !rings_.ptr) {
         DeviceBuffer<float> bigger;
         bigger.reserve((size_t)(cap * kScopeTraces * n_streams_));
@@ -197,7 +202,14 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
         return e && atoi(e) != 0;
     }();
     sa.phase_timing = phase_timing ? 1u : 0u;
-    launch_oscilloscope(sa, stream);
+    sa.estimates = nullptr;
+    if (two_pass_shape && sa.lds_scratch && fast_acf) {
+        estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
+        sa.estimates = estimates_.ptr;
+        launch_oscilloscope_two_pass(sa, stream);
+    } else {
+        launch_oscilloscope(sa, stream);
+    }
     OMX_HIP(hipGetLastError());
 
     for (int t = 0; t < kScopeTraces; ++t) {  // same bookkeeping as the kernel (:673-681)

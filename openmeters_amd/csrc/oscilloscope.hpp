@@ -29,6 +29,11 @@ struct ScopeBlockHeader {   // per (stream, block) snapshot header
     uint32_t _pad;
 };
 
+struct ScopeEstimate {      // PeriodEstimator::estimate_period result for one (stream, block, view), computed ahead of the trigger pass
+    int some;
+    float period, confidence, last_peak;
+};
+
 struct ScopeArgs {
     const float* pcm;       // [n_streams][frames_total][channels]
     uint64_t frames_total;
@@ -62,11 +67,16 @@ struct ScopeArgs {
     float* samples;         // [n_streams][2][kScopeTarget] snapshot of the newest block
     uint32_t phase_timing;  // tuning aid: accumulate per-phase cycles (OMX_SCOPE_PHASES=1)
     uint32_t lds_scratch;   // hot scratch arrays in LDS (fast 8192 configuration whose two phase layouts fit 150 KiB)
+    // two-pass form (many blocks per call): every block is pushed into the rings first (cap >= history + frames of the call),
+    // the period estimates — a pure function of the trace — are computed for all (stream, block, view) in parallel, and the
+    // per-stream kernel only runs the stateful part (stabilise / locate / snapshot) block after block
+    ScopeEstimate* estimates;    // [n_streams][n_blocks][kScopeTraces] or nullptr (single-pass form)
 };
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
 constexpr int SCOPE_PHASES = 6;
 void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
+void launch_oscilloscope_two_pass(const ScopeArgs& a, hipStream_t stream);  // a.estimates != nullptr
 uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search, uint32_t probe_frames, uint32_t max_period);
 
 void oscilloscope_config_default(omx_oscilloscope_config* c);
@@ -105,6 +115,7 @@ private:
     DeviceBuffer<float> rings_, reference_, scratch_, samples_, staging_, tw_fft_, fft_global_, tw256_, tw4096_;
     DeviceBuffer<ScopeTriggerState> trig_;
     DeviceBuffer<ScopeBlockHeader> headers_;
+    DeviceBuffer<ScopeEstimate> estimates_;
     hipStream_t last_stream_ = nullptr;
 };
 

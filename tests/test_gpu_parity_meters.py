@@ -344,3 +344,37 @@ def test_stereometer_non_finite_samples_reset_the_filters_like_the_reference(omx
             both_nan = np.isnan(gp) & np.isnan(wp)
             assert np.array_equal(gp.view(np.uint32)[~both_nan], wp.view(np.uint32)[~both_nan]), (k, band)
     assert seen >= 10
+
+
+def test_oscilloscope_two_pass_form_equals_block_by_block_calls(omx):
+    """Calls with >= 4 blocks push every block first, estimate the periods of all (stream, block) in parallel and then run the
+    stateful trigger pass; calls with fewer blocks do everything in one kernel.  Same functions on the same samples: headers and
+    the newest snapshot must be BIT-identical, whatever mix of call shapes fed the bank (the ring grows on the first long call)."""
+    S, blocks = 5, 48
+    pcm = np.stack([cfg4_pcm(s + 3, 256 * blocks) for s in range(S)])
+    a, b, c = (banks.OscilloscopeBank(omx, scope_cfg(), S) for _ in range(3))
+    hdr_a, hdr_b, hdr_c = [], [], []
+
+    def headers(bank, n):
+        return [[tuple(bytes(bank.fetch(s, k)[0])) for s in range(S)] for k in range(n)]
+
+    a.process_host(pcm, 256, 2, FS)                                   # one long call: two-pass
+    hdr_a = headers(a, blocks)
+    for k in range(blocks):                                           # block by block: single pass
+        b.process_host(pcm[:, k * 256:(k + 1) * 256], 256, 2, FS)
+        hdr_b += headers(b, 1)
+    k = 0
+    for n in (2, 10, 1, 3, 20, 12):                                   # mixed shapes
+        c.process_host(pcm[:, k * 256:(k + n) * 256], 256, 2, FS)
+        hdr_c += headers(c, n)
+        k += n
+    assert k == blocks and hdr_a == hdr_b == hdr_c
+    for s in range(S):
+        ha, sa = a.fetch(s, blocks - 1, with_samples=True)
+        hb, sb = b.fetch(s, 0, with_samples=True)
+        hc, sc = c.fetch(s, 11, with_samples=True)
+        n = ha.samples_per_channel
+        assert ha.produced and n == hb.samples_per_channel == hc.samples_per_channel
+        for ch in range(ha.channels):   # what lies beyond samples_per_channel is not part of the snapshot
+            assert np.array_equal(sa[ch, :n].view(np.uint32), sb[ch, :n].view(np.uint32))
+            assert np.array_equal(sa[ch, :n].view(np.uint32), sc[ch, :n].view(np.uint32))
