@@ -73,7 +73,7 @@ struct ScopeArgs {
     ScopeEstimate* estimates;    // [n_streams][n_blocks][kScopeTraces] or nullptr (single-pass form)
 };
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
-constexpr int SCOPE_PHASES = 6;
+constexpr int SCOPE_PHASES = 10;
 void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
 void launch_oscilloscope_two_pass(const ScopeArgs& a, hipStream_t stream);  // a.estimates != nullptr

@@ -487,19 +487,130 @@ __device__ void prepare_template(float* candidate, const float* reference, uint3
 }
 
 // Evaluate scores[offset] for offsets lo + k*step (k = 0..count-1); one wave per offset.
+// Up to M offsets per wavefront in ONE sweep over the template: y[i] is read once for all of them, the M accumulation chains
+// are independent (a single correlation per sweep was a dependent ds_read -> fma chain, 30 exposed LDS round trips each), and
+// every offset keeps the element order of wave_normalized_correlation — same sums, bit for bit.
+template <int M>
+__device__ void wave_correlations(float* scores, const float* work, const float* tmpl, uint32_t len, float sum_y, float sum_yy,
+                                  const uint32_t (&off)[M], int valid) {
+    const unsigned lane = threadIdx.x & 63;
+    float sx[M], sxx[M], sxy[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) sx[m] = sxx[m] = sxy[m] = 0.0f;
+    for (uint32_t i = lane; i < len; i += 64) {
+        const float yv = tmpl[i];
+        float xv[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) xv[m] = work[off[m] + i];  // invalid slots repeat a valid offset: always in bounds
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            sx[m] += xv[m];
+            sxx[m] += xv[m] * xv[m];
+            sxy[m] += xv[m] * yv;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            sx[m] += __shfl_xor(sx[m], o);
+            sxx[m] += __shfl_xor(sxx[m], o);
+            sxy[m] += __shfl_xor(sxy[m], o);
+        }
+    }
+    if (lane != 0) return;
+    const float nf = (float)len;
+    const float ey = fmaxf(sum_yy - sum_y * sum_y / nf, 0.0f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        if (m >= valid) break;
+        float v = 0.0f;
+        if (len != 0) {
+            const float dot = sxy[m] - sx[m] * sum_y / nf;
+            const float ex = fmaxf(sxx[m] - sx[m] * sx[m] / nf, 0.0f);
+            const float denom = sqrtf(ex * ey);
+            v = denom > F32_EPS ? rclamp(dot / denom, -1.0f, 1.0f) : 0.0f;
+        }
+        scores[off[m]] = v;
+    }
+}
+
+// Evaluate scores[offset] for offsets lo + k*step (k = 0..count-1); wavefront w takes k = w, w + 4, ...
 __device__ void eval_scores(float* scores, const float* work, const float* tmpl, uint32_t len, float sum_y, float sum_yy,
-                            uint32_t lo, uint32_t step, uint32_t count) {
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t k = wave; k < count; k += 4) {
-        const uint32_t off = lo + k * step;
-        const float v = wave_normalized_correlation(work + off, tmpl, len, sum_y, sum_yy);
-        if (lane == 0) scores[off] = v;
+                            uint32_t lo, uint32_t step, uint32_t count_in, bool extra_zero) {
+    const unsigned wave = threadIdx.x >> 6;
+    constexpr int M = 8;
+    const uint32_t count = count_in + (extra_zero ? 1u : 0u);  // entry `count_in` is offset 0
+    for (uint32_t k0 = wave; k0 < count; k0 += 4 * M) {
+        uint32_t off[M];
+        int valid = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t k = k0 + 4u * (uint32_t)m;
+            const uint32_t kc = k < count ? k : k0;
+            off[m] = kc < count_in ? lo + kc * step : 0u;
+            valid += k < count ? 1 : 0;
+        }
+        if (valid <= 2) {
+            const uint32_t o2[2] = {off[0], off[1]};
+            wave_correlations<2>(scores, work, tmpl, len, sum_y, sum_yy, o2, valid);
+        } else if (valid <= 4) {
+            const uint32_t o4[4] = {off[0], off[1], off[2], off[3]};
+            wave_correlations<4>(scores, work, tmpl, len, sum_y, sum_yy, o4, valid);
+        } else {
+            wave_correlations<M>(scores, work, tmpl, len, sum_y, sum_yy, off, valid);
+        }
     }
     __syncthreads();
 }
 
+// The strict-> scan of one search round (:455-470): offsets top, top - step, ... (count of them), then 0 when `extra_zero`;
+// the incumbent (bo, bs) only loses to a strictly larger score, the earliest offset in scan order wins among equals.  One
+// wavefront reads the scores in parallel and reduces (score, scan index) — the serial scan on thread 0 was 10-27 dependent LDS
+// round trips per round.
+__device__ void select_best(const float* scores, uint32_t top, uint32_t step, uint32_t count, bool extra_zero, uint32_t& bo, float& bs,
+                            Shared& sh) {
+    const uint32_t total = count + (extra_zero ? 1u : 0u);
+    if (threadIdx.x < 64) {
+        if (total <= 64) {
+            const uint32_t k = threadIdx.x;
+            const uint32_t off = k < count ? top - k * step : 0u;
+            float v = k < total ? scores[off] : NEG_INF;
+            uint32_t kk = k < total ? k : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(v, o);
+                const uint32_t ok = __shfl_xor(kk, o);
+                if (ov > v || (ov == v && ok < kk)) {
+                    v = ov;
+                    kk = ok;
+                }
+            }
+            if (threadIdx.x == 0) {
+                if (kk != 0xFFFFFFFFu && v > bs) {
+                    bo = kk < count ? top - kk * step : 0u;
+                    bs = v;
+                }
+                sh.u[0] = bo;
+                sh.f[0] = bs;
+            }
+        } else if (threadIdx.x == 0) {
+            for (uint32_t k = 0; k < total; ++k) {
+                const uint32_t off = k < count ? top - k * step : 0u;
+                if (scores[off] > bs) { bo = off; bs = scores[off]; }
+            }
+            sh.u[0] = bo;
+            sh.f[0] = bs;
+        }
+    }
+    __syncthreads();
+    bo = sh.u[0];
+    bs = sh.f[0];
+    __syncthreads();
+}
+
 // find_best (:441-484): coarse-to-fine search; the lazily filled score cache of the reference becomes
-// "evaluate the offsets of this round in parallel, then replay the strict-> scan on thread 0".
+// "evaluate the offsets of this round in parallel, then replay the strict-> scan".
 __device__ void find_best(float* scores, const float* work, const float* tmpl, uint32_t len, uint32_t search, float period,
                           uint32_t& best_off_out, float& frac_out, Shared& sh) {
     float sum_y, sum_yy;
@@ -507,26 +618,15 @@ __device__ void find_best(float* scores, const float* work, const float* tmpl, u
     uint32_t stride = f2u(roundf(period / 16.0f));
     stride = min(max(stride, 1u), 128u);
     stride = min(stride, max(search, 1u));
-    // coarse: (0..=search).rev().step_by(stride).chain([0])
+    // coarse: (0..=search).rev().step_by(stride).chain([0]) — offset 0 rides in the same sweep
     const uint32_t n_coarse = search / stride + 1;
     const uint32_t lowest = search - (n_coarse - 1) * stride;
-    eval_scores(scores, work, tmpl, len, sum_y, sum_yy, lowest, stride, n_coarse);
-    if (lowest != 0) eval_scores(scores, work, tmpl, len, sum_y, sum_yy, 0, 1, 1);
-    if (threadIdx.x == 0) {
-        uint32_t bo = search / 2;
-        float bs = NEG_INF;
-        for (uint32_t k = 0; k < n_coarse; ++k) {
-            const uint32_t off = search - k * stride;
-            if (scores[off] > bs) { bo = off; bs = scores[off]; }
-        }
-        if (scores[0] > bs) { bo = 0; bs = scores[0]; }
-        sh.u[0] = bo;
-        sh.f[0] = bs;
-    }
-    __syncthreads();
-    uint32_t best_off = sh.u[0];
-    float best_score = sh.f[0];
-    __syncthreads();
+    eval_scores(scores, work, tmpl, len, sum_y, sum_yy, lowest, stride, n_coarse, lowest != 0);
+    uint32_t best_off = search / 2;
+    float best_score = NEG_INF;
+    select_best(scores, search, stride, n_coarse, true, best_off, best_score, sh);
+    // offsets [dense_lo, dense_hi] all carry a score of THIS call (needed for the parabolic refinement below)
+    uint32_t dense_lo = stride == 1 ? 0u : 1u, dense_hi = stride == 1 ? search : 0u;
     uint32_t step = stride;
     while (step > 1) {
         const uint32_t next = max(step / 4, 1u);
@@ -534,26 +634,18 @@ __device__ void find_best(float* scores, const float* work, const float* tmpl, u
         const uint32_t hi = min(best_off + step, search);
         const uint32_t cnt = (hi - lo) / next + 1;
         const uint32_t first = hi - (cnt - 1) * next;
-        eval_scores(scores, work, tmpl, len, sum_y, sum_yy, first, next, cnt);
-        if (threadIdx.x == 0) {
-            uint32_t bo = best_off;
-            float bs = best_score;
-            for (uint32_t k = 0; k < cnt; ++k) {  // (lo..=hi).rev().step_by(next)
-                const uint32_t off = hi - k * next;
-                if (scores[off] > bs) { bo = off; bs = scores[off]; }
-            }
-            sh.u[0] = bo;
-            sh.f[0] = bs;
+        eval_scores(scores, work, tmpl, len, sum_y, sum_yy, first, next, cnt, false);
+        select_best(scores, hi, next, cnt, false, best_off, best_score, sh);  // (lo..=hi).rev().step_by(next)
+        if (next == 1) {
+            dense_lo = first;
+            dense_hi = hi;
         }
-        __syncthreads();
-        best_off = sh.u[0];
-        best_score = sh.f[0];
-        __syncthreads();
         step = next;
     }
     float frac = 0.0f;
     if (best_off > 0 && best_off < search) {
-        eval_scores(scores, work, tmpl, len, sum_y, sum_yy, best_off - 1, 2, 2);
+        if (!(best_off - 1 >= dense_lo && best_off + 1 <= dense_hi))  // the reference's cache would compute them now
+            eval_scores(scores, work, tmpl, len, sum_y, sum_yy, best_off - 1, 2, 2, false);
         const float prev = scores[best_off - 1], nxt = scores[best_off + 1];
         frac = rclamp(parabolic_refine(prev, best_score, nxt, best_off) - (float)best_off, -0.5f, 0.5f);
     }
@@ -606,7 +698,7 @@ __device__ float write_candidate(float* candidate, const float* reference, const
 
 // locate (:358-411)
 __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& trace, Estimate est, uint32_t cycles, float rate,
-                          Scratch& sc, Shared& sh) {
+                          Scratch& sc, Shared& sh, PhaseClock& pc) {
     Capture none{0, 0.0f, 0, 0.0f};
     const uint32_t n = trace.n;
     const float period = fmaxf(est.period, 1.0f);
@@ -653,9 +745,11 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
     for (uint32_t i = threadIdx.x; i < data.n; i += 256) sc.work[i] = data.at(i) - t.mean;
     const bool use_reference = red[1] > 1.0e-3f;  // any(|sample| > 1e-3) (:381)
     prepare_template(sc.candidate, reference, len, period, use_reference);  // ends with the barrier that also publishes work[]
+    pc.mark(6);  // (sub-phase of locate) retune, span mean, work[], template
     uint32_t offset;
     float frac_offset;
     find_best(sc.scores, sc.work, sc.candidate, len, search, period, offset, frac_offset, sh);
+    pc.mark(7);  // (sub-phase) coarse-to-fine search
     const bool confident = est.confidence >= MIN_PERIODICITY;
     bool reset = false;
     bool candidate_written = false;
@@ -670,6 +764,7 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
         find_best(sc.scores, sc.work, sc.candidate, len, search, period, offset, frac_offset, sh);
         candidate_written = false;
     }
+    pc.mark(8);  // (sub-phase) candidate vs reference (+ reset search)
     if (confident) {
         if (!use_reference || reset || !candidate_written)
             write_candidate(sc.candidate, reference, trace.sub(left + offset - before, len), period, sh);
@@ -686,6 +781,7 @@ __device__ Capture locate(ScopeTriggerState& t, float* reference, const View& tr
         t.reference_period += BUFFER_RESPONSIVENESS * (period - t.reference_period);
         __syncthreads();
     }
+    pc.mark(9);  // (sub-phase) reference update
     uint32_t start = left + offset;
     if (frac_offset < 0.0f && start > 0) {
         start -= 1;
@@ -711,7 +807,7 @@ __device__ Capture stable_capture(ScopeTriggerState& t, float* reference, const 
     if (probe_len > 0 && last_peak < MIN_SIGNAL_PEAK) trigger_unlock(t);
     const Estimate est = stabilize(t, detected);
     if (est.some) {
-        const Capture c = locate(t, reference, trace, est, a.num_cycles, a.sample_rate, sc, sh);
+        const Capture c = locate(t, reference, trace, est, a.num_cycles, a.sample_rate, sc, sh, pc);
         pc.mark(4);  // locate (template correlation search)
         if (c.some) return c;
     }

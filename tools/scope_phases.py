@@ -26,15 +26,16 @@ sc = banks.OscilloscopeBank(api, capi.OscilloscopeConfig(segment_duration=0.02, 
                                                          trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT), S)
 pos = capi.positions_fallback(2)
 f = api.fn("debug_scope_phase_cycles", C.c_int, [C.POINTER(C.c_uint64), C.c_uint32, C.c_int])
-out = (C.c_uint64 * 6)()
+out = (C.c_uint64 * 10)()
 sc.process_device(pcm[:, :frames].contiguous().data_ptr(), 256, blocks, 2, 48000.0, pos)
 torch.cuda.synchronize()
-f(out, 6, 1)
+f(out, 10, 1)
 sc.process_device(pcm[:, frames:2 * frames].contiguous().data_ptr(), 256, blocks, 2, 48000.0, pos)
 torch.cuda.synchronize()
-f(out, 6, 1)
+f(out, 10, 1)
 c = np.array(out[:], np.float64)
 for name, v in zip(["ring push", "pre-FFT (mean, peak, copy, prefix energy)", "two FFTs", "NSDF + peak picking", "locate (template search)",
-                    "snapshot"], c):
+                    "snapshot", "  locate: retune / mean / work / template", "  locate: coarse-to-fine search", "  locate: candidate vs reference",
+                    "  locate: reference update"], c):
     print(f"{name:44s} {v / c.sum() * 100:5.1f} %   {v / (S * blocks):9.0f} cycles/block")
 print("total cycles/block", c.sum() / (S * blocks))
