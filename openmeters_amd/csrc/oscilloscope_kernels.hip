@@ -431,31 +431,6 @@ __device__ Estimate stabilize(ScopeTriggerState& t, Estimate detected) {  // :33
     return detected;
 }
 
-// normalized_correlation (:210-236) of x (len n) against y with precomputed stats of y; one wave.
-__device__ float wave_normalized_correlation(const float* x, const float* y, uint32_t n, float sum_y, float sum_yy) {
-    const unsigned lane = threadIdx.x & 63;
-    float sx = 0.0f, sxx = 0.0f, sxy = 0.0f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const float xv = x[i], yv = y[i];
-        sx += xv;
-        sxx += xv * xv;
-        sxy += xv * yv;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sx += __shfl_xor(sx, off);
-        sxx += __shfl_xor(sxx, off);
-        sxy += __shfl_xor(sxy, off);
-    }
-    if (n == 0) return 0.0f;
-    const float nf = (float)n;
-    const float dot = sxy - sx * sum_y / nf;
-    const float ex = fmaxf(sxx - sx * sx / nf, 0.0f);
-    const float ey = fmaxf(sum_yy - sum_y * sum_y / nf, 0.0f);
-    const float denom = sqrtf(ex * ey);
-    return denom > F32_EPS ? rclamp(dot / denom, -1.0f, 1.0f) : 0.0f;
-}
-
 __device__ void correlation_stats(const float* y, uint32_t n, float& sum, float& squares, Shared& sh) {  // :206-208
     float s = 0.0f, q = 0.0f;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -489,7 +464,8 @@ __device__ void prepare_template(float* candidate, const float* reference, uint3
 // Evaluate scores[offset] for offsets lo + k*step (k = 0..count-1); one wave per offset.
 // Up to M offsets per wavefront in ONE sweep over the template: y[i] is read once for all of them, the M accumulation chains
 // are independent (a single correlation per sweep was a dependent ds_read -> fma chain, 30 exposed LDS round trips each), and
-// every offset keeps the element order of wave_normalized_correlation — same sums, bit for bit.
+// every offset keeps the element order of a one-offset-per-wavefront sweep (lane l sums elements l, l + 64, ...; xor-shuffle
+// tree) — normalized_correlation (:210-236) with the template statistics precomputed; same sums, bit for bit.
 template <int M>
 __device__ void wave_correlations(float* scores, const float* work, const float* tmpl, uint32_t len, float sum_y, float sum_yy,
                                   const uint32_t (&off)[M], int valid) {
