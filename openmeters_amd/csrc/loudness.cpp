@@ -88,7 +88,7 @@ void LoudnessBank::ensure_state(uint32_t requested, float sample_rate_in, hipStr
     const bool realloc = ring_len_ != len || !ring_.ptr;
     if (realloc) {
         ring_len_ = len;
-        ring_.reserve((size_t)(len * n_streams_ * 8));
+        ring_.reserve((size_t)(len * (((uint64_t)n_streams_ * 8 + 63) / 64) * 64));  // [group of 64 slots][ring slot][64]
         state_.reserve((size_t)n_streams_ * 8);
     }
     if (rate_changed || channels_ != channels || realloc) {

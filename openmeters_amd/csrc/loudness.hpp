@@ -36,7 +36,8 @@ struct LoudnessArgs {
     LoudnessChannelState* state;  // [n_streams * 8]
     float floor_db;
     omx_loudness_snapshot* snapshots;  // [n_streams][n_blocks]
-    uint32_t n_meter_blocks;           // split launch: workgroups [0, n) = K-weighting + windows, [n, 2n) = true peak
+    uint32_t n_meter_blocks;
+    uint32_t role_perm;  // TEMP           // split launch: workgroups [0, n) = K-weighting + windows, [n, 2n) = true peak
 };
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream);
 

@@ -14,6 +14,14 @@
 
 namespace omx {
 
+// Ring layout: [group of 64 (stream, channel) slots][ring slot][64].  A workgroup's expiring-value reads and its ring writes then
+// walk five sequential 512-byte-row streams inside one contiguous region (the first layout, [ring slot][all slots], put every
+// access of a workgroup 64 KiB x n_streams / 1024 apart: one DRAM page and one TLB reach per 512 bytes).
+constexpr uint32_t kRingRow = 64;
+__device__ __forceinline__ double* ring_column(double* ring, uint32_t chan, uint64_t ring_len) {
+    return ring + (uint64_t)(chan >> 6) * ring_len * kRingRow + (chan & 63u);
+}
+
 __device__ __forceinline__ void kbn_add(double& sum, double& corr, double v) {  // dsp.rs:277-285
     // corr += |sum| >= |v| ? (sum - next) + v : (v - next) + sum;  picking (big, small) first evaluates one branch's two f64
     // operations instead of both branches' four (f64 issues at half rate): same operands, same order, same bits
@@ -141,7 +149,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     const uint32_t r = gid & 3, chan = gid >> 2;      // chan = stream * 8 + channel
     const uint32_t s = chan >> 3, c = chan & 7;
     const bool live = s < a.n_streams && c < a.channels;
-    const uint32_t row = a.n_streams * 8;
+    const uint32_t row = kRingRow;
     LoudLane<DL> L;
     L.sum0 = L.sum1 = L.cor0 = L.cor1 = 0.0;
 #pragma unroll
@@ -177,7 +185,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     L.refresh = (uint32_t)(a.frames_seen % a.capacities[r]);                                             // dsp.rs:363
     L.unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);  // pushes until count >= cap
     uint64_t seen = a.frames_seen;
-    double* ring_col = a.ring + (live ? chan : 0);  // dead lanes read column 0 (discarded) and never store
+    double* ring_col = ring_column(a.ring, live ? chan : 0, a.ring_len);  // dead lanes read column 0 (discarded) and never store
     const bool store_lane = live && r == 0;
     const uint32_t full = a.block_frames / B, tail = a.block_frames % B;
 
@@ -305,27 +313,46 @@ __global__ __launch_bounds__(64) void loudness_kernel(LoudnessArgs a) {
 // global loads (__syncthreads would drain the expiring-value prefetches of the window wavefronts at every round).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int B, int NSUB, int DL>  // B samples per prefetch batch, NSUB batches per barrier round (= prefetch depth of the windows)
-__global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
+// SIX: six wavefronts instead of five.  Wavefront w runs on SIMD w % 4, so the five-wavefront form puts the K-weighting
+// wavefront and a window wavefront (28 + 34 VALU per sample) on one SIMD, and that SIMD paces the workgroup.  Here the `since
+// last refresh` Kahan pairs of all four windows move to a wavefront of their own (one round behind the filter, one ahead of the
+// windows, which take the pair over through a mailbox when CompensatedPair::refresh fires); the four windows then sit on four
+// different SIMDs and the filter / pair wavefronts are the lighter second tenant of two of them.
+// Every accumulator still sees the same additions in the same order.
+template <int B, int NSUB, int DL, bool SIX>  // B samples per prefetch batch, NSUB batches per barrier round
+__global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(LoudnessArgs a) {
     static_assert(NSUB == 4, "four rotating prefetch buffers");
-    if (blockIdx.x >= a.n_meter_blocks) {  // true-peak workgroups: 80 channels x 4 phase lanes
-        loudness_body<8, DL, 2>(a, (blockIdx.x - a.n_meter_blocks) * 320 + threadIdx.x);
+    constexpr uint32_t THREADS = SIX ? 384 : 320;
+    constexpr uint32_t NBUF = SIX ? 3 : 2, LAG = SIX ? 2 : 1;  // value buffers; rounds between the filter and the windows
+    if (blockIdx.x >= a.n_meter_blocks) {  // true-peak workgroups: 4 phase lanes per channel
+        loudness_body<8, DL, 2>(a, (blockIdx.x - a.n_meter_blocks) * THREADS + threadIdx.x);
         return;
     }
-    __shared__ double vals[2][NSUB * B][64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double vals[NBUF][NSUB * B][64];
+    __shared__ double mailbox[SIX ? 2 : 1][4][2][64];  // [round parity][window][sum, correction][lane]
+    // wave-uniform by construction; readfirstlane tells the compiler, so that everything derived from the role (window length,
+    // ring slots, refresh counters) lives in SGPRs and the ring accesses take the scalar-base + lane-offset form
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // roles: five-wave form 0 = filter, 1..4 = windows; six-wave form 0..3 = windows (one per SIMD: wavefronts w and w + 4 share
+    // a SIMD, tools/microbench/wave_simd.hip), 4 = filter, 5 = `since refresh` pairs — measured over all 30 assignments: 2.13 ms
+    // for this one, 2.25-2.5 ms for those that put two windows on one SIMD
+    const bool k_role = SIX ? wave == 4 : wave == 0;
+    const bool s1_role = SIX && wave == 5;
     const uint32_t chan = blockIdx.x * 64 + lane;  // stream * 8 + channel
     const uint32_t s = chan >> 3, c = chan & 7;
     const bool live = s < a.n_streams && c < a.channels;
-    const uint32_t row = a.n_streams * 8;
     const uint32_t full = a.block_frames / B;           // batches per block (block_frames % (B * NSUB) == 0, host-checked)
     const uint64_t total = (uint64_t)a.n_blocks * full;   // batches of the call
     const uint64_t rounds = total / NSUB;                 // barrier rounds carrying data
     const float* pcm = a.pcm + ((uint64_t)(live ? s : 0) * a.frames_total) * a.channels + (live ? c : 0);
-    double* ring_col = a.ring + (live ? chan : 0);  // dead lanes read column 0 (discarded) and never store
+    // [ring slot][64] of this workgroup: a uniform base (SGPR pair) + unsigned 32-bit byte offsets (ring slot x 512 + lane x 8,
+    // < 2^32 for any ring the host accepts) select the scalar-base + vector-offset addressing form — one VALU per access
+    // instead of the seven of a per-lane 64-bit address
+    char* group_bytes = reinterpret_cast<char*>(a.ring + (uint64_t)blockIdx.x * a.ring_len * kRingRow);
+    const uint32_t lane_bytes = lane * 8u;
     const uint32_t len = (uint32_t)a.ring_len;
 
-    if (wave == 0) {
+    if (k_role) {
         // ---------------- K-weighting wavefront ----------------
         double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
         if (live) {
@@ -365,15 +392,16 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
         fetch(xa, 0);
         // round i: this wavefront fills buffer i & 1 with batches [i NSUB, (i + 1) NSUB) while the window wavefronts consume
         // round i - 1 from the other buffer; one barrier per round
-        for (uint64_t i = 0; i <= rounds; ++i) {
+        for (uint64_t i = 0; i < rounds + LAG; ++i) {
             if (i < rounds) {
                 const uint64_t b0 = i * NSUB;
+                const uint32_t buf = (uint32_t)(i % NBUF);
 #pragma unroll
                 for (int sb = 0; sb < NSUB; sb += 2) {
                     fetch(xb, b0 + sb + 1);
-                    produce(xa, (uint32_t)(i & 1), sb, b0 + sb);
+                    produce(xa, buf, sb, b0 + sb);
                     fetch(xa, b0 + sb + 2);
-                    produce(xb, (uint32_t)(i & 1), sb + 1, b0 + sb + 1);
+                    produce(xb, buf, sb + 1, b0 + sb + 1);
                 }
             }
             lds_barrier();
@@ -388,8 +416,78 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
         return;
     }
 
+    if (s1_role) {
+        // ---------------- `since last refresh` pairs of the four windows (six-wave form) ----------------
+        double s1[4], c1[4];
+        uint32_t refresh4[4], cap4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s1[w] = c1[w] = 0.0;
+            cap4[w] = (uint32_t)a.capacities[w];
+            refresh4[w] = (uint32_t)(a.frames_seen % a.capacities[w]);
+            if (live) {
+                s1[w] = a.state[chan].sums[w][1];
+                c1[w] = a.state[chan].corrections[w][1];
+            }
+        }
+        for (uint64_t i = 0; i < rounds + LAG; ++i) {
+            if (i >= 1 && i <= rounds) {  // round i - 1
+                const uint32_t buf = (uint32_t)((i - 1) % NBUF), par = (uint32_t)((i - 1) & 1);
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb) {
+                    double batch[B];
+#pragma unroll
+                    for (int k = 0; k < B; ++k) batch[k] = vals[buf][sb * B + k][lane];
+                    bool any = false;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) any = any || refresh4[w] + (uint32_t)B >= cap4[w];
+                    auto sweep = [&](auto check_c) {  // instantiated without the refresh test for the (usual) batch that cannot fire it
+                        constexpr bool CHECK = decltype(check_c)::value;
+#pragma unroll
+                        for (int k = 0; k < B; ++k) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                // the pair only ever adds values >= +0.0 to a sum that starts at +0.0: |sum| >= |v| is sum >= v, and
+                                // (big, small) = (max, min) — same operands as kbn_add, three instructions less
+                                const double next = s1[w] + batch[k];
+                                const double big = fmax(s1[w], batch[k]), small = fmin(s1[w], batch[k]);
+                                c1[w] += (big - next) + small;
+                                s1[w] = next;
+                                if constexpr (CHECK) {
+                                    if (refresh4[w] + (uint32_t)k + 1u == cap4[w]) {  // CompensatedPair::refresh (dsp.rs:287-289)
+                                        mailbox[par][w][0][lane] = s1[w];
+                                        mailbox[par][w][1][lane] = c1[w];
+                                        s1[w] = 0.0;
+                                        c1[w] = 0.0;
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    if (any) sweep(std::true_type{});
+                    else sweep(std::false_type{});
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        refresh4[w] += (uint32_t)B;
+                        refresh4[w] = refresh4[w] >= cap4[w] ? refresh4[w] - cap4[w] : refresh4[w];
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        if (live) {
+            LoudnessChannelState& st = a.state[chan];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                st.sums[w][1] = s1[w];
+                st.corrections[w][1] = c1[w];
+            }
+        }
+        return;
+    }
+
     // ---------------- window wavefronts ----------------
-    const uint32_t r = wave - 1;
+    const uint32_t r = SIX ? wave : wave - 1;
     const uint32_t cap = (uint32_t)a.capacities[r];
     double sum0 = 0.0, sum1 = 0.0, cor0 = 0.0, cor1 = 0.0;
     if (live) {
@@ -414,7 +512,9 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
             uint32_t pos = h + (uint32_t)k;
             pos = pos >= len ? pos - len : pos;
             const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
-            old[k] = ring_col[(uint64_t)idx * row];
+            // the ring slot is wave-uniform and the workgroup's 64 columns are contiguous: scalar row address + lane offset
+            // (the per-lane 64-bit address arithmetic was 7 VALU per load, a fifth of this wavefront's instructions)
+            old[k] = *reinterpret_cast<const double*>(group_bytes + (idx * (kRingRow * 8u) + lane_bytes));
         }
         return batch < total ? unf : (uint32_t)B;  // first sample of the batch that has an expiring value
     };
@@ -449,6 +549,7 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
     // (STORE) and per "can CompensatedPair::refresh fire in this batch" (REFRESH; once per `cap` >= 14 400 pushes) — the common
     // instantiation is straight-line code.
     const bool store_wave = __builtin_amdgcn_readfirstlane((int)(r == 0)) != 0;
+    uint32_t round_parity = 0;  // six-wave form: parity of the round being consumed (mailbox slot)
     auto consume_as = [&](auto store_c, auto refresh_c, const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub) {
         constexpr bool STORE = decltype(store_c)::value, REFRESH = decltype(refresh_c)::value;
         // all B values of the batch in one burst of LDS reads (read-per-sample exposed the LDS latency at every sample)
@@ -461,18 +562,24 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
             const double value = batch[k];
             const double expiring = (live && (uint32_t)k >= first_valid) ? old[k] : 0.0;
             kbn_add(sum0, cor0, value);
-            kbn_add(sum1, cor1, value);
+            if constexpr (!SIX) kbn_add(sum1, cor1, value);
             kbn_add(sum0, cor0, -expiring);
             if constexpr (REFRESH) {
                 if (refresh + (uint32_t)k + 1u == cap) {  // CompensatedPair::refresh (dsp.rs:287-289)
-                    sum0 = sum1;
-                    sum1 = 0.0;
-                    cor0 = cor1;
-                    cor1 = 0.0;
+                    if constexpr (SIX) {  // the pair kept by the `since refresh` wavefront, as of this very sample
+                        sum0 = mailbox[round_parity][r][0][lane];
+                        cor0 = mailbox[round_parity][r][1][lane];
+                    } else {
+                        sum0 = sum1;
+                        sum1 = 0.0;
+                        cor0 = cor1;
+                        cor1 = 0.0;
+                    }
                 }
             }
             if constexpr (STORE) {
-                if (live) ring_col[(uint64_t)(head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * row] = value;
+                if (live)
+                    *reinterpret_cast<double*>(group_bytes + ((head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * (kRingRow * 8u) + lane_bytes)) = value;
             }
         }
     };
@@ -496,10 +603,11 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
         if ((batch + 1) % full == 0) snapshot((uint32_t)((batch + 1) / full - 1));
     };
     uint32_t u0 = fetch_old(o0, 0, 0), u1 = fetch_old(o1, B, 1), u2 = fetch_old(o2, 2 * B, 2), u3 = fetch_old(o3, 3 * B, 3);
-    for (uint64_t i = 0; i <= rounds; ++i) {
-        if (i >= 1) {  // consume round i - 1 (buffer (i - 1) & 1); after a batch is consumed its registers take the batch 4 ahead
-            const uint64_t b0 = (i - 1) * NSUB;
-            const uint32_t buf = (uint32_t)((i - 1) & 1);
+    for (uint64_t i = 0; i < rounds + LAG; ++i) {
+        if (i >= LAG) {  // consume round i - LAG; after a batch is consumed its registers take the batch 4 ahead
+            const uint64_t b0 = (i - LAG) * NSUB;
+            const uint32_t buf = (uint32_t)((i - LAG) % NBUF);
+            round_parity = (uint32_t)((i - LAG) & 1);
             consume(o0, u0, buf, 0, b0);
             u0 = fetch_old(o0, 3 * B, b0 + 4);
             consume(o1, u1, buf, 1, b0 + 1);
@@ -514,9 +622,11 @@ __global__ __launch_bounds__(320) void loudness_roles_kernel(LoudnessArgs a) {
     if (live) {
         LoudnessChannelState& st = a.state[chan];
         st.sums[r][0] = sum0;
-        st.sums[r][1] = sum1;
         st.corrections[r][0] = cor0;
-        st.corrections[r][1] = cor1;
+        if constexpr (!SIX) {
+            st.sums[r][1] = sum1;
+            st.corrections[r][1] = cor1;
+        }
     }
 }
 
@@ -543,12 +653,18 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
     }();
     const bool split = force >= 0 ? force != 0 : (a.delay_len != 0 && grid <= 4096);
     // role-per-wavefront form (OMX_LOUDNESS_SPLIT=2 pins it, default when it applies): whole batches per block, 4x interpolator
-    const bool roles = (force == 2 || (force < 0 && grid <= 4096)) && min_cap >= 64 && a.block_frames % 32 == 0 && a.delay_len == 12;
+    const bool roles = a.ring_len * (uint64_t)(kRingRow * 8u) <= 0xFFFFFFFFull &&  // 32-bit byte offsets inside a group's ring
+                       (force == 2 || force == 3 || (force < 0 && grid <= 4096)) && min_cap >= 64 && a.block_frames % 32 == 0 && a.delay_len == 12;
     if (roles) {
         LoudnessArgs r = a;
         r.n_meter_blocks = (a.n_streams * 8 + 63) / 64;
-        const uint32_t peak_blocks = (a.n_streams * 32 + 319) / 320;
-        hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12>), dim3(r.n_meter_blocks + peak_blocks), dim3(320), 0, stream, r);
+        if (force == 2) {  // the five-wavefront form (A/B and tests)
+            const uint32_t peak_blocks = (a.n_streams * 32 + 319) / 320;
+            hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12, false>), dim3(r.n_meter_blocks + peak_blocks), dim3(320), 0, stream, r);
+        } else {
+            const uint32_t peak_blocks = (a.n_streams * 32 + 383) / 384;
+            hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12, true>), dim3(r.n_meter_blocks + peak_blocks), dim3(384), 0, stream, r);
+        }
         return;
     }
     if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, split, stream);
