@@ -277,10 +277,230 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     a.state[gid] = st_mem;
 }
 
+// ---- role-pipelined form (2 channels, band analysis on, whole rounds per block) ---------------------------------------------
+// The four-wavefront form above gives the mid and the high band FOUR cascade elements each — both evaluate HP_low on identical
+// inputs — so two SIMDs issue ~62 VALU per frame while the full-band wavefront issues 22.  Here a fifth wavefront (it shares
+// SIMD 0 with the light full-band role: wavefronts w and w + 4 of a workgroup sit on one SIMD) runs HP_low once and hands
+// `above_low` to the mid / high wavefronts through LDS, one round of ROUND frames ahead of them.  Every filter and correlator
+// still sees the same samples in the same order: results are bit-identical to the four-wavefront form.
+constexpr int kStereoRound = 32;
+
+template <int ROLE, bool PUSH>  // ROLE 0 full band, 1 low, 2 mid, 3 high, 4 HP_low producer
+__device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf)[kStereoRound][64], uint32_t s, bool live_lane,
+                                            uint32_t lane) {
+    constexpr int BATCH = 8, R = kStereoRound;
+    constexpr uint32_t band = ROLE == 4 ? 2u : (uint32_t)ROLE;
+    constexpr bool FILTERS = ROLE != 0, FROM_LDS = ROLE == 2 || ROLE == 3;
+    const uint64_t total = (uint64_t)a.n_blocks * a.block_frames, rounds = total / R;
+    const float* pcm = a.pcm + (uint64_t)s * a.frames_total * 2u;
+    // the two cascade elements of this role: stage A of the band's slot (low: LP_low; producer: HP_low), stage B (mid / high)
+    constexpr int G = (ROLE == 2 || ROLE == 3) ? 1 : 0;
+    const BiquadCoef c = G ? a.stage_b[band] : a.stage_a[band];
+    StereoLaneState* slot = a.state + (uint64_t)s * 4 + band;
+    v2f z0[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}}, z1[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+    double m[3] = {0.0, 0.0, 0.0};
+    if (FILTERS) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            z0[e] = v2f{slot->z[G][e][0][0], slot->z[G][e][1][0]};
+            z1[e] = v2f{slot->z[G][e][0][1], slot->z[G][e][1][1]};
+        }
+    }
+    if (ROLE != 4) {
+        m[0] = slot->moments[0];
+        m[1] = slot->moments[1];
+        m[2] = slot->moments[2];
+    }
+    float* hist = a.history + ((uint64_t)s * 4 + band) * a.hist_frames * 2;
+    uint32_t hslot = (uint32_t)(a.hist_pos[band] % a.hist_frames);
+    const double alpha = a.alpha;
+    float2 xnext[BATCH];
+    bool have_next = false;
+    v2f pend[BATCH];
+    uint32_t pend_slot = 0, in_block = 0, blk = 0;
+    bool has_pend = false;
+    auto flush_pending = [&]() {  // see stereometer_kernel: stores go out ahead of the next prefetch
+        if (has_pend) {
+            uint32_t sl = pend_slot;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                *reinterpret_cast<v2f*>(hist + 2u * sl) = pend[i];
+                sl = sl + 1u == a.hist_frames ? 0u : sl + 1u;
+            }
+            has_pend = false;
+        }
+    };
+    auto fold = [&](float2 x) {
+        const float left = 0.0f + x.x * a.fmt.m[0][0] + x.y * a.fmt.m[1][0];
+        const float right = 0.0f + x.x * a.fmt.m[0][1] + x.y * a.fmt.m[1][1];
+        return v2f{left, right};
+    };
+    for (uint64_t i = 0; i <= rounds; ++i) {
+        const bool active = ROLE == 4 ? i < rounds : i >= 1;
+        if (active) {
+            const uint64_t round = ROLE == 4 ? i : i - 1;
+            v2f (*ab)[64] = abuf[round & 1];
+#pragma unroll 1
+            for (int sb = 0; sb < R / BATCH; ++sb) {
+                const uint64_t g0 = round * R + (uint64_t)sb * BATCH;  // first frame of the batch, counted from the start of the call
+                v2f in[BATCH];
+                if constexpr (FROM_LDS) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) in[k] = ab[sb * BATCH + k][lane];
+                    if constexpr (PUSH) flush_pending();
+                } else {
+                    if (!have_next) {
+#pragma unroll
+                        for (int k = 0; k < BATCH; ++k) xnext[k] = *reinterpret_cast<const float2*>(pcm + 2u * (g0 + k));
+                    }
+                    float2 x[BATCH];
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) x[k] = xnext[k];
+                    if constexpr (PUSH) flush_pending();
+                    have_next = g0 + 2 * BATCH <= total;
+                    const float* nxt = pcm + 2u * (have_next ? g0 + BATCH : g0);
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) xnext[k] = *reinterpret_cast<const float2*>(nxt + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) in[k] = fold(x[k]);
+                }
+                const v2f sz0[2] = {z0[0], z0[1]}, sz1[2] = {z1[0], z1[1]};
+                const double sm[3] = {m[0], m[1], m[2]};
+                const uint32_t hslot0 = hslot;
+                v2f poison[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+                v2f y[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    v2f v = in[k];
+                    if constexpr (FILTERS) {
+                        v = biquad_core2(c, z0[0], z1[0], v, poison[0]);
+                        v = biquad_core2(c, z0[1], z1[1], v, poison[1]);
+                    }
+                    if constexpr (ROLE != 4) {
+                        const double ld = (double)v.x, rd = (double)v.y;  // Correlator::update (:40-46)
+                        m[0] += alpha * (ld * rd - m[0]);
+                        m[1] += alpha * (ld * ld - m[1]);
+                        m[2] += alpha * (rd * rd - m[2]);
+                    }
+                    y[k] = v;
+                    if constexpr (PUSH) hslot = hslot + 1u == a.hist_frames ? 0u : hslot + 1u;
+                }
+                if constexpr (FILTERS) {
+                    const v2f t2 = poison[0] + poison[1];
+                    const float taint = t2.x + t2.y;
+                    if (__builtin_expect(__ballot(!(taint == 0.0f)) != 0ull, 0)) {  // some output was inf / NaN: exact replay
+                        z0[0] = sz0[0], z0[1] = sz0[1], z1[0] = sz1[0], z1[1] = sz1[1];
+                        m[0] = sm[0], m[1] = sm[1], m[2] = sm[2];
+#pragma unroll 1
+                        for (int k = 0; k < BATCH; ++k) {
+                            v2f v;
+                            if constexpr (FROM_LDS) v = ab[sb * BATCH + k][lane];
+                            else v = fold(*reinterpret_cast<const float2*>(pcm + 2u * (g0 + (uint32_t)k)));
+                            v = biquad_step2(c, z0[0], z1[0], v);
+                            v = biquad_step2(c, z0[1], z1[1], v);
+                            if constexpr (ROLE != 4) {
+                                const double ld = (double)v.x, rd = (double)v.y;
+                                m[0] += alpha * (ld * rd - m[0]);
+                                m[1] += alpha * (ld * ld - m[1]);
+                                m[2] += alpha * (rd * rd - m[2]);
+                            }
+                            // (a dynamically indexed y[] would live in scratch: the replayed outputs go out directly)
+                            if constexpr (ROLE == 4) ab[sb * BATCH + k][lane] = v;
+                            if constexpr (PUSH) {
+                                uint32_t sl = hslot0 + (uint32_t)k;
+                                sl = sl >= a.hist_frames ? sl - a.hist_frames : sl;
+                                if (live_lane) *reinterpret_cast<v2f*>(hist + 2u * sl) = v;
+                            }
+                        }
+                        // lanes that were clean recomputed the same values; skip the batch's normal outputs
+                        if constexpr (PUSH) has_pend = false;
+                        goto batch_done;
+                    }
+                }
+                if constexpr (ROLE == 4) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) ab[sb * BATCH + k][lane] = y[k];
+                }
+                if constexpr (PUSH) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) pend[k] = y[k];
+                    pend_slot = hslot0;
+                    has_pend = live_lane;
+                }
+            batch_done:
+                in_block += BATCH;  // (a 64-bit `% block_frames` per batch would cost more than the batch's filters)
+                if (in_block == a.block_frames) {  // end of a block: flush_denormals (:134-140) and Correlator::value (:48-56)
+                    if constexpr (FILTERS) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            z0[e] = v2f{fabsf(z0[e].x) < 1.0e-20f ? 0.0f : z0[e].x, fabsf(z0[e].y) < 1.0e-20f ? 0.0f : z0[e].y};
+                            z1[e] = v2f{fabsf(z1[e].x) < 1.0e-20f ? 0.0f : z1[e].x, fabsf(z1[e].y) < 1.0e-20f ? 0.0f : z1[e].y};
+                        }
+                    }
+                    if constexpr (ROLE != 4) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (fabs(m[q]) < 1.0e-30) m[q] = 0.0;
+                        float value = 0.0f;
+                        const double denom = sqrt(m[1] * m[2]);
+                        if (denom > 1e-12) {
+                            const double v = m[0] / denom;
+                            if (isfinite(v)) value = (float)fmin(fmax(v, -1.0), 1.0);
+                        }
+                        if (live_lane) a.correlations[((uint64_t)s * a.n_blocks + blk) * 4 + band] = value;
+                    }
+                    in_block = 0;
+                    ++blk;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if constexpr (PUSH) flush_pending();
+    if (!live_lane) return;
+    if constexpr (FILTERS) {
+        const int n_slots = ROLE == 4 ? 2 : 1;  // the producer's HP_low state is stage A of BOTH the mid and the high slot
+        for (int q = 0; q < n_slots; ++q) {
+            StereoLaneState* dst = a.state + (uint64_t)s * 4 + band + q;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                dst->z[G][e][0][0] = z0[e].x;
+                dst->z[G][e][1][0] = z0[e].y;
+                dst->z[G][e][0][1] = z1[e].x;
+                dst->z[G][e][1][1] = z1[e].y;
+            }
+        }
+    }
+    if constexpr (ROLE != 4) {
+        slot->moments[0] = m[0];
+        slot->moments[1] = m[1];
+        slot->moments[2] = m[2];
+    }
+}
+
+__global__ __launch_bounds__(320) void stereometer_roles_kernel(StereometerArgs a) {
+    __shared__ v2f abuf[2][kStereoRound][64];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t s_raw = blockIdx.x * 64 + lane;
+    const bool live_lane = s_raw < a.n_streams;
+    const uint32_t s = live_lane ? s_raw : a.n_streams - 1;  // idle lanes shadow the last stream (loads stay in bounds; no stores)
+    const bool push = a.emit_band_points != 0;
+    switch (wave) {
+        case 0: stereo_role<0, true>(a, abuf, s, live_lane, lane); break;
+        case 1: push ? stereo_role<1, true>(a, abuf, s, live_lane, lane) : stereo_role<1, false>(a, abuf, s, live_lane, lane); break;
+        case 2: push ? stereo_role<2, true>(a, abuf, s, live_lane, lane) : stereo_role<2, false>(a, abuf, s, live_lane, lane); break;
+        case 3: push ? stereo_role<3, true>(a, abuf, s, live_lane, lane) : stereo_role<3, false>(a, abuf, s, live_lane, lane); break;
+        default: stereo_role<4, false>(a, abuf, s, live_lane, lane); break;
+    }
+}
+
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     const uint32_t groups = (a.n_streams + 63) / 64;
-    if (a.fmt.channels == 2)
+    static const bool no_roles = [] { const char* e = getenv("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
+    if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles)
+        hipLaunchKernelGGL(stereometer_roles_kernel, dim3(groups), dim3(320), 0, stream, a);
+    else if (a.fmt.channels == 2)
         hipLaunchKernelGGL(stereometer_kernel<2>, dim3(groups), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(stereometer_kernel<0>, dim3(groups), dim3(256), 0, stream, a);
