@@ -286,11 +286,12 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
 constexpr int kStereoRound = 32;
 
 template <int ROLE, bool PUSH>  // ROLE 0 full band, 1 low, 2 mid, 3 high, 4 HP_low producer
-__device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf)[kStereoRound][64], uint32_t s, bool live_lane,
-                                            uint32_t lane) {
+__device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf)[kStereoRound][64], v2f (*xbuf)[kStereoRound][64],
+                                            uint32_t s, bool live_lane, uint32_t lane) {
     constexpr int BATCH = 8, R = kStereoRound;
     constexpr uint32_t band = ROLE == 4 ? 2u : (uint32_t)ROLE;
-    constexpr bool FILTERS = ROLE != 0, FROM_LDS = ROLE == 2 || ROLE == 3;
+    // only the producer reads the PCM: it publishes the folded frame (for the full-band and low roles) next to `above_low`
+    constexpr bool FILTERS = ROLE != 0, FROM_LDS = ROLE != 4;
     const uint64_t total = (uint64_t)a.n_blocks * a.block_frames, rounds = total / R;
     const float* pcm = a.pcm + (uint64_t)s * a.frames_total * 2u;
     // the two cascade elements of this role: stage A of the band's slot (low: LP_low; producer: HP_low), stage B (mid / high)
@@ -339,7 +340,8 @@ __device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf
         const bool active = ROLE == 4 ? i < rounds : i >= 1;
         if (active) {
             const uint64_t round = ROLE == 4 ? i : i - 1;
-            v2f (*ab)[64] = abuf[round & 1];
+            v2f (*ab)[64] = (ROLE == 0 || ROLE == 1) ? xbuf[round & 1] : abuf[round & 1];  // this role's input (producer: its output)
+            v2f (*xb)[64] = xbuf[round & 1];
 #pragma unroll 1
             for (int sb = 0; sb < R / BATCH; ++sb) {
                 const uint64_t g0 = round * R + (uint64_t)sb * BATCH;  // first frame of the batch, counted from the start of the call
@@ -363,6 +365,8 @@ __device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf
                     for (int k = 0; k < BATCH; ++k) xnext[k] = *reinterpret_cast<const float2*>(nxt + 2 * k);
 #pragma unroll
                     for (int k = 0; k < BATCH; ++k) in[k] = fold(x[k]);
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) xb[sb * BATCH + k][lane] = in[k];
                 }
                 const v2f sz0[2] = {z0[0], z0[1]}, sz1[2] = {z1[0], z1[1]};
                 const double sm[3] = {m[0], m[1], m[2]};
@@ -395,7 +399,7 @@ __device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf
                         for (int k = 0; k < BATCH; ++k) {
                             v2f v;
                             if constexpr (FROM_LDS) v = ab[sb * BATCH + k][lane];
-                            else v = fold(*reinterpret_cast<const float2*>(pcm + 2u * (g0 + (uint32_t)k)));
+                            else v = xb[sb * BATCH + k][lane];  // the folded frame this wavefront published above
                             v = biquad_step2(c, z0[0], z1[0], v);
                             v = biquad_step2(c, z0[1], z1[1], v);
                             if constexpr (ROLE != 4) {
@@ -479,18 +483,20 @@ __device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf
 }
 
 __global__ __launch_bounds__(320) void stereometer_roles_kernel(StereometerArgs a) {
-    __shared__ v2f abuf[2][kStereoRound][64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stereo_smem[];
+    v2f (*abuf)[kStereoRound][64] = reinterpret_cast<v2f (*)[kStereoRound][64]>(stereo_smem);  // [2]: above_low
+    v2f (*xbuf)[kStereoRound][64] = abuf + 2;                                                   // [2]: folded frames
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t s_raw = blockIdx.x * 64 + lane;
     const bool live_lane = s_raw < a.n_streams;
     const uint32_t s = live_lane ? s_raw : a.n_streams - 1;  // idle lanes shadow the last stream (loads stay in bounds; no stores)
     const bool push = a.emit_band_points != 0;
     switch (wave) {
-        case 0: stereo_role<0, true>(a, abuf, s, live_lane, lane); break;
-        case 1: push ? stereo_role<1, true>(a, abuf, s, live_lane, lane) : stereo_role<1, false>(a, abuf, s, live_lane, lane); break;
-        case 2: push ? stereo_role<2, true>(a, abuf, s, live_lane, lane) : stereo_role<2, false>(a, abuf, s, live_lane, lane); break;
-        case 3: push ? stereo_role<3, true>(a, abuf, s, live_lane, lane) : stereo_role<3, false>(a, abuf, s, live_lane, lane); break;
-        default: stereo_role<4, false>(a, abuf, s, live_lane, lane); break;
+        case 0: stereo_role<0, true>(a, abuf, xbuf, s, live_lane, lane); break;
+        case 1: push ? stereo_role<1, true>(a, abuf, xbuf, s, live_lane, lane) : stereo_role<1, false>(a, abuf, xbuf, s, live_lane, lane); break;
+        case 2: push ? stereo_role<2, true>(a, abuf, xbuf, s, live_lane, lane) : stereo_role<2, false>(a, abuf, xbuf, s, live_lane, lane); break;
+        case 3: push ? stereo_role<3, true>(a, abuf, xbuf, s, live_lane, lane) : stereo_role<3, false>(a, abuf, xbuf, s, live_lane, lane); break;
+        default: stereo_role<4, false>(a, abuf, xbuf, s, live_lane, lane); break;
     }
 }
 
@@ -499,7 +505,16 @@ void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     const uint32_t groups = (a.n_streams + 63) / 64;
     static const bool no_roles = [] { const char* e = getenv("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
     if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles)
-        hipLaunchKernelGGL(stereometer_roles_kernel, dim3(groups), dim3(320), 0, stream, a);
+    {
+        const size_t lds = (size_t)4 * kStereoRound * 64 * sizeof(v2f);  // 64 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stereometer_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(stereometer_roles_kernel, dim3(groups), dim3(320), lds, stream, a);
+    }
     else if (a.fmt.channels == 2)
         hipLaunchKernelGGL(stereometer_kernel<2>, dim3(groups), dim3(256), 0, stream, a);
     else
