@@ -322,6 +322,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int B, int NSUB, int DL, bool SIX>  // B samples per prefetch batch, NSUB batches per barrier round
 __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(LoudnessArgs a) {
     static_assert(NSUB == 4, "four rotating prefetch buffers");
+    // one latency-bound wavefront per SIMD: when another kernel's wavefronts share the SIMD (the shard pipeline runs the fused
+    // STFT beside this bank) this one should win the issue arbitration — it has nothing else to hide its latency with
+    __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t THREADS = SIX ? 384 : 320;
     constexpr uint32_t NBUF = SIX ? 3 : 2, LAG = SIX ? 2 : 1;  // value buffers; rounds between the filter and the windows
     if (blockIdx.x >= a.n_meter_blocks) {  // true-peak workgroups: 4 phase lanes per channel

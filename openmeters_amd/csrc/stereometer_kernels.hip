@@ -483,6 +483,7 @@ __device__ __forceinline__ void stereo_role(const StereometerArgs& a, v2f (*abuf
 }
 
 __global__ __launch_bounds__(320) void stereometer_roles_kernel(StereometerArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // see loudness_roles_kernel: latency-bound wavefronts win the issue arbitration on a shared SIMD
     extern __shared__ __attribute__((aligned(16))) unsigned char stereo_smem[];
     v2f (*abuf)[kStereoRound][64] = reinterpret_cast<v2f (*)[kStereoRound][64]>(stereo_smem);  // [2]: above_low
     v2f (*xbuf)[kStereoRound][64] = abuf + 2;                                                   // [2]: folded frames
