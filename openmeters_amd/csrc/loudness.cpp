@@ -122,6 +122,7 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     la.n_blocks = (uint32_t)n_blocks;
     la.n_streams = n_streams_;
     la.channels = channels;
+    la.slot_shift = channels == 1 ? 0u : (channels == 2 ? 1u : (channels == 4 ? 2u : 3u));  // state / ring are cleared on a channel change
     for (int i = 0; i < 5; ++i) {
         la.b[i] = b_[i];
         la.a[i] = a_[i];

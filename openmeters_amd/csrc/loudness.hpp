@@ -32,8 +32,10 @@ struct LoudnessArgs {
     uint64_t capacities[kLoudnessWindows];
     uint64_t ring_len;      // longest capacity
     uint64_t frames_seen;   // pushes since the state was created (head = frames_seen % ring_len)
-    double* ring;           // [ring_len][n_streams * 8] squared K-weighted samples
-    LoudnessChannelState* state;  // [n_streams * 8]
+    uint32_t slot_shift;    // log2 of the (stream, channel) slots per stream: 8, or the channel count itself when it is 1 / 2 / 4
+                            // (a 2-channel bank would otherwise spend three quarters of its lanes and workgroups on dead slots)
+    double* ring;           // [slot group of 64][ring_len][64] squared K-weighted samples
+    LoudnessChannelState* state;  // [n_streams << slot_shift] (allocated for 8 slots per stream)
     float floor_db;
     omx_loudness_snapshot* snapshots;  // [n_streams][n_blocks]
     uint32_t n_meter_blocks;

@@ -147,7 +147,7 @@ __device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float 
 template <int B, int DL, int MODE>
 __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gid) {
     const uint32_t r = gid & 3, chan = gid >> 2;      // chan = stream * 8 + channel
-    const uint32_t s = chan >> 3, c = chan & 7;
+    const uint32_t s = chan >> a.slot_shift, c = chan & ((1u << a.slot_shift) - 1u);
     const bool live = s < a.n_streams && c < a.channels;
     const uint32_t row = kRingRow;
     LoudLane<DL> L;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
             const double mean_fast = __shfl(mean_r, chan_lane0 + 2), mean_slow = __shfl(mean_r, chan_lane0 + 3);
             // position-weighted channel sums in channel order (:292-296): lane (stream_lane0 + 4k + w) holds window w of channel k
             double short_term = 0.0, momentary = 0.0;
-            const int stream_lane0 = lane & ~31;
+            const int stream_lane0 = lane & ~(int)((4u << a.slot_shift) - 1u);
             for (uint32_t k = 0; k < a.channels; ++k) {
                 const double ms = __shfl(mean_r, stream_lane0 + 4 * (int)k + 0);
                 const double mm = __shfl(mean_r, stream_lane0 + 4 * (int)k + 1);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
     const bool k_role = SIX ? wave == 4 : wave == 0;
     const bool s1_role = SIX && wave == 5;
     const uint32_t chan = blockIdx.x * 64 + lane;  // stream * 8 + channel
-    const uint32_t s = chan >> 3, c = chan & 7;
+    const uint32_t s = chan >> a.slot_shift, c = chan & ((1u << a.slot_shift) - 1u);
     const bool live = s < a.n_streams && c < a.channels;
     const uint32_t full = a.block_frames / B;           // batches per block (block_frames % (B * NSUB) == 0, host-checked)
     const uint64_t total = (uint64_t)a.n_blocks * full;   // batches of the call
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
         omx_loudness_snapshot* snap = a.snapshots + (uint64_t)(live ? s : 0) * a.n_blocks + blk;
         if (r < 2) {  // position-weighted channel sum in channel order (:292-296): the 8 lanes of a stream
             double acc = 0.0;
-            const int stream_lane0 = (int)(lane & ~7u);
+            const int stream_lane0 = (int)(lane & ~((1u << a.slot_shift) - 1u));
             for (uint32_t k = 0; k < a.channels; ++k) acc += __shfl(mean_r, stream_lane0 + (int)k) * a.weights[k];
             if (live && c == 0) {
                 const float lufs = mean_square_to_lufs(acc, a.floor_db);
@@ -643,7 +643,7 @@ static void launch_loudness_dl(LoudnessArgs a, uint32_t blocks, bool batched, bo
 
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
-    const uint32_t threads = a.n_streams * 32;  // 8 channels x 4 lanes per stream
+    const uint32_t threads = (a.n_streams << a.slot_shift) * 4;  // slots x 4 lanes per stream
     const uint32_t grid = (threads + 63) / 64;
     uint64_t min_cap = a.capacities[0];
     for (int w = 1; w < kLoudnessWindows; ++w) min_cap = std::min(min_cap, a.capacities[w]);
@@ -660,12 +660,12 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
                        (force == 2 || force == 3 || (force < 0 && grid <= 4096)) && min_cap >= 64 && a.block_frames % 32 == 0 && a.delay_len == 12;
     if (roles) {
         LoudnessArgs r = a;
-        r.n_meter_blocks = (a.n_streams * 8 + 63) / 64;
+        r.n_meter_blocks = ((a.n_streams << a.slot_shift) + 63) / 64;
         if (force == 2) {  // the five-wavefront form (A/B and tests)
-            const uint32_t peak_blocks = (a.n_streams * 32 + 319) / 320;
+            const uint32_t peak_blocks = ((a.n_streams << a.slot_shift) * 4 + 319) / 320;
             hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12, false>), dim3(r.n_meter_blocks + peak_blocks), dim3(320), 0, stream, r);
         } else {
-            const uint32_t peak_blocks = (a.n_streams * 32 + 383) / 384;
+            const uint32_t peak_blocks = ((a.n_streams << a.slot_shift) * 4 + 383) / 384;
             hipLaunchKernelGGL((loudness_roles_kernel<8, 4, 12, true>), dim3(r.n_meter_blocks + peak_blocks), dim3(384), 0, stream, r);
         }
         return;
