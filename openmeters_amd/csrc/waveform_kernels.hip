@@ -4,6 +4,8 @@
 // 16 lanes per stream (12 live): lane = channel * 3 + band.  Every lane evaluates the L and R band filters of its
 // band (identical inputs -> bit-identical outputs across the four channel lanes) and forms its channel's value,
 // so the Mid/Side trackers need no cross-lane traffic.  Built with -ffp-contract=off.
+#include <type_traits>
+
 #include "waveform.hpp"
 
 namespace omx {
@@ -14,14 +16,16 @@ __device__ __forceinline__ void kbn_add(double& sum, double& corr, double v) {  
     corr += (fabs(sum) >= fabs(v)) ? (sum - next) + v : (v - next) + sum;
     sum = next;
 }
-__device__ __forceinline__ float biquad_step(const BiquadCoef& c, float (&z)[2], float x) {  // dsp.rs:422-432
+// Biquad::process (dsp.rs:422-432) with the non-finite reset as selects: the lanes of a wavefront carry different channels and
+// bands, so a branch here is a divergent one per element and sample
+__device__ __forceinline__ float biquad_step(const BiquadCoef& c, float (&z)[2], float x) {
     const float out = c.b[0] * x + z[0];
-    z[0] = c.b[1] * x - c.a[0] * out + z[1];
-    z[1] = c.b[2] * x - c.a[1] * out;
-    if (isfinite(out)) return out;
-    z[0] = 0.0f;
-    z[1] = 0.0f;
-    return 0.0f;
+    const float n0 = c.b[1] * x - c.a[0] * out + z[1];
+    const float n1 = c.b[2] * x - c.a[1] * out;
+    const bool ok = isfinite(out);
+    z[0] = ok ? n0 : 0.0f;
+    z[1] = ok ? n1 : 0.0f;
+    return ok ? out : 0.0f;
 }
 __device__ __forceinline__ float power_to_db_f(float power, float floor) {  // level.rs:28-34
     return power > 0.0f ? fmaxf(logf(power) * 4.3429448f, floor) : floor;
@@ -29,17 +33,23 @@ __device__ __forceinline__ float power_to_db_f(float power, float floor) {  // l
 struct Window {  // one WindowedMeans window of one value
     double s0, s1, c0, c1;
     uint32_t cap, refresh, unfilled;
-    __device__ __forceinline__ void push(double v, double old) {  // dsp.rs:335-352 for one (window, value)
+    // dsp.rs:335-352 for one (window, value).  CHECK = false: the caller has established that CompensatedPair::refresh cannot fire
+    // in this batch (refresh + batch < cap), the common case, and gets straight-line code
+    template <bool CHECK>
+    __device__ __forceinline__ void push(double v, double old) {
         kbn_add(s0, c0, v);
         kbn_add(s1, c1, v);
         kbn_add(s0, c0, -old);  // old == 0.0 until the window is full
         unfilled -= unfilled != 0u ? 1u : 0u;
-        if (++refresh == cap) {
-            s0 = s1;
-            s1 = 0.0;
-            c0 = c1;
-            c1 = 0.0;
-            refresh = 0;
+        ++refresh;
+        if constexpr (CHECK) {
+            if (refresh == cap) {
+                s0 = s1;
+                s1 = 0.0;
+                c0 = c1;
+                c1 = 0.0;
+                refresh = 0;
+            }
         }
     }
     __device__ __forceinline__ double mean(uint64_t pushes, uint32_t ring_len) const {  // dsp.rs:367-370
@@ -81,8 +91,8 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     wh1.init(st.hist[1], a.slow_len, a.pushes);
     uint32_t head_c = (uint32_t)(a.pushes % a.color_len), head_h = (uint32_t)(a.pushes % a.slow_len);
     uint64_t pushes = a.pushes;
-    float* cring = a.color_ring + gid;
-    float* hring = a.hist_ring + gid;
+    float* cring = a.color_ring + (s < a.n_streams ? gid : 0u);  // lanes past the last stream read column 0 (discarded), store nothing
+    float* hring = a.hist_ring + (s < a.n_streams ? gid : 0u);
     const float* pcm = a.pcm + (uint64_t)(live ? s : 0) * a.frames * a.fmt.channels;
     double phase = a.column_phase;
     uint64_t col = 0;
@@ -115,94 +125,94 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         dst->rms_db[1][band] = rms1;
     };
 
+    // hp_lo runs on every lane and is selected by band (a divergent `if (use_a)` costs the other bands the same instructions
+    // anyway); its state only matters on the mid-band lanes
     for (uint64_t f0 = 0; f0 < a.frames; f0 += B) {
         const uint32_t nb = (uint32_t)min((uint64_t)B, a.frames - f0);
         float lr[B][2];
         float old_c[B], old_h0[B], old_h1[B];
+        // every load of the batch is unconditional (clamped frame index, always-valid ring slots; non-live lanes point at
+        // stream 0 / their own padding column): a conditional load waits for its data on the spot and serialises the batch.
+        // What must not be used is discarded where it is consumed.
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-            lr[k][0] = lr[k][1] = 0.0f;
-            old_c[k] = old_h0[k] = old_h1[k] = 0.0f;
-            if (live && (uint32_t)k < nb) {
-                const float* frame = pcm + (f0 + k) * a.fmt.channels;
-                float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
-                for (uint32_t c = 0; c < a.fmt.channels; ++c) {
-                    const float v = frame[c];
-                    left = left + v * a.fmt.m[c][0];
-                    right = right + v * a.fmt.m[c][1];
-                }
-                lr[k][0] = left;
-                lr[k][1] = right;
-                if (analyze) {  // expiring values, read before this batch's stores (windows >= B samples long)
-                    if ((uint32_t)k >= wc.unfilled) old_c[k] = cring[(uint64_t)expiring_index(head_c, k, a.color_len, a.color_len) * row];
-                    if (history) {
-                        if ((uint32_t)k >= wh0.unfilled) old_h0[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.color_len) * row];
-                        if ((uint32_t)k >= wh1.unfilled) old_h1[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.slow_len) * row];
+            const uint32_t kc = (uint32_t)k < nb ? (uint32_t)k : nb - 1u;
+            const float* frame = pcm + (f0 + kc) * a.fmt.channels;
+            float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
+            for (uint32_t c = 0; c < a.fmt.channels; ++c) {
+                const float v = frame[c];
+                left = left + v * a.fmt.m[c][0];
+                right = right + v * a.fmt.m[c][1];
+            }
+            lr[k][0] = left;
+            lr[k][1] = right;
+            // expiring values, read before this batch's stores (windows >= B samples long)
+            old_c[k] = cring[(uint64_t)expiring_index(head_c, k, a.color_len, a.color_len) * row];
+            old_h0[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.color_len) * row];
+            old_h1[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.slow_len) * row];
+        }
+        // samples of this batch that precede a window's first expiring value (dsp.rs:336-338), fixed before the pushes move them
+        const uint32_t unf_c = wc.unfilled, unf_h0 = wh0.unfilled, unf_h1 = wh1.unfilled;
+        auto samples = [&](auto check_c) {
+            constexpr bool CHECK = decltype(check_c)::value;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                if ((uint32_t)k >= nb) break;
+                const float left = lr[k][0], right = lr[k][1];
+                // derived_frame (:123-125): Left, Right, Mid, Side
+                const float derived = ch == 0 ? left : (ch == 1 ? right : (ch == 2 ? (left + right) * 0.5f : (left - right) * 0.5f));
+                const bool fin = isfinite(derived);
+                if (a.analyze != 0) {  // :258-272 (uniform; non-live lanes compute on zeros and store nothing)
+                    float xl = isfinite(left) ? left : 0.0f, xr = isfinite(right) ? right : 0.0f;
+                    // mid = LP_high(HP_low(x))  (CASCADE_HIGH = false: the high band takes the raw sample)
+                    const float hl = biquad_step(a.hp_lo, st.za[0], xl), hr = biquad_step(a.hp_lo, st.za[1], xr);
+                    xl = use_a ? hl : xl;
+                    xr = use_a ? hr : xr;
+                    const float bl = biquad_step(cb, st.zb[0], xl), br = biquad_step(cb, st.zb[1], xr);
+                    float v = ch == 0 ? bl : (ch == 1 ? br : (ch == 2 ? (bl + br) * 0.5f : (bl - br) * 0.5f));
+                    v = fin ? v : 0.0f;
+                    // BandTracker::process (:108-121)
+                    float cv = fabsf(v) * gain;
+                    cv = isfinite(cv) ? cv : 0.0f;
+                    wc.template push<CHECK>((double)cv, (uint32_t)k >= unf_c ? (double)old_c[k] : 0.0);
+                    if (analyze) cring[(uint64_t)head_c * row] = cv;
+                    head_c = head_c + 1 == a.color_len ? 0 : head_c + 1;
+                    if (a.track_history != 0) {
+                        float pw = v * v;
+                        pw = isfinite(pw) ? pw : 0.0f;
+                        wh0.template push<CHECK>((double)pw, (uint32_t)k >= unf_h0 ? (double)old_h0[k] : 0.0);
+                        wh1.template push<CHECK>((double)pw, (uint32_t)k >= unf_h1 ? (double)old_h1[k] : 0.0);
+                        if (history) hring[(uint64_t)head_h * row] = pw;
+                        head_h = head_h + 1 == a.slow_len ? 0 : head_h + 1;
                     }
+                    ++pushes;
+                }
+                // ingest_derived (:275-291), as selects
+                const bool some = st.cur_some != 0;
+                st.cur_min = fin ? (some ? fminf(st.cur_min, derived) : derived) : st.cur_min;
+                st.cur_max = fin ? (some ? fmaxf(st.cur_max, derived) : derived) : st.cur_max;
+                st.cur_last = fin ? derived : st.cur_last;
+                st.cur_has_last = fin ? 1 : (some ? 0 : st.cur_has_last);
+                st.cur_some = fin ? 1 : st.cur_some;
+                st.last_valid = fin ? st.last_valid : 0;
+                phase += a.step;
+                if (phase >= 1.0) {  // emit_column (:237-250); uniform over the wavefront
+                    if (live && col >= a.first_kept)
+                        write_column(a.columns + ((uint64_t)s * (a.n_emit - a.first_kept) + (col - a.first_kept)) * 4 + ch);
+                    if (st.cur_some && st.cur_has_last) {
+                        st.last_valid = 1;
+                        st.last_sample = st.cur_last;
+                    }
+                    st.cur_some = 0;
+                    st.cur_has_last = 0;
+                    ++col;
+                    phase -= 1.0;
                 }
             }
-        }
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            if ((uint32_t)k >= nb) break;
-            const float left = lr[k][0], right = lr[k][1];
-            // derived_frame (:123-125): Left, Right, Mid, Side
-            const float derived = ch == 0 ? left : (ch == 1 ? right : (ch == 2 ? (left + right) * 0.5f : (left - right) * 0.5f));
-            const bool fin = isfinite(derived);
-            if (analyze) {  // :258-272
-                float xl = isfinite(left) ? left : 0.0f, xr = isfinite(right) ? right : 0.0f;
-                if (use_a) {  // mid = LP_high(HP_low(x))  (CASCADE_HIGH = false: the high band takes the raw sample)
-                    xl = biquad_step(a.hp_lo, st.za[0], xl);
-                    xr = biquad_step(a.hp_lo, st.za[1], xr);
-                }
-                const float bl = biquad_step(cb, st.zb[0], xl), br = biquad_step(cb, st.zb[1], xr);
-                float v = ch == 0 ? bl : (ch == 1 ? br : (ch == 2 ? (bl + br) * 0.5f : (bl - br) * 0.5f));
-                if (!fin) v = 0.0f;
-                // BandTracker::process (:108-121)
-                float cv = fabsf(v) * gain;
-                cv = isfinite(cv) ? cv : 0.0f;
-                wc.push((double)cv, (double)old_c[k]);
-                cring[(uint64_t)head_c * row] = cv;
-                head_c = head_c + 1 == a.color_len ? 0 : head_c + 1;
-                if (history) {
-                    float pw = v * v;
-                    pw = isfinite(pw) ? pw : 0.0f;
-                    wh0.push((double)pw, (double)old_h0[k]);
-                    wh1.push((double)pw, (double)old_h1[k]);
-                    hring[(uint64_t)head_h * row] = pw;
-                    head_h = head_h + 1 == a.slow_len ? 0 : head_h + 1;
-                }
-                ++pushes;
-            }
-            // ingest_derived (:275-291)
-            if (fin) {
-                if (st.cur_some) {
-                    st.cur_min = fminf(st.cur_min, derived);
-                    st.cur_max = fmaxf(st.cur_max, derived);
-                } else {
-                    st.cur_some = 1;
-                    st.cur_min = st.cur_max = derived;
-                }
-                st.cur_has_last = 1;
-                st.cur_last = derived;
-            } else {
-                if (st.cur_some) st.cur_has_last = 0;
-                st.last_valid = 0;
-            }
-            phase += a.step;
-            if (phase >= 1.0) {  // emit_column (:237-250)
-                if (live && col >= a.first_kept)
-                    write_column(a.columns + ((uint64_t)s * (a.n_emit - a.first_kept) + (col - a.first_kept)) * 4 + ch);
-                if (st.cur_some && st.cur_has_last) {
-                    st.last_valid = 1;
-                    st.last_sample = st.cur_last;
-                }
-                st.cur_some = 0;
-                st.cur_has_last = 0;
-                ++col;
-                phase -= 1.0;
-            }
-        }
+        };
+        const bool may_refresh = wc.refresh + (uint32_t)B >= wc.cap || wh0.refresh + (uint32_t)B >= wh0.cap || wh1.refresh + (uint32_t)B >= wh1.cap;
+        if (may_refresh) samples(std::true_type{});
+        else samples(std::false_type{});
     }
     // BandFilter::flush_denormals once per block (:321-323)
     if (analyze) {
