@@ -12,8 +12,18 @@ namespace omx {
 
 namespace {
 __device__ __forceinline__ void kbn_add(double& sum, double& corr, double v) {  // dsp.rs:277-285
+    // (big, small) picked first: one branch's two f64 operations instead of both branches' four — same operands, same order
     const double next = sum + v;
-    corr += (fabs(sum) >= fabs(v)) ? (sum - next) + v : (v - next) + sum;
+    const bool sum_is_big = fabs(sum) >= fabs(v);
+    const double big = sum_is_big ? sum : v, small = sum_is_big ? v : sum;
+    corr += (big - next) + small;
+    sum = next;
+}
+// the `since refresh` pair only ever adds values >= +0.0 to a sum that starts at +0.0: |sum| >= |v| is sum >= v and
+// (big, small) = (max, min) — same operands again
+__device__ __forceinline__ void kbn_add_nonneg(double& sum, double& corr, double v) {
+    const double next = sum + v;
+    corr += (fmax(sum, v) - next) + fmin(sum, v);
     sum = next;
 }
 // Biquad::process (dsp.rs:422-432) with the non-finite reset as selects: the lanes of a wavefront carry different channels and
@@ -38,7 +48,7 @@ struct Window {  // one WindowedMeans window of one value
     template <bool CHECK>
     __device__ __forceinline__ void push(double v, double old) {
         kbn_add(s0, c0, v);
-        kbn_add(s1, c1, v);
+        kbn_add_nonneg(s1, c1, v);  // v is |band value| x gain or a squared band value, NaN / inf already zeroed (:108-121)
         kbn_add(s0, c0, -old);  // old == 0.0 until the window is full
         unfilled -= unfilled != 0u ? 1u : 0u;
         ++refresh;
@@ -71,7 +81,8 @@ __device__ __forceinline__ uint32_t expiring_index(uint32_t head, uint32_t k, ui
 }
 }  // namespace
 
-template <int B>
+// ANALYZE / HISTORY: the configuration's band analysis and RMS history, compile-time so that a frame's code is one basic block
+template <int B, bool ANALYZE, bool HISTORY>
 __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x;  // stream * 16 + lane
     const uint32_t s = gid >> 4, ln = gid & 15;
@@ -97,6 +108,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     double phase = a.column_phase;
     uint64_t col = 0;
     const bool minmax_lane = live && band == 0;
+    const bool two_channels = a.fmt.channels == 2;
 
     auto write_column = [&](omx_wave_column* dst) {  // column_for (:213-235) for this lane's fields
         if (minmax_lane) {
@@ -139,10 +151,16 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
             const uint32_t kc = (uint32_t)k < nb ? (uint32_t)k : nb - 1u;
             const float* frame = pcm + (f0 + kc) * a.fmt.channels;
             float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
-            for (uint32_t c = 0; c < a.fmt.channels; ++c) {
-                const float v = frame[c];
-                left = left + v * a.fmt.m[c][0];
-                right = right + v * a.fmt.m[c][1];
+            if (two_channels) {  // uniform; the common shape without a runtime trip count
+                const float2 x = *reinterpret_cast<const float2*>(frame);
+                left = 0.0f + x.x * a.fmt.m[0][0] + x.y * a.fmt.m[1][0];
+                right = 0.0f + x.x * a.fmt.m[0][1] + x.y * a.fmt.m[1][1];
+            } else {
+                for (uint32_t c = 0; c < a.fmt.channels; ++c) {
+                    const float v = frame[c];
+                    left = left + v * a.fmt.m[c][0];
+                    right = right + v * a.fmt.m[c][1];
+                }
             }
             lr[k][0] = left;
             lr[k][1] = right;
@@ -153,16 +171,18 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         }
         // samples of this batch that precede a window's first expiring value (dsp.rs:336-338), fixed before the pushes move them
         const uint32_t unf_c = wc.unfilled, unf_h0 = wh0.unfilled, unf_h1 = wh1.unfilled;
-        auto samples = [&](auto check_c) {
-            constexpr bool CHECK = decltype(check_c)::value;
+        auto samples = [&](auto check_c, auto tail_c, auto emit_c) {
+            constexpr bool CHECK = decltype(check_c)::value, TAIL = decltype(tail_c)::value, EMIT = decltype(emit_c)::value;
 #pragma unroll
             for (int k = 0; k < B; ++k) {
-                if ((uint32_t)k >= nb) break;
+                if constexpr (TAIL) {
+                    if ((uint32_t)k >= nb) break;
+                }
                 const float left = lr[k][0], right = lr[k][1];
                 // derived_frame (:123-125): Left, Right, Mid, Side
                 const float derived = ch == 0 ? left : (ch == 1 ? right : (ch == 2 ? (left + right) * 0.5f : (left - right) * 0.5f));
                 const bool fin = isfinite(derived);
-                if (a.analyze != 0) {  // :258-272 (uniform; non-live lanes compute on zeros and store nothing)
+                if constexpr (ANALYZE) {  // :258-272 (non-live lanes compute on a neighbour's frames and store nothing)
                     float xl = isfinite(left) ? left : 0.0f, xr = isfinite(right) ? right : 0.0f;
                     // mid = LP_high(HP_low(x))  (CASCADE_HIGH = false: the high band takes the raw sample)
                     const float hl = biquad_step(a.hp_lo, st.za[0], xl), hr = biquad_step(a.hp_lo, st.za[1], xr);
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                     wc.template push<CHECK>((double)cv, (uint32_t)k >= unf_c ? (double)old_c[k] : 0.0);
                     if (analyze) cring[(uint64_t)head_c * row] = cv;
                     head_c = head_c + 1 == a.color_len ? 0 : head_c + 1;
-                    if (a.track_history != 0) {
+                    if constexpr (HISTORY) {
                         float pw = v * v;
                         pw = isfinite(pw) ? pw : 0.0f;
                         wh0.template push<CHECK>((double)pw, (uint32_t)k >= unf_h0 ? (double)old_h0[k] : 0.0);
@@ -196,6 +216,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                 st.cur_some = fin ? 1 : st.cur_some;
                 st.last_valid = fin ? st.last_valid : 0;
                 phase += a.step;
+                if constexpr (!EMIT) continue;  // the caller has replayed the phase additions: no column ends in this batch
                 if (phase >= 1.0) {  // emit_column (:237-250); uniform over the wavefront
                     if (live && col >= a.first_kept)
                         write_column(a.columns + ((uint64_t)s * (a.n_emit - a.first_kept) + (col - a.first_kept)) * 4 + ch);
@@ -211,8 +232,21 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
             }
         };
         const bool may_refresh = wc.refresh + (uint32_t)B >= wc.cap || wh0.refresh + (uint32_t)B >= wh0.cap || wh1.refresh + (uint32_t)B >= wh1.cap;
-        if (may_refresh) samples(std::true_type{});
-        else samples(std::false_type{});
+        // does a column end inside this batch?  Replay the f64 phase additions (they are the reference's, bit for bit)
+        bool emits = false;
+        {
+            double ph = phase;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                ph += a.step;
+                emits = emits || ph >= 1.0;
+            }
+        }
+        using T = std::true_type;
+        using F = std::false_type;
+        if (nb == (uint32_t)B && !emits && !may_refresh) samples(F{}, F{}, F{});  // the straight-line batch
+        else if (nb == (uint32_t)B && !emits) samples(T{}, F{}, F{});
+        else samples(T{}, T{}, T{});
     }
     // BandFilter::flush_denormals once per block (:321-323)
     if (analyze) {
@@ -234,8 +268,15 @@ void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
     if (a.n_streams == 0) return;
     const uint32_t threads = a.n_streams * 16;
     const dim3 grid((threads + 63) / 64);
-    if (a.color_len >= 8 && a.slow_len >= 8) hipLaunchKernelGGL(waveform_kernel<8>, grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(waveform_kernel<1>, grid, dim3(64), 0, stream, a);
+    const bool analyze = a.analyze != 0, history = analyze && a.track_history != 0;
+    auto launch = [&](auto b_c) {
+        constexpr int B = decltype(b_c)::value;
+        if (history) hipLaunchKernelGGL((waveform_kernel<B, true, true>), grid, dim3(64), 0, stream, a);
+        else if (analyze) hipLaunchKernelGGL((waveform_kernel<B, true, false>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((waveform_kernel<B, false, false>), grid, dim3(64), 0, stream, a);
+    };
+    if (a.color_len >= 8 && a.slow_len >= 8) launch(std::integral_constant<int, 8>{});
+    else launch(std::integral_constant<int, 1>{});
 }
 
 }  // namespace omx
