@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X-native OpenMeters DSP hot path.
 
-Metric (BASELINE.json): STFT frames/s (4096-pt Hann, hop 256, time-frequency reassignment on) +
-achieved HBM GB/s vs the 8 TB/s roofline, on config[1]:
-    64 streams x 2 ch, 48 kHz f32, Spectrogram{4096, hop 256, Hann, reassigned} (+ A-weighted Spectrum
-    {4096, hop 256, Hann} once its bank is built — reported in `config.spectrum`).
+Metric (BASELINE.json): STFT frames/s (4096-pt Hann, hop 256, time-frequency reassignment on) + achieved HBM GB/s vs the
+8 TB/s roofline.
 
-A "step" is one pass of the hot path over one batch of synthetic PCM per stream (`--frames-per-step`
-new samples per stream, already resident in HBM): K0 ingest (stereo fold + Mid projection into the
-per-stream rings) + K2 fused reassigned STFT for every ready (stream, hop).
+Workloads (`--config`):
+  cfg2  BASELINE.json configs[1] — the N = 1 default: 64 streams x 2 ch, 48 kHz f32, Spectrogram{4096, hop 256, Hann,
+        reassigned} + A-weighted Spectrum{4096, hop 256, Hann}; one step = 262 144 new frames per stream.
+  cfg5  BASELINE.json configs[4] — the N > 1 default (and `--config cfg5` at N = 1): every GPU owns 1024 contiguous 2-ch
+        streams of the 8192-stream set and runs the FULL pipeline on them (reassigned STFT 4096/256 + BS.1770 loudness +
+        band-split phase correlation, the two recurrence banks on side HIP streams beside the FFT kernel); one step = 16 384
+        new frames per stream (64 STFT columns, 64 blocks of 256); the per-stream summary rows are assembled and all-gathered
+        over RCCL once per step on a side stream.  No data-path collective: streams are independent.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); streams are
-independent, so ranks shard them with no data-path collective (weak scaling: 64 streams per GPU) and
-only all-gather a small per-stream summary once per step.
+A "step" is one pass of the hot path over one batch of synthetic PCM per stream, already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg5]
+
+N > 1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment).  Started WITHOUT those (`python bench.py --gpus 8`), this process spawns exactly that launcher as a child —
+before torch is imported or the GPU is touched, never by re-exec — and relays rank 0's JSON line.
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,44 +35,66 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide: peak FP32 vector
 BYTES_PER_FRAME_DENSE = 256 * 2 * 4 + 4 + 2049 * 12  # 26,640 B/frame (dense column)
-FLOPS_PER_FRAME = 1.80e6        # 2*5*8192*13 + 3*5*4096*12
+FLOPS_PER_FRAME = 1.80e6         # SURVEY §8(d), the REFERENCE algorithm: 2*5*8192*13 + 3*5*4096*12
+# what the kernel executes (5 N log2 N per complex transform): one packed-real forward + one inverse for the Hilbert pair
+# (single-IFFT shortcut) + the windowed 4096-point transforms of the kernel form in use
+FLOPS_PER_FFT4096 = 5.0 * 4096 * 12
+TOTAL_STREAMS_CFG5 = 8192
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--frames-per-step", type=int, default=256 * 1024, help="new PCM frames per stream per step")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=("auto", "cfg2", "cfg5"), default="auto",
+                    help="auto = cfg2 (BASELINE configs[1]) at N = 1, cfg5 (configs[4], 1024 streams per GPU, full pipeline) at N > 1")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default 64 for cfg2, 1024 for cfg5)")
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="new PCM frames per stream per step (default 262144 for cfg2, 16384 for cfg5)")
     ap.add_argument("--cpu-columns", type=int, default=8192, help="columns per stream in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-spectrum", action="store_true", help="leave the A-weighted spectrum bank out of the step")
+    ap.add_argument("--no-spectrum", action="store_true", help="cfg2: leave the A-weighted spectrum bank out of the step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 side measurements (N = 1 only)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / gather check without device work (CPU tests: OMX_BENCH_BACKEND=gloo)")
+    return ap.parse_args(argv)
 
 
-def synth_pcm(torch, device, n_streams, frames, stream0):
-    """cfg2 generator: per-stream exponential sweep 20 Hz -> 20 kHz over 10 s, start phase
-    2*pi*s/64, amplitude 0.5, R = 0.8 L, plus -60 dBFS white noise; generated on the GPU."""
-    t = torch.arange(frames, device=device, dtype=torch.float64) / 48000.0
-    k = float(np.log(1000.0))
-    seconds = 10.0
-    base = 2.0 * np.pi * 20.0 * seconds / k * (torch.exp((t % seconds) / seconds * k) - 1.0)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(0x9E3779B9 + stream0)
-    pcm = torch.empty((n_streams, frames, 2), device=device, dtype=torch.float32)
-    for s in range(n_streams):
-        phase0 = 2.0 * np.pi * ((stream0 + s) % 64) / 64.0
-        left = (0.5 * torch.sin(base + phase0)).to(torch.float32)
-        left += (torch.rand(frames, device=device, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * 1e-3
-        pcm[s, :, 0] = left
-        pcm[s, :, 1] = 0.8 * left
-    return pcm.contiguous()
+# ------------------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no RANK in the environment: start N rank processes through torch.distributed.run as a
+    CHILD of this (GPU-untouched, torch-unimported) process and pass rank 0's JSON line through."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit code {proc.returncode}, result line {'present' if line else 'missing'})",
+              file=sys.stderr)
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        print(f"bench.py: the ranks report n_gpus != {args.gpus}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 class DeviceView:
@@ -76,55 +105,116 @@ class DeviceView:
                                          "version": 2, "strides": None}
 
 
+# ------------------------------------------------------------------------------------------------------------ CPU leg
 def cpu_baseline(columns, log):
-    """Times the CPU oracle (kind "port": our C++ restatement, the reference's Rust cannot be built
-    here) on a bounded sample of the same workload, on this node's host cores."""
+    """The CPU oracle (kind "port": our C++ restatement — the reference's Rust cannot be built here) timed on this node's host
+    cores on a bounded sample of the same workload: SURVEY §8(d) — `-O3 -march=native`, 1 thread and
+    T = hardware_concurrency threads (streams statically partitioned), cfg2 shape and cfg1 (1024-pt classic) shape."""
+    import tempfile
     from openmeters_amd import capi
-    lib_path = os.path.join(ROOT, "oracle", "libomx_oracle.so")
-    if not os.path.exists(lib_path):
-        import subprocess
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    import workloads
+    # -march=native objects do not travel between hosts: build in a temp dir of THIS host, every time
+    build_dir = tempfile.mkdtemp(prefix="omx_oracle_native_")
+    lib_path = os.path.join(build_dir, "libomx_oracle_native.so")
+    flags = "-O3 -march=native"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native", f"NATIVE_OUT={lib_path}"], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(lib_path):
+        log("cpu_baseline: native build failed, falling back to the -O2 oracle:\n" + r.stderr[-500:])
+        lib_path, flags = os.path.join(ROOT, "oracle", "libomx_oracle.so"), "-O2"
+        if not os.path.exists(lib_path):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     oracle = capi.Api(lib_path, "omxo_")
     f = oracle.lib.omxo_bench_spectrogram
     f.restype = C.c_double
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    frames = 8192 + 256 * (columns - 1)
-    cfg = capi.SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192, use_reassignment=True).to_c()
+    try:
+        cores = len(os.sched_getaffinity(0)) or cores
+    except (AttributeError, OSError):
+        pass
+    threads = cores
 
-    def exp_sweep(n, phase0):  # SURVEY §8(d) cfg2 generator (same formula as tests/signals.py)
-        t = np.arange(n, dtype=np.float64) / 48000.0
-        k = np.log(1000.0)
-        return (0.5 * np.sin(2.0 * np.pi * 20.0 * 10.0 / k * (np.exp((t % 10.0) / 10.0 * k) - 1.0) + phase0)).astype(np.float32)
-
-    rng = np.random.default_rng(1234)
-    out = {}
-    for label, T, S in (("single_thread", 1, 1), ("all_threads", threads, threads)):
-        pcm = np.empty((S, frames, 2), np.float32)
-        for s in range(S):
-            left = exp_sweep(frames, phase0=2 * np.pi * s / 64) + (rng.random(frames, dtype=np.float32) * 2 - 1) * 1e-3
-            pcm[s, :, 0] = left
-            pcm[s, :, 1] = 0.8 * left
+    def run(cfg, pcm, T):
+        S, frames = pcm.shape[0], pcm.shape[1]
         cols = C.c_uint64()
         secs = f(C.byref(cfg), pcm.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint64(S), C.c_uint64(frames), C.c_uint32(2),
                  C.c_uint64(256), C.c_uint32(T), C.byref(cols))
-        out[label] = cols.value / secs
-        log(f"cpu_baseline {label}: {cols.value} frames in {secs:.2f} s on {T} thread(s)")
+        return cols.value, secs
+
+    out = {}
+    # cfg2 shape: reassigned 4096 / hop 256, blocks of 256 frames (the DspBatcher quantum)
+    cfg = capi.SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192, use_reassignment=True).to_c()
+    frames = 8192 + 256 * (columns - 1)
+    one = workloads.cfg2_bank(0, 1, frames)
+    n, secs = run(cfg, one, 1)
+    out["single_thread"] = n / secs
+    log(f"cpu_baseline cfg2 shape, 1 thread: {n} frames in {secs:.2f} s")
+    reps = -(-threads // 8)
+    many = np.tile(workloads.cfg2_bank(0, min(threads, 8), frames), (reps, 1, 1))[:threads]  # T streams (8 distinct ones, tiled)
+    n, secs = run(cfg, np.ascontiguousarray(many), threads)
+    out["all_threads"] = n / secs
+    log(f"cpu_baseline cfg2 shape, {threads} threads: {n} frames in {secs:.2f} s")
+    # cfg1 (BASELINE configs[0], the reference's own CPU case): 1024-pt Hann classic, hop 256
+    cfg1 = capi.SpectrogramConfig(fft_size=1024, hop_size=256, history_length=8192, use_reassignment=False).to_c()
+    frames1 = 1024 + 256 * (8 * columns - 1)
+    p1 = workloads.cfg1_pcm(frames1)[None]
+    n1, s1 = run(cfg1, np.ascontiguousarray(p1), 1)
+    nT, sT = run(cfg1, np.ascontiguousarray(np.tile(p1, (threads, 1, 1))), threads)
+    log(f"cpu_baseline cfg1 (classic 1024/256): 1 thread {n1 / s1:.0f} frames/s, {threads} threads {nT / sT:.0f} frames/s")
     return {"value": out["all_threads"], "unit": "frames/s", "cores": threads, "kind": "port",
             "single_thread": out["single_thread"],
-            "sample": f"{threads} streams x {columns} reassigned 4096/256 columns each (blocks of 256 frames), "
-                      f"C++ oracle -O2, {threads} threads; {cores} host cores visible"}
+            "cfg1_classic_1024": {"single_thread": n1 / s1, "all_threads": nT / sT, "unit": "frames/s",
+                                  "sample": f"{8 * columns} columns per stream, 1 and {threads} streams"},
+            "sample": f"{threads} streams x {columns} reassigned 4096/256 columns each (blocks of 256 frames), C++ oracle "
+                      f"{flags} -ffp-contract=off, {threads} threads = every host core visible to the process; "
+                      f"single_thread = 1 stream x {columns} columns"}
 
 
+# ------------------------------------------------------------------------------------------------------------ rank body
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}) or drop RANK/WORLD_SIZE")
     log = (lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
+    config = args.config if args.config != "auto" else ("cfg2" if world == 1 else "cfg5")
+    S = args.streams or (64 if config == "cfg2" else 1024)
+    F = args.frames_per_step or (256 * 1024 if config == "cfg2" else 16384)
+    hop, W = 256, 4096
+    cols_per_step = F // hop
+    if cols_per_step > 8192 or F % 256:
+        raise SystemExit("frames-per-step must be a multiple of 256 and frames-per-step / hop <= 8192 (history retention clamp)")
 
     import torch
     import torch.distributed as dist
+    from openmeters_amd.sharding import STATS_COLUMNS, gather_stats, shard_streams
+
+    backend = os.environ.get("OMX_BENCH_BACKEND", "nccl")  # "gloo": test hook to exercise N > 1 on a 1-GPU (or GPU-less) box
+    if args.dry_run:
+        # launcher / rendezvous / shard map / gather, no device work
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        total = S * world
+        first, count = shard_streams(total, rank, world)
+        local = torch.zeros((count, len(STATS_COLUMNS)), dtype=torch.float32)
+        local[:, 7] = torch.arange(first, first + count, dtype=torch.float32)
+        table = gather_stats(local, total)
+        assert table.shape == (total, len(STATS_COLUMNS)) and torch.equal(table[:, 7], torch.arange(total, dtype=torch.float32))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "STFT frames/s (4096-pt Hann, hop 256, reassignment on)", "value": None, "unit": "frames/s",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
+                              "config": {"workload": config, "streams_per_gpu": S, "gathered_rows": int(table.shape[0])}}), flush=True)
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -132,7 +222,6 @@ def main():
     dev_index = local_rank % max(n_dev, 1)  # == local_rank on a real multi-GPU node
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    backend = os.environ.get("OMX_BENCH_BACKEND", "nccl")  # "gloo": test hook to exercise N > 1 on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -143,55 +232,74 @@ def main():
     import openmeters_amd
     from openmeters_amd import capi
     from openmeters_amd.banks import SpectrogramBank, SpectrumBank
-    from openmeters_amd.sharding import STATS_COLUMNS, gather_stats
+    from openmeters_amd.pipeline import FullPipeline
+    import workloads
 
     api = openmeters_amd.api()
     assert openmeters_amd.device_available()
-
-    S, F = args.streams, args.frames_per_step
-    hop, W = 256, 4096
-    cfg = capi.SpectrogramConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
-                                 history_length=8192, use_reassignment=True, zero_padding_factor=1)
-    cols_per_step = F // hop
-    if cols_per_step > 8192:
-        raise SystemExit("frames-per-step / hop must stay <= 8192 (history retention clamp, SURVEY §7)")
-    pcm = synth_pcm(torch, device, S, F, stream0=rank * S)
+    stream0 = rank * S
+    # cfg2 / cfg5 share one generator: sweep with start phase 2 pi s / 64 + xorshift32 noise at -60 dBFS
+    t_gen = time.perf_counter()
+    pcm = torch.from_numpy(workloads.cfg2_bank(stream0, S, F)).to(device).contiguous()
     torch.cuda.synchronize()
+    log(f"synthetic PCM: streams {stream0}..{stream0 + S - 1}, {F} frames each, generated in {time.perf_counter() - t_gen:.1f} s")
     stream = torch.cuda.current_stream().cuda_stream
-    bank = SpectrogramBank(api, cfg, S)
-    spectrum = None
-    if not args.no_spectrum:
-        # "+ A-weighted spectrum" of configs[1]: Spectrum{4096, hop 256, Hann, averaging None, source Mid}; every hop
-        # is materialised (what the reference computes when fed one hop per block)
-        spectrum = SpectrumBank(api, capi.SpectrumConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
-                                                         averaging_mode=capi.AVG_NONE, source=capi.CH_MID,
-                                                         secondary_source=capi.CH_NONE, floor_db=-100.0), S, emit_all_hops=True)
     positions = capi.positions_fallback(2)
+    side = torch.cuda.Stream(device=device)
 
-    # K8 runs beside the data path: the per-stream counts are snapshotted on the compute stream (the bank reuses its output
-    # buffers every call), then the summary rows are assembled and all-gathered over RCCL/xGMI on a second HIP stream while
-    # the next step's kernels run (48 B/stream: latency-bound, must not sit between two K2 launches)
-    side = torch.cuda.Stream(device=device) if world > 1 else None
+    def gather_on_side(make_rows, keep_alive):
+        """K8: summary rows assembled and all-gathered on the side stream while the next step's kernels run"""
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            rows = make_rows()
+            gather_stats(rows if backend == "nccl" else rows.cpu(), world * S)
+            for t in keep_alive:
+                t.record_stream(side)
 
-    def step():
-        up = bank.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
-        if spectrum is not None:
-            spectrum.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
-        if world > 1 and up is not None:
-            counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).clone()
-            n_columns = float(up.n_columns)
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                cf = counts.to(torch.float32)
-                stats = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
-                stats[:, 7] = n_columns
-                stats[:, 8] = cf.mean(dim=1)
-                stats[:, 9] = cf[:, -1]
-                gather_stats(stats if backend == "nccl" else stats.cpu(), world * S)
-                counts.record_stream(side)
-        return up
+    spectrum = None
+    if config == "cfg2":
+        cfg = capi.SpectrogramConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
+                                     history_length=8192, use_reassignment=True, zero_padding_factor=1)
+        bank = SpectrogramBank(api, cfg, S)
+        if not args.no_spectrum:
+            # "+ A-weighted spectrum" of configs[1]: Spectrum{4096, hop 256, Hann, averaging None, source Mid}; every hop is
+            # materialised (what the reference computes when fed one hop per block)
+            spectrum = SpectrumBank(api, capi.SpectrumConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
+                                                             averaging_mode=capi.AVG_NONE, source=capi.CH_MID,
+                                                             secondary_source=capi.CH_NONE, floor_db=-100.0), S, emit_all_hops=True)
+
+        def step():
+            up = bank.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
+            if spectrum is not None:
+                spectrum.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
+            if world > 1 and up is not None:
+                counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).clone()
+                n_columns = float(up.n_columns)
+
+                def rows():
+                    cf = counts.to(torch.float32)
+                    stats = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
+                    stats[:, 7] = n_columns
+                    stats[:, 8] = cf.mean(dim=1)
+                    stats[:, 9] = cf[:, -1]
+                    return stats
+                gather_on_side(rows, [counts])
+            return up
+    else:
+        pipe = FullPipeline(api, S)
+        bank = pipe.spectrogram
+
+        def step():
+            up, snaps, st, n_blocks = pipe.step_concurrent(torch, pcm.data_ptr(), F)
+            if up is not None:
+                # the banks reuse their output buffers every call: the rows are assembled on the compute stream (a few
+                # small torch ops over device-resident outputs), the all-gather itself rides the side stream
+                rows = pipe.stats(torch, device, up, snaps, st, n_blocks)
+                if world > 1:
+                    gather_on_side(lambda: rows, [rows])
+            return up
 
     for _ in range(args.warmup):
         step()
@@ -215,30 +323,39 @@ def main():
         elapsed = float(te.item())
 
     kernel_ms, launches = bank.kernel_time()
+    assert last is not None and last.n_columns == cols_per_step, (last.n_columns if last else None, cols_per_step)
     counts = torch.as_tensor(DeviceView(last.d_counts, (S, last.n_columns), "<i4"), device=device)
     mean_points = float(counts.to(torch.float64).mean().item())
-    assert last.n_columns == cols_per_step, (last.n_columns, cols_per_step)
 
     frames_total = world * S * cols_per_step * args.steps
     value = frames_total / elapsed
     frames_per_launch = S * cols_per_step
     bytes_per_frame = hop * 2 * 4 + 4 + mean_points * 12.0  # PCM once + count + points actually written
-    achieved_gbs = frames_per_launch * bytes_per_frame / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside this process): the newest
-    # profiles/*_traffic.json written by tools/profile_bench.sh + tools/summarize_pmc.py for this same workload, else null.
+    per_s = frames_per_launch / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    achieved_gbs = per_s * bytes_per_frame / 1e9
+    transforms = api.fn("debug_transforms_per_frame", C.c_int, [])()
+    executed_flops = transforms * FLOPS_PER_FFT4096
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside
+    # this process): tools/profile_bench.sh writes profiles/<tag>_traffic.json with the git commit and kernel_ms of THAT run.
+    # It is echoed here only as a tagged record of that profile, never as a measurement of this run.
     traffic, traffic_source = None, None
     try:
         import glob
-        here = os.path.dirname(os.path.abspath(__file__))
-        for path in sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
             with open(path) as fh:
                 rec = json.load(fh)
             w = rec.get("workload", {})
-            if w.get("streams_per_gpu") == S and w.get("columns_per_step_per_gpu") == frames_per_launch:
-                traffic, traffic_source = rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
+            if w.get("config", "cfg2") == config and w.get("streams_per_gpu") == S and w.get("columns_per_step_per_gpu") == frames_per_launch:
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_source = {"file": "profiles/" + os.path.basename(path), "commit": rec.get("commit"),
+                                  "kernel_ms_of_that_run": rec.get("kernel_ms"), "transforms_per_frame": rec.get("transforms_per_frame")}
                 break
     except Exception:
         pass
+    workload = ("BASELINE.json configs[1]: 64-stream x 2-ch 48 kHz, 4096-pt Hann STFT hop 256, time-frequency reassignment + A-weighted spectrum"
+                if config == "cfg2" else
+                "BASELINE.json configs[4]: 8192 independent 2-ch streams sharded 1024/GPU, full pipeline (reassigned STFT 4096/256 + "
+                "BS.1770 LUFS + band-split correlation), RCCL gather of per-stream stats once per step")
     result = {
         "metric": "STFT frames/s (4096-pt Hann, hop 256, reassignment on)",
         "value": value,
@@ -252,12 +369,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: 64-stream x 2-ch 48 kHz, 4096-pt Hann STFT hop 256, "
-                               "time-frequency reassignment",
+        "config": {"workload": workload, "name": config,
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "columns_per_step_per_gpu": frames_per_launch,
-                   "spectrum": ("A-weighted Spectrum{4096, hop 256, Hann, avg None, Mid}, every hop materialised, in the timed step"
-                                if spectrum is not None else "excluded (--no-spectrum)"),
-                   "parallelism": f"streams sharded x{world}"},
+                   "pipeline": ("Spectrogram{4096, 256, Hann, reassigned}" +
+                                ("" if spectrum is None else " + A-weighted Spectrum{4096, 256, Hann, avg None, Mid}, every hop materialised"))
+                   if config == "cfg2" else
+                   "Spectrogram{4096, 256, Hann, reassigned} || Loudness{BS.1770 M/S LUFS, 4x true peak} || Stereometer{bands, 50 ms} + stats rows + gather",
+                   "noise": "xorshift32(0x9E3779B9 ^ s) at -60 dBFS (SURVEY §8d)",
+                   "parallelism": f"streams sharded x{world}, no data-path collective; all_gather of {len(STATS_COLUMNS)} f32 per stream per step"},
         "roofline": {
             "bound": "hbm",
             "achieved": achieved_gbs,
@@ -272,26 +391,28 @@ def main():
             "bytes_per_frame": bytes_per_frame,
             "bytes_per_frame_dense": BYTES_PER_FRAME_DENSE,
             "mean_points_per_frame": mean_points,
-            "note": "this kernel is VALU/LDS-bound by construction (68 flop/B, SURVEY §8d): see fp32 fraction",
-            "fp32_vector_tflops": frames_per_launch * FLOPS_PER_FRAME / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,
-            "fp32_vector_frac": (frames_per_launch * FLOPS_PER_FRAME / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS)
-            if kernel_ms > 0 else 0.0,
+            "note": "this kernel is VALU/LDS-bound by construction (68 flop/B, SURVEY §8d): see the fp32 fractions",
+            "transforms_per_frame": transforms,
+            "fp32_vector_frac_executed": per_s * executed_flops / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "fp32_vector_frac_reference_algorithm": per_s * FLOPS_PER_FRAME / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
         },
     }
     if rank == 0:
         if world == 1 and not args.no_secondary:
             # BASELINE.json's other single-GPU configurations, measured after the timed region (a few seconds; never part of
-            # `value`): cfg3 loudness, cfg4 oscilloscope + stereometer, cfg5's per-GPU shard of the full pipeline
+            # `value`): cfg3 loudness, cfg4 oscilloscope + stereometer, and the other one of cfg2 / cfg5
             try:
-                del pcm, bank, spectrum
+                del pcm, bank, spectrum, step
+                if config == "cfg5":
+                    del pipe
                 torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_meters
                 import bench_pipeline
-                side = {"cfg3_loudness": bench_meters.loudness(out=sys.stderr)}
-                side.update({"cfg4_" + k: v for k, v in bench_meters.scope_stereo(out=sys.stderr).items()})
-                side["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
-                result["secondary"] = side
+                sec = {"cfg3_loudness": bench_meters.loudness(out=sys.stderr)}
+                sec.update({"cfg4_" + k: v for k, v in bench_meters.scope_stereo(out=sys.stderr).items()})
+                if config == "cfg2":
+                    sec["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
+                result["secondary"] = sec
             except Exception as e:  # the headline line must survive a failure here
                 result["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

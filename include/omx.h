@@ -213,11 +213,19 @@ int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, ui
 /* Diagnostics knobs shared by the banks. */
 enum {
     OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
-    OMX_OPT_FORCE_GENERIC = 2  /* value != 0: route through the generic any-size kernels (A/B checks) */
+    OMX_OPT_FORCE_GENERIC = 2, /* value != 0: route through the generic any-size kernels (A/B checks) */
+    OMX_OPT_KERNEL_FORM = 3    /* spectrogram bank, reassigned 4096 / hop any: which of the equivalent kernel forms runs.
+                                * 0 = tuned kernel (default); 1 = the previous tuned kernel (five transforms per frame);
+                                * 30 = size-templated kernel; 31 = three-kernel form through an HBM scratch.  All compute
+                                * the same columns (tests cross-check them); unknown values are rejected. */
 };
-/* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the OMX_K2_VARIANT=7 build
- * (setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store) */
+/* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the phase-timing builds of the TUNING library
+ * (`make TUNING=1`; setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store).
+ * The product build returns OMX_ERR_UNSUPPORTED. */
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset);
+/* Number of 4096-point complex transforms the default reassigned 4096 kernel executes per frame (bench.py prices the
+ * executed-flop fraction of the FP32 vector peak with it).  No device needed. */
+int omx_debug_transforms_per_frame(void);
 /* same for the oscilloscope kernel with OMX_SCOPE_PHASES=1 (ring push, pre-FFT, FFTs, NSDF + peak, locate, snapshot) */
 int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset);
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);

@@ -38,7 +38,7 @@ AVG_NONE, AVG_EXPONENTIAL, AVG_PEAK_HOLD = range(3)
 # TriggerMode (reference src/visuals/oscilloscope/processor.rs:21-25)
 TRIGGER_ZERO_CROSSING, TRIGGER_STABLE = range(2)
 COLUMN_REASSIGNED, COLUMN_CLASSIC = range(2)
-OPT_KERNEL_TIMING, OPT_FORCE_GENERIC = 1, 2
+OPT_KERNEL_TIMING, OPT_FORCE_GENERIC, OPT_KERNEL_FORM = 1, 2, 3
 
 DEFAULT_SAMPLE_RATE = 48_000.0
 

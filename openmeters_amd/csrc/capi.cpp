@@ -189,9 +189,14 @@ int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset) {
         return (int)SCOPE_PHASES;
     });
 }
+int omx_debug_transforms_per_frame(void) { return stft_reassigned_4096_transforms_per_frame(); }
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;
     REQUIRE_DEVICE();
+#ifndef OMX_TUNING
+    set_last_error("omx_debug_k2_phase_cycles: phase-timing kernels exist only in the tuning build (make TUNING=1)");
+    return OMX_ERR_UNSUPPORTED;
+#endif
     return guarded([&] {
         unsigned long long c[K2_PHASES];
         k2_phase_cycles(c, reset != 0);
@@ -204,6 +209,10 @@ int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, ui
     switch (option) {
         case OMX_OPT_KERNEL_TIMING: b->impl.timer().enabled = value != 0; return OMX_NONE;
         case OMX_OPT_FORCE_GENERIC: b->impl.force_generic(value != 0); return OMX_NONE;
+        case OMX_OPT_KERNEL_FORM:
+            if (value != 0 && value != 1 && value != 30 && value != 31) return OMX_ERR_INVALID;
+            b->impl.kernel_form((int)value);
+            return OMX_NONE;
         default: return OMX_ERR_INVALID;
     }
 }

@@ -104,14 +104,23 @@ void SpectrogramBank::advance(uint64_t count) {  // :406-410
     pending_skip_ += missing;
 }
 
-void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
-    const size_t W = (size_t)cfg_.fft_size;
+// Shapes the HIP path computes.  The reference accepts any fft_size (rustfft plans any length, :71-82 only normalises);
+// here a shape outside the supported set is a backend failure (OMX_ERR_UNSUPPORTED), raised BEFORE any state changes.
+static void require_supported(const omx_spectrogram_config& c) {
+    const size_t W = (size_t)c.fft_size;
     if (!is_pow2(W)) unsupported("spectrogram fft_size must be a power of two, got " + std::to_string(W));
-    if (!is_pow2((size_t)cfg_.zero_padding_factor))
-        unsupported("spectrogram zero_padding_factor must be a power of two, got " + std::to_string(cfg_.zero_padding_factor));
+    if (!is_pow2((size_t)c.zero_padding_factor))
+        unsupported("spectrogram zero_padding_factor must be a power of two, got " + std::to_string(c.zero_padding_factor));
+    if (W > (size_t(1) << 24) || (size_t)c.zero_padding_factor > (size_t(1) << 24) || W * (size_t)c.zero_padding_factor > (size_t(1) << 24))
+        unsupported("spectrogram padded FFT longer than 2^24");
+}
+
+void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
+    require_supported(cfg_);
+    prepared_ = false;  // a failure below (HIP error) must not leave tables of two configurations mixed behind a prepared flag
+    const size_t W = (size_t)cfg_.fft_size;
     fft_size_ = W * (size_t)cfg_.zero_padding_factor;
     hilbert_len_ = hilbert_len_for(W);
-    if (fft_size_ > (size_t(1) << 24)) unsupported("spectrogram padded FFT longer than 2^24");
     const bool reassign = cfg_.use_reassignment != 0;
     const size_t active_len = reassign ? hilbert_len_ : fft_size_;
 
@@ -192,6 +201,7 @@ void SpectrogramBank::update_config(const omx_spectrogram_config& in, hipStream_
     normalize(cfg);
     const omx_spectrogram_config prev = cfg_;
     const bool prepared = prepared_;
+    if (prepared) require_supported(cfg);  // rejected configurations leave the handle exactly as it was (old config, old tables)
     cfg_ = cfg;
     const bool rate_changed = prev.sample_rate != cfg.sample_rate;
     const bool rebuild = prev.fft_size != cfg.fft_size || prev.zero_padding_factor != cfg.zero_padding_factor ||
@@ -312,14 +322,8 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         fa.latency_hops = latency_hops;
         fa.points = d_points_.ptr;
         fa.counts = d_counts_.ptr;
-        static const bool cross_check = [] {  // OMX_K2_VARIANT=30: run 4096 through the size-templated kernel as well
-            const char* e = getenv("OMX_K2_VARIANT");
-            return e && atoi(e) == 30;
-        }();
-        static const bool split_check = [] {  // OMX_K2_VARIANT=31: 4096 through the three-kernel form (tuning)
-            const char* e = getenv("OMX_K2_VARIANT");
-            return e && atoi(e) == 31;
-        }();
+        const bool cross_check = kernel_form_ == 30;  // OMX_OPT_KERNEL_FORM: 4096 through the size-templated kernel
+        const bool split_check = kernel_form_ == 31;  // ... or through the three-kernel form
         if (reassign && fft_size_ == 4096 && !fast_zp_ && split_check) {
             const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 4096);
             d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));
@@ -341,7 +345,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         else if (!reassign)
             launch_stft_classic_pow2(fa, d_codes_.ptr, (uint32_t)fft_size_, stream);
         else if (fft_size_ == 4096 && !cross_check)
-            launch_stft_reassigned_4096(fa, stream);
+            launch_stft_reassigned_4096(fa, kernel_form_, stream);
         else
             launch_stft_reassigned_pow2(fa, (uint32_t)fft_size_, stream);
     } else {

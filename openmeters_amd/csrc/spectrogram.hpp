@@ -22,6 +22,7 @@ public:
     int fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out, hipStream_t stream);
     EventTimer& timer() { return timer_; }
     void force_generic(bool on) { force_generic_ = on; }
+    void kernel_form(int form) { kernel_form_ = form; }
     hipStream_t last_stream() const { return last_stream_; }
 
 private:
@@ -33,6 +34,7 @@ private:
 
     omx_spectrogram_config cfg_{};
     uint32_t n_streams_;
+    int kernel_form_ = 0;  // OMX_OPT_KERNEL_FORM
     bool prepared_ = false, reset_ = true, fast4096_ = false, fast_zp_ = false, force_generic_ = false;
     size_t fft_size_ = 0, hilbert_len_ = 0;
     float power_scale_ = 1.0f;

@@ -61,10 +61,18 @@ void SpectrumBank::prepare(hipStream_t stream) {
     if (!prepared_) rebuild_fft(stream);
 }
 
-void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
-    const size_t N = (size_t)cfg_.fft_size;
+// The reference plans any length (:71-82 only normalises); a shape the HIP path does not compute is a backend failure raised
+// before any state changes.
+static void require_supported(const omx_spectrum_config& c) {
+    const size_t N = (size_t)c.fft_size;
     if (!is_pow2(N)) unsupported("spectrum fft_size must be a power of two, got " + std::to_string(N));
     if (N > (size_t(1) << 24)) unsupported("spectrum FFT longer than 2^24");
+}
+
+void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
+    require_supported(cfg_);
+    prepared_ = false;
+    const size_t N = (size_t)cfg_.fft_size;
     const std::vector<float> window = window_coefficients(cfg_.window, N);
     d_window_.upload(window, stream);
     d_bin_norm_.upload(fft_bin_normalization(window, N), stream);
@@ -111,6 +119,7 @@ void SpectrumBank::update_config(const omx_spectrum_config& in, hipStream_t stre
     const omx_spectrum_config old = cfg_;
     omx_spectrum_config cfg = in;
     normalize(cfg);
+    if (prepared_) require_supported(cfg);  // rejected: the handle keeps its old configuration and tables
     cfg_ = cfg;
     if (!prepared_) return;
     const bool mode_changed = old.averaging_mode != cfg.averaging_mode;

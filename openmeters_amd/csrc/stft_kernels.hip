@@ -13,7 +13,9 @@
 #include "stft_kernels.hpp"
 
 #include "fft_device.hpp"
+#ifdef OMX_TUNING
 #include "fft_wave_device.hpp"
+#endif
 
 namespace omx {
 
@@ -550,6 +552,7 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
     }
 }
 
+#ifdef OMX_TUNING  // rejected design, kept as the documented negative result in the tuning build only
 // ================================================================================================
 // K2W: the same fused pipeline with ONE WAVEFRONT PER FRAME (4 frames per 256-thread workgroup, no s_barrier).
 // Each lane keeps 64 complex values; a 4096-point FFT is two radix-64 passes with one wave-private LDS exchange
@@ -686,6 +689,7 @@ static void launch_k2_wave(const StftFastArgs& a, hipStream_t stream) {
     const uint32_t chunks = (a.n_cols + K2W_FRAMES_PER_WG - 1) / K2W_FRAMES_PER_WG;
     hipLaunchKernelGGL(stft_reassigned_4096_wave_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
 }
+#endif  // OMX_TUNING
 
 template <class V>
 static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
@@ -697,14 +701,18 @@ static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    size_t pad = 0;
+#ifdef OMX_TUNING
     // OMX_K2_LDS_PAD (bytes): occupancy experiment only — a larger LDS request lowers the workgroups per CU
-    static const size_t pad = [] {
+    static const size_t env_pad = [] {
         const char* e = getenv("OMX_K2_LDS_PAD");
         return e ? (size_t)atol(e) : (size_t)0;
     }();
+    pad = env_pad;
     if (pad)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_kernel<V>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad));
+#endif
     const uint32_t chunks = (a.n_cols + V::COLS_PER_WG - 1) / V::COLS_PER_WG;
     hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds + pad, stream, a);
 }
@@ -717,40 +725,51 @@ void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset) {
     }
 }
 
-void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream) {
+using K2Default = K2Variant<1, true, true, true, true, false, 2, false, true, false, true>;
+
+int stft_reassigned_4096_transforms_per_frame() { return 5; }
+
+void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    // OMX_K2_VARIANT selects an A/B build of the kernel (tuning only; every variant computes the same thing)
+    (void)form;
+#ifdef OMX_TUNING
+    // Tuning build only (make TUNING=1 -> libomx_hip_tuning.so, loaded through OMX_HIP_LIB): OMX_K2_VARIANT selects an A/B
+    // build of the kernel.  100 / 1 / 2 / 3 / 12 / 13 / 14 / 20 compute the same columns as the default; 7 / 8 / 9 add phase
+    // timing; 41-49 are KNOCK-OUT builds that leave one stage out and return WRONG columns (pricing a stage by the kernel
+    // time that disappears).  None of this is compiled into the product library.
+    // Measured on MI355X, 65 536 frames per launch (kernel ms): 100 -> 2.54, 1 -> 2.57, 2 -> 2.43, 3 -> 2.34,
+    // 12 -> 2.22, default (12 + loads issued one transform ahead, t*w rebuilt in registers, 32-bit offsets) -> 2.10;
+    // persistent multi-column loops (4.5 ms) and 3-workgroup/CU single-buffer forms (2.8-5.6 ms) lost to register spills
+    // and were removed except variant 13, kept as the documented negative result.
     static const int variant = [] {
         const char* e = getenv("OMX_K2_VARIANT");
         return e ? atoi(e) : 0;
     }();
-    // Measured on MI355X, 65 536 frames per launch (kernel ms): 100 -> 2.54, 1 -> 2.57, 2 -> 2.43, 3 -> 2.34,
-    // 12 -> 2.22, default (12 + loads issued one transform ahead, t*w rebuilt in registers, 32-bit offsets) -> 2.10;
-    // 7 / 9 are the phase-timing builds of 12 / default (tools/k2_phases.py); persistent multi-column loops (4.5 ms) and 3-workgroup/CU single-buffer forms (2.8-5.6 ms)
-    // lost to register spills and were removed except variant 13, kept as the documented negative result.
     switch (variant) {                                  //     cols tw2lds tw3reg dual  pingpong onebuf minw recompute
-        case 100: launch_k2_variant<K2Variant<1, false, false, true, false>>(a, stream); break;  // round-1 first form
-        case 1: launch_k2_variant<K2Variant<1, false, false, true, true>>(a, stream); break;
-        case 2: launch_k2_variant<K2Variant<1, true, false, true, false>>(a, stream); break;
-        case 3: launch_k2_variant<K2Variant<1, false, true, true, false>>(a, stream); break;
-        case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); break;
-        case 20: launch_k2_wave(a, stream); break;  // one wavefront per frame
-        case 9: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true>>(a, stream); break;
-        case 41: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 1>>(a, stream); break;
-        case 42: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 2>>(a, stream); break;
-        case 43: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 3>>(a, stream); break;
-        case 44: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 4>>(a, stream); break;
-        case 45: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 5>>(a, stream); break;
-        case 47: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 7>>(a, stream); break;
-        case 48: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 8>>(a, stream); break;
-        case 49: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 9>>(a, stream); break;
-        case 46: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 6>>(a, stream); break;
-        case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); break;
-        case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); break;
-        case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); break;
-        case 12: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); break;  // default until the early-load form
-        default: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true>>(a, stream); break;
+        case 100: launch_k2_variant<K2Variant<1, false, false, true, false>>(a, stream); return;  // round-1 first form
+        case 1: launch_k2_variant<K2Variant<1, false, false, true, true>>(a, stream); return;
+        case 2: launch_k2_variant<K2Variant<1, true, false, true, false>>(a, stream); return;
+        case 3: launch_k2_variant<K2Variant<1, false, true, true, false>>(a, stream); return;
+        case 13: launch_k2_variant<K2Variant<1, true, true, false, false, true, 3, true>>(a, stream); return;
+        case 20: launch_k2_wave(a, stream); return;  // one wavefront per frame
+        case 9: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true>>(a, stream); return;
+        case 41: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 1>>(a, stream); return;
+        case 42: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 2>>(a, stream); return;
+        case 43: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 3>>(a, stream); return;
+        case 44: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 4>>(a, stream); return;
+        case 45: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 5>>(a, stream); return;
+        case 47: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 7>>(a, stream); return;
+        case 48: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 8>>(a, stream); return;
+        case 49: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 9>>(a, stream); return;
+        case 46: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, false, 6>>(a, stream); return;
+        case 14: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, false, true, false, true>>(a, stream); return;
+        case 8: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, true, true>>(a, stream); return;
+        case 7: launch_k2_variant<K2Variant<1, true, true, true, true, false, 2, false, true, true, false>>(a, stream); return;
+        case 12: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); return;  // default until the early-load form
+        default: break;
     }
+#endif
+    launch_k2_variant<K2Default>(a, stream);
 }
 
 // ================================================================================================

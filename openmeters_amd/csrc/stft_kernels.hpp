@@ -53,7 +53,9 @@ struct StftFastArgs {
 };
 constexpr int K2_PHASES = 12;
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning builds only (OMX_K2_VARIANT=7)
-void launch_stft_reassigned_4096(const StftFastArgs& a, hipStream_t stream);
+// form: OMX_OPT_KERNEL_FORM (0 = tuned kernel, 1 = the five-transform kernel of round 1)
+void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream);
+int stft_reassigned_4096_transforms_per_frame();  // of form 0
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
 // size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);

@@ -30,6 +30,39 @@ def test_non_power_of_two_fft_is_reported_not_computed(omx):
     assert e.value.status == capi.ERR_UNSUPPORTED
 
 
+def test_rejected_update_config_leaves_a_prepared_handle_untouched(omx, oracle):
+    """A prepared handle that is handed a shape the HIP path refuses must stay on its old configuration: same get_config,
+    same tables, and the next block still yields the OLD configuration's columns (checked against the oracle that never saw
+    the rejected update)."""
+    from parity import check_reassigned_update
+    cfg = SpectrogramConfig(fft_size=1024, hop_size=256, history_length=64, use_reassignment=True)
+    t = np.arange(2048 + 256 * 11) / 48000.0
+    left = (0.4 * np.sin(2 * np.pi * (300.0 + 3000.0 * t) * t)).astype(np.float32)
+    pcm = np.stack([left, 0.7 * left], 1).reshape(-1)
+    half = 2 * (2048 + 256 * 4)
+    got, ref = SpectrogramProcessor(omx, cfg), SpectrogramProcessor(oracle, cfg)
+    a0, b0 = got.process_block(AudioBlock(pcm[:half], 2, 48000.0)), ref.process_block(AudioBlock(pcm[:half], 2, 48000.0))
+    assert len(a0.new_columns) == len(b0.new_columns) == 5
+    for bad in (SpectrogramConfig(fft_size=3000, hop_size=256), SpectrogramConfig(fft_size=1024, hop_size=64, zero_padding_factor=3)):
+        with pytest.raises(capi.OmxError) as e:
+            got.update_config(bad)
+        assert e.value.status == capi.ERR_UNSUPPORTED
+        kept = got.config()
+        assert (kept.fft_size, kept.hop_size, kept.zero_padding_factor) == (1024, 256, 1)
+    a1, b1 = got.process_block(AudioBlock(pcm[half:], 2, 48000.0)), ref.process_block(AudioBlock(pcm[half:], 2, 48000.0))
+    assert a1 is not None and len(a1.new_columns) == len(b1.new_columns) == 7 and a1.reset == b1.reset
+    check_reassigned_update(a1, b1, 48000.0, 256)
+    # spectrum: same contract
+    sg, sr = SpectrumProcessor(omx, SpectrumConfig(fft_size=1024, hop_size=256)), SpectrumProcessor(oracle, SpectrumConfig(fft_size=1024, hop_size=256))
+    sg.process_block(AudioBlock(pcm[:half], 2, 48000.0)); sr.process_block(AudioBlock(pcm[:half], 2, 48000.0))
+    with pytest.raises(capi.OmxError) as e:
+        sg.update_config(SpectrumConfig(fft_size=1000, hop_size=250))
+    assert e.value.status == capi.ERR_UNSUPPORTED and sg.config().fft_size == 1024
+    x, y = sg.process_block(AudioBlock(pcm[half:], 2, 48000.0)), sr.process_block(AudioBlock(pcm[half:], 2, 48000.0))
+    assert x is not None and y is not None
+    np.testing.assert_allclose(10 ** (np.asarray(x.traces[0][1]) / 10), 10 ** (np.asarray(y.traces[0][1]) / 10), atol=1e-5 * (10 ** (np.max(y.traces[0][1]) / 10)))
+
+
 def test_invalid_arguments_are_rejected(omx):
     f = omx.fn("spectrogram_bank_create", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)])
     h = C.c_void_p()
