@@ -149,6 +149,8 @@ def cpu_baseline(columns, log):
     out["single_thread"] = n / secs
     log(f"cpu_baseline cfg2 shape, 1 thread: {n} frames in {secs:.2f} s")
     reps = -(-threads // 8)
+    all_cols = max(256, columns // 4) if threads > 16 else columns    # 256 host threads contend for memory: keep the leg ~10 s
+    frames = 8192 + 256 * (all_cols - 1)
     many = np.tile(workloads.cfg2_bank(0, min(threads, 8), frames), (reps, 1, 1))[:threads]  # T streams (8 distinct ones, tiled)
     n, secs = run(cfg, np.ascontiguousarray(many), threads)
     out["all_threads"] = n / secs
@@ -164,7 +166,7 @@ def cpu_baseline(columns, log):
             "single_thread": out["single_thread"],
             "cfg1_classic_1024": {"single_thread": n1 / s1, "all_threads": nT / sT, "unit": "frames/s",
                                   "sample": f"{8 * columns} columns per stream, 1 and {threads} streams"},
-            "sample": f"{threads} streams x {columns} reassigned 4096/256 columns each (blocks of 256 frames), C++ oracle "
+            "sample": f"{threads} streams x {all_cols} reassigned 4096/256 columns each (blocks of 256 frames), C++ oracle "
                       f"{flags} -ffp-contract=off, {threads} threads = every host core visible to the process; "
                       f"single_thread = 1 stream x {columns} columns"}
 

@@ -22,6 +22,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (gfx950) device")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("OMX_PARITY_REPORT")
+    if path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import parity
+        if parity.LEDGER:
+            parity.write_ledger(path)
+
+
 def _build_oracle() -> str:
     path = os.path.join(ROOT, "oracle", "libomx_oracle.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))

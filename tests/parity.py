@@ -6,7 +6,36 @@ one list only.  `align_points` finds the minimum-cost monotone alignment of the 
 anything else is an orphan and must be weak (checked by the caller).  All errors are normalised the
 way SURVEY §7 defines "1e-5 relative": against the column's maximum, not per-bin.
 """
+import os
+
 import numpy as np
+
+# ---- measured-maximum ledger: every float bar of the -m gpu suite goes through bar(); with OMX_PARITY_REPORT=<path> the
+# session writes name / bar / measured maximum / count to that file (tests/conftest.py), which is how profiles/parity_rNN.txt
+# is produced on the GPU box (tools/parity_report.py).
+LEDGER = {}
+
+
+def bar(name, err, limit, detail=None):
+    """assert err <= limit, remembering the largest err seen under `name`."""
+    err = float(err)
+    rec = LEDGER.setdefault(name, [float(limit), 0.0, 0])
+    rec[0] = max(rec[0], float(limit))
+    if err == err:
+        rec[1] = max(rec[1], err)
+    rec[2] += 1
+    assert err <= limit, (name, err, limit, detail)
+    return err
+
+
+def write_ledger(path):
+    with open(path, "w") as fh:
+        fh.write("# measured maxima of every float parity bar of `pytest -m gpu` on this box (HIP product vs CPU oracle / fixtures)\n")
+        fh.write(f"# {'name':<58} {'bar':>10} {'measured max':>14} {'checks':>8} {'bar/max':>9}\n")
+        for name in sorted(LEDGER):
+            limit, worst, n = LEDGER[name]
+            ratio = f"{limit / worst:9.1f}" if worst > 0 else "      inf"
+            fh.write(f"{name:<60} {limit:10.3g} {worst:14.3e} {n:8d} {ratio}\n")
 
 
 def align_points(a, b, max_power, band_extra=8):
@@ -101,10 +130,13 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
               d*conj(b)/|b|^2 amplifies the f32 FFT noise floor by 1/r on weak bins)
       time  : max |dt| * r   (hops)
       orphan: max P(orphan) / max P
+      freq_strong / time_strong: the same two errors UNWEIGHTED, |df| / (fs/2) and |dt| (hops), over the pairs whose power is
+              within 40 dB of the column maximum (P >= 1e-4 max P)
     """
     max_power = float(max(ora[:, 2].max() if len(ora) else 0.0, hip[:, 2].max() if len(hip) else 0.0))
     if max_power <= 0.0:
-        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, n=0, orphans=len(hip) + len(ora))
+        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, n=0, orphans=len(hip) + len(ora), freq_strong=0.0, time_strong=0.0,
+                    n_strong=0)
     pairs, oa, ob = align_points(hip, ora, max_power)
     pa = np.array([p[0] for p in pairs], int)
     pb = np.array([p[1] for p in pairs], int)
@@ -115,11 +147,49 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
         m["power"] = float(np.abs(h[:, 2] - o[:, 2]).max() / max_power)
         m["freq"] = float((np.abs(h[:, 1] - o[:, 1]) * r).max() / (sample_rate * 0.5))
         m["time"] = float((np.abs(h[:, 0] - o[:, 0]) * r).max())
+        strong = o[:, 2] >= 1e-4 * max_power
+        m["n_strong"] = int(strong.sum())
+        m["freq_strong"] = float(np.abs(h[strong, 1] - o[strong, 1]).max() / (sample_rate * 0.5)) if strong.any() else 0.0
+        m["time_strong"] = float(np.abs(h[strong, 0] - o[strong, 0]).max()) if strong.any() else 0.0
     else:
-        m.update(power=0.0, freq=0.0, time=0.0)
+        m.update(power=0.0, freq=0.0, time=0.0, freq_strong=0.0, time_strong=0.0, n_strong=0)
     orphan_p = [hip[i, 2] for i in oa] + [ora[j, 2] for j in ob]
     m["orphan"] = float(max(orphan_p) / max_power) if orphan_p else 0.0
     return m
+
+
+# Bars of the reassigned path (every -m gpu test goes through these).  Weighted: SURVEY §7's "relative to the column maximum".
+# Unweighted, on the bins within 40 dB of the column maximum: f_hat = k fs/F + Im(D conj B)/|B|^2 fs/2pi and
+# t_hat = Re(T conj B)/|B|^2/hop are RATIOS of spectra, so an amplitude error e (relative to the column's peak amplitude A)
+# moves them by ~ e A/|B| times the size of the correction term: at |B| = 1e-2 A (P = 1e-4 max) the weighted bars scale by 100.
+# Measured maxima over every configuration of tools/parity_report.py are in profiles/parity_r02.txt; each bar is <= 10x them.
+BAR_POWER, BAR_FREQ, BAR_TIME, BAR_ORPHAN = 1e-5, 1e-7, 1e-4, 1e-8
+BAR_FREQ_STRONG, BAR_TIME_STRONG = 2e-7, 5e-4   # measured 2.0e-8 / 6.7e-5 (profiles/parity_r02.txt)
+
+
+def check_reassigned_columns(got, want, sample_rate, hop, scale=1.0):
+    """`scale` >= 1 loosens every float bar for ill-conditioned input (state-machine tests: a window on near-silence next to a
+    loud passage, DESIGN §2 conditioning note)."""
+    assert len(got) == len(want), (len(got), len(want))
+    worst = {}
+    for h, o in zip(got, want):
+        m = reassigned_column_metrics(h, o, sample_rate, hop)
+        tag = "reassigned" if scale == 1.0 else "reassigned(ill-conditioned, scaled bars)"
+        bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER * scale, m)
+        bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ * scale, m)
+        bar(f"{tag}: r |dt| hops", m["time"], BAR_TIME * scale, m)
+        bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN * scale, m)
+        bar(f"{tag}: |df| / (fs/2), P >= 1e-4 max", m["freq_strong"], BAR_FREQ_STRONG * scale, m)
+        bar(f"{tag}: |dt| hops, P >= 1e-4 max", m["time_strong"], BAR_TIME_STRONG * scale, m)
+        assert m["orphans"] <= 4, m
+        for k, v in m.items():
+            worst[k] = max(worst.get(k, 0), v)
+    return worst
+
+
+def check_reassigned_update(got, want, sample_rate, hop, scale=1.0):
+    assert got.fft_size == want.fft_size and got.reset == want.reset and got.reassigned_power_scale == want.reassigned_power_scale
+    return check_reassigned_columns(got.new_columns, want.new_columns, sample_rate, hop, scale)
 
 
 def classic_column_metrics(hip, ora):
@@ -147,4 +217,5 @@ def check_classic(got, want):
     assert len(got) == len(want)
     for h, o in zip(got, want):
         m = classic_column_metrics(h, o)
-        assert m["loud_code_diff"] <= 1 and m["weak_power"] <= 6e-8, m   # 6e-8 = one code at -40 dB
+        bar("classic (fused): |d code| within 40 dB of max", m["loud_code_diff"], 1, m)
+        bar("classic (fused): |dP| / max P below -40 dB", m["weak_power"], 6e-8, m)   # 6e-8 = one code at -40 dB

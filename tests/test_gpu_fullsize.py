@@ -14,7 +14,7 @@ from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, OscilloscopeConfig, OscilloscopeProcessor,
                                  SpectrogramConfig, SpectrogramProcessor, StereometerConfig, StereometerProcessor)
 from golden_inputs import cfg2_pcm, cfg3_pcm, cfg4_pcm
-from parity import reassigned_column_metrics
+from parity import bar, check_reassigned_columns, reassigned_column_metrics
 
 pytestmark = pytest.mark.gpu
 FS = 48000.0
@@ -77,8 +77,7 @@ def test_cfg2_full_size_shift_partition_and_oracle_spot_checks(omx, oracle):
         at = (k + c) * hop
         want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(base[at:at + 8192].reshape(-1), 2, FS)).new_columns[0]
         got = one.fetch_column(k, c, capi.COLUMN_REASSIGNED, 2049)
-        m = reassigned_column_metrics(got, want, FS, hop)
-        assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, m
+        check_reassigned_columns([got], [want], FS, hop)
 
 
 def test_cfg3_full_size_replication_gain_and_oracle_spot_checks(omx, oracle):
@@ -100,16 +99,17 @@ def test_cfg3_full_size_replication_gain_and_oracle_spot_checks(omx, oracle):
     step = 10.0 * np.log10(4.0)
     for lo, hi in ((0, 2), (2, 2 + C), (10, 10 + C), (18, 18 + C)):   # LUFS pair, rms fast, rms slow, true peak
         d = (a[:, lo:hi] - b[:, lo:hi]).cpu().numpy()
-        assert np.abs(d - step).max() < 2e-4, (lo, np.abs(d - step).max())
+        bar("cfg3 full size: |d dB - 6.0206| under x0.5 gain", np.abs(d - step).max(), 2e-4, lo)
 
     for s in (0, 9, 1023):
         p = LoudnessProcessor(oracle, LoudnessConfig())
         for k in range(0, frames, 256):
             w = p.process_block(AudioBlock(distinct[s % 16, k:k + 256].reshape(-1), C, FS, capi.SURROUND))
         g = bank.fetch(s, blocks - 1)
-        assert abs(g.momentary_loudness - w.momentary_loudness) <= 1e-4 and abs(g.short_term_loudness - w.short_term_loudness) <= 1e-4
+        bar("loudness: |d momentary LUFS|", abs(g.momentary_loudness - w.momentary_loudness), 1e-4)
+        bar("loudness: |d short-term LUFS|", abs(g.short_term_loudness - w.short_term_loudness), 1e-4)
         for f in ("rms_fast_db", "rms_slow_db", "true_peak_db"):
-            assert np.abs(getattr(g, f) - getattr(w, f)).max() <= 1e-4, f
+            bar(f"loudness: |d {f}|", np.abs(getattr(g, f) - getattr(w, f)).max(), 1e-4)
 
 
 def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
@@ -140,7 +140,7 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
     us2 = st2.process_device(d_half.data_ptr(), 256, blocks, 2, FS, pos)
     c1 = dview(torch, us.d_correlations, (S, blocks, 4), "<f4")
     c2 = dview(torch, us2.d_correlations, (S, blocks, 4), "<f4")
-    assert float((c1 - c2).abs().max()) <= 1e-6
+    bar("cfg4 full size: |d rho| under x0.5 gain", float((c1 - c2).abs().max()), 1e-6)
 
     for s in (0, 21, 255):
         sp, op = StereometerProcessor(oracle, scfg), OscilloscopeProcessor(oracle, ocfg)
@@ -148,12 +148,13 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
             blk = AudioBlock(distinct[s % 32, k:k + 256].reshape(-1), 2, FS)
             ws, wo = sp.process_block(blk), op.process_block(blk)
         got, produced = st.fetch(s, blocks - 1)
-        assert produced and np.abs(got - ws.correlations).max() <= 1e-6
+        assert produced
+        bar("stereometer: |d rho|", np.abs(got - ws.correlations).max(), 1e-6)
         h, samples = sc.fetch(s, blocks - 1, with_samples=True)
         assert bool(h.locked) == (op.last_cycle_rate() is not None) and h.samples_per_channel == wo.samples_per_channel
-        assert abs(h.period - FS / op.last_cycle_rate()) <= 1e-4 * h.period
+        bar("oscilloscope: rel |d cycle rate|", abs(h.period - FS / op.last_cycle_rate()) / h.period, 1e-4)
         flat = np.concatenate([samples[c, :h.samples_per_channel] for c in range(h.channels)])
-        assert np.abs(flat - wo.samples).max() <= 2e-3
+        bar("oscilloscope (Stable): |d trace|", np.abs(flat - wo.samples).max(), 2e-3)
 
 
 @pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256), (8192, 512)])
@@ -195,5 +196,4 @@ def test_fused_small_windows_full_size_shift_partition_and_oracle(omx, oracle, W
         want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(base[at:at + 2 * W].reshape(-1), 2, FS)).new_columns[0]
         for bank in (one, gen):
             got = bank.fetch_column(k, c, capi.COLUMN_REASSIGNED, W // 2 + 1)
-            m = reassigned_column_metrics(got, want, FS, hop)
-            assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, (m, bank is gen)
+            check_reassigned_columns([got], [want], FS, hop)

@@ -6,7 +6,7 @@ import pytest
 from openmeters_amd import capi
 from openmeters_amd.capi import (AudioBlock, SpectrogramConfig, SpectrogramProcessor, SpectrumConfig, SpectrumProcessor)
 from test_gpu_parity import check_reassigned, check_trace, stream_pcm
-from parity import check_classic
+from parity import check_reassigned_columns, check_classic
 
 pytestmark = pytest.mark.gpu
 WINDOWS = [capi.WINDOW_RECTANGULAR, capi.WINDOW_HANN, capi.WINDOW_HAMMING, capi.WINDOW_BLACKMAN, capi.WINDOW_BLACKMAN_HARRIS]
@@ -67,8 +67,7 @@ def test_sample_rates_and_channel_layouts(omx, oracle, rate, channels, positions
         assert len(g.new_columns) == len(w.new_columns) == 5
         for h, o in zip(g.new_columns, w.new_columns):
             from parity import reassigned_column_metrics
-            m = reassigned_column_metrics(h, o, rate, 256)
-            assert m["power"] <= 1e-5 and m["freq"] <= 1e-7 and m["time"] <= 1e-4 and m["orphan"] < 1e-8, m
+            check_reassigned_columns([h], [o], rate, 256)
     sc = SpectrumConfig(sample_rate=rate, fft_size=4096, hop_size=512, source=capi.CH_MID, secondary_source=capi.CH_RIGHT)
     gs, ws = SpectrumProcessor(omx, sc).process_block(blk), SpectrumProcessor(oracle, sc).process_block(blk)
     assert (gs is None) == (ws is None)

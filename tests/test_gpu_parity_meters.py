@@ -15,10 +15,12 @@ import pytest
 from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, OscilloscopeConfig, OscilloscopeProcessor,
                                  StereometerConfig, StereometerProcessor)
+from parity import bar
 from signals import xorshift32_noise
 
 pytestmark = pytest.mark.gpu
 FS = 48000.0
+SCOPE_TRACE_BAR = 2e-3   # Stable-mode resampled trace, absolute on +-0.8 signals
 
 
 def cfg3_pcm(s, frames, channels=8):
@@ -32,10 +34,10 @@ def cfg3_pcm(s, frames, channels=8):
 
 
 def snapshots_close(a, b, tol=1e-4):
-    assert abs(a.short_term_loudness - b.short_term_loudness) <= tol
-    assert abs(a.momentary_loudness - b.momentary_loudness) <= tol
+    bar("loudness: |d short-term LUFS|", abs(a.short_term_loudness - b.short_term_loudness), tol)
+    bar("loudness: |d momentary LUFS|", abs(a.momentary_loudness - b.momentary_loudness), tol)
     for f in ("rms_fast_db", "rms_slow_db", "true_peak_db"):
-        assert np.abs(getattr(a, f) - getattr(b, f)).max() <= tol, f
+        bar(f"loudness: |d {f}|", np.abs(getattr(a, f) - getattr(b, f)).max(), tol)
     assert a.channel_count == b.channel_count and a.positions == b.positions
 
 
@@ -102,7 +104,7 @@ def test_stereometer_blocks_match_oracle(omx, oracle):
         assert (g is None) == (w is None)
         if g is None:
             continue
-        assert np.abs(g.correlations - w.correlations).max() <= 1e-6
+        bar("stereometer: |d rho|", np.abs(g.correlations - w.correlations).max(), 1e-6)
         for band in range(4):
             assert g.points[band].shape == w.points[band].shape
             assert np.array_equal(g.points[band].view(np.uint32), w.points[band].view(np.uint32)), band  # bit-exact biquads
@@ -121,7 +123,7 @@ def test_stereometer_bank_and_surround_fold(omx, oracle):
             corr, produced = bank.fetch(s, blk)
             assert produced == (w is not None)
             if w is not None:
-                assert np.abs(corr - w.correlations).max() <= 1e-6
+                bar("stereometer: |d rho|", np.abs(corr - w.correlations).max(), 1e-6)
     # 8-channel SURROUND fold feeds the same kernel (dsp.rs:135-176 weights)
     x = cfg3_pcm(2, 256 * 6, 8)
     a, b = StereometerProcessor(omx, cfg), StereometerProcessor(oracle, cfg)
@@ -130,7 +132,7 @@ def test_stereometer_bank_and_surround_fold(omx, oracle):
         w = b.process_block(AudioBlock(x[k:k + 256].reshape(-1), 8, FS, capi.SURROUND))
         assert (g is None) == (w is None)
         if g is not None:
-            assert np.abs(g.correlations - w.correlations).max() <= 1e-6
+            bar("stereometer: |d rho|", np.abs(g.correlations - w.correlations).max(), 1e-6)
             assert np.array_equal(g.points[0].view(np.uint32), w.points[0].view(np.uint32))
 
 
@@ -154,7 +156,7 @@ def test_oscilloscope_blocks_match_oracle(omx, oracle, s):
         ra, rb = a.last_cycle_rate(), b.last_cycle_rate()
         assert (ra is None) == (rb is None)
         if ra is not None:
-            assert abs(ra - rb) <= 1e-4 * rb
+            bar("oscilloscope: rel |d cycle rate|", abs(ra - rb) / rb, 1e-4)
         if g is None:
             continue
         assert (g.epoch, g.channels, g.slots[:g.channels], g.samples_per_channel) == (w.epoch, w.channels, w.slots[:w.channels],
@@ -162,8 +164,7 @@ def test_oscilloscope_blocks_match_oracle(omx, oracle, s):
         if ra is not None and k > 256 * 60:
             # same capture (up to f32 noise) -> same resampled trace; a near-tie argmax flip would show up as a whole-sample
             # or whole-period shift, which the reference's own jitter test tolerates (< 3 samples, :933-955)
-            d = np.abs(g.samples - w.samples).max()
-            assert d <= 2e-3, (k, d)
+            bar("oscilloscope (Stable): |d trace|", np.abs(g.samples - w.samples).max(), SCOPE_TRACE_BAR, k)
             compared += 1
     assert compared > 30
     assert abs(FS / a.last_cycle_rate() - period) < 0.02 * period
@@ -189,7 +190,7 @@ def test_oscilloscope_bank_matches_single_stream_handles(omx, oracle):
         hdr, samples = bank.fetch(s, blocks - 1, with_samples=True)
         n = hdr.samples_per_channel
         got = np.concatenate([samples[c, :n] for c in range(hdr.channels)])
-        assert np.abs(got - want.samples).max() <= 2e-3
+        bar("oscilloscope (Stable): |d trace|", np.abs(got - want.samples).max(), SCOPE_TRACE_BAR)
 
 
 def test_oscilloscope_zero_crossing_mode_matches_oracle(omx, oracle):
@@ -203,7 +204,7 @@ def test_oscilloscope_zero_crossing_mode_matches_oracle(omx, oracle):
         assert (g is None) == (w is None)
         if g is not None:
             assert (g.channels, g.samples_per_channel) == (w.channels, w.samples_per_channel)
-            assert np.abs(g.samples - w.samples).max() <= 1e-6
+            bar("oscilloscope (zero crossing): |d trace|", np.abs(g.samples - w.samples).max(), 1e-6)
 
 
 def test_waveform_blocks_match_oracle(omx, oracle):
@@ -222,12 +223,13 @@ def test_waveform_blocks_match_oracle(omx, oracle):
         total += len(g.columns)
         assert np.array_equal(g.columns[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32))  # min / max
         if len(g.columns):
-            assert np.abs(g.columns[:, :, 2:5] - w.columns[:, :, 2:5]).max() <= 1e-6 * max(1.0, np.abs(w.columns[:, :, 2:5]).max())
-            assert np.abs(g.columns[:, :, 5:] - w.columns[:, :, 5:]).max() <= 2e-4  # dB
+            bar("waveform: |d band colour| / max(1, max)", np.abs(g.columns[:, :, 2:5] - w.columns[:, :, 2:5]).max() /
+                max(1.0, np.abs(w.columns[:, :, 2:5]).max()), 1e-6)
+            bar("waveform: |d RMS history dB|", np.abs(g.columns[:, :, 5:] - w.columns[:, :, 5:]).max(), 2e-4)
         assert (g.preview is None) == (w.preview is None)
         if g.preview is not None:
             assert np.array_equal(g.preview[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32))
-            assert np.abs(g.preview[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-6
+            bar("waveform: |d band colour| / max(1, max)", np.abs(g.preview[:, 2:5] - w.preview[:, 2:5]).max(), 1e-6)
     assert total in (319, 320)  # 0.00625 is not exact in f64: the reference phase accumulator lands one column short
 
 
@@ -337,7 +339,7 @@ def test_stereometer_non_finite_samples_reset_the_filters_like_the_reference(omx
             continue
         seen += 1
         assert np.array_equal(np.isnan(g.correlations), np.isnan(w.correlations))
-        assert np.nanmax(np.abs(g.correlations - w.correlations), initial=0.0) <= 1e-6, k
+        bar("stereometer: |d rho|", np.nanmax(np.abs(g.correlations - w.correlations), initial=0.0), 1e-6, k)
         for band in range(4):
             assert g.points[band].shape == w.points[band].shape
             gp, wp = g.points[band], w.points[band]

@@ -43,3 +43,100 @@ def test_full_pipeline_summary_rows_match_oracle(omx, oracle):
         assert abs(table[s, 2] - ls.true_peak_db[:2].max()) < 1e-4
         assert np.abs(table[s, 3:7] - ss.correlations).max() < 1e-6 and table[s, 3] < -0.99
         assert table[s, 7] == len(counts) and abs(table[s, 8] - np.mean(counts)) < 0.5 and abs(table[s, 9] - counts[-1]) <= 4
+
+
+def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_rows(omx, oracle):
+    """BASELINE configs[4], one GPU's shard at full size: 1024 x 2-ch streams through FullPipeline.step_concurrent (the
+    bench step: reassigned STFT on the main HIP stream, loudness + stereometer banks on side streams), 2 x 16 384 frames.
+      replication  stream s = distinct[s % 32] => rows / columns of every replica are BIT-identical (different workgroups, XCDs,
+                   bank slots, side-stream interleavings)
+      shift        distinct stream 1 carries distinct stream 0 advanced by one hop => column c equals column c + 1
+      partition    the two concurrent steps == one serial 32 768-frame step on a fresh pipeline (spectrogram columns and
+                   stereometer correlations bit-exact, loudness rows bit-exact)
+      oracle       summary rows of 3 streams vs the CPU oracle run block by block (the 6-stream test's bars)"""
+    import torch
+    from openmeters_amd.pipeline import FullPipeline
+    from test_gpu_fullsize import dview, spectrogram_outputs
+    dev = torch.device("cuda", 0)
+    S, D, frames, hop = 1024, 32, 16384, 256
+    base0 = cfg2_pcm(3, 2 * frames + hop)
+    distinct = [base0[:2 * frames], base0[hop:hop + 2 * frames]] + [cfg2_pcm(40 + d, 2 * frames) for d in range(2, D)]
+    distinct = np.stack(distinct)
+    distinct[:, :, 1] *= np.float32(-1.0)      # anti-phase right channel: rho < 0
+    d_all = torch.from_numpy(distinct).to(dev).repeat(S // D, 1, 1).contiguous()      # [S][2 frames][2]
+    pipe = FullPipeline(omx, S)
+    outs = []
+    for k in range(2):
+        chunk = d_all[:, k * frames:(k + 1) * frames].contiguous()
+        up, snaps, st, n_blocks = pipe.step_concurrent(torch, chunk.data_ptr(), frames)
+        torch.cuda.synchronize()
+        table = pipe.stats(torch, dev, up, snaps, st, n_blocks)
+        counts, points = spectrogram_outputs(torch, up)
+        outs.append((counts, points, dview(torch, snaps, (S, n_blocks, 30)).clone(), dview(torch, st.d_correlations, (S, n_blocks, 4)).clone(),
+                     table.clone()))
+    assert outs[0][0].shape == (S, (frames - 8192) // hop + 1) and outs[1][0].shape == (S, frames // hop)
+    for counts, points, snaps, corr, table in outs:
+        assert torch.equal(counts[:D].repeat(S // D, 1), counts)
+        assert torch.equal(points[:D].repeat(S // D, 1, 1, 1), points)
+        assert torch.equal(snaps[:D].repeat(S // D, 1, 1), snaps)
+        assert torch.equal(corr[:D].repeat(S // D, 1, 1), corr)
+        assert torch.equal(table[:D].repeat(S // D, 1), table)
+        n = counts.shape[1]
+        assert torch.equal(counts[1, :n - 1], counts[0, 1:]) and torch.equal(points[1, :n - 1], points[0, 1:])
+    assert torch.equal(outs[0][0][1, -1], outs[1][0][0, 0]) and torch.equal(outs[0][1][1, -1], outs[1][1][0, 0])   # across the step boundary
+
+    serial = FullPipeline(omx, S)
+    up, snaps, st, n_blocks = serial.step(d_all.data_ptr(), 2 * frames, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    counts, points = spectrogram_outputs(torch, up)
+    assert torch.equal(counts, torch.cat([outs[0][0], outs[1][0]], 1)) and torch.equal(points, torch.cat([outs[0][1], outs[1][1]], 1))
+    assert torch.equal(dview(torch, snaps, (S, n_blocks, 30)), torch.cat([outs[0][2], outs[1][2]], 1))
+    assert torch.equal(dview(torch, st.d_correlations, (S, n_blocks, 4)), torch.cat([outs[0][3], outs[1][3]], 1))
+
+    table = outs[1][4].cpu().numpy()
+    for s in (0, 17, 1023):
+        pcm = distinct[s % D]
+        lp = LoudnessProcessor(oracle, LoudnessConfig())
+        sp = StereometerProcessor(oracle, StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02,
+                                                            target_sample_count=2000))
+        for k in range(0, 2 * frames, 256):
+            blk = AudioBlock(pcm[k:k + 256].reshape(-1), 2, 48000.0)
+            ls, ss = lp.process_block(blk), sp.process_block(blk)
+        sg = SpectrogramProcessor(oracle, SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192)).process_block(
+            AudioBlock(pcm[frames - 8192 + hop:].reshape(-1), 2, 48000.0))      # the second step's 64 columns
+        cnt = [len(c) for c in sg.new_columns]
+        assert len(cnt) == 64 and table[s, 7] == 64
+        assert abs(table[s, 0] - ls.momentary_loudness) < 1e-4 and abs(table[s, 1] - ls.short_term_loudness) < 1e-4
+        assert abs(table[s, 2] - ls.true_peak_db[:2].max()) < 1e-4
+        assert np.abs(table[s, 3:7] - ss.correlations).max() < 1e-6 and table[s, 3] < -0.99
+        assert abs(table[s, 8] - np.mean(cnt)) < 0.5 and abs(table[s, 9] - cnt[-1]) <= 4
+        got = pipe.spectrogram.fetch_column(s, 63, capi.COLUMN_REASSIGNED, 2049)
+        from parity import check_reassigned_columns, reassigned_column_metrics
+        check_reassigned_columns([got], [sg.new_columns[-1]], 48000.0, hop)
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo_runs_the_cfg5_step():
+    """`python bench.py --gpus 2` (no RANK in the environment) on a 1-GPU box: the launcher starts two ranks, both run the
+    cfg5 step (full pipeline, small shard) on device 0, the summary rows travel over gloo; one JSON line, n_gpus = 2, and
+    `python bench.py --config cfg5` at N = 1 runs the same step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(OMX_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    common = ["--steps", "3", "--warmup", "2", "--streams", "16", "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["name"] == "cfg5" and two["value"] > 0 and two["roofline"]["kernel_ms"] > 0
+    assert two["config"]["columns_per_step_per_gpu"] == 16 * 64
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg5"] + common, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and one["config"]["name"] == "cfg5" and one["roofline"]["mean_points_per_frame"] > 1900
