@@ -1,7 +1,10 @@
 """Known-answer tests ported from reference src/visuals/loudness/processor.rs:323-454.
-The two `ebur128`-crate comparisons (an un-vendored dev-dependency) are replaced by the analytic
-BS.1770 anchors recorded in SURVEY §8c: 997 Hz 0 dBFS mono -> -3.0103 LKFS; the reference test's
-own signal (1 kHz, 0.5 amp, identical channels) -> -6.0139 LKFS (2 ch)."""
+The two `ebur128`-crate comparisons (an un-vendored dev-dependency) run against tests/golden/ebur128_scipy.json: an
+independent scipy restatement of libebur128's published algorithm (tools/make_ebur128_golden.py: K-filter by `lfilter` from
+the published constants per rate, 49-tap Hann-sinc polyphase true peak), at the reference's own bars — < 1e-3 LU over
+{44.1, 48, 96 kHz} x {2, 4, 5, 6 ch}, < 1e-3 dB true peak at 48 / 96 / 192 kHz — plus the analytic anchors of SURVEY §8c."""
+import json
+import os
 import numpy as np
 import pytest
 
@@ -45,8 +48,35 @@ def test_k_weighting_matches_bs1770_table(backend):
     assert np.allclose(a, np.convolve(sa, ra), atol=1e-10)
 
 
+EBUR128 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ebur128_scipy.json")))
+
+
+@pytest.mark.parametrize("case", EBUR128["short_term"], ids=lambda c: f"{int(c['sample_rate'])}Hz-{c['channels']}ch")
+def test_processor_matches_ebur128_short_term(backend, case):
+    # :366-398: every rate x channel count of the reference test, its signal, its tolerance (< 0.001 LU)
+    rate, channels = case["sample_rate"], case["channels"]
+    mono = lsine(rate, case["seconds"], case["freq"], case["amp"])
+    inter = np.repeat(mono[:, None], channels, 1).reshape(-1)
+    snap = LoudnessProcessor(backend, LoudnessConfig(sample_rate=rate)).process_block(AudioBlock(inter, channels, rate))
+    diff = abs(float(snap.short_term_loudness) - case["lufs_s"])
+    assert diff < 1e-3, f"{rate} Hz / {channels} ch mismatch: {snap.short_term_loudness:.6f} vs {case['lufs_s']:.6f} (diff={diff:.8f})"
+
+
+@pytest.mark.parametrize("case", EBUR128["true_peak"], ids=lambda c: f"{int(c['sample_rate'])}Hz-{int(c['freq'])}Hz")
+def test_true_peak_matches_ebur128_at_standard_rates(backend, case):
+    # :426-454 (17 kHz, 0.9 amp, 10 ms at 48 / 96 / 192 kHz, < 1e-3 dB) + fs/4 tones with a pi/4 phase (the +3 dB inter-sample case)
+    rate = case["sample_rate"]
+    if "phase" in case:
+        n = np.arange(int(rate * case["seconds"]))
+        x = (case["amp"] * np.sin(2.0 * np.pi * 0.25 * n + np.pi / 4.0)).astype(np.float32)
+    else:
+        x = lsine(rate, case["seconds"], case["freq"], case["amp"])
+    snap = LoudnessProcessor(backend, LoudnessConfig(sample_rate=rate)).process_block(AudioBlock(x, 1, rate))
+    assert abs(float(snap.true_peak_db[0]) - case["dbtp"]) < 1e-3, (rate, snap.true_peak_db[0], case["dbtp"])
+
+
 def test_processor_matches_bs1770_short_term_anchor(backend):
-    # replaces :366-398 (ebur128 LUFS-S, tolerance 1e-3 LU kept)
+    # analytic anchors, kept beside the fixture comparison above
     mono = lsine(48000.0, 4.0, 997.0, 1.0)
     snap = LoudnessProcessor(backend, LoudnessConfig()).process_block(AudioBlock(mono, 1, 48000.0))
     assert abs(snap.short_term_loudness - (-3.0103)) < 2e-3
