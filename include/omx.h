@@ -442,6 +442,9 @@ int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block,
 /* Test/diagnostic view of the trigger state (reference `last_cycle_rate`, :602-609):
  * returns 1 and writes Hz when a period is locked, else 0. */
 int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz);
+/* Test-only view, like last_cycle_rate: Capture{start, frac_offset} (`oscilloscope/processor.rs:265-269`) behind the newest
+ * snapshot — the resampled trace begins at history sample start + frac_offset.  1 if a snapshot exists, else 0. */
+int omx_oscilloscope_last_capture(const omx_oscilloscope* h, uint32_t* start, float* frac_offset);
 
 
 /* ===================================================================== *
@@ -552,6 +555,8 @@ typedef struct omx_oscilloscope_block_header {
     uint32_t samples_per_channel;
     uint32_t locked;
     float period;
+    uint32_t capture_start;  /* Capture::start / frac_offset of the first captured trace (`:265-269`): where the resampled */
+    float capture_frac;      /* trace begins in the trace history, in samples — diagnostics for the parity tests        */
     uint32_t _pad;
 } omx_oscilloscope_block_header;
 /* d_headers: [n_streams][n_blocks]; d_samples: f32 [n_streams][2][sample_stride], the snapshot of

@@ -246,7 +246,8 @@ class StereometerBank(_BlockBank):
 
 class COscilloscopeBlockHeader(C.Structure):
     _fields_ = [("produced", C.c_uint32), ("channels", C.c_uint32), ("slots", C.c_uint32 * 2),
-                ("samples_per_channel", C.c_uint32), ("locked", C.c_uint32), ("period", C.c_float), ("_pad", C.c_uint32)]
+                ("samples_per_channel", C.c_uint32), ("locked", C.c_uint32), ("period", C.c_float), ("capture_start", C.c_uint32),
+                ("capture_frac", C.c_float), ("_pad", C.c_uint32)]
 
 
 class COscilloscopeBankUpdate(C.Structure):

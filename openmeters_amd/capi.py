@@ -612,6 +612,12 @@ class OscilloscopeProcessor(_Handle):
         f = self.api.fn("oscilloscope_last_cycle_rate", C.c_int, [C.c_void_p, C.POINTER(C.c_float)])
         return float(hz.value) if f(self._h, C.byref(hz)) == 1 else None
 
+    def last_capture(self):
+        """(start, frac_offset) of the Capture behind the newest snapshot (test-only view), or None"""
+        start, frac = C.c_uint32(), C.c_float()
+        f = self.api.fn("oscilloscope_last_capture", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)])
+        return (int(start.value), float(frac.value)) if f(self._h, C.byref(start), C.byref(frac)) == 1 else None
+
     def process_block(self, block: AudioBlock) -> Optional[OscilloscopeSnapshot]:
         cb = block.to_c()
         out = COscilloscopeSnapshot()

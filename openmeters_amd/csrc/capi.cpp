@@ -531,6 +531,12 @@ int omx_oscilloscope_process_block(omx_oscilloscope* h, const omx_block* block, 
         return (int)OMX_PRODUCED;
     });
 }
+int omx_oscilloscope_last_capture(const omx_oscilloscope* h, uint32_t* start, float* frac_offset) {
+    if (!h || !h->have_last || !h->last.produced) return 0;
+    if (start) *start = h->last.capture_start;
+    if (frac_offset) *frac_offset = h->last.capture_frac;
+    return 1;
+}
 int omx_oscilloscope_last_cycle_rate(const omx_oscilloscope* h, float* hz) {
     if (!h || !hz || !h->have_last || !h->last.locked) return 0;
     *hz = h->bank.config().sample_rate / h->last.period;

@@ -26,6 +26,8 @@ struct ScopeBlockHeader {   // per (stream, block) snapshot header
     uint32_t samples_per_channel;
     uint32_t locked;        // last_cycle_rate().is_some() after this block (:602-609)
     float period;           // the period behind last_cycle_rate
+    uint32_t capture_start; // Capture::start / frac_offset of the first captured trace
+    float capture_frac;
     uint32_t _pad;
 };
 

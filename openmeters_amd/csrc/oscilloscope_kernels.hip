@@ -967,6 +967,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
                 }
             target = min(max(target, 2u), (uint32_t)kScopeTarget);
             hdr.produced = 1;
+            hdr.capture_start = caps[0].some ? caps[0].start : caps[1].start;
+            hdr.capture_frac = caps[0].some ? caps[0].frac_offset : caps[1].frac_offset;
             const bool newest = blk + 1 == a.n_blocks;
             for (int slot = 0; slot < 2; ++slot) {
                 if (!caps[slot].some) continue;

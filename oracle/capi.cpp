@@ -457,6 +457,13 @@ int omxo_oscilloscope_last_cycle_rate(const omxo_oscilloscope* h, float* hz) {
     *hz = *r;
     return 1;
 }
+int omxo_oscilloscope_last_capture(const omxo_oscilloscope* h, uint32_t* start, float* frac_offset) {
+    const auto& c = h->p.last_capture();
+    if (!c) return 0;
+    if (start) *start = (uint32_t)c->start;
+    if (frac_offset) *frac_offset = c->frac_offset;
+    return 1;
+}
 uint64_t omxo_oscilloscope_trace_len(const omxo_oscilloscope* h, int slot) { return h->p.trace_buffer(slot).size(); }
 
 // PeriodEstimator::estimate_period on a bare slice (reference test :957-995)

@@ -556,6 +556,7 @@ public:
         snapshot_.epoch = epoch;
     }
 
+    const std::optional<Capture>& last_capture() const { return last_capture_; }
     std::optional<float> last_cycle_rate() const {  // :602-609
         std::optional<float> p = source_.trigger.period;
         if (!p)
@@ -629,6 +630,7 @@ public:
             captures[s] = linked ? linked : capture(traces_[s].buffer, traces_[s].trigger);
         }
         if (!captures[0] && !captures[1]) return false;
+        last_capture_ = captures[0] ? captures[0] : captures[1];  // test-only view (omx_oscilloscope_last_capture)
         write_snapshot(captures);
         out = snapshot_;
         return true;
@@ -684,6 +686,7 @@ private:
 
     OscilloscopeConfig config_;
     OscilloscopeSnapshot snapshot_;
+    std::optional<Capture> last_capture_;
     bool has_history_channels_ = false;
     size_t history_channels_ = 0;
     TraceState traces_[2];

@@ -126,7 +126,7 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
     us = st.process_device(d_pcm.data_ptr(), 256, blocks, 2, FS, pos)
     uo = sc.process_device(d_pcm.data_ptr(), 256, blocks, 2, FS, pos)
     corr = dview(torch, us.d_correlations, (S, blocks, 4)).clone()
-    hdr = dview(torch, uo.d_headers, (S, blocks, 8)).clone()
+    hdr = dview(torch, uo.d_headers, (S, blocks, 10))[:, :, :8].clone()   # capture_start / capture_frac follow
     smp = dview(torch, uo.d_samples, (S, 2, int(uo.sample_stride))).clone()
     assert torch.equal(corr[:32].repeat(S // 32, 1, 1), corr)
     assert torch.equal(hdr[:32].repeat(S // 32, 1, 1), hdr)
@@ -154,7 +154,9 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
         assert bool(h.locked) == (op.last_cycle_rate() is not None) and h.samples_per_channel == wo.samples_per_channel
         bar("oscilloscope: rel |d cycle rate|", abs(h.period - FS / op.last_cycle_rate()) / h.period, 1e-4)
         flat = np.concatenate([samples[c, :h.samples_per_channel] for c in range(h.channels)])
-        bar("oscilloscope (Stable): |d trace|", np.abs(flat - wo.samples).max(), 2e-3)
+        from test_gpu_parity_meters import check_stable_trace
+        check_stable_trace("oscilloscope (Stable)", flat, wo.samples, (h.capture_start, h.capture_frac), op.last_capture(),
+                           float(np.abs(np.diff(distinct[s % 32], axis=0)).max()), s)
 
 
 @pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256), (8192, 512)])
