@@ -636,9 +636,9 @@ int omx_loudness_meters(const omx_loudness_snapshot* snapshots, int on_device, u
  * :215-237 (fs_accum, fs_resolve), src/util/audio/frequency.rs:15-37.
  * The reference runs this as two raster passes over an Rg16Float target; here the
  * same per-point math feeds an f32 grid (no half-float saturation channel), and
- * quad coverage follows the rasteriser's pixel-centre / top-left rule.  Columns are
- * given oldest -> newest (age = n_columns - 1 - column) instead of through the
- * renderer's slot ring.
+ * quad coverage follows the rasteriser's pixel-centre / top-left rule.
+ * omx_spectrogram_splat takes columns oldest -> newest (age = n_columns - 1 - column);
+ * omx_spectrogram_history_* keeps the renderer's slot ring (below) and splats from it.
  * ===================================================================== */
 enum { OMX_FREQ_SCALE_LINEAR = 0, OMX_FREQ_SCALE_LOGARITHMIC = 1, OMX_FREQ_SCALE_ERB = 2 };
 typedef struct omx_splat_view {
@@ -662,6 +662,42 @@ int omx_spectrogram_splat(const omx_spectrogram_point* points, const uint32_t* c
                           uint64_t n_streams, uint64_t n_columns, uint64_t column_stride,
                           float reassigned_power_scale, const omx_splat_view* view, void* stream,
                           float* accum, float* db);
+
+
+/* ---- the column history ring between the processor and the splat passes --------------------------------------------
+ * SpectrogramHistory::apply_update (`spectrogram/state.rs:53-175`: reset, capacity changes with remap_retained, one slot per
+ * new column, slot_counts) together with the renderer's ring buffer it drives (`spectrogram/render.rs:457-597`: resize copy
+ * plan, slot uploads) and the accumulation pass over it (`render.rs:106-160`; age = (newest_col + hl - slot) % hl,
+ * `spectrogram.wgsl:141-142`).  The ring lives in device memory: [n_streams][ring_capacity][fft_size / 2 + 1] points (or u16
+ * codes for classic columns) + slot_counts [n_streams][ring_capacity]; the bookkeeping integers are common to the streams of a
+ * lock-step bank.  `reassigned_points_per_slot` is tracked (state.rs:131-148) but only sizes the reference's vertex buffer. */
+typedef struct omx_spectrogram_history omx_spectrogram_history;
+typedef struct omx_spectrogram_history_info {
+    uint32_t kind;                       /* OMX_COLUMN_* of the ring */
+    uint32_t ring_capacity;
+    uint32_t write_slot;
+    uint32_t col_count;
+    uint32_t points_per_column;          /* fft_size / 2 + 1 */
+    uint32_t reassigned_points_per_slot; /* of stream 0 */
+    uint32_t newest_slot;                /* (write_slot + ring_capacity - 1) % ring_capacity (render.rs:221) */
+    uint32_t visible_slots;              /* min(col_count, ring_capacity) (render.rs:106) */
+} omx_spectrogram_history_info;
+int omx_spectrogram_history_create(uint32_t n_streams, omx_spectrogram_history** out);
+void omx_spectrogram_history_destroy(omx_spectrogram_history* h);
+/* apply one single-stream update (host columns, n_streams must be 1): SpectrogramState::apply_snapshot -> history.apply_update */
+int omx_spectrogram_history_apply(omx_spectrogram_history* h, const omx_spectrogram_update* update);
+/* apply one bank update (device-resident columns of every stream), enqueued on `stream` */
+int omx_spectrogram_bank_history_apply(omx_spectrogram_history* h, const omx_spectrogram_bank_update* update, void* stream);
+int omx_spectrogram_history_get_info(omx_spectrogram_history* h, omx_spectrogram_history_info* out);
+/* slot_counts of one stream -> out[0 .. min(capacity, ring_capacity)) ; returns ring_capacity (or < 0) */
+int64_t omx_spectrogram_history_slot_counts(omx_spectrogram_history* h, uint64_t stream_index, uint32_t* out, uint64_t capacity);
+/* copy one ring slot of one stream to host memory: points (12 B each) or u16 codes; n_out = valid entries of the slot */
+int omx_spectrogram_history_fetch_slot(omx_spectrogram_history* h, uint64_t stream_index, uint32_t slot, void* dst,
+                                       uint64_t dst_capacity_elems, uint64_t* n_out);
+/* accumulation + resolve over the visible slots of the ring; accum / db as in omx_spectrogram_splat ([n_streams][width][height]);
+ * on_device = 0: host outputs (synchronous), 1: device outputs, enqueued on `stream`.  A classic ring yields an empty image. */
+int omx_spectrogram_history_splat(omx_spectrogram_history* h, float reassigned_power_scale, const omx_splat_view* view,
+                                  int on_device, void* stream, float* accum, float* db);
 
 #ifdef __cplusplus
 }

@@ -713,3 +713,88 @@ def spectrogram_splat(api: Api, columns: Sequence[np.ndarray], view: CSplatView,
     api.check(f(pts.ctypes.data, counts.ctypes.data, 0, 1, len(columns), stride, reassigned_power_scale, C.byref(view), None,
                 accum.ctypes.data, db.ctypes.data if want_db else None))
     return accum.T, db.T
+
+
+# --------------------------------------------------------------------------- column history ring
+class CSpectrogramHistoryInfo(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("ring_capacity", C.c_uint32), ("write_slot", C.c_uint32), ("col_count", C.c_uint32),
+                ("points_per_column", C.c_uint32), ("reassigned_points_per_slot", C.c_uint32), ("newest_slot", C.c_uint32),
+                ("visible_slots", C.c_uint32)]
+
+
+class SpectrogramHistory:
+    """SpectrogramHistory::apply_update + the renderer's column ring (reference src/visuals/spectrogram/state.rs:53-175,
+    render.rs:106-160, 457-597) for `n_streams` lock-step streams (the oracle models one)."""
+
+    def __init__(self, api: Api, n_streams: int = 1):
+        self.api, self.n_streams = api, n_streams
+        self._h = C.c_void_p()
+        api.check(api.fn("spectrogram_history_create", C.c_int, [C.c_uint32, C.POINTER(C.c_void_p)])(n_streams, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.fn("spectrogram_history_destroy", None, [C.c_void_p])(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def apply(self, update: "SpectrogramUpdate"):
+        """one single-stream update (host columns)"""
+        cols = update.new_columns
+        offs = np.zeros(len(cols) + 1, np.uint64)
+        for i, c in enumerate(cols):
+            offs[i + 1] = offs[i] + len(c)
+        cu = CSpectrogramUpdate()
+        cu.fft_size, cu.hop_size, cu.history_length, cu.n_columns = update.fft_size, update.hop_size, update.history_length, len(cols)
+        cu.sample_rate, cu.reassigned_power_scale, cu.reset, cu.kind = update.sample_rate, update.reassigned_power_scale, int(update.reset), update.kind
+        cu.column_offsets = offs.ctypes.data_as(C.POINTER(C.c_uint64))
+        keep = None
+        if update.kind == COLUMN_REASSIGNED:
+            keep = (np.concatenate([np.asarray(c, np.float32).reshape(-1, 3) for c in cols]) if cols else np.zeros((0, 3), np.float32))
+            keep = np.ascontiguousarray(keep, np.float32)
+            cu.points = C.cast(keep.ctypes.data, C.POINTER(CSpectrogramPoint))
+        else:
+            keep = np.ascontiguousarray(np.concatenate([np.asarray(c, np.uint16) for c in cols]) if cols else np.zeros(0, np.uint16))
+            cu.codes = keep.ctypes.data_as(C.POINTER(C.c_uint16))
+        self.api.check(self.api.fn("spectrogram_history_apply", C.c_int, [C.c_void_p, C.c_void_p])(self._h, C.byref(cu)))
+
+    def apply_bank(self, bank_update, stream: int = 0):
+        """one bank update (device-resident columns): CSpectrogramBankUpdate as returned by banks.SpectrogramBank"""
+        self.api.check(self.api.fn("spectrogram_bank_history_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p])(
+            self._h, C.byref(bank_update), C.c_void_p(stream or 0)))
+
+    def info(self) -> CSpectrogramHistoryInfo:
+        out = CSpectrogramHistoryInfo()
+        self.api.check(self.api.fn("spectrogram_history_get_info", C.c_int, [C.c_void_p, C.c_void_p])(self._h, C.byref(out)))
+        return out
+
+    def slot_counts(self, stream_index: int = 0) -> np.ndarray:
+        cap = self.info().ring_capacity
+        out = np.zeros(max(cap, 1), np.uint32)
+        f = self.api.fn("spectrogram_history_slot_counts", C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64])
+        rc = f(self._h, stream_index, out.ctypes.data, cap)
+        if rc < 0:
+            self.api.check(int(rc))
+        return out[:cap]
+
+    def fetch_slot(self, slot: int, stream_index: int = 0) -> np.ndarray:
+        i = self.info()
+        n = C.c_uint64()
+        buf = np.zeros((i.points_per_column, 3), np.float32) if i.kind == COLUMN_REASSIGNED else np.zeros(i.points_per_column, np.uint16)
+        self.api.check(self.api.fn("spectrogram_history_fetch_slot", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                                               C.POINTER(C.c_uint64)])(
+            self._h, stream_index, slot, buf.ctypes.data, i.points_per_column, C.byref(n)))
+        return buf[:n.value]
+
+    def splat(self, view: CSplatView, reassigned_power_scale: float):
+        """host images of every stream: (accum, db) as [n_streams][height][width] float32"""
+        accum = np.zeros((self.n_streams, view.width, view.height), np.float32)
+        db = np.zeros_like(accum)
+        self.api.check(self.api.fn("spectrogram_history_splat", C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                                          C.c_void_p])(
+            self._h, reassigned_power_scale, C.byref(view), 0, None, accum.ctypes.data, db.ctypes.data))
+        return accum.transpose(0, 2, 1), db.transpose(0, 2, 1)

@@ -44,6 +44,15 @@ __device__ __forceinline__ void wave_merged_add(float* acc, bool active, uint32_
     if (active && (lane == 63 || next != key)) unsafeAtomicAdd(acc + key, v);
 }
 
+// column c (time order, 0 = oldest) -> storage slot; age = n_columns - 1 - c is the reference's (newest + hl - slot) % hl
+// (spectrogram.wgsl:141) for the visible slots of the ring
+__device__ __forceinline__ uint32_t splat_slots(const SplatArgs& a) { return a.ring_slots ? a.ring_slots : a.n_columns; }
+__device__ __forceinline__ uint32_t splat_slot(const SplatArgs& a, uint32_t col) {
+    if (!a.ring_slots) return col;
+    const uint32_t v = a.slot0 + col;
+    return v >= a.ring_slots ? v - a.ring_slots : v;
+}
+
 constexpr uint32_t SPLAT_COLS_PER_WG = 8;  // global-atomic form: a workgroup walks 8 columns x ceil(points / 256) chunks
 
 struct SplatFootprint {
@@ -56,7 +65,7 @@ __device__ __forceinline__ SplatFootprint splat_footprint(const SplatArgs& a, ui
     SplatFootprint f{};
     bool live = i < n;
     omx_spectrogram_point p{0.0f, 0.0f, 0.0f};
-    if (live) p = a.points[((uint64_t)s * a.n_columns + col) * a.column_stride + i];
+    if (live) p = a.points[((uint64_t)s * splat_slots(a) + splat_slot(a, col)) * a.column_stride + i];
     const float zoomed = ((freq_scale_value(a.freq_scale, p.freq_hz) - a.axis_lo) * a.axis_inv - a.uv_lo) * a.inv_uv;
     live = live && p.power > 0.0f && !(zoomed < -0.01f) && !(zoomed > 1.01f);
     float power = p.power;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void splat_accumulate_kernel(SplatArgs a) {
     float* acc = a.accum + (uint64_t)s * a.width * a.height;
     const uint32_t reach = (uint32_t)ceilf(a.scale_factor) + 1u;  // a footprint is at most ceil(scale_factor) + 1 wide
     for (uint32_t col = blockIdx.x * SPLAT_COLS_PER_WG; col < col_end; ++col) {
-        const uint32_t n = min(a.counts[(uint64_t)s * a.n_columns + col], a.column_stride);
+        const uint32_t n = min(a.counts[(uint64_t)s * splat_slots(a) + splat_slot(a, col)], a.column_stride);
         for (uint32_t base = 0; base < n; base += 256u) {
             if (base + (threadIdx.x & ~63u) >= n) continue;  // whole wave past the end of the column
             const SplatFootprint f = splat_footprint(a, s, col, n, base + threadIdx.x);
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(1024) void splat_tiled_kernel(SplatArgs a, SplatTil
     float* acc = a.accum + (uint64_t)s * a.width * a.height;
     const uint32_t reach = (uint32_t)ceilf(sf) + 1u;
     for (uint32_t col = c0; col < c1; ++col) {
-        const uint32_t n = min(a.counts[(uint64_t)s * a.n_columns + col], a.column_stride);
+        const uint32_t n = min(a.counts[(uint64_t)s * splat_slots(a) + splat_slot(a, col)], a.column_stride);
         for (uint32_t base = 0; base < n; base += 1024u) {
             const SplatFootprint f = splat_footprint(a, s, col, n, base + threadIdx.x);
             if (!f.live || f.j1 <= j_lo || f.j0 >= j_hi) continue;
@@ -193,6 +202,59 @@ void launch_splat(const SplatArgs& a, float* db, float power_scale, hipStream_t 
         }
     }
     if (db) hipLaunchKernelGGL(splat_resolve_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, stream, a.accum, db, px, power_scale);
+}
+
+// ---- column history ring ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void history_scatter_kernel(HistoryScatterArgs a) {
+    const uint32_t c = a.first_col + blockIdx.x, s = blockIdx.y;
+    uint32_t slot = (a.slot0 + c) % a.ring_slots;
+    const uint32_t n = a.src_counts ? min(a.src_counts[(uint64_t)s * a.n_cols + c], a.ring_stride) : min(a.src_stride, a.ring_stride);
+    const unsigned char* src_b = a.src + ((uint64_t)s * a.n_cols + c) * a.src_stride * a.elem;
+    unsigned char* dst_b = a.ring + ((uint64_t)s * a.ring_slots + slot) * a.ring_stride * a.elem;
+    if (a.elem == 2u) {  // classic u16 codes: bank rows of an odd bin count are only 2-byte aligned
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(src_b);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(dst_b);
+        for (uint32_t i = threadIdx.x; i < a.ring_stride; i += 256u) dst[i] = i < n ? src[i] : (uint16_t)0;  // zero-filled to the stride
+    } else {             // 12-byte points: whole 4-byte words
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(src_b);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(dst_b);
+        const uint32_t words = n * (a.elem / 4u);
+        for (uint32_t i = threadIdx.x; i < words; i += 256u) dst[i] = src[i];
+    }
+    if (a.slot_counts && threadIdx.x == 0) a.slot_counts[(uint64_t)s * a.ring_slots + slot] = a.src_counts[(uint64_t)s * a.n_cols + c];
+}
+void launch_history_scatter(const HistoryScatterArgs& a, hipStream_t stream) {
+    if (a.n_cols <= a.first_col || a.n_streams == 0) return;
+    hipLaunchKernelGGL(history_scatter_kernel, dim3(a.n_cols - a.first_col, a.n_streams), dim3(256), 0, stream, a);
+}
+
+__global__ __launch_bounds__(256) void history_remap_kernel(HistoryRemapArgs a) {
+    const uint32_t src = blockIdx.x, s = blockIdx.y;
+    const uint32_t dst = (src + a.old_slots - a.start) % a.old_slots;
+    if (dst >= a.keep || dst >= a.new_slots) return;
+    const uint32_t* from = reinterpret_cast<const uint32_t*>(a.old_ring + ((uint64_t)s * a.old_slots + src) * a.stride_bytes);
+    uint32_t* to = reinterpret_cast<uint32_t*>(a.new_ring + ((uint64_t)s * a.new_slots + dst) * a.stride_bytes);
+    for (uint32_t i = threadIdx.x; i < a.stride_bytes / 4u; i += 256u) to[i] = from[i];
+    if (a.old_counts && threadIdx.x == 0) a.new_counts[(uint64_t)s * a.new_slots + dst] = a.old_counts[(uint64_t)s * a.old_slots + src];
+}
+void launch_history_remap(const HistoryRemapArgs& a, hipStream_t stream) {
+    if (a.old_slots == 0 || a.n_streams == 0) return;
+    hipLaunchKernelGGL(history_remap_kernel, dim3(a.old_slots, a.n_streams), dim3(256), 0, stream, a);
+}
+
+__global__ __launch_bounds__(64) void history_fit_kernel(const uint32_t* slot_counts, uint32_t ring_slots, uint32_t* state) {
+    uint32_t needed = 1;
+    for (uint32_t i = threadIdx.x; i < ring_slots; i += 64u) needed = max(needed, slot_counts[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) needed = max(needed, (uint32_t)__shfl_xor((int)needed, o));
+    if (threadIdx.x == 0) {
+        const uint32_t current = state[0];
+        const unsigned long long quad = max((unsigned long long)needed * 4ull, 1ull);
+        if (needed > current || (unsigned long long)current > quad) state[0] = needed;
+    }
+}
+void launch_history_fit(const uint32_t* slot_counts, uint32_t ring_slots, uint32_t* state, hipStream_t stream) {
+    hipLaunchKernelGGL(history_fit_kernel, dim3(1), dim3(64), 0, stream, slot_counts, ring_slots, state);
 }
 
 }  // namespace omx

@@ -791,6 +791,55 @@ int omxo_loudness_meters(const omx_loudness_snapshot* snapshots, int, uint64_t n
     return OMX_PRODUCED;
 }
 
+// ---- column history ring (splat.hpp: SpectrogramHistoryRing) ----
+struct omxo_spectrogram_history {
+    SpectrogramHistoryRing ring;
+};
+int omxo_spectrogram_history_create(uint32_t n_streams, omxo_spectrogram_history** out) {
+    if (!out || n_streams != 1) return OMX_ERR_INVALID;  // the checker models one stream
+    *out = new omxo_spectrogram_history();
+    return OMX_NONE;
+}
+void omxo_spectrogram_history_destroy(omxo_spectrogram_history* h) { delete h; }
+int omxo_spectrogram_history_apply(omxo_spectrogram_history* h, const omx_spectrogram_update* update) {
+    if (!h || !update) return OMX_ERR_INVALID;
+    h->ring.apply_update(*update);
+    return OMX_NONE;
+}
+int omxo_spectrogram_history_get_info(omxo_spectrogram_history* h, omx_spectrogram_history_info* out) {
+    if (!h || !out) return OMX_ERR_INVALID;
+    const SpectrogramHistoryRing& r = h->ring;
+    *out = omx_spectrogram_history_info{r.col_kind, r.ring_capacity, r.write_slot, r.col_count, r.points_per_column,
+                                        r.reassigned_points_per_slot, r.newest_slot(), r.visible_slots()};
+    return OMX_NONE;
+}
+int64_t omxo_spectrogram_history_slot_counts(omxo_spectrogram_history* h, uint64_t stream_index, uint32_t* out, uint64_t capacity) {
+    if (!h || stream_index != 0) return OMX_ERR_INVALID;
+    for (uint64_t i = 0; i < capacity && i < h->ring.slot_counts.size(); ++i) out[i] = h->ring.slot_counts[i];
+    return (int64_t)h->ring.ring_capacity;
+}
+int omxo_spectrogram_history_fetch_slot(omxo_spectrogram_history* h, uint64_t stream_index, uint32_t slot, void* dst, uint64_t cap,
+                                        uint64_t* n_out) {
+    if (!h || stream_index != 0 || slot >= h->ring.ring_capacity || !dst) return OMX_ERR_INVALID;
+    const SpectrogramHistoryRing& r = h->ring;
+    const uint32_t ppc = r.points_per_column;
+    if (r.col_kind == OMX_COLUMN_REASSIGNED) {
+        const uint64_t n = std::min<uint64_t>(r.slot_counts[slot], ppc);
+        std::memcpy(dst, r.points.data() + (size_t)slot * ppc, (size_t)std::min(n, cap) * sizeof(omx_spectrogram_point));
+        if (n_out) *n_out = n;
+    } else {
+        std::memcpy(dst, r.codes.data() + (size_t)slot * ppc, (size_t)std::min<uint64_t>(ppc, cap) * sizeof(uint16_t));
+        if (n_out) *n_out = ppc;
+    }
+    return OMX_NONE;
+}
+int omxo_spectrogram_history_splat(omxo_spectrogram_history* h, float reassigned_power_scale, const omx_splat_view* view, int, void*,
+                                   float* accum, float* db) {
+    if (!h || !view || !accum || view->width == 0 || view->height == 0) return OMX_ERR_INVALID;
+    h->ring.splat(reassigned_power_scale, *view, accum, db);
+    return OMX_PRODUCED;
+}
+
 // ---- reassigned-splat accumulation + resolve (splat.hpp) ----
 void omxo_splat_view_size(omx_splat_view* view) {
     if (view) splat_view_size(view);

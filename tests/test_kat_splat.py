@@ -80,3 +80,98 @@ def test_resolve_floor_and_many_points(backend):
     acc, db = one(backend, pts, v, scale=2.0 / 3.0)
     assert db[2, 3] == -140.0                                   # 6.7e-19 -> -181.7 dB, clamped to the analysis floor
     assert abs(acc[2, 2] - 1.0) < 1e-4 and abs(db[2, 2] - 10.0 * np.log10(2.0 / 3.0)) < 1e-3
+
+
+# ---- the column history ring (reference src/visuals/spectrogram/state.rs:53-175; its tests :803-861 ported) ---------------
+def _update(history_length, reset, columns, kind, ppc=2, scale=0.25):
+    return capi.SpectrogramUpdate(fft_size=(ppc - 1) * 2, hop_size=1, sample_rate=48000.0, history_length=history_length, reset=reset,
+                                  reassigned_power_scale=scale, kind=kind, new_columns=columns)
+
+
+def classic_update(history_length, reset, values):        # state.rs:771-775
+    return _update(history_length, reset, [np.full(2, int(v), np.uint16) for v in values], capi.COLUMN_CLASSIC)
+
+
+def reassigned_update(history_length, reset, counts, ppc=3):   # state.rs:777-786
+    point = np.array([0.0, 100.0, 0.01], np.float32)
+    return _update(history_length, reset, [np.tile(point, (c, 1)) for c in counts], capi.COLUMN_REASSIGNED, ppc=ppc)
+
+
+def ring_values(h):
+    """the classic test values as they sit in the slots"""
+    i = h.info()
+    return [int(h.fetch_slot(s)[0]) for s in range(i.ring_capacity)]
+
+
+def test_resize_copy_plans_preserve_visible_columns(backend):
+    # state.rs:810-834: the copy plans [2, 3, 0, 1] and [MAX, MAX, 0, 1] are observed through the slots' contents
+    h = capi.SpectrogramHistory(backend)
+    h.apply(classic_update(4, True, [10, 11, 12, 13]))
+    assert ring_values(h) == [10, 11, 12, 13]
+    h.apply(classic_update(4, False, [14, 15]))                     # uploads to slots 0, 1
+    i = h.info()
+    assert (i.ring_capacity, i.col_count, i.write_slot) == (4, 4, 2) and ring_values(h) == [14, 15, 12, 13]
+    h.apply(classic_update(6, False, [16]))                         # grow while full: remap_retained(write_slot, col_count)
+    i = h.info()
+    assert (i.ring_capacity, i.col_count, i.write_slot) == (6, 5, 5)
+    assert ring_values(h)[:5] == [12, 13, 14, 15, 16]               # plan [2, 3, 0, 1], then the new column in slot 4
+    assert (i.newest_slot, i.visible_slots) == (4, 5)
+
+    h = capi.SpectrogramHistory(backend)
+    h.apply(classic_update(4, True, [10, 11, 12, 13]))
+    h.apply(classic_update(2, False, [14]))                         # shrink: keep the newest two, then upload to slot 0
+    i = h.info()
+    assert (i.ring_capacity, i.col_count, i.write_slot) == (2, 2, 1)
+    assert ring_values(h) == [14, 13]                               # plan [MAX, MAX, 0, 1] -> [12, 13], slot 0 overwritten
+
+
+def test_reassigned_params_track_sparse_slot_counts(backend):
+    # state.rs:836-861
+    h = capi.SpectrogramHistory(backend)
+    h.apply(reassigned_update(4, True, [0, 2, 1]))
+    i = h.info()
+    assert i.reassigned_points_per_slot == 2 and i.kind == capi.COLUMN_REASSIGNED
+    assert h.slot_counts().tolist() == [0, 2, 1, 0]
+    assert [len(h.fetch_slot(s)) for s in range(4)] == [0, 2, 1, 0]
+    # hysteresis of fit_reassigned_slot_capacity (state.rs:131-148): shrinks only when more than 4x oversized
+    h.apply(reassigned_update(4, False, [1, 1, 1, 1], ppc=3))
+    assert h.info().reassigned_points_per_slot == 2
+    h.apply(reassigned_update(4, True, [3], ppc=20))
+    h.apply(reassigned_update(4, False, [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 13], ppc=20))
+    assert h.info().reassigned_points_per_slot == 13 and h.slot_counts().tolist() == [13, 0, 0, 0]   # column 27 lands in slot (1 + 27) % 4
+
+
+def test_history_ring_age_arithmetic_matches_time_ordered_splat(backend):
+    """age = (newest_col + hl - slot) % hl (spectrogram.wgsl:141-142): the image splatted from the ring equals the image of
+    the same columns handed over oldest -> newest, through wrap-around, growth and shrink of the ring."""
+    rng = np.random.default_rng(7)
+    view = capi.splat_view(backend, 24.0, 32.0, freq_scale=capi.FREQ_SCALE_LINEAR)
+    ppc = 9
+    h = capi.SpectrogramHistory(backend)
+    kept = []                                                       # the columns a time-ordered consumer would still hold
+
+    def column():
+        n = int(rng.integers(0, ppc + 1))
+        pts = np.zeros((n, 3), np.float32)
+        pts[:, 0] = rng.uniform(-3.0, 0.0, n)
+        pts[:, 1] = np.sort(rng.uniform(100.0, 23000.0, n))
+        pts[:, 2] = rng.uniform(0.1, 1.0, n)
+        return pts
+
+    for step, (hist, n_new, reset) in enumerate([(6, 4, True), (6, 5, False), (10, 3, False), (10, 9, False), (4, 2, False), (4, 0, False),
+                                                 (4, 11, False), (7, 1, False), (7, 3, True), (3, 1, False)]):
+        cols = [column() for _ in range(n_new)]
+        h.apply(_update(hist, reset, cols, capi.COLUMN_REASSIGNED, ppc=ppc, scale=1.0))
+        if reset:
+            kept = []
+        kept = (kept + cols)[-hist:]
+        i = h.info()
+        assert i.ring_capacity == hist and i.visible_slots == min(len(kept), hist) == i.col_count, (step, i.col_count, len(kept))
+        acc, db = h.splat(view, 1.0)
+        want_acc, want_db = capi.spectrogram_splat(backend, kept, view, 1.0) if kept else (np.zeros_like(acc[0]), None)
+        assert np.array_equal(acc[0], want_acc), step
+        if want_db is not None:
+            assert np.array_equal(db[0], want_db, equal_nan=True), step
+        # slot -> age bookkeeping: the newest column sits in newest_slot
+        if kept:
+            assert np.array_equal(h.fetch_slot(i.newest_slot), kept[-1]), step
