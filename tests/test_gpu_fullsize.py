@@ -156,7 +156,8 @@ def test_cfg4_full_size_replication_and_oracle_spot_checks(omx, oracle):
         flat = np.concatenate([samples[c, :h.samples_per_channel] for c in range(h.channels)])
         from test_gpu_parity_meters import check_stable_trace
         check_stable_trace("oscilloscope (Stable)", flat, wo.samples, (h.capture_start, h.capture_frac), op.last_capture(),
-                           float(np.abs(np.diff(distinct[s % 32], axis=0)).max()), s)
+                           float(np.abs(np.diff(distinct[s % 32], axis=0)).max()), h.samples_per_channel,
+                           abs(h.period - FS / op.last_cycle_rate()) / h.period, s)
 
 
 @pytest.mark.parametrize("W,hop", [(2048, 64), (1024, 256), (8192, 512)])

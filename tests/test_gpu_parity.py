@@ -277,4 +277,50 @@ def test_splat_kernel_forms_stay_correct(form):
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", "splat and not forms", os.path.join(here, "test_kat_splat.py"),
                         os.path.join(here, "test_gpu_parity.py")], env=env, capture_output=True, text=True, cwd=os.path.dirname(here))
-    assert r.returncode == 0 and "10 passed" in r.stdout, r.stdout[-2000:]
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and m and int(m.group(1)) >= 13 and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+def test_history_ring_fed_from_device_resident_bank_updates_matches_oracle_ring(omx, oracle):
+    """SURVEY §8f rank 2, the slot ring: bank updates stay on the device (omx_spectrogram_bank_history_apply scatters the new
+    columns into their slots), across several calls, a history_length change (ring resize with remap) and a reset; every
+    stream's ring — slot counts, newest slot content, and the image splatted from the ring — against the oracle's ring fed with
+    the same columns fetched to the host."""
+    S = 3
+    cfg = SpectrogramConfig(fft_size=1024, hop_size=256, use_reassignment=True, history_length=12)
+    bank = banks.SpectrogramBank(omx, cfg, S)
+    hist = capi.SpectrogramHistory(omx, S)
+    refs = [capi.SpectrogramHistory(oracle) for _ in range(S)]
+    view = capi.splat_view(omx, 40.0, 96.0, scale_factor=2.0)
+    at = 0
+    total = 2048 + 256 * 60
+    pcm = np.stack([stream_pcm(20 + s, total) for s in range(S)])
+    plan = [(2048 + 256 * 4, None), (256 * 9, None), (256 * 3, 20), (256 * 15, None), (256 * 2, 5), (256 * 7, None), ("reset", None),
+            (2048 + 256 * 3, None)]
+    for n, new_len in plan:
+        if n == "reset":
+            bank.reset_audio()
+            continue
+        if new_len is not None:
+            cfg = SpectrogramConfig(fft_size=1024, hop_size=256, use_reassignment=True, history_length=new_len)
+            bank.update_config(cfg)
+        up = bank.process_host(pcm[:, at:at + n], 2, 48000.0)
+        at += n
+        assert up is not None
+        hist.apply_bank(up)
+        for s in range(S):
+            cols = [bank.fetch_column(s, c, capi.COLUMN_REASSIGNED, up.column_stride) for c in range(up.n_columns)]
+            refs[s].apply(capi.SpectrogramUpdate(up.fft_size, up.hop_size, up.sample_rate, up.history_length, bool(up.reset),
+                                                 up.reassigned_power_scale, up.kind, cols))
+        gi = hist.info()
+        acc, db = hist.splat(view, up.reassigned_power_scale)
+        for s in range(S):
+            ri = refs[s].info()
+            assert (gi.ring_capacity, gi.write_slot, gi.col_count, gi.newest_slot, gi.visible_slots) == \
+                   (ri.ring_capacity, ri.write_slot, ri.col_count, ri.newest_slot, ri.visible_slots)
+            assert np.array_equal(hist.slot_counts(s), refs[s].slot_counts())
+            assert np.array_equal(hist.fetch_slot(gi.newest_slot, s), refs[s].fetch_slot(ri.newest_slot))
+            want_acc, want_db = refs[s].splat(capi.splat_view(oracle, 40.0, 96.0, scale_factor=2.0), up.reassigned_power_scale)
+            bar("history ring splat: |d accumulated power| / max", np.abs(acc[s] - want_acc[0]).max() / max(want_acc.max(), 1e-30), 1e-5)
+        assert gi.reassigned_points_per_slot == refs[0].info().reassigned_points_per_slot
