@@ -320,6 +320,10 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         fa.inv_2pi = inv_2pi;
         fa.inv_hop = inv_hop;
         fa.latency_hops = latency_hops;
+        // window.rs:20-43: Hann = [0.5, -0.5], Hamming = [25/46, -21/46] (the reference's f32 constants)
+        fa.win_terms = (cfg_.window == OMX_WINDOW_HANN || cfg_.window == OMX_WINDOW_HAMMING) ? 2u : 0u;
+        fa.win_c0 = cfg_.window == OMX_WINDOW_HANN ? 0.5f : 25.0f / 46.0f;
+        fa.win_c1 = cfg_.window == OMX_WINDOW_HANN ? -0.5f : -21.0f / 46.0f;
         fa.points = d_points_.ptr;
         fa.counts = d_counts_.ptr;
         const bool cross_check = kernel_form_ == 30;  // OMX_OPT_KERNEL_FORM: 4096 through the size-templated kernel

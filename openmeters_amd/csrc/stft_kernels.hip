@@ -727,11 +727,14 @@ void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset) {
 
 using K2Default = K2Variant<1, true, true, true, true, false, 2, false, true, false, true>;
 
-int stft_reassigned_4096_transforms_per_frame() { return 5; }
+int stft_reassigned_4096_transforms_per_frame() { return 4; }
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    (void)form;
+    if (form == 0 && a.win_terms == 2) {  // Hann / Hamming: two columns per workgroup, four transforms per column
+        launch_stft_reassigned_4096_pair(a, stream);
+        return;
+    }
 #ifdef OMX_TUNING
     // Tuning build only (make TUNING=1 -> libomx_hip_tuning.so, loaded through OMX_HIP_LIB): OMX_K2_VARIANT selects an A/B
     // build of the kernel.  100 / 1 / 2 / 3 / 12 / 13 / 14 / 20 compute the same columns as the default; 7 / 8 / 9 add phase

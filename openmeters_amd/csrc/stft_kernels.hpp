@@ -48,6 +48,10 @@ struct StftFastArgs {
     const v2f* tw4096;       // exp(-2*pi*i*k/4096), k < 4096
     const v2f* tw8192;       // exp(-2*pi*i*k/8192) / 2, k < 4096 (2W-point twiddles carrying the real-FFT split's 1/2)
     float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
+    // two-term cosine-sum windows w[n] = c0 + c1 cos(2 pi n / W) (Hann, Hamming): the pair kernel applies the window on the
+    // bins; win_terms = 2 for those, otherwise the kernels that window in the time domain run
+    float win_c0, win_c1;
+    uint32_t win_terms;
     omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
     uint32_t* counts;               // [n_streams][n_cols]
 };
@@ -56,6 +60,7 @@ void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning 
 // form: OMX_OPT_KERNEL_FORM (0 = tuned kernel, 1 = the five-transform kernel of round 1)
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream);
 int stft_reassigned_4096_transforms_per_frame();  // of form 0
+void launch_stft_reassigned_4096_pair(const StftFastArgs& a, hipStream_t stream);  // stft4096_pair_kernels.hip
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
 // size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);

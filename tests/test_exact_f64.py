@@ -4,8 +4,8 @@ against an EXACT-arithmetic (f64 numpy) restatement of a spectrogram column, ora
   * CPU (`-m "not gpu"`): the oracle is within 1e-5 of the column maximum of exact arithmetic (power), 1e-7 of Nyquist
     (amplitude-weighted f-hat) and 1e-4 hop (amplitude-weighted t-hat) on cfg2 input — so any f32 implementation that is
     equally close to exact arithmetic (rustfft included) is within 2e-5 of this oracle;
-  * GPU (`-m gpu`): the same for the HIP product, and the two distances are within 2x of each other (neither
-    implementation is the noisier one; floors keep the ratio meaningful when both errors sit at the f32 ulp level).
+  * GPU (`-m gpu`): the same for the HIP product, whose distance must stay within 2x of the oracle's (it may be closer;
+    floors keep the ratio meaningful when both errors sit at the f32 ulp level).
 Classic columns are compared in the code domain: the u16 quantum is 0.0024 dB (5.5e-4 in linear power), so the pin is
 |dB(code) - dB(exact)| <= half a code + 1e-4 dB on every bin within 40 dB of the column maximum."""
 import os
@@ -84,11 +84,13 @@ def test_hip_and_oracle_are_equally_close_to_exact_arithmetic_reassigned(omx, or
         bar(f"{who} vs exact f64: |dP| / max P", e["power"], 1e-5)
         bar(f"{who} vs exact f64: r |df| / (fs/2)", e["freq"], 1e-7)
         bar(f"{who} vs exact f64: r |dt| hops", e["time"], 1e-4)
-    # within 2x of each other; the floors are the f32 resolution of each quantity (1 ulp of the peak power; 1 ulp of a
-    # frequency near Nyquist; 1 ulp of a +-8 hop offset) below which the ratio is rounding luck
+    # the product must not be the noisier implementation: its distance from exact arithmetic within 2x of the oracle's.  (The
+    # other direction is recorded too, with a 4x bar: the fused kernels take fewer rounding steps than the oracle's radix-2
+    # transforms and sit CLOSER to exact arithmetic on some shapes.)  The floors are the f32 resolution of each quantity (1 ulp
+    # of the peak power, of a frequency near Nyquist, of a +-8 hop offset), below which the ratio is rounding luck.
     for k, floor in (("power", 2e-7), ("freq", 2e-9), ("time", 2e-6)):
         bar(f"hip / oracle distance ratio from exact ({k})", max(h[k], floor) / max(o[k], floor), 2.0)
-        bar(f"oracle / hip distance ratio from exact ({k})", max(o[k], floor) / max(h[k], floor), 2.0)
+        bar(f"oracle / hip distance ratio from exact ({k})", max(o[k], floor) / max(h[k], floor), 4.0)
 
 
 @pytest.mark.gpu
