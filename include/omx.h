@@ -401,6 +401,13 @@ int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int 
                                  void* stream, omx_stereometer_bank_update* out);
 int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block,
                                float correlations[4], uint32_t* produced);
+/* decimated points of one band of the newest snapshot (`stereometer/processor.rs:152-170`) -> dst[2 * n_pairs] (l, r);
+ * n_pairs = 0 when that band produced nothing */
+int omx_stereometer_bank_fetch_points(omx_stereometer_bank* b, uint64_t stream_index, uint32_t band, float* dst,
+                                      uint64_t dst_capacity_pairs, uint64_t* n_pairs);
+/* OMX_OPT_KERNEL_FORM: 0 = choose by call shape (default), 1 = sequential kernels only (reference operation order, bit-identical
+ * filters), 2 = chunk-parallel evaluation whenever the shape allows (2 channels, blocks of a multiple of 16 frames, >= 2 blocks) */
+int omx_stereometer_bank_set_option(omx_stereometer_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *
  * Oscilloscope — reference src/visuals/oscilloscope/processor.rs

@@ -235,6 +235,17 @@ class StereometerBank(_BlockBank):
         assert pcm.shape[1] % block_frames == 0
         return self._process(pcm.ctypes.data, False, block_frames, pcm.shape[1] // block_frames, channels, sample_rate, positions, 0)
 
+    def set_option(self, option, value):
+        self.api.check(self.api.fn("stereometer_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
+
+    def fetch_points(self, stream_index, band, capacity=4096):
+        buf = np.zeros((capacity, 2), np.float32)
+        n = C.c_uint64()
+        self.api.check(self.api.fn("stereometer_bank_fetch_points", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                                              C.POINTER(C.c_uint64)])(
+            self._h, stream_index, band, buf.ctypes.data, capacity, C.byref(n)))
+        return buf[:n.value]
+
     def fetch(self, stream_index, block):
         corr = (C.c_float * 4)()
         produced = C.c_uint32()

@@ -467,6 +467,18 @@ int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, u
     return guarded([&] { return b->impl.fetch(stream_index, block, correlations, produced, b->impl.last_stream()); });
 }
 
+int omx_stereometer_bank_fetch_points(omx_stereometer_bank* b, uint64_t stream_index, uint32_t band, float* dst, uint64_t cap_pairs,
+                                      uint64_t* n_pairs) {
+    if (!b || !dst || !n_pairs) return OMX_ERR_INVALID;
+    if (cap_pairs < b->impl.target()) return OMX_ERR_INVALID;
+    return guarded([&] { return b->impl.fetch_points(stream_index, band, dst, n_pairs, b->impl.last_stream()); });
+}
+int omx_stereometer_bank_set_option(omx_stereometer_bank* b, uint32_t option, uint64_t value) {
+    if (!b || option != OMX_OPT_KERNEL_FORM || value > 2) return OMX_ERR_INVALID;
+    b->impl.chunked_mode(value == 0 ? -1 : (value == 1 ? 0 : 1));
+    return OMX_NONE;
+}
+
 // ------------------------------------------------------------------ oscilloscope
 void omx_oscilloscope_config_default(omx_oscilloscope_config* out) {
     if (out) oscilloscope_config_default(out);

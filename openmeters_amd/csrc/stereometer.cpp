@@ -59,6 +59,46 @@ uint32_t StereometerBank::segment_frames() const {  // :142-144
                                       0x7FFFFFFFu);
 }
 
+// Zero-input transition of the band cascades over `frames` frames (and its powers 2, 4 ... 32), in f64 from the f32 coefficients: column m of T_band is the
+// state after `frames` steps of Biquad::process (dsp.rs:422-432) with x = 0 started from the unit state e_m.  State order:
+// [stage A element 0 (z0, z1), A element 1, stage B element 0, B element 1]; the low band has stage A only.
+static std::vector<double> band_transitions(const BiquadCoef& lp_lo, const BiquadCoef& hp_lo, const BiquadCoef& lp_hi, const BiquadCoef& hp_hi,
+                                            uint64_t frames) {
+    std::vector<double> T(3 * 6 * 64, 0.0);  // [band][power 1, 2, 4 ... 32][8][8]
+    const BiquadCoef* stage_a[3] = {&lp_lo, &hp_lo, &hp_lo};
+    const BiquadCoef* stage_b[3] = {nullptr, &lp_hi, &hp_hi};
+    for (int band = 0; band < 3; ++band) {
+        const int n = stage_b[band] ? 8 : 4;
+        for (int m = 0; m < n; ++m) {
+            double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            z[m] = 1.0;
+            for (uint64_t f = 0; f < frames; ++f) {
+                double x = 0.0;
+                for (int e = 0; e < n / 2; ++e) {
+                    const BiquadCoef& c = e < 2 ? *stage_a[band] : *stage_b[band];
+                    const double out = (double)c.b[0] * x + z[2 * e];
+                    z[2 * e] = (double)c.b[1] * x - (double)c.a[0] * out + z[2 * e + 1];
+                    z[2 * e + 1] = (double)c.b[2] * x - (double)c.a[1] * out;
+                    x = out;
+                }
+            }
+            for (int k = 0; k < n; ++k) T[(size_t)band * 384 + (size_t)k * 8 + m] = z[k];
+        }
+        // T^2, T^4 ... T^32 by repeated squaring (the scan's doubling steps)
+        for (int p = 1; p < 6; ++p) {
+            const double* prev = T.data() + (size_t)band * 384 + (size_t)(p - 1) * 64;
+            double* next = T.data() + (size_t)band * 384 + (size_t)p * 64;
+            for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 8; ++j) {
+                    long double acc = 0.0L;
+                    for (int k = 0; k < 8; ++k) acc += (long double)prev[i * 8 + k] * (long double)prev[k * 8 + j];
+                    next[i * 8 + j] = (double)acc;
+                }
+        }
+    }
+    return T;
+}
+
 void StereometerBank::reset_audio() {  // :92-97
     for (int b = 0; b < 4; ++b) hist_len_[b] = 0;
     pending_full_reset_ = true;  // band_splitter.clear() + correlators = default
@@ -162,6 +202,55 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
     sa.hist_frames = frames;
     for (int b = 0; b < 4; ++b) sa.hist_pos[b] = hist_pos_[b];
     sa.correlations = correlations_.ptr;
+    // chunk-parallel evaluation for bank-sized calls (stereometer_chunked.hip); everything else — single-stream handles, short
+    // calls, other channel counts — stays on the sequential kernels, whose results are bit-identical to the reference's order
+    const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
+    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && (uint64_t)n_streams_ * n_blocks >= 512));
+    if (chunked) {
+        if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
+            transition_.upload(band_transitions(lp_lo, hp_lo, lp_hi, hp_hi, block_frames), stream);
+            transition_rate_ = cfg_.sample_rate;
+            transition_frames_ = block_frames;
+        }
+        const uint64_t items = (uint64_t)n_streams_ * n_blocks;
+        chunk_state_.reserve((size_t)items * 3 * 16);
+        chunk_moments_.reserve((size_t)items * 12);
+        bad_.reserve(1);
+        state_backup_.reserve(state_.count);
+        OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
+        OMX_HIP(hipMemcpyAsync(state_backup_.ptr, state_.ptr, state_.count * sizeof(StereoLaneState), hipMemcpyDeviceToDevice, stream));
+        StereoChunkArgs ca{};
+        ca.pcm = d_pcm;
+        ca.frames_total = total;
+        ca.block_frames = (uint32_t)block_frames;
+        ca.n_blocks = (uint32_t)n_blocks;
+        ca.n_streams = n_streams_;
+        ca.m00 = sa.fmt.m[0][0];
+        ca.m10 = sa.fmt.m[1][0];
+        ca.m01 = sa.fmt.m[0][1];
+        ca.m11 = sa.fmt.m[1][1];
+        ca.lp_lo = lp_lo;
+        ca.hp_lo = hp_lo;
+        ca.lp_hi = lp_hi;
+        ca.hp_hi = hp_hi;
+        ca.analyze_bands = cfg_.analyze_bands;
+        ca.emit_band_points = cfg_.emit_band_points;
+        ca.alpha = alpha_;
+        ca.state = state_.ptr;
+        ca.history = history_.ptr;
+        ca.hist_frames = frames;
+        for (int b = 0; b < 4; ++b) ca.hist_pos[b] = hist_pos_[b];
+        ca.correlations = correlations_.ptr;
+        ca.chunk_state = chunk_state_.ptr;
+        ca.chunk_moments = chunk_moments_.ptr;
+        ca.bad = bad_.ptr;
+        launch_stereometer_chunked(ca, transition_.ptr, std::pow(1.0 - alpha_, (double)block_frames), stream);
+        OMX_HIP(hipGetLastError());
+        // non-finite input / output breaks the linearity the chunks rely on (Biquad::process resets, dsp.rs:428-431): the
+        // sequential kernel then redoes the whole call from the saved state (it exits at once when the flag is clear)
+        sa.run_if = bad_.ptr;
+        sa.state_in = state_backup_.ptr;
+    }
     launch_stereometer(sa, stream);
     OMX_HIP(hipGetLastError());
 

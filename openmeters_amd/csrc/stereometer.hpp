@@ -31,8 +31,32 @@ struct StereometerArgs {
     uint32_t hist_frames;
     uint64_t hist_pos[4];    // absolute pair count pushed so far per band
     float* correlations;     // [n_streams][n_blocks][4]
+    // fallback of the chunk-parallel path (stereometer_chunked.hip): run only when *run_if != 0, starting from state_in
+    const uint32_t* run_if;
+    const StereoLaneState* state_in;
 };
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream);
+
+// ---- chunk-parallel evaluation (stereometer_chunked.hip): one chunk = one block of the call, 2-channel input
+struct StereoChunkArgs {
+    const float* pcm;  // [n_streams][frames_total][2]
+    uint64_t frames_total;
+    uint32_t block_frames, n_blocks, n_streams;
+    float m00, m10, m01, m11;  // stereo fold weights: left = (0 + s0 m00) + s1 m10, right = (0 + s0 m01) + s1 m11
+    BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;
+    uint32_t analyze_bands, emit_band_points;
+    double alpha;
+    StereoLaneState* state;  // [n_streams][4]
+    float* history;
+    uint32_t hist_frames;
+    uint64_t hist_pos[4];
+    float* correlations;     // [n_streams][n_blocks][4]
+    float* chunk_state;      // [n_streams * n_blocks][3 bands][8 states][2 channels]
+    double* chunk_moments;   // [n_streams * n_blocks][4 bands][3]
+    uint32_t* bad;           // set when a non-finite sample or filter output was seen: the caller re-runs the sequential kernel
+};
+// d_T: [3][6][8][8] f64, the L-frame zero-input transition of the low / mid / high cascades and its powers 2 ... 32; decay = (1 - alpha)^L
+void launch_stereometer_chunked(const StereoChunkArgs& a, const double* d_T, double decay, hipStream_t stream);
 // points[s][band][i] = history pair (oldest + i*frames/target), band points scaled by 0.8 (:152-170)
 void launch_stereometer_rehome(const float* from, float* to, uint32_t n_streams, uint32_t from_frames, uint32_t to_frames,
                                const uint64_t hist_pos[4], const uint64_t keep[4], hipStream_t stream);
@@ -76,6 +100,17 @@ private:
     DeviceBuffer<StereoLaneState> state_;
     DeviceBuffer<float> history_, history_next_, correlations_, points_, staging_;
     DeviceBuffer<uint32_t> produced_;
+    // chunk-parallel path
+    DeviceBuffer<float> chunk_state_;
+    DeviceBuffer<double> chunk_moments_, transition_;
+    DeviceBuffer<uint32_t> bad_;
+    DeviceBuffer<StereoLaneState> state_backup_;
+    float transition_rate_ = 0.0f;
+    uint64_t transition_frames_ = 0;
+    int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows (OMX_OPT_KERNEL_FORM)
+public:
+    void chunked_mode(int mode) { chunked_mode_ = mode; }
+private:
     hipStream_t last_stream_ = nullptr;
 };
 

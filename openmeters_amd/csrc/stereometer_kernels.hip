@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     const uint32_t band = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, in an SGPR
     const uint32_t s = blockIdx.x * 64 + (threadIdx.x & 63);
     if (s >= a.n_streams) return;
+    if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path: nothing non-finite was seen
     const uint32_t gid = s * 4 + band;  // state / history / output slot of this (stream, band)
     const bool active = band == 0 || a.analyze_bands != 0;
-    StereoLaneState st_mem = a.state[gid];
+    StereoLaneState st_mem = (a.state_in ? a.state_in : a.state)[gid];
     StereoRegs st = load_regs(st_mem);
     const BiquadCoef ca = a.stage_a[band], cb = a.stage_b[band];
     const bool use_a = a.use_a[band] != 0, use_b = a.use_b[band] != 0;
@@ -505,7 +506,7 @@ void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     const uint32_t groups = (a.n_streams + 63) / 64;
     static const bool no_roles = [] { const char* e = getenv("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
-    if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles)
+    if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles && !a.run_if)
     {
         const size_t lds = (size_t)4 * kStereoRound * 64 * sizeof(v2f);  // 64 KiB
         static bool attr_set = false;

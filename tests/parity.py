@@ -192,6 +192,43 @@ def check_reassigned_update(got, want, sample_rate, hop, scale=1.0):
     return check_reassigned_columns(got.new_columns, want.new_columns, sample_rate, hop, scale)
 
 
+def stereometer_band_rms(pcm_lr, fs=48000.0, tail=7200):
+    """rms of [full, low, mid, high] (L and R together) over the newest `tail` frames of a 2-channel stream, from an f64
+    evaluation of the reference's band split (RBJ Butterworth sections of src/dsp.rs:402-420 at 200 / 2000 Hz, two in cascade)."""
+    from scipy.signal import lfilter
+
+    def biquad(highpass, f):
+        w = 2.0 * np.pi * min(max(f / fs, 1e-6), 0.49)
+        alpha = np.sin(w) * np.sqrt(0.5)
+        gain, sign = (1.0 + np.cos(w), -1.0) if highpass else (1.0 - np.cos(w), 1.0)
+        return np.array([gain * 0.5, gain * sign, gain * 0.5]) / (1.0 + alpha), np.array([1.0 + alpha, -2.0 * np.cos(w), 1.0 - alpha]) / (1.0 + alpha)
+
+    def lr4(c, x):
+        return lfilter(c[0], c[1], lfilter(c[0], c[1], x, axis=0), axis=0)
+    x = np.asarray(pcm_lr, np.float64)
+    above = lr4(biquad(True, 200.0), x)
+    bands = [x, lr4(biquad(False, 200.0), x), lr4(biquad(False, 2000.0), above), lr4(biquad(True, 2000.0), above)]
+    return [float(np.sqrt(np.mean(np.square(b[-tail:])))) for b in bands]
+
+
+def check_chunked_rho(got, want, band_rms, detail=None):
+    """Correlations of the CHUNK-PARALLEL stereometer form against the oracle.  The reference's band filters are f32 TDF-II sections
+    with poles at 200 Hz / 48 kHz: their samples carry rounding noise of ~4e-5 of the FULL-band level
+    (tests/test_kat_stereometer.py::test_band_filters_sit_on_an_f32_noise_floor: 1e-5 ... 2e-5 absolute on rms 0.3 ... 0.6), i.e.
+    eta_b = 4e-5 rms(full) / rms(band b) relative to what band b keeps.  rho = cross / sqrt(ll rr) moves by
+    ~ eta sqrt(1 - rho^2) (first order) + eta^2 (second order) under such noise — in the reference's own evaluation as much as in
+    a re-ordered one.  Bar: 1e-6 + 0.5 eta sqrt(1 - rho^2) + 0.5 eta^2 (measured maximum: 0.32 of it, profiles/parity_r02.txt);
+    1e-6 flat for the unfiltered full band and for every band within 16 dB of the full level (measured 6e-8)."""
+    for b in range(4):
+        eta = 0.0 if b == 0 else 4e-5 * band_rms[0] / max(band_rms[b], 1e-30)
+        rho = float(want[b])
+        limit = 1e-6 + 0.5 * eta * float(np.sqrt(max(1.0 - rho * rho, 0.0))) + 0.5 * eta * eta
+        err = abs(float(got[b]) - rho)
+        bar("stereometer (chunk-parallel): |d rho| / (1e-6 + 0.5 eta sqrt(1 - rho^2) + 0.5 eta^2)", err / limit, 1.0, (b, float(got[b]), rho, eta, detail))
+        if eta < 2.5e-4:   # bands within ~16 dB of the full level
+            bar("stereometer (chunk-parallel): |d rho|, bands within 16 dB of the full level", err, 1e-6, (b, detail))
+
+
 def classic_column_metrics(hip, ora):
     """u16 dB codes (code = (dB + 144) * 65535 / 156, one code = 0.0024 dB).
     max_code_diff / n_diff: over every bin.  An f32 FFT carries a noise floor of ~1e-7 of the column's largest amplitude,

@@ -15,7 +15,7 @@ import pytest
 from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, OscilloscopeConfig, OscilloscopeProcessor,
                                  StereometerConfig, StereometerProcessor)
-from parity import bar
+from parity import bar, check_chunked_rho, stereometer_band_rms
 from signals import xorshift32_noise
 
 pytestmark = pytest.mark.gpu
@@ -407,3 +407,75 @@ def test_oscilloscope_two_pass_form_equals_block_by_block_calls(omx):
         for ch in range(ha.channels):   # what lies beyond samples_per_channel is not part of the snapshot
             assert np.array_equal(sa[ch, :n].view(np.uint32), sb[ch, :n].view(np.uint32))
             assert np.array_equal(sa[ch, :n].view(np.uint32), sc[ch, :n].view(np.uint32))
+
+
+def test_stereometer_chunk_parallel_form_matches_oracle_and_sequential_form(omx, oracle):
+    """stereometer_chunked.hip: every block of a bank call evaluated in parallel (zero-state pass, state scan, true-state pass,
+    moment scan).  Against the oracle block by block (rho <= 1e-6, points <= 1e-6 of the full scale 1.0) and against the
+    sequential kernels on the same bank input, over three calls: a long one, one whose state carries over, and a short one that
+    falls back to the sequential kernels on the chunked path's state."""
+    S = 6
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02,
+                            target_sample_count=500)
+    calls = [40, 24, 1]
+    total = 256 * sum(calls)
+    pcm = np.stack([cfg4_pcm(30 + s, total) for s in range(S)])
+    pcm[2] *= np.float32(1e-3)        # a quiet stream
+    pcm[3, :256 * 7] = 0.0            # leading silence: states and moments start from exact zeros
+    chunk, seq = banks.StereometerBank(omx, cfg, S), banks.StereometerBank(omx, cfg, S)
+    chunk.set_option(capi.OPT_KERNEL_FORM, 2)
+    seq.set_option(capi.OPT_KERNEL_FORM, 1)
+    refs = [StereometerProcessor(oracle, cfg) for _ in range(S)]
+    at = 0
+    for n_blocks in calls:
+        part = pcm[:, at:at + 256 * n_blocks]
+        chunk.process_host(part, 256, 2, FS)
+        seq.process_host(part, 256, 2, FS)
+        for s in range(S):
+            w = None
+            for blk in range(n_blocks):
+                w = refs[s].process_block(AudioBlock(part[s, blk * 256:(blk + 1) * 256].reshape(-1), 2, FS))
+                gc, pc = chunk.fetch(s, blk)
+                gs, ps = seq.fetch(s, blk)
+                assert pc == ps == (w is not None)
+                if w is not None:
+                    bar("stereometer: |d rho|", np.abs(gs - w.correlations).max(), 1e-6)
+                    check_chunked_rho(gc, w.correlations, stereometer_band_rms(pcm[s, :at + 256 * (blk + 1)]), (s, blk))
+            for band in range(4):
+                got_c, got_s = chunk.fetch_points(s, band), seq.fetch_points(s, band)
+                assert got_c.shape == got_s.shape == w.points[band].shape
+                assert np.array_equal(got_s.view(np.uint32), w.points[band].view(np.uint32))       # sequential form: bit-exact biquads
+                # points: the reference's f32 biquads are themselves 1e-5 ... 2e-5 away from exact arithmetic on these signals
+                # (TDF-II sections with poles at 200 Hz / 48 kHz amplify every rounding error by ~fs / fc;
+                # tests/test_kat_stereometer.py::test_band_filters_sit_on_an_f32_noise_floor measures it on the oracle), so
+                # a second evaluation order differs from the first by that much: bar 1e-4 of full scale, measured 1.7e-5
+                bar("stereometer (chunk-parallel): |d point| vs oracle", np.abs(got_c - w.points[band]).max(), 1e-4)
+        at += 256 * n_blocks
+
+
+def test_stereometer_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx, oracle):
+    """Biquad::process zeroes a filter whose output is not finite (dsp.rs:428-431): not linear, so the chunk-parallel path
+    detects it and the whole call is redone sequentially — the results must equal the sequential form bit for bit, and the oracle."""
+    S, n_blocks = 4, 16
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02,
+                            target_sample_count=300)
+    pcm = np.stack([cfg4_pcm(50 + s, 256 * n_blocks) for s in range(S)])
+    pcm[1, 777, 0] = np.inf
+    pcm[2, 2000:2003, 1] = np.nan
+    pcm[3, 1500, :] = np.float32(3e38)   # finite input, overflowing filter arithmetic
+    chunk, seq = banks.StereometerBank(omx, cfg, S), banks.StereometerBank(omx, cfg, S)
+    chunk.set_option(capi.OPT_KERNEL_FORM, 2)
+    seq.set_option(capi.OPT_KERNEL_FORM, 1)
+    chunk.process_host(pcm, 256, 2, FS)
+    seq.process_host(pcm, 256, 2, FS)
+    for s in range(S):
+        p = StereometerProcessor(oracle, cfg)
+        for blk in range(n_blocks):
+            w = p.process_block(AudioBlock(pcm[s, blk * 256:(blk + 1) * 256].reshape(-1), 2, FS))
+            gc, _ = chunk.fetch(s, blk)
+            gs, _ = seq.fetch(s, blk)
+            assert np.array_equal(gc.view(np.uint32), gs.view(np.uint32)), (s, blk)
+            if w is not None:
+                assert np.nanmax(np.abs(gs - w.correlations), initial=0.0) <= 1e-6
+        for band in range(4):
+            assert np.array_equal(chunk.fetch_points(s, band).view(np.uint32), seq.fetch_points(s, band).view(np.uint32))

@@ -44,3 +44,44 @@ def test_none_until_segment_is_full_then_band_correlations(backend):
     assert last.points[0].shape == (960, 2)
     assert all(len(last.points[b]) == 0 for b in (1, 2, 3))  # emit_band_points is off
     assert np.all(last.correlations < -0.999)
+
+
+def test_band_filters_sit_on_an_f32_noise_floor(oracle):
+    """Not a reference test: the evidence behind the bars of the chunk-parallel stereometer form.  The reference evaluates its
+    LR4 band split with f32 TDF-II biquads (src/dsp.rs:399-437); with poles at 200 Hz / 48 kHz every rounding error is amplified
+    by ~fs / fc, so its band samples are 1e-5 ... 2e-5 (of a +-0.8 full scale) away from EXACT arithmetic on the cfg4 signals —
+    measured here on the oracle against scipy's f64 `lfilter` with the same f32 coefficients.  Any other evaluation order of the
+    same f32 arithmetic (the chunk-parallel kernels) differs from the reference's by the same order: hence |d point| <= 1e-4,
+    not 1e-6, for that form (the sequential kernels keep the reference's order and stay bit-exact)."""
+    from scipy.signal import lfilter
+    from golden_inputs import cfg4_pcm
+    FS = 48000.0
+    f32 = np.float32
+
+    def biquad(highpass, f):     # Biquad::new (dsp.rs:402-420) in f32
+        ratio = np.clip(f32(f) / f32(FS), f32(1e-6), f32(0.49))
+        ang = f32(6.2831855) * ratio
+        sin, cos = f32(np.sin(ang)), f32(np.cos(ang))
+        alpha = sin * f32(0.70710677)
+        gain, sign = (f32(1) + cos, f32(-1)) if highpass else (f32(1) - cos, f32(1))
+        inv = f32(1) / (f32(1) + alpha)
+        return (np.array([gain * f32(0.5) * inv, gain * inv * sign, gain * f32(0.5) * inv], np.float64),
+                np.array([1.0, f32(-2) * cos * inv, (f32(1) - alpha) * inv], np.float64))
+
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=960)
+    worst = 0.0
+    for s in (30, 32):
+        n = 256 * 40
+        pcm = cfg4_pcm(s, n)
+        p = StereometerProcessor(oracle, cfg)
+        for k in range(0, n, 256):
+            w = p.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+        hp_lo, lp_hi = biquad(True, 200.0), biquad(False, 2000.0)
+        x = pcm.astype(np.float64)
+        above = lfilter(*hp_lo, lfilter(*hp_lo, x, axis=0), axis=0)
+        mid = lfilter(*lp_hi, lfilter(*lp_hi, above, axis=0), axis=0)
+        got = w.points[2].astype(np.float64) / 0.8
+        err = float(np.abs(got - mid[-960:]).max())
+        assert 3e-6 < err < 1e-4, err      # 1.7e-5 / 2.1e-5 measured: the reference's own distance from exact arithmetic
+        worst = max(worst, err)
+    assert worst > 1e-5
