@@ -377,6 +377,10 @@ int omx_loudness_bank_set_option(omx_loudness_bank* b, uint32_t option, uint64_t
         b->impl.timer().enabled = value != 0;
         return OMX_NONE;
     }
+    if (option == OMX_OPT_KERNEL_FORM && value <= 2) {  // 0 = by call shape, 1 = sequential kernels, 2 = chunk-parallel when the shape allows
+        b->impl.chunked_mode(value == 0 ? -1 : (value == 1 ? 0 : 1));
+        return OMX_NONE;
+    }
     return OMX_ERR_INVALID;
 }
 

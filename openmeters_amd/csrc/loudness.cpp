@@ -59,6 +59,33 @@ static double channel_weight(uint8_t position) {  // :174-183
     }
 }
 
+// Zero-input transition of the K-weighting TDF-II over `frames` samples and its powers 2, 4 ... 32 (f64): [6][4][4].
+// One step with x = 0 (loudness/processor.rs:153-162): y = f0; f0' = f1 - a1 y; f1' = f2 - a2 y; f2' = f3 - a3 y; f3' = -a4 y.
+static std::vector<double> k_weighting_transitions(const double b[5], const double a[5], uint64_t frames) {
+    (void)b;
+    std::vector<double> T(6 * 16, 0.0);
+    for (int m = 0; m < 4; ++m) {
+        long double f[4] = {0, 0, 0, 0};
+        f[m] = 1.0L;
+        for (uint64_t n = 0; n < frames; ++n) {
+            const long double y = f[0];
+            f[0] = f[1] - (long double)a[1] * y;
+            f[1] = f[2] - (long double)a[2] * y;
+            f[2] = f[3] - (long double)a[3] * y;
+            f[3] = -(long double)a[4] * y;
+        }
+        for (int k = 0; k < 4; ++k) T[(size_t)k * 4 + m] = (double)f[k];
+    }
+    for (int p = 1; p < 6; ++p)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                long double acc = 0.0L;
+                for (int k = 0; k < 4; ++k) acc += (long double)T[(size_t)(p - 1) * 16 + i * 4 + k] * (long double)T[(size_t)(p - 1) * 16 + k * 4 + j];
+                T[(size_t)p * 16 + i * 4 + j] = (double)acc;
+            }
+    return T;
+}
+
 LoudnessBank::LoudnessBank(const omx_loudness_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {
     cfg_ = cfg;  // :225-232: the config is stored as given; the weighting uses the sanitised rate
     k_weighting_coefficients((double)sanitize_sample_rate(cfg.sample_rate), b_, a_);
@@ -69,6 +96,7 @@ void LoudnessBank::clear_state(hipStream_t stream) {
     if (state_.ptr) OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(LoudnessChannelState), stream));
     if (ring_.ptr) OMX_HIP(hipMemsetAsync(ring_.ptr, 0, ring_.count * sizeof(double), stream));
     state_clean_ = true;
+    q_valid_ = true;  // no samples yet: the running totals of the chunk-parallel path start from nothing
 }
 
 void LoudnessBank::reset_audio() {  // :234-236 every ChannelState back to default
@@ -143,8 +171,76 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     la.state = state_.ptr;
     la.floor_db = cfg_.floor_db;
     la.snapshots = snapshots_.ptr;
+    // chunk-parallel evaluation for bank-sized calls (loudness_chunked.hip): every block of the call in parallel
+    constexpr uint64_t kQLen = 4096;
+    bool shape_ok = (channels == 1 || channels == 2 || channels == 4 || channels == 8) && block_frames % 64 == 0 && n_blocks >= 2 &&
+                    frames_seen_ % 64 == 0 && ring_len_ / 64 + frames / 64 + 2 <= kQLen;
+    for (int w = 0; w < 4; ++w) shape_ok = shape_ok && la.capacities[w] % 64 == 0;
+    const uint64_t slots = (uint64_t)n_streams_ * channels;
+    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && slots * n_blocks >= 4096));
     timer_.begin(stream);
-    launch_loudness(la, stream);
+    if (chunked) {
+        if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
+            transition_.upload(k_weighting_transitions(b_, a_, block_frames), stream);
+            transition_rate_ = cfg_.sample_rate;
+            transition_frames_ = block_frames;
+        }
+        LoudChunkArgs ca{};
+        ca.pcm = d_pcm;
+        ca.frames_total = frames;
+        ca.block_frames = (uint32_t)block_frames;
+        ca.n_blocks = (uint32_t)n_blocks;
+        ca.n_streams = n_streams_;
+        ca.channels = channels;
+        for (int i = 0; i < 5; ++i) {
+            ca.b[i] = la.b[i];
+            ca.a[i] = la.a[i];
+        }
+        for (int i = 0; i < OMX_MAX_CHANNELS; ++i) {
+            ca.weights[i] = la.weights[i];
+            ca.positions[i] = la.positions[i];
+        }
+        std::memcpy(ca.fir4, la.fir4, sizeof(ca.fir4));
+        std::memcpy(ca.fir2, la.fir2, sizeof(ca.fir2));
+        ca.delay_len = la.delay_len;
+        for (int w = 0; w < 4; ++w) ca.capacities[w] = la.capacities[w];
+        ca.ring_len = ring_len_;
+        ca.frames_seen = frames_seen_;
+        ca.ring = ring_.ptr;
+        ca.state = state_.ptr;
+        ca.floor_db = cfg_.floor_db;
+        ca.snapshots = snapshots_.ptr;
+        chunk_filter_.reserve((size_t)(slots * n_blocks * 4));
+        sub_sums_.reserve((size_t)(slots * (frames / 64)));
+        if (!q_ring_.ptr) {
+            q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * kQLen));
+            OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
+        }
+        bad_.reserve(1);
+        OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
+        ca.chunk_filter = chunk_filter_.ptr;
+        ca.sub_sums = sub_sums_.ptr;
+        ca.q_ring = q_ring_.ptr;
+        ca.q_len = kQLen;
+        ca.bad = bad_.ptr;
+        rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
+        if (!q_valid_) {  // earlier calls went through the sequential kernels: the running totals come back from the ring
+            launch_loudness_rebuild_q(ca, rebuild_scratch_.ptr, nullptr, stream);
+            q_valid_ = true;
+        }
+        launch_loudness_chunked(ca, transition_.ptr, stream);
+        OMX_HIP(hipGetLastError());
+        // non-finite PCM (pass A's flag): nothing above touched the state; the sequential kernel does the call instead, and
+        // the running totals are rebuilt from the ring it leaves
+        la.run_if = bad_.ptr;
+        launch_loudness(la, stream);
+        LoudChunkArgs after = ca;
+        after.frames_seen = frames_seen_ + frames;
+        launch_loudness_rebuild_q(after, rebuild_scratch_.ptr, bad_.ptr, stream);
+    } else {
+        launch_loudness(la, stream);
+        q_valid_ = false;
+    }
     timer_.end(stream);
     OMX_HIP(hipGetLastError());
     frames_seen_ += frames;

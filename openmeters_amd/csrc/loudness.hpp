@@ -40,8 +40,35 @@ struct LoudnessArgs {
     omx_loudness_snapshot* snapshots;  // [n_streams][n_blocks]
     uint32_t n_meter_blocks;
     uint32_t role_perm;  // TEMP           // split launch: workgroups [0, n) = K-weighting + windows, [n, 2n) = true peak
+    const uint32_t* run_if;  // fallback launch of the chunk-parallel path: run only when *run_if != 0
 };
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream);
+
+// ---- chunk-parallel evaluation (loudness_chunked.hip)
+struct LoudChunkArgs {
+    const float* pcm;       // [n_streams][frames_total][channels]
+    uint64_t frames_total;
+    uint32_t block_frames, n_blocks, n_streams, channels;  // channels in {1, 2, 4, 8}: slot = stream * channels + channel
+    double b[5], a[5];
+    double weights[OMX_MAX_CHANNELS];
+    uint8_t positions[OMX_MAX_CHANNELS];
+    float fir4[12][3];
+    float fir2[24];
+    uint32_t delay_len;
+    uint64_t capacities[kLoudnessWindows];
+    uint64_t ring_len, frames_seen;
+    double* ring;                  // the sequential kernels' ring: [group of 64 slots][ring slot][64]
+    LoudnessChannelState* state;   // [slots]
+    float floor_db;
+    omx_loudness_snapshot* snapshots;
+    double* chunk_filter;          // [slots][n_blocks][4]: pass A's zero-state end states, then the true start states
+    double* sub_sums;              // [slots][n_blocks * block_frames / 64]
+    double* q_ring;                // [slots][q_len]: running total of the squared samples at the end of every 64-sample sub-block
+    uint64_t q_len;                // power of two
+    uint32_t* bad;
+};
+void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T /* [6][4][4] */, hipStream_t stream);
+void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const uint32_t* only_if, hipStream_t stream);
 
 void loudness_config_default(omx_loudness_config* c);
 void k_weighting_coefficients(double fs, double b[5], double a[5]);
@@ -73,6 +100,15 @@ private:
     DeviceBuffer<float> staging_;
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
+    // chunk-parallel path
+    DeviceBuffer<double> chunk_filter_, sub_sums_, q_ring_, transition_, rebuild_scratch_;
+    DeviceBuffer<uint32_t> bad_;
+    bool q_valid_ = false;
+    float transition_rate_ = 0.0f;
+    uint64_t transition_frames_ = 0;
+    int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows
+public:
+    void chunked_mode(int mode) { chunked_mode_ = mode; }
 };
 
 }  // namespace omx

@@ -146,6 +146,7 @@ __device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float 
 
 template <int B, int DL, int MODE>
 __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gid) {
+    if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path: the PCM was finite
     const uint32_t r = gid & 3, chan = gid >> 2;      // chan = stream * 8 + channel
     const uint32_t s = chan >> a.slot_shift, c = chan & ((1u << a.slot_shift) - 1u);
     const bool live = s < a.n_streams && c < a.channels;
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
     __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t THREADS = SIX ? 384 : 320;
     constexpr uint32_t NBUF = SIX ? 3 : 2, LAG = SIX ? 2 : 1;  // value buffers; rounds between the filter and the windows
+    if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path (workgroup-uniform)
     if (blockIdx.x >= a.n_meter_blocks) {  // true-peak workgroups: 4 phase lanes per channel
         loudness_body<8, DL, 2>(a, (blockIdx.x - a.n_meter_blocks) * THREADS + threadIdx.x);
         return;

@@ -479,3 +479,92 @@ def test_stereometer_chunk_parallel_form_hands_non_finite_input_to_the_sequentia
                 assert np.nanmax(np.abs(gs - w.correlations), initial=0.0) <= 1e-6
         for band in range(4):
             assert np.array_equal(chunk.fetch_points(s, band).view(np.uint32), seq.fetch_points(s, band).view(np.uint32))
+
+
+def test_loudness_chunk_parallel_form_matches_oracle_and_alternates_with_the_sequential_form(omx, oracle):
+    """loudness_chunked.hip: every block of a bank call in parallel (K-weighting by zero-state pass + scan + true-state pass,
+    window sums from a prefix over 64-sample sub-block sums, true peak per block).  Against the oracle block by block (1e-4 dB)
+    through a sequence of calls that alternates the two forms: chunked, chunked (windows fill, ring wraps), sequential (the
+    chunked state must be usable), chunked again (running totals rebuilt from the ring), then a reset."""
+    S, C = 5, 2
+    calls = [(48, 2), (600, 2), (20, 1), (64, 2), (30, 2)]     # (blocks, form): 600 blocks = 3.2 s: the 3 s window fills and refreshes
+    total = 256 * sum(n for n, _ in calls)
+    pcm = np.stack([cfg3_pcm(70 + s, total, C) for s in range(S)])
+    pcm[1, :256 * 30] = 0.0                                    # leading silence
+    pcm[2] *= np.float32(1e-4)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig()) for _ in range(S)]
+    at = 0
+    for n_blocks, form in calls:
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        part = pcm[:, at:at + 256 * n_blocks]
+        assert bank.process_host(part, 256, C, FS) is not None
+        check = sorted(set([0, 1, 2, n_blocks // 2, n_blocks - 2, n_blocks - 1]) & set(range(n_blocks)))
+        for s in range(S):
+            want = [refs[s].process_block(AudioBlock(part[s, k:k + 256].reshape(-1), C, FS)) for k in range(0, 256 * n_blocks, 256)]
+            for blk in check:
+                got = bank.fetch(s, blk)
+                tag = "loudness (chunk-parallel)" if form == 2 else "loudness"
+                bar(f"{tag}: |d short-term LUFS|", abs(got.short_term_loudness - want[blk].short_term_loudness), 1e-4, (s, blk))
+                bar(f"{tag}: |d momentary LUFS|", abs(got.momentary_loudness - want[blk].momentary_loudness), 1e-4, (s, blk))
+                for f in ("rms_fast_db", "rms_slow_db"):
+                    bar(f"{tag}: |d {f}|", np.abs(getattr(got, f) - getattr(want[blk], f)).max(), 1e-4, (s, blk))
+                bar(f"{tag}: |d true_peak_db|", np.abs(got.true_peak_db - want[blk].true_peak_db).max(), 1e-4, (s, blk))
+                assert got.channel_count == want[blk].channel_count and got.positions == want[blk].positions
+        at += 256 * n_blocks
+    bank.reset_audio()
+    refs = [LoudnessProcessor(oracle, LoudnessConfig()) for _ in range(S)]
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    part = pcm[:, :256 * 16]
+    bank.process_host(part, 256, C, FS)
+    for s in range(S):
+        for k in range(0, 256 * 16, 256):
+            w = refs[s].process_block(AudioBlock(part[s, k:k + 256].reshape(-1), C, FS))
+        snapshots_close(bank.fetch(s, 15), w)
+
+
+@pytest.mark.parametrize("channels,rate", [(8, 48000.0), (1, 96000.0), (4, 192000.0)])
+def test_loudness_chunk_parallel_form_other_layouts_and_rates(omx, oracle, channels, rate):
+    """1 / 4 / 8 channels (SURROUND weights), 2x true-peak interpolation at 96 kHz, none at 192 kHz; the chunked and the
+    sequential bank must agree with each other bit for bit on the true peak and within 1e-4 dB elsewhere."""
+    S, n_blocks, block = 3, 24, 512 if rate > 48000.0 else 256
+    pcm = np.stack([cfg3_pcm(s, block * n_blocks, channels) for s in range(S)])
+    positions = capi.SURROUND if channels == 8 else capi.positions_fallback(channels)
+    a, b = banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, channels), banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, channels)
+    a.set_option(capi.OPT_KERNEL_FORM, 2)
+    b.set_option(capi.OPT_KERNEL_FORM, 1)
+    a.process_host(pcm, block, channels, rate, positions)
+    b.process_host(pcm, block, channels, rate, positions)
+    for s in range(S):
+        p = LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate))
+        for blk in range(n_blocks):
+            w = p.process_block(AudioBlock(pcm[s, blk * block:(blk + 1) * block].reshape(-1), channels, rate, positions))
+            ga, gb = a.fetch(s, blk), b.fetch(s, blk)
+            assert np.array_equal(ga.true_peak_db.view(np.uint32), gb.true_peak_db.view(np.uint32))
+            snapshots_close(ga, w)
+            snapshots_close(gb, w)
+
+
+def test_loudness_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx):
+    S, C, n_blocks = 4, 2, 16
+    pcm = np.stack([cfg3_pcm(90 + s, 256 * n_blocks * 2, C) for s in range(S)])
+    pcm[1, 1000, 0] = np.nan
+    pcm[3, 3333, 1] = np.inf
+    a, b = banks.LoudnessBank(omx, LoudnessConfig(), S, C), banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    a.set_option(capi.OPT_KERNEL_FORM, 2)
+    b.set_option(capi.OPT_KERNEL_FORM, 1)
+    for half in range(2):     # second call: finite again; the chunked form continues from the fallback's state and rebuilt totals
+        part = pcm[:, half * 256 * n_blocks:(half + 1) * 256 * n_blocks]
+        if half == 1:
+            part = np.nan_to_num(part, nan=0.0, posinf=0.0)
+        a.process_host(part, 256, C, FS)
+        b.process_host(part, 256, C, FS)
+        for s in range(S):
+            for blk in (0, 5, n_blocks - 1):
+                ga, gb = a.fetch(s, blk), b.fetch(s, blk)
+                if half == 0:
+                    for f in ("rms_fast_db", "rms_slow_db", "true_peak_db"):
+                        assert np.array_equal(getattr(ga, f).view(np.uint32), getattr(gb, f).view(np.uint32)), (s, blk, f)
+                    assert ga.short_term_loudness == gb.short_term_loudness or (np.isnan(ga.short_term_loudness) and np.isnan(gb.short_term_loudness))
+                elif s in (0, 2):   # streams that never saw a non-finite sample
+                    snapshots_close(ga, gb)
