@@ -387,7 +387,7 @@ def main():
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": "stft_reassigned_4096_kernel",
+            "kernel": "stft_reassigned_4096_pair_kernel",
             "kernel_ms": kernel_ms,
             "launches_timed": launches,
             "bytes_per_frame": bytes_per_frame,

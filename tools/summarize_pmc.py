@@ -37,17 +37,26 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for f in glob.glob(os.path.join(p, "*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "stft_reassigned_4096_kernel" in row.get("Kernel_Name", "") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                if "stft_reassigned_4096_pair_kernel" in row.get("Kernel_Name", "") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
     fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
     write = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
-    rec = {"kernel": "stft_reassigned_4096_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
+    # provenance: which commit and which kernel time this traffic figure belongs to (bench.py echoes it as a tagged record only)
+    commit, kernel_ms, transforms = os.environ.get("OMX_PROFILE_COMMIT"), None, None
+    try:
+        with open(os.path.join(out, "bench_line.json")) as fh:
+            line = json.loads(fh.read().strip().splitlines()[-1])
+        kernel_ms, transforms = line["roofline"]["kernel_ms"], line["roofline"].get("transforms_per_frame")
+    except Exception:
+        pass
+    rec = {"kernel": "stft_reassigned_4096_pair_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE x2)",
-           "launches": len(traffic["FETCH_SIZE"]), "workload": {"streams_per_gpu": 64, "columns_per_step_per_gpu": 65536}}
+           "launches": len(traffic["FETCH_SIZE"]), "commit": commit, "kernel_ms": kernel_ms, "transforms_per_frame": transforms,
+           "workload": {"config": "cfg2", "streams_per_gpu": 64, "columns_per_step_per_gpu": 65536}}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
-    lines.append(f"== HBM traffic per launch (stft_reassigned_4096_kernel): {rec['hbm_bytes_per_launch'] / 1e9:.3f} GB ==")
+    lines.append(f"== HBM traffic per launch (stft_reassigned_4096_pair_kernel): {rec['hbm_bytes_per_launch'] / 1e9:.3f} GB ==")
 txt = "\n".join(lines)
 print(txt)
 with open(os.path.join(out, "summary.txt"), "w") as fh:
