@@ -40,7 +40,7 @@ struct omx_spectrum_bank {
 
 struct omx_loudness {
     LoudnessBank bank;
-    explicit omx_loudness(const omx_loudness_config& c) : bank(c, 1) {}
+    explicit omx_loudness(const omx_loudness_config& c) : bank(c, 1) { bank.host_outputs(true); }
 };
 struct omx_loudness_bank {
     LoudnessBank impl;
@@ -49,7 +49,7 @@ struct omx_loudness_bank {
 struct omx_stereometer {
     StereometerBank bank;
     std::vector<float> points[4];
-    explicit omx_stereometer(const omx_stereometer_config& c) : bank(c, 1) {}
+    explicit omx_stereometer(const omx_stereometer_config& c) : bank(c, 1) { bank.host_outputs(true); }
 };
 struct omx_stereometer_bank {
     StereometerBank impl;
@@ -60,7 +60,7 @@ struct omx_oscilloscope {
     std::vector<float> samples;
     ScopeBlockHeader last{};
     bool have_last = false;
-    explicit omx_oscilloscope(const omx_oscilloscope_config& c) : bank(c, 1) {}
+    explicit omx_oscilloscope(const omx_oscilloscope_config& c) : bank(c, 1) { bank.host_outputs(true); }
 };
 struct omx_oscilloscope_bank {
     OscilloscopeBank impl;
@@ -70,7 +70,7 @@ struct omx_oscilloscope_bank {
 struct omx_waveform {
     WaveformBank bank;
     std::vector<omx_wave_column> columns;
-    explicit omx_waveform(const omx_waveform_config& c) : bank(c, 1) {}
+    explicit omx_waveform(const omx_waveform_config& c) : bank(c, 1) { bank.host_outputs(true); }
 };
 struct omx_waveform_bank {
     WaveformBank impl;

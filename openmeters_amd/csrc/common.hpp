@@ -87,6 +87,86 @@ struct DeviceBuffer {
     }
 };
 
+// Pinned (page-locked) host memory: the device reads / writes it through PCIe without a copy command; what the device wrote is
+// visible to the host after a stream synchronisation.  The single-stream handles stage their blocks and take their snapshots
+// through it: one synchronisation per call instead of a blocking copy in each direction.
+template <class T>
+struct PinnedBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    void reserve(size_t n) {  // grow-only; contents are NOT preserved
+        if (n <= count) return;
+        release();
+        OMX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault));
+        count = n;
+    }
+};
+
+// Output of a bank: device memory, or — for the single-stream handles, while it stays small — pinned host memory
+template <class T>
+struct OutBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    bool pinned = false;
+    OutBuffer() = default;
+    OutBuffer(const OutBuffer&) = delete;
+    OutBuffer& operator=(const OutBuffer&) = delete;
+    ~OutBuffer() { release(); }
+    void release() {
+        if (ptr) (void)(pinned ? hipHostFree(ptr) : hipFree(ptr));
+        ptr = nullptr;
+        count = 0;
+    }
+    void reserve(size_t n, bool want_pinned = false) {
+        if (n <= count && want_pinned == pinned) return;
+        release();
+        pinned = want_pinned;
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (pinned) OMX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ptr), bytes, hipHostMallocDefault));
+        else OMX_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), bytes));
+        count = n;
+    }
+};
+
+// Host PCM handed to a bank ("pcm_on_device = 0"): a small block goes through pinned memory that the kernels read directly over
+// PCIe (no copy command, no second synchronisation); a large one by one bulk copy into device memory.
+struct HostStage {
+    PinnedBuffer<float> pinned;
+    DeviceBuffer<float> device;
+    const float* stage(const float* host, size_t n, hipStream_t stream) {
+        if (n * sizeof(float) <= (size_t(256) << 10)) {
+            OMX_HIP(hipStreamSynchronize(stream));  // the previous call's kernels may still be reading the buffer
+            pinned.reserve(n);
+            std::memcpy(pinned.ptr, host, n * sizeof(float));
+            return pinned.ptr;
+        }
+        device.reserve(n);
+        OMX_HIP(hipMemcpyAsync(device.ptr, host, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
+        return device.ptr;
+    }
+};
+
+// A bank output handed to the caller: straight from pinned memory once the stream is idle, else one device-to-host copy.
+inline void copy_out(void* dst, const void* src, size_t bytes, bool pinned, hipStream_t stream) {
+    if (pinned) {
+        OMX_HIP(hipStreamSynchronize(stream));  // ~1 us when the kernels that wrote `src` have already finished
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    OMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+}
+
 struct EventTimer {  // HIP-event timing of one kernel family on its launch stream
     hipEvent_t start = nullptr, stop = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

@@ -137,12 +137,9 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * frames * channels;
-        staging_.reserve(n);
-        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-        d_pcm = staging_.ptr;
+        d_pcm = staging_.stage(pcm, n, stream);
     }
-    snapshots_.reserve((size_t)(n_streams_ * n_blocks));
+    snapshots_.reserve((size_t)(n_streams_ * n_blocks), host_outputs_ && n_streams_ * n_blocks <= 4096);
     LoudnessArgs la{};
     la.pcm = d_pcm;
     la.frames_total = frames;
@@ -255,8 +252,7 @@ int LoudnessBank::fetch(uint64_t stream_index, uint64_t block, omx_loudness_snap
         set_last_error("loudness fetch: index out of range");
         return OMX_ERR_INVALID;
     }
-    OMX_HIP(hipMemcpyAsync(dst, snapshots_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(dst, snapshots_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), snapshots_.pinned, stream);
     return OMX_NONE;
 }
 

@@ -96,8 +96,9 @@ private:
     bool state_clean_ = false;
     DeviceBuffer<double> ring_;
     DeviceBuffer<LoudnessChannelState> state_;
-    DeviceBuffer<omx_loudness_snapshot> snapshots_;
-    DeviceBuffer<float> staging_;
+    OutBuffer<omx_loudness_snapshot> snapshots_;
+    bool host_outputs_ = false;
+    HostStage staging_;
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
     // chunk-parallel path
@@ -109,6 +110,7 @@ private:
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
+    void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: snapshots in pinned host memory
 };
 
 }  // namespace omx

@@ -145,16 +145,13 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
         OMX_HIP(hipMemsetAsync(trig_.ptr, 0, trig_.count * sizeof(ScopeTriggerState), stream));
         pending_unlock_ = false;
     }
-    headers_.reserve((size_t)(n_streams_ * n_blocks));
-    samples_.reserve((size_t)n_streams_ * 2 * kScopeTarget);
+    headers_.reserve((size_t)(n_streams_ * n_blocks), host_outputs_ && n_streams_ * n_blocks <= 4096);
+    samples_.reserve((size_t)n_streams_ * 2 * kScopeTarget, host_outputs_ && n_streams_ <= 4);
     const uint64_t total = block_frames * n_blocks;
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * total * channels;
-        staging_.reserve(n);
-        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-        d_pcm = staging_.ptr;
+        d_pcm = staging_.stage(pcm, n, stream);
     }
 
     ScopeArgs sa{};
@@ -230,15 +227,13 @@ int OscilloscopeBank::fetch_header(uint64_t stream_index, uint64_t block, ScopeB
         set_last_error("oscilloscope fetch: index out of range");
         return OMX_ERR_INVALID;
     }
-    OMX_HIP(hipMemcpyAsync(dst, headers_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(dst, headers_.ptr + stream_index * last_blocks_ + block, sizeof(*dst), headers_.pinned, stream);
     return OMX_NONE;
 }
 
 int OscilloscopeBank::fetch_samples(uint64_t stream_index, float* dst, uint64_t count, hipStream_t stream) {
     if (stream_index >= n_streams_ || count > 2 * kScopeTarget) return OMX_ERR_INVALID;
-    OMX_HIP(hipMemcpyAsync(dst, samples_.ptr + stream_index * 2 * kScopeTarget, count * sizeof(float), hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(dst, samples_.ptr + stream_index * 2 * kScopeTarget, count * sizeof(float), samples_.pinned, stream);
     return OMX_NONE;
 }
 

@@ -100,6 +100,7 @@ public:
     hipStream_t last_stream() const { return last_stream_; }
     const ScopeBlockHeader* d_headers() const { return headers_.ptr; }
     const float* d_samples() const { return samples_.ptr; }
+    void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: headers / samples in pinned host memory
 
 private:
     void rebuild(const omx_oscilloscope_config& cfg);
@@ -114,9 +115,12 @@ private:
     uint64_t cap_ = 0, last_blocks_ = 0;
     bool pending_unlock_ = true;
     uint32_t max_kernel_ = 0, fft_size_ = 0;
-    DeviceBuffer<float> rings_, reference_, scratch_, samples_, staging_, tw_fft_, fft_global_, tw256_, tw4096_;
+    HostStage staging_;
+    OutBuffer<float> samples_;
+    bool host_outputs_ = false;
+    DeviceBuffer<float> rings_, reference_, scratch_, tw_fft_, fft_global_, tw256_, tw4096_;
     DeviceBuffer<ScopeTriggerState> trig_;
-    DeviceBuffer<ScopeBlockHeader> headers_;
+    OutBuffer<ScopeBlockHeader> headers_;
     DeviceBuffer<ScopeEstimate> estimates_;
     hipStream_t last_stream_ = nullptr;
 };

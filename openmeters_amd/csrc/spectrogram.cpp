@@ -243,10 +243,7 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         const float* d_pcm = pcm;
         if (!pcm_on_device) {
             const size_t n = (size_t)n_streams_ * frames * channels;
-            staging_.reserve(n);
-            OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-            OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-            d_pcm = staging_.ptr;
+            d_pcm = staging_.stage(pcm, n, stream);
         }
         IngestArgs ia{};
         ia.pcm = d_pcm;
@@ -283,9 +280,11 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
     if (n_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
 
     const uint64_t stride = bin_count;
-    d_counts_.reserve((size_t)(n_streams_ * n_cols));
-    if (reassign) d_points_.reserve((size_t)(n_streams_ * n_cols * stride));
-    else d_codes_.reserve((size_t)(n_streams_ * n_cols * stride));
+    const size_t out_bytes = (size_t)(n_streams_ * n_cols * stride) * (reassign ? sizeof(omx_spectrogram_point) : sizeof(uint16_t));
+    const bool pinned = host_output_limit_ != 0 && out_bytes <= host_output_limit_;
+    d_counts_.reserve((size_t)(n_streams_ * n_cols), pinned);
+    if (reassign) d_points_.reserve((size_t)(n_streams_ * n_cols * stride), pinned);
+    else d_codes_.reserve((size_t)(n_streams_ * n_cols * stride), pinned);
 
     const float sr = cfg_.sample_rate;
     const float bin_hz = sr / (float)fft_size_;             // :446-450
@@ -457,6 +456,8 @@ int SpectrogramSingle::process_block(const omx_block* block, omx_spectrogram_upd
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(block->channels, 1), OMX_MAX_CHANNELS);
     if (block->n_samples < channels) return OMX_NONE;  // AudioBlock::is_empty (dsp.rs:259-261)
     const uint64_t frames = block->n_samples / channels;
+    // The bank stages the block in pinned host memory that the ingest kernel reads directly (HostStage), and small results come
+    // back through pinned memory too: one synchronisation per producing call instead of a blocking copy each way.
     omx_spectrogram_bank_update bu;
     const int rc = bank.process(block->samples, false, frames, channels, block->sample_rate, block->positions, nullptr, &bu);
     if (rc != OMX_PRODUCED) return rc;
@@ -464,18 +465,29 @@ int SpectrogramSingle::process_block(const omx_block* block, omx_spectrogram_upd
     offsets.assign(1, 0);
     points.clear();
     codes.clear();
+    const bool on_host = bank.outputs_on_host();
+    if (on_host) OMX_HIP(hipStreamSynchronize(nullptr));  // the kernels wrote straight into host memory
     if (bu.kind == OMX_COLUMN_REASSIGNED) {
-        std::vector<uint32_t> counts(n_cols);
-        OMX_HIP(hipMemcpy(counts.data(), bu.d_counts, n_cols * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<omx_spectrogram_point> all(n_cols * stride);
-        OMX_HIP(hipMemcpy(all.data(), bu.d_points, all.size() * sizeof(omx_spectrogram_point), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> counts_copy;
+        std::vector<omx_spectrogram_point> all_copy;
+        const uint32_t* counts = bu.d_counts;
+        const omx_spectrogram_point* all = bu.d_points;
+        if (!on_host) {
+            counts_copy.resize(n_cols);
+            OMX_HIP(hipMemcpy(counts_copy.data(), bu.d_counts, n_cols * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            all_copy.resize(n_cols * stride);
+            OMX_HIP(hipMemcpy(all_copy.data(), bu.d_points, all_copy.size() * sizeof(omx_spectrogram_point), hipMemcpyDeviceToHost));
+            counts = counts_copy.data();
+            all = all_copy.data();
+        }
         for (uint64_t c = 0; c < n_cols; ++c) {
-            points.insert(points.end(), all.begin() + c * stride, all.begin() + c * stride + counts[c]);
+            points.insert(points.end(), all + c * stride, all + c * stride + counts[c]);
             offsets.push_back(points.size());
         }
     } else {
         codes.resize(n_cols * stride);
-        OMX_HIP(hipMemcpy(codes.data(), bu.d_codes, codes.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        if (on_host) std::memcpy(codes.data(), bu.d_codes, codes.size() * sizeof(uint16_t));
+        else OMX_HIP(hipMemcpy(codes.data(), bu.d_codes, codes.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
         for (uint64_t c = 0; c < n_cols; ++c) offsets.push_back((c + 1) * stride);
     }
     std::memset(out, 0, sizeof(*out));

@@ -23,6 +23,9 @@ public:
     EventTimer& timer() { return timer_; }
     void force_generic(bool on) { force_generic_ = on; }
     void kernel_form(int form) { kernel_form_ = form; }
+    // single-stream handles: outputs of at most `limit_bytes` go to pinned host memory (read by the host after one stream sync)
+    void host_outputs(size_t limit_bytes) { host_output_limit_ = limit_bytes; }
+    bool outputs_on_host() const { return d_counts_.pinned; }
     hipStream_t last_stream() const { return last_stream_; }
 
 private:
@@ -40,13 +43,15 @@ private:
     float power_scale_ = 1.0f;
     // pending audio: absolute sample counters shared by all streams (lock-step pushes)
     uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
-    DeviceBuffer<float> ring_, staging_;
+    DeviceBuffer<float> ring_;
+    HostStage staging_;
     DeviceBuffer<long long> last_nonzero_, partial_nonzero_;
     DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
     DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_twF_, d_workspace_;
-    DeviceBuffer<omx_spectrogram_point> d_points_;
-    DeviceBuffer<uint32_t> d_counts_;
-    DeviceBuffer<uint16_t> d_codes_;
+    OutBuffer<omx_spectrogram_point> d_points_;
+    OutBuffer<uint32_t> d_counts_;
+    OutBuffer<uint16_t> d_codes_;
+    size_t host_output_limit_ = 0;
     uint64_t last_cols_ = 0, last_stride_ = 0;
     uint32_t last_kind_ = OMX_COLUMN_REASSIGNED;
     EventTimer timer_;
@@ -58,7 +63,7 @@ struct SpectrogramSingle {
     std::vector<uint64_t> offsets;
     std::vector<omx_spectrogram_point> points;
     std::vector<uint16_t> codes;
-    explicit SpectrogramSingle(const omx_spectrogram_config& c) : bank(c, 1) {}
+    explicit SpectrogramSingle(const omx_spectrogram_config& c) : bank(c, 1) { bank.host_outputs(size_t(2) << 20); }
     int process_block(const omx_block* block, omx_spectrogram_update* out);
 };
 

@@ -184,10 +184,7 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         const float* d_pcm = pcm;
         if (!pcm_on_device) {
             const size_t n = (size_t)n_streams_ * frames * channels;
-            staging_.reserve(n);
-            OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-            OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-            d_pcm = staging_.ptr;
+            d_pcm = staging_.stage(pcm, n, stream);
         }
         IngestArgs ia{};
         ia.pcm = d_pcm;
@@ -231,7 +228,7 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     if (averaging) d_power_.reserve((size_t)(n_streams_ * n_traces * hops_launch * bins));
     const size_t traces_count = (size_t)(n_streams_ * hops_out * 4 * bins);
     if (d_traces_.count < traces_count) {
-        d_traces_.reserve(traces_count);
+        d_traces_.reserve(traces_count, host_outputs_ && traces_count * sizeof(float) <= (size_t(1) << 20));
         traces_dirty_ = true;
     }
     if (traces_dirty_ || hops_out != last_hops_out_) {  // inactive traces stay at the floor (:155-157)
@@ -338,9 +335,7 @@ int SpectrumBank::fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStre
         return OMX_ERR_INVALID;
     }
     const uint64_t bins = cfg_.fft_size / 2 + 1;
-    OMX_HIP(hipMemcpyAsync(dst, d_traces_.ptr + (stream_index * last_hops_out_ + hop) * 4 * bins, 4 * bins * sizeof(float),
-                           hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(dst, d_traces_.ptr + (stream_index * last_hops_out_ + hop) * 4 * bins, 4 * bins * sizeof(float), d_traces_.pinned, stream);
     return OMX_NONE;
 }
 

@@ -22,6 +22,7 @@ public:
     uint64_t bins() const { return cfg_.fft_size / 2 + 1; }
     hipStream_t last_stream() const { return last_stream_; }
     void force_generic(bool on) { force_generic_ = on; }
+    void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: traces in pinned host memory
     EventTimer& timer() { return timer_; }
 
 private:
@@ -35,9 +36,12 @@ private:
     uint32_t n_streams_;
     bool emit_all_, prepared_ = false, fast4096_ = false, force_generic_ = false, traces_dirty_ = true;
     uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
-    DeviceBuffer<float> ring_[2], staging_;
+    DeviceBuffer<float> ring_[2];
+    HostStage staging_;
     DeviceBuffer<float> d_window_, d_bin_norm_, d_a_weight_, d_freq_bins_, d_tw_fft_, d_tw256_, d_tw4096_, d_workspace_;
-    DeviceBuffer<float> d_power_, d_smoothed_, d_traces_;
+    DeviceBuffer<float> d_power_, d_smoothed_;
+    OutBuffer<float> d_traces_;
+    bool host_outputs_ = false;
     std::vector<float> freq_bins_, a_weight_;
     float state_floor_ = 0.0f;
     uint64_t last_hops_out_ = 0;
@@ -48,7 +52,7 @@ private:
 struct SpectrumSingle {
     SpectrumBank bank;
     std::vector<float> traces;  // [2][2][bins]
-    explicit SpectrumSingle(const omx_spectrum_config& c) : bank(c, 1, false) {}
+    explicit SpectrumSingle(const omx_spectrum_config& c) : bank(c, 1, false) { bank.host_outputs(true); }
     int process_block(const omx_block* block, omx_spectrum_snapshot* out);
 };
 

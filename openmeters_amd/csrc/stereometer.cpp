@@ -172,12 +172,9 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * total * channels;
-        staging_.reserve(n);
-        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-        d_pcm = staging_.ptr;
+        d_pcm = staging_.stage(pcm, n, stream);
     }
-    correlations_.reserve((size_t)(n_streams_ * n_blocks * 4));
+    correlations_.reserve((size_t)(n_streams_ * n_blocks * 4), host_outputs_ && n_streams_ * n_blocks <= 4096);
 
     StereometerArgs sa{};
     sa.pcm = d_pcm;
@@ -281,7 +278,7 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
         band_valid_[b] = (produced_last && in_play && hist_len_[b] >= frames) ? 1u : 0u;
     }
     if (produced_last) {
-        points_.reserve((size_t)n_streams_ * 4 * target * 2);
+        points_.reserve((size_t)n_streams_ * 4 * target * 2, host_outputs_ && n_streams_ <= 4);
         launch_stereometer_points(history_.ptr, n_streams_, frames, hist_pos_, band_valid_, target, points_.ptr, stream);
         OMX_HIP(hipGetLastError());
     }
@@ -301,9 +298,7 @@ int StereometerBank::fetch(uint64_t stream_index, uint64_t block, float correlat
         set_last_error("stereometer fetch: index out of range");
         return OMX_ERR_INVALID;
     }
-    OMX_HIP(hipMemcpyAsync(correlations, correlations_.ptr + (stream_index * last_blocks_ + block) * 4, 4 * sizeof(float),
-                           hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(correlations, correlations_.ptr + (stream_index * last_blocks_ + block) * 4, 4 * sizeof(float), correlations_.pinned, stream);
     if (produced) *produced = produced_host_[block];
     return OMX_NONE;
 }
@@ -314,9 +309,8 @@ int StereometerBank::fetch_points(uint64_t stream_index, uint32_t band, float* d
         *n_pairs = 0;
         return OMX_NONE;
     }
-    OMX_HIP(hipMemcpyAsync(dst, points_.ptr + (stream_index * 4 + band) * (uint64_t)last_target_ * 2,
-                           (size_t)last_target_ * 2 * sizeof(float), hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+    copy_out(dst, points_.ptr + (stream_index * 4 + band) * (uint64_t)last_target_ * 2, (size_t)last_target_ * 2 * sizeof(float),
+             points_.pinned, stream);
     *n_pairs = last_target_;
     return OMX_NONE;
 }

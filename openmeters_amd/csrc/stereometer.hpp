@@ -98,7 +98,10 @@ private:
     uint32_t band_valid_[4] = {0, 0, 0, 0};
     std::vector<uint32_t> produced_host_;
     DeviceBuffer<StereoLaneState> state_;
-    DeviceBuffer<float> history_, history_next_, correlations_, points_, staging_;
+    DeviceBuffer<float> history_, history_next_;
+    OutBuffer<float> correlations_, points_;
+    bool host_outputs_ = false;
+    HostStage staging_;
     DeviceBuffer<uint32_t> produced_;
     // chunk-parallel path
     DeviceBuffer<float> chunk_state_;
@@ -110,6 +113,7 @@ private:
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows (OMX_OPT_KERNEL_FORM)
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
+    void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: correlations / points in pinned host memory
 private:
     hipStream_t last_stream_ = nullptr;
 };

@@ -91,7 +91,11 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
         if (threadIdx.x == 0) {
             long long m = wave_best[0];
             for (int w = 1; w < 4; ++w) m = wave_best[w] > m ? wave_best[w] : m;
-            a.partial_nonzero[(uint64_t)s * gridDim.x + blockIdx.x] = m;
+            if (gridDim.x == 1 && a.last_nonzero) {  // one workgroup per stream (every single-block call): no finalize launch
+                if (m > a.last_nonzero[s]) a.last_nonzero[s] = m;
+            } else {
+                a.partial_nonzero[(uint64_t)s * gridDim.x + blockIdx.x] = m;
+            }
         }
     }
 }
@@ -118,7 +122,7 @@ void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) 
     if (a.count == 0 || n_streams == 0) return;
     const uint32_t wgs = ingest_partials_per_stream(a.count);
     hipLaunchKernelGGL(ingest_project_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
-    if (a.partial_nonzero && a.last_nonzero)
+    if (a.partial_nonzero && a.last_nonzero && wgs > 1)
         hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, a.partial_nonzero, wgs, a.last_nonzero);
 }
 

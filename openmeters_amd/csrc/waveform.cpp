@@ -119,16 +119,13 @@ int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         }
     }
     const uint64_t kept = std::min<uint64_t>(n_emit, cfg_.max_columns);  // cap_pending_columns (:293-298)
-    columns_.reserve((size_t)(n_streams_ * std::max<uint64_t>(kept, 1) * 4));
-    preview_.reserve((size_t)n_streams_ * 4);
+    columns_.reserve((size_t)(n_streams_ * std::max<uint64_t>(kept, 1) * 4), host_outputs_ && n_streams_ * kept <= 16384);
+    preview_.reserve((size_t)n_streams_ * 4, host_outputs_ && n_streams_ <= 64);
 
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * frames * channels;
-        staging_.reserve(n);
-        OMX_HIP(hipMemcpyAsync(staging_.ptr, pcm, n * sizeof(float), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipStreamSynchronize(stream));  // the caller's buffer is borrowed for the call only (include/omx.h)
-        d_pcm = staging_.ptr;
+        d_pcm = staging_.stage(pcm, n, stream);
     }
     const float progress = (float)std::min(std::max(phase, 0.0), 1.0);  // preview (:300-306)
     WaveformArgs wa{};
@@ -177,11 +174,8 @@ int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
 int WaveformBank::fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream) {
     if (stream_index >= n_streams_) return OMX_ERR_INVALID;
     if (columns && last_cols_)
-        OMX_HIP(hipMemcpyAsync(columns, columns_.ptr + stream_index * last_cols_ * 4, last_cols_ * 4 * sizeof(omx_wave_column),
-                               hipMemcpyDeviceToHost, stream));
-    if (preview)
-        OMX_HIP(hipMemcpyAsync(preview, preview_.ptr + stream_index * 4, 4 * sizeof(omx_wave_column), hipMemcpyDeviceToHost, stream));
-    OMX_HIP(hipStreamSynchronize(stream));
+        copy_out(columns, columns_.ptr + stream_index * last_cols_ * 4, last_cols_ * 4 * sizeof(omx_wave_column), columns_.pinned, stream);
+    if (preview) copy_out(preview, preview_.ptr + stream_index * 4, 4 * sizeof(omx_wave_column), preview_.pinned, stream);
     return OMX_NONE;
 }
 

@@ -41,6 +41,7 @@ void waveform_config_default(omx_waveform_config* c);
 
 class WaveformBank {
 public:
+    void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: columns in pinned host memory
     WaveformBank(const omx_waveform_config& cfg, uint32_t n_streams);
     const omx_waveform_config& config() const { return cfg_; }
     void update_config(const omx_waveform_config& cfg);
@@ -63,9 +64,11 @@ private:
     double column_phase_ = 0.0;
     uint64_t pushes_ = 0, last_cols_ = 0;
     uint32_t color_len_ = 0, slow_len_ = 0;
-    DeviceBuffer<float> color_ring_, hist_ring_, staging_;
+    DeviceBuffer<float> color_ring_, hist_ring_;
+    HostStage staging_;
     DeviceBuffer<WaveLaneState> state_;
-    DeviceBuffer<omx_wave_column> columns_, preview_;
+    OutBuffer<omx_wave_column> columns_, preview_;
+    bool host_outputs_ = false;
     hipStream_t last_stream_ = nullptr;
 };
 
