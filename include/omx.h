@@ -203,6 +203,34 @@ int omx_spectrogram_bank_process(omx_spectrogram_bank* b, const float* pcm, int 
                                  uint64_t frames, uint32_t channels, float sample_rate,
                                  const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
                                  omx_spectrogram_bank_update* out);
+/* Ragged call — streams advance independently (one capture service per stream: `visuals/registry.rs:396-418` resets and
+ * feeds every VisualManager on its own).  Stream s receives frames[s] (<= frames_capacity, 0 allowed) new frames — row s of
+ * `pcm` (DEVICE memory, f32 [n_streams][frames_capacity][channels]) holds them at its start — after reset_audio() when
+ * reset_mask[s] != 0 (reset_mask may be NULL).  `frames` and `reset_mask` are HOST arrays of n_streams entries.  The frame-index
+ * rule, skip / retention and the `reset` flag are evaluated per stream on the device; outputs are laid out with `max_columns`
+ * column slots per stream, of which stream s filled the first d_n_columns[s].  The first ragged call moves the bank to
+ * per-stream positions; omx_spectrogram_bank_process is refused from then on until omx_spectrogram_bank_reset_audio. */
+typedef struct omx_spectrogram_ragged_update {
+    uint64_t fft_size;
+    uint64_t hop_size;
+    uint64_t history_length;
+    uint64_t n_streams;
+    uint64_t max_columns;            /* column slots per stream in d_counts / d_points / d_codes */
+    uint64_t column_stride;
+    const uint32_t* d_n_columns;     /* device [n_streams]: columns produced by each stream in this call */
+    const uint32_t* d_reset;         /* device [n_streams]: SpectrogramUpdate::reset of each stream's update */
+    const uint32_t* d_counts;        /* device [n_streams][max_columns] (0 beyond a stream's own columns) */
+    const omx_spectrogram_point* d_points; /* device [n_streams][max_columns][column_stride] (reassigned) */
+    const uint16_t* d_codes;         /* device [n_streams][max_columns][column_stride] (classic) */
+    float sample_rate;
+    float reassigned_power_scale;
+    uint32_t kind;
+    uint32_t _pad;
+} omx_spectrogram_ragged_update;
+int omx_spectrogram_bank_process_ragged(omx_spectrogram_bank* b, const float* pcm, uint64_t frames_capacity,
+                                        const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                                        float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
+                                        omx_spectrogram_ragged_update* out);
 /* Copy one column of one stream to host memory (synchronises `stream`). */
 int omx_spectrogram_bank_fetch_column(omx_spectrogram_bank* b, uint64_t stream_index,
                                       uint64_t column, void* dst, uint64_t dst_capacity_elems,

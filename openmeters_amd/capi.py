@@ -85,6 +85,14 @@ class CSpectrogramBankUpdate(C.Structure):
                 ("reset", C.c_uint32), ("kind", C.c_uint32)]
 
 
+class CSpectrogramRaggedUpdate(C.Structure):
+    _fields_ = [("fft_size", C.c_uint64), ("hop_size", C.c_uint64), ("history_length", C.c_uint64),
+                ("n_streams", C.c_uint64), ("max_columns", C.c_uint64), ("column_stride", C.c_uint64),
+                ("d_n_columns", C.c_void_p), ("d_reset", C.c_void_p), ("d_counts", C.c_void_p), ("d_points", C.c_void_p),
+                ("d_codes", C.c_void_p), ("sample_rate", C.c_float), ("reassigned_power_scale", C.c_float),
+                ("kind", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class CSpectrumConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_float), ("window", C.c_uint32), ("fft_size", C.c_uint64),
                 ("hop_size", C.c_uint64), ("averaging_mode", C.c_uint32), ("averaging_param", C.c_float),

@@ -204,6 +204,14 @@ int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
         return (int)K2_PHASES;
     });
 }
+int omx_spectrogram_bank_process_ragged(omx_spectrogram_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                        const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                        const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_spectrogram_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_ragged(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value) {
     if (!b) return OMX_ERR_INVALID;
     switch (option) {

@@ -58,6 +58,7 @@ SpectrogramBank::SpectrogramBank(const omx_spectrogram_config& cfg, uint32_t n_s
 }
 
 void SpectrogramBank::reset_audio() {  // :212-217
+    ragged_ = false;  // every stream drops its pending audio: the common host-side positions describe the bank again
     tail_ = head_;
     pending_skip_ = 0;
     clear_last_nonzero(last_stream_);
@@ -218,71 +219,18 @@ void SpectrogramBank::update_config(const omx_spectrogram_config& in, hipStream_
     reset_ = reset_ || rebuild || hop_changed;
 }
 
-int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in,
-                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
-                             omx_spectrogram_bank_update* out) {  // :490-516
-    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
-    last_stream_ = stream;
-    if (frames == 0) return OMX_NONE;  // block.is_empty()
-    const float sample_rate = sanitize_sample_rate(sample_rate_in);
-    if (cfg_.sample_rate != sample_rate) {
-        cfg_.sample_rate = sample_rate;
-        rebuild_fft(stream);
-        tail_ = head_;
-        clear_last_nonzero(stream);
-        reset_ = true;
-    }
-    prepare(stream);
-
-    // ---- push_audio (:412-437)
-    const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
-    pending_skip_ -= skip;
-    if (skip != frames) {
-        const uint64_t count = frames - skip;
-        ensure_ring(count, stream);
-        const float* d_pcm = pcm;
-        if (!pcm_on_device) {
-            const size_t n = (size_t)n_streams_ * frames * channels;
-            d_pcm = staging_.stage(pcm, n, stream);
-        }
-        IngestArgs ia{};
-        ia.pcm = d_pcm;
-        ia.frames_total = frames;
-        ia.skip = skip;
-        ia.count = count;
-        ia.fmt = make_format(channels, positions);
-        ia.n_out = 1;
-        ia.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
-        ia.ring[0] = ring_.ptr;
-        ia.cap = ring_cap_;
-        ia.head = head_;
-        ia.last_nonzero = last_nonzero_.ptr;
-        partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(count));
-        ia.partial_nonzero = partial_nonzero_.ptr;
-        launch_ingest(ia, n_streams_, stream);
-        head_ += count;
-    }
-
-    // ---- process_ready_windows (:281-388)
+// The column kernels of one call: `n_cols` = columns per stream slot of the outputs; lock-step banks pass the common tail,
+// ragged banks the per-stream tails / column counts written by spectrogram_plan_kernel.
+void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint64_t* tails, const uint32_t* cols, hipStream_t stream) {
     const uint64_t W = cfg_.fft_size, hop = cfg_.hop_size;
     const bool reassign = cfg_.use_reassignment != 0;
     const uint64_t bin_count = fft_size_ / 2 + 1;
-    const uint64_t read_len = reassign ? hilbert_len_ : W;
     const uint64_t center_offset = reassign ? (hilbert_len_ - W) / 2 : 0;
-    const uint64_t pending = head_ - tail_;
-    const uint64_t ready = pending >= read_len ? (pending - read_len) / hop + 1 : 0;
-    const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;
-    const uint64_t retained = history_columns(kind, (uint32_t)bin_count, cfg_.history_length);
-    const uint64_t skip_cols = ready > retained ? ready - retained : 0;
-    advance(skip_cols * hop);
-    const uint64_t n_cols = ready - skip_cols;
-    if (n_cols == 0) return OMX_NONE;
-    if (n_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
-
     const uint64_t stride = bin_count;
     const size_t out_bytes = (size_t)(n_streams_ * n_cols * stride) * (reassign ? sizeof(omx_spectrogram_point) : sizeof(uint16_t));
     const bool pinned = host_output_limit_ != 0 && out_bytes <= host_output_limit_;
     d_counts_.reserve((size_t)(n_streams_ * n_cols), pinned);
+    if (cols) OMX_HIP(hipMemsetAsync(d_counts_.ptr, 0, (size_t)(n_streams_ * n_cols) * sizeof(uint32_t), stream));  // ragged: slots past a stream's own columns
     if (reassign) d_points_.reserve((size_t)(n_streams_ * n_cols * stride), pinned);
     else d_codes_.reserve((size_t)(n_streams_ * n_cols * stride), pinned);
 
@@ -300,7 +248,9 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         StftFastArgs fa{};
         fa.ring = ring_.ptr;
         fa.cap = ring_cap_;
-        fa.tail = tail_;
+        fa.tail = tail;
+        fa.tails = tails;
+        fa.cols = cols;
         fa.hop = (uint32_t)hop;
         fa.n_streams = n_streams_;
         fa.n_cols = (uint32_t)n_cols;
@@ -365,7 +315,9 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         StftGenericArgs ga{};
         ga.ring = ring_.ptr;
         ga.cap = ring_cap_;
-        ga.tail = tail_;
+        ga.tail = tail;
+        ga.tails = tails;
+        ga.cols = cols;
         ga.hop = (uint32_t)hop;
         ga.n_streams = n_streams_;
         ga.n_cols = (uint32_t)n_cols;
@@ -398,6 +350,76 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
     timer_.end(stream);
     OMX_HIP(hipGetLastError());
 
+}
+
+int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in,
+                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                             omx_spectrogram_bank_update* out) {  // :490-516
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (ragged_) {
+        set_last_error("spectrogram bank is in ragged mode (per-stream positions): use process_ragged, or reset_audio() first");
+        return OMX_ERR_INVALID;
+    }
+    if (frames == 0) return OMX_NONE;  // block.is_empty()
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (cfg_.sample_rate != sample_rate) {
+        cfg_.sample_rate = sample_rate;
+        rebuild_fft(stream);
+        tail_ = head_;
+        clear_last_nonzero(stream);
+        reset_ = true;
+    }
+    prepare(stream);
+
+    // ---- push_audio (:412-437)
+    const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
+    pending_skip_ -= skip;
+    if (skip != frames) {
+        const uint64_t count = frames - skip;
+        ensure_ring(count, stream);
+        const float* d_pcm = pcm;
+        if (!pcm_on_device) {
+            const size_t n = (size_t)n_streams_ * frames * channels;
+            d_pcm = staging_.stage(pcm, n, stream);
+        }
+        IngestArgs ia{};
+        ia.pcm = d_pcm;
+        ia.frames_total = frames;
+        ia.skip = skip;
+        ia.count = count;
+        ia.fmt = make_format(channels, positions);
+        ia.n_out = 1;
+        ia.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
+        ia.ring[0] = ring_.ptr;
+        ia.cap = ring_cap_;
+        ia.head = head_;
+        ia.last_nonzero = last_nonzero_.ptr;
+        partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(count));
+        ia.partial_nonzero = partial_nonzero_.ptr;
+        launch_ingest(ia, n_streams_, stream);
+        head_ += count;
+    }
+
+    // ---- process_ready_windows (:281-388)
+    const uint64_t W = cfg_.fft_size, hop = cfg_.hop_size;
+    const bool reassign = cfg_.use_reassignment != 0;
+    const uint64_t bin_count = fft_size_ / 2 + 1;
+    const uint64_t read_len = reassign ? hilbert_len_ : W;
+    const uint64_t center_offset = reassign ? (hilbert_len_ - W) / 2 : 0;
+    const uint64_t pending = head_ - tail_;
+    const uint64_t ready = pending >= read_len ? (pending - read_len) / hop + 1 : 0;
+    const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;
+    const uint64_t retained = history_columns(kind, (uint32_t)bin_count, cfg_.history_length);
+    const uint64_t skip_cols = ready > retained ? ready - retained : 0;
+    advance(skip_cols * hop);
+    const uint64_t n_cols = ready - skip_cols;
+    if (n_cols == 0) return OMX_NONE;
+    if (n_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
+
+    launch_columns(n_cols, tail_, nullptr, nullptr, stream);
+    const uint64_t stride = bin_count;
+
     for (uint64_t c = 0; c < n_cols; ++c) advance(hop);  // :384 per column (missing samples -> pending_skip)
 
     last_cols_ = n_cols;
@@ -421,6 +443,139 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
     }
     reset_ = false;  // std::mem::take (:511)
     return OMX_PRODUCED;
+}
+
+void SpectrogramBank::enter_ragged(hipStream_t stream) {
+    // the lock-step state (common head / tail / pending_skip / reset) becomes every stream's own
+    std::vector<uint64_t> h(n_streams_, head_), t(n_streams_, tail_), k(n_streams_, pending_skip_);
+    std::vector<uint32_t> r(n_streams_, reset_ ? 1u : 0u);
+    r_head_.upload(h, stream);
+    r_tail_.upload(t, stream);
+    r_skip_.upload(k, stream);
+    r_reset_flag_.upload(r, stream);
+    for (DeviceBuffer<uint64_t>* b : {&r_ing_head_, &r_col_tail_}) b->reserve(n_streams_);
+    for (DeviceBuffer<uint32_t>* b : {&r_frames_, &r_ing_skip_, &r_ing_count_, &r_ncols_, &r_reset_out_}) b->reserve(n_streams_);
+    r_mask_.reserve(n_streams_);
+    r_frames_host_.reserve(n_streams_);
+    r_mask_host_.reserve(n_streams_);
+    ragged_ = true;
+}
+
+int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                    uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                    omx_spectrogram_ragged_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) return OMX_ERR_INVALID;
+    for (uint32_t s = 0; s < n_streams_; ++s)
+        if (frames[s] > frames_capacity) return OMX_ERR_INVALID;
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (cfg_.sample_rate != sample_rate) {  // a format change concerns every stream of the bank (:493-500)
+        cfg_.sample_rate = sample_rate;
+        rebuild_fft(stream);
+        reset_audio();
+    }
+    prepare(stream);
+    if (!ragged_) enter_ragged(stream);
+    const uint64_t W = cfg_.fft_size, hop = cfg_.hop_size;
+    const bool reassign = cfg_.use_reassignment != 0;
+    const uint64_t bin_count = fft_size_ / 2 + 1;
+    const uint64_t read_len = reassign ? hilbert_len_ : W;
+    const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;
+    const uint64_t retained = history_columns(kind, (uint32_t)bin_count, cfg_.history_length);
+    // every stream enters a call with fewer than read_len pending samples (all of its ready windows were consumed), except right
+    // after the switch from lock-step mode, where the common pending count is known
+    const uint64_t pending_bound = std::max<uint64_t>(head_ - tail_, read_len ? read_len - 1 : 0);
+    const uint64_t most = pending_bound + frames_capacity;
+    const uint64_t max_cols = std::min<uint64_t>(most >= read_len ? (most - read_len) / hop + 1 : 0, retained);
+    if (max_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
+
+    // ring: room for the pending samples + this call's; growth re-homes every stream's pending samples on the device
+    if (most > ring_cap_ || !ring_.ptr) {
+        const uint64_t cap = std::max<uint64_t>(next_pow2(most), 1024);
+        DeviceBuffer<float> bigger;
+        bigger.reserve((size_t)(cap * n_streams_));
+        if (ring_.ptr) {
+            launch_ring_rehome(ring_.ptr, ring_cap_, bigger.ptr, cap, r_head_.ptr, r_tail_.ptr, n_streams_, stream);
+            OMX_HIP(hipStreamSynchronize(stream));
+        }
+        std::swap(ring_.ptr, bigger.ptr);
+        std::swap(ring_.count, bigger.count);
+        ring_cap_ = cap;
+    }
+    // the call's per-stream inputs (small: through pinned memory)
+    OMX_HIP(hipStreamSynchronize(stream));
+    std::memcpy(r_frames_host_.ptr, frames, n_streams_ * sizeof(uint32_t));
+    OMX_HIP(hipMemcpyAsync(r_frames_.ptr, r_frames_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if (reset_mask) {
+        std::memcpy(r_mask_host_.ptr, reset_mask, n_streams_);
+        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_, hipMemcpyHostToDevice, stream));
+    }
+    SpectrogramPlanArgs pa{};
+    pa.n_streams = n_streams_;
+    pa.read_len = read_len;
+    pa.hop = hop;
+    pa.retained = retained;
+    pa.max_cols = (uint32_t)max_cols;
+    pa.frames = r_frames_.ptr;
+    pa.reset_mask = reset_mask ? r_mask_.ptr : nullptr;
+    pa.head = r_head_.ptr;
+    pa.tail = r_tail_.ptr;
+    pa.pending_skip = r_skip_.ptr;
+    pa.reset_flag = r_reset_flag_.ptr;
+    pa.last_nonzero = last_nonzero_.ptr;
+    pa.ing_skip = r_ing_skip_.ptr;
+    pa.ing_count = r_ing_count_.ptr;
+    pa.ing_head = r_ing_head_.ptr;
+    pa.col_tail = r_col_tail_.ptr;
+    pa.n_cols = r_ncols_.ptr;
+    pa.reset_out = r_reset_out_.ptr;
+    launch_spectrogram_plan(pa, stream);
+
+    IngestArgs ia{};
+    ia.pcm = d_pcm;
+    ia.frames_total = frames_capacity;
+    ia.count = frames_capacity;  // grid bound; the per-stream values follow
+    ia.skips = r_ing_skip_.ptr;
+    ia.counts = r_ing_count_.ptr;
+    ia.heads = r_ing_head_.ptr;
+    ia.fmt = make_format(channels, positions);
+    ia.n_out = 1;
+    ia.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
+    ia.ring[0] = ring_.ptr;
+    ia.cap = ring_cap_;
+    ia.last_nonzero = last_nonzero_.ptr;
+    partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(frames_capacity));
+    ia.partial_nonzero = partial_nonzero_.ptr;
+    launch_ingest(ia, n_streams_, stream);
+    OMX_HIP(hipGetLastError());
+    head_ = tail_ = 0;  // from here on only the bound above uses them (pending_bound = read_len - 1)
+
+    if (max_cols > 0) {
+        launch_columns(max_cols, 0, r_col_tail_.ptr, r_ncols_.ptr, stream);
+        OMX_HIP(hipGetLastError());
+    }
+    last_cols_ = max_cols;
+    last_stride_ = bin_count;
+    last_kind_ = kind;
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->fft_size = fft_size_;
+        out->hop_size = hop;
+        out->history_length = cfg_.history_length;
+        out->n_streams = n_streams_;
+        out->max_columns = max_cols;
+        out->column_stride = bin_count;
+        out->d_n_columns = r_ncols_.ptr;
+        out->d_reset = r_reset_out_.ptr;
+        out->d_counts = max_cols ? d_counts_.ptr : nullptr;
+        out->d_points = (max_cols && reassign) ? d_points_.ptr : nullptr;
+        out->d_codes = (max_cols && !reassign) ? d_codes_.ptr : nullptr;
+        out->sample_rate = cfg_.sample_rate;
+        out->reassigned_power_scale = power_scale_;
+        out->kind = kind;
+    }
+    return max_cols ? OMX_PRODUCED : OMX_NONE;
 }
 
 int SpectrogramBank::fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out,

@@ -19,6 +19,11 @@ public:
     void prepare(hipStream_t stream);
     int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrogram_bank_update* out);
+    // Ragged call: stream s receives frames[s] <= frames_capacity new frames (its rows of `pcm` are frames_capacity frames apart),
+    // streams flagged in reset_mask get reset_audio() first.  The per-stream positions then live on the device
+    // (spectrogram_plan_kernel); the bank stays in ragged mode until reset_audio() of the whole bank.
+    int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrogram_ragged_update* out);
     int fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out, hipStream_t stream);
     EventTimer& timer() { return timer_; }
     void force_generic(bool on) { force_generic_ = on; }
@@ -30,6 +35,8 @@ public:
 
 private:
     void rebuild_fft(hipStream_t stream);
+    void launch_columns(uint64_t n_cols, uint64_t tail, const uint64_t* tails, const uint32_t* cols, hipStream_t stream);
+    void enter_ragged(hipStream_t stream);
     void ensure_ring(uint64_t incoming, hipStream_t stream);
     void drain(uint64_t count);
     void advance(uint64_t count);
@@ -52,6 +59,13 @@ private:
     OutBuffer<uint32_t> d_counts_;
     OutBuffer<uint16_t> d_codes_;
     size_t host_output_limit_ = 0;
+    // ragged mode: per-stream positions on the device
+    bool ragged_ = false;
+    DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_col_tail_;
+    DeviceBuffer<uint32_t> r_reset_flag_, r_frames_, r_ing_skip_, r_ing_count_, r_ncols_, r_reset_out_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_frames_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
     uint64_t last_cols_ = 0, last_stride_ = 0;
     uint32_t last_kind_ = OMX_COLUMN_REASSIGNED;
     EventTimer timer_;

@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     const PairConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
 
     const uint32_t col0 = chunk * 2u;
-    const bool have1 = col0 + 1u < a.n_cols;
+    const uint32_t n_cols_s = stft_cols(a, s);  // ragged banks: this stream's own column count
+    if (col0 >= n_cols_s) return;
+    const bool have1 = col0 + 1u < n_cols_s;
     const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
-    const uint64_t p0a = a.tail + (uint64_t)col0 * a.hop, p0b = a.tail + (uint64_t)col1 * a.hop;
+    const uint64_t tail_s = stft_tail(a, s);
+    const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
     // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
     const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;
     uint32_t* count_a = a.counts + (uint64_t)s * a.n_cols + col0;

@@ -43,13 +43,14 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
     __shared__ long long wave_best[4];
     const uint32_t s = blockIdx.y;
     const uint64_t wg_base = (uint64_t)blockIdx.x * INGEST_FRAMES_PER_WG;
-    const float* src = a.pcm + ((uint64_t)s * a.frames_total + a.skip) * a.fmt.channels;
+    const uint64_t skip_s = a.skips ? a.skips[s] : a.skip, count_s = a.counts ? a.counts[s] : a.count, head_s = a.heads ? a.heads[s] : a.head;
+    const float* src = a.pcm + ((uint64_t)s * a.frames_total + skip_s) * a.fmt.channels;
     const uint64_t ring_base = (uint64_t)s * a.cap;
     long long best = -1;
 #pragma unroll 4
     for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k) {
         const uint64_t idx = wg_base + (uint64_t)k * 256 + threadIdx.x;
-        const bool live = idx < a.count;
+        const bool live = idx < count_s;
         float out0 = 0.0f;
         if (live) {
             const float* frame = src + idx * a.fmt.channels;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
                     right = right + v * a.fmt.m[c][1];
                 }
             }
-            const uint64_t slot = ring_base + ((a.head + idx) & (a.cap - 1));
+            const uint64_t slot = ring_base + ((head_s + idx) & (a.cap - 1));
 #pragma unroll
             for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
                 if (o >= a.n_out) break;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
         }
         const unsigned long long nz = __ballot(live && out0 != 0.0f);  // audio_last_nonzero (:423-425, :432-434)
         if (nz != 0ull)
-            best = (long long)(a.head + wg_base + (uint64_t)k * 256 + (threadIdx.x & ~63u)) + (63 - __clzll((long long)nz));
+            best = (long long)(head_s + wg_base + (uint64_t)k * 256 + (threadIdx.x & ~63u)) + (63 - __clzll((long long)nz));
     }
     if (a.partial_nonzero) {
         if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
@@ -124,6 +125,78 @@ void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) 
     hipLaunchKernelGGL(ingest_project_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
     if (a.partial_nonzero && a.last_nonzero && wgs > 1)
         hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, a.partial_nonzero, wgs, a.last_nonzero);
+}
+
+// ================================================================================================
+// Ragged banks: per-stream frame indexing on the device (bit-exact integers: `ready = (pending - read_len) / hop + 1`)
+// ================================================================================================
+__global__ __launch_bounds__(64) void spectrogram_plan_kernel(SpectrogramPlanArgs a) {
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= a.n_streams) return;
+    uint64_t head = a.head[s], tail = a.tail[s], pending_skip = a.pending_skip[s];
+    uint32_t reset = a.reset_flag[s];
+    if (a.reset_mask && a.reset_mask[s]) {  // reset_audio (:212-217)
+        tail = head;
+        pending_skip = 0;
+        a.last_nonzero[s] = -1;
+        reset = 1u;
+    }
+    const uint64_t frames = a.frames[s];
+    uint32_t n_cols = 0, skip32 = 0, count32 = 0;
+    const uint64_t head_before = head;
+    if (frames != 0) {  // block.is_empty() -> None, nothing else happens (:490-492)
+        // push_audio (:412-437)
+        const uint64_t skip = min(pending_skip, frames);
+        pending_skip -= skip;
+        const uint64_t count = frames - skip;
+        skip32 = (uint32_t)skip;
+        count32 = (uint32_t)count;
+        head += count;
+        // process_ready_windows (:281-388)
+        const uint64_t pending = head - tail;
+        const uint64_t ready = pending >= a.read_len ? (pending - a.read_len) / a.hop + 1u : 0u;
+        const uint64_t skip_cols = ready > a.retained ? ready - a.retained : 0u;
+        {   // advance_audio(skip_cols * hop) (:406-410)
+            const uint64_t cnt = skip_cols * a.hop, len = head - tail, taken = min(cnt, len);
+            tail += taken;
+            pending_skip += cnt - taken;
+        }
+        n_cols = (uint32_t)min(ready - skip_cols, (uint64_t)a.max_cols);
+        a.col_tail[s] = tail;
+        {   // one advance_audio(hop) per column (:384): once the buffer runs dry every further hop is all `missing`
+            const uint64_t cnt = (uint64_t)n_cols * a.hop, len = head - tail, taken = min(cnt, len);
+            tail += taken;
+            pending_skip += cnt - taken;
+        }
+    } else {
+        a.col_tail[s] = tail;
+    }
+    a.ing_skip[s] = skip32;
+    a.ing_count[s] = count32;
+    a.ing_head[s] = head_before;
+    a.n_cols[s] = n_cols;
+    a.reset_out[s] = reset;
+    if (n_cols != 0) reset = 0u;  // std::mem::take (:511): consumed by the update this call returns
+    a.head[s] = head;
+    a.tail[s] = tail;
+    a.pending_skip[s] = pending_skip;
+    a.reset_flag[s] = reset;
+}
+void launch_spectrogram_plan(const SpectrogramPlanArgs& a, hipStream_t stream) {
+    if (a.n_streams == 0) return;
+    hipLaunchKernelGGL(spectrogram_plan_kernel, dim3((a.n_streams + 63u) / 64u), dim3(64), 0, stream, a);
+}
+
+__global__ __launch_bounds__(256) void ring_rehome_kernel(const float* from, uint64_t from_cap, float* to, uint64_t to_cap,
+                                                          const uint64_t* head, const uint64_t* tail) {
+    const uint32_t s = blockIdx.x;
+    const uint64_t h = head[s], t = tail[s];
+    for (uint64_t p = t + threadIdx.x; p < h; p += 256u) to[(uint64_t)s * to_cap + (p & (to_cap - 1u))] = from[(uint64_t)s * from_cap + (p & (from_cap - 1u))];
+}
+void launch_ring_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* head, const uint64_t* tail,
+                        uint32_t n_streams, hipStream_t stream) {
+    if (n_streams == 0) return;
+    hipLaunchKernelGGL(ring_rehome_kernel, dim3(n_streams), dim3(256), 0, stream, from, from_cap, to, to_cap, head, tail);
 }
 
 // ================================================================================================
@@ -284,9 +357,10 @@ __global__ __launch_bounds__(256, V::MIN_WAVES) void stft_reassigned_4096_kernel
             }
         }
     };
-    const uint32_t col_end = min(a.n_cols, (chunk + 1) * V::COLS_PER_WG);
+    const uint32_t col_end = min(stft_cols(a, s), (chunk + 1) * V::COLS_PER_WG);  // ragged banks: this stream's own column count
+    const uint64_t tail_s = stft_tail(a, s);
     for (uint32_t col = chunk * V::COLS_PER_WG; col < col_end; ++col) {
-        const uint64_t p0 = a.tail + (uint64_t)col * a.hop;  // absolute position of this window's first sample
+        const uint64_t p0 = tail_s + (uint64_t)col * a.hop;  // absolute position of this window's first sample
         uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
         const float *win = a.window, *dwin = a.dwindow, *twin = a.twindow, *bnorm = a.bin_norm;
         const v2f* tw8192 = a.tw8192;
@@ -798,7 +872,8 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
 
     for (uint64_t item = blockIdx.x; item < total; item += gridDim.x) {
         const uint32_t s = (uint32_t)(item / a.n_cols), col = (uint32_t)(item % a.n_cols);
-        const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+        if (a.cols && col >= a.cols[s]) continue;  // ragged banks: past this stream's own column count (workgroup-uniform)
+        const uint64_t p0 = (a.tails ? a.tails[s] : a.tail) + (uint64_t)col * a.hop;
         const float* ring = a.ring + (uint64_t)s * a.cap;
         const uint64_t mask = a.cap - 1;
         const bool silent = a.last_nonzero[s] < (long long)p0;

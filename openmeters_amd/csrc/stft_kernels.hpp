@@ -25,8 +25,37 @@ struct IngestArgs {
     uint64_t head;            // absolute write position of the first pushed sample
     long long* last_nonzero;     // [n_streams] absolute position of the newest non-zero sample of ring 0, or nullptr
     long long* partial_nonzero;  // [n_streams][ingest_partials_per_stream(count)] scratch, or nullptr
+    // ragged banks: per-stream {skip, count, head} (spectrogram_plan_kernel); `count` above is then the largest count (grid)
+    const uint32_t* skips;
+    const uint32_t* counts;
+    const uint64_t* heads;
 };
 uint32_t ingest_partials_per_stream(uint64_t count);
+
+// ---- ragged banks: the integer state machine of SpectrogramProcessor (push_audio / process_ready_windows / advance_audio,
+// reference spectrogram/processor.rs:281-437, :490-516) per stream ON THE DEVICE, one thread per stream
+struct SpectrogramPlanArgs {
+    uint32_t n_streams;
+    uint64_t read_len, hop, retained;  // retained = history_columns(kind, bins, history_length)
+    uint32_t max_cols;                 // layout stride of the outputs (upper bound of any stream's columns in this call)
+    const uint32_t* frames;            // [n_streams] new frames per stream in this call
+    const uint8_t* reset_mask;         // [n_streams] reset_audio() before the push, or nullptr
+    uint64_t* head;                    // [n_streams] state: absolute write position
+    uint64_t* tail;                    //             absolute position of the oldest pending sample
+    uint64_t* pending_skip;            //             samples still to skip (hop > window, :406-418)
+    uint32_t* reset_flag;              //             `reset` of the next update (:511 std::mem::take)
+    long long* last_nonzero;           //             audio_last_nonzero as an absolute position (-1 = None)
+    uint32_t* ing_skip;                // out [n_streams]: leading frames of the block not pushed
+    uint32_t* ing_count;               //                  frames pushed
+    uint64_t* ing_head;                //                  absolute position of the first pushed sample
+    uint64_t* col_tail;                //                  absolute position of column 0's first sample
+    uint32_t* n_cols;                  //                  columns produced
+    uint32_t* reset_out;               //                  the update's `reset` (meaningful where n_cols > 0)
+};
+void launch_spectrogram_plan(const SpectrogramPlanArgs& a, hipStream_t stream);
+// ring re-homing on growth with per-stream positions: pending samples keep their absolute positions, only the modulus changes
+void launch_ring_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* head, const uint64_t* tail,
+                        uint32_t n_streams, hipStream_t stream);
 void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream);
 
 // ---------------------------------------------------------------- K2 fast reassigned STFT (W = F = 4096)
@@ -52,9 +81,15 @@ struct StftFastArgs {
     // bins; win_terms = 2 for those, otherwise the kernels that window in the time domain run
     float win_c0, win_c1;
     uint32_t win_terms;
+    // ragged banks (per-stream frame counts): tail and column count of every stream, written by spectrogram_plan_kernel; the
+    // scalar `tail` / `n_cols` above then hold nothing / the layout stride (columns per stream slot of points / counts / codes)
+    const uint64_t* tails;
+    const uint32_t* cols;
     omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
     uint32_t* counts;               // [n_streams][n_cols]
 };
+__device__ __forceinline__ uint64_t stft_tail(const StftFastArgs& a, uint32_t s) { return a.tails ? a.tails[s] : a.tail; }
+__device__ __forceinline__ uint32_t stft_cols(const StftFastArgs& a, uint32_t s) { return a.cols ? a.cols[s] : a.n_cols; }
 constexpr int K2_PHASES = 12;
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning builds only (OMX_K2_VARIANT=7)
 // form: OMX_OPT_KERNEL_FORM (0 = tuned kernel, 1 = the five-transform kernel of round 1)
@@ -102,6 +137,8 @@ struct StftGenericArgs {
     omx_spectrogram_point* points;
     uint32_t* counts;
     uint16_t* codes;           // [n_streams][n_cols][column_stride] (classic)
+    const uint64_t* tails;     // ragged banks: per-stream tail / column count (see StftFastArgs)
+    const uint32_t* cols;
 };
 void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream);
 

@@ -53,18 +53,20 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
     uint32_t* scan = scan_all + fs * 9 * WPF;
     float* hil = hil_all + fs * 2;
     const uint32_t col_raw = chunk * F + (uint32_t)fs;
-    const bool in_range = col_raw < a.n_cols;
-    const uint32_t col = in_range ? col_raw : a.n_cols - 1u;  // idle frame slots shadow the last column (barriers stay uniform)
+    const uint32_t n_cols_s = stft_cols(a, s);  // ragged banks: this stream's own column count
+    if (chunk * F >= n_cols_s) return;           // (whole workgroup: every frame slot is past it)
+    const bool in_range = col_raw < n_cols_s;
+    const uint32_t col = in_range ? col_raw : n_cols_s - 1u;  // idle frame slots shadow the last column (barriers stay uniform)
 
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const long long last_nonzero = a.last_nonzero[s];
     const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
-    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    const uint64_t p0 = stft_tail(a, s) + (uint64_t)col * a.hop;
     const uint32_t p32 = (uint32_t)p0;
     uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
     // silent fast path (:307-316).  The first frame slot has the smallest p0: if it is silent, all of them are.
-    const uint64_t p0_first = a.tail + (uint64_t)(chunk * F) * a.hop;
+    const uint64_t p0_first = stft_tail(a, s) + (uint64_t)(chunk * F) * a.hop;
     if (last_nonzero < (long long)p0_first) {
         if (jf == 0 && in_range) *count_out = 0;
         return;
@@ -222,15 +224,17 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
     const unsigned ju = (unsigned)jf;
     const int wf = jf >> 6;
     v2f* buf = lds + fs * G::LDS;
+    const uint32_t n_cols_s = stft_cols(a, s), pairs_s = (n_cols_s + 1u) / 2u;  // ragged banks: this stream's own column count
+    if (chunk * F >= pairs_s) return;
     const uint32_t pair_raw = chunk * F + (uint32_t)fs;
-    const bool in_range = pair_raw < pairs;
-    const uint32_t pair = in_range ? pair_raw : pairs - 1u;
+    const bool in_range = pair_raw < pairs_s;
+    const uint32_t pair = in_range ? pair_raw : pairs_s - 1u;
     const uint32_t col_a = 2u * pair;
-    const bool has_b = col_a + 1u < a.n_cols;
+    const bool has_b = col_a + 1u < n_cols_s;
 
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
-    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)col_a * a.hop);
+    const uint32_t p32 = (uint32_t)(stft_tail(a, s) + (uint64_t)col_a * a.hop);
     // zero padding (window W < transform N, `processor.rs:350-368`): element i = jf + T t of the frame is sample i of the window
     // for i < W and 0 beyond; loads use a clamped index and the selects sit where the values are consumed
     const uint32_t Wn = a.window_size ? a.window_size : (uint32_t)N;
@@ -365,17 +369,19 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
     uint32_t* scan = scan_all + fs * 9 * WPF;
     float* hil = hil_all + fs * 2;
     const uint32_t col_raw = chunk * F + (uint32_t)fs;
-    const bool in_range = col_raw < a.n_cols;
-    const uint32_t col = in_range ? col_raw : a.n_cols - 1u;
+    const uint32_t n_cols_s = stft_cols(a, s);
+    if (chunk * F >= n_cols_s) return;
+    const bool in_range = col_raw < n_cols_s;
+    const uint32_t col = in_range ? col_raw : n_cols_s - 1u;
 
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const long long last_nonzero = a.last_nonzero[s];
     const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
-    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
+    const uint64_t p0 = stft_tail(a, s) + (uint64_t)col * a.hop;
     const uint32_t p32 = (uint32_t)p0;
     uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
-    const uint64_t p0_first = a.tail + (uint64_t)(chunk * F) * a.hop;
+    const uint64_t p0_first = stft_tail(a, s) + (uint64_t)(chunk * F) * a.hop;
     if (last_nonzero < (long long)p0_first) {  // silent fast path (:307-316): the first slot has the smallest p0
         if (jf == 0 && in_range) *count_out = 0;
         return;
@@ -576,8 +582,8 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFast
     const uint32_t s = item / a.n_cols, col = item % a.n_cols;
     const int j = threadIdx.x;
     const unsigned ju = threadIdx.x;
-    const uint64_t p0 = a.tail + (uint64_t)col * a.hop;
-    if (a.last_nonzero[s] < (long long)p0) return;  // silent column (:307-316): reassign_big_kernel emits it empty
+    const uint64_t p0 = stft_tail(a, s) + (uint64_t)col * a.hop;
+    if (col >= stft_cols(a, s) || a.last_nonzero[s] < (long long)p0) return;  // past the stream's count / silent column (:307-316): reassign_big_kernel emits it empty
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const uint32_t p32 = (uint32_t)p0;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFas
     v2f* tw2_lds = buf + G::LDS;
     const uint32_t item = sc.first + blockIdx.x, q = blockIdx.y;
     const uint32_t s = item / a.n_cols, col = item % a.n_cols;
-    if (a.last_nonzero[s] < (long long)(a.tail + (uint64_t)col * a.hop)) return;
+    if (col >= stft_cols(a, s) || a.last_nonzero[s] < (long long)(stft_tail(a, s) + (uint64_t)col * a.hop)) return;
     const int j = threadIdx.x;
     const unsigned ju = threadIdx.x;
     TwiddlesPow2<LOGN> tw;
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
     const unsigned ju = threadIdx.x;
     const int lane = j & 63, wf = j >> 6;
     uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
-    if (a.last_nonzero[s] < (long long)(a.tail + (uint64_t)col * a.hop)) {
+    if (col >= stft_cols(a, s) || a.last_nonzero[s] < (long long)(stft_tail(a, s) + (uint64_t)col * a.hop)) {
         if (j == 0) *count_out = 0;
         return;
     }

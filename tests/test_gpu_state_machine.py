@@ -4,7 +4,7 @@ restatement at every step (column counts, `reset` flags, None vs Some), and the 
 import numpy as np
 import pytest
 
-from openmeters_amd import capi
+from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
                                  SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
                                  WaveformProcessor)
@@ -265,3 +265,80 @@ def test_oscilloscope_random_operation_sequences(omx, oracle, seed):
         assert np.abs(g.samples - w.samples).max() <= 0.05, step
         compared += 1
     assert compared >= 0   # seeds whose traces are switched off most of the time compare few snapshots
+
+
+@pytest.mark.parametrize("seed,W,hop,reassign", [(1, 1024, 256, True), (2, 4096, 256, True), (3, 2048, 64, True), (4, 1024, 300, False),
+                                                   (5, 256, 700, True), (6, 4096, 1024, False)])
+def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx, oracle, seed, W, hop, reassign):
+    """Per-stream independence inside a bank (reference: one VisualManager per capture, reset and fed on its own,
+    visuals/registry.rs:396-418).  Every stream of a ragged bank gets its own random frame counts (0 ... 3 blocks, uneven) and its
+    own reset_audio() calls; stream s must behave exactly like a single SpectrogramProcessor fed the same sequence: column counts,
+    `reset` flags and point counts per column bit-exact (frame indexing, hop > window skips, retention), columns at the usual bars."""
+    import torch
+    from parity import check_classic, check_reassigned_columns
+    rng = np.random.default_rng(seed)
+    S, calls, cap = 7, 14, 3 * 256 + 77
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=reassign, history_length=5 if seed % 2 else 8192)
+    bank = banks.SpectrogramBank(omx, cfg, S)
+    refs = [SpectrogramProcessor(oracle, cfg) for _ in range(S)]
+    feeds = [_stream_signal(rng, 60000) for _ in range(S)]
+    at = [0] * S
+    pos = capi.positions_fallback(2)
+    # two lock-step calls first: the switch to per-stream positions must carry the common state over
+    for n in (300, 2 * W + 50):
+        chunk = np.stack([f[a:a + n] for f, a in zip(feeds, at)])
+        up = bank.process_host(chunk, 2, 48000.0)
+        for s in range(S):
+            w = refs[s].process_block(AudioBlock(chunk[s].reshape(-1), 2, 48000.0))
+            assert (up is None) == (w is None)
+            at[s] += n
+    produced = 0
+    for call in range(calls):
+        frames = rng.integers(0, cap + 1, S)
+        frames[rng.integers(0, S)] = 0                       # someone always sits a call out
+        mask = (rng.random(S) < 0.15).astype(np.uint8)
+        pcm = np.zeros((S, cap, 2), np.float32)
+        for s in range(S):
+            pcm[s, :frames[s]] = feeds[s][at[s]:at[s] + frames[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
+        torch.cuda.synchronize()
+        n_cols = _dev(torch, up.d_n_columns, (S,)).cpu().numpy() if up.max_columns else np.zeros(S, int)
+        resets = _dev(torch, up.d_reset, (S,)).cpu().numpy()
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            w = refs[s].process_block(AudioBlock(pcm[s, :frames[s]].reshape(-1), 2, 48000.0)) if frames[s] else None
+            at[s] += int(frames[s])
+            want_cols = len(w.new_columns) if w is not None else 0
+            assert int(n_cols[s]) == want_cols, (call, s, int(n_cols[s]), want_cols)
+            if w is None:
+                continue
+            assert bool(resets[s]) == w.reset, (call, s)
+            kind = capi.COLUMN_REASSIGNED if reassign else capi.COLUMN_CLASSIC
+            got = [bank.fetch_column(s, c, kind, up.column_stride) for c in range(want_cols)]
+            if reassign:
+                strong = [(h, o) for h, o in zip(got, w.new_columns) if len(o) and o[:, 2].max() > 1e-8]
+                check_reassigned_columns([h for h, _ in strong], [o for _, o in strong], 48000.0, hop, scale=30.0)
+            elif up.fft_size in (1024, 2048, 4096, 8192, 16384):
+                check_classic(got, w.new_columns)
+            produced += want_cols
+    assert produced > 10
+    # the lock-step entry point is refused while the positions are per stream, and works again after a bank-wide reset
+    with pytest.raises(capi.OmxError):
+        bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0)
+    bank.reset_audio()
+    assert bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0) is None
+
+
+def _stream_signal(rng, n):
+    t = np.arange(n) / 48000.0
+    f0, f1 = rng.uniform(100.0, 3000.0), rng.uniform(4000.0, 12000.0)
+    left = 0.4 * np.sin(2 * np.pi * (f0 + (f1 - f0) * t / t[-1] * 0.5) * t) + 0.01 * rng.standard_normal(n)
+    return np.stack([left, 0.6 * left[::-1]], 1).astype(np.float32)
+
+
+def _dev(torch, ptr, shape, typestr="<u4"):
+    class V:
+        __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+    return torch.as_tensor(V(), device="cuda:0")
