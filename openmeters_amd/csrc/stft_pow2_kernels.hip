@@ -30,7 +30,11 @@ __device__ __forceinline__ bool reassign_bin_p(uint32_t i, v2f b, v2f d, v2f t, 
 }
 }  // namespace
 
-template <int LOGN>
+// BINS: the window is applied on the bins (two-term cosine-sum windows, Hann / Hamming): Z = FFT(s) and Z2 = FFT((n - c) s) as ONE
+// dual transform, then FFT(w s)[k] = c0 Z[k] + c1/2 (Z[k-1] + Z[k+1]), FFT(t w s) the same combination of Z2, and
+// FFT(w' s)[k] = i c1 (pi / N) (Z[k-1] - Z[k+1]) — four transforms per column instead of five, no window tables
+// (derivation and accuracy: stft4096_pair_kernels.hip).
+template <int LOGN, bool BINS>
 __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1) void stft_reassigned_pow2_kernel(StftFastArgs a) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // waves per frame
@@ -123,8 +127,12 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
         const uint32_t qe = p32 + (uint32_t)(N / 2) + ju;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            pw[t] = a.window[ju + (unsigned)T * (unsigned)t];
-            pdw[t] = a.dwindow[ju + (unsigned)T * (unsigned)t];
+            if constexpr (!BINS) {
+                pw[t] = a.window[ju + (unsigned)T * (unsigned)t];
+                pdw[t] = a.dwindow[ju + (unsigned)T * (unsigned)t];
+            } else {
+                pw[t] = pdw[t] = 0.0f;
+            }
             pxr[t] = *reinterpret_cast<const float*>(ring_bytes + (((qe + (unsigned)T * (unsigned)t) << 2) & bytemask));
         }
     }
@@ -139,28 +147,66 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
     const float parity = (jf & 1) ? -half_xn : half_xn;  // n = N/2 + i has the parity of jf (N/2 and T are even)
     v2f vb[16], vd[16], vt[16];
     constexpr float CENTER = (float)(N - 1) * 0.5f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const v2f sv{(float)N * pxr[t] - half_x0 + parity, imag[jf + T * t]};
-        const float w = pw[t], dw = pdw[t];
-        const float wt = ((float)(jf + T * t) - CENTER) * w;  // compute_time_weighted (:601-608)
-        vb[t] = v2f{sv.x * w, sv.y * w};
-        vd[t] = v2f{sv.x * dw, sv.y * dw};
-        vt[t] = v2f{sv.x * wt, sv.y * wt};
-    }
-    frame_sync<LOGN>();  // imag[] (in B) is consumed
-    fftp_dual<false, LOGN>(vb, vd, A, B, jf, tw);
     v2f bb[9], bd[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        bb[t] = vb[t];
-        bd[t] = vd[t];
-    }
     float pn[9];
+    if constexpr (!BINS) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
-    frame_sync<LOGN>();  // the paired transform's last pass still reads A and B
-    fftp<false, LOGN>(vt, A, B, jf, tw);
+        for (int t = 0; t < 16; ++t) {
+            const v2f sv{(float)N * pxr[t] - half_x0 + parity, imag[jf + T * t]};
+            const float w = pw[t], dw = pdw[t];
+            const float wt = ((float)(jf + T * t) - CENTER) * w;  // compute_time_weighted (:601-608)
+            vb[t] = v2f{sv.x * w, sv.y * w};
+            vd[t] = v2f{sv.x * dw, sv.y * dw};
+            vt[t] = v2f{sv.x * wt, sv.y * wt};
+        }
+        frame_sync<LOGN>();  // imag[] (in B) is consumed
+        fftp_dual<false, LOGN>(vb, vd, A, B, jf, tw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            bb[t] = vb[t];
+            bd[t] = vd[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+        frame_sync<LOGN>();  // the paired transform's last pass still reads A and B
+        fftp<false, LOGN>(vt, A, B, jf, tw);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const v2f sv{(float)N * pxr[t] - half_x0 + parity, imag[jf + T * t]};
+            const float nc = (float)(jf + T * t) - CENTER;  // compute_time_weighted's ramp (:601-608)
+            vb[t] = sv;                                     // Z  = FFT(s)
+            vd[t] = v2f{sv.x * nc, sv.y * nc};              // Z2 = FFT((n - c) s)
+        }
+        frame_sync<LOGN>();  // imag[] (in B) is consumed
+        fftp_dual<false, LOGN>(vb, vd, A, B, jf, tw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+        frame_sync<LOGN>();  // the transform's last pass still reads A and B
+        // natural-order copy of bins -1 ... N/2 + T of both spectra (slot 1 + k = bin k, slot 0 = bin -1 = bin N - 1)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            A[1 + jf + T * t] = vb[t];
+            B[1 + jf + T * t] = vd[t];
+        }
+        if (jf == T - 1) {
+            A[0] = vb[15];
+            B[0] = vd[15];
+        }
+        frame_sync<LOGN>();
+        const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / (float)N);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+            const bool mine = t < 8 || jf == 0;
+            const uint32_t at = mine ? bin : 0u;
+            const v2f zm = A[at], zp = A[at + 2], z2m = B[at], z2p = B[at + 2];
+            const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y}, z2s{z2m.x + z2p.x, z2m.y + z2p.y};
+            bb[t] = v2f{c0 * vb[t].x + half_c1 * zs.x, c0 * vb[t].y + half_c1 * zs.y};
+            bd[t] = v2f{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / N) (Z[k-1] - Z[k+1])
+            vt[t] = v2f{c0 * vd[t].x + half_c1 * z2s.x, c0 * vd[t].y + half_c1 * z2s.y};
+        }
+    }
 
     // ---- 4. reassignment + ordered compaction (bins jf + T t, t < 8, and bin N/2 on thread 0) ----------------------------
     omx_spectrogram_point pts[9];
@@ -777,16 +823,20 @@ void launch_stft_reassigned_4096_split(const StftFastArgs& a, void* scratch, uin
 template <int LOGN>
 static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
     using G = FftGeom<LOGN>;
+    const bool bins = a.win_terms == 2;  // Hann / Hamming: window applied on the bins, four transforms per column
     constexpr int F = G::FRAMES, WPF = G::T / 64;
     const size_t lds = (size_t)(2 * F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) + (size_t)F * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_kernel<LOGN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_kernel<LOGN, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_kernel<LOGN, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const uint32_t chunks = (a.n_cols + F - 1) / F;
-    hipLaunchKernelGGL(stft_reassigned_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
+    if (bins) hipLaunchKernelGGL((stft_reassigned_pow2_kernel<LOGN, true>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
+    else hipLaunchKernelGGL((stft_reassigned_pow2_kernel<LOGN, false>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
 }
 
 // fft_size = 1024, 2048, 4096 or 8192 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
