@@ -609,6 +609,9 @@ bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t 
 //   reassign_big_kernel    per-bin reassignment + ordered compaction
 // One frame per 1024-thread workgroup, one in-place 16384-point transform at a time.
 // ================================================================================================
+constexpr int kBigHalo = 16;                       // neighbour bins kept on either side of 0 ... N/2 (zero padding <= 16)
+template <int LOGN>
+constexpr int kBigRow = (1 << LOGN) / 2 + 1 + 2 * kBigHalo;  // complex values per (frame, spectrum) row in bins mode
 struct BigScratch {
     v2f* sv;          // [chunk][N]
     v2f* spec;        // [3][chunk][N/2 + 1]
@@ -702,6 +705,8 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFas
     if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
     const uint32_t W = a.window_size;  // == N unless the window is zero-padded to the transform (:334-342)
     const v2f* sv = sc.sv + (uint64_t)blockIdx.x * W;
+    const bool bins = a.win_terms == 2;  // Hann / Hamming: q = 0 -> Z = FFT(s), q = 1 -> Z2 = FFT((n - c) s); the window is applied
+                                         // on the bins by reassign_big_kernel (see stft4096_pair_kernels.hip)
     const float* win = q == 1 ? a.dwindow : a.window;
     const float center = (float)(W - 1u) * 0.5f;
     v2f v[16];
@@ -710,12 +715,20 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFas
         const uint32_t i = ju + (unsigned)T * (unsigned)u;
         const uint32_t ic = i < W ? i : 0u;  // unconditional loads, selected afterwards
         const v2f x = sv[ic];
-        float w = win[ic];
-        if (q == 2) w = ((float)ic - center) * w;  // compute_time_weighted (:601-608)
+        float w = bins ? 1.0f : win[ic];
+        if (bins ? q == 1 : q == 2) w = ((float)ic - center) * w;  // compute_time_weighted (:601-608)
         v[u] = i < W ? v2f{x.x * w, x.y * w} : v2f{0.0f, 0.0f};
     }
     __syncthreads();  // tw2_lds
     fftp_inplace<false, LOGN>(v, buf, j, tw);
+    if (bins) {  // bins -kBigHalo ... N/2 + kBigHalo (row slot = bin + kBigHalo): the window's cosine shifts by F / W <= 16 bins
+        v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * kBigRow<LOGN> + kBigHalo;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out[j + T * u] = v[u];
+        if (j <= kBigHalo) out[N / 2 + j] = v[8];
+        if (j >= T - kBigHalo) out[j - T] = v[15];  // bin N - m sits at slot -m
+        return;
+    }
     v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * (N / 2 + 1);
 #pragma unroll
     for (int u = 0; u < 8; ++u) out[j + T * u] = v[u];
@@ -738,14 +751,31 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
         return;
     }
     const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
-    const uint64_t per = (uint64_t)sc.count * (N / 2 + 1);
-    const v2f* sb = sc.spec + (uint64_t)blockIdx.x * (N / 2 + 1);
+    const bool bins = a.win_terms == 2;
+    const uint64_t row = bins ? (uint64_t)kBigRow<LOGN> : (uint64_t)(N / 2 + 1);
+    const uint64_t per = (uint64_t)sc.count * row;
+    const v2f* sb = sc.spec + (uint64_t)blockIdx.x * row + (bins ? kBigHalo : 0);
+    // window on the bins: cos(2 pi n / W) shifts an F-point spectrum by F / W bins
+    const int shift = (int)((uint32_t)N / a.window_size);
+    const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / (float)a.window_size);
     omx_spectrogram_point pts[9];
     unsigned long long masks[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint32_t bin = (t < 8 || j == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
-        const v2f b = sb[bin], d = sb[per + bin], tt = sb[2 * per + bin];
+        v2f b, d, tt;
+        if (bins) {
+            const v2f* z = sb + bin;
+            const v2f* z2 = sb + per + bin;
+            const v2f zc = z[0], zm = z[-shift], zp = z[shift], z2c = z2[0], z2m = z2[-shift], z2p = z2[shift];
+            b = v2f{c0 * zc.x + half_c1 * (zm.x + zp.x), c0 * zc.y + half_c1 * (zm.y + zp.y)};
+            d = v2f{-dscale * (zm.y - zp.y), dscale * (zm.x - zp.x)};  // i c1 (pi / W) (Z[k - F/W] - Z[k + F/W])
+            tt = v2f{c0 * z2c.x + half_c1 * (z2m.x + z2p.x), c0 * z2c.y + half_c1 * (z2m.y + z2p.y)};
+        } else {
+            b = sb[bin];
+            d = sb[per + bin];
+            tt = sb[2 * per + bin];
+        }
         const float norm = a.bin_norm[bin];
         bool keep = false;
         if (t < 8 || j == 0) keep = reassign_bin_p(bin, b, d, tt, norm, rc, pts[t]);
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
 }
 
 // bytes of scratch per frame of a chunk, and the launcher (frames [first, first + count) of the call)
-uint64_t stft_big_scratch_bytes_per_frame() { return (uint64_t)(16384 + 3 * 8193) * sizeof(v2f); }
+uint64_t stft_big_scratch_bytes_per_frame() { return (uint64_t)(16384 + 3 * 8193 + 4 * kBigHalo) * sizeof(v2f); }
 // LOGW = window (Hilbert pair on 2W samples), LOGF = transform; W == F unless zero-padded
 template <int LOGW, int LOGF>
 static void launch_big(const StftFastArgs& a, const v2f* twF, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
@@ -794,7 +824,7 @@ static void launch_big(const StftFastArgs& a, const v2f* twF, void* scratch, uin
     StftFastArgs af = a;  // the windowed transforms run at F points: their twiddles are exp(-2 pi i k / F)
     if (twF) af.tw4096 = twF;
     hipLaunchKernelGGL(hilbert_big_kernel<LOGW>, dim3(count), dim3(GW::T), lds_w, stream, a, sc);
-    hipLaunchKernelGGL(windowed_big_kernel<LOGF>, dim3(count, 3), dim3(GF::T), lds_f, stream, af, sc);
+    hipLaunchKernelGGL(windowed_big_kernel<LOGF>, dim3(count, a.win_terms == 2 ? 2 : 3), dim3(GF::T), lds_f, stream, af, sc);
     hipLaunchKernelGGL(reassign_big_kernel<LOGF>, dim3(count), dim3(GF::T), 0, stream, af, sc);
 }
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
