@@ -809,6 +809,16 @@ int stft_reassigned_4096_transforms_per_frame() { return 4; }
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
+#ifdef OMX_TUNING
+    if (form == 0 && a.win_terms == 2) {  // 50 / 51: the structural alternatives of stft4096_swz_kernels.hip (same columns, slower)
+        static const int swz_variant = [] {
+            const char* e = getenv("OMX_K2_VARIANT");
+            return e ? atoi(e) : 0;
+        }();
+        if (swz_variant == 50) { launch_stft_reassigned_4096_swz_pair(a, stream); return; }
+        if (swz_variant == 51) { launch_stft_reassigned_4096_col(a, stream); return; }
+    }
+#endif
     if (form == 0 && a.win_terms == 2) {  // Hann / Hamming: two columns per workgroup, four transforms per column
         launch_stft_reassigned_4096_pair(a, stream);
         return;

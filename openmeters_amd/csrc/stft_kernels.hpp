@@ -96,6 +96,9 @@ void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning 
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream);
 int stft_reassigned_4096_transforms_per_frame();  // of form 0
 void launch_stft_reassigned_4096_pair(const StftFastArgs& a, hipStream_t stream);  // stft4096_pair_kernels.hip
+// tuning builds only (stft4096_swz_kernels.hip): the swizzled pair kernel and the one-column-per-workgroup kernel
+void launch_stft_reassigned_4096_swz_pair(const StftFastArgs& a, hipStream_t stream);
+void launch_stft_reassigned_4096_col(const StftFastArgs& a, hipStream_t stream);
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
 // size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);

@@ -37,7 +37,7 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for f in glob.glob(os.path.join(p, "*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "stft_reassigned_4096_pair_kernel" in row.get("Kernel_Name", "") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                if "stft_reassigned_4096_" in row.get("Kernel_Name", "") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
     fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
