@@ -18,6 +18,7 @@
 #include "stft_kernels.hpp"
 
 #include "fft_device.hpp"
+#include <cstdlib>
 
 namespace omx {
 
@@ -32,7 +33,10 @@ __device__ __forceinline__ bool reassign_one(uint32_t i, v2f b, v2f d, v2f t, fl
     const float pow = b.x * b.x + b.y * b.y;
     const float scaled_power = pow * norm;
     if (scaled_power < 1e-14f) return false;  // ANALYSIS_FLOOR_POWER (:69)
-    const float inv_pow = 1.0f / pow;
+    // 1 / pow by v_rcp_f32 (1 ulp) and one Newton step (<= 1 ulp of the exact quotient): ten dependent VALU instructions fewer per
+    // bin than the IEEE division sequence; pow >= 1e-14 / norm is far from the denormal range the long sequence exists for
+    const float r0 = __builtin_amdgcn_rcpf(pow);
+    const float inv_pow = __builtin_fmaf(__builtin_fmaf(-pow, r0, 1.0f), r0, r0);
     const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
     const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
     if (!(freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f)) return false;
@@ -40,6 +44,20 @@ __device__ __forceinline__ bool reassign_one(uint32_t i, v2f b, v2f d, v2f t, fl
     p.freq_hz = freq_hz;
     p.power = scaled_power;
     return true;
+}
+
+// the same statements without the early returns (every value is computed; NaN / inf from a zero power fail the comparisons)
+__device__ __forceinline__ bool reassign_flat(uint32_t i, v2f b, v2f d, v2f t, float norm, const PairConsts& c, omx_spectrogram_point& p) {
+    const float pow = b.x * b.x + b.y * b.y;
+    const float scaled_power = pow * norm;
+    const float r0 = __builtin_amdgcn_rcpf(pow);
+    const float inv_pow = __builtin_fmaf(__builtin_fmaf(-pow, r0, 1.0f), r0, r0);
+    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
+    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
+    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
+    p.freq_hz = freq_hz;
+    p.power = scaled_power;
+    return !(scaled_power < 1e-14f) && freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f;  // ANALYSIS_FLOOR_POWER (:69), the band (:472-475)
 }
 
 __device__ __forceinline__ bool pair_block_to_stream_chunk(uint32_t n_streams, uint32_t chunks, uint32_t& s, uint32_t& chunk) {
@@ -55,10 +73,28 @@ __device__ __forceinline__ bool pair_block_to_stream_chunk(uint32_t n_streams, u
 // per 65 536 frames, 1.72 as committed): LDS reads issued as single ds_read_b64 through inline asm instead of the
 // ds_read2st64_b64 pairs hipcc forms (1.78: the forced full wait and 18 spilled registers cost more than the read2 penalty),
 // volatile reads (3.08: 58 spilled registers), -amdgpu-sched-strategy=max-ilp (1.89: 16 spilled registers).
-template <bool INV, class TW>
-__device__ __forceinline__ void pair_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const TW& tw) {
+// inclusive prefix sum over the 64 lanes of a wavefront (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast 15 / 31)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x = dpp_add<0x111, 0xf>(x);
+    x = dpp_add<0x112, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    x = dpp_add<0x142, 0xa>(x);  // lane 15 of rows 0 / 2 -> rows 1 / 3
+    x = dpp_add<0x143, 0xc>(x);  // lane 31 -> rows 2 and 3
+    return x;
+}
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool INV, class TW, class Hook = NoHook>
+__device__ __forceinline__ void pair_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const TW& tw, Hook before_first_barrier = Hook{}) {
     fft4096_pass1<INV>(v0, A, j);
     fft4096_pass1<INV>(v1, B, j);
+    before_first_barrier();
     __syncthreads();
     {
         v2f a[16], b[16];
@@ -110,7 +146,20 @@ __device__ __forceinline__ void pair_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftFastArgs a) {
+// PHASES (tuning builds, OMX_K2_VARIANT=52): thread 0 adds the shader-clock cycles between phase marks to phases[0 ... 8]
+template <bool PHASES>
+__global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftFastArgs a, unsigned long long* phases) {
+    long long phase_t = 0;
+    if constexpr (PHASES) phase_t = clock64();
+    auto mark = [&](int i) {
+        if constexpr (PHASES) {
+            if (threadIdx.x == 0) {
+                const long long now = clock64();
+                atomicAdd(&phases[i], (unsigned long long)(now - phase_t));
+                phase_t = now;
+            }
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* A = reinterpret_cast<v2f*>(smem_raw);
     v2f* B = A + FFT4096_LDS;
@@ -128,15 +177,18 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     const uint32_t mask32 = (uint32_t)(a.cap - 1);  // cap <= 2^30 (checked on the host)
     const uint32_t bytemask = mask32 << 2;
     const char* ring_bytes = reinterpret_cast<const char*>(ring);
+    // per-stream words first, back to back (each is a dependent scalar load: one wait for the three, not three)
     const long long last_nonzero = a.last_nonzero[s];
+    const uint32_t* cols_p = a.cols;
+    const uint64_t* tails_p = a.tails;
+    const uint32_t n_cols_s = cols_p ? cols_p[s] : a.n_cols;  // ragged banks: this stream's own column count ...
+    const uint64_t tail_s = tails_p ? tails_p[s] : a.tail;    // ... and tail
     const PairConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
 
     const uint32_t col0 = chunk * 2u;
-    const uint32_t n_cols_s = stft_cols(a, s);  // ragged banks: this stream's own column count
     if (col0 >= n_cols_s) return;
     const bool have1 = col0 + 1u < n_cols_s;
     const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
-    const uint64_t tail_s = stft_tail(a, s);
     const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
     // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
     const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;
@@ -150,34 +202,41 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         return;
     }
 
+    // Everything the forward transforms need from memory is requested here, in one batch: the pass-2 twiddle this thread copies
+    // to LDS, both windows, the resident pass-3 twiddles.
     using TW = TwiddleSource<true, true>;
     TW tw;
     tw.j = ju;
     tw.tw3_global = a.tw4096;
     tw.tw2 = tw2_lds;
-#pragma unroll
-    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
-    tw2_lds[j] = a.tw256[ju];  // first read in pass 2 of the first transform, behind that transform's pass-1 barrier
+    const v2f tw2_mine = a.tw256[ju];
 
     // ---- 1. packed real FFTs of the two 8192-sample windows -----------------------------------------------------------
     const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
     v2f va[16], vb[16];
-    auto load_window = [&](v2f (&v)[16], uint64_t p0, uint32_t p32) {
-        if ((p0 & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+    if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
-                v[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((p32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
-        } else {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const uint32_t q = p32 + 2u * (ju + 256u * (unsigned)t);
-                v[t] = v2f{ring[q & mask32], ring[(q + 1u) & mask32]};
-            }
+        for (int t = 0; t < 16; ++t) {
+            va[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((pa32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
+            vb[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((pb32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
         }
-    };
-    load_window(va, p0a, pa32);
-    load_window(vb, p0b, pb32);
-    pair_dual<false>(va, vb, A, B, j, tw);  // v[t] = Zf[j + 256 t]
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qa = pa32 + 2u * (ju + 256u * (unsigned)t), qb = pb32 + 2u * (ju + 256u * (unsigned)t);
+            va[t] = v2f{ring[qa & mask32], ring[(qa + 1u) & mask32]};
+            vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
+        }
+    }
+#pragma unroll
+    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
+    float pn[9];  // bin normalisation of this thread's bins: the same for both columns, requested with the first batch
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u];
+    mark(0);
+    // (the LDS copy of the pass-2 twiddles is first read in pass 2, behind the pass-1 barrier)
+    pair_dual<false>(va, vb, A, B, j, tw, [&] { tw2_lds[j] = tw2_mine; });  // v[t] = Zf[j + 256 t]
+    mark(1);
 
     // ---- 2. Hilbert transform with ONE half-length inverse per column (derivation: stft_kernels.hip step 2) -----------
     __syncthreads();  // pass 3 of the dual transform still reads A and B
@@ -195,14 +254,20 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     __syncthreads();
     v2f ya[16], yb[16];
     {
-        v2f w8[16];  // exp(-2 pi i k / 8192) / 2, k = j + 256 t: one table read serves both columns
+        // exp(-2 pi i k / 8192) / 2, k = j + 256 t: one table read serves both columns.  (Requested earlier — with the first batch, or
+        // ahead of the natural-order copy — the kernel is 1-2 % SLOWER, same-box A/B.)
+        v2f w8[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) w8[t] = a.tw8192[ju + 256u * (unsigned)t];
+        // partner Zf[(4096 - k) & 4095] of k = j + 256 t sits at pad16(4096 - j) - 272 t (4096 - j is not a multiple of 16 for
+        // j > 0 ... and pad16 is linear across multiples of 256 anyway); thread 0's partners 4096 - 256 t sit at 4352 - 272 t, and
+        // its t = 0 read (one slot past the block, inside the allocation) is not used
+        const int part = (j ? pad16(4096 - j) : 4352) - 272 * 15;
         auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16], const v2f* X) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const unsigned k = (unsigned)(j + 256 * t);
-                const v2f z = v[t], zr = X[pad16((int)((4096u - k) & 4095u))];
+                const v2f z = v[t], zr = X[part + 272 * (15 - t)];
                 const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
                 y[t] = cmulc(sum, w8[t]) - cmul(dif, w8[t]);
                 if (t == 0 && k == 0) y[t] = v2f{0.0f, 0.0f};
@@ -225,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         }
     }
     __syncthreads();  // partners are read from the buffers the inverse is about to overwrite
+    mark(2);
     pair_dual<true>(ya, yb, A, B, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
+    mark(3);
 
     // ---- 3. gather s[i] = analytic[2048 + i], i = j + 256 t, for both columns -------------------------------------------
     __syncthreads();
@@ -247,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         }
     }
     const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / 4096.0f);
+    mark(4);
     v2f* lin_z = A;   // [LIN_BINS] natural-order bins of Z  (slot 1 + k)
     v2f* lin_z2 = B;  // [LIN_BINS] natural-order bins of Z2
 
@@ -261,9 +329,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         }
         __syncthreads();  // the gather above / the previous column's neighbour reads still use A and B
         pair_dual<false>(z, z2, A, B, j, tw);
-        float pn[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u];
+        mark(5);
         __syncthreads();  // pass 3 still reads A and B
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -276,44 +342,55 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         }
         __syncthreads();
 
+        // Branch-free, neighbour reads first: written with the reference's early returns, every bin was a serial chain of
+        // `LDS read - wait - arithmetic - branch - LDS read - wait`, each wait exposed (the phase cost as much as a dual transform).
+        // Every lane computes every bin it touches; what the early returns decided goes into the keep flag.
         omx_spectrogram_point pts[9];
         unsigned long long masks[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const uint32_t bin = (uint32_t)(j + 256 * t);
-            bool keep = false;
-            if ((t < 8 || j == 0) && !silent) {
-                const v2f zm = lin_z[bin], zp = lin_z[bin + 2], z2m = lin_z2[bin], z2p = lin_z2[bin + 2];
+        for (int h = 0; h < 9; h += 3) {  // three bins at a time: 24 registers of neighbours in flight
+            v2f nzm[3], nzp[3], nz2m[3], nz2p[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int bin = j + 256 * (h + u);  // (t = 8: only thread 0's bin exists; the others read slots inside the buffer and drop the result)
+                nzm[u] = lin_z[bin];
+                nzp[u] = lin_z[bin + 2];
+                nz2m[u] = lin_z2[bin];
+                nz2p[u] = lin_z2[bin + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = h + u;
+                const uint32_t bin = (uint32_t)(j + 256 * t);
+                const v2f zm = nzm[u], zp = nzp[u], z2m = nz2m[u], z2p = nz2p[u];
                 const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y}, z2s{z2m.x + z2p.x, z2m.y + z2p.y};
                 const v2f bb{c0 * z[t].x + half_c1 * zs.x, c0 * z[t].y + half_c1 * zs.y};
                 const v2f bd{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / W) (Z[k-1] - Z[k+1])
                 const v2f bt{c0 * z2[t].x + half_c1 * z2s.x, c0 * z2[t].y + half_c1 * z2s.y};
-                keep = reassign_one(bin, bb, bd, bt, pn[t], rc, pts[t]);
+                const bool keep = reassign_flat(bin, bb, bd, bt, pn[t], rc, pts[t]) && (t < 8 || j == 0) && !silent;
+                masks[t] = __ballot(keep);
+                if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
             }
-            masks[t] = __ballot(keep);
-            if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
         }
         __syncthreads();
         omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
-        uint4 counts4[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) counts4[t] = *reinterpret_cast<const uint4*>(scan + t * 4);
-        uint32_t running = 0;
+        // exclusive prefix of the 36 wave counts ([t][wave] row-major = bin order), by every wavefront for itself: one LDS read,
+        // six DPP adds, then one v_readlane per t — 5 VALU instructions per t where summing the counts per thread took 22
+        const uint32_t cnt = lane < 36 ? scan[lane] : 0u;
+        const uint32_t inc = wave_inclusive_sum(cnt);
+        const uint32_t exc = inc - cnt;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t running = (uint32_t)__builtin_amdgcn_readlane((int)inc, 35);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const uint32_t c[4] = {counts4[t].x, counts4[t].y, counts4[t].z, counts4[t].w};
-            uint32_t before = running;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if (w < wave) before += c[w];
-                running += c[w];
-            }
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, 4 * t + wave_u);
             if ((masks[t] >> lane) & 1ull) {
-                const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
+                const uint32_t pos = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(masks[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)masks[t], 0u));
                 *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
             }
         }
         if (j == 0) *count_out = running;
+        mark(6);
     };
     column(sa, silent_a, col0, count_a);
     if (have1) column(sb, silent_b, col1, count_b);
@@ -324,12 +401,30 @@ void launch_stft_reassigned_4096_pair(const StftFastArgs& a, hipStream_t stream)
     const size_t lds = (size_t)(2 * FFT4096_LDS + 256) * sizeof(v2f) + 9 * 4 * sizeof(uint32_t) + 4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_set = true;
     }
     const uint32_t chunks = (a.n_cols + 1u) / 2u;
-    hipLaunchKernelGGL(stft_reassigned_4096_pair_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a);
+#ifdef OMX_TUNING
+    static const bool phases = [] {
+        const char* e = getenv("OMX_K2_VARIANT");
+        return e && atoi(e) == 52;
+    }();
+    if (phases) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_pair_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(stft_reassigned_4096_pair_kernel<true>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a,
+                           k2_phase_buffer());
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(stft_reassigned_4096_pair_kernel<false>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds, stream, a,
+                       (unsigned long long*)nullptr);
 }
 
 }  // namespace omx

@@ -795,6 +795,11 @@ static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(stft_reassigned_4096_kernel<V>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), lds + pad, stream, a);
 }
 
+unsigned long long* k2_phase_buffer() {
+    void* p = nullptr;
+    OMX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_k2_phase_cycles)));
+    return static_cast<unsigned long long*>(p);
+}
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset) {
     OMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_phase_cycles), K2_PHASES * sizeof(unsigned long long)));
     if (reset) {

@@ -92,6 +92,7 @@ __device__ __forceinline__ uint64_t stft_tail(const StftFastArgs& a, uint32_t s)
 __device__ __forceinline__ uint32_t stft_cols(const StftFastArgs& a, uint32_t s) { return a.cols ? a.cols[s] : a.n_cols; }
 constexpr int K2_PHASES = 12;
 void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset);  // tuning builds only (OMX_K2_VARIANT=7)
+unsigned long long* k2_phase_buffer();  // device address of the phase counters (OMX_K2_VARIANT=52: the pair kernel's marks)
 // form: OMX_OPT_KERNEL_FORM (0 = tuned kernel, 1 = the five-transform kernel of round 1)
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream);
 int stft_reassigned_4096_transforms_per_frame();  // of form 0
