@@ -18,47 +18,12 @@
 #include "stft_kernels.hpp"
 
 #include "fft_device.hpp"
+#include "reassign_device.hpp"
 #include <cstdlib>
 
 namespace omx {
 
 namespace {
-
-struct PairConsts {
-    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
-};
-
-// spectrogram/processor.rs:459-485 for one bin (same statement order as reassign_bin in stft_kernels.hip)
-__device__ __forceinline__ bool reassign_one(uint32_t i, v2f b, v2f d, v2f t, float norm, const PairConsts& c, omx_spectrogram_point& p) {
-    const float pow = b.x * b.x + b.y * b.y;
-    const float scaled_power = pow * norm;
-    if (scaled_power < 1e-14f) return false;  // ANALYSIS_FLOOR_POWER (:69)
-    // 1 / pow by v_rcp_f32 (1 ulp) and one Newton step (<= 1 ulp of the exact quotient): ten dependent VALU instructions fewer per
-    // bin than the IEEE division sequence; pow >= 1e-14 / norm is far from the denormal range the long sequence exists for
-    const float r0 = __builtin_amdgcn_rcpf(pow);
-    const float inv_pow = __builtin_fmaf(__builtin_fmaf(-pow, r0, 1.0f), r0, r0);
-    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
-    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
-    if (!(freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f)) return false;
-    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
-    p.freq_hz = freq_hz;
-    p.power = scaled_power;
-    return true;
-}
-
-// the same statements without the early returns (every value is computed; NaN / inf from a zero power fail the comparisons)
-__device__ __forceinline__ bool reassign_flat(uint32_t i, v2f b, v2f d, v2f t, float norm, const PairConsts& c, omx_spectrogram_point& p) {
-    const float pow = b.x * b.x + b.y * b.y;
-    const float scaled_power = pow * norm;
-    const float r0 = __builtin_amdgcn_rcpf(pow);
-    const float inv_pow = __builtin_fmaf(__builtin_fmaf(-pow, r0, 1.0f), r0, r0);
-    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
-    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
-    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
-    p.freq_hz = freq_hz;
-    p.power = scaled_power;
-    return !(scaled_power < 1e-14f) && freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f;  // ANALYSIS_FLOOR_POWER (:69), the band (:472-475)
-}
 
 __device__ __forceinline__ bool pair_block_to_stream_chunk(uint32_t n_streams, uint32_t chunks, uint32_t& s, uint32_t& chunk) {
     // XCD-aware map (same as block_to_stream_column): block b runs on XCD b % 8; stream s is pinned to XCD s % 8
@@ -73,20 +38,6 @@ __device__ __forceinline__ bool pair_block_to_stream_chunk(uint32_t n_streams, u
 // per 65 536 frames, 1.72 as committed): LDS reads issued as single ds_read_b64 through inline asm instead of the
 // ds_read2st64_b64 pairs hipcc forms (1.78: the forced full wait and 18 spilled registers cost more than the read2 penalty),
 // volatile reads (3.08: 58 spilled registers), -amdgpu-sched-strategy=max-ilp (1.89: 16 spilled registers).
-// inclusive prefix sum over the 64 lanes of a wavefront (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast 15 / 31)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
-    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    x = dpp_add<0x111, 0xf>(x);
-    x = dpp_add<0x112, 0xf>(x);
-    x = dpp_add<0x114, 0xf>(x);
-    x = dpp_add<0x118, 0xf>(x);
-    x = dpp_add<0x142, 0xa>(x);  // lane 15 of rows 0 / 2 -> rows 1 / 3
-    x = dpp_add<0x143, 0xc>(x);  // lane 31 -> rows 2 and 3
-    return x;
-}
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -183,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     const uint64_t* tails_p = a.tails;
     const uint32_t n_cols_s = cols_p ? cols_p[s] : a.n_cols;  // ragged banks: this stream's own column count ...
     const uint64_t tail_s = tails_p ? tails_p[s] : a.tail;    // ... and tail
-    const PairConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
 
     const uint32_t col0 = chunk * 2u;
     if (col0 >= n_cols_s) return;
@@ -385,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         for (int t = 0; t < 9; ++t) {
             const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, 4 * t + wave_u);
             if ((masks[t] >> lane) & 1ull) {
-                const uint32_t pos = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(masks[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)masks[t], 0u));
+                const uint32_t pos = before + lanes_below(masks[t]);
                 *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
             }
         }

@@ -5,30 +5,51 @@
 //   packed real FFT of the 2N-sample window -> Hilbert with one half-length inverse -> analytic slice ->
 //   three windowed FFTs (w, w', t w) -> per-bin reassignment -> ordered compaction.
 #include "fft_pow2_device.hpp"
+#include "reassign_device.hpp"
 #include "stft_kernels.hpp"
 
 namespace omx {
 
-namespace {
-struct ReassignConstsP {
-    float bin_hz, max_hz, inv_2pi, inv_hop, latency_hops;
-};
-// spectrogram/processor.rs:459-485 for one bin; returns keep flag (same statement order as reassign_bin in stft_kernels.hip)
-__device__ __forceinline__ bool reassign_bin_p(uint32_t i, v2f b, v2f d, v2f t, float norm, const ReassignConstsP& c,
-                                               omx_spectrogram_point& p) {
-    const float pow = b.x * b.x + b.y * b.y;
-    const float scaled_power = pow * norm;
-    if (scaled_power < 1e-14f) return false;
-    const float inv_pow = 1.0f / pow;
-    const float d_omega = -(d.y * b.x - d.x * b.y) * inv_pow;
-    const float freq_hz = (float)i * c.bin_hz + d_omega * c.inv_2pi;
-    if (!(freq_hz > 0.0f && c.max_hz - freq_hz > 0.0f)) return false;
-    p.time_offset = (t.x * b.x + t.y * b.y) * inv_pow * c.inv_hop - c.latency_hops;
-    p.freq_hz = freq_hz;
-    p.power = scaled_power;
-    return true;
+// ordered compaction, shared by the kernels of this file: `masks[t]` = ballot of the kept bins jf + T t of this wavefront, `scan` =
+// this frame's [9][WPF] wave counts in LDS (written before the frame barrier).  The exclusive prefix over the counts ([t][wave]
+// row-major = bin order) is taken by every wavefront for itself with six DPP adds and read per t with v_readlane; returns the
+// column's point count.  WPF = 8 (8192 points) has 72 counts: the 64 of t < 8 are scanned, t = 8 (bin N/2, thread 0) follows them.
+template <int WPF>
+__device__ __forceinline__ uint32_t store_ordered(const unsigned long long (&masks)[9], const omx_spectrogram_point (&pts)[9], const uint32_t* scan,
+                                                  int lane, int wf, bool in_range, omx_spectrogram_point* out) {
+    static_assert(WPF <= 8 || WPF == 16, "one wavefront's lanes hold the counts of t < 8");
+    const int wf_u = __builtin_amdgcn_readfirstlane(wf);
+    uint32_t running = 0;
+    if constexpr (WPF <= 8) {
+        constexpr int NCNT = WPF < 8 ? 9 * WPF : 64;
+        const uint32_t cnt = lane < NCNT ? scan[lane] : 0u;
+        const uint32_t inc = wave_inclusive_sum(cnt);
+        const uint32_t exc = inc - cnt;
+        running = (uint32_t)__builtin_amdgcn_readlane((int)inc, NCNT - 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            uint32_t before;
+            if (WPF == 8 && t == 8) before = running;  // bin N/2 comes last
+            else before = (uint32_t)__builtin_amdgcn_readlane((int)exc, t * WPF + wf_u);
+            if (in_range && ((masks[t] >> lane) & 1ull))
+                *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + (before + lanes_below(masks[t])) * 12u) = pts[t];
+        }
+        if constexpr (WPF == 8) running += scan[8 * WPF];
+    } else {  // 16384 points: 144 counts, summed per thread
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            uint32_t before = running;
+            for (int w = 0; w < WPF; ++w) {
+                const uint32_t c = scan[t * WPF + w];
+                if (w < wf) before += c;
+                running += c;
+            }
+            if (in_range && ((masks[t] >> lane) & 1ull))
+                *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + (before + lanes_below(masks[t])) * 12u) = pts[t];
+        }
+    }
+    return running;
 }
-}  // namespace
 
 // BINS: the window is applied on the bins (two-term cosine-sum windows, Hann / Hamming): Z = FFT(s) and Z2 = FFT((n - c) s) as ONE
 // dual transform, then FFT(w s)[k] = c0 Z[k] + c1/2 (Z[k-1] + Z[k+1]), FFT(t w s) the same combination of Z2, and
@@ -65,7 +86,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const long long last_nonzero = a.last_nonzero[s];
-    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
     const uint64_t p0 = stft_tail(a, s) + (uint64_t)col * a.hop;
     const uint32_t p32 = (uint32_t)p0;
     uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
@@ -214,28 +235,13 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint32_t bin = ju + (unsigned)T * (unsigned)t;
-        bool keep = false;
-        if ((t < 8 || jf == 0) && !silent) keep = reassign_bin_p(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]);
+        const bool keep = reassign_flat(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]) && (t < 8 || jf == 0) && !silent;
         masks[t] = __ballot(keep);
         if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
     }
     frame_sync<LOGN>();
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
-    uint32_t running = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        uint32_t before = running;
-#pragma unroll
-        for (int w = 0; w < WPF; ++w) {
-            const uint32_t c = scan[t * WPF + w];
-            if (w < wf) before += c;
-            running += c;
-        }
-        if (in_range && ((masks[t] >> lane) & 1ull)) {
-            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
-            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
-        }
-    }
+    const uint32_t running = store_ordered<WPF>(masks, pts, scan, lane, wf, in_range, out);
     if (jf == 0 && in_range) *count_out = running;
 }
 
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
     const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
     const long long last_nonzero = a.last_nonzero[s];
-    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
     const uint64_t p0 = stft_tail(a, s) + (uint64_t)col * a.hop;
     const uint32_t p32 = (uint32_t)p0;
     uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
@@ -546,28 +552,13 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const uint32_t bin = ju + (unsigned)T * (unsigned)t;
-        bool keep = false;
-        if ((t < 8 || jf == 0) && !silent) keep = reassign_bin_p(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]);
+        const bool keep = reassign_flat(bin, bb[t], bd[t], vt[t], pn[t], rc, pts[t]) && (t < 8 || jf == 0) && !silent;
         masks[t] = __ballot(keep);
         if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
     }
     frame_sync<LOGF>();
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
-    uint32_t running = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        uint32_t before = running;
-#pragma unroll
-        for (int w = 0; w < WPF; ++w) {
-            const uint32_t c = scan[t * WPF + w];
-            if (w < wf) before += c;
-            running += c;
-        }
-        if (in_range && ((masks[t] >> lane) & 1ull)) {
-            const uint32_t pos = before + (uint32_t)__popcll(masks[t] & ((1ull << lane) - 1ull));
-            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
-        }
-    }
+    const uint32_t running = store_ordered<WPF>(masks, pts, scan, lane, wf, in_range, out);
     if (jf == 0 && in_range) *count_out = running;
 }
 
@@ -750,7 +741,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
         if (j == 0) *count_out = 0;
         return;
     }
-    const ReassignConstsP rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
     const bool bins = a.win_terms == 2;
     const uint64_t row = bins ? (uint64_t)kBigRow<LOGN> : (uint64_t)(N / 2 + 1);
     const uint64_t per = (uint64_t)sc.count * row;
@@ -778,7 +769,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
         }
         const float norm = a.bin_norm[bin];
         bool keep = false;
-        if (t < 8 || j == 0) keep = reassign_bin_p(bin, b, d, tt, norm, rc, pts[t]);
+        if (t < 8 || j == 0) keep = reassign_flat(bin, b, d, tt, norm, rc, pts[t]);
         masks[t] = __ballot(keep);
         if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
     }
