@@ -299,6 +299,8 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
             launch_stft_classic_pow2(fa, d_codes_.ptr, (uint32_t)fft_size_, stream);
         else if (fft_size_ == 4096 && !cross_check)
             launch_stft_reassigned_4096(fa, kernel_form_, stream);
+        else if (fft_size_ == 8192 && fa.win_terms == 2 && kernel_form_ == 0 && !cross_check)
+            launch_stft_reassigned_8192(fa, stream);  // one dual 4096-point transform per 8192-point transform (stft8192_kernels.hip)
         else
             launch_stft_reassigned_pow2(fa, (uint32_t)fft_size_, stream);
     } else {

@@ -103,6 +103,8 @@ void launch_stft_reassigned_4096_col(const StftFastArgs& a, hipStream_t stream);
 uint32_t stream_column_grid(uint32_t n_streams, uint32_t n_cols);
 // size-templated fused kernel (stft_pow2_kernels.hip): fft_size 1024 / 2048 (/ 4096 as a cross-check of the tuned kernel)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream);
+// W = F = 8192, Hann / Hamming (stft8192_kernels.hip): `a.tw4096` = exp(-2 pi i k / 8192), `a.tw8192` = exp(-2 pi i k / 16384) / 2
+void launch_stft_reassigned_8192(const StftFastArgs& a, hipStream_t stream);
 // reassigned 16384: three kernels through an HBM scratch, frames [first, first + count) of the call per launch
 uint64_t stft_big_scratch_bytes_per_frame();
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream);
