@@ -17,6 +17,7 @@
 // LDS: two padded 4096-complex buffers (68 KiB) -> two workgroups = four columns in flight per CU (was two).
 #include "stft_kernels.hpp"
 
+#include "buffer_device.hpp"
 #include "fft_device.hpp"
 #include "reassign_device.hpp"
 #include <cstdlib>
@@ -165,11 +166,18 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     // ---- 1. packed real FFTs of the two 8192-sample windows -----------------------------------------------------------
     const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
     v2f va[16], vb[16];
-    if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+    // Both windows lie in one piece of the ring (no wrap inside [p0a, p0b + 8192)) and pairs are 8-byte aligned: buffer loads, one
+    // lane offset for the whole batch and the step in a scalar register (buffer_device.hpp); otherwise every index is wrapped by the mask.
+    const uint32_t off_a = pa32 & mask32, hop_bytes = (pb32 - pa32) * 4u;
+    const bool direct = (uint64_t)off_a + (uint64_t)(pb32 - pa32) + 8192ull <= a.cap && ((p0a | p0b) & 1ull) == 0;
+    const GlobalBuffer windowb = global_buffer(ring + off_a, hop_bytes + 8192u * 4u);
+    const GlobalBuffer tw4096b = global_buffer(a.tw4096, 4096u * 8u), tw8192b = global_buffer(a.tw8192, 4096u * 8u),
+                       normb = global_buffer(a.bin_norm, 2049u * 4u);
+    if (direct) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            va[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((pa32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
-            vb[t] = *reinterpret_cast<const v2f*>(ring_bytes + (((pb32 + 2u * (ju + 256u * (unsigned)t)) << 2) & bytemask));
+            va[t] = load_v2f(windowb, ju * 8u, 2048u * (unsigned)t);
+            vb[t] = load_v2f(windowb, ju * 8u, hop_bytes + 2048u * (unsigned)t);
         }
     } else {
 #pragma unroll
@@ -180,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         }
     }
 #pragma unroll
-    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[ju * (unsigned)t];
+    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = load_v2f(tw4096b, ju * 8u * (unsigned)t, 0);
     float pn[9];  // bin normalisation of this thread's bins: the same for both columns, requested with the first batch
 #pragma unroll
-    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || j == 0) ? ju + 256u * (unsigned)t : 0u];
+    for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
     mark(0);
     // (the LDS copy of the pass-2 twiddles is first read in pass 2, behind the pass-1 barrier)
     pair_dual<false>(va, vb, A, B, j, tw, [&] { tw2_lds[j] = tw2_mine; });  // v[t] = Zf[j + 256 t]
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         // ahead of the natural-order copy — the kernel is 1-2 % SLOWER, same-box A/B.)
         v2f w8[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) w8[t] = a.tw8192[ju + 256u * (unsigned)t];
+        for (int t = 0; t < 16; ++t) w8[t] = load_v2f(tw8192b, ju * 8u, 2048u * (unsigned)t);
         // partner Zf[(4096 - k) & 4095] of k = j + 256 t sits at pad16(4096 - j) - 272 t (4096 - j is not a multiple of 16 for
         // j > 0 ... and pad16 is linear across multiples of 256 anyway); thread 0's partners 4096 - 256 t sit at 4352 - 272 t, and
         // its t = 0 read (one slot past the block, inside the allocation) is not used
@@ -232,7 +240,13 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
     // the real part's samples, in flight during the inverse: Re analytic[n] = 4096 x[n] - X[0]/2 + X[4096] (-1)^n / 2
     float xra[16], xrb[16];
-    {
+    if (direct) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            xra[t] = load_f32(windowb, ju * 4u, 8192u + 1024u * (unsigned)t);
+            xrb[t] = load_f32(windowb, ju * 4u, hop_bytes + 8192u + 1024u * (unsigned)t);
+        }
+    } else {
         const uint32_t qa = pa32 + 2048u + ju, qb = pb32 + 2048u + ju;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
