@@ -106,6 +106,18 @@ void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipSt
 // W = F = 8192, Hann / Hamming (stft8192_kernels.hip): `a.tw4096` = exp(-2 pi i k / 8192), `a.tw8192` = exp(-2 pi i k / 16384) / 2
 void launch_stft_reassigned_8192(const StftFastArgs& a, hipStream_t stream);
 // reassigned 16384: three kernels through an HBM scratch, frames [first, first + count) of the call per launch
+constexpr int kBigHalo = 16;                       // neighbour bins kept on either side of 0 ... N/2 (zero padding <= 16)
+template <int LOGN>
+constexpr int kBigRow = (1 << LOGN) / 2 + 1 + 2 * kBigHalo;  // complex values per (frame, spectrum) row in bins mode
+struct BigScratch {
+    v2f* sv;          // [chunk][W] analytic slices
+    v2f* spec;        // [3][chunk][N/2 + 1], or [2][chunk][kBigRow] in bins mode
+    uint32_t first;   // first frame (item = stream * n_cols + column) of this chunk
+    uint32_t count;   // frames in this chunk
+};
+void launch_hilbert_16k(const StftFastArgs& a, const BigScratch& sc, bool imag_only, hipStream_t stream);   // stft16384_kernels.hip
+void launch_windowed_reassign_16k(const StftFastArgs& a, const BigScratch& sc, bool imag_only, hipStream_t stream);
+void launch_windowed_16k(const StftFastArgs& a, const BigScratch& sc, hipStream_t stream);
 uint64_t stft_big_scratch_bytes_per_frame();
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream);
 bool launch_stft_reassigned_zp_16384(const StftFastArgs& a, uint32_t window, const v2f* twF, void* scratch, uint32_t first, uint32_t count,

@@ -600,16 +600,6 @@ bool launch_stft_reassigned_zp(const StftFastArgs& a, uint32_t window, uint32_t 
 //   reassign_big_kernel    per-bin reassignment + ordered compaction
 // One frame per 1024-thread workgroup, one in-place 16384-point transform at a time.
 // ================================================================================================
-constexpr int kBigHalo = 16;                       // neighbour bins kept on either side of 0 ... N/2 (zero padding <= 16)
-template <int LOGN>
-constexpr int kBigRow = (1 << LOGN) / 2 + 1 + 2 * kBigHalo;  // complex values per (frame, spectrum) row in bins mode
-struct BigScratch {
-    v2f* sv;          // [chunk][N]
-    v2f* spec;        // [3][chunk][N/2 + 1]
-    uint32_t first;   // first frame (item = stream * n_cols + column) of this chunk
-    uint32_t count;   // frames in this chunk
-};
-
 template <int LOGN>
 __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFastArgs a, BigScratch sc) {
     using G = FftGeom<LOGN>;
@@ -814,8 +804,15 @@ static void launch_big(const StftFastArgs& a, const v2f* twF, void* scratch, uin
     }
     StftFastArgs af = a;  // the windowed transforms run at F points: their twiddles are exp(-2 pi i k / F)
     if (twF) af.tw4096 = twF;
-    hipLaunchKernelGGL(hilbert_big_kernel<LOGW>, dim3(count), dim3(GW::T), lds_w, stream, a, sc);
-    hipLaunchKernelGGL(windowed_big_kernel<LOGF>, dim3(count, a.win_terms == 2 ? 2 : 3), dim3(GF::T), lds_f, stream, af, sc);
+    const bool fused = LOGF == 14 && a.win_terms == 2;  // Hann / Hamming at 16384 points: windowed transforms + reassignment in one kernel
+    if constexpr (LOGW == 14) launch_hilbert_16k(a, sc, fused, stream);  // stft16384_kernels.hip: 256 threads per frame, 4 x 4096-point transforms
+    else hipLaunchKernelGGL(hilbert_big_kernel<LOGW>, dim3(count), dim3(GW::T), lds_w, stream, a, sc);
+    if (fused) {
+        launch_windowed_reassign_16k(af, sc, LOGW == 14, stream);
+        return;
+    }
+    if constexpr (LOGF == 14) launch_windowed_16k(af, sc, stream);
+    else hipLaunchKernelGGL(windowed_big_kernel<LOGF>, dim3(count, a.win_terms == 2 ? 2 : 3), dim3(GF::T), lds_f, stream, af, sc);
     hipLaunchKernelGGL(reassign_big_kernel<LOGF>, dim3(count), dim3(GF::T), 0, stream, af, sc);
 }
 void launch_stft_reassigned_16384(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
