@@ -34,6 +34,20 @@ def test_reassigned_every_window_kind(omx, oracle, window, W):
 
 
 @pytest.mark.parametrize("window", WINDOWS)
+@pytest.mark.parametrize("W,zp,hop", [(8192, 1, 1024), (16384, 1, 2048), (2048, 8, 256)])
+def test_reassigned_big_transforms_every_window_kind(omx, oracle, window, W, zp, hop):
+    """8192 (one dual 4096-point transform per transform, stft8192_kernels.hip) and 16384 (four, stft16384_kernels.hip; window 16384
+    and a zero-padded one): Hann / Hamming run the kernels that window on the bins, the other kinds the table-driven ones"""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, window=window, zero_padding_factor=zp, use_reassignment=True, history_length=16)
+    pcm = stream_pcm(5, 2 * W + hop * 2)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert len(g.new_columns) == len(w.new_columns) == 3 and g.reassigned_power_scale == w.reassigned_power_scale
+    # Hamming through 8x zero padding: the ORACLE's t-hat is 1.08e-4 hops from exact arithmetic (HIP 3.3e-6), see tests/test_exact_f64.py
+    check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop, scale=2.0 if (window == capi.WINDOW_HAMMING and zp == 8) else 1.0)
+
+
+@pytest.mark.parametrize("window", WINDOWS)
 def test_classic_and_spectrum_every_window_kind(omx, oracle, window):
     pcm = stream_pcm(4, 4096 + 256 * 7)
     blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
