@@ -4,6 +4,8 @@
 //   src/util/audio/window.rs:20-43, :90-109.
 #include "common.hpp"
 
+#include <complex>
+
 namespace omx {
 
 static thread_local std::string g_last_error;
@@ -177,6 +179,84 @@ std::vector<float> twiddle_table(size_t n, size_t count) {
         t[2 * k + 1] = (float)std::sin(step * (double)k);
     }
     return t;
+}
+
+namespace {
+void fft_radix2_host(std::vector<std::complex<double>>& a) {  // forward, in place, power-of-two length
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k));
+                const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+}  // namespace
+
+BluesteinHostTables bluestein_tables(size_t n) {
+    BluesteinHostTables t;
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    t.m = m;
+    t.chirp.resize(2 * n);
+    std::vector<std::complex<double>> b(m, std::complex<double>(0.0, 0.0));
+    for (size_t k = 0; k < n; ++k) {
+        const uint64_t k2 = ((uint64_t)k * (uint64_t)k) % (2 * (uint64_t)n);  // the phase pi k^2 / n is periodic in k^2 mod 2n
+        const double ang = M_PI * (double)k2 / (double)n;
+        t.chirp[2 * k] = (float)std::cos(ang);
+        t.chirp[2 * k + 1] = (float)-std::sin(ang);
+        b[k] = std::complex<double>(std::cos(ang), std::sin(ang));
+        if (k) b[m - k] = b[k];
+    }
+    fft_radix2_host(b);
+    t.bf.resize(2 * m);
+    for (size_t k = 0; k < m; ++k) {
+        t.bf[2 * k] = (float)b[k].real();
+        t.bf[2 * k + 1] = (float)b[k].imag();
+    }
+    t.tw_m = twiddle_table(m, m / 2);
+    return t;
+}
+
+std::vector<float> derivative_window_host(const std::vector<float>& window) {
+    const size_t n = window.size();
+    std::vector<float> out(n, 0.0f);
+    if (n <= 1) return out;
+    // X[k] = sum_j w[j] e^{-2 pi i j k / n};  D[k] = i omega_k X[k] (0 at DC and, for even n, at Nyquist);  w'[j] = Re IDFT(D)[j] / n
+    std::vector<std::complex<double>> X(n);
+    for (size_t k = 0; k < n; ++k) {
+        std::complex<double> acc(0.0, 0.0);
+        for (size_t j = 0; j < n; ++j) {
+            const double ang = -2.0 * M_PI * (double)((j * k) % n) / (double)n;
+            acc += (double)window[j] * std::complex<double>(std::cos(ang), std::sin(ang));
+        }
+        X[k] = acc;
+    }
+    const size_t half = n / 2;
+    const double scale = 2.0 * M_PI / (double)n;
+    for (size_t k = 0; k < n; ++k) {
+        const double omega = scale * ((double)k - (k > half ? (double)n : 0.0));
+        X[k] = (k == 0 || (n % 2 == 0 && k == half)) ? std::complex<double>(0.0, 0.0) : std::complex<double>(-omega * X[k].imag(), omega * X[k].real());
+    }
+    for (size_t j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (size_t k = 0; k < n; ++k) {
+            const double ang = 2.0 * M_PI * (double)((j * k) % n) / (double)n;
+            acc += X[k].real() * std::cos(ang) - X[k].imag() * std::sin(ang);
+        }
+        out[j] = (float)(acc / (double)n);
+    }
+    return out;
 }
 
 }  // namespace omx

@@ -258,5 +258,13 @@ std::vector<float> window_coefficients(uint32_t kind, size_t len);
 std::vector<float> fft_bin_normalization(const std::vector<float>& window, size_t fft_size);
 // exp(-2*pi*i*k/n) for k < count, computed in f64 and rounded to f32 (interleaved re,im)
 std::vector<float> twiddle_table(size_t n, size_t count);
+// Bluestein tables of an n-point DFT (n not a power of two), as interleaved (re, im) floats; built in double precision
+struct BluesteinHostTables {
+    size_t m = 0;
+    std::vector<float> chirp, bf, tw_m;
+};
+BluesteinHostTables bluestein_tables(size_t n);
+// the reference's spectral derivative window (spectrogram/processor.rs:569-599) for any window length, evaluated in double precision
+std::vector<float> derivative_window_host(const std::vector<float>& window);
 
 }  // namespace omx

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "bluestein_plan.hpp"
+
 namespace omx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // (re, im)
@@ -309,6 +311,41 @@ __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* 
         }
         __syncthreads();
     }
+}
+
+// Any-length forward DFT by Bluestein's chirp-z on top of the radix-2 transform: with c[k] = exp(-i pi k^2 / n),
+//   X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j]      (j k = (j^2 + k^2 - (k - j)^2) / 2)
+// the sum is a cyclic convolution of length m = next_pow2(2n - 1) with the chirp filter b (b[k] = b[m - k] = conj(c[k]), k < n),
+// whose transform `bf` = FFT_m(b) the host prepares in double precision.  `x` holds n values in and out; `scratch` m values.
+// The reference plans any length (rustfft), so shapes that are not powers of two are part of the path (generic kernels only).
+__device__ inline void fft_bluestein(v2f* x, unsigned n, v2f* scratch, const BluesteinPlan& bp, unsigned tid, unsigned nthreads) {
+    __syncthreads();
+    for (unsigned i = tid; i < bp.m; i += nthreads) {
+        v2f v{0.0f, 0.0f};
+        if (i < n) {
+            const v2f a = x[i], c = bp.chirp[i];
+            v = v2f{a.x * c.x - a.y * c.y, a.x * c.y + a.y * c.x};
+        }
+        scratch[i] = v;
+    }
+    fft_radix2(scratch, bp.m, bp.log_m, bp.tw_m, false, tid, nthreads);
+    for (unsigned i = tid; i < bp.m; i += nthreads) {
+        const v2f a = scratch[i], f = bp.bf[i];
+        scratch[i] = v2f{a.x * f.x - a.y * f.y, a.x * f.y + a.y * f.x};
+    }
+    fft_radix2(scratch, bp.m, bp.log_m, bp.tw_m, true, tid, nthreads);
+    const float inv_m = 1.0f / (float)bp.m;
+    for (unsigned k = tid; k < n; k += nthreads) {
+        const v2f a = scratch[k], c = bp.chirp[k];
+        x[k] = v2f{(a.x * c.x - a.y * c.y) * inv_m, (a.x * c.y + a.y * c.x) * inv_m};
+    }
+    __syncthreads();
+}
+// forward transform of any length: radix-2 when it is a power of two, Bluestein otherwise
+__device__ inline void fft_forward_any(v2f* x, unsigned n, unsigned logn, const v2f* tw, v2f* scratch, const BluesteinPlan& bp, unsigned tid,
+                                       unsigned nthreads) {
+    if (bp.m) fft_bluestein(x, n, scratch, bp, tid, nthreads);
+    else fft_radix2(x, n, logn, tw, false, tid, nthreads);
 }
 
 }  // namespace omx

@@ -108,12 +108,12 @@ void SpectrogramBank::advance(uint64_t count) {  // :406-410
 // Shapes the HIP path computes.  The reference accepts any fft_size (rustfft plans any length, :71-82 only normalises);
 // here a shape outside the supported set is a backend failure (OMX_ERR_UNSUPPORTED), raised BEFORE any state changes.
 static void require_supported(const omx_spectrogram_config& c) {
-    const size_t W = (size_t)c.fft_size;
-    if (!is_pow2(W)) unsupported("spectrogram fft_size must be a power of two, got " + std::to_string(W));
-    if (!is_pow2((size_t)c.zero_padding_factor))
-        unsupported("spectrogram zero_padding_factor must be a power of two, got " + std::to_string(c.zero_padding_factor));
-    if (W > (size_t(1) << 24) || (size_t)c.zero_padding_factor > (size_t(1) << 24) || W * (size_t)c.zero_padding_factor > (size_t(1) << 24))
+    const size_t W = (size_t)c.fft_size, zp = (size_t)c.zero_padding_factor;
+    if (W > (size_t(1) << 24) || zp > (size_t(1) << 24) || W * zp > (size_t(1) << 24))
         unsupported("spectrogram padded FFT longer than 2^24");
+    // lengths that are not powers of two run Bluestein's chirp-z on the generic kernel; their derivative window is evaluated on the
+    // host as a plain O(W^2) DFT pair
+    if (c.use_reassignment && !is_pow2(W) && W > (size_t(1) << 16)) unsupported("spectrogram window longer than 65536 that is not a power of two");
 }
 
 void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
@@ -129,6 +129,15 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
     std::vector<float> bin_norm = fft_bin_normalization(window, fft_size_);
     d_window_.upload(window, stream);
     d_tw_fft_.upload(twiddle_table(fft_size_, std::max<size_t>(fft_size_ / 2, 1)), stream);
+    blu_m_ = 0;
+    if (!is_pow2(fft_size_)) {  // any other transform length (the reference plans it with rustfft): Bluestein's chirp-z
+        const BluesteinHostTables t = bluestein_tables(fft_size_);
+        blu_m_ = t.m;
+        d_blu_chirp_.upload(t.chirp, stream);
+        d_blu_bf_.upload(t.bf, stream);
+        d_blu_tw_.upload(t.tw_m, stream);
+        OMX_HIP(hipStreamSynchronize(stream));  // host vectors above go out of scope
+    }
     if (reassign) {
         const float inv_h = 1.0f / (float)hilbert_len_;  // :263-266
         for (float& n : bin_norm) n *= inv_h * inv_h;
@@ -137,6 +146,9 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
         d_dwindow_.reserve(W);
         if (W <= 1) {
             OMX_HIP(hipMemsetAsync(d_dwindow_.ptr, 0, std::max<size_t>(W, 1) * sizeof(float), stream));
+        } else if (!is_pow2(W)) {
+            d_dwindow_.upload(derivative_window_host(window), stream);
+            OMX_HIP(hipStreamSynchronize(stream));
         } else {
             DeviceBuffer<float> tw_w, scratch;
             tw_w.upload(twiddle_table(W, W / 2), stream);
@@ -305,7 +317,7 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
             launch_stft_reassigned_pow2(fa, (uint32_t)fft_size_, stream);
     } else {
         if (hop > 0xFFFFFFFFull) unsupported("hop_size beyond 2^32");
-        const uint64_t per_wg = reassign ? hilbert_len_ + 3 * fft_size_ : fft_size_;
+        const uint64_t per_wg = (reassign ? hilbert_len_ + 3 * fft_size_ : fft_size_) + blu_m_;  // (+ the chirp-z scratch)
         const uint64_t total = (uint64_t)n_streams_ * n_cols;
         // working set in LDS when it fits one CU (<= 144 KiB), else a global workspace bounded to ~1 GiB
         const bool ws_in_lds = per_wg * sizeof(v2f) <= 144 * 1024;
@@ -330,6 +342,8 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
         ga.fft_size = (uint32_t)fft_size_;
         ga.hilbert_len = (uint32_t)hilbert_len_;
         ga.log_fft = log2_exact(fft_size_);
+        ga.blu = BluesteinPlan{(uint32_t)blu_m_, blu_m_ ? log2_exact(blu_m_) : 0u, reinterpret_cast<const v2f*>(d_blu_chirp_.ptr),
+                               reinterpret_cast<const v2f*>(d_blu_bf_.ptr), reinterpret_cast<const v2f*>(d_blu_tw_.ptr)};
         ga.log_hilbert = log2_exact(hilbert_len_);
         ga.window = d_window_.ptr;
         ga.dwindow = d_dwindow_.ptr;

@@ -55,6 +55,8 @@ private:
     DeviceBuffer<long long> last_nonzero_, partial_nonzero_;
     DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
     DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_twF_, d_workspace_;
+    DeviceBuffer<float> d_blu_chirp_, d_blu_bf_, d_blu_tw_;  // Bluestein tables when the transform length is not a power of two
+    size_t blu_m_ = 0;
     OutBuffer<omx_spectrogram_point> d_points_;
     OutBuffer<uint32_t> d_counts_;
     OutBuffer<uint16_t> d_codes_;

@@ -65,8 +65,8 @@ void SpectrumBank::prepare(hipStream_t stream) {
 // before any state changes.
 static void require_supported(const omx_spectrum_config& c) {
     const size_t N = (size_t)c.fft_size;
-    if (!is_pow2(N)) unsupported("spectrum fft_size must be a power of two, got " + std::to_string(N));
     if (N > (size_t(1) << 24)) unsupported("spectrum FFT longer than 2^24");
+    if (N < 1) unsupported("spectrum fft_size 0");
 }
 
 void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
@@ -77,6 +77,15 @@ void SpectrumBank::rebuild_fft(hipStream_t stream) {  // :126-136
     d_window_.upload(window, stream);
     d_bin_norm_.upload(fft_bin_normalization(window, N), stream);
     d_tw_fft_.upload(twiddle_table(N, std::max<size_t>(N / 2, 1)), stream);
+    blu_m_ = 0;
+    if (!is_pow2(N)) {  // any other length (the reference plans it with rustfft): Bluestein's chirp-z on the generic kernel
+        const BluesteinHostTables t = bluestein_tables(N);
+        blu_m_ = t.m;
+        d_blu_chirp_.upload(t.chirp, stream);
+        d_blu_bf_.upload(t.bf, stream);
+        d_blu_tw_.upload(t.tw_m, stream);
+        OMX_HIP(hipStreamSynchronize(stream));  // host vectors above go out of scope
+    }
     fast4096_ = N == 16384 || N == 8192 || N == 4096 || N == 2048 || N == 1024;  // fused kernel sizes (every FFT size the GUI offers)
     if (fast4096_) {
         d_tw256_.upload(twiddle_table(256, 256), stream);
@@ -255,6 +264,8 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     pa.n_traces = n_traces;
     pa.fft_size = (uint32_t)N;
     pa.log_fft = log2_exact(N);
+    pa.blu = BluesteinPlan{(uint32_t)blu_m_, blu_m_ ? log2_exact(blu_m_) : 0u, reinterpret_cast<const v2f*>(d_blu_chirp_.ptr),
+                           reinterpret_cast<const v2f*>(d_blu_bf_.ptr), reinterpret_cast<const v2f*>(d_blu_tw_.ptr)};
     pa.bins = (uint32_t)bins;
     pa.window = d_window_.ptr;
     pa.bin_norm = d_bin_norm_.ptr;
@@ -265,8 +276,8 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     uint64_t wgs = 0;
     if (!fast) {
         wgs = std::min<uint64_t>((uint64_t)n_streams_ * n_traces * hops_launch, 1024);
-        while (wgs > 1 && wgs * N * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
-        d_workspace_.reserve((size_t)(wgs * N * 2));
+        while (wgs > 1 && wgs * (N + blu_m_) * sizeof(v2f) > (uint64_t(1) << 30)) wgs /= 2;
+        d_workspace_.reserve((size_t)(wgs * (N + blu_m_) * 2));
         pa.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
     }
     pa.power = d_power_.ptr;

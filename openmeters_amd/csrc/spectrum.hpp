@@ -34,6 +34,8 @@ private:
 
     omx_spectrum_config cfg_{};
     uint32_t n_streams_;
+    size_t blu_m_ = 0;  // Bluestein convolution length (0: fft_size is a power of two)
+    DeviceBuffer<float> d_blu_chirp_, d_blu_bf_, d_blu_tw_;
     bool emit_all_, prepared_ = false, fast4096_ = false, force_generic_ = false, traces_dirty_ = true;
     uint64_t head_ = 0, tail_ = 0, pending_skip_ = 0, ring_cap_ = 0;
     DeviceBuffer<float> ring_[2];

@@ -43,8 +43,12 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
     float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
     const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F;
-    const uint32_t item = blockIdx.x;  // ((s * n_traces) + tr) * chunks + chunk, chunk fastest
-    const uint32_t chunk = item % chunks, st = item / chunks;
+    // XCD-aware map (as block_to_stream_column in stft_kernels.hip): block b runs on XCD b % 8 and every (stream, trace) is pinned to
+    // one XCD, so the 16 hops that share a sample find it in that XCD's L2 (chunk-fastest over all XCDs fetched the rings 8 times:
+    // 524 MB per launch against 67 MB of new samples)
+    const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
+    const uint32_t chunk = bq % chunks, st = (bq / chunks) * 8u + xcd;
+    if (st >= a.n_streams * a.n_traces) return;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
     const int fs = threadIdx.x / T, jf = threadIdx.x % T, wf = jf >> 6;
     const unsigned ju = (unsigned)jf;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
     __shared__ float mean_sh;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
     const uint64_t total = (uint64_t)a.n_streams * a.n_traces * a.n_hops;
-    v2f* ws = a.workspace + (uint64_t)blockIdx.x * a.fft_size;
+    v2f* ws = a.workspace + (uint64_t)blockIdx.x * ((uint64_t)a.fft_size + a.blu.m);
     for (uint64_t item = blockIdx.x; item < total; item += gridDim.x) {
         const uint32_t h = (uint32_t)(item % a.n_hops), st = (uint32_t)(item / a.n_hops);
         const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
         __syncthreads();
         const float mean = mean_sh;
         for (uint32_t i = tid; i < a.fft_size; i += nt) ws[i] = v2f{(ring[(p0 + i) & mask] - mean) * a.window[i], 0.0f};
-        fft_radix2(ws, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
+        fft_forward_any(ws, a.fft_size, a.log_fft, a.tw_fft, ws + a.fft_size, a.blu, tid, nt);
         for (uint32_t i = tid; i < a.bins; i += nt) {
             const v2f c = ws[i];
             spectrum_store(a, s, tr, h, i, (c.x * c.x + c.y * c.y) * a.bin_norm[i]);
@@ -188,7 +192,7 @@ static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_tra
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_traces * ((hop_pairs + F - 1) / F)), dim3(G::WG), lds, stream, a);
+    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_column_grid(stream_traces, (hop_pairs + F - 1) / F)), dim3(G::WG), lds, stream, a);
 }
 
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream) {

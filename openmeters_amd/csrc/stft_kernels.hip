@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
                 spec[2 * a.fft_size + i] = t;
             }
             for (int q = 0; q < 3; ++q)
-                fft_radix2(spec + (uint64_t)q * a.fft_size, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
+                fft_forward_any(spec + (uint64_t)q * a.fft_size, a.fft_size, a.log_fft, a.tw_fft, spec + 3ull * a.fft_size, a.blu, tid, nt);
             if (tid == 0) running_sh = 0;
             __syncthreads();
             for (uint32_t base = 0; base < bins; base += nt) {  // ordered compaction, ascending bins
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftGenericArgs a) {
                 if (i < a.window_size) x = (ring[(p0 + i) & mask] - mean) * a.window[i];
                 ws[i] = v2f{x, 0.0f};
             }
-            fft_radix2(ws, a.fft_size, a.log_fft, a.tw_fft, false, tid, nt);
+            fft_forward_any(ws, a.fft_size, a.log_fft, a.tw_fft, ws + a.fft_size, a.blu, tid, nt);
             for (uint32_t i = tid; i < bins; i += nt) {  // :369-379
                 const v2f c = ws[i];
                 out[i] = pack_classic_db_dev(power_to_db_dev((c.x * c.x + c.y * c.y) * a.bin_norm[i], -140.0f));

@@ -2,6 +2,7 @@
 // of device pointers and scalars, passed by value as kernel arguments.  Every translation unit of
 // the library is compiled by hipcc, so the clang vector type below is available on both sides.
 #pragma once
+#include "bluestein_plan.hpp"
 #include "common.hpp"
 
 namespace omx {
@@ -157,6 +158,7 @@ struct StftGenericArgs {
     uint16_t* codes;           // [n_streams][n_cols][column_stride] (classic)
     const uint64_t* tails;     // ragged banks: per-stream tail / column count (see StftFastArgs)
     const uint32_t* cols;
+    BluesteinPlan blu;         // F not a power of two: chirp-z through a transform of blu.m points (scratch = the workspace's tail)
 };
 void launch_stft_generic(const StftGenericArgs& a, uint32_t n_workgroups, hipStream_t stream);
 
@@ -184,6 +186,7 @@ struct SpectrumPowerArgs {
     float state_floor, floor_db;
     const float* a_weighting_db;  // [bins]
     float* traces;         // [n_streams][n_hops_out][2 traces][2 weightings][bins]
+    BluesteinPlan blu;     // fft_size not a power of two (generic kernel; scratch behind each workgroup's transform buffer)
 };
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream);
 

@@ -24,7 +24,7 @@ import exact_f64 as ex  # noqa: E402
 
 FS = 48000.0
 REASSIGNED_SHAPES = [(4096, 256, 1, 1), (2048, 64, 1, 1), (1024, 256, 2, 3), (4096, 256, 1, 4), (2048, 512, 4, 2), (8192, 512, 1, 1),
-                     (16384, 2048, 1, 2), (2048, 256, 8, 2)]   # W, hop, zp, window
+                     (16384, 2048, 1, 2), (2048, 256, 8, 2), (1536, 384, 1, 1), (1000, 250, 3, 1)]   # the last two: lengths that are not powers of two   # W, hop, zp, window
 CLASSIC_SHAPES = [(1024, 256, 1, 1), (4096, 256, 1, 1), (2048, 128, 2, 3)]
 HALF_CODE_DB = 0.5 * 156.0 / 65535.0
 # The reference's OWN f32 arithmetic is this far from exact arithmetic in t-hat on one shape of the list: Hamming (whose end points are
@@ -39,7 +39,8 @@ def mid_of(pcm):
 
 
 def reassigned_errors(api, W, hop, zp, kind, ncols=6, stream=3):
-    pcm = cfg2_pcm(stream, 20000 + 2 * W + hop * (ncols - 1))[20000:]
+    H = max(int(2 ** np.ceil(np.log2(2 * W))), 2)   # the Hilbert step works on next_pow2(2 W) samples (:225-227)
+    pcm = cfg2_pcm(stream, 20000 + H + hop * (ncols - 1))[20000:]
     cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, window=kind, use_reassignment=True, history_length=8192)
     up = SpectrogramProcessor(api, cfg).process_block(AudioBlock(pcm.reshape(-1), 2, FS))
     assert len(up.new_columns) == ncols

@@ -12,8 +12,10 @@ from openmeters_amd.capi import AudioBlock, SpectrogramConfig, SpectrogramProces
 pytestmark = pytest.mark.gpu
 
 
-def test_non_power_of_two_fft_is_reported_not_computed(omx):
-    p = SpectrogramProcessor(omx, SpectrogramConfig(fft_size=3000, hop_size=500))
+def test_oversized_transforms_are_reported_not_computed(omx):
+    """What is left of the unsupported set: padded transforms beyond 2^24 points, and reassigned windows beyond 65536 samples whose
+    length is not a power of two (every other length the reference accepts is computed: tests/test_gpu_parity.py)."""
+    p = SpectrogramProcessor(omx, SpectrogramConfig(fft_size=1 << 20, hop_size=500, zero_padding_factor=32))
     x = np.zeros(8000 * 2, np.float32)
     with pytest.raises(capi.OmxError) as e:
         p.process_block(AudioBlock(x, 2, 48000.0))
@@ -24,7 +26,7 @@ def test_non_power_of_two_fft_is_reported_not_computed(omx):
     pcm = np.stack([np.sin(2 * np.pi * 1000 * t), np.sin(2 * np.pi * 1000 * t)], 1).astype(np.float32)
     up = p.process_block(AudioBlock(pcm.reshape(-1), 2, 48000.0))
     assert up is not None and len(up.new_columns) == (4096 - 2048) // 256 + 1
-    s = SpectrumProcessor(omx, SpectrumConfig(fft_size=1000, hop_size=250))
+    s = SpectrumProcessor(omx, SpectrumConfig(fft_size=(1 << 24) + 2, hop_size=250))
     with pytest.raises(capi.OmxError) as e:
         s.process_block(AudioBlock(pcm.reshape(-1), 2, 48000.0))
     assert e.value.status == capi.ERR_UNSUPPORTED
@@ -43,7 +45,7 @@ def test_rejected_update_config_leaves_a_prepared_handle_untouched(omx, oracle):
     got, ref = SpectrogramProcessor(omx, cfg), SpectrogramProcessor(oracle, cfg)
     a0, b0 = got.process_block(AudioBlock(pcm[:half], 2, 48000.0)), ref.process_block(AudioBlock(pcm[:half], 2, 48000.0))
     assert len(a0.new_columns) == len(b0.new_columns) == 5
-    for bad in (SpectrogramConfig(fft_size=3000, hop_size=256), SpectrogramConfig(fft_size=1024, hop_size=64, zero_padding_factor=3)):
+    for bad in (SpectrogramConfig(fft_size=100003, hop_size=256), SpectrogramConfig(fft_size=1 << 20, hop_size=64, zero_padding_factor=32)):
         with pytest.raises(capi.OmxError) as e:
             got.update_config(bad)
         assert e.value.status == capi.ERR_UNSUPPORTED
@@ -56,7 +58,7 @@ def test_rejected_update_config_leaves_a_prepared_handle_untouched(omx, oracle):
     sg, sr = SpectrumProcessor(omx, SpectrumConfig(fft_size=1024, hop_size=256)), SpectrumProcessor(oracle, SpectrumConfig(fft_size=1024, hop_size=256))
     sg.process_block(AudioBlock(pcm[:half], 2, 48000.0)); sr.process_block(AudioBlock(pcm[:half], 2, 48000.0))
     with pytest.raises(capi.OmxError) as e:
-        sg.update_config(SpectrumConfig(fft_size=1000, hop_size=250))
+        sg.update_config(SpectrumConfig(fft_size=(1 << 24) + 2, hop_size=250))
     assert e.value.status == capi.ERR_UNSUPPORTED and sg.config().fft_size == 1024
     x, y = sg.process_block(AudioBlock(pcm[half:], 2, 48000.0)), sr.process_block(AudioBlock(pcm[half:], 2, 48000.0))
     assert x is not None and y is not None

@@ -324,3 +324,34 @@ def test_history_ring_fed_from_device_resident_bank_updates_matches_oracle_ring(
             want_acc, want_db = refs[s].splat(capi.splat_view(oracle, 40.0, 96.0, scale_factor=2.0), up.reassigned_power_scale)
             bar("history ring splat: |d accumulated power| / max", np.abs(acc[s] - want_acc[0]).max() / max(want_acc.max(), 1e-30), 1e-5)
         assert gi.reassigned_points_per_slot == refs[0].info().reassigned_points_per_slot
+
+
+@pytest.mark.parametrize("W,hop,zp,reassign", [(1000, 250, 1, True), (1536, 384, 1, True), (3000, 750, 1, True), (1000, 250, 3, True),
+                                                (1024, 256, 3, True), (1000, 250, 1, False), (1536, 512, 1, False), (1024, 256, 3, False)])
+def test_lengths_that_are_not_powers_of_two_match_oracle(omx, oracle, W, hop, zp, reassign):
+    """The reference plans any transform length (rustfft; `spectrogram/processor.rs:71-82` only normalises the configuration).  The HIP
+    path runs them as Bluestein chirp-z transforms on the generic kernel; the oracle evaluates the plain DFT sum."""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, use_reassignment=reassign, history_length=16)
+    need = (1 << int(np.ceil(np.log2(2 * W)))) if reassign else W * zp   # the Hilbert step works on next_pow2(2 W) samples (:225-227)
+    pcm = stream_pcm(7, need + hop * 3)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert g is not None and w is not None and len(g.new_columns) == len(w.new_columns) and len(w.new_columns) >= 3
+    assert g.fft_size == w.fft_size == W * zp
+    if reassign:
+        assert g.reassigned_power_scale == w.reassigned_power_scale
+        check_reassigned(g.new_columns, w.new_columns, hop)
+    else:
+        check_classic(g.new_columns, w.new_columns)
+
+
+@pytest.mark.parametrize("N,hop", [(1000, 250), (3000, 1000), (1536, 384)])
+def test_spectrum_lengths_that_are_not_powers_of_two_match_oracle(omx, oracle, N, hop):
+    cfg = SpectrumConfig(fft_size=N, hop_size=hop)
+    pcm = stream_pcm(8, N + hop * 5)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrumProcessor(omx, cfg).process_block(blk), SpectrumProcessor(oracle, cfg).process_block(blk)
+    assert g is not None and w is not None and np.array_equal(g.frequency_bins, w.frequency_bins)
+    for wt in range(2):
+        check_trace(g.traces[0][wt], w.traces[0][wt])
+
