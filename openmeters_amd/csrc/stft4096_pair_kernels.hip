@@ -20,6 +20,7 @@
 #include "buffer_device.hpp"
 #include "fft_device.hpp"
 #include "reassign_device.hpp"
+#include "twiddle_run_device.hpp"
 #include <cstdlib>
 
 namespace omx {
@@ -39,6 +40,15 @@ __device__ __forceinline__ bool pair_block_to_stream_chunk(uint32_t n_streams, u
 // per 65 536 frames, 1.72 as committed): LDS reads issued as single ds_read_b64 through inline asm instead of the
 // ds_read2st64_b64 pairs hipcc forms (1.78: the forced full wait and 18 spilled registers cost more than the read2 penalty),
 // volatile reads (3.08: 58 spilled registers), -amdgpu-sched-strategy=max-ilp (1.89: 16 spilled registers).
+// w8[t] = base * exp(-2 pi i t / 32): the 8192-point twiddles of the Hilbert step as one table read per thread and 15 rotations by
+// compile-time constants (a run of 16 table reads is a global round trip in the middle of the kernel with nothing to overlap it)
+template <int TT>
+__device__ __forceinline__ void w8_run(v2f (&w8)[16], v2f base) {
+    if constexpr (TT < 16) {
+        w8[TT] = rotate128<4 * TT>(base);
+        w8_run<TT + 1>(w8, base);
+    }
+}
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     }
 #pragma unroll
     for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = load_v2f(tw4096b, ju * 8u * (unsigned)t, 0);
+    const v2f w8_base = load_v2f(tw8192b, ju * 8u, 0);  // exp(-2 pi i j / 8192) / 2: element j + 256 t of the Hilbert step's twiddles is it times exp(-2 pi i t / 32)
     float pn[9];  // bin normalisation of this thread's bins: the same for both columns, requested with the first batch
 #pragma unroll
     for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
@@ -216,8 +227,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
         // exp(-2 pi i k / 8192) / 2, k = j + 256 t: one table read serves both columns.  (Requested earlier — with the first batch, or
         // ahead of the natural-order copy — the kernel is 1-2 % SLOWER, same-box A/B.)
         v2f w8[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) w8[t] = load_v2f(tw8192b, ju * 8u, 2048u * (unsigned)t);
+        w8_run<0>(w8, w8_base);
         // partner Zf[(4096 - k) & 4095] of k = j + 256 t sits at pad16(4096 - j) - 272 t (4096 - j is not a multiple of 16 for
         // j > 0 ... and pad16 is linear across multiples of 256 anyway); thread 0's partners 4096 - 256 t sit at 4352 - 272 t, and
         // its t = 0 read (one slot past the block, inside the allocation) is not used
