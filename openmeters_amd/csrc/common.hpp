@@ -172,21 +172,35 @@ struct EventTimer {  // HIP-event timing of one kernel family on its launch stre
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     bool enabled = false;
     ~EventTimer() {
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
         for (auto& p : pending) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
     }
+    // A begin() whose end() never comes (the launch between them threw) leaves one pair behind: it is destroyed by the next begin().
+    // The tally is bounded: beyond kMaxPending launches without a collect() the oldest pair is dropped.
+    static constexpr size_t kMaxPending = 4096;
     void begin(hipStream_t s) {
         if (!enabled) return;
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
+        start = stop = nullptr;
         OMX_HIP(hipEventCreate(&start));
         OMX_HIP(hipEventCreate(&stop));
         OMX_HIP(hipEventRecord(start, s));
     }
     void end(hipStream_t s) {
-        if (!enabled) return;
+        if (!enabled || !start) return;
         OMX_HIP(hipEventRecord(stop, s));
+        if (pending.size() >= kMaxPending) {
+            (void)hipEventDestroy(pending.front().first);
+            (void)hipEventDestroy(pending.front().second);
+            pending.erase(pending.begin());
+        }
         pending.emplace_back(start, stop);
+        start = stop = nullptr;
     }
     // average ms over the recorded launches; clears the tally
     double collect(uint64_t* launches) {

@@ -268,7 +268,8 @@ def test_oscilloscope_random_operation_sequences(omx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed,W,hop,reassign", [(1, 1024, 256, True), (2, 4096, 256, True), (3, 2048, 64, True), (4, 1024, 300, False),
-                                                   (5, 256, 700, True), (6, 4096, 1024, False)])
+                                                   (5, 256, 700, True), (6, 4096, 1024, False), (7, 8192, 512, True), (8, 16384, 1024, True),
+                                                   (9, 1000, 250, True)])
 def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx, oracle, seed, W, hop, reassign):
     """Per-stream independence inside a bank (reference: one VisualManager per capture, reset and fed on its own,
     visuals/registry.rs:396-418).  Every stream of a ragged bank gets its own random frame counts (0 ... 3 blocks, uneven) and its
@@ -323,7 +324,7 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
             elif up.fft_size in (1024, 2048, 4096, 8192, 16384):
                 check_classic(got, w.new_columns)
             produced += want_cols
-    assert produced > 10
+    assert produced > (10 if W <= 4096 else 4)   # (long windows: few columns in 14 calls of at most 845 frames)
     # the lock-step entry point is refused while the positions are per stream, and works again after a bank-wide reset
     with pytest.raises(capi.OmxError):
         bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0)
