@@ -70,3 +70,29 @@ def test_spectrogram_and_spectrum_rings_wrap_over_many_calls(omx, oracle):
         if sw is not None and calls % 25 == 0:
             check_trace(sg.traces[0][0], sw.traces[0][0])
     assert calls > 250 and checked >= 8
+
+
+@pytest.mark.parametrize("W,hop,zp", [(8192, 2048, 1), (16384, 4096, 1), (4096, 1024, 4), (4096, 256, 1)])
+def test_long_window_kernels_cross_the_ring_wrap(omx, oracle, W, hop, zp):
+    """The 8192 / 16384-point kernels (and the pair kernel) read their window with buffer loads off one lane offset while the window lies
+    in one piece of the pending-audio ring, and index by index through the wrap mask when it does not: irregular calls (odd sizes, so
+    odd and even window starts) until the ring has wrapped several times, the newest column of every call against the oracle."""
+    rng = np.random.default_rng(W + zp)
+    frames = 40 * W
+    pcm = long_signal(2, frames)
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, use_reassignment=True, history_length=8)
+    a, b = SpectrogramProcessor(omx, cfg), SpectrogramProcessor(oracle, cfg)
+    at, checked = 0, 0
+    while at < frames:
+        n = min(int(rng.choice([3 * hop + 1, 2 * hop, 5 * hop - 3, hop // 2 + 7, 4 * W + 5])), frames - at)
+        blk = AudioBlock(pcm[at:at + n].reshape(-1), 2, FS)
+        at += n
+        g, w = a.process_block(blk), b.process_block(blk)
+        assert (g is None) == (w is None)
+        if w is not None:
+            assert len(g.new_columns) == len(w.new_columns) and g.reset == w.reset
+            if w.new_columns:
+                check_reassigned_columns([g.new_columns[-1]], [w.new_columns[-1]], FS, hop)
+                checked += 1
+    assert checked >= 10
+
