@@ -152,17 +152,8 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     const bool have1 = col0 + 1u < n_cols_s;
     const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
     const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
-    // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer
-    const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;
     uint32_t* count_a = a.counts + (uint64_t)s * a.n_cols + col0;
     uint32_t* count_b = a.counts + (uint64_t)s * a.n_cols + col1;
-    if (silent_a && (silent_b || !have1)) {  // column 1 starts later: silent_a implies silent_b
-        if (j == 0) {
-            *count_a = 0;
-            if (have1) *count_b = 0;
-        }
-        return;
-    }
 
     // Everything the forward transforms need from memory is requested here, in one batch: the pass-2 twiddle this thread copies
     // to LDS, both windows, the resident pass-3 twiddles.
@@ -203,6 +194,17 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_4096_pair_kernel(StftF
     float pn[9];  // bin normalisation of this thread's bins: the same for both columns, requested with the first batch
 #pragma unroll
     for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
+    // silent fast path (:307-316): no non-zero sample at or after the front of the pending buffer.  Decided AFTER the first batch of
+    // loads is in flight: `last_nonzero` is one more dependent scalar round trip, which now overlaps the vector loads instead of
+    // preceding them (a silent pair wastes its loads; it is the rare case)
+    const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;
+    if (silent_a && (silent_b || !have1)) {  // column 1 starts later: silent_a implies silent_b
+        if (j == 0) {
+            *count_a = 0;
+            if (have1) *count_b = 0;
+        }
+        return;
+    }
     mark(0);
     // (the LDS copy of the pass-2 twiddles is first read in pass 2, behind the pass-1 barrier)
     pair_dual<false>(va, vb, A, B, j, tw, [&] { tw2_lds[j] = tw2_mine; });  // v[t] = Zf[j + 256 t]
