@@ -4,8 +4,11 @@
 // operation order per bin (reference src/visuals/spectrogram/processor.rs:318-348, 439-488, 546-567):
 //   packed real FFT of the 2N-sample window -> Hilbert with one half-length inverse -> analytic slice ->
 //   three windowed FFTs (w, w', t w) -> per-bin reassignment -> ordered compaction.
+#include <cstdlib>
+
 #include "fft_pow2_device.hpp"
 #include "reassign_device.hpp"
+#include "twiddle_run_device.hpp"
 #include "stft_kernels.hpp"
 
 namespace omx {
@@ -243,6 +246,240 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
     const uint32_t running = store_ordered<WPF>(masks, pts, scan, lane, wf, in_range, out);
     if (jf == 0 && in_range) *count_out = running;
+}
+
+// ================================================================================================
+// K2p-pair: the pair form of the tuned 4096 kernel (stft4096_pair_kernels.hip) for W = F = 1024 / 2048, Hann / Hamming: a frame slot
+// (T = N/16 threads) carries TWO consecutive columns, so the packed-real forward transform and the Hilbert inverse run as dual
+// transforms too (two dependency chains per wavefront between shared syncs) — two dual-transform phases per column where the
+// one-column-per-slot kernel above spends three transform phases.  With T = 64 (1024 points) a slot is one wavefront and no phase
+// of it needs a workgroup barrier.  2048 / hop 64 is the reference's default spectrogram shape.
+// ================================================================================================
+template <int TT>
+__device__ __forceinline__ void half_twiddle_run(v2f (&w8)[16], v2f base) {  // base * exp(-2 pi i t / 32): element jf + T t of exp(-2 pi i k / 2N) / 2
+    if constexpr (TT < 16) {
+        w8[TT] = rotate128<4 * TT>(base);
+        half_twiddle_run<TT + 1>(w8, base);
+    }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_pair_kernel(StftFastArgs a) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // F pair slots per workgroup
+    static_assert(LOGN == 10 || LOGN == 11, "1024 / 2048 points");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* lds = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = lds + 2 * F * G::LDS;                              // [256]
+    uint32_t* scan_all = reinterpret_cast<uint32_t*>(tw2_lds + 256);  // [F][9][WPF]
+    float* hil_all = reinterpret_cast<float*>(scan_all + F * 9 * WPF);  // [F][4]
+
+    const uint32_t pairs = (a.n_cols + 1u) / 2u, chunks = (pairs + F - 1) / F;
+    const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
+    const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
+    if (s >= a.n_streams) return;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    const unsigned ju = (unsigned)jf;
+    const int lane = threadIdx.x & 63, wf = jf >> 6;
+    v2f* A = lds + (2 * fs) * G::LDS;
+    v2f* B = A + G::LDS;
+    uint32_t* scan = scan_all + fs * 9 * WPF;
+    float* hil = hil_all + fs * 4;
+    const uint32_t n_cols_s = stft_cols(a, s), pairs_s = (n_cols_s + 1u) / 2u;
+    if (chunk * F >= pairs_s) return;  // (whole workgroup: every slot is past this stream's columns)
+    const uint32_t pair_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = pair_raw < pairs_s;
+    const uint32_t pair = in_range ? pair_raw : pairs_s - 1u;  // idle slots shadow the last pair (syncs stay uniform)
+    const uint32_t col0 = 2u * pair;
+    const bool have1 = col0 + 1u < n_cols_s;
+    const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
+
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint32_t mask32 = (uint32_t)(a.cap - 1);
+    const long long last_nonzero = a.last_nonzero[s];
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t tail_s = stft_tail(a, s);
+    const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
+    // silent fast path (:307-316).  The first slot's first column has the smallest p0: if it is silent, every column here is.
+    const uint64_t p0_first = tail_s + (uint64_t)(2u * chunk * F) * a.hop;
+    if (last_nonzero < (long long)p0_first) {
+        if (jf == 0 && in_range) {
+            a.counts[(uint64_t)s * a.n_cols + col0] = 0;
+            if (have1) a.counts[(uint64_t)s * a.n_cols + col1] = 0;
+        }
+        return;
+    }
+    const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;  // computed anyway, emitted empty
+
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);  // `tw4096` carries exp(-2 pi i k / N) for this N
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    const v2f w8_base = a.tw8192[ju];  // exp(-2 pi i jf / 2N) / 2
+    float pn[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+
+    // ---- 1. packed real FFTs of the two 2N-sample windows ------------------------------------------------------------------------------
+    const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
+    v2f va[16], vb[16];
+    if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            va[t] = *reinterpret_cast<const v2f*>(ring + ((pa32 + 2u * (ju + (unsigned)T * (unsigned)t)) & mask32));
+            vb[t] = *reinterpret_cast<const v2f*>(ring + ((pb32 + 2u * (ju + (unsigned)T * (unsigned)t)) & mask32));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qa = pa32 + 2u * (ju + (unsigned)T * (unsigned)t), qb = pb32 + 2u * (ju + (unsigned)T * (unsigned)t);
+            va[t] = v2f{ring[qa & mask32], ring[(qa + 1u) & mask32]};
+            vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
+        }
+    }
+    __syncthreads();  // tw2_lds (shared by every slot)
+    fftp_dual<false, LOGN>(va, vb, A, B, jf, tw);  // v[t] = Zf[jf + T t]
+
+    // ---- 2. Hilbert transform with one half-length inverse per column (derivation: stft_kernels.hip step 2) ---------------------------
+    frame_sync<LOGN>();  // pass 3 of the dual transform still reads A and B
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        A[pad16(jf + T * t)] = va[t];
+        B[pad16(jf + T * t)] = vb[t];
+    }
+    if (jf == 0) {
+        hil[0] = (va[0].x + va[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (va[0].x - va[0].y) * 0.5f;  // X[N] / 2
+        hil[2] = (vb[0].x + vb[0].y) * 0.5f;
+        hil[3] = (vb[0].x - vb[0].y) * 0.5f;
+    }
+    frame_sync<LOGN>();
+    v2f ya[16], yb[16];
+    {
+        v2f w8[16];
+        half_twiddle_run<0>(w8, w8_base);
+        // partner Zf[(N - k) & (N - 1)] of k = jf + T t sits at pad16(N - jf) - (T + T/16) t (thread 0: pad16(N) - ...; its t = 0 read
+        // lands one slot past the buffer, inside the allocation, and is not used)
+        constexpr int PS = T + T / 16;
+        const int part = (jf ? pad16(N - jf) : N + N / 16) - PS * 15;
+        auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16], const v2f* X) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const v2f z = v[t], zr = X[part + PS * (15 - t)];
+                const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
+                y[t] = cmulc(sum, w8[t]) - cmul(dif, w8[t]);
+                if (t == 0 && jf == 0) y[t] = v2f{0.0f, 0.0f};
+            }
+        };
+        hilbert_spectrum(ya, va, A);
+        hilbert_spectrum(yb, vb, B);
+    }
+    const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
+    float xra[16], xrb[16];  // the real part's samples, in flight during the inverse
+    {
+        const uint32_t qa = pa32 + (uint32_t)(N / 2) + ju, qb = pb32 + (uint32_t)(N / 2) + ju;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            xra[t] = ring[(qa + (unsigned)T * (unsigned)t) & mask32];
+            xrb[t] = ring[(qb + (unsigned)T * (unsigned)t) & mask32];
+        }
+    }
+    frame_sync<LOGN>();  // partners are read from the buffers the inverse is about to overwrite
+    fftp_dual<true, LOGN>(ya, yb, A, B, jf, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = jf + T t
+
+    // ---- 3. analytic slices s[i] = analytic[N/2 + i], i = jf + T t -------------------------------------------------------------------------
+    frame_sync<LOGN>();
+    float* imag_a = reinterpret_cast<float*>(A);
+    float* imag_b = reinterpret_cast<float*>(B);
+#pragma unroll
+    for (int t = 4; t < 12; ++t) {
+        *reinterpret_cast<v2f*>(imag_a + 2 * (jf + T * t - N / 4)) = ya[t];
+        *reinterpret_cast<v2f*>(imag_b + 2 * (jf + T * t - N / 4)) = yb[t];
+    }
+    frame_sync<LOGN>();
+    v2f sa[16], sb[16];
+    {
+        const float par_a = (jf & 1) ? -half_xna : half_xna, par_b = (jf & 1) ? -half_xnb : half_xnb;  // n = N/2 + i has jf's parity
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            sa[t] = v2f{(float)N * xra[t] - half_x0a + par_a, imag_a[jf + T * t]};
+            sb[t] = v2f{(float)N * xrb[t] - half_x0b + par_b, imag_b[jf + T * t]};
+        }
+    }
+    const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / (float)N);
+    constexpr float CENTER = (float)(N - 1) * 0.5f;
+
+    // ---- 4. per column: Z = FFT(s), Z2 = FFT((n - c) s) as one dual transform; windows applied on the bins -------------------------------
+    auto column = [&](const v2f (&sv)[16], bool silent, bool store, uint32_t col) {
+        v2f z[16], z2[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float nc = (float)(jf + T * t) - CENTER;  // compute_time_weighted's ramp (:601-608)
+            z[t] = sv[t];
+            z2[t] = v2f{sv[t].x * nc, sv[t].y * nc};
+        }
+        frame_sync<LOGN>();  // the gather above / the previous column's neighbour reads still use A and B
+        fftp_dual<false, LOGN>(z, z2, A, B, jf, tw);
+        frame_sync<LOGN>();  // pass 3 still reads A and B
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {  // natural-order copy of bins -1 ... N/2 + T (slot 1 + k = bin k, slot 0 = bin -1 = bin N - 1)
+            A[1 + jf + T * t] = z[t];
+            B[1 + jf + T * t] = z2[t];
+        }
+        if (jf == T - 1) {
+            A[0] = z[15];
+            B[0] = z2[15];
+        }
+        frame_sync<LOGN>();
+        omx_spectrogram_point pts[9];
+        unsigned long long masks[9];
+#pragma unroll
+        for (int h = 0; h < 9; h += 3) {  // three bins at a time: the neighbour reads of a group are issued together
+            v2f nzm[3], nzp[3], nz2m[3], nz2p[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int bin = jf + T * (h + u);  // (t = 8: only thread 0's bin exists; the others read slots inside the buffer)
+                nzm[u] = A[bin];
+                nzp[u] = A[bin + 2];
+                nz2m[u] = B[bin];
+                nz2p[u] = B[bin + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = h + u;
+                const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+                const v2f zm = nzm[u], zp = nzp[u], z2m = nz2m[u], z2p = nz2p[u];
+                const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y}, z2s{z2m.x + z2p.x, z2m.y + z2p.y};
+                const v2f bb{c0 * z[t].x + half_c1 * zs.x, c0 * z[t].y + half_c1 * zs.y};
+                const v2f bd{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / N) (Z[k-1] - Z[k+1])
+                const v2f bt{c0 * z2[t].x + half_c1 * z2s.x, c0 * z2[t].y + half_c1 * z2s.y};
+                const bool keep = reassign_flat(bin, bb, bd, bt, pn[t], rc, pts[t]) && (t < 8 || jf == 0) && !silent;
+                masks[t] = __ballot(keep);
+                if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
+            }
+        }
+        frame_sync<LOGN>();
+        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        const uint32_t running = store_ordered<WPF>(masks, pts, scan, lane, wf, store, out);
+        if (jf == 0 && store) a.counts[(uint64_t)s * a.n_cols + col] = running;
+    };
+    column(sa, silent_a, in_range, col0);
+    column(sb, silent_b, in_range && have1, col1);
+}
+
+template <int LOGN>
+static void launch_pow2_pair(const StftFastArgs& a, hipStream_t stream) {
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)(2 * F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) + (size_t)F * 4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_pair_kernel<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    const uint32_t pairs = (a.n_cols + 1u) / 2u, chunks = (pairs + F - 1) / F;
+    hipLaunchKernelGGL((stft_reassigned_pow2_pair_kernel<LOGN>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
 }
 
 // ================================================================================================
@@ -860,6 +1097,12 @@ static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
 // fft_size = 1024, 2048, 4096 or 8192 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
+    static const bool one_column_slots = [] { const char* e = getenv("OMX_POW2_SINGLE"); return e && atoi(e) == 1; }();  // A/B: the one-column-per-slot kernel
+    if (a.win_terms == 2 && !one_column_slots && (fft_size == 1024 || fft_size == 2048)) {  // Hann / Hamming: two columns per slot
+        if (fft_size == 1024) launch_pow2_pair<10>(a, stream);
+        else launch_pow2_pair<11>(a, stream);
+        return;
+    }
     switch (fft_size) {
         case 1024: launch_pow2<10>(a, stream); break;
         case 2048: launch_pow2<11>(a, stream); break;
