@@ -632,7 +632,9 @@ void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t f
 // (W values) is then spread over all F/16 threads, zero-extended to F (`apply_complex_window`, :559-567) and the three
 // windowed transforms, the reassignment and the compaction run exactly as in the unpadded kernel, over F/2 + 1 bins.
 // ================================================================================================
-template <int LOGW, int LOGF>
+// BINS: Hann / Hamming, the window applied on the bins (cos(2 pi n / W) shifts an F-point spectrum by F / W bins): two windowed
+// transforms (Z, Z2 as one dual) instead of three, no window tables
+template <int LOGW, int LOGF, bool BINS>
 __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1) void stft_reassigned_zp_kernel(
     StftFastArgs a, const v2f* __restrict__ twF) {
     using GW = FftGeom<LOGW>;
@@ -734,8 +736,12 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
         for (int u = 0; u < 16; ++u) {
             const unsigned i = ju + (unsigned)T * (unsigned)u;
             const unsigned ic = i < (unsigned)W ? i : 0u;  // clamped: the value is discarded below when i >= W
-            pw[u] = a.window[ic];
-            pdw[u] = a.dwindow[ic];
+            if constexpr (!BINS) {
+                pw[u] = a.window[ic];
+                pdw[u] = a.dwindow[ic];
+            } else {
+                pw[u] = pdw[u] = 0.0f;
+            }
             pxr[u] = *reinterpret_cast<const float*>(ring_bytes + (((qe + ic) << 2) & bytemask));
         }
     }
@@ -761,9 +767,14 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
         float w = 0.0f, dw = 0.0f, wt = 0.0f;
         if (i < W) {  // compile-time for most u: i < W  <=>  u < 16 / zp (T u is a multiple of T, jf < T)
             sv = v2f{(float)W * pxr[u] - half_x0 + parity, imag[i]};
-            w = pw[u];
-            dw = pdw[u];
-            wt = ((float)i - CENTER) * w;  // compute_time_weighted (:601-608)
+            if constexpr (BINS) {
+                w = 1.0f;                    // Z  = FFT(s)
+                dw = (float)i - CENTER;      // Z2 = FFT((n - c) s): compute_time_weighted's ramp (:601-608)
+            } else {
+                w = pw[u];
+                dw = pdw[u];
+                wt = ((float)i - CENTER) * w;  // compute_time_weighted (:601-608)
+            }
         }
         vb[u] = v2f{sv.x * w, sv.y * w};   // zero beyond the window (:563-566)
         vd[u] = v2f{sv.x * dw, sv.y * dw};
@@ -772,16 +783,43 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
     frame_sync<LOGF>();  // imag[] (in B) is consumed
     fftp_dual<false, LOGF>(vb, vd, A, B, jf, tw);
     v2f bb[9], bd[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        bb[t] = vb[t];
-        bd[t] = vd[t];
-    }
     float pn[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
     frame_sync<LOGF>();  // the paired transform's last pass still reads A and B
-    fftp<false, LOGF>(vt, A, B, jf, tw);
+    if constexpr (!BINS) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            bb[t] = vb[t];
+            bd[t] = vd[t];
+        }
+        fftp<false, LOGF>(vt, A, B, jf, tw);
+    } else {
+        // natural-order copy of bins -SH ... F/2 + T of both spectra (slot SH + k = bin k; bins -m = F - m sit below slot SH)
+        constexpr int SH = N / W;  // F / W
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            A[SH + jf + T * t] = vb[t];
+            B[SH + jf + T * t] = vd[t];
+        }
+        if (jf >= T - SH) {
+            A[SH - (T - jf)] = vb[15];
+            B[SH - (T - jf)] = vd[15];
+        }
+        frame_sync<LOGF>();
+        const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / (float)W);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+            const bool mine = t < 8 || jf == 0;
+            const uint32_t at = (mine ? bin : 0u) + (unsigned)SH;
+            const v2f zm = A[at - SH], zp = A[at + SH], z2m = B[at - SH], z2p = B[at + SH];
+            const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y}, z2s{z2m.x + z2p.x, z2m.y + z2p.y};
+            bb[t] = v2f{c0 * vb[t].x + half_c1 * zs.x, c0 * vb[t].y + half_c1 * zs.y};
+            bd[t] = v2f{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / W) (Z[k - F/W] - Z[k + F/W])
+            vt[t] = v2f{c0 * vd[t].x + half_c1 * z2s.x, c0 * vd[t].y + half_c1 * z2s.y};
+        }
+    }
 
     // ---- 4. reassignment + ordered compaction (bins jf + T t, t < 8, and bin F/2 on thread 0) ----------------------------
     omx_spectrogram_point pts[9];
@@ -806,13 +844,17 @@ static void launch_zp(const StftFastArgs& a, const v2f* twF, hipStream_t stream)
     const size_t lds = (size_t)(2 * F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) + (size_t)F * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_zp_kernel<LOGW, LOGF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_zp_kernel<LOGW, LOGF, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_zp_kernel<LOGW, LOGF, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const uint32_t chunks = (a.n_cols + F - 1) / F;
-    hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a,
-                       twF);
+    if (a.win_terms == 2)  // Hann / Hamming: window applied on the bins, four transforms per column
+        hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF, true>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a, twF);
+    else
+        hipLaunchKernelGGL((stft_reassigned_zp_kernel<LOGW, LOGF, false>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a, twF);
 }
 
 // window 1024 / 2048 / 4096 zero-padded to 2048 / 4096 / 8192: `a.tw4096` = exp(-2 pi i k / W), `a.tw8192` = exp(-2 pi i k / 2W), twF = exp(-2 pi i k / F)
