@@ -3,6 +3,9 @@
 //                          (reference src/util/audio/window.rs:66-88, src/visuals/spectrum/processor.rs:215-244)
 //   K3b spectrum_levels    per-bin None / Exponential / PeakHold recurrence over hops + raw and
 //                          A-weighted dB (reference spectrum/processor.rs:349-402)
+#include <cstdlib>
+
+#include "buffer_device.hpp"
 #include "fft_pow2_device.hpp"
 #include "stft_kernels.hpp"
 
@@ -152,6 +155,143 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     }
 }
 
+// ---- K3a split: N = 16384 (the reference's default spectrum size) as ONE packed-real transform per hop on the tuned 4096-point dual
+// transform (fft_device.hpp): z[m] = (x[2m], x[2m+1]), M = 8192 complex points = the dual transform of the even / odd interleaved
+// halves + a radix-2 step in registers (cf. stft8192_kernels.hip), then the real-input split
+//   X[k] = (Z[k] + conj Z[M-k]) / 2 - i w^k (Z[k] - conj Z[M-k]) / 2,   w = exp(-2 pi i / N)
+// with the partners read from a natural-order copy in both LDS buffers.  256 threads per hop, two workgroups per CU; the
+// size-templated kernel above runs this size with 1024 threads, four in-place passes and one workgroup per CU (19.4 M hops/s;
+// this one 23.0 M).  The same form for N = 8192 (two hops per workgroup as one dual transform) measured the same as the
+// size-templated kernel (46 M hops/s) and was not kept.
+__global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPowerArgs a) {
+    constexpr int N = 16384, M = N / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char spectrum_smem[];
+    v2f* A = reinterpret_cast<v2f*>(spectrum_smem);
+    v2f* B = A + FFT4096_LDS;        // contiguous with A: one 8704-slot buffer for the partner exchange
+    v2f* tw2_lds = B + FFT4096_LDS;  // [256]
+    float* wave_sum = reinterpret_cast<float*>(tw2_lds + 256);  // [4]
+    const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
+    const uint32_t h0 = bq % a.n_hops, st = (bq / a.n_hops) * 8u + xcd;  // XCD-aware: a (stream, trace) stays on one XCD
+    if (st >= a.n_streams * a.n_traces) return;
+    const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+    const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const unsigned ju = threadIdx.x;
+    const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
+    const uint32_t mask32 = (uint32_t)(a.cap - 1);  // cap <= 2^30 (host-checked)
+    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)(a.first_hop + h0) * a.hop);
+    const v2f* T = a.tw4096;  // exp(-2 pi i k / N), k < N
+    struct TW {
+        const v2f* tw2;
+        const v2f* table;
+        unsigned step;  // 4 j
+        __device__ __forceinline__ v2f w2(unsigned k, int t) const { return tw2[k * (unsigned)t]; }
+        __device__ __forceinline__ v2f w3(int t) const { return table[step * (unsigned)t]; }  // exp(-2 pi i j t / 4096)
+    };
+    const TW tw{tw2_lds, T, ju * 4u};
+    tw2_lds[j] = a.tw256[ju];
+
+    // ---- load, remove the mean, window (window.rs:66-88; the mean in tree order, like the size-templated kernel) ---------------------------
+    // v0 / v1 = even / odd packed elements 2 (j + 256 t) + r -> samples 4 (j + 256 t) + 2r, + 1
+    v2f v0[16], v1[16];
+    // the samples of the hop lie in one piece of the ring and pairs are 8-byte aligned: buffer loads (buffer_device.hpp)
+    const uint32_t off0 = p32 & mask32;
+    const bool direct = (uint64_t)off0 + (uint64_t)N <= a.cap && (p32 & 1u) == 0;
+    const GlobalBuffer window = global_buffer(ring + off0, (uint32_t)N * 4u);
+    const GlobalBuffer winb = global_buffer(a.window, (uint32_t)N * 4u), normb = global_buffer(a.bin_norm, (uint32_t)(M + 1) * 4u),
+                       awb = global_buffer(a.a_weighting_db, (uint32_t)(M + 1) * 4u), Tb = global_buffer(T, (uint32_t)N * 8u);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (direct) {
+            v0[t] = load_v2f(window, ju * 16u, 4096u * (unsigned)t);
+            v1[t] = load_v2f(window, ju * 16u + 8u, 4096u * (unsigned)t);
+        } else {
+            const uint32_t q = p32 + 4u * (ju + 256u * (unsigned)t);
+            v0[t] = v2f{ring[q & mask32], ring[(q + 1u) & mask32]};
+            v1[t] = v2f{ring[(q + 2u) & mask32], ring[(q + 3u) & mask32]};
+        }
+    }
+    float sum0 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sum0 += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum0 += __shfl_xor(sum0, off);
+    if (lane == 0) wave_sum[wave] = sum0;
+    __syncthreads();  // wave sums, tw2_lds
+    const float mean0 = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) / (float)N;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const v2f wl = load_v2f(winb, ju * 16u, 4096u * (unsigned)t), wh = load_v2f(winb, ju * 16u + 8u, 4096u * (unsigned)t);
+        v0[t] = v2f{(v0[t].x - mean0) * wl.x, (v0[t].y - mean0) * wl.y};
+        v1[t] = v2f{(v1[t].x - mean0) * wh.x, (v1[t].y - mean0) * wh.y};
+    }
+    fft4096t_dual<false>(v0, v1, A, B, j, tw);
+
+    // ---- radix-2 step and the natural-order copy for the partner reads -------------------------------------------------------------------------
+    __syncthreads();  // pass 3 still reads A and B
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {  // Z[k] = F0[k] + w2^k F1[k], Z[k + 4096] = F0[k] - w2^k F1[k], w2 = exp(-2 pi i / 8192)
+        const v2f m = cmul(v1[t], load_v2f(Tb, ju * 16u, 4096u * (unsigned)t));
+        const v2f lo = v0[t] + m, hi = v0[t] - m;
+        v0[t] = lo;
+        v1[t] = hi;
+        A[pad16(j + 256 * t)] = lo;
+        A[pad16(j + 256 * t + 4096)] = hi;
+    }
+    __syncthreads();
+
+    // ---- real-input split, power, dB; bins k = j + 256 t' (t' < 32) and bin M (thread 0) ---------------------------------------------------------
+    constexpr int PER = M / 256;
+    const int part = (j ? pad16(M - j) : M + M / 16) - 272 * (PER - 1);  // partner Z[M - k] of k = j + 256 t': pad16(M - j) - 272 t'
+    float* out0 = nullptr;
+    if (a.fused_db) out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
+    auto emit = [&](uint32_t k, v2f x, float norm, float aw) {
+        const float p = (x.x * x.x + x.y * x.y) * norm;
+        if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
+            const float db = fast_power_db(p);
+            const bool low = p < a.state_floor;
+            out0[k] = low ? a.floor_db : fmaxf(db + aw, a.floor_db);
+            out0[a.bins + k] = low ? a.floor_db : fmaxf(db, a.floor_db);
+        } else {
+            a.power[(((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins + k] = p;
+        }
+    };
+    auto split = [&](v2f z, v2f zr, v2f w) {  // (Z + conj Zr)/2 - i w (Z - conj Zr)/2
+        const v2f e{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f}, o{(z.x - zr.x) * 0.5f, (z.y + zr.y) * 0.5f};
+        const v2f wo = cmul(o, w);
+        return v2f{e.x + wo.y, e.y - wo.x};
+    };
+#pragma unroll
+    for (int g = 0; g < PER; g += 8) {  // eight bins at a time: their table and partner reads are issued together
+        v2f w[8], zr[8];
+        float norm[8], aw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tp = g + u;
+            w[u] = load_v2f(Tb, ju * 8u, 2048u * (unsigned)tp);
+            norm[u] = load_f32(normb, ju * 4u, 1024u * (unsigned)tp);
+            aw[u] = a.fused_db ? load_f32(awb, ju * 4u, 1024u * (unsigned)tp) : 0.0f;
+            zr[u] = A[part + 272 * (PER - 1 - tp)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tp = g + u;
+            const v2f z = tp < 16 ? v0[tp & 15] : v1[tp & 15];
+            emit(ju + 256u * (unsigned)tp, split(z, (tp == 0 && j == 0) ? v0[0] : zr[u], w[u]), norm[u], aw[u]);  // k = 0: Z[M] is Z[0]
+        }
+    }
+    if (j == 0) emit((uint32_t)M, v2f{v0[0].x - v0[0].y, 0.0f}, a.bin_norm[M], a.fused_db ? a.a_weighting_db[M] : 0.0f);  // X[M] = Re Z[0] - Im Z[0]
+}
+
+static void launch_spectrum_16384(const SpectrumPowerArgs& a, uint32_t stream_traces, hipStream_t stream) {
+    const size_t lds = (size_t)(2 * FFT4096_LDS + 256) * sizeof(v2f) + 4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_16384_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(spectrum_power_16384_kernel, dim3(stream_column_grid(stream_traces, a.n_hops)), dim3(256), lds, stream, a);
+}
+
 // ---- K3a generic: any power-of-two N, radix-2 in a global workspace, reference operation order ------
 __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPowerArgs a) {
     __shared__ float mean_sh;
@@ -201,7 +341,9 @@ void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t g
     const uint64_t pairs = (uint64_t)a.n_streams * a.n_traces * ((a.n_hops + 1) / 2);
     const uint32_t hop_pairs = (a.n_hops + 1) / 2, st = a.n_streams * a.n_traces;
     (void)pairs;
-    if (fast4096 && a.fft_size == 16384) launch_spectrum_pow2<14>(a, st, hop_pairs, stream);
+    static const bool templated = [] { const char* e = getenv("OMX_SPECTRUM_TEMPLATED"); return e && atoi(e) == 1; }();  // A/B: the size-templated kernel
+    if (fast4096 && a.fft_size == 16384 && !templated) launch_spectrum_16384(a, st, stream);
+    else if (fast4096 && a.fft_size == 16384) launch_spectrum_pow2<14>(a, st, hop_pairs, stream);
     else if (fast4096 && a.fft_size == 8192) launch_spectrum_pow2<13>(a, st, hop_pairs, stream);
     else if (fast4096 && a.fft_size == 4096) launch_spectrum_pow2<12>(a, st, hop_pairs, stream);
     else if (fast4096 && a.fft_size == 2048) launch_spectrum_pow2<11>(a, st, hop_pairs, stream);
