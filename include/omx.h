@@ -319,6 +319,26 @@ int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on
                               uint64_t frames, uint32_t channels, float sample_rate,
                               const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
                               omx_spectrum_bank_update* out);
+/* Per-stream frame counts and per-stream reset_audio, as for the spectrogram bank (the reference runs one SpectrumProcessor per
+ * capture, reset and fed on its own, visuals/registry.rs:396-418): `pcm` is device memory [n_streams][frames_capacity][channels],
+ * stream s pushes its first frames[s] <= frames_capacity frames (0 = sits the call out, nothing of it changes); reset_mask (or NULL)
+ * [n_streams]: non-zero = reset_audio() of that stream before its push (pending audio dropped, averaging state cleared, traces back
+ * to the floor).  The hop rule of process_ready_windows (:179-213) is evaluated per stream on the device; `max_hops` hop slots per
+ * stream are laid out, of which stream s filled the first d_n_hops[s] (emit_all_hops), or its slot 0 holds its newest hop
+ * (emit_all_hops == 0; untouched when the stream produced none).  The first ragged call moves the bank to per-stream positions;
+ * omx_spectrum_bank_process is refused from then on until omx_spectrum_bank_reset_audio. */
+typedef struct omx_spectrum_ragged_update {
+    uint64_t bins;
+    uint64_t n_streams;
+    uint64_t max_hops;            /* upper bound of any stream's hops in this call */
+    uint64_t n_hops_out;          /* hop slots per stream in d_traces (max_hops with emit_all_hops, else 1) */
+    const uint32_t* d_n_hops;     /* device [n_streams]: hops processed by each stream in this call */
+    const float* d_traces;        /* device [n_streams][n_hops_out][2][2][bins] */
+    const float* d_frequency_bins;
+} omx_spectrum_ragged_update;
+int omx_spectrum_bank_process_ragged(omx_spectrum_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                     const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_spectrum_ragged_update* out);
 int omx_spectrum_bank_fetch(omx_spectrum_bank* b, uint64_t stream_index, uint64_t hop,
                             float* dst /* [2][2][bins] */);
 int omx_spectrum_bank_set_option(omx_spectrum_bank* b, uint32_t option, uint64_t value);

@@ -138,6 +138,19 @@ class SpectrumBank:
     def process_device(self, device_ptr, frames, channels, sample_rate, positions, stream=0):
         return self._process(device_ptr, True, frames, channels, sample_rate, positions, stream)
 
+    def process_ragged(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """Streams advance independently: stream s receives frames[s] (<= frames_capacity) new frames, after reset_audio() when
+        reset_mask[s]; pcm = device f32 [n_streams][frames_capacity][channels].  Returns the CSpectrumRaggedUpdate."""
+        out = capi.CSpectrumRaggedUpdate()
+        fr = np.ascontiguousarray(frames, np.uint32)
+        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        f = self.api.fn("spectrum_bank_process_ragged", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
     def process_host(self, pcm, channels, sample_rate, positions=None):
         pcm = np.ascontiguousarray(pcm, np.float32).reshape(self.n_streams, -1, channels)
         positions = positions if positions is not None else capi.positions_fallback(channels)

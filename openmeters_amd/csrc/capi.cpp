@@ -295,6 +295,14 @@ int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on
                                static_cast<hipStream_t>(stream), out);
     });
 }
+int omx_spectrum_bank_process_ragged(omx_spectrum_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                     const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_spectrum_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_ragged(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_spectrum_bank_fetch(omx_spectrum_bank* b, uint64_t stream_index, uint64_t hop, float* dst) {
     if (!b || !dst) return OMX_ERR_INVALID;
     return guarded([&] { return b->impl.fetch(stream_index, hop, dst, b->impl.last_stream()); });

@@ -55,6 +55,7 @@ void SpectrumBank::reset_audio() {  // :112-118
     if (prepared_) reset_level_buffers(last_stream_);
     tail_ = head_;
     pending_skip_ = 0;
+    ragged_ = false;  // every stream drops its pending audio: the common host-side positions describe the bank again
 }
 
 void SpectrumBank::prepare(hipStream_t stream) {
@@ -173,6 +174,10 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
                           const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
+    if (ragged_) {
+        set_last_error("spectrum bank is in ragged mode (per-stream positions): use process_ragged, or reset_audio() first");
+        return OMX_ERR_INVALID;
+    }
     if (frames == 0) return OMX_NONE;
     const float sample_rate = sanitize_sample_rate(sample_rate_in);
     if (sample_rate != cfg_.sample_rate) {  // :258-263
@@ -229,9 +234,28 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
 
     const uint64_t bins = N / 2 + 1;
     const bool averaging = cfg_.averaging_mode != OMX_AVERAGING_NONE;
-    const uint64_t hops_out = emit_all_ ? n_hops : 1;
     // AveragingMode::None with latest-hop output: earlier hops cannot influence the snapshot (:364-365)
     const uint64_t first_hop = (!averaging && !emit_all_) ? n_hops - 1 : 0;
+    const int rc = launch_hops(tail0, nullptr, nullptr, n_hops, first_hop, n_traces, active, stream);
+    if (out) {
+        out->bins = bins;
+        out->n_streams = n_streams_;
+        out->n_hops = n_hops;
+        out->n_hops_out = last_hops_out_;
+        out->d_traces = d_traces_.ptr;
+        out->d_frequency_bins = d_freq_bins_.ptr;
+    }
+    return rc;
+}
+
+// The power (+ levels) launches of `n_hops` hops per stream slot, starting at hop `first_hop`.  Lock-step: every stream from
+// `tail0`; ragged: stream s from tails[s], hops[s] of them (n_hops = the layout stride).
+int SpectrumBank::launch_hops(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop, uint32_t n_traces,
+                              const bool active[2], hipStream_t stream) {
+    const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size;
+    const uint64_t bins = N / 2 + 1;
+    const bool averaging = cfg_.averaging_mode != OMX_AVERAGING_NONE;
+    const uint64_t hops_out = emit_all_ ? n_hops : 1;
     const uint64_t hops_launch = n_hops - first_hop;
 
     if (averaging) d_power_.reserve((size_t)(n_streams_ * n_traces * hops_launch * bins));
@@ -257,6 +281,8 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         }
     pa.cap = ring_cap_;
     pa.tail = tail0;
+    pa.tails = tails;
+    pa.hops = hops;
     pa.hop = (uint32_t)hop;
     pa.first_hop = (uint32_t)first_hop;
     pa.n_hops = (uint32_t)hops_launch;
@@ -294,14 +320,6 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     if (!averaging) {  // the power kernel wrote the traces itself
         timer_.end(stream);
         OMX_HIP(hipGetLastError());
-        if (out) {
-            out->bins = bins;
-            out->n_streams = n_streams_;
-            out->n_hops = n_hops;
-            out->n_hops_out = hops_out;
-            out->d_traces = d_traces_.ptr;
-            out->d_frequency_bins = d_freq_bins_.ptr;
-        }
         return OMX_PRODUCED;
     }
 
@@ -319,6 +337,7 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     la.bins = (uint32_t)bins;
     la.mode = cfg_.averaging_mode;
     la.emit_all = emit_all_ ? 1 : 0;
+    la.hops = hops;
     const float dt_seconds = (float)hop / cfg_.sample_rate;  // :184
     const float factor = cfg_.averaging_param;
     la.alpha = factor < 0.0f ? 0.0f : (factor > 0.9999f ? 0.9999f : factor);           // :367
@@ -328,16 +347,142 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     launch_spectrum_levels(la, stream);
     timer_.end(stream);
     OMX_HIP(hipGetLastError());
+    return OMX_PRODUCED;
+}
 
+
+// ------------------------------------------------------------------ ragged calls (per-stream frame counts and reset)
+void SpectrumBank::enter_ragged(hipStream_t stream) {
+    const size_t S = n_streams_;
+    for (DeviceBuffer<uint64_t>* b : {&r_head_, &r_tail_, &r_skip_, &r_ing_head_, &r_hop_tail_}) b->reserve(S);
+    for (DeviceBuffer<uint32_t>* b : {&r_frames_, &r_ing_skip_, &r_ing_count_, &r_nhops_}) b->reserve(S);
+    r_mask_.reserve(S);
+    r_frames_host_.reserve(S);
+    r_mask_host_.reserve(S);
+    std::vector<uint64_t> h(S, head_), t(S, tail_), k(S, pending_skip_);  // the common lock-step state becomes every stream's state
+    OMX_HIP(hipMemcpyAsync(r_head_.ptr, h.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    OMX_HIP(hipMemcpyAsync(r_tail_.ptr, t.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    OMX_HIP(hipMemcpyAsync(r_skip_.ptr, k.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    OMX_HIP(hipStreamSynchronize(stream));
+    ragged_ = true;
+}
+
+int SpectrumBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                 uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                 omx_spectrum_ragged_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) return OMX_ERR_INVALID;
+    for (uint32_t s = 0; s < n_streams_; ++s)
+        if (frames[s] > frames_capacity) return OMX_ERR_INVALID;
+    const float sample_rate = sanitize_sample_rate(sample_rate_in);
+    if (sample_rate != cfg_.sample_rate) {  // a format change concerns every stream of the bank (:258-263)
+        cfg_.sample_rate = sample_rate;
+        if (prepared_) reset_buffers(stream);
+        ragged_ = false;  // (reset_buffers dropped every stream's pending audio: the common positions describe the bank again)
+    }
+    prepare(stream);
+    bool active[2];
+    active_traces(active);
+    const uint32_t n_traces = (active[0] ? 1 : 0) + (active[1] ? 1 : 0);
+    if (n_traces == 0) return OMX_NONE;
+    if (!ragged_) enter_ragged(stream);
+    const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size, bins = N / 2 + 1;
+    if (hop > 0xFFFFFFFFull) unsupported("hop beyond 2^32");
+    // every stream enters a call with fewer than N pending samples (its ready windows were consumed), except right after the switch
+    // from lock-step mode, where the common pending count is known
+    const uint64_t pending_bound = std::max<uint64_t>(head_ - tail_, N ? N - 1 : 0);
+    const uint64_t most = pending_bound + frames_capacity;
+    const uint64_t max_hops = most >= N ? (most - N) / std::max<uint64_t>(std::min(hop, N), 1) + 1 : 0;
+    if (max_hops > 0x7FFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many hops in one call");
+
+    // rings: room for the pending samples + this call's; growth re-homes every stream's pending samples on the device
+    if (most > ring_cap_ || !ring_[0].ptr || !ring_[1].ptr) {
+        const uint64_t cap = std::max<uint64_t>(next_pow2(std::max(most, ring_cap_)), 1024);
+        for (int t = 0; t < 2; ++t) {
+            DeviceBuffer<float> bigger;
+            bigger.reserve((size_t)(cap * n_streams_));
+            if (ring_[t].ptr && ring_cap_) launch_ring_rehome(ring_[t].ptr, ring_cap_, bigger.ptr, cap, r_head_.ptr, r_tail_.ptr, n_streams_, stream);
+            OMX_HIP(hipStreamSynchronize(stream));  // the old buffer is freed below
+            std::swap(ring_[t].ptr, bigger.ptr);
+            std::swap(ring_[t].count, bigger.count);
+        }
+        ring_cap_ = cap;
+    }
+    // level state and trace rows exist before a reset can touch them
+    const bool averaging = cfg_.averaging_mode != OMX_AVERAGING_NONE;
+    const uint64_t hops_out = emit_all_ ? std::max<uint64_t>(max_hops, 1) : 1;
+    {
+        const size_t traces_count = (size_t)(n_streams_ * hops_out * 4 * bins);
+        if (d_traces_.count < traces_count) {
+            d_traces_.reserve(traces_count, false);
+            traces_dirty_ = true;
+        }
+        if (traces_dirty_ || hops_out != last_hops_out_) {
+            launch_fill(d_traces_.ptr, d_traces_.count, cfg_.floor_db, stream);
+            traces_dirty_ = false;
+        }
+        last_hops_out_ = hops_out;
+    }
+    // the call's per-stream inputs (small: through pinned memory)
+    OMX_HIP(hipStreamSynchronize(stream));
+    std::memcpy(r_frames_host_.ptr, frames, n_streams_ * sizeof(uint32_t));
+    OMX_HIP(hipMemcpyAsync(r_frames_.ptr, r_frames_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if (reset_mask) {
+        std::memcpy(r_mask_host_.ptr, reset_mask, n_streams_);
+        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_, hipMemcpyHostToDevice, stream));
+        launch_spectrum_reset_streams(r_mask_.ptr, n_streams_, averaging ? d_smoothed_.ptr : nullptr, 2 * bins, d_traces_.ptr, hops_out * 4 * bins,
+                                      cfg_.floor_db, stream);
+    }
+    SpectrumPlanArgs pl{};
+    pl.n_streams = n_streams_;
+    pl.fft_size = N;
+    pl.hop = hop;
+    pl.max_hops = (uint32_t)max_hops;
+    pl.frames = r_frames_.ptr;
+    pl.reset_mask = reset_mask ? r_mask_.ptr : nullptr;
+    pl.head = r_head_.ptr;
+    pl.tail = r_tail_.ptr;
+    pl.pending_skip = r_skip_.ptr;
+    pl.ing_skip = r_ing_skip_.ptr;
+    pl.ing_count = r_ing_count_.ptr;
+    pl.ing_head = r_ing_head_.ptr;
+    pl.hop_tail = r_hop_tail_.ptr;
+    pl.n_hops = r_nhops_.ptr;
+    launch_spectrum_plan(pl, stream);
+
+    IngestArgs ia{};
+    ia.pcm = d_pcm;
+    ia.frames_total = frames_capacity;
+    ia.count = frames_capacity;  // grid bound; the per-stream values follow
+    ia.skips = r_ing_skip_.ptr;
+    ia.counts = r_ing_count_.ptr;
+    ia.heads = r_ing_head_.ptr;
+    ia.fmt = make_format(channels, positions);
+    ia.n_out = 0;
+    if (active[0]) { ia.project[ia.n_out] = (int)cfg_.source; ia.ring[ia.n_out] = ring_[0].ptr; ++ia.n_out; }
+    if (active[1]) { ia.project[ia.n_out] = (int)cfg_.secondary_source; ia.ring[ia.n_out] = ring_[1].ptr; ++ia.n_out; }
+    ia.cap = ring_cap_;
+    ia.last_nonzero = nullptr;
+    ia.partial_nonzero = nullptr;
+    launch_ingest(ia, n_streams_, stream);
+    OMX_HIP(hipGetLastError());
+    head_ = tail_ = 0;  // from here on only the bound above uses them (pending_bound = N - 1)
+    pending_skip_ = 0;
+
+    int rc = OMX_NONE;
+    if (max_hops > 0) rc = launch_hops(0, r_hop_tail_.ptr, r_nhops_.ptr, max_hops, 0, n_traces, active, stream);
     if (out) {
+        std::memset(out, 0, sizeof(*out));
         out->bins = bins;
         out->n_streams = n_streams_;
-        out->n_hops = n_hops;
+        out->max_hops = max_hops;
         out->n_hops_out = hops_out;
+        out->d_n_hops = r_nhops_.ptr;
         out->d_traces = d_traces_.ptr;
         out->d_frequency_bins = d_freq_bins_.ptr;
     }
-    return OMX_PRODUCED;
+    return rc;
 }
 
 int SpectrumBank::fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStream_t stream) {

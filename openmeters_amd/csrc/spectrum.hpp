@@ -17,6 +17,9 @@ public:
     void prepare(hipStream_t stream);
     int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out);
+    // per-stream frame counts / reset (include/omx.h: omx_spectrum_bank_process_ragged); pcm in device memory
+    int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStream_t stream);
     const std::vector<float>& frequency_bins() const { return freq_bins_; }
     uint64_t bins() const { return cfg_.fft_size / 2 + 1; }
@@ -31,6 +34,9 @@ private:
     void reset_level_buffers(hipStream_t stream);
     void active_traces(bool out[2]) const;
     void ensure_ring(uint64_t incoming, hipStream_t stream);
+    void enter_ragged(hipStream_t stream);
+    int launch_hops(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop, uint32_t n_traces,
+                    const bool active[2], hipStream_t stream);
 
     omx_spectrum_config cfg_{};
     uint32_t n_streams_;
@@ -49,6 +55,13 @@ private:
     uint64_t last_hops_out_ = 0;
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
+    // ragged mode: per-stream positions on the device (the host-side head_ / tail_ then only bound the pending length)
+    bool ragged_ = false;
+    DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_hop_tail_;
+    DeviceBuffer<uint32_t> r_frames_, r_ing_skip_, r_ing_count_, r_nhops_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_frames_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
 };
 
 struct SpectrumSingle {

@@ -3,6 +3,7 @@
 //                          (reference src/util/audio/window.rs:66-88, src/visuals/spectrum/processor.rs:215-244)
 //   K3b spectrum_levels    per-bin None / Exponential / PeakHold recurrence over hops + raw and
 //                          A-weighted dB (reference spectrum/processor.rs:349-402)
+#include <algorithm>
 #include <cstdlib>
 
 #include "buffer_device.hpp"
@@ -22,6 +23,7 @@ __device__ __forceinline__ float fast_power_db(float p) { return __builtin_amdgc
 __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint32_t s, uint32_t tr, uint32_t h, uint32_t k,
                                                float power) {
     if (a.fused_db) {
+        if (!(a.emit_all || a.hops == nullptr || h + 1 == a.hops[s])) return;  // ragged, newest hop only: the stream's last hop writes
         float raw = a.floor_db, weighted = a.floor_db;
         if (!(power < a.state_floor)) {
             const float db = logf(power) * 4.3429448f;
@@ -56,16 +58,18 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     const int fs = threadIdx.x / T, jf = threadIdx.x % T, wf = jf >> 6;
     const unsigned ju = (unsigned)jf;
     v2f* A = lds + fs * G::LDS;
+    const uint32_t n_hops_s = spectrum_hops(a, s), pairs_s = (n_hops_s + 1) / 2;  // ragged banks: this stream's own hop count
+    if (chunk * F >= pairs_s) return;  // (whole workgroup)
     const uint32_t pair_raw = chunk * F + (uint32_t)fs;
-    const bool in_range = pair_raw < pairs;
-    const uint32_t pr = in_range ? pair_raw : pairs - 1u;  // idle slots shadow the last pair (barriers stay uniform)
+    const bool in_range = pair_raw < pairs_s;
+    const uint32_t pr = in_range ? pair_raw : pairs_s - 1u;  // idle slots shadow the last pair (barriers stay uniform)
     const uint32_t h0 = 2 * pr;
-    const bool has_b = h0 + 1 < a.n_hops;
+    const bool has_b = h0 + 1 < n_hops_s;
     // every global load of the workgroup is issued up front (unsigned 32-bit offsets: SGPR base + VGPR offset
     // addressing), so one memory round trip covers the ring, the window, the twiddles and the per-bin tables
     const char* ring = reinterpret_cast<const char*>(a.ring[tr] + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;  // cap <= 2^30 (host-checked)
-    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)(a.first_hop + h0) * a.hop);
+    const uint32_t p32 = (uint32_t)(spectrum_tail(a, s) + (uint64_t)(a.first_hop + h0) * a.hop);
     float xa[16], xb[16], w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -140,10 +144,13 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
             const bool low_a = pa < a.state_floor, low_b = pb < a.state_floor;
             const float raw_a = low_a ? a.floor_db : fmaxf(db_a, a.floor_db), wt_a = low_a ? a.floor_db : fmaxf(db_a + aw[t], a.floor_db);
             const float raw_b = low_b ? a.floor_db : fmaxf(db_b, a.floor_db), wt_b = low_b ? a.floor_db : fmaxf(db_b + aw[t], a.floor_db);
-            // emit_all == 0: only the newest hop is materialised; the host launches that hop alone (n_hops == 1)
-            out0[k] = wt_a;
-            out0[a.bins + k] = raw_a;
-            if (has_b && a.emit_all) {
+            // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
+            // a ragged call launches every hop and the stream's last one writes
+            if (a.emit_all || h0 + 1 == n_hops_s) {
+                out0[k] = wt_a;
+                out0[a.bins + k] = raw_a;
+            }
+            if (has_b && (a.emit_all || h0 + 2 == n_hops_s)) {
                 out0[hop_stride + k] = wt_b;
                 out0[hop_stride + a.bins + k] = raw_b;
             }
@@ -174,11 +181,13 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
     const uint32_t h0 = bq % a.n_hops, st = (bq / a.n_hops) * 8u + xcd;  // XCD-aware: a (stream, trace) stays on one XCD
     if (st >= a.n_streams * a.n_traces) return;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+    const uint32_t n_hops_s = spectrum_hops(a, s);  // ragged banks: this stream's own hop count
+    if (h0 >= n_hops_s) return;
     const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
     const unsigned ju = threadIdx.x;
     const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
     const uint32_t mask32 = (uint32_t)(a.cap - 1);  // cap <= 2^30 (host-checked)
-    const uint32_t p32 = (uint32_t)(a.tail + (uint64_t)(a.first_hop + h0) * a.hop);
+    const uint32_t p32 = (uint32_t)(spectrum_tail(a, s) + (uint64_t)(a.first_hop + h0) * a.hop);
     const v2f* T = a.tw4096;  // exp(-2 pi i k / N), k < N
     struct TW {
         const v2f* tw2;
@@ -247,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
     auto emit = [&](uint32_t k, v2f x, float norm, float aw) {
         const float p = (x.x * x.x + x.y * x.y) * norm;
         if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
+            if (!(a.emit_all || h0 + 1 == n_hops_s)) return;  // emit_all == 0: the stream's last hop is the one materialised
             const float db = fast_power_db(p);
             const bool low = p < a.state_floor;
             out0[k] = low ? a.floor_db : fmaxf(db + aw, a.floor_db);
@@ -301,9 +311,10 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
     for (uint64_t item = blockIdx.x; item < total; item += gridDim.x) {
         const uint32_t h = (uint32_t)(item % a.n_hops), st = (uint32_t)(item / a.n_hops);
         const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+        if (h >= spectrum_hops(a, s)) continue;  // ragged banks: past this stream's own hop count (workgroup-uniform)
         const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
         const uint64_t mask = a.cap - 1;
-        const uint64_t p0 = a.tail + (uint64_t)(a.first_hop + h) * a.hop;
+        const uint64_t p0 = spectrum_tail(a, s) + (uint64_t)(a.first_hop + h) * a.hop;
         __syncthreads();
         if (tid == 0) {
             float sum = -0.0f;
@@ -361,7 +372,8 @@ __global__ __launch_bounds__(256) void spectrum_levels_kernel(SpectrumLevelsArgs
     float st = state ? *state : 0.0f;
     const float aw = a.a_weighting_db[bin];
     const float* pw = a.power + ((uint64_t)s * a.n_traces + tr) * a.n_hops * a.bins + bin;
-    for (uint32_t h = 0; h < a.n_hops; ++h) {
+    const uint32_t n_hops_s = a.hops ? a.hops[s] : a.n_hops;  // ragged banks: this stream's own hop count
+    for (uint32_t h = 0; h < n_hops_s; ++h) {
         const float power = pw[(uint64_t)h * a.bins];
         float p = power;
         if (a.mode == OMX_AVERAGING_EXPONENTIAL) {  // :366-379
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void spectrum_levels_kernel(SpectrumLevelsArgs
             if (st < a.state_floor) st = 0.0f;
             p = st;
         }
-        const bool last = h + 1 == a.n_hops;
+        const bool last = h + 1 == n_hops_s;
         if (a.emit_all || last) {
             const uint32_t ho = a.emit_all ? h : 0;
             float* out = a.traces + (((uint64_t)s * a.n_hops_out + ho) * 2 + slot) * 2 * a.bins + bin;
@@ -402,6 +414,63 @@ __global__ void fill_kernel(float* p, uint64_t n, float v) {
 }
 void launch_fill(float* p, uint64_t n, float v, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n, v);
+}
+
+// ---- ragged bank: per-stream state machine ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void spectrum_plan_kernel(SpectrumPlanArgs a) {
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= a.n_streams) return;
+    uint64_t head = a.head[s], tail = a.tail[s], pending_skip = a.pending_skip[s];
+    if (a.reset_mask && a.reset_mask[s]) {  // reset_audio (:112-118): the pending audio is dropped (the level state: spectrum_reset_streams)
+        tail = head;
+        pending_skip = 0;
+    }
+    const uint64_t frames = a.frames[s];
+    uint32_t n_hops = 0, skip32 = 0, count32 = 0;
+    const uint64_t head_before = head;
+    uint64_t tail0 = tail;
+    if (frames != 0) {  // block.is_empty() -> None (:256)
+        const uint64_t skip = min(pending_skip, frames);  // push_sources (:271-298)
+        pending_skip -= skip;
+        const uint64_t count = frames - skip;
+        skip32 = (uint32_t)skip;
+        count32 = (uint32_t)count;
+        head += count;
+        while (head - tail >= a.fft_size && n_hops < a.max_hops) {  // process_ready_windows (:179-213)
+            const uint64_t len = head - tail, d = min(a.hop, len);
+            tail += d;
+            pending_skip += a.hop - d;
+            ++n_hops;
+        }
+    }
+    a.ing_skip[s] = skip32;
+    a.ing_count[s] = count32;
+    a.ing_head[s] = head_before;
+    a.hop_tail[s] = tail0;
+    a.n_hops[s] = n_hops;
+    a.head[s] = head;
+    a.tail[s] = tail;
+    a.pending_skip[s] = pending_skip;
+}
+void launch_spectrum_plan(const SpectrumPlanArgs& a, hipStream_t stream) {
+    if (a.n_streams == 0) return;
+    hipLaunchKernelGGL(spectrum_plan_kernel, dim3((a.n_streams + 63u) / 64u), dim3(64), 0, stream, a);
+}
+
+__global__ __launch_bounds__(256) void spectrum_reset_streams_kernel(const uint8_t* reset_mask, float* smoothed, uint64_t smoothed_per_stream,
+                                                                     float* traces, uint64_t traces_per_stream, float floor_db) {
+    const uint32_t s = blockIdx.y;
+    if (!reset_mask[s]) return;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (smoothed && i < smoothed_per_stream) smoothed[(uint64_t)s * smoothed_per_stream + i] = 0.0f;
+    if (traces && i < traces_per_stream) traces[(uint64_t)s * traces_per_stream + i] = floor_db;
+}
+void launch_spectrum_reset_streams(const uint8_t* reset_mask, uint32_t n_streams, float* smoothed, uint64_t smoothed_per_stream, float* traces,
+                                   uint64_t traces_per_stream, float floor_db, hipStream_t stream) {
+    const uint64_t most = std::max(smoothed ? smoothed_per_stream : 0, traces ? traces_per_stream : 0);
+    if (n_streams == 0 || most == 0) return;
+    hipLaunchKernelGGL(spectrum_reset_streams_kernel, dim3((uint32_t)((most + 255) / 256), n_streams), dim3(256), 0, stream, reset_mask, smoothed,
+                       smoothed_per_stream, traces, traces_per_stream, floor_db);
 }
 
 }  // namespace omx

@@ -187,7 +187,14 @@ struct SpectrumPowerArgs {
     const float* a_weighting_db;  // [bins]
     float* traces;         // [n_streams][n_hops_out][2 traces][2 weightings][bins]
     BluesteinPlan blu;     // fft_size not a power of two (generic kernel; scratch behind each workgroup's transform buffer)
+    // ragged banks (per-stream frame counts): tail and hop count of every stream, written by spectrum_plan_kernel; `tail` above is then
+    // unused and `n_hops` the layout stride (hops per stream slot of `power` / `traces`, the largest count of the call).  With
+    // emit_all == 0 a stream's LAST hop is the one written to its slot 0.
+    const uint64_t* tails;
+    const uint32_t* hops;
 };
+__device__ __forceinline__ uint64_t spectrum_tail(const SpectrumPowerArgs& a, uint32_t s) { return a.tails ? a.tails[s] : a.tail; }
+__device__ __forceinline__ uint32_t spectrum_hops(const SpectrumPowerArgs& a, uint32_t s) { return a.hops ? a.hops[s] : a.n_hops; }
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream);
 
 struct SpectrumLevelsArgs {
@@ -199,9 +206,29 @@ struct SpectrumLevelsArgs {
     uint32_t n_streams, n_traces, n_hops, n_hops_out, bins;
     uint32_t mode, emit_all;
     float alpha, decay, state_floor, floor_db;
+    const uint32_t* hops;  // ragged banks: hops of every stream in this call (n_hops = layout stride)
 };
 void launch_spectrum_levels(const SpectrumLevelsArgs& a, hipStream_t stream);
 void launch_fill(float* p, uint64_t n, float v, hipStream_t stream);
+
+// ---- ragged spectrum bank: SpectrumProcessor's integer state machine (push_sources / process_ready_windows, reference
+// spectrum/processor.rs:179-213, :271-298) and reset_audio (:112-118) per stream on the device, one thread per stream
+struct SpectrumPlanArgs {
+    uint32_t n_streams;
+    uint64_t fft_size, hop;
+    uint32_t max_hops;                 // layout stride (upper bound of any stream's hops in this call)
+    const uint32_t* frames;            // [n_streams] frames pushed by each stream in this call
+    const uint8_t* reset_mask;         // [n_streams] or nullptr
+    uint64_t *head, *tail, *pending_skip;  // [n_streams] per-stream positions (in / out)
+    uint32_t *ing_skip, *ing_count;    // [n_streams] per-stream ingest arguments
+    uint64_t* ing_head;
+    uint64_t* hop_tail;                // [n_streams] absolute position of hop 0's first sample
+    uint32_t* n_hops;                  // [n_streams]
+};
+void launch_spectrum_plan(const SpectrumPlanArgs& a, hipStream_t stream);
+// reset_audio of the masked streams' level state: averaging state to 0, trace rows back to the floor
+void launch_spectrum_reset_streams(const uint8_t* reset_mask, uint32_t n_streams, float* smoothed, uint64_t smoothed_per_stream, float* traces,
+                                   uint64_t traces_per_stream, float floor_db, hipStream_t stream);
 
 // compute_derivative_spectral on the device: n = power of two >= 2, tw = exp(-2*pi*i*k/n) (k < n/2),
 // scratch = n complex values.

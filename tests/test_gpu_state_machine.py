@@ -332,6 +332,87 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
     assert bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0) is None
 
 
+@pytest.mark.parametrize("seed,N,hop,mode,param,emit_all", [(1, 1024, 256, capi.AVG_NONE, 0.0, False), (2, 4096, 512, capi.AVG_EXPONENTIAL, 0.6, False),
+                                                              (3, 2048, 300, capi.AVG_PEAK_HOLD, 12.0, True), (4, 16384, 2048, capi.AVG_NONE, 0.0, True),
+                                                              (5, 1000, 250, capi.AVG_EXPONENTIAL, 0.3, False), (6, 512, 900, capi.AVG_NONE, 0.0, False)])
+def test_ragged_spectrum_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx, oracle, seed, N, hop, mode, param, emit_all):
+    """Per-stream independence of the spectrum bank: every stream gets its own random frame counts and its own reset_audio() calls;
+    stream s must behave exactly like a single SpectrumProcessor fed the same sequence — hop counts bit-exact (frame indexing, hop >
+    window skips), the newest hop's traces (and, with emit_all_hops, every hop of a call) at the usual bars, the averaging state
+    carried per stream across calls and cleared by its own reset only."""
+    import torch
+    from test_gpu_parity import check_trace
+    rng = np.random.default_rng(100 + seed)
+    S, calls, cap = 6, 16, 3 * 256 + 77
+    cfg = SpectrumConfig(fft_size=N, hop_size=hop, averaging_mode=mode, averaging_param=param, source=capi.CH_MID, secondary_source=capi.CH_SIDE,
+                         floor_db=-100.0)
+    bank = banks.SpectrumBank(omx, cfg, S, emit_all_hops=emit_all)
+    refs = [SpectrumProcessor(oracle, cfg) for _ in range(S)]
+    feeds = [_stream_signal(rng, 80000) for _ in range(S)]
+    at = [0] * S
+    pos = capi.positions_fallback(2)
+    # two lock-step calls first: the switch to per-stream positions must carry the common state over
+    for n in (300, N + 50):
+        chunk = np.stack([f[a:a + n] for f, a in zip(feeds, at)])
+        up = bank.process_host(chunk, 2, 48000.0)
+        for s in range(S):
+            w = refs[s].process_block(AudioBlock(chunk[s].reshape(-1), 2, 48000.0))
+            assert (up is None) == (w is None)
+            at[s] += n
+    compared = 0
+    bins = N // 2 + 1
+    last = [None] * S
+    for call in range(calls):
+        frames = rng.integers(0, cap + 1, S)
+        frames[rng.integers(0, S)] = 0                       # someone always sits a call out
+        mask = (rng.random(S) < 0.15).astype(np.uint8)
+        pcm = np.zeros((S, cap, 2), np.float32)
+        for s in range(S):
+            pcm[s, :frames[s]] = feeds[s][at[s]:at[s] + frames[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
+        torch.cuda.synchronize()
+        n_hops = _dev(torch, up.d_n_hops, (S,)).cpu().numpy()
+        traces = _dev(torch, up.d_traces, (S, up.n_hops_out, 2, 2, bins), "<f4").cpu().numpy() if up.d_traces else None
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+                last[s] = None
+            # the oracle fed hop-sized pieces tells how many hops this push completes and what the snapshot is after each of them
+            snaps = []
+            if frames[s]:
+                blk = pcm[s, :frames[s]]
+                w = refs[s].process_block(AudioBlock(blk.reshape(-1), 2, 48000.0))
+                if w is not None:
+                    snaps.append(w)
+            at[s] += int(frames[s])
+            if not emit_all:
+                if snaps:
+                    assert int(n_hops[s]) >= 1, (call, s)
+                    last[s] = snaps[-1]
+                    for t in range(2):
+                        for wt in range(2):
+                            check_trace(traces[s, 0, t, wt], np.asarray(snaps[-1].traces[t][wt]))
+                    compared += 1
+                else:
+                    assert int(n_hops[s]) == 0, (call, s, int(n_hops[s]))
+                    if last[s] is not None and not mask[s]:   # a stream that produced nothing keeps its newest snapshot
+                        check_trace(traces[s, 0, 0, 0], np.asarray(last[s].traces[0][0]))
+            else:
+                assert (int(n_hops[s]) >= 1) == bool(snaps), (call, s, int(n_hops[s]))
+                if snaps:   # the last hop of the call is the oracle's snapshot
+                    h = int(n_hops[s]) - 1
+                    for t in range(2):
+                        for wt in range(2):
+                            check_trace(traces[s, h, t, wt], np.asarray(snaps[-1].traces[t][wt]))
+                    compared += 1
+    assert compared > (12 if N <= 4096 else 3)   # (long windows: few hops in 16 calls of at most 845 frames)
+    with pytest.raises(capi.OmxError):
+        bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0)
+    bank.reset_audio()
+    assert bank.process_host(np.zeros((S, 64, 2), np.float32), 2, 48000.0) is None
+
+
 def _stream_signal(rng, n):
     t = np.arange(n) / 48000.0
     f0, f1 = rng.uniform(100.0, 3000.0), rng.uniform(4000.0, 12000.0)
