@@ -422,7 +422,6 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
     const bool reassign = cfg_.use_reassignment != 0;
     const uint64_t bin_count = fft_size_ / 2 + 1;
     const uint64_t read_len = reassign ? hilbert_len_ : W;
-    const uint64_t center_offset = reassign ? (hilbert_len_ - W) / 2 : 0;
     const uint64_t pending = head_ - tail_;
     const uint64_t ready = pending >= read_len ? (pending - read_len) / hop + 1 : 0;
     const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;

@@ -36,6 +36,10 @@ struct WaveformArgs {
     uint32_t write_preview;
 };
 void launch_waveform(const WaveformArgs& a, hipStream_t stream);
+// role-per-wavefront form (waveform_roles_kernels.hip); launch_waveform picks it whenever it applies (OMX_WAVEFORM_SINGLE=1 pins
+// the one-wavefront kernel: A/B runs and the bit-identity test)
+bool waveform_roles_applicable(const WaveformArgs& a);
+void launch_waveform_roles(const WaveformArgs& a, hipStream_t stream);
 
 void waveform_config_default(omx_waveform_config* c);
 

@@ -4,82 +4,14 @@
 // 16 lanes per stream (12 live): lane = channel * 3 + band.  Every lane evaluates the L and R band filters of its
 // band (identical inputs -> bit-identical outputs across the four channel lanes) and forms its channel's value,
 // so the Mid/Side trackers need no cross-lane traffic.  Built with -ffp-contract=off.
+#include <cstdlib>
 #include <type_traits>
 
-#include "waveform.hpp"
+#include "waveform_device.hpp"
 
 namespace omx {
 
-namespace {
-__device__ __forceinline__ void kbn_add(double& sum, double& corr, double v) {  // dsp.rs:277-285
-    // (big, small) picked first: one branch's two f64 operations instead of both branches' four — same operands, same order
-    const double next = sum + v;
-    const bool sum_is_big = fabs(sum) >= fabs(v);
-    const double big = sum_is_big ? sum : v, small = sum_is_big ? v : sum;
-    corr += (big - next) + small;
-    sum = next;
-}
-// the `since refresh` pair only ever adds values >= +0.0 to a sum that starts at +0.0: |sum| >= |v| is sum >= v and
-// (big, small) = (max, min) — same operands again
-__device__ __forceinline__ void kbn_add_nonneg(double& sum, double& corr, double v) {
-    const double next = sum + v;
-    corr += (fmax(sum, v) - next) + fmin(sum, v);
-    sum = next;
-}
-// Biquad::process (dsp.rs:422-432) with the non-finite reset as selects: the lanes of a wavefront carry different channels and
-// bands, so a branch here is a divergent one per element and sample
-__device__ __forceinline__ float biquad_step(const BiquadCoef& c, float (&z)[2], float x) {
-    const float out = c.b[0] * x + z[0];
-    const float n0 = c.b[1] * x - c.a[0] * out + z[1];
-    const float n1 = c.b[2] * x - c.a[1] * out;
-    const bool ok = isfinite(out);
-    z[0] = ok ? n0 : 0.0f;
-    z[1] = ok ? n1 : 0.0f;
-    return ok ? out : 0.0f;
-}
-__device__ __forceinline__ float power_to_db_f(float power, float floor) {  // level.rs:28-34
-    return power > 0.0f ? fmaxf(logf(power) * 4.3429448f, floor) : floor;
-}
-struct Window {  // one WindowedMeans window of one value
-    double s0, s1, c0, c1;
-    uint32_t cap, refresh, unfilled;
-    // dsp.rs:335-352 for one (window, value).  CHECK = false: the caller has established that CompensatedPair::refresh cannot fire
-    // in this batch (refresh + batch < cap), the common case, and gets straight-line code
-    template <bool CHECK>
-    __device__ __forceinline__ void push(double v, double old) {
-        kbn_add(s0, c0, v);
-        kbn_add_nonneg(s1, c1, v);  // v is |band value| x gain or a squared band value, NaN / inf already zeroed (:108-121)
-        kbn_add(s0, c0, -old);  // old == 0.0 until the window is full
-        unfilled -= unfilled != 0u ? 1u : 0u;
-        ++refresh;
-        if constexpr (CHECK) {
-            if (refresh == cap) {
-                s0 = s1;
-                s1 = 0.0;
-                c0 = c1;
-                c1 = 0.0;
-                refresh = 0;
-            }
-        }
-    }
-    __device__ __forceinline__ double mean(uint64_t pushes, uint32_t ring_len) const {  // dsp.rs:367-370
-        const uint64_t count = max(min(min(pushes, (uint64_t)ring_len), (uint64_t)cap), (uint64_t)1);
-        return (s0 + c0) / (double)count;
-    }
-    __device__ __forceinline__ void init(const double (&st)[4], uint32_t cap_, uint64_t pushes) {
-        s0 = st[0]; s1 = st[1]; c0 = st[2]; c1 = st[3];
-        cap = cap_;
-        refresh = (uint32_t)(pushes % cap_);
-        unfilled = pushes >= cap_ ? 0u : (uint32_t)(cap_ - pushes);
-    }
-    __device__ __forceinline__ void save(double (&st)[4]) const { st[0] = s0; st[1] = s1; st[2] = c0; st[3] = c1; }
-};
-__device__ __forceinline__ uint32_t expiring_index(uint32_t head, uint32_t k, uint32_t len, uint32_t cap) {
-    uint32_t pos = head + k;
-    pos = pos >= len ? pos - len : pos;
-    return pos >= cap ? pos - cap : pos + len - cap;
-}
-}  // namespace
+using namespace wf;
 
 // ANALYZE / HISTORY: the configuration's band analysis and RMS history, compile-time so that a frame's code is one basic block
 template <int B, bool ANALYZE, bool HISTORY>
@@ -104,7 +36,26 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     uint64_t pushes = a.pushes;
     float* cring = a.color_ring + (s < a.n_streams ? gid : 0u);  // lanes past the last stream read column 0 (discarded), store nothing
     float* hring = a.hist_ring + (s < a.n_streams ? gid : 0u);
-    const float* pcm = a.pcm + (uint64_t)(live ? s : 0) * a.frames * a.fmt.channels;
+    const float* pcm = a.pcm + (uint64_t)(s < a.n_streams ? s : 0) * a.frames * a.fmt.channels;
+    // PCM goes through LDS, kStage frames at a time, loaded by the stream's 16 lanes in one burst: per-frame global loads would
+    // pay the memory latency — PCIe for a single-stream handle, whose block sits in pinned host memory — once per batch
+    constexpr uint32_t kStage = 128;
+    __shared__ float stage[4][kStage * OMX_MAX_CHANNELS];
+    float* my_stage = stage[threadIdx.x >> 4];
+    auto refill = [&](uint64_t f) {
+        const uint32_t n = (uint32_t)min((uint64_t)kStage, a.frames - f) * a.fmt.channels;
+        const float* src = pcm + f * a.fmt.channels;
+        const uint32_t l16 = threadIdx.x & 15;
+        for (uint32_t e0 = 0; e0 < n; e0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[min(e0 + (uint32_t)j * 16 + l16, n - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (e0 + (uint32_t)j * 16 + l16 < n) my_stage[e0 + (uint32_t)j * 16 + l16] = v[j];
+        }
+        __syncthreads();  // one wavefront per workgroup: orders the LDS writes before the other lanes' reads
+    };
     double phase = a.column_phase;
     uint64_t col = 0;
     const bool minmax_lane = live && band == 0;
@@ -137,24 +88,70 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         dst->rms_db[1][band] = rms1;
     };
 
-    // hp_lo runs on every lane and is selected by band (a divergent `if (use_a)` costs the other bands the same instructions
-    // anyway); its state only matters on the mid-band lanes
-    for (uint64_t f0 = 0; f0 < a.frames; f0 += B) {
-        const uint32_t nb = (uint32_t)min((uint64_t)B, a.frames - f0);
-        float lr[B][2];
-        float old_c[B], old_h0[B], old_h1[B];
+    // The loads of batch i + 1 (PCM, the three expiring values per frame) are issued before batch i is computed: a batch's own
+    // loads would expose the memory latency 1 ... 2 us — PCM of a single-stream handle sits in pinned host memory — once per
+    // B frames.  Batch i + 1 expires slots that batch i does not store (windows >= 2 B samples long, launch_waveform).
+    float nold_c[B], nold_h0[B], nold_h1[B];
+    uint32_t fetch_head_c = head_c, fetch_head_h = head_h;
+    // Ring stores trail the pushes by one batch: issued right after a batch's pushes they would be the newest memory operations
+    // when the next batch waits for its (older) loads, and the wait would cover their round trip too.
+    float pend_c[B] = {}, pend_h[B] = {};
+    uint32_t store_head_c = head_c, store_head_h = head_h;
+    auto flush_stores = [&](uint32_t n) {
+        if constexpr (ANALYZE) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                if ((uint32_t)k < n) {  // n == B except after the call's last batch
+                    uint32_t slot = store_head_c + (uint32_t)k;
+                    slot = slot >= a.color_len ? slot - a.color_len : slot;
+                    if (analyze) cring[(uint64_t)slot * row] = pend_c[k];
+                    if constexpr (HISTORY) {
+                        uint32_t hs = store_head_h + (uint32_t)k;
+                        hs = hs >= a.slow_len ? hs - a.slow_len : hs;
+                        if (history) hring[(uint64_t)hs * row] = pend_h[k];
+                    }
+                }
+            }
+            store_head_c = (store_head_c + n) % a.color_len;
+            store_head_h = (store_head_h + n) % a.slow_len;
+        }
+    };
+    auto fetch = [&]() {
         // every load of the batch is unconditional (clamped frame index, always-valid ring slots; non-live lanes point at
         // stream 0 / their own padding column): a conditional load waits for its data on the spot and serialises the batch.
         // What must not be used is discarded where it is consumed.
 #pragma unroll
         for (int k = 0; k < B; ++k) {
+            if constexpr (ANALYZE) {
+                nold_c[k] = cring[(uint64_t)expiring_index(fetch_head_c, k, a.color_len, a.color_len) * row];
+                if constexpr (HISTORY) {
+                    nold_h0[k] = hring[(uint64_t)expiring_index(fetch_head_h, k, a.slow_len, a.color_len) * row];
+                    nold_h1[k] = hring[(uint64_t)expiring_index(fetch_head_h, k, a.slow_len, a.slow_len) * row];
+                }
+            }
+        }
+        if constexpr (ANALYZE) {  // the ring heads after this batch (a whole batch: a short one is the call's last)
+            fetch_head_c = (fetch_head_c + (uint32_t)B) % a.color_len;
+            fetch_head_h = (fetch_head_h + (uint32_t)B) % a.slow_len;
+        }
+    };
+    if (B > 1 && a.frames) fetch();  // B == 1 serves windows shorter than 16 samples: each frame's loads follow the previous frame's stores
+    // hp_lo runs on every lane and is selected by band (a divergent `if (use_a)` costs the other bands the same instructions
+    // anyway); its state only matters on the mid-band lanes
+    for (uint64_t f0 = 0; f0 < a.frames; f0 += B) {
+        const uint32_t nb = (uint32_t)min((uint64_t)B, a.frames - f0);
+        if (B == 1) fetch();
+        if (f0 % kStage == 0) refill(f0);
+        float lr[B][2];
+        float old_c[B] = {}, old_h0[B] = {}, old_h1[B] = {};
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
             const uint32_t kc = (uint32_t)k < nb ? (uint32_t)k : nb - 1u;
-            const float* frame = pcm + (f0 + kc) * a.fmt.channels;
+            const float* frame = my_stage + ((uint32_t)(f0 % kStage) + kc) * a.fmt.channels;
             float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
             if (two_channels) {  // uniform; the common shape without a runtime trip count
-                const float2 x = *reinterpret_cast<const float2*>(frame);
-                left = 0.0f + x.x * a.fmt.m[0][0] + x.y * a.fmt.m[1][0];
-                right = 0.0f + x.x * a.fmt.m[0][1] + x.y * a.fmt.m[1][1];
+                left = 0.0f + frame[0] * a.fmt.m[0][0] + frame[1] * a.fmt.m[1][0];
+                right = 0.0f + frame[0] * a.fmt.m[0][1] + frame[1] * a.fmt.m[1][1];
             } else {
                 for (uint32_t c = 0; c < a.fmt.channels; ++c) {
                     const float v = frame[c];
@@ -164,10 +161,15 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
             }
             lr[k][0] = left;
             lr[k][1] = right;
-            // expiring values, read before this batch's stores (windows >= B samples long)
-            old_c[k] = cring[(uint64_t)expiring_index(head_c, k, a.color_len, a.color_len) * row];
-            old_h0[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.color_len) * row];
-            old_h1[k] = hring[(uint64_t)expiring_index(head_h, k, a.slow_len, a.slow_len) * row];
+            if constexpr (ANALYZE) old_c[k] = nold_c[k];
+            if constexpr (HISTORY) {
+                old_h0[k] = nold_h0[k];
+                old_h1[k] = nold_h1[k];
+            }
+        }
+        if constexpr (B > 1) {
+            if (f0) flush_stores((uint32_t)B);  // the previous batch's ring values, after the wait for this batch's loads (above) and not before it
+            if (f0 + B < a.frames) fetch();
         }
         // samples of this batch that precede a window's first expiring value (dsp.rs:336-338), fixed before the pushes move them
         const uint32_t unf_c = wc.unfilled, unf_h0 = wh0.unfilled, unf_h1 = wh1.unfilled;
@@ -195,14 +197,14 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                     float cv = fabsf(v) * gain;
                     cv = isfinite(cv) ? cv : 0.0f;
                     wc.template push<CHECK>((double)cv, (uint32_t)k >= unf_c ? (double)old_c[k] : 0.0);
-                    if (analyze) cring[(uint64_t)head_c * row] = cv;
+                    pend_c[k] = cv;
                     head_c = head_c + 1 == a.color_len ? 0 : head_c + 1;
                     if constexpr (HISTORY) {
                         float pw = v * v;
                         pw = isfinite(pw) ? pw : 0.0f;
                         wh0.template push<CHECK>((double)pw, (uint32_t)k >= unf_h0 ? (double)old_h0[k] : 0.0);
                         wh1.template push<CHECK>((double)pw, (uint32_t)k >= unf_h1 ? (double)old_h1[k] : 0.0);
-                        if (history) hring[(uint64_t)head_h * row] = pw;
+                        pend_h[k] = pw;
                         head_h = head_h + 1 == a.slow_len ? 0 : head_h + 1;
                     }
                     ++pushes;
@@ -247,6 +249,10 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         if (nb == (uint32_t)B && !emits && !may_refresh) samples(F{}, F{}, F{});  // the straight-line batch
         else if (nb == (uint32_t)B && !emits) samples(T{}, F{}, F{});
         else samples(T{}, T{}, T{});
+        if constexpr (B == 1) flush_stores(1u);  // short windows: the next frame may expire this very slot
+    }
+    if constexpr (B > 1) {
+        if (a.frames) flush_stores((uint32_t)(a.frames - (a.frames - 1) / B * B));  // the last batch, whole or short
     }
     // BandFilter::flush_denormals once per block (:321-323)
     if (analyze) {
@@ -266,6 +272,11 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
 
 void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
     if (a.n_streams == 0) return;
+    static const bool pin_single = std::getenv("OMX_WAVEFORM_SINGLE") != nullptr;
+    if (!pin_single && waveform_roles_applicable(a)) {
+        launch_waveform_roles(a, stream);
+        return;
+    }
     const uint32_t threads = a.n_streams * 16;
     const dim3 grid((threads + 63) / 64);
     const bool analyze = a.analyze != 0, history = analyze && a.track_history != 0;
@@ -275,7 +286,7 @@ void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
         else if (analyze) hipLaunchKernelGGL((waveform_kernel<B, true, false>), grid, dim3(64), 0, stream, a);
         else hipLaunchKernelGGL((waveform_kernel<B, false, false>), grid, dim3(64), 0, stream, a);
     };
-    if (a.color_len >= 8 && a.slow_len >= 8) launch(std::integral_constant<int, 8>{});
+    if (a.color_len >= 32 && a.slow_len >= 32) launch(std::integral_constant<int, 8>{});
     else launch(std::integral_constant<int, 1>{});
 }
 
