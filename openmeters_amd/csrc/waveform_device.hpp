@@ -68,6 +68,39 @@ struct Window {  // one WindowedMeans window of one value
     }
     __device__ __forceinline__ void save(double (&st)[4]) const { st[0] = s0; st[1] = s1; st[2] = c0; st[3] = c1; }
 };
+// derived_frame (waveform/processor.rs:123-125) for a lane's channel: Left, Right, Mid = (l + r) / 2, Side = (l - r) / 2.  The
+// selection is spelled with per-lane bit masks: as nested `ch == 0 ? ... :` the compiler turns it into a switch, i.e. three levels
+// of divergent branches per frame (saveexec / cbranch / restore around one or two instructions each), and the frame's code falls
+// apart into a dozen basic blocks.  Pure selection of the same four candidates: bit-identical.
+struct ChannelPick {
+    uint32_t m_right, m_side, m_pair;  // all ones: take right over left / side over mid / the (mid, side) pair over (left, right)
+    __device__ __forceinline__ explicit ChannelPick(uint32_t ch) : m_right(ch == 1 ? ~0u : 0u), m_side(ch == 3 ? ~0u : 0u), m_pair(ch >= 2 ? ~0u : 0u) {
+        // opaque to the optimiser: with visible 0 / ~0 values it rewrites the bit selects as compare + v_cndmask pairs (ten instructions
+        // per pick instead of seven)
+        asm volatile("" : "+v"(m_right), "+v"(m_side), "+v"(m_pair));
+    }
+    static __device__ __forceinline__ uint32_t bits(uint32_t mask, uint32_t if_set, uint32_t if_clear) {  // v_bfi_b32
+        return (mask & if_set) | (~mask & if_clear);
+    }
+    __device__ __forceinline__ float operator()(float left, float right) const {
+        const float mid = (left + right) * 0.5f, side = (left - right) * 0.5f;
+        const uint32_t lr = bits(m_right, __float_as_uint(right), __float_as_uint(left));
+        const uint32_t ms = bits(m_side, __float_as_uint(side), __float_as_uint(mid));
+        return __uint_as_float(bits(m_pair, ms, lr));
+    }
+};
+// fminf / fmaxf of two values that are known not to be NaN (the min/max column state only ever takes finite samples): the library
+// forms canonicalise both operands first (v_max_f32 x, x, x), three instructions per call
+__device__ __forceinline__ float min_finite(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_finite(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t expiring_index(uint32_t head, uint32_t k, uint32_t len, uint32_t cap) {
     uint32_t pos = head + k;
     pos = pos >= len ? pos - len : pos;

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     const bool analyze = a.analyze != 0 && live, history = a.track_history != 0 && analyze;
     const BiquadCoef cb = band == 0 ? a.lp_lo : (band == 1 ? a.lp_hi : a.hp_hi);
     const bool use_a = band == 1;
+    const ChannelPick pick(ch);
     const float gain = band == 0 ? 1.0f : (band == 1 ? 0.7f : 2.0f);  // BAND_COLOR_GAINS (:22)
     Window wc, wh0, wh1;
     wc.init(st.color, a.color_len, a.pushes);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                 }
                 const float left = lr[k][0], right = lr[k][1];
                 // derived_frame (:123-125): Left, Right, Mid, Side
-                const float derived = ch == 0 ? left : (ch == 1 ? right : (ch == 2 ? (left + right) * 0.5f : (left - right) * 0.5f));
+                const float derived = pick(left, right);
                 const bool fin = isfinite(derived);
                 if constexpr (ANALYZE) {  // :258-272 (non-live lanes compute on a neighbour's frames and store nothing)
                     float xl = isfinite(left) ? left : 0.0f, xr = isfinite(right) ? right : 0.0f;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                     xl = use_a ? hl : xl;
                     xr = use_a ? hr : xr;
                     const float bl = biquad_step(cb, st.zb[0], xl), br = biquad_step(cb, st.zb[1], xr);
-                    float v = ch == 0 ? bl : (ch == 1 ? br : (ch == 2 ? (bl + br) * 0.5f : (bl - br) * 0.5f));
+                    float v = pick(bl, br);
                     v = fin ? v : 0.0f;
                     // BandTracker::process (:108-121)
                     float cv = fabsf(v) * gain;

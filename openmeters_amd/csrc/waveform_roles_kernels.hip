@@ -3,18 +3,20 @@
 // streams per workgroup), same operations on every value in the same order — the results are bit-identical — but the work of
 // one lane is spread over the wavefronts of a workgroup, each with its own short instruction stream:
 //
-//   wavefront 0  memory     every global access of the batch loop: PCM -> LDS (kStage frames at a time), the expiring ring values
-//                           of the next batch -> LDS, the previous batch's new ring values LDS -> rings
-//   wavefront 1  front      stereo fold, band filters, channel value -> |v| gain and v^2 into an LDS batch; min/max column state
-//                           machine, fractional column phase, min / max fields of the columns
-//   wavefront 2  colour     the colour window of every lane: KBN pair, refresh, its field of the columns
-//   wavefront 3, 4          the fast / slow RMS history windows (HISTORY only)
+//   wavefront 0     memory   every global access of the frame loop: PCM -> LDS (kStage frames at a time), the expiring ring values of a
+//                           round -> LDS, the new ring values of an earlier round LDS -> rings
+//   wavefront 1, 2  filters  the left / right half of the band split: stereo fold of its side, HP_low, band filter -> LDS
+//   wavefront 3     mix      one round behind the filters: channel value from the two filtered sides -> |v| gain and v^2 into LDS;
+//                           min/max column state machine, fractional column phase, min / max fields of the columns
+//   wavefront 4     colour   two rounds behind: the colour window of every lane (KBN pair, refresh), its field of the columns
+//   wavefront 5, 6           the fast / slow RMS history windows (HISTORY only)
 //
 // Why: a lone wavefront that issues its own loads meets an `s_waitcnt vmcnt(0)` somewhere in every batch (the counter is in-order
 // and the compiler's bookkeeping across the batch loop's control flow is conservative), i.e. one exposed memory round trip per
-// eight frames on top of ~160 dependent VALU instructions per frame: 165 us for a 256-frame block.  Here the wavefronts that
-// compute never wait for memory (their only global accesses are column stores), the memory wavefront's round trip overlaps the
-// others' arithmetic, and the longest instruction stream per frame is the front's.  Rounds are separated by one LDS barrier.
+// eight frames, on top of ~160 mostly dependent VALU instructions per frame: 165 us for a 256-frame block.  Here the wavefronts
+// that compute never wait for memory (their only global accesses are column stores), the memory wavefront's round trip overlaps
+// the others' arithmetic, and the longest instruction stream per frame is 35 ... 45 instructions.  Rounds (R frames) are
+// separated by one LDS barrier; data of round d is filtered in round d, mixed in d + 1, windowed and stored in d + 2.
 #include <type_traits>
 
 #include "waveform_device.hpp"
@@ -26,22 +28,39 @@ using namespace wf;
 namespace {
 // Workgroup barrier for data handed over through LDS: waits for this wavefront's LDS traffic, not for its outstanding global
 // stores / loads (__syncthreads would add vmcnt(0)).
+#ifdef OMX_WF_PHASES
+// per-wavefront timing of the rounds (build this file with -DOMX_WF_PHASES; the latency harness then prints one line per wavefront)
+#define WF_T0 const long long wf_t0 = clock64(); long long wf_wait = 0;
+__device__ __forceinline__ void lds_barrier_timed(long long& acc) {
+    const long long t = clock64();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    acc += clock64() - t;
+}
+#define lds_barrier() lds_barrier_timed(wf_wait)
+#define WF_REPORT(name) if (lane == 0 && blockIdx.x == 0 && a.pushes == 256 * 300) printf("%s wave %u: total %lld barrier-wait %lld\n", name, wave, (long long)(clock64() - wf_t0), wf_wait);
+#else
+#define WF_T0
+#define WF_REPORT(name)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 constexpr uint32_t kStage = 64;  // frames of PCM per LDS refill
 }  // namespace
 
 // B frames per straight-line batch, NSUB batches per round (R = B * NSUB frames between two barriers): the memory wavefront's round
 // trip — about 2.5 us on an otherwise idle device — has to fit under the front's R frames
 template <int B, int NSUB, bool HISTORY>
-__global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(WaveformArgs a) {
+__global__ __launch_bounds__(HISTORY ? 448 : 320) void waveform_roles_kernel(WaveformArgs a) {
     constexpr int R = B * NSUB;
     constexpr int NW = HISTORY ? 3 : 1, NV = HISTORY ? 2 : 1;
     static_assert(kStage % R == 0, "a round never straddles two PCM refills");
     __shared__ float stage[2][4][kStage * OMX_MAX_CHANNELS];  // PCM, two refills in flight: [parity][stream of the group][frame][channel]
     __shared__ float olds[2][NW][R][64];                       // expiring values [round parity][window][frame][lane]
     __shared__ float vals[2][NV][R][64];                       // |v| gain, v^2 [round parity][which][frame][lane]
+    __shared__ float sides[2][2][R][64];                       // band-filtered left, right [round parity][side][frame][lane]
+    __shared__ float folded[2][2][R][64];                      // the folded left, right themselves (the mix derives the channel value)
     __shared__ uint32_t flags[2][R];                           // 1 + kept column index when a column ends at the frame, else 0
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    WF_T0
     const uint32_t gid = blockIdx.x * 64 + lane;  // stream * 16 + lane of the stream
     const uint32_t s = gid >> 4, ln = gid & 15;
     const bool in_bank = s < a.n_streams, live = in_bank && ln < 12;
@@ -50,6 +69,8 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
     const uint64_t n_rounds = (a.frames + R - 1) / R;
     const uint32_t tail = (uint32_t)(a.frames - (n_rounds - 1) * R);  // frames of the last round
     const uint64_t kept_cols = a.n_emit - a.first_kept;
+    const uint64_t last_iter = n_rounds + 1;  // rounds 0 ... n_rounds + 1: the windows run two behind the filters
+    auto frames_of = [&](uint64_t d) { return d + 1 == n_rounds ? tail : (uint32_t)R; };
 
     if (wave == 0) {
         // ---------------------------------------------------------------- memory wavefront
@@ -75,11 +96,12 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
         };
         if (a.frames) refill(0);
         lds_barrier();  // round -1
-        for (uint64_t r = 0; r <= n_rounds; ++r) {
-            if (r < n_rounds) {
-                // the expiring values of round r, for the windows' round r + 1.  The slots are those of round r itself (colour,
-                // slow: cap == ring length) or `color_len` pushes back (fast history): written at least two rounds ago, or —
-                // a window that is not full yet — never used.  Every load is unconditional (always-valid slots).
+        for (uint64_t r = 0; r <= last_iter; ++r) {
+            if (r >= 1 && r <= n_rounds) {
+                // the expiring values of data round d = r - 1, for the windows' round r + 1.  The slots are those of round d itself
+                // (colour, slow: cap == ring length) or `color_len` pushes back (fast history): stored in an earlier round than
+                // this one (cap >= 2 R), or — a window that is not full yet — never used.  Every load is unconditional.
+                const uint64_t d = r - 1;
                 float oc[R], oh0[HISTORY ? R : 1], oh1[HISTORY ? R : 1];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -91,21 +113,22 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
                 }
                 head_c = (head_c + (uint32_t)R) % a.color_len;
                 head_h = (head_h + (uint32_t)R) % a.slow_len;
-                // PCM of the next refill, if round r + 1 is its first (the front reads the other parity meanwhile)
-                const uint64_t f_next = (r + 1) * R;
-                if (f_next % kStage == 0 && f_next < a.frames) refill(f_next);
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    olds[r & 1][0][k][lane] = oc[k];
+                    olds[d & 1][0][k][lane] = oc[k];
                     if constexpr (HISTORY) {
-                        olds[r & 1][1][k][lane] = oh0[k];
-                        olds[r & 1][2][k][lane] = oh1[k];
+                        olds[d & 1][1][k][lane] = oh0[k];
+                        olds[d & 1][2][k][lane] = oh1[k];
                     }
                 }
             }
-            if (r >= 1) {  // the ring values of round r - 1 (the front wrote them in round r - 1), after this round's loads
-                const uint64_t b = r - 1;
-                const uint32_t nr = b + 1 == n_rounds ? tail : (uint32_t)R;
+            {  // PCM of the next refill, if round r + 1 is its first (filters and mix read the other parity meanwhile)
+                const uint64_t f_next = (r + 1) * R;
+                if (f_next % kStage == 0 && f_next < a.frames) refill(f_next);
+            }
+            if (r >= 2) {  // the ring values of data round r - 2 (the mix wrote them in round r - 1), after this round's loads
+                const uint64_t b = r - 2;
+                const uint32_t nr = frames_of(b);
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if ((uint32_t)k < nr && live) {
@@ -124,26 +147,91 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
             }
             lds_barrier();
         }
+        WF_REPORT("memory")
         return;
     }
 
-    if (wave == 1) {
-        // ---------------------------------------------------------------- front wavefront
-        float za[2][2] = {}, zb[2][2] = {};
+    if (wave == 1 || wave == 2) {
+        // ---------------------------------------------------------------- filter wavefronts: left (1), right (2)
+        const uint32_t side = wave - 1;  // wave-uniform
+        float za[2] = {0.0f, 0.0f}, zb[2] = {0.0f, 0.0f};
+        if (live) {
+            const WaveLaneState& st = a.state[gid];
+            za[0] = st.za[side][0]; za[1] = st.za[side][1];
+            zb[0] = st.zb[side][0]; zb[1] = st.zb[side][1];
+        }
+        const BiquadCoef cb = band == 0 ? a.lp_lo : (band == 1 ? a.lp_hi : a.hp_hi);
+        const bool use_a = band == 1;
+        const bool two_channels = a.fmt.channels == 2;
+        const float m0 = a.fmt.m[0][side], m1 = a.fmt.m[1][side];
+        lds_barrier();  // round -1: the first PCM refill
+        for (uint64_t r = 0; r <= last_iter; ++r) {
+            const uint32_t nr = r < n_rounds ? frames_of(r) : 0u;
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < nr; k0 += B) {  // the round's batches
+                const uint64_t f0 = r * R + k0;
+                const uint32_t nb = min(nr - k0, (uint32_t)B);
+                const float* chunk = stage[(f0 / kStage) & 1][lane >> 4] + (uint32_t)(f0 % kStage) * a.fmt.channels;
+                float x[B];
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const uint32_t kc = (uint32_t)k < nb ? (uint32_t)k : nb - 1u;
+                    const float* frame = chunk + kc * a.fmt.channels;
+                    float folded = 0.0f;  // dsp.rs:223-249 stereo fold, this side's column of the matrix
+                    if (two_channels) {  // uniform; the common shape without a runtime trip count
+                        folded = 0.0f + frame[0] * m0 + frame[1] * m1;
+                    } else {
+                        for (uint32_t c = 0; c < a.fmt.channels; ++c) folded = folded + frame[c] * a.fmt.m[c][side];
+                    }
+                    x[k] = folded;
+                }
+                auto samples = [&](auto tail_c) {
+                    constexpr bool TAIL = decltype(tail_c)::value;
+#pragma unroll
+                    for (int k = 0; k < B; ++k) {
+                        if constexpr (TAIL) {
+                            if ((uint32_t)k >= nb) break;
+                        }
+                        // :258-272 (non-live lanes compute on a neighbour's frames; nothing of theirs is stored)
+                        folded[r & 1][side][k0 + k][lane] = x[k];
+                        float xs = isfinite(x[k]) ? x[k] : 0.0f;
+                        // mid = LP_high(HP_low(x))  (CASCADE_HIGH = false: the high band takes the raw sample)
+                        const float h = biquad_step(a.hp_lo, za, xs);
+                        xs = use_a ? h : xs;
+                        sides[r & 1][side][k0 + k][lane] = biquad_step(cb, zb, xs);
+                    }
+                };
+                if (nb == (uint32_t)B) samples(std::false_type{});
+                else samples(std::true_type{});
+            }
+            lds_barrier();
+        }
+        WF_REPORT("filter")
+        // BandFilter::flush_denormals once per block (:321-323)
+        if (fabsf(za[0]) < 1.0e-20f) za[0] = 0.0f;
+        if (fabsf(za[1]) < 1.0e-20f) za[1] = 0.0f;
+        if (fabsf(zb[0]) < 1.0e-20f) zb[0] = 0.0f;
+        if (fabsf(zb[1]) < 1.0e-20f) zb[1] = 0.0f;
+        if (live) {
+            WaveLaneState& st = a.state[gid];
+            st.za[side][0] = za[0]; st.za[side][1] = za[1];
+            st.zb[side][0] = zb[0]; st.zb[side][1] = zb[1];
+        }
+        return;
+    }
+
+    if (wave == 3) {
+        // ---------------------------------------------------------------- mix wavefront (data round d = r - 1)
         float cur_min = 0.0f, cur_max = 0.0f, cur_last = 0.0f, last_sample = 0.0f;
         uint32_t cur_some = 0, cur_has_last = 0, last_valid = 0;
         if (live) {
             const WaveLaneState& st = a.state[gid];
-            za[0][0] = st.za[0][0]; za[0][1] = st.za[0][1]; za[1][0] = st.za[1][0]; za[1][1] = st.za[1][1];
-            zb[0][0] = st.zb[0][0]; zb[0][1] = st.zb[0][1]; zb[1][0] = st.zb[1][0]; zb[1][1] = st.zb[1][1];
             cur_min = st.cur_min; cur_max = st.cur_max; cur_last = st.cur_last; last_sample = st.last_sample;
             cur_some = st.cur_some; cur_has_last = st.cur_has_last; last_valid = st.last_valid;
         }
-        const BiquadCoef cb = band == 0 ? a.lp_lo : (band == 1 ? a.lp_hi : a.hp_hi);
-        const bool use_a = band == 1;
         const float gain = band == 0 ? 1.0f : (band == 1 ? 0.7f : 2.0f);  // BAND_COLOR_GAINS (:22)
+        const ChannelPick pick(ch);
         const bool minmax_lane = live && band == 0;
-        const bool two_channels = a.fmt.channels == 2;
         double phase = a.column_phase;
         uint64_t col = 0;
         auto write_minmax = [&](omx_wave_column* dst) {  // column_for (:213-235), the min / max fields
@@ -159,32 +247,20 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
             dst->min = mn;
             dst->max = mx;
         };
-        lds_barrier();  // round -1: the first PCM refill
-        for (uint64_t r = 0; r <= n_rounds; ++r) {
-            const uint32_t nr = r < n_rounds ? (r + 1 == n_rounds ? tail : (uint32_t)R) : 0u;
+        lds_barrier();  // round -1
+        for (uint64_t r = 0; r <= last_iter; ++r) {
+            const uint64_t d = r - 1;
+            const uint32_t nr = (r >= 1 && d < n_rounds) ? frames_of(d) : 0u;
 #pragma unroll 1
             for (uint32_t k0 = 0; k0 < nr; k0 += B) {  // the round's batches
-                const uint64_t f0 = r * R + k0;
                 const uint32_t nb = min(nr - k0, (uint32_t)B);
-                const float* chunk = stage[(f0 / kStage) & 1][lane >> 4] + (uint32_t)(f0 % kStage) * a.fmt.channels;
-                float lr[B][2];
+                float lr[B][2], fl[B], fr[B];
 #pragma unroll
-                for (int k = 0; k < B; ++k) {
-                    const uint32_t kc = (uint32_t)k < nb ? (uint32_t)k : nb - 1u;
-                    const float* frame = chunk + kc * a.fmt.channels;
-                    float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
-                    if (two_channels) {  // uniform; the common shape without a runtime trip count
-                        left = 0.0f + frame[0] * a.fmt.m[0][0] + frame[1] * a.fmt.m[1][0];
-                        right = 0.0f + frame[0] * a.fmt.m[0][1] + frame[1] * a.fmt.m[1][1];
-                    } else {
-                        for (uint32_t c = 0; c < a.fmt.channels; ++c) {
-                            const float v = frame[c];
-                            left = left + v * a.fmt.m[c][0];
-                            right = right + v * a.fmt.m[c][1];
-                        }
-                    }
-                    lr[k][0] = left;
-                    lr[k][1] = right;
+                for (int k = 0; k < B; ++k) {  // (frames past a short batch's end: stale LDS, never used)
+                    lr[k][0] = folded[d & 1][0][k0 + k][lane];
+                    lr[k][1] = folded[d & 1][1][k0 + k][lane];
+                    fl[k] = sides[d & 1][0][k0 + k][lane];
+                    fr[k] = sides[d & 1][1][k0 + k][lane];
                 }
                 auto samples = [&](auto tail_c, auto emit_c) {
                     constexpr bool TAIL = decltype(tail_c)::value, EMIT = decltype(emit_c)::value;
@@ -195,30 +271,24 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
                         }
                         const float left = lr[k][0], right = lr[k][1];
                         // derived_frame (:123-125): Left, Right, Mid, Side
-                        const float derived = ch == 0 ? left : (ch == 1 ? right : (ch == 2 ? (left + right) * 0.5f : (left - right) * 0.5f));
+                        const float derived = pick(left, right);
                         const bool fin = isfinite(derived);
-                        // :258-272 (non-live lanes compute on a neighbour's frames; nothing of theirs is stored)
-                        float xl = isfinite(left) ? left : 0.0f, xr = isfinite(right) ? right : 0.0f;
-                        // mid = LP_high(HP_low(x))  (CASCADE_HIGH = false: the high band takes the raw sample)
-                        const float hl = biquad_step(a.hp_lo, za[0], xl), hr = biquad_step(a.hp_lo, za[1], xr);
-                        xl = use_a ? hl : xl;
-                        xr = use_a ? hr : xr;
-                        const float bl = biquad_step(cb, zb[0], xl), br = biquad_step(cb, zb[1], xr);
-                        float v = ch == 0 ? bl : (ch == 1 ? br : (ch == 2 ? (bl + br) * 0.5f : (bl - br) * 0.5f));
+                        const float bl = fl[k], br = fr[k];
+                        float v = pick(bl, br);
                         v = fin ? v : 0.0f;
                         // BandTracker::process (:108-121)
                         float cv = fabsf(v) * gain;
                         cv = isfinite(cv) ? cv : 0.0f;
-                        vals[r & 1][0][k0 + k][lane] = cv;
+                        vals[d & 1][0][k0 + k][lane] = cv;
                         if constexpr (HISTORY) {
                             float pw = v * v;
                             pw = isfinite(pw) ? pw : 0.0f;
-                            vals[r & 1][1][k0 + k][lane] = pw;
+                            vals[d & 1][1][k0 + k][lane] = pw;
                         }
                         // ingest_derived (:275-291), as selects
                         const bool some = cur_some != 0;
-                        cur_min = fin ? (some ? fminf(cur_min, derived) : derived) : cur_min;
-                        cur_max = fin ? (some ? fmaxf(cur_max, derived) : derived) : cur_max;
+                        cur_min = fin ? (some ? min_finite(cur_min, derived) : derived) : cur_min;
+                        cur_max = fin ? (some ? max_finite(cur_max, derived) : derived) : cur_max;
                         cur_last = fin ? derived : cur_last;
                         cur_has_last = fin ? 1 : (some ? 0 : cur_has_last);
                         cur_some = fin ? 1 : cur_some;
@@ -240,7 +310,7 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
                             ++col;
                             phase -= 1.0;
                         }
-                        if (lane == 0) flags[r & 1][k0 + k] = flag;
+                        if (lane == 0) flags[d & 1][k0 + k] = flag;
                     }
                 };
                 // does a column end inside this batch?  Replay the f64 phase additions (they are the reference's, bit for bit)
@@ -256,7 +326,7 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
                 using T = std::true_type;
                 using F = std::false_type;
                 if (nb == (uint32_t)B && !emits) {
-                    if (lane < (uint32_t)B) flags[r & 1][k0 + lane] = 0u;
+                    if (lane < (uint32_t)B) flags[d & 1][k0 + lane] = 0u;
                     samples(F{}, F{});  // the straight-line batch
                 } else {
                     samples(T{}, T{});
@@ -264,24 +334,18 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
             }
             lds_barrier();
         }
-        // BandFilter::flush_denormals once per block (:321-323)
-        float* z[8] = {&za[0][0], &za[0][1], &za[1][0], &za[1][1], &zb[0][0], &zb[0][1], &zb[1][0], &zb[1][1]};
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (fabsf(*z[i]) < 1.0e-20f) *z[i] = 0.0f;
+        WF_REPORT("mix")
         if (minmax_lane && a.write_preview) write_minmax(a.preview + (uint64_t)s * 4 + ch);  // preview (:300-306)
         if (live) {
             WaveLaneState& st = a.state[gid];
-            st.za[0][0] = za[0][0]; st.za[0][1] = za[0][1]; st.za[1][0] = za[1][0]; st.za[1][1] = za[1][1];
-            st.zb[0][0] = zb[0][0]; st.zb[0][1] = zb[0][1]; st.zb[1][0] = zb[1][0]; st.zb[1][1] = zb[1][1];
             st.cur_min = cur_min; st.cur_max = cur_max; st.cur_last = cur_last; st.last_sample = last_sample;
             st.cur_some = cur_some; st.cur_has_last = cur_has_last; st.last_valid = last_valid;
         }
         return;
     }
 
-    // -------------------------------------------------------------------- window wavefronts: 2 colour, 3 fast history, 4 slow history
-    const uint32_t role = wave - 2;                                 // wave-uniform
+    // -------------------------------------------------------------------- window wavefronts: 4 colour, 5 fast history, 6 slow history (data round d = r - 2)
+    const uint32_t role = wave - 4;                                 // wave-uniform
     const uint32_t cap = role == 2 ? a.slow_len : a.color_len;      // colour, fast: color_len; slow: slow_len
     const uint32_t mean_len = role == 0 ? a.color_len : a.slow_len; // ring length of the reference's WindowedMeans (dsp.rs:367-370)
     const uint32_t which = role == 0 ? 0u : 1u;                     // |v| gain for the colour window, v^2 for the histories
@@ -308,9 +372,9 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
         }
     };
     lds_barrier();  // round -1
-    for (uint64_t r = 0; r <= n_rounds; ++r) {
-        const uint64_t b = r - 1;  // the round being consumed
-        const uint32_t nr = r >= 1 ? (b + 1 == n_rounds ? tail : (uint32_t)R) : 0u;
+    for (uint64_t r = 0; r <= last_iter; ++r) {
+        const uint64_t b = r - 2;  // the data round being consumed
+        const uint32_t nr = r >= 2 ? frames_of(b) : 0u;
 #pragma unroll 1
         for (uint32_t k0 = 0; k0 < nr; k0 += B) {  // the round's batches
             const uint32_t nb = min(nr - k0, (uint32_t)B);
@@ -348,6 +412,7 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
         }
         lds_barrier();
     }
+    WF_REPORT("window")
     if (live && a.write_preview) write_field(a.preview + (uint64_t)s * 4 + ch);  // preview (:300-306)
     if (live) {
         double out[4];
@@ -358,14 +423,19 @@ __global__ __launch_bounds__(HISTORY ? 320 : 192) void waveform_roles_kernel(Wav
 }
 
 // true when the role form applies: band analysis on, windows long enough for the two-round distance between a ring store and the
-// load of the same slot (see the memory wavefront)
-bool waveform_roles_applicable(const WaveformArgs& a) { return a.analyze != 0 && a.color_len >= 64 && a.slow_len >= 64; }  // 2 R
+// load of the same slot (see the memory wavefront).  Measured (tools/bench_meters.py waveform, 64 blocks per call): 3.1x ... 3.2x the
+// one-wavefront kernel up to 1024 streams (one workgroup per CU, every wavefront at its own pace), 1.13x with RMS history at 4096
+// streams, 0.89x without history at 4096 streams (four workgroups per CU's worth of work: the one-wavefront kernel's 1024
+// wavefronts fill the SIMDs and execute fewer instructions in total) — that last shape keeps the one-wavefront kernel.
+bool waveform_roles_applicable(const WaveformArgs& a) {
+    return a.analyze != 0 && a.color_len >= 32 && a.slow_len >= 32 /* 2 R */ && (a.track_history != 0 || a.n_streams < 2048);
+}
 
 void launch_waveform_roles(const WaveformArgs& a, hipStream_t stream) {
     const uint32_t threads = a.n_streams * 16;
     const dim3 grid((threads + 63) / 64);
-    if (a.track_history) hipLaunchKernelGGL((waveform_roles_kernel<8, 4, true>), grid, dim3(320), 0, stream, a);
-    else hipLaunchKernelGGL((waveform_roles_kernel<8, 4, false>), grid, dim3(192), 0, stream, a);
+    if (a.track_history) hipLaunchKernelGGL((waveform_roles_kernel<8, 2, true>), grid, dim3(448), 0, stream, a);
+    else hipLaunchKernelGGL((waveform_roles_kernel<8, 2, false>), grid, dim3(320), 0, stream, a);
 }
 
 }  // namespace omx

@@ -89,6 +89,30 @@ def scope_stereo(S=256, blocks=64, reps=5, out=sys.stdout):
     return res
 
 
+def waveform(blocks=64, reps=5, out=sys.stdout):
+    """the waveform bank (band analysis on; with and without RMS history), 256-frame blocks x `blocks` per call."""
+    frames = 256 * blocks
+    res = {}
+    for S in (64, 1024, 4096):
+        g = torch.Generator(device=dev).manual_seed(S)
+        pcm = (torch.rand((S, frames, 2), device=dev, generator=g) - 0.5).contiguous()
+        pos = capi.positions_fallback(2)
+        for history in (False, True):
+            bank = banks.WaveformBank(api, capi.WaveformConfig(analyze_bands=True, track_history=history), S)
+            run = lambda: bank.process_device(pcm.data_ptr(), frames, 2, FS, pos, stream)
+            run()
+            dt = timed(run, reps)
+            print(f"waveform: {S} streams, history={int(history)}, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
+                  f"{frames/dt/FS:.0f}x real time per stream", file=out)
+            res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3}
+            bank.close()
+    return res
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "waveform":
+        waveform()
+        sys.exit(0)
     loudness()
     scope_stereo()
+    waveform()
