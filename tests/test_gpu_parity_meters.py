@@ -312,6 +312,29 @@ def test_summary_reductions_on_device_resident_bank_outputs(omx, oracle):
     assert (want["peaks"][:, 20, 0] > want["values"][:, 20, 0] + 10.0).all() and (want["peaks"][:, -1, 0] < want["peaks"][:, 20, 0]).all()
 
 
+@pytest.mark.parametrize("rate", [600.0, 1000.0, 3000.0])
+def test_waveform_short_windows_match_oracle(omx, oracle, rate):
+    """Low sample rates shrink the colour / history windows (2048 and 16384 samples at 44.1 kHz): 600 Hz -> 28 / 223 samples (the
+    frame-at-a-time instantiation of the one-wavefront kernel), 1000 Hz -> 46 / 372 (its batched instantiation with the shortest
+    windows it accepts; the role kernel too: >= 32), 3000 Hz -> 139 / 1115.  Windows wrap many times per call."""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    cfg = WaveformConfig(sample_rate=rate, scroll_speed=40.0, max_columns=512, analyze_bands=True, track_history=True)
+    pcm = cfg4_pcm(11, 6000)
+    a, b = WaveformProcessor(omx, cfg), WaveformProcessor(oracle, cfg)
+    total = 0
+    for lo, hi in [(0, 256), (256, 1300), (1300, 1301), (1301, 4000), (4000, 6000)]:
+        g = a.process_block(AudioBlock(pcm[lo:hi].reshape(-1), 2, rate))
+        w = b.process_block(AudioBlock(pcm[lo:hi].reshape(-1), 2, rate))
+        assert g.reset == w.reset and g.columns.shape == w.columns.shape
+        total += len(g.columns)
+        assert np.array_equal(g.columns[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32))  # min / max
+        if len(g.columns):
+            bar("waveform (short windows): |d band colour| / max(1, max)", np.abs(g.columns[:, :, 2:5] - w.columns[:, :, 2:5]).max() /
+                max(1.0, np.abs(w.columns[:, :, 2:5]).max()), 1e-6)
+            bar("waveform (short windows): |d RMS history dB|", np.abs(g.columns[:, :, 5:] - w.columns[:, :, 5:]).max(), 2e-4)
+    assert total > 50
+
+
 def test_waveform_bank_matches_per_stream_oracle(omx, oracle):
     """bank of 7 streams, irregular block sizes: column counts / reset flags in lock-step, min / max bit-exact per stream"""
     from openmeters_amd.capi import WaveformConfig, WaveformProcessor
