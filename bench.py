@@ -399,6 +399,21 @@ def main():
             "fp32_vector_frac_reference_algorithm": per_s * FLOPS_PER_FRAME / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
         },
     }
+    if world > 1:
+        # Weak scaling of the N > 1 workload is measured against the SAME workload at N = 1 (`python bench.py --config cfg5`), not against
+        # the default N = 1 line (cfg2, the configuration the metric is quoted on): the newest recorded N = 1 line of it is echoed, tagged
+        result["per_gpu_value"] = value / world
+        ref = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_bench_line_{config}.json")), reverse=True):
+            try:
+                with open(path) as fh:
+                    rec = json.load(fh)
+                if rec.get("n_gpus") == 1 and rec.get("config", {}).get("name") == config:
+                    ref = {"file": "profiles/" + os.path.basename(path), "value": rec["value"], "ms_per_step": rec["ms_per_step"]}
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
+        result["n1_same_workload"] = {"command": f"python bench.py --config {config}", "recorded": ref}
     if rank == 0:
         if world == 1 and not args.no_secondary:
             # BASELINE.json's other single-GPU configurations, measured after the timed region (a few seconds; never part of
