@@ -389,6 +389,20 @@ int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on
                               uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                               float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
                               void* stream, const omx_loudness_snapshot** d_snapshots);
+/* Ragged call — the reference's VisualManager feeds every stream's LoudnessProcessor its own blocks (registry.rs:396-418): stream s
+ * runs n_blocks[s] <= max_blocks blocks of block_frames frames; its row of `pcm` (device memory) is block_frames * max_blocks frames
+ * long.  Streams flagged in reset_mask (may be NULL) get reset_audio() first.  d_snapshots is [n_streams][max_blocks], of which stream
+ * s filled the first d_n_blocks[s].  The first ragged call moves the bank to per-stream sample counters; lock-step
+ * omx_loudness_bank_process calls are refused until omx_loudness_bank_reset_audio. */
+typedef struct omx_loudness_ragged_update {
+    uint64_t n_streams;
+    uint64_t max_blocks;
+    const uint32_t* d_n_blocks;               /* device: [n_streams] */
+    const omx_loudness_snapshot* d_snapshots; /* device: [n_streams][max_blocks] */
+} omx_loudness_ragged_update;
+int omx_loudness_bank_process_ragged(omx_loudness_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
+                                     const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_loudness_ragged_update* out);
 int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block,
                             omx_loudness_snapshot* dst);
 int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t* launches);

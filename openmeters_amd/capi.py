@@ -109,6 +109,10 @@ class CSpectrumBankUpdate(C.Structure):
                 ("n_hops_out", C.c_uint64), ("d_traces", C.c_void_p), ("d_frequency_bins", C.c_void_p)]
 
 
+class CLoudnessRaggedUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("d_n_blocks", C.c_void_p), ("d_snapshots", C.c_void_p)]
+
+
 class CSpectrumRaggedUpdate(C.Structure):
     _fields_ = [("bins", C.c_uint64), ("n_streams", C.c_uint64), ("max_hops", C.c_uint64), ("n_hops_out", C.c_uint64),
                 ("d_n_hops", C.c_void_p), ("d_traces", C.c_void_p), ("d_frequency_bins", C.c_void_p)]

@@ -376,6 +376,15 @@ int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on
                                static_cast<hipStream_t>(stream), d_snapshots);
     });
 }
+int omx_loudness_bank_process_ragged(omx_loudness_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
+                                     const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_loudness_ragged_update* out) {
+    if (!b || !pcm || !n_blocks || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_ragged(pcm, block_frames, max_blocks, n_blocks, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst) {
     if (!b || !dst) return OMX_ERR_INVALID;
     return guarded([&] { return b->impl.fetch(stream_index, block, dst, b->impl.last_stream()); });

@@ -101,6 +101,70 @@ void LoudnessBank::clear_state(hipStream_t stream) {
 
 void LoudnessBank::reset_audio() {  // :234-236 every ChannelState back to default
     clear_state(last_stream_);
+    ragged_ = false;
+}
+
+int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks,
+                                 const uint8_t* reset_mask, uint32_t channels_in, float sample_rate,
+                                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_loudness_ragged_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (block_frames == 0 || block_frames > 0xFFFFFFFFull || max_blocks > 0xFFFFFFFFull) {
+        set_last_error("loudness process_ragged: block_frames must be in 1 ... 2^32 - 1");
+        return OMX_ERR_INVALID;
+    }
+    bool any = false, any_reset = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (n_blocks[s] > max_blocks) {
+            set_last_error("loudness process_ragged: n_blocks[s] > max_blocks");
+            return OMX_ERR_INVALID;
+        }
+        any = any || n_blocks[s] != 0;
+        any_reset = any_reset || (reset_mask && reset_mask[s]);
+    }
+    const bool clean_before = state_clean_;
+    ensure_state(channels, sample_rate, stream);  // (a rate / channel-count change clears every stream, as in the lock-step call)
+    const bool cleared_now = state_clean_ && !clean_before;
+    if (!ragged_) {  // every stream starts from the bank's common counter
+        r_seen_.upload(std::vector<uint64_t>(n_streams_, frames_seen_), stream);
+        ragged_ = true;
+        q_valid_ = false;
+    } else if (cleared_now) {
+        OMX_HIP(hipMemsetAsync(r_seen_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
+    }
+    if (!any && !any_reset) return OMX_NONE;
+    // per-stream counts / flags: pinned staging -> device (the caller's arrays are borrowed for the call only)
+    OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
+    r_blocks_host_.reserve(n_streams_);
+    r_mask_host_.reserve(n_streams_);
+    r_blocks_.reserve(n_streams_);
+    r_mask_.reserve(n_streams_);
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        r_blocks_host_.ptr[s] = n_blocks[s];
+        r_mask_host_.ptr[s] = reset_mask ? reset_mask[s] : 0;
+    }
+    OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+    const uint64_t slots = std::max<uint64_t>(max_blocks, 1);
+    snapshots_.reserve((size_t)(n_streams_ * slots), false);
+    LoudnessArgs la{};
+    fill_args(la, d_pcm, block_frames, slots, channels, positions);
+    la.seen_v = r_seen_.ptr;
+    la.blocks_v = r_blocks_.ptr;
+    la.reset_v = r_mask_.ptr;
+    timer_.begin(stream);
+    launch_loudness(la, stream);
+    timer_.end(stream);
+    OMX_HIP(hipGetLastError());
+    state_clean_ = false;  // (frames_seen_ is meaningless from here on: the counters are per stream)
+    last_blocks_ = slots;
+    if (out) {
+        out->n_streams = n_streams_;
+        out->max_blocks = slots;
+        out->d_n_blocks = r_blocks_.ptr;
+        out->d_snapshots = snapshots_.ptr;
+    }
+    return any ? OMX_PRODUCED : OMX_NONE;
 }
 
 void LoudnessBank::ensure_state(uint32_t requested, float sample_rate_in, hipStream_t stream) {  // :238-251
@@ -125,24 +189,10 @@ void LoudnessBank::ensure_state(uint32_t requested, float sample_rate_in, hipStr
     }
 }
 
-int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
-                          float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
-                          const omx_loudness_snapshot** d_snapshots) {  // :253-311
-    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
-    last_stream_ = stream;
-    if (block_frames == 0 || n_blocks == 0) return OMX_NONE;  // block.is_empty()
-    if (block_frames > 0xFFFFFFFFull || n_blocks > 0xFFFFFFFFull) unsupported("loudness block shape beyond 2^32");
-    ensure_state(channels, sample_rate, stream);
-    const uint64_t frames = block_frames * n_blocks;
-    const float* d_pcm = pcm;
-    if (!pcm_on_device) {
-        const size_t n = (size_t)n_streams_ * frames * channels;
-        d_pcm = staging_.stage(pcm, n, stream);
-    }
-    snapshots_.reserve((size_t)(n_streams_ * n_blocks), host_outputs_ && n_streams_ * n_blocks <= 4096);
-    LoudnessArgs la{};
+void LoudnessBank::fill_args(LoudnessArgs& la, const float* d_pcm, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                             const uint8_t positions[OMX_MAX_CHANNELS]) {
     la.pcm = d_pcm;
-    la.frames_total = frames;
+    la.frames_total = block_frames * n_blocks;
     la.block_frames = (uint32_t)block_frames;
     la.n_blocks = (uint32_t)n_blocks;
     la.n_streams = n_streams_;
@@ -168,6 +218,29 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     la.state = state_.ptr;
     la.floor_db = cfg_.floor_db;
     la.snapshots = snapshots_.ptr;
+}
+
+int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                          float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                          const omx_loudness_snapshot** d_snapshots) {  // :253-311
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    if (block_frames == 0 || n_blocks == 0) return OMX_NONE;  // block.is_empty()
+    if (block_frames > 0xFFFFFFFFull || n_blocks > 0xFFFFFFFFull) unsupported("loudness block shape beyond 2^32");
+    if (ragged_) {
+        set_last_error("loudness bank: per-stream positions are in use (process_ragged); reset_audio() returns the bank to lock-step calls");
+        return OMX_ERR_INVALID;
+    }
+    ensure_state(channels, sample_rate, stream);
+    const uint64_t frames = block_frames * n_blocks;
+    const float* d_pcm = pcm;
+    if (!pcm_on_device) {
+        const size_t n = (size_t)n_streams_ * frames * channels;
+        d_pcm = staging_.stage(pcm, n, stream);
+    }
+    snapshots_.reserve((size_t)(n_streams_ * n_blocks), host_outputs_ && n_streams_ * n_blocks <= 4096);
+    LoudnessArgs la{};
+    fill_args(la, d_pcm, block_frames, n_blocks, channels, positions);
     // chunk-parallel evaluation for bank-sized calls (loudness_chunked.hip): every block of the call in parallel
     constexpr uint64_t kQLen = 4096;
     bool shape_ok = (channels == 1 || channels == 2 || channels == 4 || channels == 8) && block_frames % 64 == 0 && n_blocks >= 2 &&

@@ -41,6 +41,11 @@ struct LoudnessArgs {
     uint32_t n_meter_blocks;
     uint32_t role_perm;  // TEMP           // split launch: workgroups [0, n) = K-weighting + windows, [n, 2n) = true peak
     const uint32_t* run_if;  // fallback launch of the chunk-parallel path: run only when *run_if != 0
+    // ragged banks (per-stream block counts; nullptr = lock-step): stream s runs blocks_v[s] <= n_blocks blocks from its own sample
+    // counter seen_v[s] (frames_seen above is then unused), after a reset of its state when reset_v[s] != 0.  Lane-quad kernel only.
+    uint64_t* seen_v;
+    const uint32_t* blocks_v;
+    const uint8_t* reset_v;
 };
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream);
 
@@ -80,6 +85,12 @@ public:
     int process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                 const omx_loudness_snapshot** d_snapshots);
+    // Ragged call (include/omx.h: omx_loudness_bank_process_ragged): stream s runs n_blocks[s] <= max_blocks blocks of block_frames
+    // frames (its rows of `d_pcm` are block_frames * max_blocks frames apart); streams flagged in reset_mask are reset first.  The
+    // per-stream sample counters then live on the device; the bank stays ragged until reset_audio() of the whole bank.
+    int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
+                       uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                       omx_loudness_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst, hipStream_t stream);
     EventTimer& timer() { return timer_; }
     hipStream_t last_stream() const { return last_stream_; }
@@ -87,6 +98,8 @@ public:
 private:
     void ensure_state(uint32_t channels, float sample_rate, hipStream_t stream);
     void clear_state(hipStream_t stream);
+    void fill_args(LoudnessArgs& la, const float* d_pcm, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
+                   const uint8_t positions[OMX_MAX_CHANNELS]);
 
     omx_loudness_config cfg_{};
     uint32_t n_streams_;
@@ -108,6 +121,13 @@ private:
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows
+    // ragged mode: per-stream sample counters on the device
+    bool ragged_ = false;
+    DeviceBuffer<uint64_t> r_seen_;
+    DeviceBuffer<uint32_t> r_blocks_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_blocks_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: snapshots in pinned host memory

@@ -151,13 +151,19 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     const uint32_t s = chan >> a.slot_shift, c = chan & ((1u << a.slot_shift) - 1u);
     const bool live = s < a.n_streams && c < a.channels;
     const uint32_t row = kRingRow;
+    // ragged banks: the stream's own block count, sample counter and reset flag (every lane of a stream sits in one wavefront and
+    // sees the same values; the block loop below then has a per-lane trip count and its shuffles stay inside the stream's lanes)
+    const bool ragged = a.blocks_v != nullptr, in_bank = s < a.n_streams;
+    const bool reset = ragged && in_bank && a.reset_v != nullptr && a.reset_v[s] != 0;
+    const uint64_t seen0 = ragged ? ((in_bank && !reset) ? a.seen_v[s] : 0ull) : a.frames_seen;
+    const uint32_t n_blocks_s = ragged ? (in_bank ? a.blocks_v[s] : 0u) : a.n_blocks;
     LoudLane<DL> L;
     L.sum0 = L.sum1 = L.cor0 = L.cor1 = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) L.filt[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < (DL > 1 ? DL - 1 : 1); ++i) L.hist[i] = 0.0f;
-    if (live) {
+    if (live && !reset) {
         const LoudnessChannelState& st = a.state[chan];
         if constexpr (MODE != 2) {
             L.sum0 = st.sums[r][0];
@@ -182,15 +188,15 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     }
     const float* pcm = a.pcm + ((uint64_t)(live ? s : 0) * a.frames_total) * a.channels + (live ? c : 0);
     const uint32_t len = (uint32_t)a.ring_len, cap = (uint32_t)a.capacities[r];
-    L.head = (uint32_t)(a.frames_seen % a.ring_len);
-    L.refresh = (uint32_t)(a.frames_seen % a.capacities[r]);                                             // dsp.rs:363
-    L.unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);  // pushes until count >= cap
-    uint64_t seen = a.frames_seen;
+    L.head = (uint32_t)(seen0 % a.ring_len);
+    L.refresh = (uint32_t)(seen0 % a.capacities[r]);                                   // dsp.rs:363
+    L.unfilled = seen0 >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - seen0);  // pushes until count >= cap
+    uint64_t seen = seen0;
     double* ring_col = ring_column(a.ring, live ? chan : 0, a.ring_len);  // dead lanes read column 0 (discarded) and never store
     const bool store_lane = live && r == 0;
     const uint32_t full = a.block_frames / B, tail = a.block_frames % B;
 
-    for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
+    for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
         const uint64_t f_blk = (uint64_t)blk * a.block_frames;
         // full batches, two per iteration so the prefetch buffers swap roles without register copies: the loads of
         // batch n+1 are issued before batch n is computed (HBM round trip hidden behind ~8 samples of f64 work)
@@ -265,6 +271,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
             }
         }
     }
+    if (ragged && live && r == 0 && c == 0) a.seen_v[s] = seen;  // (read above by every lane of the stream: same wavefront)
     if (live) {
         LoudnessChannelState& st = a.state[chan];
         if constexpr (MODE != 2) {
@@ -656,6 +663,12 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
         const char* e = getenv("OMX_LOUDNESS_SPLIT");  // 0 / 1 pins the form (A/B and tests)
         return e ? atoi(e) : -1;
     }();
+    if (a.blocks_v) {  // ragged banks: everything of a (stream, channel) in its four lanes (MODE 0), no role split
+        if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, false, stream);
+        else if (a.delay_len == 24) launch_loudness_dl<24>(a, grid, batched, false, stream);
+        else launch_loudness_dl<0>(a, grid, batched, false, stream);
+        return;
+    }
     const bool split = force >= 0 ? force != 0 : (a.delay_len != 0 && grid <= 4096);
     // role-per-wavefront form (OMX_LOUDNESS_SPLIT=2 pins it, default when it applies): whole batches per block, 4x interpolator
     const bool roles = a.ring_len * (uint64_t)(kRingRow * 8u) <= 0xFFFFFFFFull &&  // 32-bit byte offsets inside a group's ring

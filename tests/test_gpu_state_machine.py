@@ -424,3 +424,67 @@ def _dev(torch, ptr, shape, typestr="<u4"):
     class V:
         __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
     return torch.as_tensor(V(), device="cuda:0")
+
+
+@pytest.mark.parametrize("seed,C,rate,block", [(1, 2, 48000.0, 256), (2, 8, 48000.0, 256), (3, 6, 96000.0, 100), (4, 1, 44100.0, 37), (5, 3, 192000.0, 64)])
+def test_ragged_loudness_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, rate, block):
+    """Per-stream independence of the loudness bank: every stream gets its own random block counts and its own reset_audio()
+    calls; stream s must behave exactly like a single LoudnessProcessor fed the same blocks — every snapshot of every block at the
+    usual 1e-4 dB bar (window fill / refresh positions, K-weighting and true-peak state carried per stream across calls, cleared
+    by the stream's own reset only).  Two lock-step calls first: the switch to per-stream counters must carry the common state."""
+    import torch
+    from test_gpu_parity_meters import snapshots_close
+    rng = np.random.default_rng(300 + seed)
+    S, calls, max_blocks = 5, 14, 9
+    positions = capi.SURROUND if C == 8 else capi.positions_fallback(C)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, C)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate)) for _ in range(S)]
+    total = block * (2 * 12 + calls * max_blocks)
+    feeds = []
+    for s in range(S):
+        t = np.arange(total) / rate
+        x = np.stack([(0.1 + 0.1 * c) * np.sin(2 * np.pi * (200.0 + 170.0 * s + 31.0 * c) * t) for c in range(C)], 1)
+        x += 0.01 * rng.standard_normal(x.shape)
+        if s == 1:
+            x[:block * 30] = 0.0            # leading silence: lazy channel activation
+        feeds.append(x.astype(np.float32))
+    at = [0] * S
+    for n in (12, 12):
+        chunk = np.stack([f[a:a + n * block] for f, a in zip(feeds, at)])
+        assert bank.process_host(chunk, block, C, rate, positions) is not None
+        for s in range(S):
+            for k in range(n):
+                w = refs[s].process_block(AudioBlock(chunk[s, k * block:(k + 1) * block].reshape(-1), C, rate, positions))
+            snapshots_close(bank.fetch(s, n - 1), w)
+            at[s] += n * block
+    compared = 0
+    for call in range(calls):
+        nb = rng.integers(0, max_blocks + 1, S)
+        nb[rng.integers(0, S)] = 0                     # someone always sits a call out
+        mask = (rng.random(S) < 0.15).astype(np.uint8)
+        pcm = np.zeros((S, max_blocks * block, C), np.float32)
+        for s in range(S):
+            pcm[s, :nb[s] * block] = feeds[s][at[s]:at[s] + nb[s] * block]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), block, max_blocks, nb, C, rate, positions, mask)
+        torch.cuda.synchronize()
+        if int(nb.max()) > 0:
+            assert int(up.max_blocks) == max_blocks and np.array_equal(_dev(torch, up.d_n_blocks, (S,)).cpu().numpy(), nb)
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            for k in range(int(nb[s])):
+                w = refs[s].process_block(AudioBlock(pcm[s, k * block:(k + 1) * block].reshape(-1), C, rate, positions))
+                if k in (0, int(nb[s]) - 1) or rng.random() < 0.3:
+                    snapshots_close(bank.fetch(s, k), w)
+                    compared += 1
+            at[s] += int(nb[s]) * block
+    assert compared > 60
+    # the bank refuses lock-step calls while its counters are per stream, and accepts them again after a bank-wide reset
+    chunk = np.stack([f[:block] for f in feeds])
+    with pytest.raises(capi.OmxError):
+        bank.process_host(chunk, block, C, rate, positions)
+    bank.reset_audio()
+    assert bank.process_host(chunk, block, C, rate, positions) is not None
+    fresh = LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate))
+    snapshots_close(bank.fetch(2, 0), fresh.process_block(AudioBlock(chunk[2].reshape(-1), C, rate, positions)))
