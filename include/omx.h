@@ -646,6 +646,23 @@ int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, in
                                   uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                                   float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
                                   void* stream, omx_oscilloscope_bank_update* out);
+/* Ragged call — one OscilloscopeProcessor per capture, fed and reset on its own (registry.rs:396-418): stream s runs
+ * n_blocks[s] <= max_blocks blocks of block_frames frames; its row of `pcm` (device memory) is block_frames * max_blocks frames long.
+ * Streams flagged in reset_mask (may be NULL) get reset_audio() first (their d_epochs[s] advances).  d_headers is
+ * [n_streams][max_blocks], of which stream s filled the first d_n_blocks[s]; d_samples holds every stream's newest snapshot.  The first
+ * ragged call moves the bank to per-stream ring positions; lock-step omx_oscilloscope_bank_process calls are refused until
+ * omx_oscilloscope_bank_reset_audio. */
+typedef struct omx_oscilloscope_ragged_update {
+    uint64_t n_streams;
+    uint64_t max_blocks;
+    const uint32_t* d_n_blocks;                        /* device: [n_streams] */
+    const uint64_t* d_epochs;                          /* device: [n_streams] */
+    const omx_oscilloscope_block_header* d_headers;    /* device: [n_streams][max_blocks] */
+    const float* d_samples;                            /* device: [n_streams][2][4096] (the newest snapshot of every stream) */
+} omx_oscilloscope_ragged_update;
+int omx_oscilloscope_bank_process_ragged(omx_oscilloscope_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
+                                         const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                         const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_ragged_update* out);
 int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
                                 omx_oscilloscope_block_header* header, float* samples);
 

@@ -307,6 +307,11 @@ class COscilloscopeBankUpdate(C.Structure):
                 ("d_headers", C.c_void_p), ("d_samples", C.c_void_p)]
 
 
+class COscilloscopeRaggedUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("d_n_blocks", C.c_void_p), ("d_epochs", C.c_void_p),
+                ("d_headers", C.c_void_p), ("d_samples", C.c_void_p)]
+
+
 class OscilloscopeBank(_BlockBank):
     """reference src/visuals/oscilloscope/processor.rs:570-759, S streams in lock-step."""
     _family = "oscilloscope"
@@ -330,6 +335,21 @@ class OscilloscopeBank(_BlockBank):
         positions = positions if positions is not None else capi.positions_fallback(channels)
         assert pcm.shape[1] % block_frames == 0
         return self._process(pcm.ctypes.data, False, block_frames, pcm.shape[1] // block_frames, channels, sample_rate, positions, 0)
+
+    def process_ragged(self, device_ptr: int, block_frames: int, max_blocks: int, n_blocks: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """Streams advance independently: stream s runs n_blocks[s] (<= max_blocks) blocks of block_frames frames, after reset_audio()
+        when reset_mask[s]; pcm = device f32 [n_streams][block_frames * max_blocks][channels].  Headers of stream s, block k:
+        fetch(s, k) for k < n_blocks[s]; fetch(s, n_blocks[s] - 1, with_samples=True) adds the stream's newest snapshot."""
+        out = COscilloscopeRaggedUpdate()
+        nb = np.ascontiguousarray(n_blocks, np.uint32)
+        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        f = self.api.fn("oscilloscope_bank_process_ragged", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
+                         C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), block_frames, max_blocks, nb.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
 
     def fetch(self, stream_index, block, with_samples=False):
         hdr = COscilloscopeBlockHeader()

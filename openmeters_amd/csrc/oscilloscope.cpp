@@ -41,6 +41,11 @@ void OscilloscopeBank::rebuild(const omx_oscilloscope_config& cfg) {  // Self::n
     has_history_channels_ = false;
     for (int t = 0; t < kScopeTraces; ++t) len_[t] = 0;
     pending_unlock_ = true;
+    if (ragged_ && r_pos_.ptr) {
+        std::vector<uint64_t> zero((size_t)n_streams_ * kScopeTraces * 2, 0);
+        r_pos_.upload(zero, last_stream_);
+        for (int t = 0; t < kScopeTraces; ++t) head_[t] = 0;
+    }
 }
 
 void OscilloscopeBank::clear_history() {  // :714-723
@@ -48,9 +53,17 @@ void OscilloscopeBank::clear_history() {  // :714-723
     has_history_channels_ = false;
     for (int t = 0; t < kScopeTraces; ++t) len_[t] = 0;
     pending_unlock_ = true;
+    if (ragged_ && r_pos_.ptr) {  // every stream's deques are emptied; their heads only matter modulo the ring
+        std::vector<uint64_t> zero((size_t)n_streams_ * kScopeTraces * 2, 0);
+        r_pos_.upload(zero, last_stream_);
+        for (int t = 0; t < kScopeTraces; ++t) head_[t] = 0;
+    }
 }
 
-void OscilloscopeBank::reset_audio() { clear_history(); }  // :593-600 (epoch survives the snapshot reset)
+void OscilloscopeBank::reset_audio() {  // :593-600 (epoch survives the snapshot reset)
+    clear_history();
+    ragged_ = false;  // (lengths are zero: the positions are common again)
+}
 
 void OscilloscopeBank::update_config(const omx_oscilloscope_config& cfg) {  // :752-758
     if (!config_eq(cfg_, cfg)) {
@@ -62,6 +75,33 @@ void OscilloscopeBank::update_config(const omx_oscilloscope_config& cfg) {  // :
 
 int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
                               float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream) {  // :611-712
+    if (ragged_) {
+        set_last_error("oscilloscope bank: per-stream positions are in use (process_ragged); reset_audio() returns the bank to lock-step calls");
+        return OMX_ERR_INVALID;
+    }
+    return process_impl(pcm, pcm_on_device, block_frames, n_blocks, channels_in, sample_rate_in, positions, stream, nullptr);
+}
+
+int OscilloscopeBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks,
+                                     const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_oscilloscope_ragged_update* out) {
+    bool any = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (n_blocks[s] > max_blocks) {
+            set_last_error("oscilloscope process_ragged: n_blocks[s] > max_blocks");
+            return OMX_ERR_INVALID;
+        }
+        any = any || n_blocks[s] != 0 || (reset_mask && reset_mask[s]);
+    }
+    last_stream_ = stream;
+    if (!any || block_frames == 0) return OMX_NONE;
+    const RaggedCall rc{n_blocks, reset_mask, out};
+    return process_impl(d_pcm, true, block_frames, std::max<uint64_t>(max_blocks, 1), channels, sample_rate, positions, stream, &rc);
+}
+
+int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                                   float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                   const RaggedCall* ragged) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
     if (block_frames == 0 || n_blocks == 0) return OMX_NONE;
@@ -96,9 +136,11 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
     // two-pass form (period estimates of every block in parallel, see oscilloscope.hpp): several blocks per call in the
     // stable-trigger steady state; the rings then hold the history plus the whole call
     const uint64_t total_frames = block_frames * n_blocks;
-    const bool two_pass_shape = n_blocks >= 4 && cfg_.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && total_frames <= (1ull << 22);
+    const bool two_pass_shape = !ragged && n_blocks >= 4 && cfg_.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && total_frames <= (1ull << 22);
     const uint64_t cap = std::max<uint64_t>(  // never shrinks: call shapes may alternate
         cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(two_pass_shape ? total_frames : block_frames, 4096)));
+    if (ragged_ && (cap != cap_ || !rings_.ptr))  // the regrow below copies by the host's (lock-step) positions
+        unsupported("oscilloscope process_ragged: block_frames grew beyond the ring sized at the first ragged call");
     if (cap != cap_ || !rings_.ptr) {
         DeviceBuffer<float> bigger;
         bigger.reserve((size_t)(cap * kScopeTraces * n_streams_));
@@ -200,6 +242,46 @@ int OscilloscopeBank::process(const float* pcm, bool pcm_on_device, uint64_t blo
     }();
     sa.phase_timing = phase_timing ? 1u : 0u;
     sa.estimates = nullptr;
+    if (ragged) {
+        if (!ragged_) {  // every stream starts from the bank's common positions
+            std::vector<uint64_t> seed((size_t)n_streams_ * kScopeTraces * 2);
+            for (uint32_t s = 0; s < n_streams_; ++s)
+                for (int t = 0; t < kScopeTraces; ++t) {
+                    seed[((size_t)s * kScopeTraces + t) * 2] = head_[t];
+                    seed[((size_t)s * kScopeTraces + t) * 2 + 1] = len_[t];
+                }
+            r_pos_.upload(seed, stream);
+            r_epoch_.upload(std::vector<uint64_t>(n_streams_, epoch_), stream);
+            ragged_ = true;
+        }
+        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
+        r_blocks_host_.reserve(n_streams_);
+        r_mask_host_.reserve(n_streams_);
+        r_blocks_.reserve(n_streams_);
+        r_mask_.reserve(n_streams_);
+        for (uint32_t s = 0; s < n_streams_; ++s) {
+            r_blocks_host_.ptr[s] = ragged->n_blocks[s];
+            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
+        }
+        OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        sa.pos_v = r_pos_.ptr;
+        sa.blocks_v = r_blocks_.ptr;
+        sa.reset_v = r_mask_.ptr;
+        sa.epoch_v = r_epoch_.ptr;
+        launch_oscilloscope(sa, stream);
+        OMX_HIP(hipGetLastError());
+        last_blocks_ = n_blocks;
+        if (ragged->out) {
+            ragged->out->n_streams = n_streams_;
+            ragged->out->max_blocks = n_blocks;
+            ragged->out->d_n_blocks = r_blocks_.ptr;
+            ragged->out->d_epochs = r_epoch_.ptr;
+            ragged->out->d_headers = reinterpret_cast<const omx_oscilloscope_block_header*>(headers_.ptr);
+            ragged->out->d_samples = samples_.ptr;
+        }
+        return OMX_PRODUCED;
+    }
     if (two_pass_shape && sa.lds_scratch && fast_acf) {
         estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
         sa.estimates = estimates_.ptr;

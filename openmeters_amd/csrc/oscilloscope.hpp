@@ -73,6 +73,13 @@ struct ScopeArgs {
     // the period estimates — a pure function of the trace — are computed for all (stream, block, view) in parallel, and the
     // per-stream kernel only runs the stateful part (stabilise / locate / snapshot) block after block
     ScopeEstimate* estimates;    // [n_streams][n_blocks][kScopeTraces] or nullptr (single-pass form)
+    // ragged banks (per-stream block counts; nullptr = lock-step; single-pass form only): stream s runs blocks_v[s] <= n_blocks
+    // blocks from its own ring positions pos_v[s][trace] = {head, len} (head / len above are then unused), after a
+    // clear_history() of its own when reset_v[s] != 0 (its epoch_v[s] then advances)
+    uint64_t* pos_v;             // [n_streams][kScopeTraces][2]
+    const uint32_t* blocks_v;    // [n_streams]
+    const uint8_t* reset_v;      // [n_streams]
+    uint64_t* epoch_v;           // [n_streams]
 };
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
 constexpr int SCOPE_PHASES = 10;
@@ -92,6 +99,12 @@ public:
     // returns OMX_PRODUCED when the newest block produced a snapshot for stream 0 .. (per stream flags in headers)
     int process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream);
+    // Ragged call (include/omx.h: omx_oscilloscope_bank_process_ragged): stream s runs n_blocks[s] <= max_blocks blocks (its rows of
+    // `d_pcm` are block_frames * max_blocks frames apart); streams flagged in reset_mask get reset_audio() first.  The per-stream ring
+    // positions then live on the device; the bank stays ragged until reset_audio() of the whole bank.
+    int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
+                       uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                       omx_oscilloscope_ragged_update* out);
     int fetch_header(uint64_t stream_index, uint64_t block, ScopeBlockHeader* dst, hipStream_t stream);
     int fetch_samples(uint64_t stream_index, float* dst, uint64_t count, hipStream_t stream);
     uint64_t epoch() const { return epoch_; }
@@ -105,6 +118,13 @@ public:
 private:
     void rebuild(const omx_oscilloscope_config& cfg);
     void clear_history();
+    struct RaggedCall {
+        const uint32_t* n_blocks;
+        const uint8_t* reset_mask;
+        omx_oscilloscope_ragged_update* out;
+    };
+    int process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels, float sample_rate,
+                     const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, const RaggedCall* ragged);
 
     omx_oscilloscope_config cfg_{};
     uint32_t n_streams_;
@@ -123,6 +143,13 @@ private:
     OutBuffer<ScopeBlockHeader> headers_;
     DeviceBuffer<ScopeEstimate> estimates_;
     hipStream_t last_stream_ = nullptr;
+    // ragged mode: per-stream ring positions and epochs on the device
+    bool ragged_ = false;
+    DeviceBuffer<uint64_t> r_pos_, r_epoch_;
+    DeviceBuffer<uint32_t> r_blocks_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_blocks_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
 };
 
 }  // namespace omx

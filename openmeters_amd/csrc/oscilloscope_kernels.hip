@@ -872,21 +872,29 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[tid * (unsigned)t];
         tw2_lds[tid] = a.tw256[tid];
     }
-    if (tid < kScopeTraces) trig[tid] = a.trig[(uint64_t)s * kScopeTraces + tid];
+    // ragged banks: the stream's own block count, ring positions and reset flag (workgroup-uniform: one workgroup per stream)
+    const bool ragged = a.blocks_v != nullptr;
+    const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;  // clear_history (:714-723) of this stream
+    const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
+    if (tid < kScopeTraces) {
+        ScopeTriggerState t0;
+        memset(&t0, 0, sizeof(t0));
+        trig[tid] = reset_stream ? t0 : a.trig[(uint64_t)s * kScopeTraces + tid];
+    }
     __syncthreads();
     const uint64_t mask = a.cap - 1;
     float* rings = a.rings + (uint64_t)s * kScopeTraces * a.cap;
     const float* pcm = a.pcm + (uint64_t)s * a.frames_total * a.fmt.channels;
     uint64_t head[kScopeTraces], len[kScopeTraces];
     for (int t = 0; t < kScopeTraces; ++t) {
-        head[t] = a.head[t];
-        len[t] = a.len[t];
+        head[t] = ragged ? a.pos_v[((uint64_t)s * kScopeTraces + t) * 2] : a.head[t];
+        len[t] = ragged ? (reset_stream ? 0ull : a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1]) : a.len[t];
     }
     const bool active[2] = {a.trace_channel[0] != OMX_CHANNEL_NONE, a.trace_channel[1] != OMX_CHANNEL_NONE};
 
     PhaseClock pc;
     pc.start(a.phase_timing != 0);
-    for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
+    for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
         // ---- push projected frames (:657-681); the two-pass form pushed every block of the call up front
         for (uint32_t f = tid; f < (a.estimates ? 0u : a.block_frames); f += 256) {
             const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
@@ -969,7 +977,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
             hdr.produced = 1;
             hdr.capture_start = caps[0].some ? caps[0].start : caps[1].start;
             hdr.capture_frac = caps[0].some ? caps[0].frac_offset : caps[1].frac_offset;
-            const bool newest = blk + 1 == a.n_blocks;
+            const bool newest = blk + 1 == n_blocks_s;
             for (int slot = 0; slot < 2; ++slot) {
                 if (!caps[slot].some) continue;
                 const View& tr = views[slot];
@@ -1004,6 +1012,13 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         pc.mark(5);  // snapshot
     }
     if (tid < kScopeTraces) a.trig[(uint64_t)s * kScopeTraces + tid] = trig[tid];
+    if (ragged && tid == 0) {
+        for (int t = 0; t < kScopeTraces; ++t) {
+            a.pos_v[((uint64_t)s * kScopeTraces + t) * 2] = head[t];
+            a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1] = len[t];
+        }
+        if (reset_stream) a.epoch_v[s] += 1;
+    }
 }
 
 // ---- two-pass form ---------------------------------------------------------------------------------------------------------

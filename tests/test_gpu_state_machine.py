@@ -488,3 +488,90 @@ def test_ragged_loudness_bank_random_per_stream_block_counts_match_per_stream_or
     assert bank.process_host(chunk, block, C, rate, positions) is not None
     fresh = LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate))
     snapshots_close(bank.fetch(2, 0), fresh.process_block(AudioBlock(chunk[2].reshape(-1), C, rate, positions)))
+
+
+@pytest.mark.parametrize("seed,mode", [(1, capi.TRIGGER_STABLE), (2, capi.TRIGGER_STABLE), (3, capi.TRIGGER_ZERO_CROSSING)])
+def test_ragged_oscilloscope_bank_random_per_stream_block_counts_match_per_stream_processors(omx, oracle, seed, mode):
+    """Per-stream independence of the oscilloscope bank: every stream gets its own random block counts and its own reset_audio()
+    calls.  Stream s must equal a single-stream HIP handle fed the same blocks BIT FOR BIT (same kernel, one block per call: header
+    fields, capture position, period, the newest snapshot's samples, the epoch) — the handle itself is pinned against the oracle
+    elsewhere — and the oracle fed the same sequence must agree on which blocks produce a snapshot, on its shape and on the lock
+    state.  Two lock-step calls first: the switch to per-stream ring positions carries the common state over."""
+    import torch
+    from openmeters_amd.capi import OscilloscopeConfig, OscilloscopeProcessor
+    rng = np.random.default_rng(500 + seed)
+    S, calls, max_blocks, block = 5, 12, 6, 256
+    cfg = OscilloscopeConfig(segment_duration=0.02, trigger_mode=mode, num_cycles=2,
+                             trigger_source=capi.CH_LEFT if mode == capi.TRIGGER_STABLE else capi.CH_NONE, channel_1=capi.CH_LEFT,
+                             channel_2=capi.CH_MID)
+    pos = capi.positions_fallback(2)
+    bank = banks.OscilloscopeBank(omx, cfg, S)
+    hips = [OscilloscopeProcessor(omx, cfg) for _ in range(S)]
+    refs = [OscilloscopeProcessor(oracle, cfg) for _ in range(S)]
+    total = block * (2 * 10 + calls * max_blocks)
+    feeds = []
+    for s in range(S):
+        t = np.arange(total) / 48000.0
+        f = 110.0 * 2.0 ** (s / 3.0)
+        left = 0.6 * np.sin(2 * np.pi * f * t) + 0.2 * np.sin(2 * np.pi * 2 * f * t + 0.3 * s) + 0.003 * rng.standard_normal(total)
+        feeds.append(np.stack([left, -0.5 * left], 1).astype(np.float32))
+    at = [0] * S
+
+    def feed_singles(s, blk):
+        g = hips[s].process_block(AudioBlock(blk.reshape(-1), 2, 48000.0))
+        w = refs[s].process_block(AudioBlock(blk.reshape(-1), 2, 48000.0))
+        return g, w
+
+    for n in (10, 10):   # lock-step
+        chunk = np.stack([f[a:a + n * block] for f, a in zip(feeds, at)])
+        bank.process_host(chunk, block, 2, 48000.0)
+        for s in range(S):
+            for k in range(n):
+                feed_singles(s, chunk[s, k * block:(k + 1) * block])
+            at[s] += n * block
+    compared = produced = 0
+    epochs = [0] * S
+    for call in range(calls):
+        nb = rng.integers(0, max_blocks + 1, S)
+        nb[rng.integers(0, S)] = 0
+        mask = (rng.random(S) < 0.12).astype(np.uint8)
+        pcm = np.zeros((S, max_blocks * block, 2), np.float32)
+        for s in range(S):
+            pcm[s, :nb[s] * block] = feeds[s][at[s]:at[s] + nb[s] * block]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), block, max_blocks, nb, 2, 48000.0, pos, mask)
+        torch.cuda.synchronize()
+        if int(nb.max()) == 0 and not mask.any():
+            continue
+        got_epochs = _dev(torch, up.d_epochs, (S, 2)).cpu().numpy()[:, 0]   # u64 as two u32 words
+        for s in range(S):
+            if mask[s]:
+                hips[s].reset_audio()
+                refs[s].reset_audio()
+                epochs[s] += 1
+            last = None
+            for k in range(int(nb[s])):
+                g, w = feed_singles(s, pcm[s, k * block:(k + 1) * block])
+                hdr, _ = bank.fetch(s, k)
+                assert bool(hdr.produced) == (g is not None) == (w is not None), (call, s, k)
+                assert bool(hdr.locked) == (hips[s].last_cycle_rate() is not None) == (refs[s].last_cycle_rate() is not None), (call, s, k)
+                if g is not None:
+                    assert (hdr.channels, hdr.samples_per_channel) == (g.channels, g.samples_per_channel) == (w.channels, w.samples_per_channel)
+                    assert (hdr.capture_start, hdr.capture_frac) == hips[s].last_capture(), (call, s, k)
+                    produced += 1
+                    last = g
+                compared += 1
+            if last is not None and bank.fetch(s, int(nb[s]) - 1)[0].produced:
+                hdr, samples = bank.fetch(s, int(nb[s]) - 1, with_samples=True)
+                n = hdr.samples_per_channel
+                got = np.concatenate([samples[c, :n] for c in range(hdr.channels)])
+                assert np.array_equal(got.view(np.uint32), last.samples.view(np.uint32)), (call, s)
+            at[s] += int(nb[s]) * block
+        base = [int(e) - epochs[i] for i, e in enumerate(got_epochs)]
+        assert len(set(base)) == 1, base   # every stream: the bank's epoch at the switch + its own resets
+    assert compared > 80 and produced > 40
+    chunk = np.stack([f[:block] for f in feeds])
+    with pytest.raises(capi.OmxError):
+        bank.process_host(chunk, block, 2, 48000.0)
+    bank.reset_audio()
+    bank.process_host(chunk, block, 2, 48000.0)
