@@ -461,6 +461,26 @@ int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int 
                                  uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                                  float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
                                  void* stream, omx_stereometer_bank_update* out);
+/* Ragged call — one StereometerProcessor per capture, fed and reset on its own (registry.rs:396-418): stream s runs
+ * n_blocks[s] <= max_blocks blocks of block_frames frames; its row of `pcm` (device memory) is block_frames * max_blocks frames long.
+ * Streams flagged in reset_mask (may be NULL) get reset_audio() first.  d_correlations is [n_streams][max_blocks][4] and d_produced
+ * [n_streams][max_blocks], of which stream s filled the first d_n_blocks[s]; d_points [n_streams][4][target][2] holds, for every
+ * stream whose last block of the call produced a snapshot, the bands flagged in d_band_valid [n_streams][4].  The first ragged call
+ * moves the bank to per-stream history positions; lock-step omx_stereometer_bank_process calls — and a change of the segment length —
+ * are refused until omx_stereometer_bank_reset_audio. */
+typedef struct omx_stereometer_ragged_update {
+    uint64_t n_streams;
+    uint64_t max_blocks;
+    uint64_t target;
+    const uint32_t* d_n_blocks;
+    const float* d_correlations;
+    const uint32_t* d_produced;
+    const float* d_points;
+    const uint32_t* d_band_valid;
+} omx_stereometer_ragged_update;
+int omx_stereometer_bank_process_ragged(omx_stereometer_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
+                                        const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                        const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_stereometer_ragged_update* out);
 int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block,
                                float correlations[4], uint32_t* produced);
 /* decimated points of one band of the newest snapshot (`stereometer/processor.rs:152-170`) -> dst[2 * n_pairs] (l, r);

@@ -252,6 +252,11 @@ class LoudnessBank(_BlockBank):
         return ms.value, n.value
 
 
+class CStereometerRaggedUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("target", C.c_uint64), ("d_n_blocks", C.c_void_p),
+                ("d_correlations", C.c_void_p), ("d_produced", C.c_void_p), ("d_points", C.c_void_p), ("d_band_valid", C.c_void_p)]
+
+
 class StereometerBank(_BlockBank):
     """reference src/visuals/stereometer/processor.rs:64-208, S streams in lock-step."""
     _family = "stereometer"
@@ -278,6 +283,21 @@ class StereometerBank(_BlockBank):
 
     def set_option(self, option, value):
         self.api.check(self.api.fn("stereometer_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
+
+    def process_ragged(self, device_ptr: int, block_frames: int, max_blocks: int, n_blocks: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """Streams advance independently: stream s runs n_blocks[s] (<= max_blocks) blocks of block_frames frames, after reset_audio()
+        when reset_mask[s]; pcm = device f32 [n_streams][block_frames * max_blocks][channels].  fetch(s, k) for k < n_blocks[s];
+        fetch_points(s, band) returns the points of the stream's last block when it produced a snapshot (else none)."""
+        out = CStereometerRaggedUpdate()
+        nb = np.ascontiguousarray(n_blocks, np.uint32)
+        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        f = self.api.fn("stereometer_bank_process_ragged", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
+                         C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), block_frames, max_blocks, nb.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
 
     def fetch_points(self, stream_index, band, capacity=4096):
         buf = np.zeros((capacity, 2), np.float32)

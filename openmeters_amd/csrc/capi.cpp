@@ -481,6 +481,15 @@ int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b) {
         return (int)OMX_NONE;
     });
 }
+int omx_stereometer_bank_process_ragged(omx_stereometer_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
+                                        const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                        const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_stereometer_ragged_update* out) {
+    if (!b || !pcm || !n_blocks || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_ragged(pcm, block_frames, max_blocks, n_blocks, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int pcm_on_device, uint64_t block_frames,
                                  uint64_t n_blocks, uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
                                  void* stream, omx_stereometer_bank_update* out) {

@@ -50,6 +50,7 @@ void StereometerBank::init(const omx_stereometer_config& in) {  // ::new (:75-86
     cfg_._pad = 0;
     history_channels_ = 0;
     for (int b = 0; b < 4; ++b) hist_len_[b] = hist_pos_[b] = 0;
+    ragged_zero_mask_ |= 0xFu;
     alpha_ = ema_alpha(cfg_.sample_rate, cfg_.correlation_window);
     pending_full_reset_ = true;
 }
@@ -102,6 +103,8 @@ static std::vector<double> band_transitions(const BiquadCoef& lp_lo, const Biqua
 void StereometerBank::reset_audio() {  // :92-97
     for (int b = 0; b < 4; ++b) hist_len_[b] = 0;
     pending_full_reset_ = true;  // band_splitter.clear() + correlators = default
+    ragged_ = false;             // every deque is empty: the (lock-step) host positions serve again
+    ragged_zero_mask_ = 0;
 }
 
 void StereometerBank::update_config(const omx_stereometer_config& in) {  // :183-207
@@ -119,13 +122,42 @@ void StereometerBank::update_config(const omx_stereometer_config& in) {  // :183
         if (window_changed) alpha_ = ema_alpha(cfg.sample_rate, cfg.correlation_window);
         if (bands_changed) pending_band_reset_ = true;  // new splitter + correlators[1..] = default
     }
-    if (!cfg.emit_band_points)
+    if (!cfg.emit_band_points) {
         for (int b = 1; b < 4; ++b) hist_len_[b] = 0;
+        ragged_zero_mask_ |= 0xEu;
+    }
 }
 
 int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
                              float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                              omx_stereometer_bank_update* out) {  // :99-182
+    if (ragged_) {
+        set_last_error("stereometer bank: per-stream positions are in use (process_ragged); reset_audio() returns the bank to lock-step calls");
+        return OMX_ERR_INVALID;
+    }
+    return process_impl(pcm, pcm_on_device, block_frames, n_blocks, channels_in, sample_rate_in, positions, stream, out, nullptr);
+}
+
+int StereometerBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks,
+                                    const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                    const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_stereometer_ragged_update* out) {
+    bool any = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (n_blocks[s] > max_blocks) {
+            set_last_error("stereometer process_ragged: n_blocks[s] > max_blocks");
+            return OMX_ERR_INVALID;
+        }
+        any = any || n_blocks[s] != 0 || (reset_mask && reset_mask[s]);
+    }
+    last_stream_ = stream;
+    if (!any || block_frames == 0) return OMX_NONE;
+    const RaggedCall rc{n_blocks, reset_mask, out};
+    return process_impl(d_pcm, true, block_frames, std::max<uint64_t>(max_blocks, 1), channels, sample_rate, positions, stream, nullptr, &rc);
+}
+
+int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
+                                  float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                  omx_stereometer_bank_update* out, const RaggedCall* ragged) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
     if (block_frames == 0 || n_blocks == 0) return OMX_NONE;
@@ -138,6 +170,7 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
     }
     if (history_channels_ != channels) {
         hist_len_[0] = 0;
+        ragged_zero_mask_ |= 1u;
         history_channels_ = channels;
     }
     const uint32_t frames = segment_frames();
@@ -146,6 +179,8 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
         history_.reserve((size_t)n_streams_ * 4 * frames * 2);
         OMX_HIP(hipMemsetAsync(history_.ptr, 0, history_.count * sizeof(float), stream));
         for (int b = 0; b < 4; ++b) hist_len_[b] = hist_pos_[b] = 0;
+    } else if (frames != hist_frames_ && ragged_) {
+        unsupported("stereometer: the segment length changed while the bank holds per-stream history positions (reset_audio first)");
     } else if (frames != hist_frames_) {
         // the deques survive a segment-length change (:183-207) and are trimmed to the new length (:146-150): carry the newest
         // min(len, frames) pairs of every band into a ring of the new length
@@ -201,7 +236,7 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
     sa.correlations = correlations_.ptr;
     // chunk-parallel evaluation for bank-sized calls (stereometer_chunked.hip); everything else — single-stream handles, short
     // calls, other channel counts — stays on the sequential kernels, whose results are bit-identical to the reference's order
-    const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
+    const bool shape_ok = !ragged && channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
     const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && (uint64_t)n_streams_ * n_blocks >= 512));
     if (chunked) {
         if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
@@ -247,6 +282,76 @@ int StereometerBank::process(const float* pcm, bool pcm_on_device, uint64_t bloc
         // sequential kernel then redoes the whole call from the saved state (it exits at once when the flag is clear)
         sa.run_if = bad_.ptr;
         sa.state_in = state_backup_.ptr;
+    }
+    if (ragged) {
+        if (!ragged_) {  // every stream starts from the bank's common positions and lengths
+            std::vector<uint64_t> pos((size_t)n_streams_ * 4), len((size_t)n_streams_ * 4);
+            for (uint32_t s = 0; s < n_streams_; ++s)
+                for (int b = 0; b < 4; ++b) {
+                    pos[(size_t)s * 4 + b] = hist_pos_[b];
+                    len[(size_t)s * 4 + b] = hist_len_[b];
+                }
+            r_pos_.upload(pos, stream);
+            r_len_.upload(len, stream);
+            ragged_ = true;
+            ragged_zero_mask_ = 0;  // (the host lengths just uploaded already carry it)
+        }
+        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
+        r_blocks_host_.reserve(n_streams_);
+        r_mask_host_.reserve(n_streams_);
+        r_blocks_.reserve(n_streams_);
+        r_mask_.reserve(n_streams_);
+        r_start_.reserve((size_t)n_streams_ * 4);
+        r_valid_.reserve((size_t)n_streams_ * 4);
+        for (uint32_t s = 0; s < n_streams_; ++s) {
+            r_blocks_host_.ptr[s] = ragged->n_blocks[s];
+            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
+        }
+        OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        produced_.reserve((size_t)(n_streams_ * n_blocks));
+        StereoPlanArgs pa{};
+        pa.n_streams = n_streams_;
+        pa.max_blocks = (uint32_t)n_blocks;
+        pa.block_frames = (uint32_t)block_frames;
+        pa.hist_frames = frames;
+        pa.analyze_bands = cfg_.analyze_bands;
+        pa.emit_band_points = cfg_.emit_band_points;
+        pa.blocks = r_blocks_.ptr;
+        pa.reset = r_mask_.ptr;
+        pa.pos = r_pos_.ptr;
+        pa.len = r_len_.ptr;
+        pa.start = r_start_.ptr;
+        pa.produced = produced_.ptr;
+        pa.band_valid = r_valid_.ptr;
+        pa.zero_len_mask = ragged_zero_mask_;
+        ragged_zero_mask_ = 0;
+        launch_stereometer_ragged_plan(pa, stream);
+        OMX_HIP(hipGetLastError());
+        sa.blocks_v = r_blocks_.ptr;
+        sa.reset_v = r_mask_.ptr;
+        sa.start_v = r_start_.ptr;
+        OMX_HIP(hipMemsetAsync(correlations_.ptr, 0, (size_t)(n_streams_ * n_blocks * 4) * sizeof(float), stream));  // slots past a stream's own blocks
+        launch_stereometer(sa, stream);
+        OMX_HIP(hipGetLastError());
+        const uint32_t target = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cfg_.target_sample_count, 1), frames);  // :152
+        last_target_ = target;
+        last_blocks_ = n_blocks;
+        produced_host_.clear();
+        points_.reserve((size_t)n_streams_ * 4 * target * 2, false);
+        launch_stereometer_points_ragged(history_.ptr, n_streams_, frames, r_pos_.ptr, r_valid_.ptr, target, points_.ptr, stream);
+        OMX_HIP(hipGetLastError());
+        if (ragged->out) {
+            ragged->out->n_streams = n_streams_;
+            ragged->out->max_blocks = n_blocks;
+            ragged->out->target = target;
+            ragged->out->d_n_blocks = r_blocks_.ptr;
+            ragged->out->d_correlations = correlations_.ptr;
+            ragged->out->d_produced = produced_.ptr;
+            ragged->out->d_points = points_.ptr;
+            ragged->out->d_band_valid = r_valid_.ptr;
+        }
+        return OMX_PRODUCED;
     }
     launch_stereometer(sa, stream);
     OMX_HIP(hipGetLastError());
@@ -299,13 +404,18 @@ int StereometerBank::fetch(uint64_t stream_index, uint64_t block, float correlat
         return OMX_ERR_INVALID;
     }
     copy_out(correlations, correlations_.ptr + (stream_index * last_blocks_ + block) * 4, 4 * sizeof(float), correlations_.pinned, stream);
-    if (produced) *produced = produced_host_[block];
+    if (produced) {
+        if (ragged_) copy_out(produced, produced_.ptr + stream_index * last_blocks_ + block, sizeof(uint32_t), false, stream);
+        else *produced = produced_host_[block];
+    }
     return OMX_NONE;
 }
 
 int StereometerBank::fetch_points(uint64_t stream_index, uint32_t band, float* dst, uint64_t* n_pairs, hipStream_t stream) {
     if (stream_index >= n_streams_ || band >= 4) return OMX_ERR_INVALID;
-    if (!band_valid_[band]) {
+    uint32_t valid = band_valid_[band];
+    if (ragged_) copy_out(&valid, r_valid_.ptr + stream_index * 4 + band, sizeof(uint32_t), false, stream);  // per stream
+    if (!valid) {
         *n_pairs = 0;
         return OMX_NONE;
     }

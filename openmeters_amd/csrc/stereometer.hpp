@@ -34,8 +34,30 @@ struct StereometerArgs {
     // fallback of the chunk-parallel path (stereometer_chunked.hip): run only when *run_if != 0, starting from state_in
     const uint32_t* run_if;
     const StereoLaneState* state_in;
+    // ragged banks (per-stream block counts; nullptr = lock-step; the four-wavefront kernel only): stream s runs blocks_v[s] <= n_blocks
+    // blocks, its history rings start at start_v[s][band] (hist_pos above is then unused), its state is cleared first when reset_v[s]
+    const uint32_t* blocks_v;
+    const uint8_t* reset_v;
+    const uint64_t* start_v;  // [n_streams][4], written by stereometer_ragged_plan_kernel
 };
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream);
+// ragged banks: the bookkeeping of one call for every stream (one lane per stream) — the positions its history pushes start from, the
+// new positions and VecDeque lengths (:116, :129, :146-150), the per-block `produced` flags and the bands whose points the call's
+// last block yields (:152-170)
+struct StereoPlanArgs {
+    uint32_t n_streams, max_blocks, block_frames, hist_frames, analyze_bands, emit_band_points;
+    const uint32_t* blocks;   // [n_streams]
+    const uint8_t* reset;     // [n_streams]
+    uint64_t* pos;            // [n_streams][4] in / out
+    uint64_t* len;            // [n_streams][4] in / out
+    uint64_t* start;          // [n_streams][4] out
+    uint32_t* produced;       // [n_streams][max_blocks] out
+    uint32_t* band_valid;     // [n_streams][4] out
+    uint32_t zero_len_mask;   // bands whose deques a config change emptied since the last call
+};
+void launch_stereometer_ragged_plan(const StereoPlanArgs& a, hipStream_t stream);
+void launch_stereometer_points_ragged(const float* history, uint32_t n_streams, uint32_t hist_frames, const uint64_t* pos_v,
+                                      const uint32_t* band_valid_v, uint32_t target, float* points, hipStream_t stream);
 
 // ---- chunk-parallel evaluation (stereometer_chunked.hip): one chunk = one block of the call, 2-channel input
 struct StereoChunkArgs {
@@ -76,6 +98,12 @@ public:
     int process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                 omx_stereometer_bank_update* out);
+    // Ragged call (include/omx.h: omx_stereometer_bank_process_ragged): stream s runs n_blocks[s] <= max_blocks blocks (its rows of `d_pcm`
+    // are block_frames * max_blocks frames apart); streams flagged in reset_mask get reset_audio() first.  The per-stream history
+    // positions and lengths then live on the device; the bank stays ragged until reset_audio() of the whole bank.
+    int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
+                       uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                       omx_stereometer_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t block, float correlations[4], uint32_t* produced, hipStream_t stream);
     int fetch_points(uint64_t stream_index, uint32_t band, float* dst, uint64_t* n_pairs, hipStream_t stream);
     hipStream_t last_stream() const { return last_stream_; }
@@ -84,6 +112,13 @@ public:
 private:
     void init(const omx_stereometer_config& cfg);
     void clear_filters(hipStream_t stream, bool bands_only);
+    struct RaggedCall {
+        const uint32_t* n_blocks;
+        const uint8_t* reset_mask;
+        omx_stereometer_ragged_update* out;
+    };
+    int process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels, float sample_rate,
+                     const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_stereometer_bank_update* out, const RaggedCall* ragged);
     uint32_t segment_frames() const;
 
     omx_stereometer_config cfg_{};
@@ -108,6 +143,14 @@ private:
     DeviceBuffer<double> chunk_moments_, transition_;
     DeviceBuffer<uint32_t> bad_;
     DeviceBuffer<StereoLaneState> state_backup_;
+    // ragged mode: per-stream history positions / lengths on the device
+    bool ragged_ = false;
+    uint32_t ragged_zero_mask_ = 0;  // bands whose deques a config change emptied (applied by the next plan kernel)
+    DeviceBuffer<uint64_t> r_pos_, r_len_, r_start_;
+    DeviceBuffer<uint32_t> r_blocks_, r_valid_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_blocks_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows (OMX_OPT_KERNEL_FORM)

@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path: nothing non-finite was seen
     const uint32_t gid = s * 4 + band;  // state / history / output slot of this (stream, band)
     const bool active = band == 0 || a.analyze_bands != 0;
+    // ragged banks: the stream's own block count, ring start and reset flag (lane = stream: per-lane values, the block loop below
+    // then has a per-lane trip count)
+    const bool ragged = a.blocks_v != nullptr;
+    const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
     StereoLaneState st_mem = (a.state_in ? a.state_in : a.state)[gid];
+    if (ragged && a.reset_v != nullptr && a.reset_v[s] != 0) memset(&st_mem, 0, sizeof(st_mem));  // reset_audio (:92-97) of this stream
     StereoRegs st = load_regs(st_mem);
     const BiquadCoef ca = a.stage_a[band], cb = a.stage_b[band];
     const bool use_a = a.use_a[band] != 0, use_b = a.use_b[band] != 0;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     const uint32_t channels = CH ? (uint32_t)CH : a.fmt.channels;
     const float* pcm = a.pcm + (uint64_t)s * a.frames_total * channels;
     float* hist = a.history + ((uint64_t)s * 4 + band) * a.hist_frames * 2;
-    uint32_t slot = (uint32_t)(a.hist_pos[band] % a.hist_frames);  // ring slot advanced with a 32-bit compare, not a 64-bit modulo
+    uint32_t slot = (uint32_t)((ragged ? a.start_v[gid] : a.hist_pos[band]) % a.hist_frames);  // ring slot advanced with a 32-bit compare, not a 64-bit modulo
     const double alpha = a.alpha;
     constexpr int BATCH = 8;  // frames whose loads are issued together
 
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
         }
     };
     const bool contiguous_batches = a.block_frames % BATCH == 0;
-    for (uint32_t blk = 0; blk < a.n_blocks; ++blk) {
+    for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
         if (active) {
             const float* base = pcm + (uint64_t)blk * a.block_frames * channels;
             uint32_t f = 0;
@@ -506,7 +511,7 @@ void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     const uint32_t groups = (a.n_streams + 63) / 64;
     static const bool no_roles = [] { const char* e = getenv("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
-    if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles && !a.run_if)
+    if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles && !a.run_if && !a.blocks_v)
     {
         const size_t lds = (size_t)4 * kStereoRound * 64 * sizeof(v2f);  // 64 KiB
         static bool attr_set = false;
@@ -529,15 +534,18 @@ struct PointsArgs {
     uint64_t hist_pos[4];
     uint32_t band_valid[4];
     float* points;
+    const uint64_t* pos_v;         // ragged banks: [n_streams][4] positions and validity per stream (else nullptr)
+    const uint32_t* band_valid_v;
 };
 __global__ __launch_bounds__(256) void stereometer_points_kernel(PointsArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t band = blockIdx.y, s = blockIdx.z;
-    if (i >= a.target || !a.band_valid[band]) return;
+    const bool valid = a.band_valid_v ? a.band_valid_v[s * 4 + band] != 0 : a.band_valid[band] != 0;
+    if (i >= a.target || !valid) return;
     // data = the newest hist_frames pairs, oldest first; pick data[i * frames / target] (:163-168)
     const uint64_t frames = a.hist_frames;
     const uint64_t idx = (uint64_t)i * frames / a.target;
-    const uint64_t oldest = a.hist_pos[band] - frames;
+    const uint64_t oldest = (a.pos_v ? a.pos_v[s * 4 + band] : a.hist_pos[band]) - frames;
     const float* hist = a.history + ((uint64_t)s * 4 + band) * frames * 2;
     const uint64_t slot = (oldest + idx) % frames;
     float l = hist[slot * 2], r = hist[slot * 2 + 1];
@@ -564,6 +572,51 @@ void launch_stereometer_points(const float* history, uint32_t n_streams, uint32_
     }
     a.points = points;
     hipLaunchKernelGGL(stereometer_points_kernel, dim3((target + 255) / 256, 4, n_streams), dim3(256), 0, stream, a);
+}
+
+void launch_stereometer_points_ragged(const float* history, uint32_t n_streams, uint32_t hist_frames, const uint64_t* pos_v,
+                                      const uint32_t* band_valid_v, uint32_t target, float* points, hipStream_t stream) {
+    if (n_streams == 0 || target == 0) return;
+    PointsArgs a{};
+    a.history = history;
+    a.n_streams = n_streams;
+    a.hist_frames = hist_frames;
+    a.target = target;
+    a.points = points;
+    a.pos_v = pos_v;
+    a.band_valid_v = band_valid_v;
+    hipLaunchKernelGGL(stereometer_points_kernel, dim3((target + 255) / 256, 4, n_streams), dim3(256), 0, stream, a);
+}
+
+__global__ __launch_bounds__(64) void stereometer_ragged_plan_kernel(StereoPlanArgs a) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= a.n_streams) return;
+    const bool reset = a.reset != nullptr && a.reset[s] != 0;
+    const uint32_t nb = a.blocks[s];
+    const uint64_t frames = a.hist_frames, pushed = (uint64_t)nb * a.block_frames;
+    uint64_t len0 = (reset || (a.zero_len_mask & 1u)) ? 0ull : a.len[s * 4];
+    for (uint32_t blk = 0; blk < a.max_blocks; ++blk) {  // :116, :129, :146-150: produced iff the full-band deque is full
+        if (blk < nb) len0 = min(len0 + (uint64_t)a.block_frames, frames);
+        a.produced[(uint64_t)s * a.max_blocks + blk] = (blk < nb && len0 >= frames) ? 1u : 0u;
+    }
+    const bool produced_last = nb != 0 && len0 >= frames;
+    for (uint32_t b = 0; b < 4; ++b) {
+        uint64_t len = (reset || ((a.zero_len_mask >> b) & 1u)) ? 0ull : a.len[s * 4 + b];
+        const uint64_t pos = a.pos[s * 4 + b];
+        a.start[s * 4 + b] = pos;
+        const bool pushes = b == 0 || (a.analyze_bands != 0 && a.emit_band_points != 0);
+        if (pushes) {
+            a.pos[s * 4 + b] = pos + pushed;
+            len = min(len + pushed, frames);
+        }
+        a.len[s * 4 + b] = len;
+        const bool in_play = b == 0 || a.emit_band_points != 0;
+        a.band_valid[s * 4 + b] = (produced_last && in_play && len >= frames) ? 1u : 0u;
+    }
+}
+void launch_stereometer_ragged_plan(const StereoPlanArgs& a, hipStream_t stream) {
+    if (a.n_streams == 0) return;
+    hipLaunchKernelGGL(stereometer_ragged_plan_kernel, dim3((a.n_streams + 63) / 64), dim3(64), 0, stream, a);
 }
 
 struct RehomeArgs {

@@ -8,7 +8,7 @@ from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
                                  SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
                                  WaveformProcessor)
-from parity import check_classic, classic_column_metrics, reassigned_column_metrics
+from parity import bar, check_classic, classic_column_metrics, reassigned_column_metrics
 from test_gpu_parity import check_trace
 
 pytestmark = pytest.mark.gpu
@@ -575,3 +575,78 @@ def test_ragged_oscilloscope_bank_random_per_stream_block_counts_match_per_strea
         bank.process_host(chunk, block, 2, 48000.0)
     bank.reset_audio()
     bank.process_host(chunk, block, 2, 48000.0)
+
+
+@pytest.mark.parametrize("seed,C,bands,points", [(1, 2, True, True), (2, 2, True, False), (3, 2, False, False), (4, 6, True, True)])
+def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, bands, points):
+    """Per-stream independence of the stereometer bank: every stream gets its own random block counts and its own reset_audio()
+    calls; stream s must behave like a single StereometerProcessor fed the same blocks — `produced` per block (the history deque
+    fills per stream), correlations at the 1e-6 bar, the points of the stream's last block bit-exact (per-stream ring positions),
+    filters / correlators carried per stream and cleared by the stream's own reset only.  Two lock-step calls first."""
+    import torch
+    from openmeters_amd.capi import StereometerConfig, StereometerProcessor
+    rng = np.random.default_rng(700 + seed)
+    S, calls, max_blocks, block = 5, 14, 5, 256
+    cfg = StereometerConfig(analyze_bands=bands, emit_band_points=points, correlation_window=0.05, segment_duration=0.02, target_sample_count=300)
+    pos = capi.SURROUND[:C] + [0] * (8 - C) if C != 2 else capi.positions_fallback(2)
+    bank = banks.StereometerBank(omx, cfg, S)
+    refs = [StereometerProcessor(oracle, cfg) for _ in range(S)]
+    total = block * (2 * 3 + calls * max_blocks)
+    feeds = []
+    for s in range(S):
+        t = np.arange(total) / 48000.0
+        base = 0.5 * np.sin(2 * np.pi * (150.0 + 333.0 * s) * t) + 0.2 * np.sin(2 * np.pi * (2500.0 + 100.0 * s) * t + s)
+        x = np.stack([base * (1.0 - 0.1 * c) * (-1.0 if c % 2 else 1.0) + 0.01 * rng.standard_normal(total) for c in range(C)], 1)
+        feeds.append(x.astype(np.float32))
+    at = [0] * S
+
+    def check(s, k, w, last_in_call):
+        corr, produced = bank.fetch(s, k)
+        assert produced == (w is not None), (s, k)
+        if w is not None:
+            bar("stereometer (ragged bank): |d rho|", np.abs(corr - w.correlations).max(), 1e-6)
+            if last_in_call:
+                for b in range(4):
+                    got = bank.fetch_points(s, b)
+                    want = w.points[b] if b < len(w.points) and w.points[b] is not None else np.zeros((0, 2), np.float32)
+                    assert got.shape == np.asarray(want).reshape(-1, 2).shape, (s, k, b, got.shape)
+                    if b == 0:
+                        assert np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).reshape(-1, 2).view(np.uint32)), (s, k, b)
+                    elif got.size:
+                        bar("stereometer (ragged bank): |d band point|", np.abs(got - np.asarray(want).reshape(-1, 2)).max(), 1e-6)
+
+    for n in (3, 3):
+        chunk = np.stack([f[a:a + n * block] for f, a in zip(feeds, at)])
+        bank.process_host(chunk, block, C, 48000.0, pos)
+        for s in range(S):
+            for k in range(n):
+                w = refs[s].process_block(AudioBlock(chunk[s, k * block:(k + 1) * block].reshape(-1), C, 48000.0, pos))
+            at[s] += n * block
+    compared = produced_n = 0
+    for call in range(calls):
+        nb = rng.integers(0, max_blocks + 1, S)
+        nb[rng.integers(0, S)] = 0
+        mask = (rng.random(S) < 0.15).astype(np.uint8)
+        pcm = np.zeros((S, max_blocks * block, C), np.float32)
+        for s in range(S):
+            pcm[s, :nb[s] * block] = feeds[s][at[s]:at[s] + nb[s] * block]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), block, max_blocks, nb, C, 48000.0, pos, mask)
+        torch.cuda.synchronize()
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            for k in range(int(nb[s])):
+                w = refs[s].process_block(AudioBlock(pcm[s, k * block:(k + 1) * block].reshape(-1), C, 48000.0, pos))
+                check(s, k, w, k == int(nb[s]) - 1)
+                compared += 1
+                produced_n += int(w is not None)
+            if int(nb[s]) == 0 and (int(nb.max()) > 0 or mask.any()):
+                assert bank.fetch_points(s, 0).shape[0] == 0      # no block, no snapshot
+            at[s] += int(nb[s]) * block
+    assert compared > 100 and produced_n > 40
+    chunk = np.stack([f[:block] for f in feeds])
+    with pytest.raises(capi.OmxError):
+        bank.process_host(chunk, block, C, 48000.0, pos)
+    bank.reset_audio()
+    bank.process_host(chunk, block, C, 48000.0, pos)
