@@ -597,6 +597,25 @@ int omx_waveform_bank_reset_audio(omx_waveform_bank* b);
 int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on_device, uint64_t frames,
                               uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
                               void* stream, omx_waveform_bank_update* out);
+/* Ragged call — one WaveformProcessor per capture, fed and reset on its own (registry.rs:396-418): stream s receives
+ * frames[s] <= frames_capacity frames; its row of `pcm` (device memory) is frames_capacity frames long.  Streams flagged in reset_mask
+ * (may be NULL) get reset_audio() first (d_reset[s] = 1: the consumer clears its history, as for `reset` of the lock-step update).
+ * d_columns is [n_streams][max_columns][4], of which stream s filled the first d_n_columns[s]; d_preview [n_streams][4] is valid where
+ * d_preview_progress[s] > 0.  frames_capacity must be small enough that a call cannot emit more than the configuration's max_columns
+ * columns.  The first ragged call moves the bank to per-stream push counts and column phases; lock-step omx_waveform_bank_process
+ * calls are refused until omx_waveform_bank_reset_audio. */
+typedef struct omx_waveform_ragged_update {
+    uint64_t n_streams;
+    uint64_t max_columns;
+    const uint32_t* d_n_columns;
+    const omx_wave_column* d_columns;
+    const omx_wave_column* d_preview;
+    const float* d_preview_progress;
+    const uint8_t* d_reset;
+} omx_waveform_ragged_update;
+int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                     const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_waveform_ragged_update* out);
 int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns /* [n_columns][4] */,
                             omx_wave_column* preview /* [4] or NULL */);
 

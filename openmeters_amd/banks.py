@@ -403,6 +403,20 @@ class WaveformBank(_BlockBank):
         positions = positions if positions is not None else capi.positions_fallback(channels)
         return self._process(pcm.ctypes.data, False, pcm.shape[1], channels, sample_rate, positions, 0)
 
+    def process_ragged(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """Streams advance independently: stream s receives frames[s] (<= frames_capacity) new frames, after reset_audio() when
+        reset_mask[s]; pcm = device f32 [n_streams][frames_capacity][channels].  Returns the CWaveformRaggedUpdate; columns of stream
+        s: fetch(s, update.max_columns)[0][:n_columns[s]]."""
+        out = capi.CWaveformRaggedUpdate()
+        fr = np.ascontiguousarray(frames, np.uint32)
+        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        f = self.api.fn("waveform_bank_process_ragged", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
     def fetch(self, stream_index, n_columns, with_preview=False):
         cols = np.zeros((max(n_columns, 1), 4, 11), np.float32)
         prev = np.zeros((4, 11), np.float32) if with_preview else None

@@ -109,6 +109,11 @@ class CSpectrumBankUpdate(C.Structure):
                 ("n_hops_out", C.c_uint64), ("d_traces", C.c_void_p), ("d_frequency_bins", C.c_void_p)]
 
 
+class CWaveformRaggedUpdate(C.Structure):
+    _fields_ = [("n_streams", C.c_uint64), ("max_columns", C.c_uint64), ("d_n_columns", C.c_void_p), ("d_columns", C.c_void_p),
+                ("d_preview", C.c_void_p), ("d_preview_progress", C.c_void_p), ("d_reset", C.c_void_p)]
+
+
 class CLoudnessRaggedUpdate(C.Structure):
     _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("d_n_blocks", C.c_void_p), ("d_snapshots", C.c_void_p)]
 

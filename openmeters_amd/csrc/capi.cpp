@@ -724,6 +724,15 @@ int omx_waveform_bank_reset_audio(omx_waveform_bank* b) {
         return (int)OMX_NONE;
     });
 }
+int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                     const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                     const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_waveform_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_ragged(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on_device, uint64_t frames, uint32_t channels,
                               float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], void* stream,
                               omx_waveform_bank_update* out) {

@@ -37,6 +37,7 @@ WaveformBank::WaveformBank(const omx_waveform_config& cfg, uint32_t n_streams) :
 
 void WaveformBank::rebuild() {  // :175-184
     column_phase_ = 0.0;
+    ragged_zero_phase_ = true;
     clear_minmax_ = true;
     if (analysis_) reset_trackers();
     reset_pending_ = true;
@@ -45,6 +46,7 @@ void WaveformBank::reset_trackers() {  // :199-201 (band_analysis is None when a
     analysis_ = cfg_.analyze_bands != 0;
     clear_trackers_ = true;
     pushes_ = 0;
+    ragged_zero_pushes_ = true;
 }
 void WaveformBank::prepare(hipStream_t) {  // :169-173
     if (cfg_.analyze_bands && !analysis_) reset_trackers();
@@ -60,6 +62,33 @@ void WaveformBank::update_config(const omx_waveform_config& in) {  // :336-352
 
 int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in, float sample_rate_in,
                           const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_bank_update* out) {  // :308-334
+    if (ragged_) {
+        set_last_error("waveform bank: per-stream positions are in use (process_ragged); reset_audio() returns the bank to lock-step calls");
+        return OMX_ERR_INVALID;
+    }
+    return process_impl(pcm, pcm_on_device, frames, channels_in, sample_rate_in, positions, stream, out, nullptr);
+}
+
+int WaveformBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                 uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                 omx_waveform_ragged_update* out) {
+    bool any = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (frames[s] > frames_capacity) {
+            set_last_error("waveform process_ragged: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
+        any = any || frames[s] != 0 || (reset_mask && reset_mask[s]);
+    }
+    last_stream_ = stream;
+    if (!any || frames_capacity == 0) return OMX_NONE;
+    const RaggedCall rc{frames, reset_mask, out};
+    return process_impl(d_pcm, true, frames_capacity, channels, sample_rate, positions, stream, nullptr, &rc);
+}
+
+int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in, float sample_rate_in,
+                               const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_bank_update* out,
+                               const RaggedCall* ragged) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
     if (frames == 0) return OMX_NONE;
@@ -78,6 +107,7 @@ int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
         hist_ring_.reserve((size_t)slow_len * n_streams_ * 16);
         clear_trackers_ = true;
         pushes_ = 0;
+        ragged_zero_pushes_ = true;
     }
     if (clear_minmax_ && clear_trackers_) {
         OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(WaveLaneState), stream));
@@ -107,8 +137,78 @@ int WaveformBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     }
     clear_minmax_ = clear_trackers_ = false;
 
-    // fractional column phase (:253-254, :287-291), exactly as the reference accumulates it
     const double step = std::min(std::max((double)cfg_.scroll_speed / (double)cfg_.sample_rate, 0.0), 1.0);
+    if (ragged) {
+        // every stream advances its own phase on the device; a call emits at most floor(phase + frames x step) <= max_cols columns
+        const uint64_t max_cols = (uint64_t)std::floor(1.0 + (double)frames * step) + 1;
+        if (max_cols > cfg_.max_columns)  // cap_pending_columns (:293-298) would drop the oldest ones: not modelled per stream
+            unsupported("waveform process_ragged: frames_capacity x scroll_speed / sample_rate exceeds max_columns");
+        if (!ragged_) {  // every stream starts from the bank's common push count and column phase
+            r_pushes_.upload(std::vector<uint64_t>(n_streams_, pushes_), stream);
+            r_phase_.upload(std::vector<double>(n_streams_, column_phase_), stream);
+            ragged_ = true;
+            ragged_zero_phase_ = ragged_zero_pushes_ = false;
+        }
+        if (ragged_zero_phase_) OMX_HIP(hipMemsetAsync(r_phase_.ptr, 0, n_streams_ * sizeof(double), stream));
+        if (ragged_zero_pushes_) OMX_HIP(hipMemsetAsync(r_pushes_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
+        ragged_zero_phase_ = ragged_zero_pushes_ = false;
+        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
+        r_frames_host_.reserve(n_streams_);
+        r_mask_host_.reserve(n_streams_);
+        r_frames_.reserve(n_streams_);
+        r_mask_.reserve(n_streams_);
+        r_cols_.reserve(n_streams_);
+        r_progress_.reserve(n_streams_);
+        for (uint32_t s = 0; s < n_streams_; ++s) {
+            r_frames_host_.ptr[s] = ragged->frames[s];
+            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
+        }
+        OMX_HIP(hipMemcpyAsync(r_frames_.ptr, r_frames_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        columns_.reserve((size_t)(n_streams_ * max_cols * 4), false);
+        preview_.reserve((size_t)n_streams_ * 4, false);
+        WaveformArgs wa{};
+        wa.pcm = pcm;
+        wa.frames = frames;  // the row stride of pcm
+        wa.n_streams = n_streams_;
+        wa.fmt = make_format(channels, positions);
+        wa.analyze = analysis_ ? 1 : 0;
+        wa.track_history = (analysis_ && cfg_.track_history) ? 1 : 0;
+        wa.lp_lo = make_biquad(false, cfg_.sample_rate, kBandSplits[0]);
+        wa.hp_lo = make_biquad(true, cfg_.sample_rate, kBandSplits[0]);
+        wa.lp_hi = make_biquad(false, cfg_.sample_rate, kBandSplits[1]);
+        wa.hp_hi = make_biquad(true, cfg_.sample_rate, kBandSplits[1]);
+        wa.step = step;
+        wa.color_len = color_len_;
+        wa.slow_len = slow_len_;
+        wa.color_ring = color_ring_.ptr;
+        wa.hist_ring = hist_ring_.ptr;
+        wa.state = state_.ptr;
+        wa.columns = columns_.ptr;
+        wa.preview = preview_.ptr;
+        wa.frames_v = r_frames_.ptr;
+        wa.reset_v = r_mask_.ptr;
+        wa.pushes_v = r_pushes_.ptr;
+        wa.phase_v = r_phase_.ptr;
+        wa.cols_v = r_cols_.ptr;
+        wa.progress_v = r_progress_.ptr;
+        wa.max_cols = max_cols;
+        launch_waveform(wa, stream);
+        OMX_HIP(hipGetLastError());
+        last_cols_ = max_cols;
+        if (ragged->out) {
+            ragged->out->n_streams = n_streams_;
+            ragged->out->max_columns = max_cols;
+            ragged->out->d_n_columns = r_cols_.ptr;
+            ragged->out->d_columns = columns_.ptr;
+            ragged->out->d_preview = preview_.ptr;
+            ragged->out->d_preview_progress = r_progress_.ptr;
+            ragged->out->d_reset = r_mask_.ptr;
+        }
+        reset_pending_ = false;
+        return OMX_PRODUCED;
+    }
+    // fractional column phase (:253-254, :287-291), exactly as the reference accumulates it
     double phase = column_phase_;
     uint64_t n_emit = 0;
     for (uint64_t f = 0; f < frames; ++f) {

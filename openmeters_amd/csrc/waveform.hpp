@@ -34,6 +34,17 @@ struct WaveformArgs {
     omx_wave_column* columns;  // [n_streams][n_emit - first_kept][4]
     omx_wave_column* preview;  // [n_streams][4]
     uint32_t write_preview;
+    // ragged banks (per-stream frame counts; nullptr = lock-step; the one-wavefront kernel only, ONE stream per workgroup so that the
+    // values below stay workgroup-uniform): stream s receives frames_v[s] <= frames frames (`frames` is then the row stride of pcm),
+    // continues from its own tracker push count / column phase, after a reset of its own when reset_v[s] != 0; columns go to
+    // columns[s][max_cols][4], their count to cols_v[s], the preview progress to progress_v[s]
+    const uint32_t* frames_v;
+    const uint8_t* reset_v;
+    uint64_t* pushes_v;
+    double* phase_v;
+    uint32_t* cols_v;
+    float* progress_v;
+    uint64_t max_cols;
 };
 void launch_waveform(const WaveformArgs& a, hipStream_t stream);
 // role-per-wavefront form (waveform_roles_kernels.hip); launch_waveform picks it whenever it applies (OMX_WAVEFORM_SINGLE=1 pins
@@ -49,10 +60,18 @@ public:
     WaveformBank(const omx_waveform_config& cfg, uint32_t n_streams);
     const omx_waveform_config& config() const { return cfg_; }
     void update_config(const omx_waveform_config& cfg);
-    void reset_audio() { rebuild(); }
+    void reset_audio() {
+        rebuild();
+        ragged_ = false;
+    }
     void prepare(hipStream_t stream);
     int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_bank_update* out);
+    // Ragged call (include/omx.h: omx_waveform_bank_process_ragged): stream s receives frames[s] <= frames_capacity frames (its rows
+    // of `d_pcm` are frames_capacity frames apart); streams flagged in reset_mask get reset_audio() first.  Push counts and column
+    // phases then live on the device per stream; the bank stays ragged until reset_audio() of the whole bank.
+    int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_ragged_update* out);
     int fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream);
     hipStream_t last_stream() const { return last_stream_; }
     uint64_t last_columns() const { return last_cols_; }
@@ -60,6 +79,13 @@ public:
 private:
     void rebuild();
     void reset_trackers();
+    struct RaggedCall {
+        const uint32_t* frames;
+        const uint8_t* reset_mask;
+        omx_waveform_ragged_update* out;
+    };
+    int process_impl(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
+                     const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_waveform_bank_update* out, const RaggedCall* ragged);
 
     omx_waveform_config cfg_{};
     uint32_t n_streams_;
@@ -74,6 +100,15 @@ private:
     OutBuffer<omx_wave_column> columns_, preview_;
     bool host_outputs_ = false;
     hipStream_t last_stream_ = nullptr;
+    // ragged mode: per-stream tracker push counts and column phases on the device
+    bool ragged_ = false, ragged_zero_phase_ = false, ragged_zero_pushes_ = false;
+    DeviceBuffer<uint64_t> r_pushes_;
+    DeviceBuffer<double> r_phase_;
+    DeviceBuffer<uint32_t> r_frames_, r_cols_;
+    DeviceBuffer<float> r_progress_;
+    DeviceBuffer<uint8_t> r_mask_;
+    PinnedBuffer<uint32_t> r_frames_host_;
+    PinnedBuffer<uint8_t> r_mask_host_;
 };
 
 }  // namespace omx

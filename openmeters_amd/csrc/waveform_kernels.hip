@@ -16,25 +16,32 @@ using namespace wf;
 // ANALYZE / HISTORY: the configuration's band analysis and RMS history, compile-time so that a frame's code is one basic block
 template <int B, bool ANALYZE, bool HISTORY>
 __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
-    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;  // stream * 16 + lane
+    // ragged banks: one stream per workgroup (lanes 0 ... 15), so that its frame count, push count and column phase are
+    // workgroup-uniform like the lock-step kernel arguments they replace
+    const bool ragged = a.frames_v != nullptr;
+    const uint32_t gid = ragged ? blockIdx.x * 16 + (threadIdx.x & 15) : blockIdx.x * 64 + threadIdx.x;  // stream * 16 + lane
     const uint32_t s = gid >> 4, ln = gid & 15;
-    const bool live = s < a.n_streams && ln < 12;
+    const bool live = s < a.n_streams && ln < 12 && (!ragged || threadIdx.x < 16);
+    const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;
+    const uint64_t frames_s = ragged ? a.frames_v[s] : a.frames;                       // frames of this call
+    const uint64_t pushes0 = ragged ? (reset_stream ? 0ull : a.pushes_v[s]) : a.pushes;
+    const double phase0 = ragged ? (reset_stream ? 0.0 : a.phase_v[s]) : a.column_phase;
     const uint32_t ch = ln / 3, band = ln % 3;
     const uint32_t row = a.n_streams * 16;
     WaveLaneState st;
     memset(&st, 0, sizeof(st));
-    if (live) st = a.state[gid];
+    if (live && !reset_stream) st = a.state[gid];
     const bool analyze = a.analyze != 0 && live, history = a.track_history != 0 && analyze;
     const BiquadCoef cb = band == 0 ? a.lp_lo : (band == 1 ? a.lp_hi : a.hp_hi);
     const bool use_a = band == 1;
     const ChannelPick pick(ch);
     const float gain = band == 0 ? 1.0f : (band == 1 ? 0.7f : 2.0f);  // BAND_COLOR_GAINS (:22)
     Window wc, wh0, wh1;
-    wc.init(st.color, a.color_len, a.pushes);
-    wh0.init(st.hist[0], a.color_len, a.pushes);
-    wh1.init(st.hist[1], a.slow_len, a.pushes);
-    uint32_t head_c = (uint32_t)(a.pushes % a.color_len), head_h = (uint32_t)(a.pushes % a.slow_len);
-    uint64_t pushes = a.pushes;
+    wc.init(st.color, a.color_len, pushes0);
+    wh0.init(st.hist[0], a.color_len, pushes0);
+    wh1.init(st.hist[1], a.slow_len, pushes0);
+    uint32_t head_c = (uint32_t)(pushes0 % a.color_len), head_h = (uint32_t)(pushes0 % a.slow_len);
+    uint64_t pushes = pushes0;
     float* cring = a.color_ring + (s < a.n_streams ? gid : 0u);  // lanes past the last stream read column 0 (discarded), store nothing
     float* hring = a.hist_ring + (s < a.n_streams ? gid : 0u);
     const float* pcm = a.pcm + (uint64_t)(s < a.n_streams ? s : 0) * a.frames * a.fmt.channels;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
     __shared__ float stage[4][kStage * OMX_MAX_CHANNELS];
     float* my_stage = stage[threadIdx.x >> 4];
     auto refill = [&](uint64_t f) {
-        const uint32_t n = (uint32_t)min((uint64_t)kStage, a.frames - f) * a.fmt.channels;
+        const uint32_t n = (uint32_t)min((uint64_t)kStage, frames_s - f) * a.fmt.channels;
         const float* src = pcm + f * a.fmt.channels;
         const uint32_t l16 = threadIdx.x & 15;
         for (uint32_t e0 = 0; e0 < n; e0 += 16 * 8) {
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         }
         __syncthreads();  // one wavefront per workgroup: orders the LDS writes before the other lanes' reads
     };
-    double phase = a.column_phase;
+    double phase = phase0;
     uint64_t col = 0;
     const bool minmax_lane = live && band == 0;
     const bool two_channels = a.fmt.channels == 2;
@@ -136,11 +143,11 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
             fetch_head_h = (fetch_head_h + (uint32_t)B) % a.slow_len;
         }
     };
-    if (B > 1 && a.frames) fetch();  // B == 1 serves windows shorter than 16 samples: each frame's loads follow the previous frame's stores
+    if (B > 1 && frames_s) fetch();  // B == 1 serves windows shorter than 16 samples: each frame's loads follow the previous frame's stores
     // hp_lo runs on every lane and is selected by band (a divergent `if (use_a)` costs the other bands the same instructions
     // anyway); its state only matters on the mid-band lanes
-    for (uint64_t f0 = 0; f0 < a.frames; f0 += B) {
-        const uint32_t nb = (uint32_t)min((uint64_t)B, a.frames - f0);
+    for (uint64_t f0 = 0; f0 < frames_s; f0 += B) {
+        const uint32_t nb = (uint32_t)min((uint64_t)B, frames_s - f0);
         if (B == 1) fetch();
         if (f0 % kStage == 0) refill(f0);
         float lr[B][2];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         }
         if constexpr (B > 1) {
             if (f0) flush_stores((uint32_t)B);  // the previous batch's ring values, after the wait for this batch's loads (above) and not before it
-            if (f0 + B < a.frames) fetch();
+            if (f0 + B < frames_s) fetch();
         }
         // samples of this batch that precede a window's first expiring value (dsp.rs:336-338), fixed before the pushes move them
         const uint32_t unf_c = wc.unfilled, unf_h0 = wh0.unfilled, unf_h1 = wh1.unfilled;
@@ -221,8 +228,11 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
                 phase += a.step;
                 if constexpr (!EMIT) continue;  // the caller has replayed the phase additions: no column ends in this batch
                 if (phase >= 1.0) {  // emit_column (:237-250); uniform over the wavefront
-                    if (live && col >= a.first_kept)
+                    if (live && ragged) {
+                        if (col < a.max_cols) write_column(a.columns + ((uint64_t)s * a.max_cols + col) * 4 + ch);
+                    } else if (live && col >= a.first_kept) {
                         write_column(a.columns + ((uint64_t)s * (a.n_emit - a.first_kept) + (col - a.first_kept)) * 4 + ch);
+                    }
                     if (st.cur_some && st.cur_has_last) {
                         st.last_valid = 1;
                         st.last_sample = st.cur_last;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         if constexpr (B == 1) flush_stores(1u);  // short windows: the next frame may expire this very slot
     }
     if constexpr (B > 1) {
-        if (a.frames) flush_stores((uint32_t)(a.frames - (a.frames - 1) / B * B));  // the last batch, whole or short
+        if (frames_s) flush_stores((uint32_t)(frames_s - (frames_s - 1) / B * B));  // the last batch, whole or short
     }
     // BandFilter::flush_denormals once per block (:321-323)
     if (analyze) {
@@ -262,7 +272,14 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         for (int i = 0; i < 8; ++i)
             if (fabsf(z[i]) < 1.0e-20f) z[i] = 0.0f;
     }
-    if (live && a.write_preview) write_column(a.preview + (uint64_t)s * 4 + ch);  // preview (:300-306)
+    const float progress = (float)fmin(fmax(phase, 0.0), 1.0);  // preview (:300-306)
+    if (live && (ragged ? progress > 0.0f : a.write_preview != 0)) write_column(a.preview + (uint64_t)s * 4 + ch);
+    if (ragged && threadIdx.x == 0 && s < a.n_streams) {
+        a.pushes_v[s] = pushes;
+        a.phase_v[s] = phase;
+        a.cols_v[s] = (uint32_t)min(col, a.max_cols);
+        a.progress_v[s] = progress;
+    }
     if (live) {
         wc.save(st.color);
         wh0.save(st.hist[0]);
@@ -274,12 +291,12 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
 void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
     if (a.n_streams == 0) return;
     static const bool pin_single = std::getenv("OMX_WAVEFORM_SINGLE") != nullptr;
-    if (!pin_single && waveform_roles_applicable(a)) {
+    if (!pin_single && !a.frames_v && waveform_roles_applicable(a)) {
         launch_waveform_roles(a, stream);
         return;
     }
     const uint32_t threads = a.n_streams * 16;
-    const dim3 grid((threads + 63) / 64);
+    const dim3 grid(a.frames_v ? a.n_streams : (threads + 63) / 64);  // ragged banks: one stream per workgroup
     const bool analyze = a.analyze != 0, history = analyze && a.track_history != 0;
     auto launch = [&](auto b_c) {
         constexpr int B = decltype(b_c)::value;

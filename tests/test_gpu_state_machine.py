@@ -650,3 +650,79 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
         bank.process_host(chunk, block, C, 48000.0, pos)
     bank.reset_audio()
     bank.process_host(chunk, block, C, 48000.0, pos)
+
+
+@pytest.mark.parametrize("seed,C,history,rate", [(1, 2, True, 48000.0), (2, 2, False, 44100.0), (3, 6, True, 48000.0), (4, 2, True, 8000.0)])
+def test_ragged_waveform_bank_random_per_stream_frame_counts_match_per_stream_oracles(omx, oracle, seed, C, history, rate):
+    """Per-stream independence of the waveform bank: every stream gets its own random frame counts (not block-aligned) and its own
+    reset_audio() calls; stream s must behave like a single WaveformProcessor fed the same pieces — column counts (the fractional
+    column phase is per stream), min / max bit-exact, band colours and RMS history at the usual bars, the preview and its progress,
+    the band filters / sliding means / min-max state carried per stream and cleared by the stream's own reset only."""
+    import torch
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    rng = np.random.default_rng(900 + seed)
+    S, calls, cap = 5, 14, 1500
+    cfg = WaveformConfig(sample_rate=rate, scroll_speed=260.0, max_columns=64, analyze_bands=True, track_history=history)
+    pos = capi.SURROUND[:C] + [0] * (8 - C) if C != 2 else capi.positions_fallback(2)
+    bank = banks.WaveformBank(omx, cfg, S)
+    refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
+    total = 2 * 700 + calls * cap
+    feeds = []
+    for s in range(S):
+        t = np.arange(total) / rate
+        base = 0.5 * np.sin(2 * np.pi * (90.0 + 210.0 * s) * t) + 0.25 * np.sin(2 * np.pi * (1500.0 + 400.0 * s) * t + s)
+        x = np.stack([base * (1.0 - 0.12 * c) * (-1.0 if c % 2 else 1.0) + 0.02 * rng.standard_normal(total) for c in range(C)], 1)
+        feeds.append(x.astype(np.float32))
+    at = [0] * S
+    for n in (700, 700):
+        chunk = np.stack([f[a:a + n] for f, a in zip(feeds, at)])
+        up = bank.process_host(chunk, C, rate, pos)
+        for s in range(S):
+            w = refs[s].process_block(AudioBlock(chunk[s].reshape(-1), C, rate, pos))
+            got, _ = bank.fetch(s, int(up.n_columns))
+            assert np.array_equal(got[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32))
+            at[s] += n
+    columns = 0
+    for call in range(calls):
+        frames = rng.integers(0, cap + 1, S)
+        frames[rng.integers(0, S)] = 0
+        mask = (rng.random(S) < 0.15).astype(np.uint8)
+        pcm = np.zeros((S, cap, C), np.float32)
+        for s in range(S):
+            pcm[s, :frames[s]] = feeds[s][at[s]:at[s] + frames[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, frames, C, rate, pos, mask)
+        torch.cuda.synchronize()
+        if int(frames.max()) == 0 and not mask.any():
+            continue
+        n_cols = _dev(torch, up.d_n_columns, (S,)).cpu().numpy()
+        progress = _dev(torch, up.d_preview_progress, (S,), "<f4").cpu().numpy()
+        M = int(up.max_columns)
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            if frames[s] == 0:
+                at[s] += 0
+                if not mask[s]:
+                    assert int(n_cols[s]) == 0
+                continue
+            w = refs[s].process_block(AudioBlock(pcm[s, :frames[s]].reshape(-1), C, rate, pos))
+            assert int(n_cols[s]) == len(w.columns), (call, s, int(n_cols[s]), len(w.columns))
+            got, prev = bank.fetch(s, M, with_preview=True)
+            got = got[:len(w.columns)]
+            assert np.array_equal(got[:, :, :2].view(np.uint32), w.columns[:, :, :2].view(np.uint32)), (call, s)   # min / max
+            if len(got):
+                bar("waveform (ragged bank): |d band colour| / max(1, max)", np.abs(got[:, :, 2:5] - w.columns[:, :, 2:5]).max() /
+                    max(1.0, np.abs(w.columns[:, :, 2:5]).max()), 1e-6)
+                bar("waveform (ragged bank): |d RMS history dB|", np.abs(got[:, :, 5:] - w.columns[:, :, 5:]).max(), 2e-4)
+                columns += len(got)
+            assert abs(float(progress[s]) - w.preview_progress) == 0.0, (call, s)
+            if w.preview is not None:
+                assert np.array_equal(prev[:, :2].view(np.uint32), w.preview[:, :2].view(np.uint32)), (call, s)
+            at[s] += int(frames[s])
+    assert columns > 150
+    chunk = np.stack([f[:300] for f in feeds])
+    with pytest.raises(capi.OmxError):
+        bank.process_host(chunk, C, rate, pos)
+    bank.reset_audio()
+    assert bank.process_host(chunk, C, rate, pos) is not None
