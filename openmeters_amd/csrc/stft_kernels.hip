@@ -47,24 +47,34 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
     const float* src = a.pcm + ((uint64_t)s * a.frames_total + skip_s) * a.fmt.channels;
     const uint64_t ring_base = (uint64_t)s * a.cap;
     long long best = -1;
-#pragma unroll 4
+    // two-channel blocks (the common shape): every load of the thread is issued up front, unconditionally (clamped index) — a load
+    // inside `if (live)` is waited for on the spot, which left four of the sixteen in flight
+    const bool two = a.fmt.channels == 2;
+    v2f pre[INGEST_FRAMES_PER_THREAD];
+    if (two) {
+        const uint64_t last = count_s ? count_s - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k)
+            pre[k] = *reinterpret_cast<const v2f*>(src + min(wg_base + (uint64_t)k * 256 + threadIdx.x, last) * 2);
+    }
+#pragma unroll
     for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k) {
         const uint64_t idx = wg_base + (uint64_t)k * 256 + threadIdx.x;
         const bool live = idx < count_s;
         float out0 = 0.0f;
         if (live) {
-            const float* frame = src + idx * a.fmt.channels;
             // dsp.rs:223-249: left = (0.0 + s0*w00) + s1*w10 + ...  (same order as the general fold; the
             // 1- and 2-channel specialisations of the reference are bit-identical to it, dsp.rs:591-624)
             float left = 0.0f, right = 0.0f, first;
-            if (a.fmt.channels == 2) {
-                const v2f f2 = *reinterpret_cast<const v2f*>(frame);
+            if (two) {
+                const v2f f2 = pre[k];
                 first = f2.x;
                 left = left + f2.x * a.fmt.m[0][0];
                 right = right + f2.x * a.fmt.m[0][1];
                 left = left + f2.y * a.fmt.m[1][0];
                 right = right + f2.y * a.fmt.m[1][1];
             } else {
+                const float* frame = src + idx * a.fmt.channels;
                 first = frame[0];
                 for (uint32_t c = 0; c < a.fmt.channels; ++c) {
                     const float v = frame[c];
