@@ -4,6 +4,11 @@
 // 16 lanes per stream (12 live): lane = channel * 3 + band.  Every lane evaluates the L and R band filters of its
 // band (identical inputs -> bit-identical outputs across the four channel lanes) and forms its channel's value,
 // so the Mid/Side trackers need no cross-lane traffic.  Built with -ffp-contract=off.
+// This one-wavefront form serves what the role-per-wavefront kernel (waveform_roles_kernels.hip) does not: band analysis off, windows
+// shorter than 32 samples, >= 2048 streams without RMS history, and ragged banks.  It is paced by one wavefront's instruction issue
+// (a dependent VALU instruction every 9 - 10 cycles) and by one memory wait per batch: the next batch's loads ARE issued a batch
+// ahead, but the compiler still places an `s_waitcnt vmcnt(0)` right after them (measured: 150 us per 256-frame block with or
+// without the prefetch) — which is what the role kernel's memory wavefront removes.
 #include <cstdlib>
 #include <type_traits>
 
@@ -96,9 +101,8 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
         dst->rms_db[1][band] = rms1;
     };
 
-    // The loads of batch i + 1 (PCM, the three expiring values per frame) are issued before batch i is computed: a batch's own
-    // loads would expose the memory latency 1 ... 2 us — PCM of a single-stream handle sits in pinned host memory — once per
-    // B frames.  Batch i + 1 expires slots that batch i does not store (windows >= 2 B samples long, launch_waveform).
+    // The expiring values of batch i + 1 are requested before batch i is computed (see the header for what that does and does not
+    // buy).  Batch i + 1 expires slots that batches i - 1 and i do not store (windows >= 4 B samples long, launch_waveform).
     float nold_c[B], nold_h0[B], nold_h1[B];
     uint32_t fetch_head_c = head_c, fetch_head_h = head_h;
     // Ring stores trail the pushes by one batch: issued right after a batch's pushes they would be the newest memory operations
