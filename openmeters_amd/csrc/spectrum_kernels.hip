@@ -55,7 +55,10 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     const uint32_t chunk = bq % chunks, st = (bq / chunks) * 8u + xcd;
     if (st >= a.n_streams * a.n_traces) return;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
-    const int fs = threadIdx.x / T, jf = threadIdx.x % T, wf = jf >> 6;
+    // F == 1 (4096 points): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
+    // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
+    // exec-mask regions and per-lane 64-bit addresses
+    const int fs = F == 1 ? 0 : (int)(threadIdx.x / T), jf = F == 1 ? (int)threadIdx.x : (int)(threadIdx.x % T), wf = jf >> 6;
     const unsigned ju = (unsigned)jf;
     v2f* A = lds + fs * G::LDS;
     const uint32_t n_hops_s = spectrum_hops(a, s), pairs_s = (n_hops_s + 1) / 2;  // ragged banks: this stream's own hop count
@@ -121,10 +124,12 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
         aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
     }
     frame_sync<LOGN>();
+    const int own_base = pad16(jf);  // pad16(j + T t) = pad16(j) + (T + T / 16) t
 #pragma unroll
-    for (int t = 0; t < 16; ++t) A[pad16(jf + T * t)] = v[t];
+    for (int t = 0; t < 16; ++t) A[own_base + (T + T / 16) * t] = v[t];
     frame_sync<LOGN>();
     if (!in_range) return;
+    const int partner_base = pad16(jf == 0 ? N : N - jf);
     float* out0 = nullptr;
     if (a.fused_db)
         out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
@@ -134,7 +139,9 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
         if (t == 8 && jf != 0) break;
         const uint32_t k = ju + (unsigned)T * (unsigned)t;
         const v2f z = v[t];
-        const v2f zr = A[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
+        // partner bin N - k = (N - j) - T t: pad16 is linear over multiples of 16, so its slot is one base + a compile-time offset
+        // (bin 0 pairs with itself)
+        const v2f zr = A[(t == 0 && jf == 0) ? 0 : partner_base - (T + T / 16) * t];
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
         const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
