@@ -294,13 +294,12 @@ def main():
         bank = pipe.spectrogram
 
         def step():
-            up, snaps, st, n_blocks = pipe.step_concurrent(torch, pcm.data_ptr(), F)
-            if up is not None:
-                # the banks reuse their output buffers every call: the rows are assembled on the compute stream (a few
-                # small torch ops over device-resident outputs), the all-gather itself rides the side stream
-                rows = pipe.stats(torch, device, up, snaps, st, n_blocks)
-                if world > 1:
-                    gather_on_side(lambda: rows, [rows])
+            # the three banks side by side; the summary rows of the loudness / stereometer banks are assembled on their side
+            # streams beside the spectrogram kernel, the three point-count columns after it (FullPipeline.step_with_stats); the
+            # all-gather itself rides a further side stream
+            up, rows = pipe.step_with_stats(torch, device, pcm.data_ptr(), F)
+            if up is not None and world > 1:
+                gather_on_side(lambda: rows, [rows])
             return up
 
     for _ in range(args.warmup):

@@ -64,11 +64,46 @@ class FullPipeline:
             main.wait_event(done)
         return up, results[0], results[1], frames // 256
 
-    def stats(self, torch, device, up, snaps_ptr, st, n_blocks):
-        """[n_streams, len(STATS_COLUMNS)] float32 summary rows in sharding.STATS_COLUMNS order."""
+    def step_with_stats(self, torch, device, device_ptr: int, frames: int):
+        """`step_concurrent` + `stats` with the summary columns of the loudness and stereometer banks assembled on THEIR side
+        streams, beside the spectrogram kernel, instead of after the join: the K9 peak-hold kernel (one lane per stream walking the
+        call's blocks on the sample clock: ~140 us of pure latency) and a dozen small torch ops leave the step's critical path; only
+        the three columns taken from the spectrogram's point counts are written after it.  Same rows, bit for bit
+        (tests/test_gpu_pipeline.py).  Returns (spectrogram update or None, rows [n_streams, len(STATS_COLUMNS)])."""
+        assert frames % 256 == 0
+        n_blocks = frames // 256
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        out = torch.zeros((self.n_streams, len(STATS_COLUMNS)), device=device, dtype=torch.float32)   # on main, ahead of the fork
+        fork = torch.cuda.Event()
+        fork.record(main)
+        up = self.spectrogram.process_device(device_ptr, frames, self.channels, self.sample_rate, self.positions, main.cuda_stream)
+        joins = []
+        for side, which in zip(self._side, ("loudness", "stereometer")):
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                out.record_stream(side)
+                if which == "loudness":
+                    snaps = self.loudness.process_device(device_ptr, 256, n_blocks, self.channels, self.sample_rate, self.positions,
+                                                         side.cuda_stream)
+                    self._loudness_columns(torch, device, out, snaps, n_blocks)
+                else:
+                    st = self.stereometer.process_device(device_ptr, 256, n_blocks, self.channels, self.sample_rate, self.positions,
+                                                         side.cuda_stream)
+                    self._stereometer_columns(torch, device, out, st, n_blocks)
+                done = torch.cuda.Event()
+                done.record(side)
+                joins.append(done)
+        for done in joins:
+            main.wait_event(done)
+        self._spectrogram_columns(torch, device, out, up)
+        return up, out
+
+    def _loudness_columns(self, torch, device, out, snaps_ptr, n_blocks):
+        """columns 0-2 and 10-11 of the summary rows, on torch's current stream"""
         import ctypes as C
         S = self.n_streams
-        out = torch.zeros((S, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
         if snaps_ptr:
             snap = torch.as_tensor(_DeviceView(snaps_ptr, (S, n_blocks, LOUDNESS_SNAPSHOT_FLOATS), "<f4"), device=device)[:, -1]
             out[:, 0] = snap[:, 1]                     # momentary LUFS
@@ -88,14 +123,27 @@ class FullPipeline:
                 rows.data_ptr()))
             self._clock += n_blocks * dt
             out[:, 10:12] = rows[:, -1, 3:5]
-        corr = torch.as_tensor(_DeviceView(st.d_correlations, (S, n_blocks, 4), "<f4"), device=device)[:, -1]
-        out[:, 3:7] = corr                             # rho full / low / mid / high
+
+    def _stereometer_columns(self, torch, device, out, st, n_blocks):
+        """columns 3-6 (rho full / low / mid / high of the last block), on torch's current stream"""
+        corr = torch.as_tensor(_DeviceView(st.d_correlations, (self.n_streams, n_blocks, 4), "<f4"), device=device)[:, -1]
+        out[:, 3:7] = corr
+
+    def _spectrogram_columns(self, torch, device, out, up):
+        """columns 7-9 (columns per step, mean points per column, points of the newest column), on torch's current stream"""
         if up is not None:
             cols = int(up.n_columns)
-            counts = torch.as_tensor(_DeviceView(up.d_counts, (S, cols), "<i4"), device=device).to(torch.float32)
+            counts = torch.as_tensor(_DeviceView(up.d_counts, (self.n_streams, cols), "<i4"), device=device).to(torch.float32)
             out[:, 7] = float(cols)
             out[:, 8] = counts.mean(dim=1)
             out[:, 9] = counts[:, -1]
+
+    def stats(self, torch, device, up, snaps_ptr, st, n_blocks):
+        """[n_streams, len(STATS_COLUMNS)] float32 summary rows in sharding.STATS_COLUMNS order (everything on the current stream)."""
+        out = torch.zeros((self.n_streams, len(STATS_COLUMNS)), device=device, dtype=torch.float32)
+        self._loudness_columns(torch, device, out, snaps_ptr, n_blocks)
+        self._stereometer_columns(torch, device, out, st, n_blocks)
+        self._spectrogram_columns(torch, device, out, up)
         return out
 
 

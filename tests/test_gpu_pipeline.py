@@ -142,3 +142,24 @@ def test_bench_two_ranks_on_one_gpu_over_gloo_runs_the_cfg5_step():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert one["n_gpus"] == 1 and one["config"]["name"] == "cfg5" and one["roofline"]["mean_points_per_frame"] > 1900
+
+
+def test_step_with_stats_equals_step_concurrent_plus_stats(omx):
+    """FullPipeline.step_with_stats assembles the loudness / stereometer columns on the banks' side streams: the rows must equal
+    step_concurrent + stats bit for bit, step after step (peak holds and clocks carried)."""
+    import torch
+    from openmeters_amd.pipeline import FullPipeline
+    S, frames = 48, 4096
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(7)
+    pcm = ((torch.rand((S, frames * 5, 2), device=dev, generator=g) - 0.5) * 0.8).contiguous()
+    a, b = FullPipeline(omx, S), FullPipeline(omx, S)
+    for k in range(5):
+        chunk = pcm[:, k * frames:(k + 1) * frames].contiguous()
+        up_a, rows_a = a.step_with_stats(torch, dev, chunk.data_ptr(), frames)
+        up_b, snaps, st, n_blocks = b.step_concurrent(torch, chunk.data_ptr(), frames)
+        rows_b = b.stats(torch, dev, up_b, snaps, st, n_blocks)
+        torch.cuda.synchronize()
+        assert (up_a is None) == (up_b is None)
+        assert torch.equal(rows_a.view(torch.int32), rows_b.view(torch.int32)), k
+    assert float(rows_a[:, 7].max()) > 0
