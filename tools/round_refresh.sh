@@ -1,4 +1,4 @@
-export OMX_PROFILE_COMMIT=47776e5
+export OMX_PROFILE_COMMIT=7265f51
 bash tools/profile_bench.sh r12 > gpurun_out/r12_profile.log 2>&1
 python bench.py > gpurun_out/r12_bench_line.json 2> gpurun_out/r12_bench_line.log
 python bench.py --config cfg5 --no-cpu-baseline --no-secondary > gpurun_out/r12_bench_line_cfg5.json 2> gpurun_out/r12_bench_line_cfg5.log
