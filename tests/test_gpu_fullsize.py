@@ -200,3 +200,39 @@ def test_fused_small_windows_full_size_shift_partition_and_oracle(omx, oracle, W
         for bank in (one, gen):
             got = bank.fetch_column(k, c, capi.COLUMN_REASSIGNED, W // 2 + 1)
             check_reassigned_columns([got], [want], FS, hop)
+
+
+@pytest.mark.parametrize("history", [False, True])
+def test_waveform_bank_1024_streams_partition_and_replication(omx, history):
+    """The role-per-wavefront waveform kernel at bank size (1024 streams = 256 workgroups of 5 / 7 wavefronts): one call == the same
+    PCM fed in several calls of uneven lengths (rounds, batches and PCM refills cut differently; carried filter / window / min-max
+    state), bit-exact; identical streams at different bank indices (different workgroups, different lane groups) produce identical
+    bits; and the one-wavefront kernel's partition agrees with it (OMX_WAVEFORM_SINGLE is per process: covered by
+    test_gpu_waveform_forms.py)."""
+    import torch
+    S, frames = 1024, 6000
+    cfg = capi.WaveformConfig(scroll_speed=350.0, max_columns=256, analyze_bands=True, track_history=history)
+    base = np.stack([cfg4_pcm(s, frames) for s in range(8)])
+    pcm = np.ascontiguousarray(base[np.arange(S) % 8])                 # stream s carries base[s % 8]
+    d_pcm = torch.from_numpy(pcm).to("cuda:0")
+    pos = capi.positions_fallback(2)
+
+    def run(cuts):
+        bank = banks.WaveformBank(omx, cfg, S)
+        cols, at = [], 0
+        for n in cuts:
+            part = d_pcm[:, at:at + n].contiguous()
+            up = bank.process_device(part.data_ptr(), n, 2, FS, pos)
+            torch.cuda.synchronize()
+            if up is not None and int(up.n_columns):
+                v = dview(torch, up.d_columns, (S, int(up.n_columns), 4, 11)).clone()
+                cols.append(v)
+            at += n
+        return torch.cat(cols, dim=1)
+
+    one = run([frames])
+    many = run([1000, 17, 2048, 1, 935, 1999])
+    assert one.shape == many.shape and one.shape[1] > 30
+    assert torch.equal(one, many)
+    for s in (8, 9, 511, 1016, 1023):
+        assert torch.equal(one[s], one[s % 8]), s
