@@ -167,6 +167,39 @@ inline void copy_out(void* dst, const void* src, size_t bytes, bool pinned, hipS
     OMX_HIP(hipStreamSynchronize(stream));
 }
 
+// The per-call host arrays of a ragged bank call (per-stream counts, reset flags) on their way to the device: two pinned staging sets
+// used alternately, each guarded by an event recorded behind its copies — a call waits only if the copies of the call BEFORE the
+// previous one are still in flight (practically never), instead of synchronising the stream on every call.
+struct RaggedStaging {
+    PinnedBuffer<uint32_t> counts[2];
+    PinnedBuffer<uint8_t> mask[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int next = 0;
+    RaggedStaging() = default;
+    RaggedStaging(const RaggedStaging&) = delete;
+    RaggedStaging& operator=(const RaggedStaging&) = delete;
+    ~RaggedStaging() {
+        for (auto& e : done)
+            if (e) (void)hipEventDestroy(e);
+    }
+    // counts_in[n] -> d_counts, mask_in[n] (nullptr = all zero) -> d_mask, asynchronously on `stream`; the caller's arrays are free
+    // again when this returns
+    void upload(const uint32_t* counts_in, const uint8_t* mask_in, uint32_t n, uint32_t* d_counts, uint8_t* d_mask, hipStream_t stream) {
+        const int b = next;
+        next ^= 1;
+        if (done[b]) OMX_HIP(hipEventSynchronize(done[b]));
+        else OMX_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        counts[b].reserve(n);
+        mask[b].reserve(n);
+        std::memcpy(counts[b].ptr, counts_in, (size_t)n * sizeof(uint32_t));
+        if (mask_in) std::memcpy(mask[b].ptr, mask_in, n);
+        else std::memset(mask[b].ptr, 0, n);
+        OMX_HIP(hipMemcpyAsync(d_counts, counts[b].ptr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipMemcpyAsync(d_mask, mask[b].ptr, n, hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipEventRecord(done[b], stream));
+    }
+};
+
 struct EventTimer {  // HIP-event timing of one kernel family on its launch stream
     hipEvent_t start = nullptr, stop = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

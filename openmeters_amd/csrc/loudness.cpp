@@ -134,17 +134,9 @@ int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint
     }
     if (!any && !any_reset) return OMX_NONE;
     // per-stream counts / flags: pinned staging -> device (the caller's arrays are borrowed for the call only)
-    OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
-    r_blocks_host_.reserve(n_streams_);
-    r_mask_host_.reserve(n_streams_);
     r_blocks_.reserve(n_streams_);
     r_mask_.reserve(n_streams_);
-    for (uint32_t s = 0; s < n_streams_; ++s) {
-        r_blocks_host_.ptr[s] = n_blocks[s];
-        r_mask_host_.ptr[s] = reset_mask ? reset_mask[s] : 0;
-    }
-    OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+    r_staging_.upload(n_blocks, reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
     const uint64_t slots = std::max<uint64_t>(max_blocks, 1);
     snapshots_.reserve((size_t)(n_streams_ * slots), false);
     LoudnessArgs la{};

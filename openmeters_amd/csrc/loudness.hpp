@@ -126,8 +126,7 @@ private:
     DeviceBuffer<uint64_t> r_seen_;
     DeviceBuffer<uint32_t> r_blocks_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_blocks_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: snapshots in pinned host memory

@@ -254,17 +254,9 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
             r_epoch_.upload(std::vector<uint64_t>(n_streams_, epoch_), stream);
             ragged_ = true;
         }
-        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
-        r_blocks_host_.reserve(n_streams_);
-        r_mask_host_.reserve(n_streams_);
         r_blocks_.reserve(n_streams_);
         r_mask_.reserve(n_streams_);
-        for (uint32_t s = 0; s < n_streams_; ++s) {
-            r_blocks_host_.ptr[s] = ragged->n_blocks[s];
-            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
-        }
-        OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
         sa.pos_v = r_pos_.ptr;
         sa.blocks_v = r_blocks_.ptr;
         sa.reset_v = r_mask_.ptr;

@@ -148,8 +148,7 @@ private:
     DeviceBuffer<uint64_t> r_pos_, r_epoch_;
     DeviceBuffer<uint32_t> r_blocks_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_blocks_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
 };
 
 }  // namespace omx

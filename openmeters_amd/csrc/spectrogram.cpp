@@ -471,8 +471,6 @@ void SpectrogramBank::enter_ragged(hipStream_t stream) {
     for (DeviceBuffer<uint64_t>* b : {&r_ing_head_, &r_col_tail_}) b->reserve(n_streams_);
     for (DeviceBuffer<uint32_t>* b : {&r_frames_, &r_ing_skip_, &r_ing_count_, &r_ncols_, &r_reset_out_}) b->reserve(n_streams_);
     r_mask_.reserve(n_streams_);
-    r_frames_host_.reserve(n_streams_);
-    r_mask_host_.reserve(n_streams_);
     ragged_ = true;
 }
 
@@ -518,14 +516,8 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
         std::swap(ring_.count, bigger.count);
         ring_cap_ = cap;
     }
-    // the call's per-stream inputs (small: through pinned memory)
-    OMX_HIP(hipStreamSynchronize(stream));
-    std::memcpy(r_frames_host_.ptr, frames, n_streams_ * sizeof(uint32_t));
-    OMX_HIP(hipMemcpyAsync(r_frames_.ptr, r_frames_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    if (reset_mask) {
-        std::memcpy(r_mask_host_.ptr, reset_mask, n_streams_);
-        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_, hipMemcpyHostToDevice, stream));
-    }
+    // the call's per-stream inputs (small: through double-buffered pinned memory, no stream synchronisation)
+    r_staging_.upload(frames, reset_mask, n_streams_, r_frames_.ptr, r_mask_.ptr, stream);
     SpectrogramPlanArgs pa{};
     pa.n_streams = n_streams_;
     pa.read_len = read_len;

@@ -66,8 +66,7 @@ private:
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_col_tail_;
     DeviceBuffer<uint32_t> r_reset_flag_, r_frames_, r_ing_skip_, r_ing_count_, r_ncols_, r_reset_out_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_frames_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
     uint64_t last_cols_ = 0, last_stride_ = 0;
     uint32_t last_kind_ = OMX_COLUMN_REASSIGNED;
     EventTimer timer_;

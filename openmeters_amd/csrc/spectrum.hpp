@@ -60,8 +60,7 @@ private:
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_hop_tail_;
     DeviceBuffer<uint32_t> r_frames_, r_ing_skip_, r_ing_count_, r_nhops_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_frames_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
 };
 
 struct SpectrumSingle {

@@ -296,19 +296,11 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
             ragged_ = true;
             ragged_zero_mask_ = 0;  // (the host lengths just uploaded already carry it)
         }
-        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
-        r_blocks_host_.reserve(n_streams_);
-        r_mask_host_.reserve(n_streams_);
         r_blocks_.reserve(n_streams_);
         r_mask_.reserve(n_streams_);
         r_start_.reserve((size_t)n_streams_ * 4);
         r_valid_.reserve((size_t)n_streams_ * 4);
-        for (uint32_t s = 0; s < n_streams_; ++s) {
-            r_blocks_host_.ptr[s] = ragged->n_blocks[s];
-            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
-        }
-        OMX_HIP(hipMemcpyAsync(r_blocks_.ptr, r_blocks_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
         produced_.reserve((size_t)(n_streams_ * n_blocks));
         StereoPlanArgs pa{};
         pa.n_streams = n_streams_;

@@ -149,8 +149,7 @@ private:
     DeviceBuffer<uint64_t> r_pos_, r_len_, r_start_;
     DeviceBuffer<uint32_t> r_blocks_, r_valid_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_blocks_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows (OMX_OPT_KERNEL_FORM)

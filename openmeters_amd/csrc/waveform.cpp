@@ -152,19 +152,11 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
         if (ragged_zero_phase_) OMX_HIP(hipMemsetAsync(r_phase_.ptr, 0, n_streams_ * sizeof(double), stream));
         if (ragged_zero_pushes_) OMX_HIP(hipMemsetAsync(r_pushes_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
         ragged_zero_phase_ = ragged_zero_pushes_ = false;
-        OMX_HIP(hipStreamSynchronize(stream));  // the previous call's copies may still be reading the pinned staging arrays
-        r_frames_host_.reserve(n_streams_);
-        r_mask_host_.reserve(n_streams_);
         r_frames_.reserve(n_streams_);
         r_mask_.reserve(n_streams_);
         r_cols_.reserve(n_streams_);
         r_progress_.reserve(n_streams_);
-        for (uint32_t s = 0; s < n_streams_; ++s) {
-            r_frames_host_.ptr[s] = ragged->frames[s];
-            r_mask_host_.ptr[s] = ragged->reset_mask ? ragged->reset_mask[s] : 0;
-        }
-        OMX_HIP(hipMemcpyAsync(r_frames_.ptr, r_frames_host_.ptr, n_streams_ * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipMemcpyAsync(r_mask_.ptr, r_mask_host_.ptr, n_streams_ * sizeof(uint8_t), hipMemcpyHostToDevice, stream));
+        r_staging_.upload(ragged->frames, ragged->reset_mask, n_streams_, r_frames_.ptr, r_mask_.ptr, stream);
         columns_.reserve((size_t)(n_streams_ * max_cols * 4), false);
         preview_.reserve((size_t)n_streams_ * 4, false);
         WaveformArgs wa{};

@@ -107,8 +107,7 @@ private:
     DeviceBuffer<uint32_t> r_frames_, r_cols_;
     DeviceBuffer<float> r_progress_;
     DeviceBuffer<uint8_t> r_mask_;
-    PinnedBuffer<uint32_t> r_frames_host_;
-    PinnedBuffer<uint8_t> r_mask_host_;
+    RaggedStaging r_staging_;
 };
 
 }  // namespace omx
