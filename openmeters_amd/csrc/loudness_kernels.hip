@@ -271,7 +271,9 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
             }
         }
     }
-    if (ragged && live && r == 0 && c == 0) a.seen_v[s] = seen;  // (read above by every lane of the stream: same wavefront)
+    // the stream's counter is written by its K-weighting / window lanes only (they read it above, in the same wavefront); the
+    // true-peak lanes of a split launch sit in other workgroups and use nothing that derives from it
+    if (MODE != 2 && ragged && live && r == 0 && c == 0) a.seen_v[s] = seen;
     if (live) {
         LoudnessChannelState& st = a.state[chan];
         if constexpr (MODE != 2) {
@@ -663,9 +665,11 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
         const char* e = getenv("OMX_LOUDNESS_SPLIT");  // 0 / 1 pins the form (A/B and tests)
         return e ? atoi(e) : -1;
     }();
-    if (a.blocks_v) {  // ragged banks: everything of a (stream, channel) in its four lanes (MODE 0), no role split
-        if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, false, stream);
-        else if (a.delay_len == 24) launch_loudness_dl<24>(a, grid, batched, false, stream);
+    if (a.blocks_v) {  // ragged banks: the lane-quad kernel (per-lane ring position, block count and reset flag); true peak in its own
+                       // workgroups while that fills idle SIMDs, as in the lock-step launch below
+        const bool split_r = a.delay_len != 0 && grid <= 4096;
+        if (a.delay_len == 12) launch_loudness_dl<12>(a, grid, batched, split_r, stream);
+        else if (a.delay_len == 24) launch_loudness_dl<24>(a, grid, batched, split_r, stream);
         else launch_loudness_dl<0>(a, grid, batched, false, stream);
         return;
     }
