@@ -183,9 +183,10 @@ int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)SCOPE_PHASES) return OMX_ERR_INVALID;
     REQUIRE_DEVICE();
     return guarded([&] {
-        unsigned long long c[SCOPE_PHASES];
-        scope_phase_cycles(c, reset != 0);
-        for (int i = 0; i < SCOPE_PHASES; ++i) out[i] = c[i];
+        unsigned long long c[SCOPE_PHASES], w[SCOPE_PHASES];
+        scope_phase_cycles(c, reset != 0);      // single-pass kernel (other sample rates)
+        scope_fast_phase_cycles(w, reset != 0);  // wide form's trigger kernel: only one of the two ran
+        for (int i = 0; i < SCOPE_PHASES; ++i) out[i] = c[i] + w[i];
         return (int)SCOPE_PHASES;
     });
 }

@@ -133,39 +133,36 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     if (cfg_.trigger_source == OMX_CHANNEL_NONE) len_[2] = 0;
 
     // ---- device buffers
-    // two-pass form (period estimates of every block in parallel, see oscilloscope.hpp): several blocks per call in the
-    // stable-trigger steady state; the rings then hold the history plus the whole call
+    const uint32_t max_kernel = trigger_kernel_len_host((float)(max_period + 2), sr) + 8;
+    const uint32_t fft_size = (uint32_t)next_pow2((uint64_t)probe_frames + max_period + 1);
+    // Wide form (scope_fast_kernels.hip) for every call shape of the configurations whose autocorrelation is an 8192-point
+    // transform and whose trigger arrays fit the LDS of one CU: every block of the call is pushed into the rings first (they
+    // hold the history plus the whole call), the period estimates — a pure function of the trace — are computed for all
+    // (stream, block, view) in parallel, and one workgroup per stream runs the stateful trigger pass in timeline order.
     const uint64_t total_frames = block_frames * n_blocks;
-    const bool two_pass_shape = !ragged && n_blocks >= 4 && cfg_.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && total_frames <= (1ull << 22);
+    const bool wide = fft_size == 8192 && scope_trigger_lds_bytes(max_kernel, max_period) <= 152 * 1024 && total_frames <= (1ull << 22);
     const uint64_t cap = std::max<uint64_t>(  // never shrinks: call shapes may alternate
-        cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(two_pass_shape ? total_frames : block_frames, 4096)));
-    if (ragged_ && (cap != cap_ || !rings_.ptr))  // the regrow below copies by the host's (lock-step) positions
+        cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(wide ? total_frames : block_frames, 4096)));
+    if (ragged_ && !wide && (cap != cap_ || !rings_.ptr))
         unsupported("oscilloscope process_ragged: block_frames grew beyond the ring sized at the first ragged call");
     if (cap != cap_ || !rings_.ptr) {
         DeviceBuffer<float> bigger;
         bigger.reserve((size_t)(cap * kScopeTraces * n_streams_));
         OMX_HIP(hipMemsetAsync(bigger.ptr, 0, bigger.count * sizeof(float), stream));
-        if (rings_.ptr && cap_) {
-            for (uint32_t s = 0; s < n_streams_; ++s)
-                for (int t = 0; t < kScopeTraces; ++t) {
-                    uint64_t pos = head_[t] - len_[t];
-                    while (pos < head_[t]) {
-                        const uint64_t so = pos & (cap_ - 1), dof = pos & (cap - 1);
-                        const uint64_t run = std::min({head_[t] - pos, cap_ - so, cap - dof});
-                        OMX_HIP(hipMemcpyAsync(bigger.ptr + ((uint64_t)s * kScopeTraces + t) * cap + dof,
-                                               rings_.ptr + ((uint64_t)s * kScopeTraces + t) * cap_ + so, run * sizeof(float),
-                                               hipMemcpyDeviceToDevice, stream));
-                        pos += run;
-                    }
-                }
-            OMX_HIP(hipStreamSynchronize(stream));
+        if (rings_.ptr && cap_) {  // the deques keep their absolute positions, only the modulus changes
+            ScopeArgs ra{};
+            ra.n_streams = n_streams_;
+            for (int t = 0; t < kScopeTraces; ++t) {
+                ra.head[t] = head_[t];
+                ra.len[t] = len_[t];
+            }
+            launch_scope_rehome(rings_.ptr, cap_, bigger.ptr, cap, ragged_ ? r_pos_.ptr : nullptr, ra, std::min<uint64_t>(history_frames, cap_), stream);
+            OMX_HIP(hipStreamSynchronize(stream));  // the old rings are freed below
         }
         std::swap(rings_.ptr, bigger.ptr);
         std::swap(rings_.count, bigger.count);
         cap_ = cap;
     }
-    const uint32_t max_kernel = trigger_kernel_len_host((float)(max_period + 2), sr) + 8;
-    const uint32_t fft_size = (uint32_t)next_pow2((uint64_t)probe_frames + max_period + 1);
     if (max_kernel != max_kernel_ || !reference_.ptr) {
         max_kernel_ = max_kernel;
         reference_.reserve((size_t)n_streams_ * kScopeTraces * max_kernel);
@@ -261,7 +258,16 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
         sa.blocks_v = r_blocks_.ptr;
         sa.reset_v = r_mask_.ptr;
         sa.epoch_v = r_epoch_.ptr;
-        launch_oscilloscope(sa, stream);
+        if (wide) {
+            estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
+            sa.estimates = estimates_.ptr;
+            sa.est_view_count = 0;
+            for (int t = 0; t < kScopeTraces; ++t)
+                if (t < 2 ? active[t] : separate) sa.est_views[sa.est_view_count++] = (uint32_t)t;
+            launch_oscilloscope_fast(sa, stream);
+        } else {
+            launch_oscilloscope(sa, stream);
+        }
         OMX_HIP(hipGetLastError());
         last_blocks_ = n_blocks;
         if (ragged->out) {
@@ -274,10 +280,27 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
         }
         return OMX_PRODUCED;
     }
-    if (two_pass_shape && sa.lds_scratch && fast_acf) {
+    if (wide) {
         estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
         sa.estimates = estimates_.ptr;
-        launch_oscilloscope_two_pass(sa, stream);
+        // the views a block of this call can ask an estimate for (:683-700): the linked view alone while every pushed trace holds
+        // the same number of samples (lock-step pushes from a common reset: always, short of a bookkeeping surprise)
+        const int linked_view = matching >= 0 ? matching : (separate ? 2 : -1);
+        bool same_len = true;
+        uint64_t common = ~0ull;
+        for (int t = 0; t < kScopeTraces; ++t)
+            if (t < 2 ? active[t] : separate) {
+                if (common == ~0ull) common = len_[t];
+                same_len = same_len && len_[t] == common;
+            }
+        sa.est_view_count = 0;
+        if (linked_view >= 0 && same_len) {
+            sa.est_views[sa.est_view_count++] = (uint32_t)linked_view;
+        } else {
+            for (int t = 0; t < kScopeTraces; ++t)
+                if (t < 2 ? active[t] : separate) sa.est_views[sa.est_view_count++] = (uint32_t)t;
+        }
+        launch_oscilloscope_fast(sa, stream);
     } else {
         launch_oscilloscope(sa, stream);
     }

@@ -73,6 +73,8 @@ struct ScopeArgs {
     // the period estimates — a pure function of the trace — are computed for all (stream, block, view) in parallel, and the
     // per-stream kernel only runs the stateful part (stabilise / locate / snapshot) block after block
     ScopeEstimate* estimates;    // [n_streams][n_blocks][kScopeTraces] or nullptr (single-pass form)
+    uint32_t est_view_count;     // wide form: the views whose estimate a block of this call can ask for (grid z of the estimate kernel)
+    uint32_t est_views[kScopeTraces];
     // ragged banks (per-stream block counts; nullptr = lock-step; single-pass form only): stream s runs blocks_v[s] <= n_blocks
     // blocks from its own ring positions pos_v[s][trace] = {head, len} (head / len above are then unused), after a
     // clear_history() of its own when reset_v[s] != 0 (its epoch_v[s] then advances)
@@ -84,8 +86,14 @@ struct ScopeArgs {
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
 constexpr int SCOPE_PHASES = 10;
 void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);
+void scope_fast_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);  // the wide form's trigger kernel
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
-void launch_oscilloscope_two_pass(const ScopeArgs& a, hipStream_t stream);  // a.estimates != nullptr
+// wide form (scope_fast_kernels.hip): push / estimate / trigger kernels; a.estimates != nullptr, rings hold history + the call
+void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream);
+uint64_t scope_trigger_lds_bytes(uint32_t max_kernel, uint32_t max_period);
+// the newest len samples of every trace into a ring of another capacity (pos_v: per-stream {head, len}, else a.head / a.len)
+void launch_scope_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* pos_v, const ScopeArgs& a,
+                         uint64_t max_len, hipStream_t stream);
 uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search, uint32_t probe_frames, uint32_t max_period);
 
 void oscilloscope_config_default(omx_oscilloscope_config* c);
