@@ -1,5 +1,6 @@
 // K6 nsdf_period + K7 template_trigger (+ zero-crossing trigger and trace resampling) — one 256-thread
-// workgroup per stream, blocks processed in timeline order.
+// workgroup per stream, blocks processed in timeline order.  Single-pass form: the path of the sample rates whose
+// autocorrelation is not an 8192-point transform (below 27.3 kHz, above 54.6 kHz); 44.1 / 48 kHz run scope_fast_kernels.hip.
 // reference src/visuals/oscilloscope/processor.rs:85-182 (PeriodEstimator), :184-263 (helpers),
 // :272-528 (StableTrigger), :530-551, :769-803 (zero crossing, downsample), :611-750 (process_block).
 //
@@ -795,8 +796,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     PhaseClock pc;
     pc.start(a.phase_timing != 0);
     for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
-        // ---- push projected frames (:657-681); the two-pass form pushed every block of the call up front
-        for (uint32_t f = tid; f < (a.estimates ? 0u : a.block_frames); f += 256) {
+        // ---- push projected frames (:657-681)
+        for (uint32_t f = tid; f < a.block_frames; f += 256) {
             const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
             float left = 0.0f, right = 0.0f;
             for (uint32_t c = 0; c < a.fmt.channels; ++c) {
@@ -832,12 +833,12 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         pc.mark(0);  // ring push
         View views[kScopeTraces];
         for (int t = 0; t < kScopeTraces; ++t)
-            views[t] = View{rings + (uint64_t)t * a.cap, head[t] - len[t], mask, (uint32_t)len[t]};
+            views[t] = View{rings + (uint64_t)t * a.cap, (uint32_t)((head[t] - len[t]) & mask), (uint32_t)mask, (uint32_t)len[t]};
 
         // ---- captures (:683-700)
         auto capture = [&](int view_index, int trig_index) -> Capture {
             const View& trace = views[view_index];
-            const ScopeEstimate* pre = a.estimates ? a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view_index : nullptr;
+            const ScopeEstimate* pre = nullptr;  // (estimates ahead of the trigger pass: the wide form, scope_fast_kernels.hip)
             if (a.trigger_mode == OMX_TRIGGER_ZERO_CROSSING) return zero_crossing_capture(trace, a.base_frames, a.max_period, sh);
             if (trace.n >= a.base_frames) {
                 float* reference = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
@@ -921,89 +922,6 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     }
 }
 
-// ---- two-pass form ---------------------------------------------------------------------------------------------------------
-// (1) every frame of the call is projected into the trace rings at once (the rings hold history + call)
-__global__ __launch_bounds__(256) void scope_push_kernel(ScopeArgs a) {
-    const uint32_t s = blockIdx.y;
-    const uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= a.frames_total) return;
-    const float* frame = a.pcm + ((uint64_t)s * a.frames_total + f) * a.fmt.channels;
-    float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
-    for (uint32_t c = 0; c < a.fmt.channels; ++c) {
-        const float v = frame[c];
-        left = left + v * a.fmt.m[c][0];
-        right = right + v * a.fmt.m[c][1];
-    }
-    float* rings = a.rings + (uint64_t)s * kScopeTraces * a.cap;
-    const uint64_t mask = a.cap - 1;
-    for (int t = 0; t < kScopeTraces; ++t) {
-        const uint32_t ch = t < 2 ? a.trace_channel[t] : a.trigger_source;
-        const bool on = t < 2 ? a.trace_channel[t] != OMX_CHANNEL_NONE : a.separate_source != 0;
-        if (!on) continue;
-        float v;
-        switch (ch) {
-            case OMX_CHANNEL_LEFT: v = left; break;
-            case OMX_CHANNEL_RIGHT: v = right; break;
-            case OMX_CHANNEL_MID: v = (left + right) * 0.5f; break;
-            case OMX_CHANNEL_SIDE: v = (left - right) * 0.5f; break;
-            default: v = 0.0f; break;
-        }
-        rings[(uint64_t)t * a.cap + ((a.head[t] + f) & mask)] = v;
-    }
-}
-
-// (2) one workgroup per (stream, block, view): the period estimate the trigger pass would compute for that view after block
-// `blk` — the same function on the same samples, so the two forms agree bit for bit
-__global__ __launch_bounds__(256) void scope_estimate_kernel(ScopeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ Shared sh;
-    __shared__ float partials[256];
-    __shared__ v2f tw2_lds[256];
-    const unsigned tid = threadIdx.x;
-    const uint32_t s = blockIdx.x, blk = blockIdx.y, view = blockIdx.z;
-    // which captures the trigger pass will attempt after this block (:683-700), from the deque lengths alone
-    auto on = [&](int t) { return t < 2 ? a.trace_channel[t] != OMX_CHANNEL_NONE : a.separate_source != 0; };
-    auto len_after = [&](int t) -> uint64_t {
-        return on(t) ? min(a.len[t] + (uint64_t)(blk + 1) * a.block_frames, (uint64_t)a.history_frames) : 0ull;
-    };
-    const int linked_view = a.matching_trace >= 0 ? a.matching_trace : (a.separate_source ? 2 : -1);
-    bool needed = false;
-    if (a.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && on((int)view)) {
-        const bool linked_runs = linked_view >= 0 && len_after(linked_view) >= a.base_frames;
-        if ((int)view == linked_view) needed = linked_runs;
-        else if (view < 2) needed = !linked_runs && len_after((int)view) >= a.base_frames;
-    }
-    ScopeEstimate* out = a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view;
-    if (!needed) {
-        if (tid == 0) *out = ScopeEstimate{0, 0.0f, 0.0f, 0.0f};
-        return;
-    }
-    v2f* fft = reinterpret_cast<v2f*>(smem_raw);
-    Scratch sc{};
-    float* lds_f = reinterpret_cast<float*>(smem_raw);
-    sc.nsdf = lds_f + 2 * FFT4096_LDS;
-    sc.energy = sc.nsdf + a.max_period + 8;
-    sc.partials = partials;
-    ScopeTwiddles tw;
-    tw.j = tid;
-    tw.tw3_global = a.tw4096;
-    tw.tw2 = tw2_lds;
-#pragma unroll
-    for (int t = 1; t < 16; ++t) tw.tw3[t - 1] = a.tw4096[tid * (unsigned)t];
-    tw2_lds[tid] = a.tw256[tid];
-    __syncthreads();
-    const uint64_t n = len_after((int)view);
-    const uint64_t head = a.head[view] + (uint64_t)(blk + 1) * a.block_frames;
-    const View trace{a.rings + ((uint64_t)s * kScopeTraces + view) * a.cap, head - n, a.cap - 1, (uint32_t)n};
-    const uint32_t probe_len = min(a.probe_frames, trace.n);
-    float last_peak = 0.0f;
-    Estimate e{0, 0.0f, 0.0f};
-    PhaseClock pc;
-    pc.start(false);
-    if (probe_len >= 3) e = estimate_period(trace.sub(trace.n - probe_len, probe_len), a.sample_rate, last_peak, a, fft, sc, sh, pc, tw);
-    if (tid == 0) *out = ScopeEstimate{e.some, e.period, e.confidence, last_peak};
-}
-
 uint64_t scope_scratch_floats(uint32_t max_kernel, uint32_t max_search_unused, uint32_t probe_frames, uint32_t max_period) {
     (void)max_search_unused;
     const uint32_t ms = (uint32_t)std::ceil((float)max_period * 1.5f) + 2;
@@ -1031,20 +949,6 @@ void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset) {
         const unsigned long long zero[SCOPE_PHASES] = {};
         OMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scope_phase_cycles), zero, sizeof(zero)));
     }
-}
-
-void launch_oscilloscope_two_pass(const ScopeArgs& a, hipStream_t stream) {
-    if (a.n_streams == 0 || a.n_blocks == 0) return;
-    hipLaunchKernelGGL(scope_push_kernel, dim3((uint32_t)((a.frames_total + 255) / 256), a.n_streams), dim3(256), 0, stream, a);
-    const size_t lds_est = (size_t)(2ull * FFT4096_LDS + (a.max_period + 8ull) + (a.probe_frames + 8ull)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_estimate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(scope_estimate_kernel, dim3(a.n_streams, a.n_blocks, kScopeTraces), dim3(256), lds_est, stream, a);
-    launch_oscilloscope(a, stream);
 }
 
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream) {

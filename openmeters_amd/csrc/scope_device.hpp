@@ -18,12 +18,12 @@ constexpr float SEARCH_PERIODS = 1.5f, NORMALIZE_FLOOR = 0.01f, MEAN_RESPONSIVEN
                 SLOPE_WIDTH_PERIODS = 0.25f, RESET_BELOW_MATCH = 0.3f, WINDOW_SECONDS = 0.04f, MIN_CYCLES = 2.0f;
 constexpr uint32_t MAX_MISSED_PERIODS = 4;
 
-struct View {  // a contiguous logical slice of a trace ring
+struct View {  // a contiguous logical slice of a trace ring (positions modulo the ring: 32-bit index arithmetic per access)
     const float* ring;
-    uint64_t start, mask;
+    uint32_t start, mask;
     uint32_t n;
     __device__ __forceinline__ float at(uint32_t i) const { return ring[(start + i) & mask]; }
-    __device__ __forceinline__ View sub(uint32_t off, uint32_t len) const { return View{ring, start + off, mask, len}; }
+    __device__ __forceinline__ View sub(uint32_t off, uint32_t len) const { return View{ring, (start + off) & mask, mask, len}; }
 };
 
 __device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }

@@ -231,6 +231,14 @@ struct PhaseClock {  // thread 0 accumulates into LDS (no global traffic inside 
     }
 };
 
+// gaussian (:199-204) with exp as v_exp_f32(x * log2 e): absolute error of a weight <= ~3e-8 (relative error |x| 2^-24 on
+// weights e^-|x|; the libm expf of the single-pass kernel is ~25 instructions, this is 3), far below the f32 noise of the sums the
+// weights enter.  The caller guarantees len > 1 and std > eps.
+__device__ __forceinline__ float gaussian_fast(float center, float index, float std_) {
+    const float r = (index - center) / std_;
+    return __builtin_amdgcn_exp2f((-0.5f * (r * r)) * 1.4426950408889634f);
+}
+
 // ---------------------------------------------------------------- scope_trigger_kernel
 // StableTrigger's scalar fields in registers for the length of a capture (ScopeTriggerState itself, with its padding array, is
 // left in scratch memory by the compiler — and a scratch reload's vmcnt(0) would drain the span DMA)
@@ -276,6 +284,7 @@ struct Ctx {
     float *ref, *dyn, *raw, *work, *tmpl;  // LDS: the fixed reference, the per-block region and its arrays
     uint32_t tmpl_stride;            // floats between template copies (0: one copy, unaligned sweeps)
     uint32_t dyn_floats;             // floats behind ref[]
+    float ref_peak;  // max |ref[]| of the resident reference (kept current by whoever changes ref[])
     RoundSums* sums;
     uint32_t round;  // parity selects the RoundSums set
     Reducer<W> red;
@@ -298,7 +307,9 @@ __device__ __forceinline__ void sweep_aligned(const float* work, const float* tm
     const float* xb[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) xb[m] = work + (off[m] - a);
-    // two groups per trip, all reads of the trip issued before its arithmetic (the other wavefront of the SIMD fills the wait)
+    // Interior groups 1 .. groups - 2, lane l takes 1 + l + 64 t.  The first `full` trips are complete for every lane: a uniform
+    // loop, two register sets alternating so that the reads of trip t + 1 are in flight while trip t is accumulated (no copies
+    // between the sets: hipcc then counts the waits instead of draining them); the last, partial trip is masked.
     auto accumulate = [&](const v4f& y, const v4f (&x)[M]) {
         const v2f y01{y.x, y.y}, y23{y.z, y.w};
 #pragma unroll
@@ -309,18 +320,30 @@ __device__ __forceinline__ void sweep_aligned(const float* work, const float* tm
             sxy[m] = pk_fma(x23, y23, pk_fma(x01, y01, sxy[m]));
         }
     };
-    for (uint32_t g = 1 + lane; g + 1 < groups; g += 128) {
-        const bool second = g + 64 + 1 < groups;
-        const uint32_t g2 = second ? g + 64 : g;
-        v4f y0, y1, x0[M], x1[M];
-        y0 = *reinterpret_cast<const v4f*>(tmpl_a + 4u * g);
+    auto fetch = [&](uint32_t g, v4f& y, v4f (&x)[M]) {
+        y = *reinterpret_cast<const v4f*>(tmpl_a + 4u * g);
 #pragma unroll
-        for (int m = 0; m < M; ++m) x0[m] = *reinterpret_cast<const v4f*>(xb[m] + 4u * g);
-        y1 = *reinterpret_cast<const v4f*>(tmpl_a + 4u * g2);
-#pragma unroll
-        for (int m = 0; m < M; ++m) x1[m] = *reinterpret_cast<const v4f*>(xb[m] + 4u * g2);
-        accumulate(y0, x0);
-        if (second) accumulate(y1, x1);
+        for (int m = 0; m < M; ++m) x[m] = *reinterpret_cast<const v4f*>(xb[m] + 4u * g);
+    };
+    const uint32_t interior = groups > 2 ? groups - 2 : 0u;
+    const uint32_t full = uni(interior >> 6);  // trips every lane takes
+    {
+        v4f ya, yb, xa[M], xb_[M];
+        uint32_t t = 0;
+        if (full) fetch(1 + lane, ya, xa);
+        while (t + 2 <= full) {  // set a holds trip t
+            fetch(1 + lane + 64u * (t + 1), yb, xb_);
+            accumulate(ya, xa);
+            fetch(1 + lane + 64u * min(t + 2, full - 1), ya, xa);  // (the last one may fetch a trip again: never accumulated twice)
+            accumulate(yb, xb_);
+            t += 2;
+        }
+        if (t < full) accumulate(ya, xa);
+        const uint32_t g = 1 + lane + 64u * full;
+        if (g + 1 < groups) {
+            fetch(g, ya, xa);
+            accumulate(ya, xa);
+        }
     }
     if (lane < 8) {  // edge groups: lanes 0-3 group 0, lanes 4-7 the last group; an element counts when it lies inside the window
         const uint32_t j = lane < 4 ? lane : 4u * (groups - 1) + (lane - 4);
@@ -481,7 +504,7 @@ __device__ __forceinline__ RoundScores select_round(Ctx<T>& c, uint32_t len, flo
 // cache lazily; here a round evaluates all of its entries — an entry evaluated again in a later round gives the same bits (its
 // sums are a pure function of work, template and offset), which is what the cache would have returned.
 template <int T>
-__device__ void find_best(Ctx<T>& c, uint32_t len, uint32_t search, float period, float sum_y, float sum_yy, uint32_t& best_off_out,
+__device__ __forceinline__ void find_best(Ctx<T>& c, uint32_t len, uint32_t search, float period, float sum_y, float sum_yy, uint32_t& best_off_out,
                           float& frac_out) {
     uint32_t stride = f2u(roundf(period / 16.0f));
     stride = min(max(stride, 1u), 128u);
@@ -529,20 +552,17 @@ __device__ void find_best(Ctx<T>& c, uint32_t len, uint32_t search, float period
 }
 
 // prepare_template (:422-439) + correlation_stats of it: -g(i) below the middle, +g(mirror) from it on (the middle element of an odd
-// length ends up +g), plus the learnt reference; one pass, one reduction.  Aligned mode writes the four delayed copies.
+// length ends up +g), plus the learnt reference; one pass.  Aligned mode writes the four delayed copies.
 template <int T>
-__device__ __forceinline__ void prepare_template(Ctx<T>& c, uint32_t len, float period, bool use_reference, float& sum_y, float& sum_yy) {
+__device__ __forceinline__ void prepare_template(Ctx<T>& c, uint32_t len, float period, bool use_reference, float (&acc)[2]) {
     const uint32_t midpoint = len / 2;
     const float max_width = fmaxf((float)max(midpoint, 1u) / 3.0f, 1.0f);
     const float width = rclamp(SLOPE_WIDTH_PERIODS * period, 1.0f, max_width);
-    float acc[2] = {0.0f, 0.0f};
+    acc[0] = acc[1] = 0.0f;  // per-thread partials of correlation_stats: the caller reduces them (with whatever else it has)
     const bool copies = c.aligned();
-    for (uint32_t e = threadIdx.x; e < len; e += T) {
-        const uint32_t mirror = len - 1 - e;
-        const bool lower = e < (len + 1) / 2 && mirror != e;
-        const float weight = gaussian(len, lower ? e : mirror, width);
-        float v = lower ? -0.5f * EDGE_STRENGTH * 2.0f * weight : 0.5f * EDGE_STRENGTH * 2.0f * weight;
-        if (use_reference) v += c.ref[e];
+    const bool flat = len <= 1 || width <= F32_EPS;  // gaussian() returns 0 (:200)
+    const float center = (float)(len - 1) * 0.5f;
+    auto put = [&](uint32_t e, float v) {  // v: the edge weight plus the learnt reference (x + 0 = x when there is none)
         c.tmpl[e] = v;
         if (copies) {
             c.tmpl[c.tmpl_stride + e + 1] = v;
@@ -551,6 +571,14 @@ __device__ __forceinline__ void prepare_template(Ctx<T>& c, uint32_t len, float 
         }
         acc[0] += v;
         acc[1] = __builtin_fmaf(v, v, acc[1]);
+    };
+    // the weight of element e < len / 2 serves e (negated) and its mirror: one exponential per pair; an odd middle element is +g
+    for (uint32_t e = threadIdx.x; e < (len + 1) / 2; e += T) {
+        const uint32_t mirror = len - 1 - e;
+        const float weight = flat ? 0.0f : gaussian_fast(center, (float)e, width);
+        const float r_lo = use_reference ? c.ref[e] : 0.0f, r_hi = use_reference ? c.ref[mirror] : 0.0f;
+        if (mirror != e) put(e, -0.5f * EDGE_STRENGTH * 2.0f * weight + r_lo);
+        put(mirror, 0.5f * EDGE_STRENGTH * 2.0f * weight + r_hi);
     }
     if (copies && threadIdx.x < 32) {  // zero padding of copy a: a floats in front, up to the next multiple of four (+4) behind
         const uint32_t a = threadIdx.x >> 3, q = threadIdx.x & 7u;
@@ -558,16 +586,13 @@ __device__ __forceinline__ void prepare_template(Ctx<T>& c, uint32_t len, float 
         if (q < a) ta[q] = 0.0f;
         ta[len + a + q] = 0.0f;
     }
-    c.red.template run<2, 0>(acc);  // its barrier also publishes tmpl[] (and work[], written just before)
-    sum_y = acc[0];
-    sum_yy = acc[1];
 }
 
 // write_candidate (:509-527): candidate = windowed, peak-normalised, mean-removed segment; returns its correlation with the
 // reference.  Two reductions: (sum, max, min) of the segment give mean and peak (|x - mean| is largest at an extreme of x, and
 // rounding is monotone, so the peak is exact); then the five sums of normalized_correlation + correlation_stats.
 template <int T>
-__device__ float write_candidate(Ctx<T>& c, const float* seg, uint32_t n, float period) {
+__device__ __forceinline__ float write_candidate(Ctx<T>& c, const float* seg, uint32_t n, float period) {
     float* cand = c.tmpl;
     float r3[3] = {0.0f, NEG_INF, -NEG_INF};
     for (uint32_t i = threadIdx.x; i < n; i += T) {
@@ -582,18 +607,24 @@ __device__ float write_candidate(Ctx<T>& c, const float* seg, uint32_t n, float 
     const float scale = 1.0f / fmaxf(pk, NORMALIZE_FLOOR);  // normalize_peak (:191-197)
     const float std_ = fmaxf(period * BUFFER_FALLOFF_PERIODS, 1.0f);
     float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // sum y, sum y^2, sum x, sum x^2, sum x y
-    for (uint32_t i = threadIdx.x; i < n; i += T) {
-        const uint32_t mirror = n - 1 - i;
-        const float weight = gaussian(n, i < (n + 1) / 2 ? i : mirror, std_);
-        float yv = (seg[i] - mean) * scale;
+    const bool flat = n <= 1 || std_ <= F32_EPS;
+    const float center = (float)(n - 1) * 0.5f;
+    auto put = [&](uint32_t i, float sv, float xv, float weight) {
+        float yv = (sv - mean) * scale;
         yv *= weight;
         cand[i] = yv;
-        const float xv = c.ref[i];
         acc[0] += yv;
         acc[1] = __builtin_fmaf(yv, yv, acc[1]);
         acc[2] += xv;
         acc[3] = __builtin_fmaf(xv, xv, acc[3]);
         acc[4] = __builtin_fmaf(xv, yv, acc[4]);
+    };
+    for (uint32_t i = threadIdx.x; i < (n + 1) / 2; i += T) {  // one weight per mirrored pair (:519-526)
+        const uint32_t mirror = n - 1 - i;
+        const float weight = flat ? 0.0f : gaussian_fast(center, (float)i, std_);
+        const float s_lo = seg[i], s_hi = seg[mirror], x_lo = c.ref[i], x_hi = c.ref[mirror];
+        put(i, s_lo, x_lo, weight);
+        if (mirror != i) put(mirror, s_hi, x_hi, weight);
     }
     c.red.template run<5, 0>(acc);  // its barrier also publishes cand[]
     if (n == 0) return 0.0f;
@@ -607,7 +638,8 @@ __device__ float write_candidate(Ctx<T>& c, const float* seg, uint32_t n, float 
 
 // locate (:358-411) on the LDS-resident reference of this trigger
 template <int T>
-__device__ Capture locate(Ctx<T>& c, TrigRegs& t, const View& trace, Estimate est, uint32_t cycles, float rate) {
+__device__ __forceinline__ Capture locate(Ctx<T>& c, uint32_t& t_ref_len, float& t_reference_period, float& t_mean, const View& trace, Estimate est,
+                                          uint32_t cycles, float rate) {
     const Capture none{0, 0.0f, 0, 0.0f};
     const uint32_t n = trace.n;
     const float period = fmaxf(est.period, 1.0f);
@@ -646,32 +678,35 @@ __device__ Capture locate(Ctx<T>& c, TrigRegs& t, const View& trace, Estimate es
     }
     c.pc.mark(1);  // span load issued
     // prepare (:413-420): retune_reference (:486-498) ...
-    if (t.ref_len == 0) {
+    if (t_ref_len == 0) {
         for (uint32_t i = threadIdx.x; i < len; i += T) c.ref[i] = 0.0f;
-        t.ref_len = len;
-        t.reference_period = period;
+        t_ref_len = len;
+        t_reference_period = period;
+        c.ref_peak = 0.0f;
         lds_barrier();
     } else {
-        const float semitones = log2f(period / t.reference_period) * 12.0f;
-        if (t.ref_len != len || fabsf(semitones) >= BUFFER_RETUNE_SEMITONES) {  // retune_reference fn (:249-263), through tmpl[]
-            const float ratio = period / t.reference_period;
+        const float semitones = log2f(period / t_reference_period) * 12.0f;
+        if (t_ref_len != len || fabsf(semitones) >= BUFFER_RETUNE_SEMITONES) {  // retune_reference fn (:249-263), through tmpl[]
+            const float ratio = period / t_reference_period;
             const bool bad = !isfinite(ratio) || ratio <= F32_EPS;
-            const float old_center = (float)(t.ref_len ? t.ref_len - 1 : 0) * 0.5f;
+            const float old_center = (float)(t_ref_len ? t_ref_len - 1 : 0) * 0.5f;
             const float new_center = (float)(len ? len - 1 : 0) * 0.5f;
-            for (uint32_t i = threadIdx.x; i < len; i += T)
-                c.tmpl[i] = bad ? 0.0f : sample_linear_zero(c.ref, t.ref_len, old_center + ((float)i - new_center) / ratio);
-            lds_barrier();
+            float pk[1] = {0.0f};
+            for (uint32_t i = threadIdx.x; i < len; i += T) {
+                const float v = bad ? 0.0f : sample_linear_zero(c.ref, t_ref_len, old_center + ((float)i - new_center) / ratio);
+                c.tmpl[i] = v;
+                pk[0] = fmaxf(pk[0], fabsf(v));
+            }
+            c.red.template run<1, OP_MAX>(pk);
+            c.ref_peak = pk[0];
             for (uint32_t i = threadIdx.x; i < len; i += T) c.ref[i] = c.tmpl[i];
-            t.ref_len = len;
-            t.reference_period = period;
+            t_ref_len = len;
+            t_reference_period = period;
             lds_barrier();
         }
     }
-    // ... any(|reference| > 1e-3) (:381) as the reference's peak ...
-    float red1[1] = {0.0f};
-    for (uint32_t i = threadIdx.x; i < len; i += T) red1[0] = fmaxf(red1[0], fabsf(c.ref[i]));
-    c.red.template run<1, OP_MAX>(red1);
-    const float ref_peak = red1[0];
+    // ... any(|reference| > 1e-3) (:381) as the reference's peak (carried along: taken where the reference last changed) ...
+    const float ref_peak = c.ref_peak;
     const bool use_reference = ref_peak > 1.0e-3f;
     const bool confident = est.confidence >= MIN_PERIODICITY;
     uint32_t offset = 0;
@@ -680,22 +715,30 @@ __device__ Capture locate(Ctx<T>& c, TrigRegs& t, const View& trace, Estimate es
     // (:383-399) as one loop: pass 0 searches with the learnt reference in the template; a confident estimate then writes the
     // candidate, and a candidate that no longer matches the reference (< 0.3) clears it and searches once more (pass 1)
     for (int pass = 0;; ++pass) {
-        float sum_y, sum_yy;
-        prepare_template(c, len, period, use_reference && pass == 0, sum_y, sum_yy);  // does not depend on the span
+        float acc[3];
+        {
+            float ty[2];
+            prepare_template(c, len, period, use_reference && pass == 0, ty);  // does not depend on the span
+            acc[0] = ty[0];
+            acc[1] = ty[1];
+            acc[2] = 0.0f;
+        }
         if (pass == 0) {
-            c.pc.mark(2);  // retune, reference peak, template + its statistics
-            // ... and the EMA-tracked mean of the span
+            c.pc.mark(2);  // retune, template
+            // ... and the EMA-tracked mean of the span: its sum rides in the same reduction as the template's statistics
             wait_vm0();  // this wavefront's part of the span has landed
-            float red2[1] = {0.0f};
-            for (uint32_t i = threadIdx.x; i < data.n; i += T) red2[0] += c.raw[i];
-            c.red.template run<1, OP_SUM>(red2);
-            const float mean = red2[0] / (float)max(data.n, 1u);
-            t.mean += MEAN_RESPONSIVENESS * (mean - t.mean);
-            const float tm = t.mean;
+            for (uint32_t i = threadIdx.x; i < data.n; i += T) acc[2] += c.raw[i];
+        }
+        c.red.template run<3, 0>(acc);  // its barrier also publishes tmpl[]
+        const float sum_y = acc[0], sum_yy = acc[1];
+        if (pass == 0) {
+            const float mean = acc[2] / (float)max(data.n, 1u);
+            t_mean += MEAN_RESPONSIVENESS * (mean - t_mean);
+            const float tm = t_mean;
             for (uint32_t i = threadIdx.x; i < data.n; i += T) c.work[i] = c.raw[i] - tm;
             if (threadIdx.x < 8) c.work[data.n + threadIdx.x] = 0.0f;  // read (and masked out) by the last aligned group
             lds_barrier();  // work[] (and every wavefront's part of raw[])
-            c.pc.mark(3);  // span consumed: mean, work[]
+            c.pc.mark(3);  // template statistics + span mean, work[]
         }
         find_best(c, len, search, period, sum_y, sum_yy, offset, frac_offset);
         c.pc.mark(4);  // coarse-to-fine search
@@ -711,16 +754,20 @@ __device__ Capture locate(Ctx<T>& c, TrigRegs& t, const View& trace, Estimate es
         break;
     }
     if (confident) {
-        // update_reference (:500-507): normalize_peak (:191-197) by the peak taken above (0 after a reset), then the EMA, one pass
+        // update_reference (:500-507): normalize_peak (:191-197) by the carried peak (0 after a reset), then the EMA, one pass;
+        // the new reference's peak is taken on the way (its reduction is also the barrier that ends this capture's use of ref[])
         const float rscale = 1.0f / fmaxf(reset ? 0.0f : ref_peak, NORMALIZE_FLOOR);
+        float pk[1] = {0.0f};
         for (uint32_t i = threadIdx.x; i < len; i += T) {
             float rv = c.ref[i] * rscale;
             rv += BUFFER_RESPONSIVENESS * (c.tmpl[i] - rv);
             c.ref[i] = rv;
+            pk[0] = fmaxf(pk[0], fabsf(rv));
         }
-        t.reference_period += BUFFER_RESPONSIVENESS * (period - t.reference_period);
+        c.red.template run<1, OP_MAX>(pk);
+        c.ref_peak = pk[0];
+        t_reference_period += BUFFER_RESPONSIVENESS * (period - t_reference_period);
     }
-    lds_barrier();  // ref[] / tmpl[] / raw[] are free for the next capture
     c.pc.mark(6);  // reference update
     uint32_t start = left + offset;
     if (frac_offset < 0.0f && start > 0) {
@@ -732,7 +779,7 @@ __device__ Capture locate(Ctx<T>& c, TrigRegs& t, const View& trace, Estimate es
 
 // find_rising_zero_crossing over indices lo..=hi (:530-551); reversed = iterate from hi down
 template <int T>
-__device__ uint32_t find_rising_zero_crossing(Ctx<T>& c, const View& v, uint32_t lo, uint32_t hi, bool reversed) {
+__device__ __forceinline__ uint32_t find_rising_zero_crossing(Ctx<T>& c, const View& v, uint32_t lo, uint32_t hi, bool reversed) {
     if (lo > hi) return 0xFFFFFFFFu;  // callers only pass in-range spans (hi < v.n)
     // a crossing between adjacent indices (i - 1, i): v[i] > 0 && v[i - 1] <= 0, reported as i
     if (!reversed) {
@@ -753,7 +800,7 @@ __device__ uint32_t find_rising_zero_crossing(Ctx<T>& c, const View& v, uint32_t
 
 // zero_crossing_capture (:769-786)
 template <int T>
-__device__ Capture zero_crossing_capture(Ctx<T>& c, const View& v, uint32_t frames_in, uint32_t search_range) {
+__device__ __forceinline__ Capture zero_crossing_capture(Ctx<T>& c, const View& v, uint32_t frames_in, uint32_t search_range) {
     const uint32_t frames = min(frames_in, v.n);
     if (frames == 0) return Capture{0, 0.0f, 0, 0.0f};
     const uint32_t end = v.n > 0 ? v.n - 1 : 0;
@@ -842,11 +889,14 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
             if (blk != 0) lds_barrier();  // every thread has taken its estimate of the chunk's last block
             if (tid < cnt) (&est_lds[0][0])[tid] = src[tid];
         }
-        __syncthreads();
-        auto view_of = [&](int t) { return View{rings + (uint64_t)t * a.cap, uni(s_head[par][t] - s_len[par][t]), mask, uni((uint32_t)s_len[par][t])}; };
+        lds_barrier();  // positions, estimates; and the previous block is through with every LDS array
+        auto view_of = [&](int t) {
+            return View{rings + (uint64_t)t * a.cap, uni((uint32_t)((s_head[par][t] - s_len[par][t]) & mask)), (uint32_t)mask, uni((uint32_t)s_len[par][t])};
+        };
 
         // ---- captures (:683-700): job 0 the linked capture, jobs 1 / 2 the slots' own when there is no linked one
         Capture linked{0, 0.0f, 0, 0.0f}, cap0{0, 0.0f, 0, 0.0f}, cap1{0, 0.0f, 0, 0.0f};
+        bool ran = false;
         for (int job = 0; job < 3; ++job) {
             int view_index, trig_index;
             if (job == 0) {
@@ -864,13 +914,21 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
             }
             const View trace = view_of(view_index);
             Capture cap{0, 0.0f, 0, 0.0f};
+            if (ran) lds_barrier();  // a second capture in one block: the first one's LDS arrays and trigger record are settled
             if (!stable) {
                 cap = zero_crossing_capture(c, trace, a.base_frames, a.max_period);
             } else if (trace.n >= a.base_frames) {
                 // StableTrigger::capture (:306-334); the trigger state lives in LDS, thread-uniform updates are done redundantly
                 const ScopeEstimate& pl = est_lds[blk % kEstChunk][view_index];
                 const ScopeEstimate pre{uni(pl.some), uni(pl.period), uni(pl.confidence), uni(pl.last_peak)};
-                TrigRegs local = load_trig_uniform(trig[trig_index]);
+                // (plain scalars, not a struct handed around by reference: hipcc otherwise keeps two of the fields in scratch memory,
+                // and a scratch reload costs a global-memory round trip per block)
+                int has_period = uni(trig[trig_index].has_period);
+                float period = uni(trig[trig_index].period);
+                uint32_t missed = uni(trig[trig_index].missed_periods);
+                float reference_period = uni(trig[trig_index].reference_period);
+                float mean = uni(trig[trig_index].mean);
+                uint32_t ref_len = uni(trig[trig_index].ref_len);
                 if (resident != trig_index) {  // bring this trigger's learnt reference into LDS (kept there for the rest of the call)
                     if (resident >= 0) {
                         float* g = a.reference + ((uint64_t)s * kScopeTraces + resident) * a.max_kernel;
@@ -878,23 +936,58 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
                     }
                     __syncthreads();
                     const float* gn = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
-                    for (uint32_t i = tid; i < local.ref_len; i += T) c.ref[i] = gn[i];
+                    float pk[1] = {0.0f};
+                    for (uint32_t i = tid; i < ref_len; i += T) {
+                        const float v = gn[i];
+                        c.ref[i] = v;
+                        pk[0] = fmaxf(pk[0], fabsf(v));
+                    }
+                    c.red.template run<1, OP_MAX>(pk);  // (its barrier publishes ref[])
+                    c.ref_peak = pk[0];
                     resident = trig_index;
-                    __syncthreads();
                 }
                 c.pc.mark(0);  // bookkeeping
                 const uint32_t probe_len = min(a.probe_frames, trace.n);
-                if (probe_len > 0 && pre.last_peak < MIN_SIGNAL_PEAK) trigger_unlock(local);
-                const Estimate est = stabilize(local, Estimate{pre.some, pre.period, pre.confidence});
-                if (est.some) cap = locate(c, local, trace, est, a.num_cycles, a.sample_rate);
+                if (probe_len > 0 && pre.last_peak < MIN_SIGNAL_PEAK) {  // unlock (:298-304)
+                    has_period = 0;
+                    missed = 0;
+                    ref_len = 0;
+                    reference_period = 0.0f;
+                    mean = 0.0f;
+                }
+                Estimate est{pre.some, pre.period, pre.confidence};  // stabilize (:336-356)
+                if (!est.some) {
+                    if (has_period) {
+                        missed = missed >= 255 ? 255 : missed + 1;
+                        if (missed > MAX_MISSED_PERIODS) {
+                            has_period = 0;
+                            missed = 0;
+                            ref_len = 0;
+                            reference_period = 0.0f;
+                            mean = 0.0f;
+                        } else {
+                            est = Estimate{1, period, 0.0f};
+                        }
+                    }
+                } else {
+                    missed = 0;
+                    if (has_period) {
+                        const float r = est.period / period;
+                        if (r >= 0.9f && r <= 1.1f) est.period = period + 0.35f * (est.period - period);
+                    }
+                    has_period = 1;
+                    period = est.period;
+                }
+                if (est.some) cap = locate(c, ref_len, reference_period, mean, trace, est, a.num_cycles, a.sample_rate);
                 if (!cap.some) {
                     cap.some = 1;
                     cap.span = (float)max(a.base_frames > 0 ? a.base_frames - 1 : 0u, 1u);
                     cap.start = trace.n > a.base_frames ? trace.n - a.base_frames : 0;
                     cap.frac_offset = 0.0f;
                 }
+                const TrigRegs local{has_period, period, missed, reference_period, mean, ref_len};
                 if (tid == 0) store_trig(trig[trig_index], local);
-                lds_barrier();
+                ran = true;
             }
             if (job == 0) linked = cap;
             else if (job == 1) cap0 = cap;
@@ -1047,7 +1140,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
     const uint64_t head = head0 + (uint64_t)(blk + 1) * a.block_frames;
     const uint32_t n = (uint32_t)min((uint64_t)a.probe_frames, n_trace);
     const float* ring = a.rings + ((uint64_t)s * kScopeTraces + view) * a.cap;
-    const uint64_t mask = a.cap - 1, start = head - n;
+    const uint32_t mask = (uint32_t)(a.cap - 1), start = (uint32_t)((head - n) & (a.cap - 1));  // 32-bit index arithmetic per load
     float last_peak = 0.0f;
     if (n < 3) {  // (:308-313: the estimator is not run, last_peak = 0)
         if (tid == 0) *out = none;

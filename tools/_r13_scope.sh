@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -x -q -k "oscilloscope or scope" 2>&1 | tail -15 > gpurun_out/r13_scope_tests.txt
-for T in 512 1024; do
+for T in ${SCOPE_TS:-512}; do
 export OMX_SCOPE_THREADS=$T
 echo "== threads $T" >> gpurun_out/r13_scope_phases1.txt
 timeout 300 python tools/scope_phases.py >> gpurun_out/r13_scope_phases1.txt 2>&1

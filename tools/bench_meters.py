@@ -113,6 +113,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "waveform":
         waveform()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "scope":  # cfg4's two banks only (tools/profile_scope_sq.sh)
+        scope_stereo()
+        sys.exit(0)
     loudness()
     scope_stereo()
     waveform()

@@ -34,7 +34,7 @@ sc.process_device(pcm[:, frames:2 * frames].contiguous().data_ptr(), 256, blocks
 torch.cuda.synchronize()
 f(out, 10, 1)
 c = np.array(out[:], np.float64)
-names = ["bookkeeping", "span load issued", "retune / reference peak / template + statistics", "span consumed: mean, work", "coarse-to-fine search",
+names = ["bookkeeping", "span load issued", "retune / template", "template statistics + span mean, work", "coarse-to-fine search",
          "candidate vs reference", "reference update", "snapshot + header", "  search: sweeps + barrier", "  search: scores + argmax"]
 for name, v in zip(names, c):
     print(f"{name:44s} {v / c.sum() * 100:5.1f} %   {v / (S * blocks):9.0f} cycles/block")
