@@ -1193,32 +1193,37 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
     __syncthreads();
     {   // E[i + 1] = c_i^2 + E[i] (:141-146): per-thread chunks, a wave scan of the chunk sums, the wavefronts in order; in place
         // (the squares sit one slot below their prefix: every chunk is in registers before anything is overwritten)
-        const uint32_t chunk = (n + 255) / 256;  // <= 32 (n <= 8192)
+        const uint32_t chunk = (n + 255) / 256;  // <= 32 (n <= 8192); 19 at the 4800-sample probe of 48 kHz
         const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
-        float sq[32];
-        float local = 0.0f;
+        auto scan = [&](auto ctag) {
+            constexpr int C = decltype(ctag)::value;
+            float sq[C];
+            float local = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const uint32_t i = lo + (uint32_t)q;
-            sq[q] = (uint32_t)q < chunk && i < hi ? E[i] : 0.0f;
-            local = sq[q] + local;
-        }
-        const float incl = wave_scan<OP_SUM>(local);  // inclusive over the wavefront
-        const unsigned lane = tid & 63u, wave = tid >> 6;
-        if (lane == 63) slots.f[red.phase][0][wave] = incl;
-        __syncthreads();  // (also: every chunk is in registers)
-        float base = incl - local;
-        for (unsigned w = 0; w < wave; ++w) base += slots.f[red.phase][0][w];
-        red.phase ^= 1;
-        if (tid == 0) E[0] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const uint32_t i = lo + (uint32_t)q;
-            if ((uint32_t)q < chunk && i < hi) {
-                base = sq[q] + base;
-                E[1 + i] = base;
+            for (int q = 0; q < C; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                sq[q] = (uint32_t)q < chunk && i < hi ? E[i] : 0.0f;
+                local = sq[q] + local;
             }
-        }
+            const float incl = wave_scan<OP_SUM>(local);  // inclusive over the wavefront
+            const unsigned lane = tid & 63u, wave = wave_index();
+            if (lane == 63) slots.f[red.phase][0][wave] = incl;
+            __syncthreads();  // (also: every chunk is in registers)
+            float base = incl - local;
+            for (unsigned w = 0; w < wave; ++w) base += slots.f[red.phase][0][w];
+            red.phase ^= 1;
+            if (tid == 0) E[0] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                if ((uint32_t)q < chunk && i < hi) {
+                    base = sq[q] + base;
+                    E[1 + i] = base;
+                }
+            }
+        };
+        if (chunk <= 20) scan(std::integral_constant<int, 20>{});
+        else scan(std::integral_constant<int, 32>{});
     }
     __syncthreads();
     const float total_energy = E[n];
@@ -1247,12 +1252,16 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         const uint32_t k = (uint32_t)(j + 256 * t);
         const v2f z = v[t];
         const v2f zr = fft[pad16((int)((N - k) & (N - 1)))];
-        const v2f e{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr) / 2
-        const v2f o{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr) / (2i)
+        // (two-element vector arithmetic: v_pk_add / v_pk_mul / v_pk_fma halve the VALU count of this step)
+        const v2f zc{zr.x, -zr.y};                       // conj Zr
+        const v2f e = (z + zc) * 0.5f;                    // (Z + conj Zr) / 2
+        const v2f d = (z - zc) * 0.5f;                    // (Z - conj Zr) / 2
+        const v2f o{d.y, -d.x};                           // ... / i
         const v2f w = w8[t];
-        const v2f wo{o.x * w.x - o.y * w.y, o.x * w.y + o.y * w.x};
-        const v2f xp{e.x + wo.x, e.y + wo.y}, xm{e.x - wo.x, e.y - wo.y};
-        const float p0 = xp.x * xp.x + xp.y * xp.y, p1 = xm.x * xm.x + xm.y * xm.y;  // P[k], P[k + N]
+        const v2f wo = cmul(o, w);                        // w^k O
+        const v2f xp = e + wo, xm = e - wo;               // X[k], X[k + N]
+        const v2f sqp = xp * xp, sqm = xm * xm;
+        const float p0 = sqp.x + sqp.y, p1 = sqm.x + sqm.y;  // P[k], P[k + N]
         const float sum = p0 + p1, dif = p0 - p1;
         y[t] = v2f{sum + dif * w.y, dif * w.x};
     }
@@ -1361,7 +1370,11 @@ void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_estimate2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (const char* e = getenv("OMX_SCOPE_THREADS")) threads = atoi(e) == 1024 ? 1024 : 512;  // tuning hook (same results: see the tests)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (const char* e = getenv("OMX_SCOPE_THREADS")) {  // tuning hook
+            const int t = atoi(e);
+            threads = t == 1024 || t == 256 ? t : 512;
+        }
         attr_set = true;
     }
     if (a.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && a.est_view_count) {
@@ -1371,7 +1384,9 @@ void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream) {
     const TriggerLayout l = trigger_layout(a.max_kernel, a.max_period);
     const uint32_t len4 = (a.max_kernel + 12 + 3) & ~3u;
     const uint32_t lds_floats = std::min<uint32_t>(l.ref + l.dyn_min + 3 * len4, 152 * 1024 / sizeof(float));  // + ~5 KiB of static LDS <= 160 KiB
-    if (threads == 1024)
+    if (threads == 256)
+        hipLaunchKernelGGL(scope_trigger_kernel<256>, dim3(a.n_streams), dim3(256), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
+    else if (threads == 1024)
         hipLaunchKernelGGL(scope_trigger_kernel<1024>, dim3(a.n_streams), dim3(1024), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
     else
         hipLaunchKernelGGL(scope_trigger_kernel<512>, dim3(a.n_streams), dim3(512), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
