@@ -64,8 +64,8 @@ class SpectrogramBank:
         """Streams advance independently: stream s receives frames[s] (<= frames_capacity) new frames, after reset_audio() when
         reset_mask[s]; pcm = device f32 [n_streams][frames_capacity][channels].  Returns the CSpectrogramRaggedUpdate."""
         out = capi.CSpectrogramRaggedUpdate()
-        fr = np.ascontiguousarray(frames, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("spectrogram_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
         self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
@@ -143,8 +143,8 @@ class SpectrumBank:
         """Streams advance independently: stream s receives frames[s] (<= frames_capacity) new frames, after reset_audio() when
         reset_mask[s]; pcm = device f32 [n_streams][frames_capacity][channels].  Returns the CSpectrumRaggedUpdate."""
         out = capi.CSpectrumRaggedUpdate()
-        fr = np.ascontiguousarray(frames, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("spectrum_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
         self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
@@ -162,6 +162,14 @@ class SpectrumBank:
         self.api.check(self.api.fn("spectrum_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p])(
             self._h, stream_index, hop, buf.ctypes.data))
         return buf
+
+
+def _per_stream(values, n_streams, dtype, what):
+    """A per-stream argument of a ragged call as a contiguous array of exactly n_streams entries (the C side reads that many)."""
+    arr = np.ascontiguousarray(values, dtype).reshape(-1)
+    if arr.size != n_streams:
+        raise ValueError(f"{what}: {arr.size} entries for a bank of {n_streams} streams")
+    return arr
 
 
 class _BlockBank:
@@ -228,8 +236,8 @@ class LoudnessBank(_BlockBank):
         when reset_mask[s]; pcm = device f32 [n_streams][block_frames * max_blocks][channels].  Returns the CLoudnessRaggedUpdate
         (snapshots of stream s, block k: fetch(s, k) for k < n_blocks[s])."""
         out = capi.CLoudnessRaggedUpdate()
-        nb = np.ascontiguousarray(n_blocks, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        nb = _per_stream(n_blocks, self.n_streams, np.uint32, "n_blocks")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("loudness_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
                          C.c_void_p])
@@ -290,8 +298,8 @@ class StereometerBank(_BlockBank):
         when reset_mask[s]; pcm = device f32 [n_streams][block_frames * max_blocks][channels].  fetch(s, k) for k < n_blocks[s];
         fetch_points(s, band) returns the points of the stream's last block when it produced a snapshot (else none)."""
         out = CStereometerRaggedUpdate()
-        nb = np.ascontiguousarray(n_blocks, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        nb = _per_stream(n_blocks, self.n_streams, np.uint32, "n_blocks")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("stereometer_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
                          C.c_void_p])
@@ -362,8 +370,8 @@ class OscilloscopeBank(_BlockBank):
         when reset_mask[s]; pcm = device f32 [n_streams][block_frames * max_blocks][channels].  Headers of stream s, block k:
         fetch(s, k) for k < n_blocks[s]; fetch(s, n_blocks[s] - 1, with_samples=True) adds the stream's newest snapshot."""
         out = COscilloscopeRaggedUpdate()
-        nb = np.ascontiguousarray(n_blocks, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        nb = _per_stream(n_blocks, self.n_streams, np.uint32, "n_blocks")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("oscilloscope_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
                          C.c_void_p])
@@ -409,8 +417,8 @@ class WaveformBank(_BlockBank):
         reset_mask[s]; pcm = device f32 [n_streams][frames_capacity][channels].  Returns the CWaveformRaggedUpdate; columns of stream
         s: fetch(s, update.max_columns)[0][:n_columns[s]]."""
         out = capi.CWaveformRaggedUpdate()
-        fr = np.ascontiguousarray(frames, np.uint32)
-        mask = np.ascontiguousarray(reset_mask, np.uint8) if reset_mask is not None else None
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
         f = self.api.fn("waveform_bank_process_ragged", C.c_int,
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
         self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,

@@ -233,12 +233,21 @@ std::vector<float> derivative_window_host(const std::vector<float>& window) {
     std::vector<float> out(n, 0.0f);
     if (n <= 1) return out;
     // X[k] = sum_j w[j] e^{-2 pi i j k / n};  D[k] = i omega_k X[k] (0 at DC and, for even n, at Nyquist);  w'[j] = Re IDFT(D)[j] / n
+    // (one n-entry table of e^{-2 pi i m / n}, indexed by (j k) mod n: the two O(n^2) sums are multiply-adds only — at the 65 536
+    // samples this path accepts, per-term cos / sin would be minutes of libm calls)
+    std::vector<std::complex<double>> tw(n);
+    for (size_t m = 0; m < n; ++m) {
+        const double ang = -2.0 * M_PI * (double)m / (double)n;
+        tw[m] = std::complex<double>(std::cos(ang), std::sin(ang));
+    }
     std::vector<std::complex<double>> X(n);
     for (size_t k = 0; k < n; ++k) {
         std::complex<double> acc(0.0, 0.0);
+        size_t m = 0;  // (j k) mod n, advanced by k per term
         for (size_t j = 0; j < n; ++j) {
-            const double ang = -2.0 * M_PI * (double)((j * k) % n) / (double)n;
-            acc += (double)window[j] * std::complex<double>(std::cos(ang), std::sin(ang));
+            acc += (double)window[j] * tw[m];
+            m += k;
+            if (m >= n) m -= n;
         }
         X[k] = acc;
     }
@@ -250,9 +259,12 @@ std::vector<float> derivative_window_host(const std::vector<float>& window) {
     }
     for (size_t j = 0; j < n; ++j) {
         double acc = 0.0;
+        size_t m = 0;
         for (size_t k = 0; k < n; ++k) {
-            const double ang = 2.0 * M_PI * (double)((j * k) % n) / (double)n;
-            acc += X[k].real() * std::cos(ang) - X[k].imag() * std::sin(ang);
+            const std::complex<double> w = std::conj(tw[m]);  // e^{+2 pi i j k / n}
+            acc += X[k].real() * w.real() - X[k].imag() * w.imag();
+            m += j;
+            if (m >= n) m -= n;
         }
         out[j] = (float)(acc / (double)n);
     }

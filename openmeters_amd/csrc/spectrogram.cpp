@@ -59,6 +59,7 @@ SpectrogramBank::SpectrogramBank(const omx_spectrogram_config& cfg, uint32_t n_s
 
 void SpectrogramBank::reset_audio() {  // :212-217
     ragged_ = false;  // every stream drops its pending audio: the common host-side positions describe the bank again
+    ragged_pending_bound_ = 0;
     tail_ = head_;
     pending_skip_ = 0;
     clear_last_nonzero(last_stream_);
@@ -215,6 +216,7 @@ void SpectrogramBank::update_config(const omx_spectrogram_config& in, hipStream_
     const omx_spectrogram_config prev = cfg_;
     const bool prepared = prepared_;
     if (prepared) require_supported(cfg);  // rejected configurations leave the handle exactly as it was (old config, old tables)
+    const uint64_t old_read_len = prev.use_reassignment ? hilbert_len_ : prev.fft_size;
     cfg_ = cfg;
     const bool rate_changed = prev.sample_rate != cfg.sample_rate;
     const bool rebuild = prev.fft_size != cfg.fft_size || prev.zero_padding_factor != cfg.zero_padding_factor ||
@@ -229,6 +231,20 @@ void SpectrogramBank::update_config(const omx_spectrogram_config& in, hipStream_
     const bool hop_changed = prev.hop_size != cfg.hop_size;
     if (hop_changed) pending_skip_ = 0;
     reset_ = reset_ || rebuild || hop_changed;
+    if (ragged_ && (rebuild || hop_changed)) {
+        // the same steps on every stream's own positions (they live on the device once process_ragged has run): a rebuild keeps
+        // the newest 2 * active_len samples (:275-278) or, on a rate change, none; pending_skip goes (:534-536, rebuild_fft); the
+        // next update of every stream carries `reset`
+        const uint64_t active_len = cfg_.use_reassignment ? hilbert_len_ : fft_size_;  // (as rebuild_fft has just left them)
+        const uint64_t keep = rate_changed ? 0 : active_len * 2;
+        const bool trim = rebuild && prepared;
+        launch_spectrogram_ragged_config(n_streams_, r_head_.ptr, r_tail_.ptr, r_skip_.ptr, r_reset_flag_.ptr, last_nonzero_.ptr, trim, keep,
+                                         hop_changed || trim, rate_changed && trim, stream);
+        OMX_HIP(hipGetLastError());
+        // what a stream can still hold when the next call sizes its ring and column count
+        const uint64_t before = std::max<uint64_t>(ragged_pending_bound_, old_read_len ? old_read_len - 1 : 0);
+        ragged_pending_bound_ = trim ? std::min<uint64_t>(before, keep) : before;
+    }
 }
 
 // The column kernels of one call: `n_cols` = columns per stream slot of the outputs; lock-step banks pass the common tail,
@@ -479,9 +495,15 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
                                     omx_spectrogram_ragged_update* out) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
-    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) return OMX_ERR_INVALID;
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
+        set_last_error("spectrogram process_ragged: frames_capacity must be 1 .. 2^32 - 1");
+        return OMX_ERR_INVALID;
+    }
     for (uint32_t s = 0; s < n_streams_; ++s)
-        if (frames[s] > frames_capacity) return OMX_ERR_INVALID;
+        if (frames[s] > frames_capacity) {
+            set_last_error("spectrogram process_ragged: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
     const float sample_rate = sanitize_sample_rate(sample_rate_in);
     if (cfg_.sample_rate != sample_rate) {  // a format change concerns every stream of the bank (:493-500)
         cfg_.sample_rate = sample_rate;
@@ -498,7 +520,7 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
     const uint64_t retained = history_columns(kind, (uint32_t)bin_count, cfg_.history_length);
     // every stream enters a call with fewer than read_len pending samples (all of its ready windows were consumed), except right
     // after the switch from lock-step mode, where the common pending count is known
-    const uint64_t pending_bound = std::max<uint64_t>(head_ - tail_, read_len ? read_len - 1 : 0);
+    const uint64_t pending_bound = std::max<uint64_t>(std::max<uint64_t>(head_ - tail_, ragged_pending_bound_), read_len ? read_len - 1 : 0);
     const uint64_t most = pending_bound + frames_capacity;
     const uint64_t max_cols = std::min<uint64_t>(most >= read_len ? (most - read_len) / hop + 1 : 0, retained);
     if (max_cols > 0xFFFFFFFFull / std::max<uint64_t>(n_streams_, 1)) unsupported("too many columns in one call");
@@ -556,7 +578,13 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
     ia.partial_nonzero = partial_nonzero_.ptr;
     launch_ingest(ia, n_streams_, stream);
     OMX_HIP(hipGetLastError());
-    head_ = tail_ = 0;  // from here on only the bound above uses them (pending_bound = read_len - 1)
+    head_ = tail_ = 0;  // from here on only the bounds above use them (pending_bound = read_len - 1)
+    {   // a stream that sat this call out still holds what update_config / the lock-step calls left it
+        bool all_fed = true;
+        for (uint32_t s = 0; s < n_streams_; ++s) all_fed = all_fed && frames[s] != 0;
+        if (all_fed) ragged_pending_bound_ = 0;
+        else ragged_pending_bound_ = pending_bound;
+    }
 
     if (max_cols > 0) {
         launch_columns(max_cols, 0, r_col_tail_.ptr, r_ncols_.ptr, stream);

@@ -63,6 +63,7 @@ private:
     size_t host_output_limit_ = 0;
     // ragged mode: per-stream positions on the device
     bool ragged_ = false;
+    uint64_t ragged_pending_bound_ = 0;  // ragged mode: the most pending samples a stream can hold beyond read_len - 1 (after update_config)
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_col_tail_;
     DeviceBuffer<uint32_t> r_reset_flag_, r_frames_, r_ing_skip_, r_ing_count_, r_ncols_, r_reset_out_;
     DeviceBuffer<uint8_t> r_mask_;

@@ -135,9 +135,11 @@ void SpectrumBank::update_config(const omx_spectrum_config& in, hipStream_t stre
     const bool mode_changed = old.averaging_mode != cfg.averaging_mode;
     if (old.fft_size != cfg.fft_size || old.window != cfg.window) {
         rebuild_fft(stream);
+        ragged_ = false;  // every stream's pending audio is gone (:138-150): the common host positions describe the bank again
     } else if (old.sample_rate != cfg.sample_rate || old.hop_size != cfg.hop_size || old.source != cfg.source ||
                old.secondary_source != cfg.secondary_source) {
         reset_buffers(stream);
+        ragged_ = false;
     } else if (mode_changed || std::fabs(old.floor_db - cfg.floor_db) > std::numeric_limits<float>::epsilon()) {
         reset_level_buffers(stream);
     }
@@ -370,9 +372,15 @@ int SpectrumBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, c
                                  omx_spectrum_ragged_update* out) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
-    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) return OMX_ERR_INVALID;
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
+        set_last_error("spectrum process_ragged: frames_capacity must be 1 .. 2^32 - 1");
+        return OMX_ERR_INVALID;
+    }
     for (uint32_t s = 0; s < n_streams_; ++s)
-        if (frames[s] > frames_capacity) return OMX_ERR_INVALID;
+        if (frames[s] > frames_capacity) {
+            set_last_error("spectrum process_ragged: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
     const float sample_rate = sanitize_sample_rate(sample_rate_in);
     if (sample_rate != cfg_.sample_rate) {  // a format change concerns every stream of the bank (:258-263)
         cfg_.sample_rate = sample_rate;

@@ -52,10 +52,14 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
     const bool two = a.fmt.channels == 2;
     v2f pre[INGEST_FRAMES_PER_THREAD];
     if (two) {
+        // clamped inside the stream's own row of `pcm`: a stream that pushes nothing (count 0, skip = its whole block) still reads a
+        // frame of its own
+        const uint64_t row_last = a.frames_total ? a.frames_total - 1 : 0;
         const uint64_t last = count_s ? count_s - 1 : 0;
+        const float* row = a.pcm + (uint64_t)s * a.frames_total * 2;
 #pragma unroll
         for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k)
-            pre[k] = *reinterpret_cast<const v2f*>(src + min(wg_base + (uint64_t)k * 256 + threadIdx.x, last) * 2);
+            pre[k] = *reinterpret_cast<const v2f*>(row + min(skip_s + min(wg_base + (uint64_t)k * 256 + threadIdx.x, last), row_last) * 2);
     }
 #pragma unroll
     for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k) {
@@ -203,6 +207,28 @@ __global__ __launch_bounds__(256) void ring_rehome_kernel(const float* from, uin
     const uint64_t h = head[s], t = tail[s];
     for (uint64_t p = t + threadIdx.x; p < h; p += 256u) to[(uint64_t)s * to_cap + (p & (to_cap - 1u))] = from[(uint64_t)s * from_cap + (p & (from_cap - 1u))];
 }
+// update_config on a bank whose positions are per stream (spectrogram/processor.rs:518-543 + rebuild_fft :275-278): every stream keeps
+// its newest `keep` pending samples (0: a rate change drops them all), forgets what it still had to skip, and flags its next update
+__global__ __launch_bounds__(256) void spectrogram_ragged_config_kernel(uint32_t n_streams, const uint64_t* head, uint64_t* tail, uint64_t* pending_skip,
+                                                                        uint32_t* reset_flag, long long* last_nonzero, int trim, uint64_t keep,
+                                                                        int zero_skip, int clear_nonzero) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_streams) return;
+    if (trim) {
+        const uint64_t pending = head[s] - tail[s];
+        if (pending > keep) tail[s] = head[s] - keep;
+    }
+    if (zero_skip) pending_skip[s] = 0;
+    if (clear_nonzero) last_nonzero[s] = -1;
+    reset_flag[s] = 1;
+}
+void launch_spectrogram_ragged_config(uint32_t n_streams, const uint64_t* head, uint64_t* tail, uint64_t* pending_skip, uint32_t* reset_flag,
+                                      long long* last_nonzero, bool trim, uint64_t keep, bool zero_skip, bool clear_nonzero, hipStream_t stream) {
+    if (n_streams == 0) return;
+    hipLaunchKernelGGL(spectrogram_ragged_config_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, n_streams, head, tail, pending_skip,
+                       reset_flag, last_nonzero, trim ? 1 : 0, keep, zero_skip ? 1 : 0, clear_nonzero ? 1 : 0);
+}
+
 void launch_ring_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* head, const uint64_t* tail,
                         uint32_t n_streams, hipStream_t stream) {
     if (n_streams == 0) return;

@@ -57,6 +57,8 @@ void launch_spectrogram_plan(const SpectrogramPlanArgs& a, hipStream_t stream);
 // ring re-homing on growth with per-stream positions: pending samples keep their absolute positions, only the modulus changes
 void launch_ring_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* head, const uint64_t* tail,
                         uint32_t n_streams, hipStream_t stream);
+void launch_spectrogram_ragged_config(uint32_t n_streams, const uint64_t* head, uint64_t* tail, uint64_t* pending_skip, uint32_t* reset_flag,
+                                      long long* last_nonzero, bool trim, uint64_t keep, bool zero_skip, bool clear_nonzero, hipStream_t stream);
 void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream);
 
 // ---------------------------------------------------------------- K2 fast reassigned STFT (W = F = 4096)

@@ -332,6 +332,62 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
     assert bank.process_host(np.zeros((S, 256, 2), np.float32), 2, 48000.0) is None
 
 
+@pytest.mark.parametrize("seed,first,second", [(1, dict(fft_size=4096, hop_size=256), dict(fft_size=1024, hop_size=256)),
+                                               (2, dict(fft_size=2048, hop_size=64), dict(fft_size=2048, hop_size=512)),
+                                               (3, dict(fft_size=1024, hop_size=300, use_reassignment=False),
+                                                dict(fft_size=4096, hop_size=300, use_reassignment=False)),
+                                               (4, dict(fft_size=2048, hop_size=256), dict(fft_size=2048, hop_size=256, window=capi.WINDOW_HAMMING))])
+def test_ragged_spectrogram_bank_update_config_matches_per_stream_oracles(omx, oracle, seed, first, second):
+    """update_config on a bank whose positions are per stream (spectrogram/processor.rs:518-543, rebuild_fft :212-279): every stream must
+    carry `reset` into its next update, lose what it still had to skip, and keep exactly the newest 2 * window pending samples — as a
+    single SpectrogramProcessor given the same update_config between the same blocks does.  (A window that shrinks leaves streams with
+    more pending samples than the new read length: the column count of the next call must come out right.)"""
+    import torch
+    rng = np.random.default_rng(900 + seed)
+    S, cap = 5, 3 * 256 + 77
+    base = dict(use_reassignment=True, history_length=8192)
+    cfg_a = SpectrogramConfig(**{**base, **first})
+    cfg_b = SpectrogramConfig(**{**base, **second})
+    bank = banks.SpectrogramBank(omx, cfg_a, S)
+    refs = [SpectrogramProcessor(oracle, cfg_a) for _ in range(S)]
+    feeds = [_stream_signal(rng, 80000) for _ in range(S)]
+    at = [0] * S
+    pos = capi.positions_fallback(2)
+
+    def ragged_call(tag):
+        frames = rng.integers(0, cap + 1, S)
+        frames[rng.integers(0, S)] = 0
+        pcm = np.zeros((S, cap, 2), np.float32)
+        for s in range(S):
+            pcm[s, :frames[s]] = feeds[s][at[s]:at[s] + frames[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, frames, 2, 48000.0, pos, None)
+        torch.cuda.synchronize()
+        n_cols = _dev(torch, up.d_n_columns, (S,)).cpu().numpy() if up.max_columns else np.zeros(S, int)
+        resets = _dev(torch, up.d_reset, (S,)).cpu().numpy()
+        total = 0
+        for s in range(S):
+            w = refs[s].process_block(AudioBlock(pcm[s, :frames[s]].reshape(-1), 2, 48000.0)) if frames[s] else None
+            at[s] += int(frames[s])
+            want = len(w.new_columns) if w is not None else 0
+            assert int(n_cols[s]) == want, (tag, s, int(n_cols[s]), want)
+            if w is not None:
+                assert bool(resets[s]) == w.reset, (tag, s)
+                total += want
+        return total
+
+    cols = 0
+    for k in range(36):   # uneven per-stream progress: different pending counts when the configuration changes
+        cols += ragged_call(("a", k))
+    bank.update_config(cfg_b)
+    for r in refs:
+        r.update_config(cfg_b)
+    after = 0
+    for k in range(14):
+        after += ragged_call(("b", k))
+    assert cols > 0 and after > 0
+
+
 @pytest.mark.parametrize("seed,N,hop,mode,param,emit_all", [(1, 1024, 256, capi.AVG_NONE, 0.0, False), (2, 4096, 512, capi.AVG_EXPONENTIAL, 0.6, False),
                                                               (3, 2048, 300, capi.AVG_PEAK_HOLD, 12.0, True), (4, 16384, 2048, capi.AVG_NONE, 0.0, True),
                                                               (5, 1000, 250, capi.AVG_EXPONENTIAL, 0.3, False), (6, 512, 900, capi.AVG_NONE, 0.0, False)])
