@@ -233,8 +233,7 @@ def main():
 
     import openmeters_amd
     from openmeters_amd import capi
-    from openmeters_amd.banks import SpectrogramBank, SpectrumBank
-    from openmeters_amd.pipeline import FullPipeline
+    from openmeters_amd.pipeline import CaptureGroup, FullPipeline
     import workloads
 
     api = openmeters_amd.api()
@@ -260,22 +259,22 @@ def main():
             for t in keep_alive:
                 t.record_stream(side)
 
-    spectrum = None
+    # Both workloads run through the capture group of the C-ABI (omx_capture_group_*: VisualManager::ingest_samples,
+    # registry.rs:396-418): one ingest call per step feeds every enabled visual, with one projection launch for the banks that keep
+    # pending audio, the meter banks on the library's side streams and the summary rows assembled by its own kernels.
     if config == "cfg2":
         cfg = capi.SpectrogramConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
                                      history_length=8192, use_reassignment=True, zero_padding_factor=1)
-        bank = SpectrogramBank(api, cfg, S)
-        if not args.no_spectrum:
-            # "+ A-weighted spectrum" of configs[1]: Spectrum{4096, hop 256, Hann, averaging None, source Mid}; every hop is
-            # materialised (what the reference computes when fed one hop per block)
-            spectrum = SpectrumBank(api, capi.SpectrumConfig(sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN,
-                                                             averaging_mode=capi.AVG_NONE, source=capi.CH_MID,
-                                                             secondary_source=capi.CH_NONE, floor_db=-100.0), S, emit_all_hops=True)
+        # "+ A-weighted spectrum" of configs[1]: Spectrum{4096, hop 256, Hann, averaging None, source Mid}; every hop is
+        # materialised (what the reference computes when fed one hop per block)
+        spectrum_cfg = None if args.no_spectrum else capi.SpectrumConfig(
+            sample_rate=48000.0, fft_size=W, hop_size=hop, window=capi.WINDOW_HANN, averaging_mode=capi.AVG_NONE, source=capi.CH_MID,
+            secondary_source=capi.CH_NONE, floor_db=-100.0)
+        group = CaptureGroup(api, S, spectrogram=cfg, spectrum=spectrum_cfg, spectrum_emit_all_hops=True)
 
         def step():
-            up = bank.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
-            if spectrum is not None:
-                spectrum.process_device(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
+            g = group.ingest(pcm.data_ptr(), F, 2, 48000.0, positions, stream)
+            up = g.spectrogram if g.produced & capi.VISUAL_SPECTROGRAM else None
             if world > 1 and up is not None:
                 counts = torch.as_tensor(DeviceView(up.d_counts, (S, up.n_columns), "<i4"), device=device).clone()
                 n_columns = float(up.n_columns)
@@ -291,20 +290,21 @@ def main():
             return up
     else:
         pipe = FullPipeline(api, S)
-        bank = pipe.spectrogram
+        group = pipe.group
 
         def step():
-            # the three banks side by side; the summary rows of the loudness / stereometer banks are assembled on their side
-            # streams beside the spectrogram kernel, the three point-count columns after it (FullPipeline.step_with_stats); the
-            # all-gather itself rides a further side stream
-            up, rows = pipe.step_with_stats(torch, device, pcm.data_ptr(), F)
+            # the three banks side by side inside the library; the summary rows come back as a view of its device buffer and are
+            # all-gathered on a further side stream
+            g, rows = pipe.step_with_stats(torch, device, pcm.data_ptr(), F)
+            up = g.spectrogram if g.produced & capi.VISUAL_SPECTROGRAM else None
             if up is not None and world > 1:
-                gather_on_side(lambda: rows, [rows])
+                snapshot = rows.clone()   # (the library reuses its row buffer in the next ingest)
+                gather_on_side(lambda: snapshot, [snapshot])
             return up
 
     for _ in range(args.warmup):
         step()
-    bank.set_option(capi.OPT_KERNEL_TIMING, 1)
+    group.set_option(capi.OPT_KERNEL_TIMING, 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -323,7 +323,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    kernel_ms, launches = bank.kernel_time()
+    kernel_ms, launches = group.kernel_time()
     assert last is not None and last.n_columns == cols_per_step, (last.n_columns if last else None, cols_per_step)
     counts = torch.as_tensor(DeviceView(last.d_counts, (S, last.n_columns), "<i4"), device=device)
     mean_points = float(counts.to(torch.float64).mean().item())
@@ -373,9 +373,10 @@ def main():
         "config": {"workload": workload, "name": config,
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "columns_per_step_per_gpu": frames_per_launch,
                    "pipeline": ("Spectrogram{4096, 256, Hann, reassigned}" +
-                                ("" if spectrum is None else " + A-weighted Spectrum{4096, 256, Hann, avg None, Mid}, every hop materialised"))
+                                ("" if args.no_spectrum else " + A-weighted Spectrum{4096, 256, Hann, avg None, Mid}, every hop materialised") +
+                                " through omx_capture_group_ingest (one projection launch for both banks)")
                    if config == "cfg2" else
-                   "Spectrogram{4096, 256, Hann, reassigned} || Loudness{BS.1770 M/S LUFS, 4x true peak} || Stereometer{bands, 50 ms} + stats rows + gather",
+                   "omx_capture_group_ingest: Spectrogram{4096, 256, Hann, reassigned} || Loudness{BS.1770 M/S LUFS, 4x true peak} || Stereometer{bands, 50 ms} + stats rows + gather",
                    "noise": "xorshift32(0x9E3779B9 ^ s) at -60 dBFS (SURVEY §8d)",
                    "parallelism": f"streams sharded x{world}, no data-path collective; all_gather of {len(STATS_COLUMNS)} f32 per stream per step"},
         "roofline": {
@@ -418,7 +419,7 @@ def main():
             # BASELINE.json's other single-GPU configurations, measured after the timed region (a few seconds; never part of
             # `value`): cfg3 loudness, cfg4 oscilloscope + stereometer, and the other one of cfg2 / cfg5
             try:
-                del pcm, bank, spectrum, step
+                del pcm, group, step
                 if config == "cfg5":
                     del pipe
                 torch.cuda.empty_cache()

@@ -824,6 +824,73 @@ int omx_spectrogram_history_fetch_slot(omx_spectrogram_history* h, uint64_t stre
 int omx_spectrogram_history_splat(omx_spectrogram_history* h, float reassigned_power_scale, const omx_splat_view* view,
                                   int on_device, void* stream, float* accum, float* db);
 
+/* ===================================================================== *
+ * Capture group — VisualManager::ingest_samples, reference src/visuals/registry.rs:396-418:
+ * one block of a capture goes to EVERY enabled visual (`for entry in &mut self.entries { if entry.enabled { module.ingest(&block) } }`),
+ * and VisualManager::reset_audio (:360-365) resets every one of them.  Here the group owns one bank per enabled visual for
+ * `n_streams` captures advancing in lock step; one omx_capture_group_ingest call
+ *   - projects the block ONCE for the visuals that keep pending audio (Spectrogram and Spectrum are fed by a single ingest launch),
+ *   - runs the Spectrogram / Spectrum banks on the caller's stream and the meter banks (Loudness + Waveform, Stereometer +
+ *     Oscilloscope) on two streams of its own beside them, joined before the call returns to the caller's stream order,
+ *   - and, on request (OMX_OPT_GROUP_STATS), leaves the per-stream summary rows — the table that is gathered over RCCL once per
+ *     epoch — in device memory: [n_streams][OMX_STATS_COLUMNS] f32 =
+ *       momentary LUFS, short-term LUFS, max true peak dBTP, rho full / low / mid / high (newest block), columns of this call,
+ *       mean points per column, points of the newest column, held true-peak bar left / right (2 s hold, 60 dB/s: loudness/state.rs:36-60).
+ * A multi-GPU host all-gathers `d_stats_rows` itself (ncclAllGather on its communicator; INTEGRATION.md shows the call): the library
+ * does not link RCCL.
+ * `pcm` is device memory [n_streams][frames][channels].  The block-based visuals see the call as frames / block_frames blocks of
+ * block_frames frames (one snapshot per block, as if VisualManager had been fed block by block) when block_frames divides frames,
+ * else as one block.
+ * ===================================================================== */
+enum {
+    OMX_VISUAL_SPECTROGRAM = 1,
+    OMX_VISUAL_SPECTRUM = 2,
+    OMX_VISUAL_LOUDNESS = 4,
+    OMX_VISUAL_STEREOMETER = 8,
+    OMX_VISUAL_OSCILLOSCOPE = 16,
+    OMX_VISUAL_WAVEFORM = 32
+};
+#define OMX_STATS_COLUMNS 12
+enum {
+    OMX_OPT_GROUP_STATS = 16,      /* value != 0: assemble the summary rows in every ingest call (needs Spectrogram, Loudness, Stereometer) */
+    OMX_OPT_GROUP_SHARED_INGEST = 17 /* value == 0: every bank runs its own ingest launch (A/B against the shared one; same rings) */
+};
+typedef struct omx_capture_group_config {
+    uint32_t n_streams;
+    uint32_t visuals;                /* OMX_VISUAL_* bits */
+    uint32_t block_frames;           /* 0 = the batcher's quantum, round(256 * sample_rate / 48000) (meter.rs:16-25) */
+    uint32_t spectrum_emit_all_hops; /* as omx_spectrum_bank_create */
+    omx_spectrogram_config spectrogram;
+    omx_spectrum_config spectrum;
+    omx_loudness_config loudness;
+    omx_stereometer_config stereometer;
+    omx_oscilloscope_config oscilloscope;
+    omx_waveform_config waveform;
+} omx_capture_group_config;
+typedef struct omx_capture_group_update {
+    uint32_t produced;               /* OMX_VISUAL_* bits: which visuals produced an update in this call */
+    uint32_t ingest_launches;        /* ingest (projection) launches this call made: 1 when Spectrogram and Spectrum shared one */
+    uint64_t n_blocks, block_frames; /* how the block-based visuals saw the call */
+    omx_spectrogram_bank_update spectrogram;
+    omx_spectrum_bank_update spectrum;
+    const omx_loudness_snapshot* d_loudness; /* [n_streams][n_blocks] */
+    omx_stereometer_bank_update stereometer;
+    omx_oscilloscope_bank_update oscilloscope;
+    omx_waveform_bank_update waveform;
+    const float* d_stats_rows;       /* [n_streams][OMX_STATS_COLUMNS], or NULL (OMX_OPT_GROUP_STATS off / a visual it needs disabled) */
+} omx_capture_group_update;
+typedef struct omx_capture_group omx_capture_group;
+void omx_capture_group_config_default(omx_capture_group_config* out); /* every visual's default config, none enabled, 1 stream */
+int omx_capture_group_create(const omx_capture_group_config* cfg, omx_capture_group** out);
+void omx_capture_group_destroy(omx_capture_group* g);
+int omx_capture_group_reset_audio(omx_capture_group* g);              /* VisualManager::reset_audio (:360-365) */
+int omx_capture_group_set_option(omx_capture_group* g, uint32_t option, uint64_t value); /* OMX_OPT_GROUP_*, OMX_OPT_KERNEL_TIMING */
+int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t frames, uint32_t channels, float sample_rate,
+                             const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_update* out);
+/* average duration of the spectrogram bank's column kernel since the last call (OMX_OPT_KERNEL_TIMING), as
+ * omx_spectrogram_bank_kernel_time */
+int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

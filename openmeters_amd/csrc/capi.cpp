@@ -6,6 +6,7 @@
 #include "spectrum.hpp"
 #include "loudness.hpp"
 #include "stereometer.hpp"
+#include "capture_group.hpp"
 #include "oscilloscope.hpp"
 #include "waveform.hpp"
 
@@ -75,6 +76,11 @@ struct omx_waveform {
 struct omx_waveform_bank {
     WaveformBank impl;
     omx_waveform_bank(const omx_waveform_config& c, uint32_t n) : impl(c, n) {}
+};
+
+struct omx_capture_group {
+    CaptureGroup impl;
+    explicit omx_capture_group(const omx_capture_group_config& c) : impl(c) {}
 };
 
 extern "C" {
@@ -745,6 +751,48 @@ int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on
 int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] { return b->impl.fetch(stream_index, columns, preview, b->impl.last_stream()); });
+}
+
+// ------------------------------------------------------------------ capture group (VisualManager fan-out, registry.rs:396-418)
+void omx_capture_group_config_default(omx_capture_group_config* out) {
+    if (out) capture_group_config_default(out);
+}
+int omx_capture_group_create(const omx_capture_group_config* cfg, omx_capture_group** out) {
+    if (!cfg || !out || cfg->n_streams == 0) return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        *out = new omx_capture_group(*cfg);
+        return (int)OMX_NONE;
+    });
+}
+void omx_capture_group_destroy(omx_capture_group* g) { delete g; }
+int omx_capture_group_reset_audio(omx_capture_group* g) {
+    if (!g) return OMX_ERR_INVALID;
+    return guarded([&] {
+        g->impl.reset_audio();
+        return (int)OMX_NONE;
+    });
+}
+int omx_capture_group_set_option(omx_capture_group* g, uint32_t option, uint64_t value) {
+    if (!g) return OMX_ERR_INVALID;
+    switch (option) {
+        case OMX_OPT_GROUP_STATS: g->impl.set_stats(value != 0); return OMX_NONE;
+        case OMX_OPT_GROUP_SHARED_INGEST: g->impl.set_shared_ingest(value != 0); return OMX_NONE;
+        case OMX_OPT_KERNEL_TIMING: g->impl.set_timing(value != 0); return OMX_NONE;
+        default: return OMX_ERR_INVALID;
+    }
+}
+int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t frames, uint32_t channels, float sample_rate,
+                             const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_update* out) {
+    if (!g || (!pcm && frames) || !positions) return OMX_ERR_INVALID;
+    return guarded([&] { return g->impl.ingest(pcm, frames, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out); });
+}
+int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t* launches) {
+    if (!g || !avg_ms || !g->impl.spectrogram()) return OMX_ERR_INVALID;
+    return guarded([&] {
+        *avg_ms = g->impl.spectrogram()->timer().collect(launches);
+        return (int)OMX_NONE;
+    });
 }
 
 }  // extern "C"

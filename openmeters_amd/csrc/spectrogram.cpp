@@ -384,10 +384,11 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
 
 }
 
-int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in,
-                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
-                             omx_spectrogram_bank_update* out) {  // :490-516
-    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+// process_block (:490-516) in three steps, so that a capture group can feed several banks from ONE ingest launch:
+// push_begin (format change, prepare, the push_audio bookkeeping; says what to project where), the ingest launch, push_end, and
+// process_pushed (process_ready_windows + the update).
+int SpectrogramBank::push_begin(uint64_t frames, uint32_t channels, float sample_rate_in, hipStream_t stream, IngestSlots& slots) {
+    slots = IngestSlots{};
     last_stream_ = stream;
     if (ragged_) {
         set_last_error("spectrogram bank is in ragged mode (per-stream positions): use process_ragged, or reset_audio() first");
@@ -403,36 +404,48 @@ int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t fram
         reset_ = true;
     }
     prepare(stream);
-
     // ---- push_audio (:412-437)
     const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
     pending_skip_ -= skip;
     if (skip != frames) {
         const uint64_t count = frames - skip;
         ensure_ring(count, stream);
+        slots.n = 1;
+        slots.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
+        slots.ring[0] = ring_.ptr;
+        slots.cap[0] = ring_cap_;
+        slots.head[0] = head_;
+        slots.skip = skip;
+        slots.count = count;
+        slots.last_nonzero = last_nonzero_.ptr;
+        partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(count));
+        slots.partial_nonzero = partial_nonzero_.ptr;
+    }
+    return OMX_PRODUCED;
+}
+void SpectrogramBank::push_end(const IngestSlots& slots) { head_ += slots.count; }
+
+int SpectrogramBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in,
+                             float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                             omx_spectrogram_bank_update* out) {  // :490-516
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    IngestSlots slots;
+    const int rc = push_begin(frames, channels, sample_rate_in, stream, slots);
+    if (rc != OMX_PRODUCED) return rc;
+    if (slots.count) {
         const float* d_pcm = pcm;
         if (!pcm_on_device) {
             const size_t n = (size_t)n_streams_ * frames * channels;
             d_pcm = staging_.stage(pcm, n, stream);
         }
-        IngestArgs ia{};
-        ia.pcm = d_pcm;
-        ia.frames_total = frames;
-        ia.skip = skip;
-        ia.count = count;
-        ia.fmt = make_format(channels, positions);
-        ia.n_out = 1;
-        ia.project[0] = channels == 1 ? OMX_PROJECT_RAW : OMX_CHANNEL_MID;  // :420-431
-        ia.ring[0] = ring_.ptr;
-        ia.cap = ring_cap_;
-        ia.head = head_;
-        ia.last_nonzero = last_nonzero_.ptr;
-        partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(count));
-        ia.partial_nonzero = partial_nonzero_.ptr;
-        launch_ingest(ia, n_streams_, stream);
-        head_ += count;
+        const IngestSlots* one[1] = {&slots};
+        launch_ingest_slots(d_pcm, frames, make_format(channels, positions), one, 1, n_streams_, stream);
+        push_end(slots);
     }
+    return process_pushed(stream, out);
+}
 
+int SpectrogramBank::process_pushed(hipStream_t stream, omx_spectrogram_bank_update* out) {
     // ---- process_ready_windows (:281-388)
     const uint64_t W = cfg_.fft_size, hop = cfg_.hop_size;
     const bool reassign = cfg_.use_reassignment != 0;

@@ -19,6 +19,10 @@ public:
     void prepare(hipStream_t stream);
     int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrogram_bank_update* out);
+    // process() in steps (see spectrogram.cpp): for callers that run the ingest launch themselves (capture group)
+    int push_begin(uint64_t frames, uint32_t channels, float sample_rate, hipStream_t stream, IngestSlots& slots);
+    void push_end(const IngestSlots& slots);
+    int process_pushed(hipStream_t stream, omx_spectrogram_bank_update* out);
     // Ragged call: stream s receives frames[s] <= frames_capacity new frames (its rows of `pcm` are frames_capacity frames apart),
     // streams flagged in reset_mask get reset_audio() first.  The per-stream positions then live on the device
     // (spectrogram_plan_kernel); the bank stays in ragged mode until reset_audio() of the whole bank.

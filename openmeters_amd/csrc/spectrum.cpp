@@ -172,9 +172,10 @@ void SpectrumBank::ensure_ring(uint64_t incoming, hipStream_t stream) {
     ring_cap_ = cap;
 }
 
-int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in, float sample_rate_in,
-                          const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out) {
-    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+// process_block (:255-269) in three steps (see SpectrogramBank::push_begin): push_sources' bookkeeping, the ingest launch, the hops
+int SpectrumBank::push_begin(uint64_t frames, uint32_t channels, float sample_rate_in, hipStream_t stream, IngestSlots& slots) {
+    (void)channels;
+    slots = IngestSlots{};
     last_stream_ = stream;
     if (ragged_) {
         set_last_error("spectrum bank is in ragged mode (per-stream positions): use process_ragged, or reset_audio() first");
@@ -190,35 +191,48 @@ int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames,
     bool active[2];
     active_traces(active);
     const uint32_t n_traces = (active[0] ? 1 : 0) + (active[1] ? 1 : 0);
-
     // ---- push_sources (:271-298)
     const uint64_t skip = std::min<uint64_t>(pending_skip_, frames);
     pending_skip_ -= skip;
     if (skip != frames && n_traces > 0) {
         const uint64_t count = frames - skip;
         ensure_ring(count, stream);
+        if (active[0]) { slots.project[slots.n] = (int)cfg_.source; slots.ring[slots.n] = ring_[0].ptr; ++slots.n; }
+        if (active[1]) { slots.project[slots.n] = (int)cfg_.secondary_source; slots.ring[slots.n] = ring_[1].ptr; ++slots.n; }
+        for (int o = 0; o < slots.n; ++o) {
+            slots.cap[o] = ring_cap_;
+            slots.head[o] = head_;
+        }
+        slots.skip = skip;
+        slots.count = count;
+    }
+    return OMX_PRODUCED;
+}
+void SpectrumBank::push_end(const IngestSlots& slots) { head_ += slots.count; }
+
+int SpectrumBank::process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels_in, float sample_rate_in,
+                          const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    IngestSlots slots;
+    const int rc = push_begin(frames, channels, sample_rate_in, stream, slots);
+    if (rc != OMX_PRODUCED) return rc;
+    if (slots.count) {
         const float* d_pcm = pcm;
         if (!pcm_on_device) {
             const size_t n = (size_t)n_streams_ * frames * channels;
             d_pcm = staging_.stage(pcm, n, stream);
         }
-        IngestArgs ia{};
-        ia.pcm = d_pcm;
-        ia.frames_total = frames;
-        ia.skip = skip;
-        ia.count = count;
-        ia.fmt = make_format(channels, positions);
-        ia.n_out = 0;
-        if (active[0]) { ia.project[ia.n_out] = (int)cfg_.source; ia.ring[ia.n_out] = ring_[0].ptr; ++ia.n_out; }
-        if (active[1]) { ia.project[ia.n_out] = (int)cfg_.secondary_source; ia.ring[ia.n_out] = ring_[1].ptr; ++ia.n_out; }
-        ia.cap = ring_cap_;
-        ia.head = head_;
-        ia.last_nonzero = nullptr;
-        ia.partial_nonzero = nullptr;
-        launch_ingest(ia, n_streams_, stream);
-        head_ += count;
+        const IngestSlots* one[1] = {&slots};
+        launch_ingest_slots(d_pcm, frames, make_format(channels, positions), one, 1, n_streams_, stream);
+        push_end(slots);
     }
+    return process_pushed(stream, out);
+}
 
+int SpectrumBank::process_pushed(hipStream_t stream, omx_spectrum_bank_update* out) {
+    bool active[2];
+    active_traces(active);
+    const uint32_t n_traces = (active[0] ? 1 : 0) + (active[1] ? 1 : 0);
     // ---- process_ready_windows (:179-213)
     if (n_traces == 0) return OMX_NONE;
     const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size;

@@ -17,6 +17,10 @@ public:
     void prepare(hipStream_t stream);
     int process(const float* pcm, bool pcm_on_device, uint64_t frames, uint32_t channels, float sample_rate,
                 const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_bank_update* out);
+    // process() in steps, for callers that run the ingest launch themselves (capture group; see SpectrogramBank::push_begin)
+    int push_begin(uint64_t frames, uint32_t channels, float sample_rate, hipStream_t stream, IngestSlots& slots);
+    void push_end(const IngestSlots& slots);
+    int process_pushed(hipStream_t stream, omx_spectrum_bank_update* out);
     // per-stream frame counts / reset (include/omx.h: omx_spectrum_bank_process_ragged); pcm in device memory
     int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
                        float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_ragged_update* out);

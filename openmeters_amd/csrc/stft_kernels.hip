@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
     __shared__ long long wave_best[4];
     const uint32_t s = blockIdx.y;
     const uint64_t wg_base = (uint64_t)blockIdx.x * INGEST_FRAMES_PER_WG;
-    const uint64_t skip_s = a.skips ? a.skips[s] : a.skip, count_s = a.counts ? a.counts[s] : a.count, head_s = a.heads ? a.heads[s] : a.head;
+    const uint64_t skip_s = a.skips ? a.skips[s] : a.skip, count_s = a.counts ? a.counts[s] : a.count,
+                   head_s = a.heads ? a.heads[s] : (a.per_out ? a.head_o[0] : a.head);
     const float* src = a.pcm + ((uint64_t)s * a.frames_total + skip_s) * a.fmt.channels;
     const uint64_t ring_base = (uint64_t)s * a.cap;
     long long best = -1;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
                 // OMX_PROJECT_RAW: spectrogram's `channels == 1` path pushes the raw samples (:420-428)
                 const float v = a.project[o] == OMX_PROJECT_RAW ? first : project_lr(a.project[o], left, right);
                 if (o == 0) out0 = v;
-                a.ring[o][slot] = v;
+                const uint64_t slot_o = a.per_out ? (uint64_t)s * a.cap_o[o] + ((a.head_o[o] + idx) & (a.cap_o[o] - 1)) : slot;
+                a.ring[o][slot_o] = v;
             }
         }
         const unsigned long long nz = __ballot(live && out0 != 0.0f);  // audio_last_nonzero (:423-425, :432-434)
@@ -139,6 +141,35 @@ void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) 
     hipLaunchKernelGGL(ingest_project_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
     if (a.partial_nonzero && a.last_nonzero && wgs > 1)
         hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, a.partial_nonzero, wgs, a.last_nonzero);
+}
+
+void launch_ingest_slots(const float* d_pcm, uint64_t frames, const AudioFormatArgs& fmt, const IngestSlots* const* banks, int n_banks,
+                         uint32_t n_streams, hipStream_t stream) {
+    IngestArgs ia{};
+    ia.pcm = d_pcm;
+    ia.frames_total = frames;
+    ia.fmt = fmt;
+    ia.per_out = 1;
+    for (int b = 0; b < n_banks; ++b) {
+        const IngestSlots& sl = *banks[b];
+        if (sl.count == 0 || sl.n == 0) continue;
+        if (ia.n_out == 0) {
+            ia.skip = sl.skip;
+            ia.count = sl.count;
+            ia.last_nonzero = sl.last_nonzero;        // (only a bank listed first can track it: out0 of the kernel)
+            ia.partial_nonzero = sl.partial_nonzero;
+        }
+        for (int o = 0; o < sl.n && ia.n_out < OMX_INGEST_MAX_OUT; ++o) {
+            ia.project[ia.n_out] = sl.project[o];
+            ia.ring[ia.n_out] = sl.ring[o];
+            ia.cap_o[ia.n_out] = sl.cap[o];
+            ia.head_o[ia.n_out] = sl.head[o];
+            ++ia.n_out;
+        }
+    }
+    ia.cap = ia.cap_o[0];
+    ia.head = ia.head_o[0];
+    if (ia.n_out) launch_ingest(ia, n_streams, stream);
 }
 
 // ================================================================================================

@@ -30,8 +30,29 @@ struct IngestArgs {
     const uint32_t* skips;
     const uint32_t* counts;
     const uint64_t* heads;
+    // one launch feeding the rings of several banks (capture group: Spectrogram + Spectrum read the same block): when `per_out`,
+    // output o lives in a ring of cap_o[o] samples per stream whose next write position is head_o[o] (lock-step banks only)
+    int per_out;
+    uint64_t cap_o[OMX_INGEST_MAX_OUT];
+    uint64_t head_o[OMX_INGEST_MAX_OUT];
 };
 uint32_t ingest_partials_per_stream(uint64_t count);
+
+// What a lock-step bank wants pushed from one block (push_audio / push_sources of the reference): `skip` leading frames dropped,
+// `count` frames projected into its ring(s).  A bank fills its slots in push_begin(); whoever launches the ingest kernel — the bank
+// itself, or a capture group for several banks at once — reports back through push_end().
+struct IngestSlots {
+    int n = 0;
+    int project[OMX_INGEST_MAX_OUT];
+    float* ring[OMX_INGEST_MAX_OUT];
+    uint64_t cap[OMX_INGEST_MAX_OUT], head[OMX_INGEST_MAX_OUT];
+    uint64_t skip = 0, count = 0;
+    long long* last_nonzero = nullptr;     // of slot 0 (spectrogram), or nullptr
+    long long* partial_nonzero = nullptr;
+};
+// one ingest launch for the slots of one or more banks that agree on (skip, count); slot 0 carries last_nonzero
+void launch_ingest_slots(const float* d_pcm, uint64_t frames, const AudioFormatArgs& fmt, const IngestSlots* const* banks, int n_banks,
+                         uint32_t n_streams, hipStream_t stream);
 
 // ---- ragged banks: the integer state machine of SpectrogramProcessor (push_audio / process_ready_windows / advance_audio,
 // reference spectrogram/processor.rs:281-437, :490-516) per stream ON THE DEVICE, one thread per stream

@@ -175,4 +175,64 @@ void launch_loudness_meters(const omx_loudness_snapshot* snapshots, uint64_t n_s
                        n_blocks, left_mode, right_mode, t0, dt, holds, rows);
 }
 
+// ---- per-stream summary rows of a capture group (the table that is gathered over RCCL once per epoch, sharding.STATS_COLUMNS):
+// three launches, each on the stream of the bank whose output it reads, each writing its own columns of rows[s][OMX_STATS_COLUMNS]
+__global__ __launch_bounds__(64) void stats_loudness_kernel(const omx_loudness_snapshot* __restrict__ snapshots, const omx_meter_row* __restrict__ meters,
+                                                           uint64_t n_streams, uint64_t n_blocks, uint32_t channels, float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_streams) return;
+    const omx_loudness_snapshot& snap = snapshots[s * n_blocks + n_blocks - 1];  // the newest block
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[0] = snap.momentary_loudness;
+    r[1] = snap.short_term_loudness;
+    float peak = snap.true_peak_db[0];
+    for (uint32_t c = 1; c < channels && c < OMX_MAX_CHANNELS; ++c) peak = fmaxf(peak, snap.true_peak_db[c]);
+    r[2] = peak;
+    const omx_meter_row& m = meters[s * n_blocks + n_blocks - 1];
+    r[10] = m.peaks[0];  // held true-peak bars, left / right (loudness/state.rs:178-217)
+    r[11] = m.peaks[1];
+}
+__global__ __launch_bounds__(64) void stats_stereometer_kernel(const float* __restrict__ correlations, uint64_t n_streams, uint64_t n_blocks,
+                                                              float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_streams) return;
+    const float* c = correlations + (s * n_blocks + n_blocks - 1) * 4;
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[3] = c[0];
+    r[4] = c[1];
+    r[5] = c[2];
+    r[6] = c[3];
+}
+__global__ __launch_bounds__(256) void stats_spectrogram_kernel(const uint32_t* __restrict__ counts, uint64_t n_streams, uint64_t n_columns,
+                                                               float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // one wavefront per stream
+    if (s >= n_streams) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long sum = 0;  // point counts are integers: their sum is exact, the mean is one f32 division
+    for (uint64_t c = lane; c < n_columns; c += 64) sum += counts[s * n_columns + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane != 0) return;
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[7] = (float)n_columns;
+    r[8] = (float)sum / (float)n_columns;
+    r[9] = (float)counts[s * n_columns + n_columns - 1];
+}
+void launch_stats_loudness(const omx_loudness_snapshot* snapshots, const omx_meter_row* meters, uint64_t n_streams, uint64_t n_blocks,
+                           uint32_t channels, float* rows, hipStream_t stream) {
+    if (n_streams == 0 || n_blocks == 0) return;
+    hipLaunchKernelGGL(stats_loudness_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, snapshots, meters, n_streams,
+                       n_blocks, channels, rows);
+}
+void launch_stats_stereometer(const float* correlations, uint64_t n_streams, uint64_t n_blocks, float* rows, hipStream_t stream) {
+    if (n_streams == 0 || n_blocks == 0) return;
+    hipLaunchKernelGGL(stats_stereometer_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, correlations, n_streams,
+                       n_blocks, rows);
+}
+void launch_stats_spectrogram(const uint32_t* counts, uint64_t n_streams, uint64_t n_columns, float* rows, hipStream_t stream) {
+    if (n_streams == 0 || n_columns == 0) return;
+    hipLaunchKernelGGL(stats_spectrogram_kernel, dim3((uint32_t)((n_streams + 3) / 4)), dim3(256), 0, stream, counts, n_streams, n_columns,
+                       rows);
+}
+
 }  // namespace omx

@@ -13,16 +13,17 @@ pytestmark = pytest.mark.gpu
 
 def test_full_pipeline_summary_rows_match_oracle(omx, oracle):
     import torch
-    from openmeters_amd.pipeline import FullPipeline, gather_stats
+    from openmeters_amd.pipeline import FullPipeline, gather_stats, stats_rows_tensor
     dev = torch.device("cuda", 0)
     S, frames = 6, 256 * 48
     pcm = np.stack([cfg2_pcm(s, frames) for s in range(S)])
     pcm[:, :, 1] *= -1.0  # anti-phase right channel: rho < 0
     d_pcm = torch.from_numpy(pcm).to(dev).contiguous()
     pipe = FullPipeline(omx, S)
-    up, snaps, st, n_blocks = pipe.step(d_pcm.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
+    up = pipe.step(d_pcm.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    table = gather_stats(pipe.stats(torch, dev, up, snaps, st, n_blocks), S).cpu().numpy()
+    assert up.produced == capi.VISUAL_SPECTROGRAM | capi.VISUAL_LOUDNESS | capi.VISUAL_STEREOMETER and up.ingest_launches == 1
+    table = gather_stats(stats_rows_tensor(torch, dev, up, S), S).cpu().numpy()
     assert table.shape == (S, 12)
     for s in range(S):
         snaps = []
@@ -46,8 +47,8 @@ def test_full_pipeline_summary_rows_match_oracle(omx, oracle):
 
 
 def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_rows(omx, oracle):
-    """BASELINE configs[4], one GPU's shard at full size: 1024 x 2-ch streams through FullPipeline.step_concurrent (the
-    bench step: reassigned STFT on the main HIP stream, loudness + stereometer banks on side streams), 2 x 16 384 frames.
+    """BASELINE configs[4], one GPU's shard at full size: 1024 x 2-ch streams through the capture group (the bench step:
+    reassigned STFT on the main HIP stream, loudness + stereometer banks on the group's side streams), 2 x 16 384 frames.
       replication  stream s = distinct[s % 32] => rows / columns of every replica are BIT-identical (different workgroups, XCDs,
                    bank slots, side-stream interleavings)
       shift        distinct stream 1 carries distinct stream 0 advanced by one hop => column c equals column c + 1
@@ -55,7 +56,7 @@ def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_row
                    stereometer correlations bit-exact, loudness rows bit-exact)
       oracle       summary rows of 3 streams vs the CPU oracle run block by block (the 6-stream test's bars)"""
     import torch
-    from openmeters_amd.pipeline import FullPipeline
+    from openmeters_amd.pipeline import FullPipeline, stats_rows_tensor
     from test_gpu_fullsize import dview, spectrogram_outputs
     dev = torch.device("cuda", 0)
     S, D, frames, hop = 1024, 32, 16384, 256
@@ -68,12 +69,13 @@ def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_row
     outs = []
     for k in range(2):
         chunk = d_all[:, k * frames:(k + 1) * frames].contiguous()
-        up, snaps, st, n_blocks = pipe.step_concurrent(torch, chunk.data_ptr(), frames)
+        up = pipe.step(chunk.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        table = pipe.stats(torch, dev, up, snaps, st, n_blocks)
-        counts, points = spectrogram_outputs(torch, up)
-        outs.append((counts, points, dview(torch, snaps, (S, n_blocks, 30)).clone(), dview(torch, st.d_correlations, (S, n_blocks, 4)).clone(),
-                     table.clone()))
+        n_blocks = int(up.n_blocks)
+        table = stats_rows_tensor(torch, dev, up, S)
+        counts, points = spectrogram_outputs(torch, up.spectrogram)
+        outs.append((counts, points, dview(torch, up.d_loudness, (S, n_blocks, 30)).clone(),
+                     dview(torch, up.stereometer.d_correlations, (S, n_blocks, 4)).clone(), table.clone()))
     assert outs[0][0].shape == (S, (frames - 8192) // hop + 1) and outs[1][0].shape == (S, frames // hop)
     for counts, points, snaps, corr, table in outs:
         assert torch.equal(counts[:D].repeat(S // D, 1), counts)
@@ -86,12 +88,13 @@ def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_row
     assert torch.equal(outs[0][0][1, -1], outs[1][0][0, 0]) and torch.equal(outs[0][1][1, -1], outs[1][1][0, 0])   # across the step boundary
 
     serial = FullPipeline(omx, S)
-    up, snaps, st, n_blocks = serial.step(d_all.data_ptr(), 2 * frames, torch.cuda.current_stream().cuda_stream)
+    up = serial.step(d_all.data_ptr(), 2 * frames, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    counts, points = spectrogram_outputs(torch, up)
+    n_blocks = int(up.n_blocks)
+    counts, points = spectrogram_outputs(torch, up.spectrogram)
     assert torch.equal(counts, torch.cat([outs[0][0], outs[1][0]], 1)) and torch.equal(points, torch.cat([outs[0][1], outs[1][1]], 1))
-    assert torch.equal(dview(torch, snaps, (S, n_blocks, 30)), torch.cat([outs[0][2], outs[1][2]], 1))
-    assert torch.equal(dview(torch, st.d_correlations, (S, n_blocks, 4)), torch.cat([outs[0][3], outs[1][3]], 1))
+    assert torch.equal(dview(torch, up.d_loudness, (S, n_blocks, 30)), torch.cat([outs[0][2], outs[1][2]], 1))
+    assert torch.equal(dview(torch, up.stereometer.d_correlations, (S, n_blocks, 4)), torch.cat([outs[0][3], outs[1][3]], 1))
 
     table = outs[1][4].cpu().numpy()
     for s in (0, 17, 1023):
@@ -112,7 +115,8 @@ def test_cfg5_full_shard_1024_streams_replication_shift_partition_and_oracle_row
         check_chunked_rho(table[s, 3:7], ss.correlations, stereometer_band_rms(pcm), s)   # 1024 x 64 blocks: chunk-parallel form
         assert table[s, 3] < -0.99
         assert abs(table[s, 8] - np.mean(cnt)) < 0.5 and abs(table[s, 9] - cnt[-1]) <= 4
-        got = pipe.spectrogram.fetch_column(s, 63, capi.COLUMN_REASSIGNED, 2049)
+        n_last = int(outs[1][0][s, 63])
+        got = outs[1][1][s, 63, :n_last].contiguous().view(torch.float32).cpu().numpy()   # the stream's newest column: (f, t, power) rows
         from parity import check_reassigned_columns, reassigned_column_metrics
         check_reassigned_columns([got], [sg.new_columns[-1]], 48000.0, hop)
 
@@ -144,22 +148,134 @@ def test_bench_two_ranks_on_one_gpu_over_gloo_runs_the_cfg5_step():
     assert one["n_gpus"] == 1 and one["config"]["name"] == "cfg5" and one["roofline"]["mean_points_per_frame"] > 1900
 
 
-def test_step_with_stats_equals_step_concurrent_plus_stats(omx):
-    """FullPipeline.step_with_stats assembles the loudness / stereometer columns on the banks' side streams: the rows must equal
-    step_concurrent + stats bit for bit, step after step (peak holds and clocks carried)."""
+def test_capture_group_equals_separate_banks_plus_torch_rows(omx):
+    """The capture group (one ingest call: fan-out, side streams and summary rows inside libomx_hip.so) against the same three banks
+    run one after the other with the summary rows assembled by torch glue (tests/pipeline_reference.py): rows, spectrogram columns,
+    loudness snapshots and correlations bit for bit, step after step (peak holds and clocks carried)."""
     import torch
     from openmeters_amd.pipeline import FullPipeline
+    from pipeline_reference import SeparateBanks
+    from test_gpu_fullsize import dview, spectrogram_outputs
     S, frames = 48, 4096
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(7)
     pcm = ((torch.rand((S, frames * 5, 2), device=dev, generator=g) - 0.5) * 0.8).contiguous()
-    a, b = FullPipeline(omx, S), FullPipeline(omx, S)
+    a, b = FullPipeline(omx, S), SeparateBanks(omx, S)
     for k in range(5):
         chunk = pcm[:, k * frames:(k + 1) * frames].contiguous()
         up_a, rows_a = a.step_with_stats(torch, dev, chunk.data_ptr(), frames)
-        up_b, snaps, st, n_blocks = b.step_concurrent(torch, chunk.data_ptr(), frames)
+        up_b, snaps, st, n_blocks = b.step(chunk.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
         rows_b = b.stats(torch, dev, up_b, snaps, st, n_blocks)
         torch.cuda.synchronize()
-        assert (up_a is None) == (up_b is None)
+        assert bool(up_a.produced & capi.VISUAL_SPECTROGRAM) == (up_b is not None)
         assert torch.equal(rows_a.view(torch.int32), rows_b.view(torch.int32)), k
+        assert torch.equal(dview(torch, up_a.d_loudness, (S, n_blocks, 30)), dview(torch, snaps, (S, n_blocks, 30)))
+        assert torch.equal(dview(torch, up_a.stereometer.d_correlations, (S, n_blocks, 4)), dview(torch, st.d_correlations, (S, n_blocks, 4)))
+        if up_b is not None:
+            ca, pa = spectrogram_outputs(torch, up_a.spectrogram)
+            cb, pb = spectrogram_outputs(torch, up_b)
+            assert torch.equal(ca, cb) and torch.equal(pa, pb)
     assert float(rows_a[:, 7].max()) > 0
+
+
+def test_capture_group_cfg2_one_ingest_launch_feeds_spectrogram_and_spectrum(omx):
+    """BASELINE configs[1] through the capture group: Spectrogram{4096, 256, reassigned} + Spectrum{4096, 256, Mid} read the same
+    block, so ONE projection launch fills both banks' rings (update.ingest_launches == 1); with the shared launch switched off
+    (OMX_OPT_GROUP_SHARED_INGEST = 0: two launches) every output is bit-identical, and both equal the two banks run separately."""
+    import torch
+    from openmeters_amd import banks
+    from openmeters_amd.pipeline import CaptureGroup
+    from test_gpu_fullsize import dview, spectrogram_outputs
+    dev = torch.device("cuda", 0)
+    S, frames = 8, 8192 + 256 * 15
+    pcm = torch.from_numpy(np.stack([cfg2_pcm(s, 3 * frames) for s in range(S)])).to(dev)
+    pos = capi.positions_fallback(2)
+    sg_cfg = SpectrogramConfig(fft_size=4096, hop_size=256, history_length=8192, use_reassignment=True)
+    sp_cfg = capi.SpectrumConfig(fft_size=4096, hop_size=256, source=capi.CH_MID, secondary_source=capi.CH_NONE, floor_db=-100.0)
+    shared = CaptureGroup(omx, S, spectrogram=sg_cfg, spectrum=sp_cfg)
+    split = CaptureGroup(omx, S, spectrogram=sg_cfg, spectrum=sp_cfg)
+    split.set_option(capi.OPT_GROUP_SHARED_INGEST, 0)
+    sg, sp = banks.SpectrogramBank(omx, sg_cfg, S), banks.SpectrumBank(omx, sp_cfg, S)
+    for k in range(3):
+        chunk = pcm[:, k * frames:(k + 1) * frames].contiguous()
+        ua = shared.ingest(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        ub = split.ingest(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        u_sg = sg.process_device(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        u_sp = sp.process_device(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        torch.cuda.synchronize()
+        assert ua.ingest_launches == 1 and ub.ingest_launches == 2
+        assert ua.produced == ub.produced == capi.VISUAL_SPECTROGRAM | capi.VISUAL_SPECTRUM
+        ca, pa = spectrogram_outputs(torch, ua.spectrogram)
+        for other in (ub.spectrogram, u_sg):
+            cb, pb = spectrogram_outputs(torch, other)
+            assert torch.equal(ca, cb) and torch.equal(pa, pb)
+        bins = int(ua.spectrum.bins)
+        ta = dview(torch, ua.spectrum.d_traces, (S, 1, 2, 2, bins))
+        assert int(ua.spectrum.n_hops) == int(ub.spectrum.n_hops) == int(u_sp.n_hops) > 0
+        assert torch.equal(ta, dview(torch, ub.spectrum.d_traces, (S, 1, 2, 2, bins))) and torch.equal(ta, dview(torch, u_sp.d_traces, (S, 1, 2, 2, bins)))
+
+
+def test_capture_group_all_six_visuals_equal_their_banks(omx):
+    """One block to EVERY visual (registry.rs:396-418): a group with all six enabled against six banks fed the same blocks —
+    every output bit for bit, reset_audio included (registry.rs:360-365)."""
+    import torch
+    from openmeters_amd import banks
+    from openmeters_amd.pipeline import CaptureGroup
+    from test_gpu_fullsize import dview, spectrogram_outputs
+    dev = torch.device("cuda", 0)
+    S, frames = 5, 2048
+    g = torch.Generator(device=dev).manual_seed(11)
+    n = torch.arange(frames * 8, device=dev, dtype=torch.float64)
+    pcm = torch.empty((S, frames * 8, 2), device=dev, dtype=torch.float32)
+    for s in range(S):
+        tone = (0.6 * torch.sin(2 * np.pi * (220.0 + 55.0 * s) * n / 48000.0)).to(torch.float32)
+        pcm[s, :, 0] = tone + 0.01 * (torch.rand(frames * 8, device=dev, generator=g) - 0.5)
+        pcm[s, :, 1] = -0.7 * tone
+    pos = capi.positions_fallback(2)
+    cfgs = dict(spectrogram=SpectrogramConfig(fft_size=2048, hop_size=64, history_length=8192), spectrum=capi.SpectrumConfig(fft_size=4096, hop_size=1024),
+                loudness=LoudnessConfig(), stereometer=StereometerConfig(analyze_bands=True),
+                oscilloscope=capi.OscilloscopeConfig(trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT),
+                waveform=capi.WaveformConfig(analyze_bands=True))
+    group = CaptureGroup(omx, S, block_frames=256, **cfgs)
+    sg, sp = banks.SpectrogramBank(omx, cfgs["spectrogram"], S), banks.SpectrumBank(omx, cfgs["spectrum"], S)
+    ld, st = banks.LoudnessBank(omx, cfgs["loudness"], S, 2), banks.StereometerBank(omx, cfgs["stereometer"], S)
+    sc, wf = banks.OscilloscopeBank(omx, cfgs["oscilloscope"], S), banks.WaveformBank(omx, cfgs["waveform"], S)
+    for k in range(8):
+        if k == 5:
+            group.reset_audio()
+            for b in (sg, sp, ld, st, sc, wf):
+                b.reset_audio()
+        chunk = pcm[:, k * frames:(k + 1) * frames].contiguous()
+        u = group.ingest(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        r_sg = sg.process_device(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        r_sp = sp.process_device(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        r_ld = ld.process_device(chunk.data_ptr(), 256, frames // 256, 2, 48000.0, pos)
+        r_st = st.process_device(chunk.data_ptr(), 256, frames // 256, 2, 48000.0, pos)
+        sc.process_device(chunk.data_ptr(), 256, frames // 256, 2, 48000.0, pos)
+        r_wf = wf.process_device(chunk.data_ptr(), frames, 2, 48000.0, pos)
+        torch.cuda.synchronize()
+        nb = frames // 256
+        assert int(u.n_blocks) == nb and u.ingest_launches == 1
+        assert bool(u.produced & capi.VISUAL_SPECTROGRAM) == (r_sg is not None)
+        if r_sg is not None:
+            ca, pa = spectrogram_outputs(torch, u.spectrogram)
+            cb, pb = spectrogram_outputs(torch, r_sg)
+            assert torch.equal(ca, cb) and torch.equal(pa, pb)
+        assert bool(u.produced & capi.VISUAL_SPECTRUM) == (r_sp is not None)
+        if r_sp is not None:
+            bins = int(r_sp.bins)
+            assert torch.equal(dview(torch, u.spectrum.d_traces, (S, 1, 2, 2, bins)), dview(torch, r_sp.d_traces, (S, 1, 2, 2, bins)))
+        assert torch.equal(dview(torch, u.d_loudness, (S, nb, 30)), dview(torch, r_ld, (S, nb, 30)))
+        assert torch.equal(dview(torch, u.stereometer.d_correlations, (S, nb, 4)), dview(torch, r_st.d_correlations, (S, nb, 4)))
+        assert torch.equal(dview(torch, u.stereometer.d_produced, (S, nb)), dview(torch, r_st.d_produced, (S, nb)))
+        for s in range(S):
+            hdr, smp = sc.fetch(s, nb - 1, with_samples=True)
+            got = dview(torch, u.oscilloscope.d_headers, (S, nb, 10))[s, nb - 1].cpu().numpy()
+            assert got[0] == hdr.produced and got[4] == hdr.samples_per_channel and got[7] == hdr.capture_start, (k, s)
+            if hdr.produced:
+                mine = dview(torch, u.oscilloscope.d_samples, (S, 2, 4096), "<f4")[s, :hdr.channels, :hdr.samples_per_channel].cpu().numpy()
+                assert np.array_equal(mine, smp[:hdr.channels, :hdr.samples_per_channel]), (k, s)
+        assert int(u.waveform.n_columns) == int(r_wf.n_columns)
+        if int(r_wf.n_columns):
+            nc = int(r_wf.n_columns)
+            assert torch.equal(dview(torch, u.waveform.d_columns, (S, nc, 4, 11)), dview(torch, r_wf.d_columns, (S, nc, 4, 11)))

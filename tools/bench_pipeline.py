@@ -1,13 +1,18 @@
 """cfg5 per-GPU shard: 1024 independent 2-ch streams through the full pipeline (reassigned STFT + LUFS + correlation), one
-step = 16384 new frames per stream (64 STFT columns, 64 blocks of 256).  Run on the GPU box."""
+step = 16384 new frames per stream (64 STFT columns, 64 blocks of 256).  Run on the GPU box.
+  serial      the three banks one after the other on one stream, rows by torch glue (tests/pipeline_reference.py)
+  group       omx_capture_group_ingest: what bench.py --config cfg5 times (fan-out, side streams and rows inside the library)"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 
 import openmeters_amd
 from openmeters_amd.pipeline import FullPipeline
+from pipeline_reference import SeparateBanks
 
 
 def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
@@ -17,19 +22,17 @@ def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
     base = 0.4 * torch.sin(t * 0.05 + 1e-7 * t * t)
     pcm = (base[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :] + 0.001 * torch.randn((S, frames * 6, 2), device=dev)).contiguous()
     res = {"workload": f"{S} streams x 2 ch: reassigned STFT 4096/256 + LUFS + band correlation, {frames} frames per step"}
-    for mode in ("serial", "concurrent", "concurrent_then_rows", "concurrent_with_rows"):
-        pipe = FullPipeline(api, S)
+    for mode in ("serial", "group"):
         chunks = [pcm[:, k * frames:(k + 1) * frames].contiguous() for k in range(6)]
         if mode == "serial":
-            run = lambda c: pipe.step(c.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
-        elif mode == "concurrent":
-            run = lambda c: pipe.step_concurrent(torch, c.data_ptr(), frames)
-        elif mode == "concurrent_then_rows":   # the summary rows assembled on the main stream after the join (round-2 start)
+            pipe = SeparateBanks(api, S)
+
             def run(c):
-                r = pipe.step_concurrent(torch, c.data_ptr(), frames)
-                return r[0], pipe.stats(torch, dev, *r)
-        else:   # what bench.py --config cfg5 times: the step AND its summary rows (FullPipeline.step_with_stats)
-            run = lambda c: pipe.step_with_stats(torch, dev, c.data_ptr(), frames)
+                r = pipe.step(c.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
+                return pipe.stats(torch, dev, *r)
+        else:
+            pipe = FullPipeline(api, S)
+            run = lambda c: pipe.step_with_stats(torch, dev, c.data_ptr(), frames)[1]
         run(chunks[0])
         run(chunks[1])
         torch.cuda.synchronize()
@@ -37,15 +40,15 @@ def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
         ev[0].record()
         timed = 24
         for k in range(timed):
-            result = run(chunks[2 + k % 4])
+            table = run(chunks[2 + k % 4])
         ev[1].record()
         torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1]) / timed
-        table = result[1] if mode in ("concurrent_with_rows", "concurrent_then_rows") else pipe.stats(torch, dev, *result)
         print(f"{mode}: {ms:.3f} ms per step of {S} streams x {frames} frames -> {S * frames / ms / 1e6:.2f} G stream-frames/s, "
               f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
               f"rho mean {float(table[:, 3].mean()):.3f}", file=out)
         res[mode] = {"ms_per_step": ms, "stft_frames_per_s": S * (frames // 256) / (ms * 1e-3), "x_real_time": frames / 48000.0 / (ms * 1e-3)}
+        del pipe
     return res
 
 
