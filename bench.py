@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spectrum", action="store_true", help="cfg2: leave the A-weighted spectrum bank out of the step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg4 / cfg5 side measurements (N = 1 only)")
+    ap.add_argument("--no-n1", action="store_true",
+                    help="N > 1: do not measure the same per-GPU workload at N = 1 first (rank 0 runs it as a child process before the "
+                         "ranks meet; the line then carries n1_same_workload.measured)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / gather check without device work (CPU tests: OMX_BENCH_BACKEND=gloo)")
     return ap.parse_args(argv)
@@ -217,6 +220,27 @@ def main():
                               "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
                               "config": {"workload": config, "streams_per_gpu": S, "gathered_rows": int(table.shape[0])}}), flush=True)
         return
+
+    # N > 1: the same per-GPU workload at N = 1, measured by THIS run (rank 0, as a child process that is gone before this process
+    # touches the GPU; the other ranks wait in the rendezvous meanwhile) so that weak-scaling efficiency is read against a number of
+    # the same box, clocks and build
+    n1_measured = None
+    if world > 1 and rank == 0 and not args.no_n1:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                                                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", config, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--streams", str(S), "--frames-per-step", str(F), "--no-secondary", "--no-cpu-baseline"]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if r.returncode == 0 and lines:
+                rec = json.loads(lines[-1])
+                n1_measured = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "kernel_ms": rec["roofline"]["kernel_ms"],
+                               "steps": rec["steps"], "command": " ".join(cmd[1:])}
+            else:
+                log(f"n1 leg failed (exit {r.returncode}): {r.stderr[-400:]}")
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            log(f"n1 leg failed: {e}")
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -413,7 +437,9 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 continue
-        result["n1_same_workload"] = {"command": f"python bench.py --config {config}", "recorded": ref}
+        result["n1_same_workload"] = {"command": f"python bench.py --config {config}", "measured": n1_measured, "recorded": ref}
+        if n1_measured:
+            result["weak_scaling_vs_measured_n1"] = (value / world) / n1_measured["value"]
     if rank == 0:
         if world == 1 and not args.no_secondary:
             # BASELINE.json's other single-GPU configurations, measured after the timed region (a few seconds; never part of

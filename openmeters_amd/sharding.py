@@ -20,14 +20,15 @@ def shard_streams(total_streams: int, rank: int, world_size: int) -> Tuple[int, 
     return first, max(0, min(per, total_streams - first))
 
 
-def gather_stats(local_stats, total_streams: int):
+def gather_stats(local_stats, total_streams: int, always_collective: bool = False):
     """All-gather the per-stream summary rows.  `local_stats` is a float32 tensor [n_local, K] on this rank's
     device; returns a tensor [total_streams, K] identical on every rank (padding rows of uneven shards are
-    dropped).  Works on CUDA/HIP tensors (RCCL) and CPU tensors (gloo)."""
+    dropped).  Works on CUDA/HIP tensors (RCCL) and CPU tensors (gloo).  A world of one rank returns its rows
+    without a collective unless `always_collective` (the 1-GPU box's way to run the RCCL call itself)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return local_stats[:total_streams]
     world = dist.get_world_size()
     per = -(-total_streams // world)

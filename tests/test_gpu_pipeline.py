@@ -140,6 +140,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo_runs_the_cfg5_step():
     assert len(lines) == 1
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["config"]["name"] == "cfg5" and two["value"] > 0 and two["roofline"]["kernel_ms"] > 0
+    assert two["n1_same_workload"]["measured"]["value"] > 0 and two["weak_scaling_vs_measured_n1"] > 0   # the run's own N = 1 leg
     assert two["config"]["columns_per_step_per_gpu"] == 16 * 64
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg5"] + common, env=env, capture_output=True, text=True,
                        timeout=900)
@@ -279,3 +280,54 @@ def test_capture_group_all_six_visuals_equal_their_banks(omx):
         if int(r_wf.n_columns):
             nc = int(r_wf.n_columns)
             assert torch.equal(dview(torch, u.waveform.d_columns, (S, nc, 4, 11)), dview(torch, r_wf.d_columns, (S, nc, 4, 11)))
+
+
+def test_rccl_all_gather_of_the_summary_rows_runs_at_world_size_one():
+    """K8 on the hardware this box has: `nccl` (= RCCL) initialised at world size 1, the capture group's summary rows pushed through
+    all_gather_into_tensor on a side stream (sharding.gather_stats(always_collective=True)) while the next step's kernels are enqueued
+    on the main one — the call pattern of bench.py at N > 1.  In a child process: the process group must not leak into pytest's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+import openmeters_amd
+from openmeters_amd.pipeline import FullPipeline
+from openmeters_amd.sharding import gather_stats
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+S, frames = 32, 4096
+pipe = FullPipeline(openmeters_amd.api(), S)
+g = torch.Generator(device=dev).manual_seed(3)
+pcm = ((torch.rand((S, frames * 4, 2), device=dev, generator=g) - 0.5) * 0.8).contiguous()
+side = torch.cuda.Stream(device=dev)
+gathered = []
+for k in range(4):
+    chunk = pcm[:, k * frames:(k + 1) * frames].contiguous()
+    up, rows = pipe.step_with_stats(torch, dev, chunk.data_ptr(), frames)
+    snapshot = rows.clone()
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        out = gather_stats(snapshot, S, always_collective=True)
+        snapshot.record_stream(side)
+    gathered.append((snapshot, out))
+torch.cuda.synchronize()
+for snapshot, out in gathered:
+    assert out.shape == (S, 12) and torch.equal(out.view(torch.int32), snapshot.view(torch.int32))
+assert float(gathered[-1][1][:, 7].max()) == 16.0
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+""" % root
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
