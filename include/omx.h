@@ -256,6 +256,11 @@ int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset);
 int omx_debug_transforms_per_frame(void);
 /* same for the oscilloscope kernel with OMX_SCOPE_PHASES=1 (ring push, pre-FFT, FFTs, NSDF + peak, locate, snapshot) */
 int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset);
+/* test hook: StableTrigger::find_best (oscilloscope/processor.rs:441-484) of the wide-form trigger pass on caller-supplied host arrays
+ * work[len + search], template[len] (period only sets the coarse stride); scores[search + 1] receives the correlation score of EVERY
+ * offset as the sweeps compute it.  The arrays must fit the LDS of one CU. */
+int omx_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len, uint32_t search, float period, uint32_t* best_off,
+                              float* frac_offset, float* best_score, float* scores);
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *

@@ -196,6 +196,32 @@ int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset) {
         return (int)SCOPE_PHASES;
     });
 }
+int omx_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len, uint32_t search, float period, uint32_t* best_off,
+                              float* frac_offset, float* best_score, float* scores) {
+    if (!work || !tmpl || !best_off || !frac_offset || !best_score || !scores || len < 8 || search == 0) return OMX_ERR_INVALID;
+    if ((uint64_t)(len + search + 16) * sizeof(float) + (uint64_t)(len + 16) * sizeof(float) > 150 * 1024) return OMX_ERR_UNSUPPORTED;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        DeviceBuffer<float> d_work, d_tmpl, d_out;
+        DeviceBuffer<uint32_t> d_off;
+        d_work.reserve((size_t)len + search);
+        d_tmpl.reserve(len);
+        d_out.reserve((size_t)search + 3);
+        d_off.reserve(1);
+        OMX_HIP(hipMemcpy(d_work.ptr, work, ((size_t)len + search) * sizeof(float), hipMemcpyHostToDevice));
+        OMX_HIP(hipMemcpy(d_tmpl.ptr, tmpl, (size_t)len * sizeof(float), hipMemcpyHostToDevice));
+        launch_scope_find_best_debug(d_work.ptr, d_tmpl.ptr, len, search, period, d_off.ptr, d_out.ptr, d_out.ptr + 1, d_out.ptr + 2, nullptr);
+        OMX_HIP(hipGetLastError());
+        OMX_HIP(hipDeviceSynchronize());
+        std::vector<float> h((size_t)search + 3);
+        OMX_HIP(hipMemcpy(h.data(), d_out.ptr, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        OMX_HIP(hipMemcpy(best_off, d_off.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        *frac_offset = h[0];
+        *best_score = h[1];
+        std::memcpy(scores, h.data() + 2, ((size_t)search + 1) * sizeof(float));
+        return (int)OMX_PRODUCED;
+    });
+}
 int omx_debug_transforms_per_frame(void) { return stft_reassigned_4096_transforms_per_frame(); }
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;

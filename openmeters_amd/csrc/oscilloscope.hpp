@@ -91,6 +91,9 @@ void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
 // wide form (scope_fast_kernels.hip): push / estimate / trigger kernels; a.estimates != nullptr, rings hold history + the call
 void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream);
 uint64_t scope_trigger_lds_bytes(uint32_t max_kernel, uint32_t max_period);
+// tests: the trigger pass' find_best on caller-supplied device arrays (work[len + search], template[len]); scores[search + 1]
+void launch_scope_find_best_debug(const float* d_work, const float* d_tmpl, uint32_t len, uint32_t search, float period, uint32_t* d_best_off,
+                                  float* d_frac, float* d_best_score, float* d_scores, hipStream_t stream);
 // the newest len samples of every trace into a ring of another capacity (pos_v: per-stream {head, len}, else a.head / a.len)
 void launch_scope_rehome(const float* from, uint64_t from_cap, float* to, uint64_t to_cap, const uint64_t* pos_v, const ScopeArgs& a,
                          uint64_t max_len, hipStream_t stream);

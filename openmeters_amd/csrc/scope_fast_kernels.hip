@@ -1062,6 +1062,78 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
     c.pc.flush();
 }
 
+// ---------------------------------------------------------------- debug: find_best on caller-supplied arrays
+// (tests: scores against the oracle's normalized_correlation at every offset, near-tie behaviour of the coarse-to-fine walk)
+__global__ __launch_bounds__(512) void scope_find_best_debug_kernel(const float* work, const float* tmpl, uint32_t len, uint32_t search,
+                                                                     float period, uint32_t lds_floats, uint32_t* best_off, float* frac_offset,
+                                                                     float* best_score, float* scores) {
+    constexpr int T = 512;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    __shared__ RedSlots<T / 64> slots;
+    __shared__ __attribute__((aligned(16))) RoundSums sums;
+    Ctx<T> c;
+    const uint32_t span = len + search, span4 = (span + 8 + 3) & ~3u, len4 = (len + 12 + 3) & ~3u;
+    c.ref = c.dyn = lds_f;
+    c.raw = c.work = lds_f;
+    c.tmpl = lds_f + span4;
+    c.dyn_floats = lds_floats;
+    c.tmpl_stride = span4 + 4 * len4 <= lds_floats ? len4 : 0u;
+    c.sums = &sums;
+    c.round = 0;
+    c.red.slots = &slots;
+    c.red.phase = 0;
+    c.ref_peak = 0.0f;
+    c.pc.start(false, nullptr);
+    for (uint32_t i = threadIdx.x; i < span; i += T) c.work[i] = work[i];
+    if (threadIdx.x < 8) c.work[span + threadIdx.x] = 0.0f;
+    float acc[2] = {0.0f, 0.0f};
+    for (uint32_t e = threadIdx.x; e < len; e += T) {
+        const float v = tmpl[e];
+        c.tmpl[e] = v;
+        if (c.aligned()) {
+            c.tmpl[c.tmpl_stride + e + 1] = v;
+            c.tmpl[2 * c.tmpl_stride + e + 2] = v;
+            c.tmpl[3 * c.tmpl_stride + e + 3] = v;
+        }
+        acc[0] += v;
+        acc[1] = __builtin_fmaf(v, v, acc[1]);
+    }
+    if (c.aligned() && threadIdx.x < 32) {
+        const uint32_t a = threadIdx.x >> 3, q = threadIdx.x & 7u;
+        float* ta = c.tmpl + a * c.tmpl_stride;
+        if (q < a) ta[q] = 0.0f;
+        ta[len + a + q] = 0.0f;
+    }
+    c.red.template run<2, 0>(acc);
+    uint32_t off = 0;
+    float frac = 0.0f;
+    find_best(c, len, search, period, acc[0], acc[1], off, frac);
+    // every offset's score, 64 entries per round
+    for (uint32_t top = search;; top -= 64) {
+        const uint32_t cnt = min(64u, top + 1);
+        uint32_t bo = 0;
+        float bs = NEG_INF;
+        eval_round(c, len, top, 1, cnt, false);
+        const RoundScores rs = select_round(c, len, acc[0], acc[1], top, 1, cnt, false, bo, bs);
+        if (threadIdx.x < cnt) scores[top - threadIdx.x] = rs.sc;
+        if (threadIdx.x == 0 && off <= top && top - off < cnt) *best_score = rs.at(top - off);
+        if (top < 64) break;
+    }
+    if (threadIdx.x == 0) {
+        *best_off = off;
+        *frac_offset = frac;
+    }
+}
+
+void launch_scope_find_best_debug(const float* d_work, const float* d_tmpl, uint32_t len, uint32_t search, float period, uint32_t* d_best_off,
+                                  float* d_frac, float* d_best_score, float* d_scores, hipStream_t stream) {
+    const uint32_t span4 = (len + search + 8 + 3) & ~3u, len4 = (len + 12 + 3) & ~3u;
+    const uint32_t lds_floats = std::min<uint32_t>(span4 + 4 * len4, 152 * 1024 / sizeof(float));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_find_best_debug_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    hipLaunchKernelGGL(scope_find_best_debug_kernel, dim3(1), dim3(512), (size_t)lds_floats * sizeof(float), stream, d_work, d_tmpl, len, search,
+                       period, lds_floats, d_best_off, d_frac, d_best_score, d_scores);
+}
+
 // ---------------------------------------------------------------- scope_push_kernel
 // every frame of the call projected into the trace rings at once (dsp.rs:223-249 stereo fold, channel.rs:13-21)
 __global__ __launch_bounds__(256) void scope_push2_kernel(ScopeArgs a) {

@@ -465,6 +465,23 @@ int omxo_oscilloscope_last_capture(const omxo_oscilloscope* h, uint32_t* start, 
     return 1;
 }
 uint64_t omxo_oscilloscope_trace_len(const omxo_oscilloscope* h, int slot) { return h->p.trace_buffer(slot).size(); }
+// StableTrigger::find_best (:441-484) on caller-supplied arrays: work[len + search], template[len].  scores[search + 1] receives
+// normalized_correlation (:210-236) at EVERY offset (the search itself evaluates only the ones its walk visits).
+int omxo_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len, uint32_t search, float period, uint32_t* best_off,
+                               float* frac_offset, float* best_score, float* scores) {
+    StableTrigger t;
+    t.work.assign(work, work + (size_t)len + search);
+    t.candidate.assign(tmpl, tmpl + len);
+    const auto best = t.find_best(search, period);
+    float stats[2];
+    correlation_stats(t.candidate, stats);
+    if (best_off) *best_off = (uint32_t)best.first;
+    if (frac_offset) *frac_offset = best.second;
+    if (best_score) *best_score = normalized_correlation(t.work.data() + best.first, t.candidate.data(), len, stats);
+    if (scores)
+        for (uint32_t o = 0; o <= search; ++o) scores[o] = normalized_correlation(t.work.data() + o, t.candidate.data(), len, stats);
+    return 1;
+}
 
 // PeriodEstimator::estimate_period on a bare slice (reference test :957-995)
 int omxo_kat_estimate_period(const float* samples, uint64_t n, float rate, float* period, float* confidence) {

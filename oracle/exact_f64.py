@@ -103,3 +103,243 @@ def codes_to_power(codes):
     """inverse of pack_classic_db (:103-108): code -> dB -> linear power"""
     db = np.asarray(codes, dtype=np.float64) * (156.0 / 65535.0) - 144.0
     return 10.0 ** (db / 10.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Oscilloscope, Stable trigger — an f64 restatement of the capture of ONE trace (the linked-trigger shape: trigger_source ==
+# channel_1), statement by statement from reference src/visuals/oscilloscope/processor.rs: PeriodEstimator (:85-182),
+# StableTrigger (:272-528) and the helpers (:14-19, :184-263).  All arithmetic in f64 on the f32 PCM samples; integer decisions
+# (lengths, strides, the coarse-to-fine walk) as in the reference.  `frac_offset` divides a score difference by the curvature of
+# a flat correlation peak (parabolic_refine), so it is the quantity whose f32 error is largest: tests/test_exact_f64.py compares
+# the C++ oracle's and the HIP product's frac_offset with this one.
+class ScopeTraceExact:
+    MIN_HZ, MAX_HZ, PROBE_SECONDS, MIN_SIGNAL_PEAK, MIN_PERIODICITY, PEAK_CUTOFF = 20.0, 8000.0, 0.1, 0.001, 0.5, 0.93   # :86-91
+    WINDOW_SECONDS, MIN_CYCLES, SEARCH_PERIODS, NORMALIZE_FLOOR, MEAN_RESPONSIVENESS = 0.04, 2.0, 1.5, 0.01, 0.25       # :285-296
+    BUFFER_RESPONSIVENESS, BUFFER_FALLOFF_PERIODS, BUFFER_RETUNE_SEMITONES, SLOPE_WIDTH_PERIODS = 0.5, 0.5, 1.0, 0.25
+    RESET_BELOW_MATCH, MAX_MISSED_PERIODS = 0.3, 4
+    EPS32 = float(np.finfo(np.float32).eps)   # the reference's f32::EPSILON thresholds keep their f32 value
+
+    def __init__(self, sample_rate=48000.0, segment_duration=0.02, num_cycles=2):
+        self.rate, self.cycles = float(sample_rate), int(num_cycles)
+        r32 = np.float32(sample_rate)
+        self.base_frames = int(max(np.round(r32 * np.float32(segment_duration)), 1.0))                       # :631-633
+        self.max_period = int(np.ceil(r32 / np.float32(self.MIN_HZ)))                                          # :634
+        self.probe_frames = max(int(np.round(r32 * np.float32(self.PROBE_SECONDS))), self.max_period * 2)      # :635-636
+        max_kernel = self._kernel_len(float(self.max_period))
+        max_tail = max(self.max_period * max(self.cycles, 1) + 1, -(-max_kernel // 2))                          # :761-767
+        self.history = max(self.probe_frames, self.base_frames,
+                           max_kernel // 2 + max_tail + int(np.ceil(self.max_period * self.SEARCH_PERIODS)) + 2)
+        self.trace = np.zeros(0, np.float64)
+        self.period = None
+        self.missed = 0
+        self.reference = np.zeros(0)
+        self.reference_period = 0.0
+        self.mean = 0.0
+        self.last_peak = 0.0
+
+    @staticmethod
+    def _round_half_away(x):
+        return float(np.sign(x) * np.floor(abs(x) + 0.5))
+
+    def _kernel_len(self, period):  # :184-189
+        return int(max(self._round_half_away(max(self.rate * self.WINDOW_SECONDS, period * self.MIN_CYCLES)), 2.0))
+
+    @staticmethod
+    def _parabolic(yp, yc, yn, tau, eps):  # :14-19
+        denom = yp - 2.0 * yc + yn
+        if abs(denom) < eps:
+            return float(tau)
+        return max(tau + min(max(0.5 * (yp - yn) / denom, -1.0), 1.0), 1.0)
+
+    def _estimate(self, samples):  # :93-131 + compute_periodicity :133-181
+        self.last_peak = 0.0
+        n = len(samples)
+        if n < 3:
+            return None
+        mean = samples.sum() / n
+        self.last_peak = np.abs(samples - mean).max()
+        if self.last_peak < self.MIN_SIGNAL_PEAK:
+            return None
+        min_period = int(max(self._round_half_away(self.rate / self.MAX_HZ), 2.0))
+        max_period = min(int(self._round_half_away(self.rate / self.MIN_HZ)), n // 2)
+        if max_period <= min_period + 1:
+            return None
+        size = 1 << int(np.ceil(np.log2(n + max_period)))
+        c = samples - mean
+        energy = np.concatenate([[0.0], np.cumsum(c * c)])
+        spec = np.fft.rfft(c, size)
+        acf = np.fft.irfft(spec.real ** 2 + spec.imag ** 2, size) * size   # the reference's inverse is unnormalised ...
+        if energy[n] <= self.EPS32:
+            return None
+        tau = np.arange(max_period + 1)
+        denom = energy[n - tau] + (energy[n] - energy[tau])
+        nsdf = np.where(denom > self.EPS32, 2.0 * acf[:max_period + 1] * (1.0 / size) / np.where(denom > self.EPS32, denom, 1.0), 0.0)  # ... * norm
+        zc = np.nonzero(nsdf[1:] <= 0.0)[0]
+        if len(zc) == 0:
+            return None
+        first_tau = max(min_period, int(zc[0]) + 1)
+        if first_tau >= max_period:
+            return None
+        cand = [t for t in range(first_tau, max_period) if nsdf[t] >= self.MIN_PERIODICITY and nsdf[t] >= nsdf[t - 1] and nsdf[t] >= nsdf[t + 1]]
+        if not cand:
+            return None
+        best = max(cand, key=lambda t: (nsdf[t], t))          # max_by keeps the last maximum
+        cutoff = nsdf[best] * self.PEAK_CUTOFF
+        peak = next((t for t in cand if t <= best and nsdf[t] >= cutoff), best)
+        return self._parabolic(nsdf[peak - 1], nsdf[peak], nsdf[peak + 1], peak, self.EPS32), min(max(nsdf[peak], 0.0), 1.0)
+
+    def _unlock(self):  # :298-304
+        self.period, self.missed, self.reference, self.reference_period, self.mean = None, 0, np.zeros(0), 0.0, 0.0
+
+    @staticmethod
+    def _gauss(n, i, std, eps):  # :199-204
+        if n <= 1 or std <= eps:
+            return np.zeros_like(np.asarray(i, np.float64))
+        return np.exp(-0.5 * ((np.asarray(i, np.float64) - (n - 1) * 0.5) / std) ** 2)
+
+    def _corr(self, x, y):  # :206-236
+        n = len(x)
+        if n == 0:
+            return 0.0
+        sx, sxx, sxy, sy, syy = x.sum(), (x * x).sum(), (x * y).sum(), y.sum(), (y * y).sum()
+        dot = sxy - sx * sy / n
+        ex, ey = max(sxx - sx * sx / n, 0.0), max(syy - sy * sy / n, 0.0)
+        den = np.sqrt(ex * ey)
+        return min(max(dot / den, -1.0), 1.0) if den > self.EPS32 else 0.0
+
+    def _template(self, n, period, use_reference):  # :422-439
+        width = min(max(self.SLOPE_WIDTH_PERIODS * period, 1.0), max(max(n // 2, 1) / 3.0, 1.0))
+        t = np.zeros(n)
+        half = -(-n // 2)
+        i = np.arange(half)
+        w = self._gauss(n, i, width, self.EPS32)
+        t[i] = -w
+        t[n - 1 - i] = w          # written second: the middle element of an odd length ends up +w
+        return t + self.reference if use_reference else t
+
+    def _write_candidate(self, seg, period):  # :509-527
+        c = seg - seg.sum() / max(len(seg), 1)
+        c = c * (1.0 / max(np.abs(c).max() if len(c) else 0.0, self.NORMALIZE_FLOOR))
+        n = len(c)
+        std = max(period * self.BUFFER_FALLOFF_PERIODS, 1.0)
+        i = np.arange(n)
+        c = c * self._gauss(n, np.minimum(i, n - 1 - i), std, self.EPS32)
+        return c, self._corr(self.reference, c)
+
+    def _find_best(self, work, tmpl, search, period):  # :441-484
+        n = len(tmpl)
+        scores = {}
+
+        def score_at(o):
+            if o not in scores:
+                scores[o] = self._corr(work[o:o + n], tmpl)
+            return scores[o]
+        stride = min(min(max(int(self._round_half_away(period / 16.0)), 1), 128), max(search, 1))
+        best = (search // 2, -np.inf)
+        for o in list(range(search, -1, -stride)) + [0]:
+            s = score_at(o)
+            if s > best[1]:
+                best = (o, s)
+        step = stride
+        while step > 1:
+            nxt = max(step // 4, 1)
+            for o in range(min(best[0] + step, search), max(best[0] - step, 0) - 1, -nxt):
+                s = score_at(o)
+                if s > best[1]:
+                    best = (o, s)
+            step = nxt
+        frac = 0.0
+        if 0 < best[0] < search:
+            frac = min(max(self._parabolic(score_at(best[0] - 1), best[1], score_at(best[0] + 1), best[0], self.EPS32) - best[0], -0.5), 0.5)
+        return best[0], frac
+
+    def _locate(self, trace, period_in, confidence):  # :358-411
+        period = max(period_in, 1.0)
+        span = period * max(self.cycles, 1)
+        frames = int(np.ceil(span)) + 1
+        n = self._kernel_len(period)
+        before = n // 2
+        after = n - before
+        if len(trace) < max(frames, after):
+            return None
+        right = len(trace) - max(frames, after)
+        if right < before:
+            return None
+        search = min(max(int(self._round_half_away(period * self.SEARCH_PERIODS)), 1), n // 2, right - before)
+        left = right - search
+        data = trace[left - before:right + after]
+        # prepare (:413-420) with retune_reference (:486-498, :249-263)
+        if len(self.reference) == 0:
+            self.reference, self.reference_period = np.zeros(n), period
+        else:
+            semis = np.log2(period / self.reference_period) * 12.0
+            if len(self.reference) != n or abs(semis) >= self.BUFFER_RETUNE_SEMITONES:
+                ratio = period / self.reference_period
+                old = self.reference
+                if not np.isfinite(ratio) or ratio <= self.EPS32:
+                    self.reference = np.zeros(n)
+                else:
+                    pos = (len(old) - 1) * 0.5 + (np.arange(n) - (n - 1) * 0.5) / ratio
+                    ok = (pos >= 0) & (pos <= len(old) - 1)
+                    idx = np.clip(np.floor(pos).astype(int), 0, len(old) - 1)
+                    fr = pos - idx
+                    nxt = np.clip(idx + 1, 0, len(old) - 1)
+                    lin = np.where((fr > self.EPS32) & (idx + 1 < len(old)), old[idx] + (old[nxt] - old[idx]) * fr, old[idx])
+                    self.reference = np.where(ok, lin, 0.0)
+                self.reference_period = period
+        self.mean += self.MEAN_RESPONSIVENESS * (data.sum() / max(len(data), 1) - self.mean)
+        work = data - self.mean
+        use_reference = bool(np.any(np.abs(self.reference) > 1.0e-3))
+        tmpl = self._template(n, period, use_reference)
+        offset, frac = self._find_best(work, tmpl, search, period)
+        confident = confidence >= self.MIN_PERIODICITY
+        seg = lambda o: trace[left + o - before:left + o - before + n]
+        cand, reset = None, False
+        if confident and use_reference:
+            cand, match = self._write_candidate(seg(offset), period)
+            reset = match < self.RESET_BELOW_MATCH
+        if reset:
+            self.reference = np.zeros(n)
+            tmpl = self._template(n, period, False)
+            offset, frac = self._find_best(work, tmpl, search, period)
+        if confident:
+            if not use_reference or reset:
+                cand, _ = self._write_candidate(seg(offset), period)
+            ref = self.reference * (1.0 / max(np.abs(self.reference).max(), self.NORMALIZE_FLOOR))   # update_reference :500-507
+            self.reference = ref + self.BUFFER_RESPONSIVENESS * (cand - ref)
+            self.reference_period += self.BUFFER_RESPONSIVENESS * (period - self.reference_period)
+        start = left + offset
+        if frac < 0.0 and start > 0:
+            start -= 1
+            frac += 1.0
+        return span, start, frac
+
+    def process_block(self, samples):
+        """Push one block of the trace's (projected) samples; returns (span, start, frac_offset) of the capture, or None."""
+        self.trace = np.concatenate([self.trace, np.asarray(samples, np.float64)])[-self.history:]
+        trace = self.trace
+        if len(trace) < self.base_frames:
+            return None
+        probe = trace[len(trace) - min(self.probe_frames, len(trace)):]
+        detected = self._estimate(probe) if len(probe) >= 3 else None       # capture :306-334
+        if len(probe) > 0 and self.last_peak < self.MIN_SIGNAL_PEAK:
+            self._unlock()
+        est = None                                                          # stabilize :336-356
+        if detected is None:
+            if self.period is not None:
+                self.missed = min(self.missed + 1, 255)
+                if self.missed > self.MAX_MISSED_PERIODS:
+                    self._unlock()
+                else:
+                    est = (self.period, 0.0)
+        else:
+            self.missed = 0
+            p, conf = detected
+            if self.period is not None and 0.9 <= p / self.period <= 1.1:
+                p = self.period + 0.35 * (p - self.period)
+            self.period = p
+            est = (p, conf)
+        cap = self._locate(trace, *est) if est is not None else None
+        if cap is None:
+            return float(max(max(self.base_frames - 1, 0), 1)), max(len(trace) - self.base_frames, 0), 0.0
+        return cap

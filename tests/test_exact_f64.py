@@ -107,3 +107,64 @@ def test_hip_and_oracle_are_equally_close_to_exact_arithmetic_classic(omx, oracl
     h, o = classic_errors(omx, W, hop, zp, kind), classic_errors(oracle, W, hop, zp, kind)
     bar("hip vs exact f64: classic |d dB| within 40 dB of max", h, HALF_CODE_DB + 1e-4)
     bar("oracle vs exact f64: classic |d dB| within 40 dB of max", o, HALF_CODE_DB + 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Oscilloscope, Stable trigger: the capture position start + frac_offset against oracle/exact_f64.py::ScopeTraceExact (an f64
+# restatement of PeriodEstimator + StableTrigger run block by block from the same reset).  frac_offset is a parabola through three
+# f32 correlation scores at a flat peak (oscilloscope/processor.rs:14-19, :472-482): the f32 rounding of the scores (1e-7) becomes
+# 1e-5 ... 1e-4 samples — of the oracle as of the product.  What is asserted: the integer start agrees with exact arithmetic, the
+# oracle's position error stays below 3e-4 samples (CPU), and the HIP product's is no more than 2x the oracle's worst (GPU).
+SCOPE_SIGNALS = {
+    "two partials 440 + 880 Hz": lambda t: 0.8 * np.sin(2 * np.pi * 440.0 * t) + 0.2 * np.sin(2 * np.pi * 880.0 * t + 0.3),
+    "saw 233 Hz (band-limited, 12 partials)": lambda t: 0.5 * sum(np.sin(2 * np.pi * 233.08 * k * t) / k for k in range(1, 13)),
+    "amplitude-modulated 660 Hz": lambda t: 0.6 * (1.0 + 0.2 * np.sin(2 * np.pi * 3.0 * t)) * np.sin(2 * np.pi * 660.0 * t),
+}
+
+
+def scope_positions(api, name, blocks=72):
+    from openmeters_amd import capi
+    from openmeters_amd.capi import OscilloscopeConfig, OscilloscopeProcessor
+    cfg = OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2, trigger_source=capi.CH_LEFT,
+                             channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT)
+    t = np.arange(256 * blocks) / FS
+    left = SCOPE_SIGNALS[name](t).astype(np.float32)
+    pcm = np.stack([left, -0.7 * left], 1).astype(np.float32)
+    proc, exact = OscilloscopeProcessor(api, cfg), ex.ScopeTraceExact(FS, 0.02, 2)
+    rows = []
+    for k in range(blocks):
+        blk = pcm[256 * k:256 * (k + 1)]
+        got = proc.process_block(AudioBlock(blk.reshape(-1), 2, FS))
+        want = exact.process_block(blk[:, 0])
+        if got is None or want is None:
+            assert got is None and want is None
+            continue
+        start, frac = proc.last_capture()
+        rows.append((k, start, frac, want[1], want[2]))
+    return rows
+
+
+def scope_errors(rows, settle=46):
+    """(start mismatches, worst |position - exact| in samples) over the blocks after the history is full and the trigger has settled"""
+    late = [r for r in rows if r[0] >= settle]
+    assert len(late) > 20
+    mismatches = sum(1 for _, s, f, es, ef in late if abs((s + f) - (es + ef)) > 0.5)
+    worst = max(abs((s + f) - (es + ef)) for _, s, f, es, ef in late if abs((s + f) - (es + ef)) <= 0.5)
+    return mismatches, worst
+
+
+@pytest.mark.parametrize("name", sorted(SCOPE_SIGNALS))
+def test_oracle_scope_capture_position_is_close_to_exact_arithmetic(oracle, name):
+    mismatches, worst = scope_errors(scope_positions(oracle, name))
+    assert mismatches == 0
+    bar("scope capture (oracle vs exact f64): |d position| samples", worst, 3e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCOPE_SIGNALS))
+def test_hip_scope_capture_position_is_as_close_to_exact_arithmetic_as_the_oracle(omx, oracle, name):
+    m_o, worst_o = scope_errors(scope_positions(oracle, name))
+    m_h, worst_h = scope_errors(scope_positions(omx, name))
+    assert m_o == 0 and m_h == 0
+    bar("scope capture (HIP vs exact f64): |d position| samples", worst_h, 3e-4)
+    bar("scope capture: HIP error / max(oracle error, 5e-5 samples)", worst_h / max(worst_o, 5e-5), 2.0)

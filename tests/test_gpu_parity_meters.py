@@ -220,6 +220,83 @@ def test_oscilloscope_bank_matches_single_stream_handles(omx, oracle):
                            float(np.abs(np.diff(pcm[s], axis=0)).max()), n, abs(hdr.period - FS / p.last_cycle_rate()) / hdr.period, s)
 
 
+def _find_best(api, work, tmpl, search, period):
+    import ctypes as C
+    work, tmpl = np.ascontiguousarray(work, np.float32), np.ascontiguousarray(tmpl, np.float32)
+    n = len(tmpl)
+    assert len(work) == n + search
+    off, frac, best, scores = C.c_uint32(), C.c_float(), C.c_float(), np.zeros(search + 1, np.float32)
+    f = api.fn("debug_scope_find_best", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint32),
+                                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p])
+    api.check(f(work.ctypes.data, tmpl.ctypes.data, n, search, period, C.byref(off), C.byref(frac), C.byref(best), scores.ctypes.data))
+    return off.value, frac.value, best.value, scores
+
+
+def _exact_scores(work, tmpl, search):
+    w, t = work.astype(np.float64), tmpl.astype(np.float64)
+    n = len(t)
+    out = np.zeros(search + 1)
+    sy, syy = t.sum(), (t * t).sum()
+    ey = max(syy - sy * sy / n, 0.0)
+    for o in range(search + 1):
+        x = w[o:o + n]
+        sx = x.sum()
+        ex = max((x * x).sum() - sx * sx / n, 0.0)
+        den = np.sqrt(ex * ey)
+        out[o] = np.clip(((x * t).sum() - sx * sy / n) / den, -1.0, 1.0) if den > np.finfo(np.float32).eps else 0.0
+    return out
+
+
+@pytest.mark.parametrize("case", ["periodic tie (period 101)", "periodic tie (period 64)", "perturbed ties", "noise", "short period, long window"])
+def test_scope_find_best_scores_and_near_tie_argmax(omx, oracle, case):
+    """StableTrigger::find_best (oscilloscope/processor.rs:441-484) of the trigger pass on fixed arrays, against the oracle's
+    statement-for-statement restatement and against exact (f64) arithmetic:
+      * the correlation score of EVERY offset: |HIP - exact| and |oracle - exact| at the f32 noise of a 2000-term sum (bar 1e-6; the HIP
+        sums — packed FMA, 64-lane tree — must not be further from exact arithmetic than twice the oracle's 4-chain sums);
+      * the argmax: a signal that repeats inside the search span puts EXACT ties into the score table (offsets a period apart see the
+        same samples).  The strict-> scan order decides them in the reference; here the two offsets' sums are taken in differently
+        aligned groups, so the last bit may fall the other way.  Whichever offset the walk ends on, its score — in the oracle's own
+        table — must equal the oracle's winner within the f32 noise (2e-6): a flip may only happen between offsets that are equally
+        good.  Without ties (noise) offset and frac_offset agree with the oracle's."""
+    seed = {"periodic tie (period 101)": 1, "periodic tie (period 64)": 2, "perturbed ties": 3, "noise": 4, "short period, long window": 5}[case]
+    rng = np.random.default_rng(seed)
+    n = 1920
+    if case.startswith("periodic tie"):
+        period = 101.0 if "101" in case else 64.0
+        search = int(round(1.5 * period))
+        cyc = (0.7 * np.sin(2 * np.pi * np.arange(int(period)) / period) + 0.2 * rng.standard_normal(int(period))).astype(np.float32)
+        work = np.tile(cyc, (n + search) // int(period) + 2)[:n + search]
+    elif case == "perturbed ties":
+        period, search = 109.09, 164
+        t = np.arange(n + search)
+        work = (0.8 * np.sin(2 * np.pi * t / 109.0) + 1e-6 * rng.standard_normal(n + search)).astype(np.float32)
+    elif case == "noise":
+        period, search = 300.0, 450
+        work = rng.standard_normal(n + search).astype(np.float32) * 0.3
+    else:
+        period, search = 12.4, 19
+        work = (0.5 * np.sin(2 * np.pi * np.arange(n + search) / 12.4)).astype(np.float32)
+    i = np.arange(n)
+    edge = np.exp(-0.5 * ((np.minimum(i, n - 1 - i) - (n - 1) * 0.5) / max(0.25 * period, 1.0)) ** 2)
+    tmpl = (np.where(i < n // 2, -edge, edge) + 0.6 * np.roll(work[:n], 7) * np.exp(-0.5 * ((i - 960) / (0.5 * period * 4)) ** 2)).astype(np.float32)
+    work = (work - work.mean(dtype=np.float32)).astype(np.float32)
+    o_off, o_frac, o_best, o_scores = _find_best(oracle, work, tmpl, search, period)
+    h_off, h_frac, h_best, h_scores = _find_best(omx, work, tmpl, search, period)
+    exact = _exact_scores(work, tmpl, search)
+    err_o, err_h = np.abs(o_scores - exact).max(), np.abs(h_scores - exact).max()
+    bar("scope find_best: |score - exact f64| (HIP)", err_h, 1e-6)
+    bar("scope find_best: |score - exact f64| (oracle)", err_o, 1e-6)
+    bar("scope find_best: HIP score error / max(oracle score error, 1.2e-7)", err_h / max(err_o, 1.2e-7), 2.0)
+    bar("scope find_best: oracle-table score of the HIP winner below the oracle winner's", float(o_scores[o_off] - o_scores[h_off]), 2e-6)
+    assert h_best == h_scores[h_off]
+    if case in ("noise", "short period, long window"):
+        assert h_off == o_off
+        bar("scope find_best: |d frac_offset| (no ties)", abs(h_frac - o_frac), 1.2e-3)
+    if h_off != o_off:   # a tie decided the other way: the two winners are a whole number of periods apart
+        k = abs(h_off - o_off) / period
+        assert abs(k - round(k)) < 0.02 and round(k) >= 1, (h_off, o_off)
+
+
 def test_oscilloscope_zero_crossing_mode_matches_oracle(omx, oracle):
     cfg = OscilloscopeConfig(segment_duration=0.01, trigger_mode=capi.TRIGGER_ZERO_CROSSING, channel_1=capi.CH_LEFT,
                              channel_2=capi.CH_MID, trigger_source=capi.CH_NONE)
