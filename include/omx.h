@@ -390,6 +390,13 @@ int omx_loudness_bank_create(const omx_loudness_config* cfg, uint32_t n_streams,
                              omx_loudness_bank** out);
 void omx_loudness_bank_destroy(omx_loudness_bank* b);
 int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
+/* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_loudness_bank_set_option pins one):
+ *   sequential kernels (sliding Kahan-Babuska-Neumaier sums in the reference's order) for single-stream handles, calls of fewer than
+ *       8 blocks or fewer than 4096 (slot, block) items (slot = stream x channel), ragged calls and non-finite PCM;
+ *   chunk-parallel kernels (window sums as differences of an f64 running total; K-weighting by a block scan) for calls of >= 8 blocks
+ *       and >= 4096 (slot, block) items whose block length and window lengths suit the sub-block grid (see loudness_chunked.hip).
+ *       Same quantities to ~1e-15 of a window sum; LUFS / RMS within 1e-4 dB of the sequential order (measured 1.5e-5), true peak
+ *       bit-identical.  OMX_OPT_KERNEL_FORM = 1 pins the sequential kernels. */
 int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device,
                               uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                               float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
@@ -462,6 +469,15 @@ int omx_stereometer_bank_create(const omx_stereometer_config* cfg, uint32_t n_st
                                 omx_stereometer_bank** out);
 void omx_stereometer_bank_destroy(omx_stereometer_bank* b);
 int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
+/* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_stereometer_bank_set_option pins one):
+ *   sequential kernels — the reference's operation order: points bit-exact, rho error 0 against the CPU restatement —
+ *       for single-stream handles, calls of fewer than 8 blocks or fewer than 512 (stream, block) items, channel counts other than 2,
+ *       blocks that are not a multiple of 16 frames (or shorter than 32), ragged calls, and any call whose PCM is not finite;
+ *   chunk-parallel kernels (every block of the call in parallel, block-boundary states by a scan) for 2-channel calls of
+ *       >= 8 blocks and >= 512 (stream, block) items.  Same arithmetic, different evaluation order of the f32 band filters: points
+ *       within 1e-4 of full scale (measured 2.9e-5), rho within 1e-6 on bands within 16 dB of the full level (measured 6e-8) and
+ *       within the reference's own f32 filter noise elsewhere (tests/parity.py::check_chunked_rho).  NOT bit-identical to the
+ *       sequential order: a host that needs the reference's exact bits sets OMX_OPT_KERNEL_FORM = 1. */
 int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int pcm_on_device,
                                  uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                                  float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],

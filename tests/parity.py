@@ -165,8 +165,13 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
 # Measured maxima over every configuration of tools/parity_report.py are in profiles/parity_r02.txt; each bar is <= 10x them.
 # orphan: a point present on one side only sits on the 1e-14 keep-floor or on the 0 < f-hat < fs/2 edge; which side of the edge a bin
 # lands on is decided by f-hat's last bits (16x zero padding puts several bins within a fraction of a Hz of 0 and of Nyquist).
-# Measured 1.2e-8 of the column maximum since the four-transform kernels (exact w') replaced the table-driven ones (1.5e-13 before).
-BAR_POWER, BAR_FREQ, BAR_TIME, BAR_ORPHAN = 1e-5, 1e-7, 1e-4, 1e-7
+# How strong can such a bin be?  f-hat of a bin of relative power r (amplitude sqrt(r) of the column's largest) carries an error of
+# ~2e-8 (fs/2) / sqrt(r) (the unweighted f-hat bars below: a ratio of spectra), so a bin within that distance of 0 or fs/2 can land on
+# either side: at r = 7e-8 that is 8e-5 (fs/2) = 2 Hz, at r = 1e-6 0.5 Hz — and 16x zero padding spaces bins 1.5 Hz apart.  Measured
+# 6.9e-8 of the column maximum since the four-transform kernels (closed-form w': the HIP f-hat is ~100x closer to exact arithmetic than
+# the oracle's table-driven one, so edge bins decide by the ORACLE's noise now; 1.5e-13 while both used the same tables).  Bar: 3e-7
+# (4x measured; a bin that strong sits within 1 Hz of the edge, and at most 4 orphans per column are accepted at all).
+BAR_POWER, BAR_FREQ, BAR_TIME, BAR_ORPHAN = 1e-5, 1e-7, 1e-4, 3e-7
 # f-hat: the ORACLE (like the reference) takes w' from an f32 spectral derivative (processor.rs:569-599); the four-transform kernels
 # use the closed form of that derivative and are ~100x closer to exact arithmetic in f-hat (tests/test_exact_f64.py: 4e-11 against the
 # oracle's 2e-8 at W = 8192).  HIP-vs-oracle on strong bins therefore measures the oracle's own table noise: up to 2.0e-7 at W = 8192.

@@ -153,7 +153,7 @@ def check_trace(x, y, floor=-100.0):
     clear = (y > floor + 12.0) & (x > floor + 12.0)   # a flushed state re-seeds (:366-369): its bin needs a few hops to re-converge
     loud = clear & (y > y.max() - 60.0)
     if loud.any():
-        bar("spectrum: |d dB| within 60 dB of max", np.abs(x[loud] - y[loud]).max(), 0.05)
+        bar("spectrum: |d dB| within 60 dB of max", np.abs(x[loud] - y[loud]).max(), 0.01)   # measured 2.1e-3 (profiles/parity_r*.txt)
     near = clear & (y > y.max() - 80.0)
     if near.any():
         assert np.abs(x - y)[near].max() <= 0.1
