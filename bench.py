@@ -453,6 +453,7 @@ def main():
                 import bench_pipeline
                 sec = {"cfg3_loudness": bench_meters.loudness(out=sys.stderr)}
                 sec.update({"cfg4_" + k: v for k, v in bench_meters.scope_stereo(out=sys.stderr).items()})
+                sec.update(bench_meters.reference_defaults(out=sys.stderr))   # the reference's default shapes (2048 / 64, 16384 / 1024)
                 if config == "cfg2":
                     sec["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
                 result["secondary"] = sec

@@ -19,6 +19,37 @@ FS = 48000.0
 stream = torch.cuda.current_stream().cuda_stream
 
 
+HBM_PEAK_GBS = 8000.0
+
+
+def meter_traffic(kernel_substrings):
+    """Measured HBM bytes per call of the kernels whose names contain one of `kernel_substrings`, from the newest
+    profiles/*_meters_traffic.json (written by tools/profile_meters_pmc.sh: FETCH_SIZE / WRITE_SIZE passes, (2 F + W) * 1024 per
+    MI355X_MICROARCH.md); None when there is no such record.  An echo tagged with its source, never a measurement of this run."""
+    import glob
+    import json
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_meters_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        total, used = 0.0, []
+        for name, v in rec.get("kernels", {}).items():
+            if any(k in name for k in kernel_substrings):
+                total += v["hbm_bytes_per_launch"] * v.get("launches_per_call", 1)
+                used.append(name)
+        if used:
+            return {"hbm_bytes_per_call": total, "kernels": used, "source": "profiles/" + os.path.basename(path), "commit": rec.get("commit")}
+    return None
+
+
+def roofline(alg_bytes, ms, kernels):
+    """SURVEY §8(d) bytes of one call against the HBM peak; `traffic` = the counters' bytes for the same kernels (see meter_traffic)"""
+    return {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": alg_bytes, "ms_per_call": ms,
+            "traffic": meter_traffic(kernels)}
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -57,6 +88,7 @@ def loudness(S=1024, C=8, blocks=64, reps=5, out=sys.stdout):
             "ms_per_call": dt * 1e3, "kernel_ms": kms, "form": "chunk-parallel (loudness_chunked.hip)",
             "hbm_frac_compulsory_12B": cs * 12 / (kms * 1e-3) / 8e12, "hbm_frac_moved_20p5B": cs * 20.5 / (kms * 1e-3) / 8e12,
             "hbm_frac_reference_formulation_44B": cs * 44 / (kms * 1e-3) / 8e12,
+            "roofline": roofline(cs * 44.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan", "loudness_"]),   # §8(d): 44 B per channel-sample + 104 B per snapshot
             "momentary_lufs_stream0": float(snap.momentary_loudness)}
 
 
@@ -76,7 +108,9 @@ def scope_stereo(S=256, blocks=64, reps=5, out=sys.stdout):
     print(f"cfg4 stereometer: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
           f"{S*frames/dt/(S*FS):.0f}x real time", file=out)
     res = {"stereometer": {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
-                           "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3}}
+                           "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3,
+                           # §8(d): ~16 B per stereo frame (8 B PCM in + 8 B per point out on emit)
+                           "roofline": roofline(S * frames * 16.0, dt * 1e3, ["stereo_chunk", "stereo_scan", "stereometer_"])}}
     sc = banks.OscilloscopeBank(api, capi.OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2,
                                                              trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT), S)
     dt = timed(lambda: sc.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
@@ -85,7 +119,45 @@ def scope_stereo(S=256, blocks=64, reps=5, out=sys.stdout):
           f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel}", file=out)
     res["oscilloscope"] = {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
                            "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3, "stream0_locked": int(hdr.locked),
-                           "stream0_period": float(hdr.period)}
+                           "stream0_period": float(hdr.period),
+                           # §8(d): <= 34 816 B per block (256 x 2 ch x 4 B in + <= 2 x 4096 x 4 B snapshot out)
+                           "roofline": roofline(S * blocks * 34816.0, dt * 1e3, ["scope_"])}
+    return res
+
+
+def reference_defaults(S=64, out=sys.stdout):
+    """The reference's DEFAULT shapes (spectrogram/processor.rs:58-59: 2048 / hop 64, reassigned; spectrum/processor.rs:24-25:
+    16384 / hop 1024), 64 streams, every hop materialised — the shapes a stock OpenMeters install runs."""
+    res = {}
+    pos = capi.positions_fallback(2)
+    W, hop, cols = 2048, 64, 1024
+    frames = 2 * W + hop * (cols - 1)
+    pcm = (torch.rand((S, frames + hop * cols * 4, 2), device=dev) - 0.5).contiguous()
+    bank = banks.SpectrogramBank(api, capi.SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=True, history_length=8192), S)
+    bank.set_option(capi.OPT_KERNEL_TIMING, 1)
+    bank.process_device(pcm[:, :frames].contiguous().data_ptr(), frames, 2, FS, pos)
+    bank.kernel_time()
+    chunks = [pcm[:, frames + it * hop * cols: frames + (it + 1) * hop * cols].contiguous() for it in range(4)]
+    dt = timed(lambda: [bank.process_device(c.data_ptr(), hop * cols, 2, FS, pos) for c in chunks], 1) / 4
+    kms, _ = bank.kernel_time()
+    n = S * cols
+    by = hop * 2 * 4 + 4 + 12 * (W // 2 + 1)
+    print(f"default spectrogram {W}/{hop} reassigned: {dt*1e3:.3f} ms per {n} frames (kernel {kms:.3f}) -> {n/dt/1e6:.1f} M frames/s", file=out)
+    res["default_spectrogram_2048_64"] = {"workload": f"{S} streams, {cols} columns per call", "frames_per_s": n / dt, "ms_per_call": dt * 1e3,
+                                           "kernel_ms": kms, "roofline": roofline(n * float(by), kms, ["stft_reassigned_pow2_pair"])}
+    del bank, pcm, chunks
+    N, hop, hops = 16384, 1024, 256
+    frames = N + hop * (hops - 1)
+    pcm = (torch.rand((S, frames + hop * hops * 3, 2), device=dev) - 0.5).contiguous()
+    sp = banks.SpectrumBank(api, capi.SpectrumConfig(fft_size=N, hop_size=hop), S, emit_all_hops=True)
+    sp.process_device(pcm[:, :frames].contiguous().data_ptr(), frames, 2, FS, pos)
+    chunks = [pcm[:, frames + it * hop * hops: frames + (it + 1) * hop * hops].contiguous() for it in range(3)]
+    dt = timed(lambda: [sp.process_device(c.data_ptr(), hop * hops, 2, FS, pos) for c in chunks], 1) / 3
+    n = S * hops
+    by = hop * 2 * 4 + 2 * (N // 2 + 1) * 4   # §8(d): PCM in + weighted and raw trace out per materialised hop
+    print(f"default spectrum {N}/{hop}: {dt*1e3:.3f} ms per {n} hops -> {n/dt/1e6:.2f} M hops/s", file=out)
+    res["default_spectrum_16384_1024"] = {"workload": f"{S} streams, {hops} hops per call, every hop materialised", "hops_per_s": n / dt,
+                                          "ms_per_call": dt * 1e3, "roofline": roofline(n * float(by), dt * 1e3, ["spectrum_"])}
     return res
 
 

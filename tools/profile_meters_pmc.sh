@@ -18,11 +18,14 @@ for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
             k = row.get("Kernel_Name", "")
             if "omx::" in k:
                 agg[k.split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-lines = []
+import json
+lines, rec = [], {"commit": os.environ.get("OMX_PROFILE_COMMIT"), "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE x2)", "kernels": {}}
 for k, cs in agg.items():
     fe = sum(cs.get("FETCH_SIZE", [0])) / max(len(cs.get("FETCH_SIZE", [1])), 1)
     wr = sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [1])), 1)
     lines.append(f"{k:60s} FETCH_SIZE {fe:12.0f} KiB  WRITE_SIZE {wr:12.0f} KiB  -> HBM bytes per launch (2*F + W)*1024 = {(2 * fe + wr) * 1024 / 1e9:.3f} GB")
+    rec["kernels"][k.strip()] = {"fetch_size_kib": fe, "write_size_kib": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "launches": len(cs.get("FETCH_SIZE", []))}
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(rec, open(os.path.join(out, "meters_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 PY
