@@ -394,9 +394,12 @@ int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
  *   sequential kernels (sliding Kahan-Babuska-Neumaier sums in the reference's order) for single-stream handles, calls of fewer than
  *       8 blocks or fewer than 4096 (slot, block) items (slot = stream x channel), ragged calls and non-finite PCM;
  *   chunk-parallel kernels (window sums as differences of an f64 running total; K-weighting by a block scan) for calls of >= 8 blocks
- *       and >= 4096 (slot, block) items whose block length and window lengths suit the sub-block grid (see loudness_chunked.hip).
+ *       and >= 4096 (slot, block) items whose block length is a multiple of 64 frames and which start at a multiple of 64 frames
+ *       since the last reset: 1-8 channels, every sample rate (44.1 / 88.2 kHz windows are off the 64-sample grid: loudness_chunked.hip).
  *       Same quantities to ~1e-15 of a window sum; LUFS / RMS within 1e-4 dB of the sequential order (measured 1.5e-5), true peak
  *       bit-identical.  OMX_OPT_KERNEL_FORM = 1 pins the sequential kernels. */
+/* test hook: which evaluation order the bank's last process call took — 1 = sequential kernels, 2 = chunk-parallel (0 = no call yet) */
+int omx_debug_loudness_bank_last_form(const omx_loudness_bank* b);
 int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device,
                               uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                               float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],

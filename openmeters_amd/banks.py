@@ -213,6 +213,10 @@ class LoudnessBank(_BlockBank):
     def set_option(self, option, value):
         self.api.check(self.api.fn("loudness_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
 
+    def last_form(self) -> int:
+        """1 = the last call ran the sequential kernels, 2 = the chunk-parallel ones (omx_debug_loudness_bank_last_form)."""
+        return self.api.fn("debug_loudness_bank_last_form", C.c_int, [C.c_void_p])(self._h)
+
     def _process(self, ptr, on_device, block_frames, n_blocks, channels, sample_rate, positions, stream):
         out = C.c_void_p()
         f = self.api.fn("loudness_bank_process", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32,

@@ -429,6 +429,7 @@ int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t
         return (int)OMX_NONE;
     });
 }
+int omx_debug_loudness_bank_last_form(const omx_loudness_bank* b) { return b ? b->impl.last_form() : OMX_ERR_INVALID; }
 int omx_loudness_bank_set_option(omx_loudness_bank* b, uint32_t option, uint64_t value) {
     if (!b) return OMX_ERR_INVALID;
     if (option == OMX_OPT_KERNEL_TIMING) {

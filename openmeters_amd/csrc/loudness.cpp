@@ -59,30 +59,65 @@ static double channel_weight(uint8_t position) {  // :174-183
     }
 }
 
-// Zero-input transition of the K-weighting TDF-II over `frames` samples and its powers 2, 4 ... 32 (f64): [6][4][4].
-// One step with x = 0 (loudness/processor.rs:153-162): y = f0; f0' = f1 - a1 y; f1' = f2 - a2 y; f2' = f3 - a3 y; f3' = -a4 y.
+// Zero-input transition of the K-weighting TDF-II over `frames` samples and its powers 2, 4 ... 32 as double-double pairs:
+// [6][4][4] high parts, then [6][4][4] low parts.  One step with x = 0 (loudness/processor.rs:153-162):
+//   y = f0; f0' = f1 - a1 y; f1' = f2 - a2 y; f2' = f3 - a3 y; f3' = -a4 y.
+// The filter's poles sit at 1 - O(f / fs) (38 Hz high-pass: 0.9988 double pole at 192 kHz), the companion form is far from normal,
+// and the block transition inherits that: entries of 3e5 whose products with the state cancel to the state's own size.  Entries
+// rounded to f64 put 4e-4 of the state into a 192 kHz scan (1e-3 dB on a 15 Hz channel), an 80-bit recurrence still 2e-13 of an
+// entry; so every power comes from its own recurrence in double-double arithmetic (~1e-32) and the device scan keeps the pairs.
+namespace {
+struct DD {
+    double h, l;
+};
+inline DD dd_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+inline DD dd_add(DD a, DD b) {
+    DD s = dd_two_sum(a.h, b.h);
+    const DD t = dd_two_sum(a.l, b.l);
+    s.l += t.h;
+    s = {s.h + s.l, s.l - ((s.h + s.l) - s.h)};
+    s.l += t.l;
+    return {s.h + s.l, s.l - ((s.h + s.l) - s.h)};
+}
+inline DD dd_mul_d(DD a, double b) {  // a * b, b an f64
+    const double p = a.h * b, e = std::fma(a.h, b, -p) + a.l * b;
+    return {p + e, e - ((p + e) - p)};
+}
+}  // namespace
 static std::vector<double> k_weighting_transitions(const double b[5], const double a[5], uint64_t frames) {
     (void)b;
-    std::vector<double> T(6 * 16, 0.0);
+    DD P[4][4];
     for (int m = 0; m < 4; ++m) {
-        long double f[4] = {0, 0, 0, 0};
-        f[m] = 1.0L;
+        DD f[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        f[m].h = 1.0;
         for (uint64_t n = 0; n < frames; ++n) {
-            const long double y = f[0];
-            f[0] = f[1] - (long double)a[1] * y;
-            f[1] = f[2] - (long double)a[2] * y;
-            f[2] = f[3] - (long double)a[3] * y;
-            f[3] = -(long double)a[4] * y;
+            const DD y = f[0];
+            f[0] = dd_add(f[1], dd_mul_d(y, -a[1]));
+            f[1] = dd_add(f[2], dd_mul_d(y, -a[2]));
+            f[2] = dd_add(f[3], dd_mul_d(y, -a[3]));
+            f[3] = dd_mul_d(y, -a[4]);
         }
-        for (int k = 0; k < 4; ++k) T[(size_t)k * 4 + m] = (double)f[k];
+        for (int k = 0; k < 4; ++k) P[k][m] = f[k];
     }
-    for (int p = 1; p < 6; ++p)
+    std::vector<double> T(2 * 6 * 16, 0.0);
+    for (int p = 0; p < 6; ++p) {
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) {
-                long double acc = 0.0L;
-                for (int k = 0; k < 4; ++k) acc += (long double)T[(size_t)(p - 1) * 16 + i * 4 + k] * (long double)T[(size_t)(p - 1) * 16 + k * 4 + j];
-                T[(size_t)p * 16 + i * 4 + j] = (double)acc;
+                T[(size_t)p * 16 + (size_t)i * 4 + j] = P[i][j].h;
+                T[(size_t)(6 + p) * 16 + (size_t)i * 4 + j] = P[i][j].l;
             }
+        DD S[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                DD acc = {0, 0};
+                for (int k = 0; k < 4; ++k) acc = dd_add(acc, dd_add(dd_mul_d(P[i][k], P[k][j].h), dd_mul_d(P[i][k], P[k][j].l)));
+                S[i][j] = acc;
+            }
+        std::memcpy(P, S, sizeof(P));
+    }
     return T;
 }
 
@@ -234,13 +269,13 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     LoudnessArgs la{};
     fill_args(la, d_pcm, block_frames, n_blocks, channels, positions);
     // chunk-parallel evaluation for bank-sized calls (loudness_chunked.hip): every block of the call in parallel
-    constexpr uint64_t kQLen = 4096;
-    bool shape_ok = (channels == 1 || channels == 2 || channels == 4 || channels == 8) && block_frames % 64 == 0 && n_blocks >= 2 &&
-                    frames_seen_ % 64 == 0 && ring_len_ / 64 + frames / 64 + 2 <= kQLen;
-    for (int w = 0; w < 4; ++w) shape_ok = shape_ok && la.capacities[w] % 64 == 0;
-    const uint64_t slots = (uint64_t)n_streams_ * channels;
+    bool shape_ok = block_frames % 64 == 0 && n_blocks >= 2 && frames_seen_ % 64 == 0;
+    bool off_grid = false;  // 44.1 / 88.2 kHz: window lengths that are not multiples of 64 samples
+    for (int w = 0; w < 4; ++w) off_grid = off_grid || la.capacities[w] % 64 != 0;
+    const uint64_t slots = (uint64_t)n_streams_ << la.slot_shift;
     const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && slots * n_blocks >= 4096));
     timer_.begin(stream);
+    last_form_ = chunked ? 2 : 1;
     if (chunked) {
         if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
             transition_.upload(k_weighting_transitions(b_, a_, block_frames), stream);
@@ -254,6 +289,7 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
         ca.n_blocks = (uint32_t)n_blocks;
         ca.n_streams = n_streams_;
         ca.channels = channels;
+        ca.slot_shift = la.slot_shift;
         for (int i = 0; i < 5; ++i) {
             ca.b[i] = la.b[i];
             ca.a[i] = la.a[i];
@@ -274,16 +310,29 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
         ca.snapshots = snapshots_.ptr;
         chunk_filter_.reserve((size_t)(slots * n_blocks * 4));
         sub_sums_.reserve((size_t)(slots * (frames / 64)));
-        if (!q_ring_.ptr) {
-            q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * kQLen));
+        // the running totals of every sub-block a window of this call can start in: the ring's and the call's, as a power of two
+        uint64_t q_need = 4096;
+        while (q_need < ring_len_ / 64 + frames / 64 + 2) q_need *= 2;
+        if (q_need > q_len_) {
+            q_len_ = q_need;
+            q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_));
             OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
+            tails_.release();
+            if (frames_seen_ != 0) q_valid_ = false;  // re-indexed: the totals come back from the squared-sample ring
         }
         bad_.reserve(1);
         OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
         ca.chunk_filter = chunk_filter_.ptr;
         ca.sub_sums = sub_sums_.ptr;
         ca.q_ring = q_ring_.ptr;
-        ca.q_len = kQLen;
+        ca.q_len = q_len_;
+        if (off_grid && !tails_.ptr) {
+            tails_.reserve((size_t)((uint64_t)n_streams_ * 8 * kLoudnessWindows * q_len_));
+            OMX_HIP(hipMemsetAsync(tails_.ptr, 0, tails_.count * sizeof(double), stream));
+            if (frames_seen_ != 0) q_valid_ = false;  // the tails of what is already in the ring
+        }
+        ca.tails = off_grid ? tails_.ptr : nullptr;
+        for (int w = 0; w < 4; ++w) ca.tail_len[w] = (uint32_t)(la.capacities[w] % 64);
         ca.bad = bad_.ptr;
         rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
         if (!q_valid_) {  // earlier calls went through the sequential kernels: the running totals come back from the ring

@@ -53,7 +53,7 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream);
 struct LoudChunkArgs {
     const float* pcm;       // [n_streams][frames_total][channels]
     uint64_t frames_total;
-    uint32_t block_frames, n_blocks, n_streams, channels;  // channels in {1, 2, 4, 8}: slot = stream * channels + channel
+    uint32_t block_frames, n_blocks, n_streams, channels, slot_shift;  // slot = (stream << slot_shift) + channel
     double b[5], a[5];
     double weights[OMX_MAX_CHANNELS];
     uint8_t positions[OMX_MAX_CHANNELS];
@@ -70,6 +70,8 @@ struct LoudChunkArgs {
     double* sub_sums;              // [slots][n_blocks * block_frames / 64]
     double* q_ring;                // [slots][q_len]: running total of the squared samples at the end of every 64-sample sub-block
     uint64_t q_len;                // power of two
+    double* tails;                 // [slots][windows][q_len]: sum of the last tail_len[w] samples of every sub-block; null when every
+    uint32_t tail_len[kLoudnessWindows];  // tail_len[w] = capacities[w] % 64 is 0 (window starts on the sub-block grid)
     uint32_t* bad;
 };
 void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T /* [6][4][4] */, hipStream_t stream);
@@ -115,11 +117,13 @@ private:
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
     // chunk-parallel path
-    DeviceBuffer<double> chunk_filter_, sub_sums_, q_ring_, transition_, rebuild_scratch_;
+    DeviceBuffer<double> chunk_filter_, sub_sums_, q_ring_, tails_, transition_, rebuild_scratch_;
     DeviceBuffer<uint32_t> bad_;
     bool q_valid_ = false;
+    uint64_t q_len_ = 0;     // entries per slot of q_ring_ / tails_ (power of two, grows with the call size)
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
+    int last_form_ = 0;      // 1 = sequential kernels, 2 = chunk-parallel (omx_debug_loudness_bank_last_form)
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows
     // ragged mode: per-stream sample counters on the device
     bool ragged_ = false;
@@ -129,6 +133,7 @@ private:
     RaggedStaging r_staging_;
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
+    int last_form() const { return last_form_; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: snapshots in pinned host memory
 };
 

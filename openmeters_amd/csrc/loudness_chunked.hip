@@ -15,10 +15,12 @@
 //                    before them, in the reference's accumulation order -> bit-identical to the sequential kernels.
 // The squared samples still go to the f64 ring in the sequential kernels' layout, and the channel state (filter, KBN pairs,
 // delay line) is written back in their form, so calls may alternate between the two forms.
-// Shapes: channels in {1, 2, 4, 8}, block_frames and every window length a multiple of 64 (48 / 96 / 192 kHz), sample counter
-// a multiple of 64.  Non-finite PCM is detected in pass A; every later kernel then leaves the state alone and the caller runs
+// Shapes: any channel count (1, 2, 4, 8 through LDS tiles of whole streams; 3, 5, 6, 7 by per-lane reads), block_frames and the
+// sample counter multiples of 64; window lengths on the 64-sample grid (48 / 96 / 192 kHz) or off it (44.1 / 88.2 kHz: `tails`).  Non-finite PCM is detected in pass A; every later kernel then leaves the state alone and the caller runs
 // the sequential kernel instead (processor.rs has no reset in k_weighted: a NaN poisons the filter for good — order matters).
 #include "loudness.hpp"
+
+#include <type_traits>
 
 namespace omx {
 
@@ -28,6 +30,11 @@ constexpr uint32_t kRow = 64;        // ring row = 64 slots (loudness_kernels.hi
 constexpr int STEP = 16;             // frames per staged PCM tile
 constexpr uint32_t SUB = 64;         // samples per sub-block sum
 
+// slot = (stream << slot_shift) + channel, the sequential kernels' numbering (1, 2, 4 or 8 slots per stream: channel counts 3, 5, 6, 7
+// leave the slots past `channels` idle), so the state, the rings and every per-slot array here are shared between the two forms
+__device__ __forceinline__ bool slot_live(const LoudChunkArgs& a, uint32_t slot) {
+    return (slot >> a.slot_shift) < a.n_streams && (slot & ((1u << a.slot_shift) - 1u)) < a.channels;
+}
 __device__ __forceinline__ void kbn(double& sum, double& corr, double v) {  // dsp.rs:277-285
     const double next = sum + v;
     const bool big_sum = fabs(sum) >= fabs(v);
@@ -86,20 +93,50 @@ struct Tile {
     }
 };
 
+// Channel counts 3, 5, 6, 7 (the reference's own 5- and 6-channel cases, loudness/processor.rs:366-398): eight slots per stream of
+// which `channels` are live, so a group's PCM is not one rectangular tile of floats; every live lane reads its own channel's 16
+// samples of the step straight from the interleaved PCM (stride C floats; a stream's lanes share the cache lines of its 16 C
+// contiguous floats), the next step's loads in flight behind the current arithmetic.
+struct Direct {
+    const float* src;
+    bool live;
+    float pre[STEP];
+    __device__ __forceinline__ void setup(const LoudChunkArgs& a, uint32_t chan, bool live_, uint64_t frame0) {
+        const uint32_t C = a.channels, s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
+        live = live_;
+        src = a.pcm + ((uint64_t)(live ? s : 0) * a.frames_total + frame0) * C + (live ? ch : 0);
+    }
+    __device__ __forceinline__ void issue(uint32_t step, uint32_t C) {
+#pragma unroll
+        for (int f = 0; f < STEP; ++f) pre[f] = live ? src[((uint64_t)step * STEP + f) * C] : 0.0f;
+    }
+    __device__ __forceinline__ uint32_t take(float (&x)[STEP]) {  // returns 1 when a sample of this slot is not finite
+        uint32_t bad = 0;
+#pragma unroll
+        for (int f = 0; f < STEP; ++f) {
+            x[f] = pre[f];
+            bad |= isfinite(x[f]) ? 0u : 1u;
+        }
+        return bad;
+    }
+};
+
 }  // namespace
 
 // ---- K-weighting: PASS 0 = zero-state end state of the block; PASS 1 = from the true start state: squared samples -> ring,
 // sub-block sums.  grid (slot groups, blocks), 64 threads: lane = slot of the group.
-template <int PASS>
+template <int PASS, bool TILED, bool TAILS>
 __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) {
-    __shared__ float tile[2][64 * 17];
+    __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     if (PASS == 1 && *a.bad != 0u) return;
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
-    const bool live = chan < a.n_streams * C;
+    const bool live = slot_live(a, chan);
     Tile t;
-    t.setup(a, group, (uint64_t)c * L, lane);
+    Direct dl;
+    if constexpr (TILED) t.setup(a, group, (uint64_t)c * L, lane);
+    else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + c) * 4u;
@@ -112,18 +149,31 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     const double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
     double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
     uint64_t pos = (a.frames_seen + (uint64_t)c * L) % a.ring_len;  // ring slot of the block's first sample
+    // a call longer than the ring: only its newest ring_len samples are stored (an earlier block must not race a later one for a slot)
+    const uint64_t idx0 = (uint64_t)c * L, first_kept = a.frames_total > a.ring_len ? a.frames_total - a.ring_len : 0u;
     double* sub = a.sub_sums + ((uint64_t)chan * a.n_blocks + c) * (L / SUB);
     double ssum = 0.0, scor = 0.0;
+    // window lengths off the 64-sample grid (44.1 / 88.2 kHz): the sum of the LAST cap_w % 64 samples of every sub-block, so that a
+    // window starting inside sub-block g is Q[end] - (Q[g] - tail_w[g])
+    double tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
+    const uint64_t g_first = a.frames_seen / SUB + (uint64_t)c * (L / SUB);
+    double* tails = TAILS && live ? a.tails + (uint64_t)chan * kLoudnessWindows * a.q_len : nullptr;
     uint32_t bad = 0;
-    t.issue(0, C);
+    if constexpr (TILED) t.issue(0, C);
+    else dl.issue(0, C);
     for (uint32_t step = 0; step < steps; ++step) {
-        bad |= t.stage(tile[step & 1u]);
-        if (step + 1u < steps) t.issue(step + 1u, C);
-        __syncthreads();
-        const float* row = tile[step & 1u] + rd;
         float x[STEP];
+        if constexpr (TILED) {
+            bad |= t.stage(tile[step & 1u]);
+            if (step + 1u < steps) t.issue(step + 1u, C);
+            __syncthreads();
+            const float* row = tile[step & 1u] + rd;
 #pragma unroll
-        for (int f = 0; f < STEP; ++f) x[f] = row[f * C];
+            for (int f = 0; f < STEP; ++f) x[f] = row[f * C];
+        } else {
+            bad |= dl.take(x);
+            if (step + 1u < steps) dl.issue(step + 1u, C);
+        }
 #pragma unroll
         for (int f = 0; f < STEP; ++f) {  // k_weighted (:153-162), the sequential kernels' statement order
             const double xd = (double)x[f];
@@ -136,15 +186,28 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
                 const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
                 double value = filtered * filtered;
                 value = isfinite(value) ? value : 0.0;     // WindowedMeans::push (dsp.rs:325)
-                if (live) ring_col[pos * kRow] = value;
+                if (live && idx0 + (uint64_t)(step * STEP + f) >= first_kept) ring_col[pos * kRow] = value;
                 pos = pos + 1u == a.ring_len ? 0u : pos + 1u;
                 kbn(ssum, scor, value);
+                if constexpr (TAILS) {
+                    const int lim = (int)SUB - STEP * (int)(step % (SUB / STEP)) - f;  // samples from this one to the sub-block's end
+#pragma unroll
+                    for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += (int)a.tail_len[w] >= lim ? value : 0.0;
+                }
             }
         }
         if constexpr (PASS == 1) {
             if ((step + 1u) % (SUB / STEP) == 0u) {
-                if (live) sub[(step + 1u) / (SUB / STEP) - 1u] = ssum + scor;
+                const uint32_t j = (step + 1u) / (SUB / STEP) - 1u;
+                if (live) sub[j] = ssum + scor;
                 ssum = scor = 0.0;
+                if constexpr (TAILS) {
+#pragma unroll
+                    for (int w = 0; w < kLoudnessWindows; ++w) {
+                        if (live) tails[(uint64_t)w * a.q_len + ((g_first + j) & (a.q_len - 1u))] = tl[w];
+                        tl[w] = 0.0;
+                    }
+                }
             }
         }
     }
@@ -159,75 +222,89 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     }
 }
 
-// ---- scan of the filter states over the blocks: wavefront = slot, lane = block (see stereometer_chunked.hip for the scheme)
-__global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, const double* __restrict__ Tp /* [6][4][4] */) {
+// ---- scan of the filter states over the blocks: wavefront = slot, lane = block (see stereometer_chunked.hip for the scheme).
+// x_c+1 = T x_c + z_c in double-double arithmetic (T as hi / lo pairs from the host, loudness.cpp: k_weighting_transitions): the
+// products T x cancel to ~1e-6 of their size at 192 kHz, and the start states must reach the f64 recurrence's own accuracy.
+struct DD {
+    double h, l;
+};
+__device__ __forceinline__ DD dd_madd(DD acc, double th, double tl, DD u) {  // acc + (th + tl) * (u.h + u.l)
+    const double p = th * u.h;
+    const double pe = fma(th, u.h, -p) + (th * u.l + tl * u.h);
+    const double s = acc.h + p, bb = s - acc.h;
+    const double e = ((acc.h - (s - bb)) + (p - bb)) + (acc.l + pe);
+    const double h = s + e;
+    return {h, e - (h - s)};
+}
+__global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, const double* __restrict__ Tp /* [2][6][4][4] */) {
     if (*a.bad != 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (chan >= a.n_streams * a.channels) return;
+    if (!slot_live(a, chan)) return;
     LoudnessChannelState& st = a.state[chan];
-    double carry[4] = {st.filter[0], st.filter[1], st.filter[2], st.filter[3]};
+    DD carry[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) carry[k] = {st.filter[k], 0.0};
+    const double* Tl = Tp + 6 * 16;
     for (uint32_t c0 = 0; c0 < a.n_blocks; c0 += 64u) {
         const uint32_t c = c0 + lane;
         const bool live = c < a.n_blocks;
         double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + (live ? c : c0)) * 4u;
-        double x[4];
+        DD x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = live ? cf[k] : 0.0;
+        for (int k = 0; k < 4; ++k) x[k] = {live ? cf[k] : 0.0, 0.0};
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                double acc = x[k];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc += Tp[k * 4 + m] * carry[m];
-                x[k] = acc;
+                for (int m = 0; m < 4; ++m) x[k] = dd_madd(x[k], Tp[k * 4 + m], Tl[k * 4 + m], carry[m]);
             }
         }
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
             const int d = 1 << step;
-            const double* Td = Tp + step * 16;
-            double up[4];
+            const double *Th = Tp + step * 16, *Tw = Tl + step * 16;
+            DD up[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) up[k] = shfl_up_f64(x[k], d);
+            for (int k = 0; k < 4; ++k) up[k] = {shfl_up_f64(x[k].h, d), shfl_up_f64(x[k].l, d)};
             if ((int)lane >= d) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    double acc = x[k];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc += Td[k * 4 + m] * up[m];
-                    x[k] = acc;
+                    for (int m = 0; m < 4; ++m) x[k] = dd_madd(x[k], Th[k * 4 + m], Tw[k * 4 + m], up[m]);
                 }
             }
         }
         const uint32_t last = min(a.n_blocks - c0, 64u) - 1u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            double start = shfl_up_f64(x[k], 1);
-            if (lane == 0) start = carry[k];
+            double start = shfl_up_f64(x[k].h, 1);
+            if (lane == 0) start = carry[k].h;
             if (live) cf[k] = fabs(start) < 1.0e-30 ? 0.0 : start;  // denormal flush once per block (:281-285)
-            const double e = shfl_f64(x[k], (int)last);
-            carry[k] = fabs(e) < 1.0e-30 ? 0.0 : e;
+            const double eh = shfl_f64(x[k].h, (int)last), el = shfl_f64(x[k].l, (int)last);
+            carry[k] = fabs(eh) < 1.0e-30 ? DD{0.0, 0.0} : DD{eh, el};
         }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) st.filter[k] = carry[k];
+        for (int k = 0; k < 4; ++k) st.filter[k] = carry[k].h;
     }
 }
 
 // ---- true peak of every block (TruePeakMeter::process, :123-151): grid (slot groups, blocks), lane = slot.  Bit-identical to
 // the sequential kernels: same samples, same tap order; the DL - 1 samples before the block come from the PCM of the call or,
 // for its first block, from the carried delay line.
-template <int DL>
+template <int DL, bool TILED>
 __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
-    __shared__ float tile[2][64 * 17];
+    __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
-    const bool live = chan < a.n_streams * C;
-    const uint32_t s = chan / C, ch = chan % C;
+    const bool live = slot_live(a, chan);
+    const uint32_t s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
     Tile t;
-    t.setup(a, group, (uint64_t)c * L, lane);
+    Direct dl;
+    if constexpr (TILED) t.setup(a, group, (uint64_t)c * L, lane);
+    else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     constexpr int H = DL > 1 ? DL - 1 : 1;
     float hist[H];  // hist[0] = newest sample before the block
@@ -244,15 +321,24 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
         }
     }
     float peak = 0.0f;
-    t.issue(0, C);
+    if constexpr (TILED) t.issue(0, C);
+    else dl.issue(0, C);
     for (uint32_t step = 0; step < steps; ++step) {
-        (void)t.stage(tile[step & 1u]);
-        if (step + 1u < steps) t.issue(step + 1u, C);
-        __syncthreads();
-        const float* row = tile[step & 1u] + rd;
         float ext[STEP + H];  // ext[STEP - 1 - k] = x[k]; ext[STEP + i] = hist[i]
+        if constexpr (TILED) {
+            (void)t.stage(tile[step & 1u]);
+            if (step + 1u < steps) t.issue(step + 1u, C);
+            __syncthreads();
+            const float* row = tile[step & 1u] + rd;
 #pragma unroll
-        for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = live ? row[k * C] : 0.0f;
+            for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = live ? row[k * C] : 0.0f;
+        } else {
+            float x[STEP];
+            (void)dl.take(x);
+            if (step + 1u < steps) dl.issue(step + 1u, C);
+#pragma unroll
+            for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = x[k];
+        }
 #pragma unroll
         for (int i = 0; i < H; ++i) ext[STEP + i] = hist[i];
 #pragma unroll
@@ -296,7 +382,7 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
 __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
     if (*a.bad != 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (chan >= a.n_streams * a.channels) return;
+    if (!slot_live(a, chan)) return;
     const uint64_t n_sub = (uint64_t)a.n_blocks * (a.block_frames / SUB), g0 = a.frames_seen / SUB;  // first new sub-block
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
     double carry = g0 == 0 ? 0.0 : q[(g0 - 1u) & (a.q_len - 1u)];
@@ -318,23 +404,36 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
 // ---- rebuild Q from the squared-sample ring (after calls that went through the sequential kernels): sub-block sums of the
 // newest min(frames_seen, ring_len) samples, then the same prefix.  grid (slot groups, sub-blocks), lane = slot.
 __global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, uint64_t first_sub, double* out /* [chan][n] */, uint64_t n,
-                                                              const uint32_t* only_if) {
+                                                              uint32_t avail, const uint32_t* only_if) {
     if (only_if && *only_if == 0u) return;
     const uint32_t lane = threadIdx.x, group = blockIdx.x;
     const uint64_t j = blockIdx.y;
     const uint32_t chan = group * 64u + lane;
-    if (chan >= a.n_streams * a.channels) return;
+    if (!slot_live(a, chan)) return;
     const double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
-    double s = 0.0, c = 0.0;
-    const uint64_t sample0 = (first_sub + j) * SUB;
-    for (uint32_t i = 0; i < SUB; ++i) kbn(s, c, ring_col[((sample0 + i) % a.ring_len) * kRow]);
-    out[(uint64_t)chan * n + j] = s + c;
+    // y == n: the sub-block before the first whole one, of which the ring still holds the newest `avail` samples (a ring length off
+    // the 64-sample grid); only its tails are needed (the longest window starts inside it)
+    const bool partial = j == n;
+    const uint64_t g = partial ? first_sub - 1u : first_sub + j;
+    const uint32_t i0 = partial ? SUB - avail : 0u;
+    double s = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t i = i0; i < SUB; ++i) {
+        const double v = ring_col[((g * SUB + i) % a.ring_len) * kRow];
+        kbn(s, c, v);
+#pragma unroll
+        for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += a.tail_len[w] >= SUB - i ? v : 0.0;
+    }
+    if (!partial) out[(uint64_t)chan * n + j] = s + c;
+    if (a.tails) {
+#pragma unroll
+        for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (g & (a.q_len - 1u))] = tl[w];
+    }
 }
 __global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, uint64_t first_sub, const double* sub, uint64_t n,
                                                              const uint32_t* only_if) {
     if (only_if && *only_if == 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (chan >= a.n_streams * a.channels) return;
+    if (!slot_live(a, chan)) return;
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
     double carry = 0.0;  // only differences of Q are used once the windows are full; before that first_sub == 0
     for (uint64_t j0 = 0; j0 < n; j0 += 64u) {
@@ -365,22 +464,31 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
     double short_term = 0.0, momentary = 0.0;
     const bool last = c + 1u == a.n_blocks;
     for (uint32_t ch = 0; ch < C; ++ch) {
-        const uint32_t chan = s * C + ch;
+        const uint32_t chan = (s << a.slot_shift) + ch;
         const double* q = a.q_ring + (uint64_t)chan * a.q_len;
         const double q_end = q[(P / SUB - 1u) & mask];
         double mean[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t m = min(P, a.capacities[w]);  // dsp.rs:367-370: min(count, cap), count itself saturates at the ring
-            const uint64_t start_sub = (P - m) / SUB;
-            const double base = start_sub == 0 ? 0.0 : q[(start_sub - 1u) & mask];
+            const uint64_t st = P - m, start_sub = st / SUB;  // st % 64 == (64 - tail_len[w]) % 64 once the window is full
+            double base;
+            if (st % SUB == 0u) base = start_sub == 0 ? 0.0 : q[(start_sub - 1u) & mask];
+            else base = q[start_sub & mask] - a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (start_sub & mask)];
             const double W = q_end - base;
             mean[w] = W / (double)max(m, (uint64_t)1);
             if (last) {  // the sequential kernels' state: live pair = the window sum, `since refresh` pair = sum since the last
                          // multiple of cap pushes (CompensatedPair::refresh, dsp.rs:287-289, :363); corrections folded in
                 LoudnessChannelState& st = a.state[chan];
-                const uint64_t refresh_sub = (P / a.capacities[w]) * a.capacities[w] / SUB;
-                const double rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
+                const uint64_t refresh = (P / a.capacities[w]) * a.capacities[w], refresh_sub = refresh / SUB;
+                double rbase;
+                if (refresh % SUB == 0u) rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
+                else {  // off the grid: the rest of that sub-block is still in the squared-sample ring (refresh > P - cap >= P - ring_len)
+                    const double* ring_col = a.ring + (uint64_t)(chan / kRow) * a.ring_len * kRow + chan % kRow;
+                    double rest = 0.0;
+                    for (uint64_t i = refresh; i < (refresh_sub + 1u) * SUB; ++i) rest += ring_col[(i % a.ring_len) * kRow];
+                    rbase = q[refresh_sub & mask] - rest;
+                }
                 st.sums[w][0] = W;
                 st.corrections[w][0] = 0.0;
                 st.sums[w][1] = q_end - rbase;
@@ -405,23 +513,40 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
 
 // a.frames_seen = the sample counter the ring content corresponds to; only_if: run only when *only_if != 0 (after a fallback)
 void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const uint32_t* only_if, hipStream_t stream) {
-    const uint64_t have = std::min<uint64_t>(a.frames_seen, a.ring_len);
-    const uint64_t n = have / SUB, first_sub = (a.frames_seen - have) / SUB;
-    if (n == 0) return;
-    const uint32_t slots = a.n_streams * a.channels, groups = (slots + 63u) / 64u;
-    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)n), dim3(64), 0, stream, a, first_sub, scratch, n, only_if);
+    const uint64_t have = std::min<uint64_t>(a.frames_seen, a.ring_len), oldest = a.frames_seen - have;
+    const uint64_t first_sub = (oldest + SUB - 1u) / SUB;  // first whole sub-block in the ring
+    if (a.frames_seen / SUB <= first_sub) return;
+    const uint64_t n = a.frames_seen / SUB - first_sub;
+    const uint32_t avail = (uint32_t)(first_sub * SUB - oldest);  // samples left of sub-block first_sub - 1
+    const uint32_t slots = a.n_streams << a.slot_shift, groups = (slots + 63u) / 64u;
+    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)n + (avail && a.tails ? 1u : 0u)), dim3(64), 0, stream, a, first_sub, scratch, n,
+                       avail, only_if);
     hipLaunchKernelGGL(loud_rebuild_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, first_sub, scratch, n, only_if);
 }
 
 void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStream_t stream) {
-    const uint32_t slots = a.n_streams * a.channels, groups = (slots + 63u) / 64u;
+    const uint32_t slots = a.n_streams << a.slot_shift, groups = (slots + 63u) / 64u;
     const dim3 grid(groups, a.n_blocks);
-    hipLaunchKernelGGL(loud_chunk_filter_kernel<0>, grid, dim3(64), 0, stream, a);
-    if (a.delay_len == 12) hipLaunchKernelGGL(loud_chunk_peak_kernel<12>, grid, dim3(64), 0, stream, a);
-    else if (a.delay_len == 24) hipLaunchKernelGGL(loud_chunk_peak_kernel<24>, grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(loud_chunk_peak_kernel<0>, grid, dim3(64), 0, stream, a);
+    const bool tiled = a.channels == 1 || a.channels == 2 || a.channels == 4 || a.channels == 8;  // 64 slots = whole streams
+    auto filter = [&](auto pass) {
+        constexpr int PASS = decltype(pass)::value;
+        if (PASS == 1 && a.tails) {
+            if (tiled) hipLaunchKernelGGL((loud_chunk_filter_kernel<1, true, true>), grid, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((loud_chunk_filter_kernel<1, false, true>), grid, dim3(64), 0, stream, a);
+        } else if (tiled) hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, true, false>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, false, false>), grid, dim3(64), 0, stream, a);
+    };
+    auto peak = [&](auto dl) {
+        constexpr int DL = decltype(dl)::value;
+        if (tiled) hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, true>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, false>), grid, dim3(64), 0, stream, a);
+    };
+    filter(std::integral_constant<int, 0>{});
+    if (a.delay_len == 12) peak(std::integral_constant<int, 12>{});
+    else if (a.delay_len == 24) peak(std::integral_constant<int, 24>{});
+    else peak(std::integral_constant<int, 0>{});
     hipLaunchKernelGGL(loud_scan_filter_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
-    hipLaunchKernelGGL(loud_chunk_filter_kernel<1>, grid, dim3(64), 0, stream, a);
+    filter(std::integral_constant<int, 1>{});
     hipLaunchKernelGGL(loud_scan_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a);
     const uint64_t snaps = (uint64_t)a.n_streams * a.n_blocks;
     hipLaunchKernelGGL(loud_chunk_snapshot_kernel, dim3((uint32_t)((snaps + 255u) / 256u)), dim3(256), 0, stream, a);

@@ -599,6 +599,7 @@ def test_loudness_chunk_parallel_form_matches_oracle_and_alternates_with_the_seq
         bank.set_option(capi.OPT_KERNEL_FORM, form)
         part = pcm[:, at:at + 256 * n_blocks]
         assert bank.process_host(part, 256, C, FS) is not None
+        assert bank.last_form() == form
         check = sorted(set([0, 1, 2, n_blocks // 2, n_blocks - 2, n_blocks - 1]) & set(range(n_blocks)))
         for s in range(S):
             want = [refs[s].process_block(AudioBlock(part[s, k:k + 256].reshape(-1), C, FS)) for k in range(0, 256 * n_blocks, 256)]
@@ -623,11 +624,15 @@ def test_loudness_chunk_parallel_form_matches_oracle_and_alternates_with_the_seq
         snapshots_close(bank.fetch(s, 15), w)
 
 
-@pytest.mark.parametrize("channels,rate", [(8, 48000.0), (1, 96000.0), (4, 192000.0)])
+@pytest.mark.parametrize("channels,rate", [(8, 48000.0), (1, 96000.0), (4, 192000.0)] +
+                         [(c, r) for r in (44100.0, 48000.0, 96000.0) for c in (2, 4, 5, 6)] + [(3, 44100.0), (7, 88200.0)])
 def test_loudness_chunk_parallel_form_other_layouts_and_rates(omx, oracle, channels, rate):
-    """1 / 4 / 8 channels (SURROUND weights), 2x true-peak interpolation at 96 kHz, none at 192 kHz; the chunked and the
-    sequential bank must agree with each other bit for bit on the true peak and within 1e-4 dB elsewhere."""
-    S, n_blocks, block = 3, 24, 512 if rate > 48000.0 else 256
+    """Every channel count (1, 2, 4, 8 through LDS tiles; 3, 5, 6, 7 by per-lane reads: eight slots per stream as in the sequential
+    kernels), SURROUND weights, 2x true-peak interpolation at 96 kHz, none at 192 kHz, and 44.1 / 88.2 kHz whose window lengths
+    (17 640, 132 300 ... samples) are off the 64-sample sub-block grid (`tails`).  Long enough that the 0.4 s window is full and
+    sliding; the chunked and the sequential bank must agree bit for bit on the true peak and within 1e-4 dB elsewhere."""
+    S, block = 3, 1024 if rate > 48000.0 else 512
+    n_blocks = int(0.55 * rate) // block + 1
     pcm = np.stack([cfg3_pcm(s, block * n_blocks, channels) for s in range(S)])
     positions = capi.SURROUND if channels == 8 else capi.positions_fallback(channels)
     a, b = banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, channels), banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, channels)
@@ -635,6 +640,7 @@ def test_loudness_chunk_parallel_form_other_layouts_and_rates(omx, oracle, chann
     b.set_option(capi.OPT_KERNEL_FORM, 1)
     a.process_host(pcm, block, channels, rate, positions)
     b.process_host(pcm, block, channels, rate, positions)
+    assert (a.last_form(), b.last_form()) == (2, 1)
     for s in range(S):
         p = LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate))
         for blk in range(n_blocks):
@@ -643,6 +649,34 @@ def test_loudness_chunk_parallel_form_other_layouts_and_rates(omx, oracle, chann
             assert np.array_equal(ga.true_peak_db.view(np.uint32), gb.true_peak_db.view(np.uint32))
             snapshots_close(ga, w)
             snapshots_close(gb, w)
+
+
+@pytest.mark.parametrize("channels", [2, 6])
+def test_loudness_chunk_parallel_form_at_44100_alternates_with_the_sequential_form(omx, oracle, channels):
+    """44.1 kHz, where no window length is a multiple of 64 samples and the squared-sample ring (132 300) is not either: chunked until
+    the 3 s window is full and has refreshed, sequential (must continue from the chunked state: live / since-refresh sums taken at an
+    off-grid refresh point), chunked again (running totals AND tails rebuilt from a ring whose oldest sub-block is partial), chunked."""
+    S, block, rate = 2, 512, 44100.0
+    calls = [(140, 2), (140, 2), (12, 1), (40, 2), (135, 2), (135, 2)]   # a call's sub-blocks + the ring's must fit the 4096-entry Q ring
+    total = block * sum(n for n, _ in calls)
+    pcm = np.stack([cfg3_pcm(170 + s, total, channels) for s in range(S)])
+    pcm[1] *= np.float32(0.05)
+    positions = capi.positions_fallback(channels)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, channels)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate)) for _ in range(S)]
+    at = 0
+    for n_blocks, form in calls:
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        part = pcm[:, at:at + block * n_blocks]
+        assert bank.process_host(part, block, channels, rate, positions) is not None
+        assert bank.last_form() == form
+        check = sorted(set([0, 1, 2, 34, 35, n_blocks // 2, 258, 259, n_blocks - 2, n_blocks - 1]) & set(range(n_blocks)))
+        for s in range(S):
+            want = [refs[s].process_block(AudioBlock(part[s, k:k + block].reshape(-1), channels, rate, positions))
+                    for k in range(0, block * n_blocks, block)]
+            for blk in check:
+                snapshots_close(bank.fetch(s, blk), want[blk])
+        at += block * n_blocks
 
 
 def test_loudness_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx):
