@@ -513,6 +513,8 @@ int omx_stereometer_bank_fetch_points(omx_stereometer_bank* b, uint64_t stream_i
                                       uint64_t dst_capacity_pairs, uint64_t* n_pairs);
 /* OMX_OPT_KERNEL_FORM: 0 = choose by call shape (default), 1 = sequential kernels only (reference operation order, bit-identical
  * filters), 2 = chunk-parallel evaluation whenever the shape allows (2 channels, blocks of a multiple of 16 frames, >= 2 blocks) */
+/* test hook: 1 = the bank's last process call ran the sequential kernels, 2 = the chunk-parallel ones (0 = no call yet) */
+int omx_debug_stereometer_bank_last_form(const omx_stereometer_bank* b);
 int omx_stereometer_bank_set_option(omx_stereometer_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *

@@ -296,6 +296,10 @@ class StereometerBank(_BlockBank):
     def set_option(self, option, value):
         self.api.check(self.api.fn("stereometer_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
 
+    def last_form(self) -> int:
+        """1 = the last call ran the sequential kernels, 2 = the chunk-parallel ones (omx_debug_stereometer_bank_last_form)."""
+        return self.api.fn("debug_stereometer_bank_last_form", C.c_int, [C.c_void_p])(self._h)
+
     def process_ragged(self, device_ptr: int, block_frames: int, max_blocks: int, n_blocks: Sequence[int], channels: int, sample_rate: float,
                        positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
         """Streams advance independently: stream s runs n_blocks[s] (<= max_blocks) blocks of block_frames frames, after reset_audio()

@@ -823,3 +823,4 @@ int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t
 }
 
 }  // extern "C"
+int omx_debug_stereometer_bank_last_form(const omx_stereometer_bank* b) { return b ? b->impl.last_form() : OMX_ERR_INVALID; }

@@ -162,10 +162,11 @@ int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint
     const bool cleared_now = state_clean_ && !clean_before;
     if (!ragged_) {  // every stream starts from the bank's common counter
         r_seen_.upload(std::vector<uint64_t>(n_streams_, frames_seen_), stream);
+        h_seen_.assign(n_streams_, frames_seen_);
         ragged_ = true;
-        q_valid_ = false;
     } else if (cleared_now) {
         OMX_HIP(hipMemsetAsync(r_seen_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
+        h_seen_.assign(n_streams_, 0);
     }
     if (!any && !any_reset) return OMX_NONE;
     // per-stream counts / flags: pinned staging -> device (the caller's arrays are borrowed for the call only)
@@ -179,8 +180,25 @@ int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint
     la.seen_v = r_seen_.ptr;
     la.blocks_v = r_blocks_.ptr;
     la.reset_v = r_mask_.ptr;
+    // the host's mirror of the per-stream counters decides the form: every stream on the 64-sample sub-block grid
+    bool grid_ok = block_frames % 64 == 0 && max_blocks >= 2;
+    uint64_t items = 0;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (reset_mask && reset_mask[s]) h_seen_[s] = 0;
+        grid_ok = grid_ok && h_seen_[s] % 64 == 0;
+        h_seen_[s] += (uint64_t)n_blocks[s] * block_frames;
+        items += n_blocks[s];
+    }
+    items <<= la.slot_shift;
+    const bool chunked = grid_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (max_blocks >= 8 && items >= 4096));
+    last_form_ = chunked ? 2 : 1;
     timer_.begin(stream);
-    launch_loudness(la, stream);
+    if (chunked) {
+        run_chunked(la, stream);
+    } else {
+        launch_loudness(la, stream);
+        q_valid_ = false;
+    }
     timer_.end(stream);
     OMX_HIP(hipGetLastError());
     state_clean_ = false;  // (frames_seen_ is meaningless from here on: the counters are per stream)
@@ -247,6 +265,89 @@ void LoudnessBank::fill_args(LoudnessArgs& la, const float* d_pcm, uint64_t bloc
     la.snapshots = snapshots_.ptr;
 }
 
+// Chunk-parallel evaluation of one call (lock-step, or ragged when la.blocks_v is set): loudness_chunked.hip.
+void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
+    const uint64_t block_frames = la.block_frames, n_blocks = la.n_blocks, frames = block_frames * n_blocks;
+    const uint64_t slots = (uint64_t)n_streams_ << la.slot_shift;
+    bool off_grid = false;  // 44.1 / 88.2 kHz: window lengths that are not multiples of 64 samples
+    for (int w = 0; w < 4; ++w) off_grid = off_grid || la.capacities[w] % 64 != 0;
+    if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
+        transition_.upload(k_weighting_transitions(b_, a_, block_frames), stream);
+        transition_rate_ = cfg_.sample_rate;
+        transition_frames_ = block_frames;
+    }
+    LoudChunkArgs ca{};
+    ca.pcm = la.pcm;
+    ca.frames_total = frames;
+    ca.block_frames = (uint32_t)block_frames;
+    ca.n_blocks = (uint32_t)n_blocks;
+    ca.n_streams = n_streams_;
+    ca.channels = la.channels;
+    ca.slot_shift = la.slot_shift;
+    for (int i = 0; i < 5; ++i) {
+        ca.b[i] = la.b[i];
+        ca.a[i] = la.a[i];
+    }
+    for (int i = 0; i < OMX_MAX_CHANNELS; ++i) {
+        ca.weights[i] = la.weights[i];
+        ca.positions[i] = la.positions[i];
+    }
+    std::memcpy(ca.fir4, la.fir4, sizeof(ca.fir4));
+    std::memcpy(ca.fir2, la.fir2, sizeof(ca.fir2));
+    ca.delay_len = la.delay_len;
+    for (int w = 0; w < 4; ++w) ca.capacities[w] = la.capacities[w];
+    ca.ring_len = ring_len_;
+    ca.frames_seen = frames_seen_;
+    ca.seen_v = la.seen_v;
+    ca.blocks_v = la.blocks_v;
+    ca.reset_v = la.reset_v;
+    ca.ring = ring_.ptr;
+    ca.state = state_.ptr;
+    ca.floor_db = cfg_.floor_db;
+    ca.snapshots = snapshots_.ptr;
+    chunk_filter_.reserve((size_t)(slots * n_blocks * 4));
+    sub_sums_.reserve((size_t)(slots * (frames / 64)));
+    // the running totals of every sub-block a window of this call can start in: the ring's and the call's, as a power of two
+    uint64_t q_need = 4096;
+    while (q_need < ring_len_ / 64 + frames / 64 + 2) q_need *= 2;
+    if (q_need > q_len_) {
+        q_len_ = q_need;
+        q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_));
+        OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
+        tails_.release();
+        if (!state_clean_) q_valid_ = false;  // re-indexed: the totals come back from the squared-sample ring
+    }
+    ca.q_ring = q_ring_.ptr;
+    ca.q_len = q_len_;
+    if (off_grid && !tails_.ptr) {
+        tails_.reserve((size_t)((uint64_t)n_streams_ * 8 * kLoudnessWindows * q_len_));
+        OMX_HIP(hipMemsetAsync(tails_.ptr, 0, tails_.count * sizeof(double), stream));
+        if (!state_clean_) q_valid_ = false;  // the tails of what is already in the ring
+    }
+    ca.tails = off_grid ? tails_.ptr : nullptr;
+    for (int w = 0; w < 4; ++w) ca.tail_len[w] = (uint32_t)(la.capacities[w] % 64);
+    bad_.reserve(1);
+    OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
+    ca.chunk_filter = chunk_filter_.ptr;
+    ca.sub_sums = sub_sums_.ptr;
+    ca.bad = bad_.ptr;
+    rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
+    if (!q_valid_) {  // earlier calls went through the sequential kernels: the running totals come back from the ring
+        launch_loudness_rebuild_q(ca, rebuild_scratch_.ptr, nullptr, stream);
+        q_valid_ = true;
+    }
+    launch_loudness_chunked(ca, transition_.ptr, stream);
+    OMX_HIP(hipGetLastError());
+    // non-finite PCM (pass A's flag): nothing above touched the state; the sequential kernel does the call instead, and
+    // the running totals are rebuilt from the ring it leaves
+    la.run_if = bad_.ptr;
+    launch_loudness(la, stream);
+    LoudChunkArgs after = ca;
+    after.frames_seen = frames_seen_ + frames;  // (ragged: the counters the sequential kernel advanced)
+    after.reset_v = nullptr;
+    launch_loudness_rebuild_q(after, rebuild_scratch_.ptr, bad_.ptr, stream);
+}
+
 int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
                           float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                           const omx_loudness_snapshot** d_snapshots) {  // :253-311
@@ -269,85 +370,13 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     LoudnessArgs la{};
     fill_args(la, d_pcm, block_frames, n_blocks, channels, positions);
     // chunk-parallel evaluation for bank-sized calls (loudness_chunked.hip): every block of the call in parallel
-    bool shape_ok = block_frames % 64 == 0 && n_blocks >= 2 && frames_seen_ % 64 == 0;
-    bool off_grid = false;  // 44.1 / 88.2 kHz: window lengths that are not multiples of 64 samples
-    for (int w = 0; w < 4; ++w) off_grid = off_grid || la.capacities[w] % 64 != 0;
+    const bool shape_ok = block_frames % 64 == 0 && n_blocks >= 2 && frames_seen_ % 64 == 0;
     const uint64_t slots = (uint64_t)n_streams_ << la.slot_shift;
     const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && slots * n_blocks >= 4096));
     timer_.begin(stream);
     last_form_ = chunked ? 2 : 1;
     if (chunked) {
-        if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
-            transition_.upload(k_weighting_transitions(b_, a_, block_frames), stream);
-            transition_rate_ = cfg_.sample_rate;
-            transition_frames_ = block_frames;
-        }
-        LoudChunkArgs ca{};
-        ca.pcm = d_pcm;
-        ca.frames_total = frames;
-        ca.block_frames = (uint32_t)block_frames;
-        ca.n_blocks = (uint32_t)n_blocks;
-        ca.n_streams = n_streams_;
-        ca.channels = channels;
-        ca.slot_shift = la.slot_shift;
-        for (int i = 0; i < 5; ++i) {
-            ca.b[i] = la.b[i];
-            ca.a[i] = la.a[i];
-        }
-        for (int i = 0; i < OMX_MAX_CHANNELS; ++i) {
-            ca.weights[i] = la.weights[i];
-            ca.positions[i] = la.positions[i];
-        }
-        std::memcpy(ca.fir4, la.fir4, sizeof(ca.fir4));
-        std::memcpy(ca.fir2, la.fir2, sizeof(ca.fir2));
-        ca.delay_len = la.delay_len;
-        for (int w = 0; w < 4; ++w) ca.capacities[w] = la.capacities[w];
-        ca.ring_len = ring_len_;
-        ca.frames_seen = frames_seen_;
-        ca.ring = ring_.ptr;
-        ca.state = state_.ptr;
-        ca.floor_db = cfg_.floor_db;
-        ca.snapshots = snapshots_.ptr;
-        chunk_filter_.reserve((size_t)(slots * n_blocks * 4));
-        sub_sums_.reserve((size_t)(slots * (frames / 64)));
-        // the running totals of every sub-block a window of this call can start in: the ring's and the call's, as a power of two
-        uint64_t q_need = 4096;
-        while (q_need < ring_len_ / 64 + frames / 64 + 2) q_need *= 2;
-        if (q_need > q_len_) {
-            q_len_ = q_need;
-            q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_));
-            OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
-            tails_.release();
-            if (frames_seen_ != 0) q_valid_ = false;  // re-indexed: the totals come back from the squared-sample ring
-        }
-        bad_.reserve(1);
-        OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
-        ca.chunk_filter = chunk_filter_.ptr;
-        ca.sub_sums = sub_sums_.ptr;
-        ca.q_ring = q_ring_.ptr;
-        ca.q_len = q_len_;
-        if (off_grid && !tails_.ptr) {
-            tails_.reserve((size_t)((uint64_t)n_streams_ * 8 * kLoudnessWindows * q_len_));
-            OMX_HIP(hipMemsetAsync(tails_.ptr, 0, tails_.count * sizeof(double), stream));
-            if (frames_seen_ != 0) q_valid_ = false;  // the tails of what is already in the ring
-        }
-        ca.tails = off_grid ? tails_.ptr : nullptr;
-        for (int w = 0; w < 4; ++w) ca.tail_len[w] = (uint32_t)(la.capacities[w] % 64);
-        ca.bad = bad_.ptr;
-        rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
-        if (!q_valid_) {  // earlier calls went through the sequential kernels: the running totals come back from the ring
-            launch_loudness_rebuild_q(ca, rebuild_scratch_.ptr, nullptr, stream);
-            q_valid_ = true;
-        }
-        launch_loudness_chunked(ca, transition_.ptr, stream);
-        OMX_HIP(hipGetLastError());
-        // non-finite PCM (pass A's flag): nothing above touched the state; the sequential kernel does the call instead, and
-        // the running totals are rebuilt from the ring it leaves
-        la.run_if = bad_.ptr;
-        launch_loudness(la, stream);
-        LoudChunkArgs after = ca;
-        after.frames_seen = frames_seen_ + frames;
-        launch_loudness_rebuild_q(after, rebuild_scratch_.ptr, bad_.ptr, stream);
+        run_chunked(la, stream);
     } else {
         launch_loudness(la, stream);
         q_valid_ = false;

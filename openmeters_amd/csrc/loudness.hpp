@@ -42,7 +42,8 @@ struct LoudnessArgs {
     uint32_t role_perm;  // TEMP           // split launch: workgroups [0, n) = K-weighting + windows, [n, 2n) = true peak
     const uint32_t* run_if;  // fallback launch of the chunk-parallel path: run only when *run_if != 0
     // ragged banks (per-stream block counts; nullptr = lock-step): stream s runs blocks_v[s] <= n_blocks blocks from its own sample
-    // counter seen_v[s] (frames_seen above is then unused), after a reset of its state when reset_v[s] != 0.  Lane-quad kernel only.
+    // counter seen_v[s] (frames_seen above is then unused), after a reset of its state when reset_v[s] != 0.  Lane-quad kernel and the
+    // chunk-parallel kernels.
     uint64_t* seen_v;
     const uint32_t* blocks_v;
     const uint8_t* reset_v;
@@ -73,6 +74,11 @@ struct LoudChunkArgs {
     double* tails;                 // [slots][windows][q_len]: sum of the last tail_len[w] samples of every sub-block; null when every
     uint32_t tail_len[kLoudnessWindows];  // tail_len[w] = capacities[w] % 64 is 0 (window starts on the sub-block grid)
     uint32_t* bad;
+    // ragged calls (nullptr = lock-step): stream s runs blocks_v[s] <= n_blocks blocks from its own counter seen_v[s] (advanced by the
+    // last kernel of the call), from a cleared state when reset_v[s] != 0
+    uint64_t* seen_v;
+    const uint32_t* blocks_v;
+    const uint8_t* reset_v;
 };
 void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T /* [6][4][4] */, hipStream_t stream);
 void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const uint32_t* only_if, hipStream_t stream);
@@ -100,6 +106,7 @@ public:
 private:
     void ensure_state(uint32_t channels, float sample_rate, hipStream_t stream);
     void clear_state(hipStream_t stream);
+    void run_chunked(LoudnessArgs& la, hipStream_t stream);
     void fill_args(LoudnessArgs& la, const float* d_pcm, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                    const uint8_t positions[OMX_MAX_CHANNELS]);
 
@@ -128,6 +135,7 @@ private:
     // ragged mode: per-stream sample counters on the device
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_seen_;
+    std::vector<uint64_t> h_seen_;  // the host's mirror of r_seen_ (the call arguments determine it)
     DeviceBuffer<uint32_t> r_blocks_;
     DeviceBuffer<uint8_t> r_mask_;
     RaggedStaging r_staging_;

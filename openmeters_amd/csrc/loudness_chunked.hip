@@ -35,6 +35,19 @@ constexpr uint32_t SUB = 64;         // samples per sub-block sum
 __device__ __forceinline__ bool slot_live(const LoudChunkArgs& a, uint32_t slot) {
     return (slot >> a.slot_shift) < a.n_streams && (slot & ((1u << a.slot_shift) - 1u)) < a.channels;
 }
+// Ragged calls (omx_loudness_bank_process_ragged; registry.rs:396-418 feeds every capture on its own): stream s runs blocks_v[s] of
+// the call's n_blocks block slots from its own sample counter seen_v[s], from a cleared state when reset_v[s] is set.  Lock-step
+// calls (blocks_v == nullptr) take the bank's common counter.  One scalar load each per kernel; the block body is the same.
+struct SlotCall {
+    uint64_t seen;
+    uint32_t blocks;
+    bool reset;
+};
+__device__ __forceinline__ SlotCall slot_call(const LoudChunkArgs& a, uint32_t s) {  // s < n_streams
+    if (!a.blocks_v) return {a.frames_seen, a.n_blocks, false};
+    const bool reset = a.reset_v && a.reset_v[s] != 0;
+    return {reset ? 0ull : a.seen_v[s], a.blocks_v[s], reset};
+}
 __device__ __forceinline__ void kbn(double& sum, double& corr, double v) {  // dsp.rs:277-285
     const double next = sum + v;
     const bool big_sum = fabs(sum) >= fabs(v);
@@ -62,14 +75,15 @@ struct Tile {
     uint32_t dst[4];
     bool live[4];
     float4 pre[4];
-    __device__ __forceinline__ void setup(const LoudChunkArgs& a, uint32_t group, uint64_t frame0, uint32_t lane) {
+    __device__ __forceinline__ void setup(const LoudChunkArgs& a, uint32_t group, uint32_t c, uint32_t lane) {
         const uint32_t C = a.channels, row_bytes = 64u * C, per_group = 64u / C;
+        const uint64_t frame0 = (uint64_t)c * a.block_frames;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const uint32_t byte = (lane + 64u * (uint32_t)n) * 16u;
             const uint32_t row = byte / row_bytes, inrow = byte % row_bytes;
             const uint64_t s = (uint64_t)group * per_group + row;
-            live[n] = s < a.n_streams;
+            live[n] = s < a.n_streams && (!a.blocks_v || c < a.blocks_v[s]);  // (a stream's unused block slots hold anything)
             src[n] = a.pcm + ((live[n] ? s : 0) * a.frames_total + frame0) * C + inrow / 4u;
             dst[n] = row * 17u * C + inrow / 4u;
         }
@@ -132,10 +146,12 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
-    const bool live = slot_live(a, chan);
+    const SlotCall sc = slot_live(a, chan) ? slot_call(a, chan >> a.slot_shift) : SlotCall{0ull, 0u, false};
+    const bool live = c < sc.blocks;
+    if (__ballot(live) == 0ull) return;  // (one wavefront per workgroup)
     Tile t;
     Direct dl;
-    if constexpr (TILED) t.setup(a, group, (uint64_t)c * L, lane);
+    if constexpr (TILED) t.setup(a, group, c, lane);
     else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
@@ -148,15 +164,15 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     }
     const double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
     double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
-    uint64_t pos = (a.frames_seen + (uint64_t)c * L) % a.ring_len;  // ring slot of the block's first sample
+    uint64_t pos = (sc.seen + (uint64_t)c * L) % a.ring_len;  // ring slot of the block's first sample
     // a call longer than the ring: only its newest ring_len samples are stored (an earlier block must not race a later one for a slot)
-    const uint64_t idx0 = (uint64_t)c * L, first_kept = a.frames_total > a.ring_len ? a.frames_total - a.ring_len : 0u;
+    const uint64_t idx0 = (uint64_t)c * L, frames_s = (uint64_t)sc.blocks * L, first_kept = frames_s > a.ring_len ? frames_s - a.ring_len : 0u;
     double* sub = a.sub_sums + ((uint64_t)chan * a.n_blocks + c) * (L / SUB);
     double ssum = 0.0, scor = 0.0;
     // window lengths off the 64-sample grid (44.1 / 88.2 kHz): the sum of the LAST cap_w % 64 samples of every sub-block, so that a
     // window starting inside sub-block g is Q[end] - (Q[g] - tail_w[g])
     double tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
-    const uint64_t g_first = a.frames_seen / SUB + (uint64_t)c * (L / SUB);
+    const uint64_t g_first = sc.seen / SUB + (uint64_t)c * (L / SUB);
     double* tails = TAILS && live ? a.tails + (uint64_t)chan * kLoudnessWindows * a.q_len : nullptr;
     uint32_t bad = 0;
     if constexpr (TILED) t.issue(0, C);
@@ -240,14 +256,19 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
     if (*a.bad != 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (!slot_live(a, chan)) return;
+    const SlotCall sc = slot_call(a, chan >> a.slot_shift);
     LoudnessChannelState& st = a.state[chan];
+    if (sc.blocks == 0u) {
+        if (sc.reset && lane == 0) st = LoudnessChannelState{};  // a reset without samples: ChannelState::default (:234-236)
+        return;
+    }
     DD carry[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) carry[k] = {st.filter[k], 0.0};
+    for (int k = 0; k < 4; ++k) carry[k] = {sc.reset ? 0.0 : st.filter[k], 0.0};
     const double* Tl = Tp + 6 * 16;
-    for (uint32_t c0 = 0; c0 < a.n_blocks; c0 += 64u) {
+    for (uint32_t c0 = 0; c0 < sc.blocks; c0 += 64u) {
         const uint32_t c = c0 + lane;
-        const bool live = c < a.n_blocks;
+        const bool live = c < sc.blocks;
         double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + (live ? c : c0)) * 4u;
         DD x[4];
 #pragma unroll
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
                 }
             }
         }
-        const uint32_t last = min(a.n_blocks - c0, 64u) - 1u;
+        const uint32_t last = min(sc.blocks - c0, 64u) - 1u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double start = shfl_up_f64(x[k].h, 1);
@@ -299,11 +320,13 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
-    const bool live = slot_live(a, chan);
     const uint32_t s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
+    const SlotCall sc = slot_live(a, chan) ? slot_call(a, s) : SlotCall{0ull, 0u, false};
+    const bool live = c < sc.blocks;
+    if (__ballot(live) == 0ull) return;
     Tile t;
     Direct dl;
-    if constexpr (TILED) t.setup(a, group, (uint64_t)c * L, lane);
+    if constexpr (TILED) t.setup(a, group, c, lane);
     else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     constexpr int H = DL > 1 ? DL - 1 : 1;
@@ -313,7 +336,7 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     if (DL > 1 && live) {
         if (c == 0) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) hist[i] = a.state[chan].delay[i];
+            for (int i = 0; i < H; ++i) hist[i] = sc.reset ? 0.0f : a.state[chan].delay[i];
         } else {
             const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)c * L) * C + ch;
 #pragma unroll
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     snap->true_peak_db[ch] = power_to_db(peak * peak, a.floor_db);
     if (ch == 0)
         for (uint32_t i = C; i < OMX_MAX_CHANNELS; ++i) snap->true_peak_db[i] = a.floor_db;  // with_floor (:197-207)
-    if (c + 1u == a.n_blocks && *a.bad == 0u) {  // (pass A, which sets the flag, ran before this kernel)
+    if (c + 1u == sc.blocks && *a.bad == 0u) {  // (pass A, which sets the flag, ran before this kernel)
         LoudnessChannelState& st = a.state[chan];
         if constexpr (DL > 1) {
 #pragma unroll
@@ -383,10 +406,11 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
     if (*a.bad != 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (!slot_live(a, chan)) return;
-    const uint64_t n_sub = (uint64_t)a.n_blocks * (a.block_frames / SUB), g0 = a.frames_seen / SUB;  // first new sub-block
+    const SlotCall sc = slot_call(a, chan >> a.slot_shift);
+    const uint64_t n_sub = (uint64_t)sc.blocks * (a.block_frames / SUB), g0 = sc.seen / SUB;  // first new sub-block
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
     double carry = g0 == 0 ? 0.0 : q[(g0 - 1u) & (a.q_len - 1u)];
-    const double* sub = a.sub_sums + (uint64_t)chan * n_sub;
+    const double* sub = a.sub_sums + (uint64_t)chan * a.n_blocks * (a.block_frames / SUB);
     for (uint64_t j0 = 0; j0 < n_sub; j0 += 64u) {
         const uint64_t j = j0 + lane;
         double x = j < n_sub ? sub[j] : 0.0;
@@ -402,53 +426,72 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
 }
 
 // ---- rebuild Q from the squared-sample ring (after calls that went through the sequential kernels): sub-block sums of the
-// newest min(frames_seen, ring_len) samples, then the same prefix.  grid (slot groups, sub-blocks), lane = slot.
-__global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, uint64_t first_sub, double* out /* [chan][n] */, uint64_t n,
-                                                              uint32_t avail, const uint32_t* only_if) {
+// newest min(seen, ring_len) samples of every slot, then the same prefix.  grid (slot groups, sub-blocks), lane = slot.
+struct RebuildSpan {
+    uint64_t first_sub, n;  // first whole sub-block in the ring, number of whole sub-blocks
+    uint32_t avail;         // samples the ring still holds of sub-block first_sub - 1 (a ring length off the 64-sample grid)
+};
+__device__ __forceinline__ RebuildSpan rebuild_span(const LoudChunkArgs& a, uint32_t s) {
+    const uint64_t seen = slot_call(a, s).seen;  // (0 for a stream about to be reset: nothing to rebuild)
+    const uint64_t have = min(seen, a.ring_len), oldest = seen - have;
+    const uint64_t first_sub = (oldest + SUB - 1u) / SUB, total = seen / SUB;
+    return {first_sub, total > first_sub ? total - first_sub : 0u, (uint32_t)(first_sub * SUB - oldest)};
+}
+__global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, double* out /* [chan][stride] */, uint64_t stride, const uint32_t* only_if) {
     if (only_if && *only_if == 0u) return;
     const uint32_t lane = threadIdx.x, group = blockIdx.x;
     const uint64_t j = blockIdx.y;
     const uint32_t chan = group * 64u + lane;
     if (!slot_live(a, chan)) return;
+    const RebuildSpan sp = rebuild_span(a, chan >> a.slot_shift);
+    // j == n: the sub-block before the first whole one; only its tails are needed (the longest window starts inside it)
+    const bool partial = j == sp.n;
+    if (j > sp.n || (partial && (sp.avail == 0u || !a.tails || sp.first_sub == 0u))) return;
     const double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
-    // y == n: the sub-block before the first whole one, of which the ring still holds the newest `avail` samples (a ring length off
-    // the 64-sample grid); only its tails are needed (the longest window starts inside it)
-    const bool partial = j == n;
-    const uint64_t g = partial ? first_sub - 1u : first_sub + j;
-    const uint32_t i0 = partial ? SUB - avail : 0u;
-    double s = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
+    const uint64_t g = partial ? sp.first_sub - 1u : sp.first_sub + j;
+    const uint32_t i0 = partial ? SUB - sp.avail : 0u;
+    double sum = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
     for (uint32_t i = i0; i < SUB; ++i) {
         const double v = ring_col[((g * SUB + i) % a.ring_len) * kRow];
-        kbn(s, c, v);
+        kbn(sum, c, v);
 #pragma unroll
         for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += a.tail_len[w] >= SUB - i ? v : 0.0;
     }
-    if (!partial) out[(uint64_t)chan * n + j] = s + c;
+    if (!partial) out[(uint64_t)chan * stride + j] = sum + c;
     if (a.tails) {
 #pragma unroll
         for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (g & (a.q_len - 1u))] = tl[w];
     }
 }
-__global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, uint64_t first_sub, const double* sub, uint64_t n,
-                                                             const uint32_t* only_if) {
+__global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, const double* sub, uint64_t stride, const uint32_t* only_if) {
     if (only_if && *only_if == 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (!slot_live(a, chan)) return;
+    const RebuildSpan sp = rebuild_span(a, chan >> a.slot_shift);
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
     double carry = 0.0;  // only differences of Q are used once the windows are full; before that first_sub == 0
-    for (uint64_t j0 = 0; j0 < n; j0 += 64u) {
+    for (uint64_t j0 = 0; j0 < sp.n; j0 += 64u) {
         const uint64_t j = j0 + lane;
-        double x = j < n ? sub[(uint64_t)chan * n + j] : 0.0;
+        double x = j < sp.n ? sub[(uint64_t)chan * stride + j] : 0.0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const double up = shfl_up_f64(x, d);
             if ((int)lane >= d) x += up;
         }
         x += carry;
-        if (j < n) q[(first_sub + j) & (a.q_len - 1u)] = x;
+        if (j < sp.n) q[(sp.first_sub + j) & (a.q_len - 1u)] = x;
         carry = shfl_f64(x, 63);
     }
-    if (first_sub > 0 && lane == 0) q[(first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+    if (sp.first_sub > 0 && lane == 0) q[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+}
+
+// ---- ragged calls: the per-stream sample counters move once every kernel above has read them
+__global__ __launch_bounds__(256) void loud_chunk_advance_kernel(LoudChunkArgs a) {
+    if (*a.bad != 0u) return;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= a.n_streams) return;
+    const SlotCall sc = slot_call(a, s);
+    if (sc.blocks != 0u || sc.reset) a.seen_v[s] = sc.seen + (uint64_t)sc.blocks * a.block_frames;
 }
 
 // ---- snapshots (loudness/processor.rs:287-310) and the write-back of the KBN pairs: thread = (stream, block)
@@ -458,11 +501,13 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
     if (i >= (uint64_t)a.n_streams * a.n_blocks) return;
     const uint32_t s = (uint32_t)(i / a.n_blocks), c = (uint32_t)(i % a.n_blocks);
     const uint32_t C = a.channels;
-    const uint64_t P = a.frames_seen + (uint64_t)(c + 1u) * a.block_frames;  // pushes at the end of this block
+    const SlotCall sc = slot_call(a, s);
+    if (c >= sc.blocks) return;
+    const uint64_t P = sc.seen + (uint64_t)(c + 1u) * a.block_frames;  // pushes at the end of this block
     const uint64_t mask = a.q_len - 1u;
     omx_loudness_snapshot* snap = a.snapshots + i;
     double short_term = 0.0, momentary = 0.0;
-    const bool last = c + 1u == a.n_blocks;
+    const bool last = c + 1u == sc.blocks;
     for (uint32_t ch = 0; ch < C; ++ch) {
         const uint32_t chan = (s << a.slot_shift) + ch;
         const double* q = a.q_ring + (uint64_t)chan * a.q_len;
@@ -511,17 +556,15 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
     }
 }
 
-// a.frames_seen = the sample counter the ring content corresponds to; only_if: run only when *only_if != 0 (after a fallback)
+// a.frames_seen / a.seen_v = the sample counters the ring content corresponds to; only_if: run only when *only_if != 0 (after a
+// fallback).  scratch: [slots][ring_len / 64 + 1]
 void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const uint32_t* only_if, hipStream_t stream) {
-    const uint64_t have = std::min<uint64_t>(a.frames_seen, a.ring_len), oldest = a.frames_seen - have;
-    const uint64_t first_sub = (oldest + SUB - 1u) / SUB;  // first whole sub-block in the ring
-    if (a.frames_seen / SUB <= first_sub) return;
-    const uint64_t n = a.frames_seen / SUB - first_sub;
-    const uint32_t avail = (uint32_t)(first_sub * SUB - oldest);  // samples left of sub-block first_sub - 1
+    const uint64_t stride = a.ring_len / SUB + 1u;
     const uint32_t slots = a.n_streams << a.slot_shift, groups = (slots + 63u) / 64u;
-    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)n + (avail && a.tails ? 1u : 0u)), dim3(64), 0, stream, a, first_sub, scratch, n,
-                       avail, only_if);
-    hipLaunchKernelGGL(loud_rebuild_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, first_sub, scratch, n, only_if);
+    if (!a.blocks_v && a.frames_seen < SUB) return;
+    const uint64_t rows = a.blocks_v ? stride + 1u : std::min<uint64_t>(a.frames_seen / SUB, stride) + 1u;
+    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)rows), dim3(64), 0, stream, a, scratch, stride, only_if);
+    hipLaunchKernelGGL(loud_rebuild_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, scratch, stride, only_if);
 }
 
 void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStream_t stream) {
@@ -550,6 +593,7 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
     hipLaunchKernelGGL(loud_scan_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a);
     const uint64_t snaps = (uint64_t)a.n_streams * a.n_blocks;
     hipLaunchKernelGGL(loud_chunk_snapshot_kernel, dim3((uint32_t)((snaps + 255u) / 256u)), dim3(256), 0, stream, a);
+    if (a.blocks_v) hipLaunchKernelGGL(loud_chunk_advance_kernel, dim3((a.n_streams + 255u) / 256u), dim3(256), 0, stream, a);
 }
 
 }  // namespace omx

@@ -236,9 +236,15 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
     sa.correlations = correlations_.ptr;
     // chunk-parallel evaluation for bank-sized calls (stereometer_chunked.hip); everything else — single-stream handles, short
     // calls, other channel counts — stays on the sequential kernels, whose results are bit-identical to the reference's order
-    const bool shape_ok = !ragged && channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
-    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && (uint64_t)n_streams_ * n_blocks >= 512));
-    if (chunked) {
+    const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
+    uint64_t items_live = (uint64_t)n_streams_ * n_blocks;
+    if (ragged) {
+        items_live = 0;
+        for (uint32_t s = 0; s < n_streams_; ++s) items_live += ragged->n_blocks[s];
+    }
+    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && items_live >= 512));
+    last_form_ = chunked ? 2 : 1;
+    auto run_chunked = [&]() {  // (after the plan kernel in a ragged call: the per-stream history positions are its output)
         if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
             transition_.upload(band_transitions(lp_lo, hp_lo, lp_hi, hp_hi, block_frames), stream);
             transition_rate_ = cfg_.sample_rate;
@@ -276,13 +282,17 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         ca.chunk_state = chunk_state_.ptr;
         ca.chunk_moments = chunk_moments_.ptr;
         ca.bad = bad_.ptr;
+        ca.blocks_v = sa.blocks_v;
+        ca.reset_v = sa.reset_v;
+        ca.start_v = sa.start_v;
         launch_stereometer_chunked(ca, transition_.ptr, std::pow(1.0 - alpha_, (double)block_frames), stream);
         OMX_HIP(hipGetLastError());
         // non-finite input / output breaks the linearity the chunks rely on (Biquad::process resets, dsp.rs:428-431): the
         // sequential kernel then redoes the whole call from the saved state (it exits at once when the flag is clear)
         sa.run_if = bad_.ptr;
         sa.state_in = state_backup_.ptr;
-    }
+    };
+    if (chunked && !ragged) run_chunked();
     if (ragged) {
         if (!ragged_) {  // every stream starts from the bank's common positions and lengths
             std::vector<uint64_t> pos((size_t)n_streams_ * 4), len((size_t)n_streams_ * 4);
@@ -324,6 +334,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         sa.reset_v = r_mask_.ptr;
         sa.start_v = r_start_.ptr;
         OMX_HIP(hipMemsetAsync(correlations_.ptr, 0, (size_t)(n_streams_ * n_blocks * 4) * sizeof(float), stream));  // slots past a stream's own blocks
+        if (chunked) run_chunked();
         launch_stereometer(sa, stream);
         OMX_HIP(hipGetLastError());
         const uint32_t target = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cfg_.target_sample_count, 1), frames);  // :152

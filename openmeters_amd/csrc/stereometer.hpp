@@ -76,6 +76,11 @@ struct StereoChunkArgs {
     float* chunk_state;      // [n_streams * n_blocks][3 bands][8 states][2 channels]
     double* chunk_moments;   // [n_streams * n_blocks][4 bands][3]
     uint32_t* bad;           // set when a non-finite sample or filter output was seen: the caller re-runs the sequential kernel
+    // ragged calls (nullptr = lock-step): stream s runs blocks_v[s] <= n_blocks blocks, after a reset of its state when reset_v[s] != 0;
+    // start_v[s * 4 + band] = the history position of its first frame (the plan kernel's output; hist_pos above is then unused)
+    const uint32_t* blocks_v;
+    const uint8_t* reset_v;
+    const uint64_t* start_v;
 };
 // d_T: [3][6][8][8] f64, the L-frame zero-input transition of the low / mid / high cascades and its powers 2 ... 32; decay = (1 - alpha)^L
 void launch_stereometer_chunked(const StereoChunkArgs& a, const double* d_T, double decay, hipStream_t stream);
@@ -152,9 +157,11 @@ private:
     RaggedStaging r_staging_;
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
+    int last_form_ = 0;      // 1 = sequential kernels, 2 = chunk-parallel (omx_debug_stereometer_bank_last_form)
     int chunked_mode_ = -1;  // -1 = choose by shape, 0 = never, 1 = whenever the shape allows (OMX_OPT_KERNEL_FORM)
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
+    int last_form() const { return last_form_; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: correlations / points in pinned host memory
 private:
     hipStream_t last_stream_ = nullptr;

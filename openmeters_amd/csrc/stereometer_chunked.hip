@@ -67,6 +67,7 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
         const uint64_t item = item0 + row;
         live[n] = q < 512u && item < items;
         const uint64_t s = live[n] ? item / a.n_blocks : 0, c = live[n] ? item % a.n_blocks : 0;
+        live[n] = live[n] && (!a.blocks_v || c < a.blocks_v[s]);  // ragged calls: a stream's unused block slots hold anything
         src[n] = a.pcm + (s * a.frames_total + c * L) * 2u + part * 4u;
         dst[n] = row * ROW_FLOATS + part * 4u;
     }
@@ -93,9 +94,14 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     };
 
     // ---- per-lane recurrence state
+    // ragged calls (omx_stereometer_bank_process_ragged): stream s runs blocks_v[s] of the call's n_blocks block slots; its history
+    // positions come from the plan kernel (start_v), its reset flag acts in the scans
     const uint64_t item = item0 + lane;
-    const bool mine = item < items;
-    const uint64_t s = mine ? item / a.n_blocks : 0, c = mine ? item % a.n_blocks : 0;
+    const bool in_call = item < items;
+    const uint64_t s = in_call ? item / a.n_blocks : 0, c = in_call ? item % a.n_blocks : 0;
+    const uint32_t blocks_s = in_call ? (a.blocks_v ? a.blocks_v[s] : a.n_blocks) : 0u;
+    const bool mine = c < blocks_s;
+    if (__ballot(mine) == 0ull) return;  // (the three wavefronts of the workgroup see the same 64 items)
     const bool bands = a.analyze_bands != 0;
     const BiquadCoef ca = role == 0 ? a.lp_lo : a.hp_lo, cb = role == 1 ? a.lp_hi : a.hp_hi;
     v2f z0[4], z1[4];  // role 0 uses elements 0, 1 (LP_low); roles 1, 2: 0, 1 = HP_low, 2, 3 = LP_high / HP_high
@@ -114,13 +120,15 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     Moments full, band;
     const double alpha = a.alpha;
     // history: the newest hist_frames pairs of the call (absolute position hist_pos + frame index, modulo the ring)
-    const uint64_t total = (uint64_t)a.n_blocks * L;
+    const uint64_t total = (uint64_t)blocks_s * L;
     const uint64_t tail_from = total > a.hist_frames ? total - a.hist_frames : 0;
     const uint32_t band_id = role + 1u;
     float* hist_band = a.history + ((s * 4u + band_id) * (uint64_t)a.hist_frames) * 2u;
     float* hist_full = a.history + ((s * 4u) * (uint64_t)a.hist_frames) * 2u;
     const bool chunk_in_tail = PASS_B && mine && (c + 1u) * (uint64_t)L > tail_from;
     const bool wave_in_tail = __ballot(chunk_in_tail) != 0ull;
+    const uint64_t pos_full = a.start_v ? a.start_v[s * 4u] : a.hist_pos[0];
+    const uint64_t pos_band = a.start_v ? a.start_v[s * 4u + band_id] : a.hist_pos[band_id];
 
     issue(0);
     for (uint32_t step = 0; step < steps; ++step) {
@@ -155,11 +163,11 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
                 const uint64_t g = c * (uint64_t)L + step * STEP + (uint32_t)f;
                 if (chunk_in_tail && g >= tail_from) {
                     if (role == 0) {
-                        const uint64_t slot = (a.hist_pos[0] + g) % a.hist_frames;
+                        const uint64_t slot = (pos_full + g) % a.hist_frames;
                         *reinterpret_cast<v2f*>(hist_full + slot * 2u) = x[f];
                     }
                     if (bands && a.emit_band_points) {
-                        const uint64_t slot = (a.hist_pos[band_id] + g) % a.hist_frames;
+                        const uint64_t slot = (pos_band + g) % a.hist_frames;
                         *reinterpret_cast<v2f*>(hist_band + slot * 2u) = y[f];
                     }
                 }
@@ -212,12 +220,14 @@ template <int N>
 __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const double* __restrict__ Tp /* [6][8][8] powers 1,2,..32 */,
                                                  uint32_t s, uint32_t r, uint32_t ch, uint32_t lane) {
     StereoLaneState& st = a.state[(uint64_t)s * 4u + r + 1u];
+    const uint32_t nb = a.blocks_v ? a.blocks_v[s] : a.n_blocks;
+    const bool reset = a.reset_v != nullptr && a.reset_v[s] != 0;  // reset_audio (:92-97) of this stream before its blocks
     double carry[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) carry[k] = (double)st.z[k >> 2][(k >> 1) & 1][ch][k & 1];  // [stage][element][channel][z0 / z1]
-    for (uint32_t c0 = 0; c0 < a.n_blocks; c0 += 64u) {
+    for (int k = 0; k < N; ++k) carry[k] = reset ? 0.0 : (double)st.z[k >> 2][(k >> 1) & 1][ch][k & 1];  // [stage][element][channel][z0 / z1]
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64u) {
         const uint32_t c = c0 + lane;
-        const bool live = c < a.n_blocks;
+        const bool live = c < nb;
         float* cs = a.chunk_state + (((uint64_t)s * a.n_blocks + (live ? c : c0)) * 3u + r) * 16u;
         double x[N];
 #pragma unroll
@@ -249,7 +259,7 @@ __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const
             }
         }
         // x = state AFTER block c; the start state of block c is lane c - 1's (the carry for the first lane)
-        const uint32_t last = min(a.n_blocks - c0, 64u) - 1u;
+        const uint32_t last = min(nb - c0, 64u) - 1u;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             double start = shfl_up_f64(x[k], 1);
@@ -260,7 +270,7 @@ __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const
             carry[k] = fabsf(e) < 1.0e-20f ? 0.0 : (double)e;            // the filters carry f32 states
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && (nb != 0u || reset)) {
 #pragma unroll
         for (int k = 0; k < N; ++k) st.z[k >> 2][(k >> 1) & 1][ch][k & 1] = (float)carry[k];
     }
@@ -280,14 +290,16 @@ __global__ __launch_bounds__(256) void stereo_scan_moments_kernel(StereoChunkArg
     const uint32_t s = w >> 2, b = w & 3u;
     const bool active = b == 0 || a.analyze_bands != 0;
     StereoLaneState& st = a.state[(uint64_t)s * 4u + b];
-    double carry[3] = {st.moments[0], st.moments[1], st.moments[2]};
+    const uint32_t nb = a.blocks_v ? a.blocks_v[s] : a.n_blocks;
+    const bool reset = a.reset_v != nullptr && a.reset_v[s] != 0;
+    double carry[3] = {reset ? 0.0 : st.moments[0], reset ? 0.0 : st.moments[1], reset ? 0.0 : st.moments[2]};
     double dp[6];  // decay^(2^k)
     dp[0] = decay;
 #pragma unroll
     for (int k = 1; k < 6; ++k) dp[k] = dp[k - 1] * dp[k - 1];
-    for (uint32_t c0 = 0; c0 < a.n_blocks; c0 += 64u) {
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64u) {
         const uint32_t c = c0 + lane;
-        const bool live = c < a.n_blocks;
+        const bool live = c < nb;
         float value = 0.0f;
         if (active) {
             const double* cm = a.chunk_moments + ((uint64_t)s * a.n_blocks + (live ? c : c0)) * 12u + 3u * b;
@@ -315,13 +327,13 @@ __global__ __launch_bounds__(256) void stereo_scan_moments_kernel(StereoChunkArg
                 const double v = x[0] / denom;
                 if (isfinite(v)) value = (float)fmin(fmax(v, -1.0), 1.0);
             }
-            const uint32_t last = min(a.n_blocks - c0, 64u) - 1u;
+            const uint32_t last = min(nb - c0, 64u) - 1u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) carry[k] = shfl_f64(x[k], (int)last);
         }
         if (live) a.correlations[((uint64_t)s * a.n_blocks + c) * 4u + b] = value;
     }
-    if (lane == 0) {
+    if (lane == 0 && (nb != 0u || reset)) {
         st.moments[0] = carry[0];
         st.moments[1] = carry[1];
         st.moments[2] = carry[2];

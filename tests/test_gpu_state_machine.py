@@ -8,7 +8,7 @@ from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
                                  SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
                                  WaveformProcessor)
-from parity import bar, check_classic, classic_column_metrics, reassigned_column_metrics
+from parity import bar, check_chunked_rho, check_classic, classic_column_metrics, reassigned_column_metrics, stereometer_band_rms
 from test_gpu_parity import check_trace
 
 pytestmark = pytest.mark.gpu
@@ -482,6 +482,63 @@ def _dev(torch, ptr, shape, typestr="<u4"):
     return torch.as_tensor(V(), device="cuda:0")
 
 
+@pytest.mark.parametrize("seed,C,rate,block", [(1, 2, 48000.0, 256), (2, 6, 44100.0, 128), (3, 8, 48000.0, 64), (4, 3, 96000.0, 512)])
+def test_ragged_loudness_bank_chunk_parallel_form_matches_per_stream_oracles(omx, oracle, seed, C, rate, block):
+    """The ragged call on the chunk-parallel kernels (loudness_chunked.hip: per-stream counter, block count and reset flag inside
+    every kernel): random per-stream block counts and resets, long enough that the 0.4 s window of most streams is full and sliding;
+    some calls are pinned to the sequential kernels, so the two forms hand the per-stream state (and the running totals rebuilt from
+    every stream's own ring position) back and forth.  Every stream against its own LoudnessProcessor."""
+    import torch
+    from test_gpu_parity_meters import snapshots_close
+    rng = np.random.default_rng(900 + seed)
+    S, calls, max_blocks = 6, 12, int(0.12 * rate) // block + 2
+    positions = capi.SURROUND if C == 8 else capi.positions_fallback(C)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(sample_rate=rate), S, C)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig(sample_rate=rate)) for _ in range(S)]
+    total = block * (8 + calls * max_blocks)
+    feeds = []
+    for s in range(S):
+        t = np.arange(total) / rate
+        x = np.stack([(0.1 + 0.1 * c) * np.sin(2 * np.pi * (200.0 + 170.0 * s + 31.0 * c) * t) for c in range(C)], 1)
+        x += 0.01 * rng.standard_normal(x.shape)
+        feeds.append(x.astype(np.float32))
+    at = [0] * S
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    chunk = np.stack([f[:8 * block] for f in feeds])                 # a lock-step call first: the common counter carries over
+    assert bank.process_host(chunk, block, C, rate, positions) is not None and bank.last_form() == 2
+    for s in range(S):
+        for k in range(8):
+            w = refs[s].process_block(AudioBlock(chunk[s, k * block:(k + 1) * block].reshape(-1), C, rate, positions))
+        snapshots_close(bank.fetch(s, 7), w)
+        at[s] = 8 * block
+    compared = 0
+    for call in range(calls):
+        form = 1 if call in (4, 9) else 2
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        nb = rng.integers(max_blocks // 2, max_blocks + 1, S)
+        nb[rng.integers(0, S)] = 0                                   # someone always sits a call out
+        nb[rng.integers(0, S)] = 1
+        mask = (rng.random(S) < 0.12).astype(np.uint8)
+        pcm = np.full((S, max_blocks * block, C), np.nan, np.float32)   # unused block slots hold anything
+        for s in range(S):
+            pcm[s, :nb[s] * block] = feeds[s][at[s]:at[s] + nb[s] * block]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), block, max_blocks, nb, C, rate, positions, mask)
+        torch.cuda.synchronize()
+        assert bank.last_form() == form
+        assert int(up.max_blocks) == max_blocks and np.array_equal(_dev(torch, up.d_n_blocks, (S,)).cpu().numpy(), nb)
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            for k in range(int(nb[s])):
+                w = refs[s].process_block(AudioBlock(pcm[s, k * block:(k + 1) * block].reshape(-1), C, rate, positions))
+                if k in (0, int(nb[s]) - 1) or rng.random() < 0.2:
+                    snapshots_close(bank.fetch(s, k), w)
+                    compared += 1
+            at[s] += int(nb[s]) * block
+    assert compared > 100
+
+
 @pytest.mark.parametrize("seed,C,rate,block", [(1, 2, 48000.0, 256), (2, 8, 48000.0, 256), (3, 6, 96000.0, 100), (4, 1, 44100.0, 37), (5, 3, 192000.0, 64)])
 def test_ragged_loudness_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, rate, block):
     """Per-stream independence of the loudness bank: every stream gets its own random block counts and its own reset_audio()
@@ -633,12 +690,14 @@ def test_ragged_oscilloscope_bank_random_per_stream_block_counts_match_per_strea
     bank.process_host(chunk, block, 2, 48000.0)
 
 
-@pytest.mark.parametrize("seed,C,bands,points", [(1, 2, True, True), (2, 2, True, False), (3, 2, False, False), (4, 6, True, True)])
-def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, bands, points):
+@pytest.mark.parametrize("seed,C,bands,points,form", [(1, 2, True, True, 0), (2, 2, True, False, 0), (3, 2, False, False, 0), (4, 6, True, True, 0),
+                                                      (5, 2, True, True, 2), (6, 2, True, False, 2), (7, 2, False, False, 2)])
+def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, bands, points, form):
     """Per-stream independence of the stereometer bank: every stream gets its own random block counts and its own reset_audio()
     calls; stream s must behave like a single StereometerProcessor fed the same blocks — `produced` per block (the history deque
     fills per stream), correlations at the 1e-6 bar, the points of the stream's last block bit-exact (per-stream ring positions),
-    filters / correlators carried per stream and cleared by the stream's own reset only.  Two lock-step calls first."""
+    filters / correlators carried per stream and cleared by the stream's own reset only.  Two lock-step calls first.
+    form 2 pins the chunk-parallel kernels (stereometer_chunked.hip with per-stream block counts, reset flags and history positions)."""
     import torch
     from openmeters_amd.capi import StereometerConfig, StereometerProcessor
     rng = np.random.default_rng(700 + seed)
@@ -646,6 +705,7 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
     cfg = StereometerConfig(analyze_bands=bands, emit_band_points=points, correlation_window=0.05, segment_duration=0.02, target_sample_count=300)
     pos = capi.SURROUND[:C] + [0] * (8 - C) if C != 2 else capi.positions_fallback(2)
     bank = banks.StereometerBank(omx, cfg, S)
+    bank.set_option(capi.OPT_KERNEL_FORM, form)
     refs = [StereometerProcessor(oracle, cfg) for _ in range(S)]
     total = block * (2 * 3 + calls * max_blocks)
     feeds = []
@@ -655,12 +715,16 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
         x = np.stack([base * (1.0 - 0.1 * c) * (-1.0 if c % 2 else 1.0) + 0.01 * rng.standard_normal(total) for c in range(C)], 1)
         feeds.append(x.astype(np.float32))
     at = [0] * S
+    band_rms = [stereometer_band_rms(f[:, :2]) for f in feeds] if C == 2 else None
 
     def check(s, k, w, last_in_call):
         corr, produced = bank.fetch(s, k)
         assert produced == (w is not None), (s, k)
         if w is not None:
-            bar("stereometer (ragged bank): |d rho|", np.abs(corr - w.correlations).max(), 1e-6)
+            if form == 2:   # a second evaluation order of the f32 band filters: the bars of the lock-step chunk-parallel test
+                check_chunked_rho(corr, w.correlations, band_rms[s], (s, k))
+            else:
+                bar("stereometer (ragged bank): |d rho|", np.abs(corr - w.correlations).max(), 1e-6)
             if last_in_call:
                 for b in range(4):
                     got = bank.fetch_points(s, b)
@@ -668,6 +732,8 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
                     assert got.shape == np.asarray(want).reshape(-1, 2).shape, (s, k, b, got.shape)
                     if b == 0:
                         assert np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).reshape(-1, 2).view(np.uint32)), (s, k, b)
+                    elif got.size and form == 2:
+                        bar("stereometer (chunk-parallel): |d point| vs oracle", np.abs(got - np.asarray(want).reshape(-1, 2)).max(), 1e-4)
                     elif got.size:
                         bar("stereometer (ragged bank): |d band point|", np.abs(got - np.asarray(want).reshape(-1, 2)).max(), 1e-6)
 
@@ -683,12 +749,14 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
         nb = rng.integers(0, max_blocks + 1, S)
         nb[rng.integers(0, S)] = 0
         mask = (rng.random(S) < 0.15).astype(np.uint8)
-        pcm = np.zeros((S, max_blocks * block, C), np.float32)
+        pcm = np.full((S, max_blocks * block, C), np.nan if form == 2 else 0.0, np.float32)   # unused block slots hold anything
         for s in range(S):
             pcm[s, :nb[s] * block] = feeds[s][at[s]:at[s] + nb[s] * block]
         d_pcm = torch.from_numpy(pcm).to("cuda:0")
         up = bank.process_ragged(d_pcm.data_ptr(), block, max_blocks, nb, C, 48000.0, pos, mask)
         torch.cuda.synchronize()
+        if int(nb.max()) > 0 or mask.any():
+            assert bank.last_form() == (2 if form == 2 else 1)
         for s in range(S):
             if mask[s]:
                 refs[s].reset_audio()
