@@ -34,8 +34,8 @@ struct WaveformArgs {
     omx_wave_column* columns;  // [n_streams][n_emit - first_kept][4]
     omx_wave_column* preview;  // [n_streams][4]
     uint32_t write_preview;
-    // ragged banks (per-stream frame counts; nullptr = lock-step; the one-wavefront kernel only, ONE stream per workgroup so that the
-    // values below stay workgroup-uniform): stream s receives frames_v[s] <= frames frames (`frames` is then the row stride of pcm),
+    // ragged banks (per-stream frame counts; nullptr = lock-step; the role-per-wavefront kernel carries them per lane, the one-wavefront
+    // kernel runs ONE stream per workgroup so that they stay workgroup-uniform): stream s receives frames_v[s] <= frames frames (`frames` is then the row stride of pcm),
     // continues from its own tracker push count / column phase, after a reset of its own when reset_v[s] != 0; columns go to
     // columns[s][max_cols][4], their count to cols_v[s], the preview progress to progress_v[s]
     const uint32_t* frames_v;

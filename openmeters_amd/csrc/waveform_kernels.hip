@@ -5,7 +5,7 @@
 // band (identical inputs -> bit-identical outputs across the four channel lanes) and forms its channel's value,
 // so the Mid/Side trackers need no cross-lane traffic.  Built with -ffp-contract=off.
 // This one-wavefront form serves what the role-per-wavefront kernel (waveform_roles_kernels.hip) does not: band analysis off, windows
-// shorter than 32 samples, >= 2048 streams without RMS history, and ragged banks.  It is paced by one wavefront's instruction issue
+// shorter than 32 samples and >= 2048 streams without RMS history (ragged banks: one stream per workgroup here).  It is paced by one wavefront's instruction issue
 // (a dependent VALU instruction every 9 - 10 cycles) and by one memory wait per batch: the next batch's loads ARE issued a batch
 // ahead, but the compiler still places an `s_waitcnt vmcnt(0)` right after them (measured: 150 us per 256-frame block with or
 // without the prefetch) — which is what the role kernel's memory wavefront removes.
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
 void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
     if (a.n_streams == 0) return;
     static const bool pin_single = std::getenv("OMX_WAVEFORM_SINGLE") != nullptr;
-    if (!pin_single && !a.frames_v && waveform_roles_applicable(a)) {
+    static const bool ragged_single = std::getenv("OMX_WAVEFORM_RAGGED_SINGLE") != nullptr;  // A/B: ragged calls on the one-wavefront kernel
+    if (!pin_single && !(a.frames_v && (ragged_single || a.frames > 0xFFFFFFFFull)) && waveform_roles_applicable(a)) {
         launch_waveform_roles(a, stream);
         return;
     }
