@@ -331,6 +331,7 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
     ca.chunk_filter = chunk_filter_.ptr;
     ca.sub_sums = sub_sums_.ptr;
     ca.bad = bad_.ptr;
+    ca.scan_dd = cfg_.sample_rate > 100000.0f ? 1u : 0u;
     rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
     if (!q_valid_) {  // earlier calls went through the sequential kernels: the running totals come back from the ring
         launch_loudness_rebuild_q(ca, rebuild_scratch_.ptr, nullptr, stream);

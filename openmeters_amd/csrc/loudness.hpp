@@ -74,6 +74,7 @@ struct LoudChunkArgs {
     double* tails;                 // [slots][windows][q_len]: sum of the last tail_len[w] samples of every sub-block; null when every
     uint32_t tail_len[kLoudnessWindows];  // tail_len[w] = capacities[w] % 64 is 0 (window starts on the sub-block grid)
     uint32_t* bad;
+    uint32_t scan_dd;              // block scan of the K-weighting states in double-double arithmetic (rates above 96 kHz)
     // ragged calls (nullptr = lock-step): stream s runs blocks_v[s] <= n_blocks blocks from its own counter seen_v[s] (advanced by the
     // last kernel of the call), from a cleared state when reset_v[s] != 0
     uint64_t* seen_v;

@@ -43,8 +43,9 @@ struct SlotCall {
     uint32_t blocks;
     bool reset;
 };
+template <bool RAGGED = true>
 __device__ __forceinline__ SlotCall slot_call(const LoudChunkArgs& a, uint32_t s) {  // s < n_streams
-    if (!a.blocks_v) return {a.frames_seen, a.n_blocks, false};
+    if (!RAGGED || !a.blocks_v) return {a.frames_seen, a.n_blocks, false};  // (RAGGED = false: wave-uniform values, scalar registers)
     const bool reset = a.reset_v && a.reset_v[s] != 0;
     return {reset ? 0ull : a.seen_v[s], a.blocks_v[s], reset};
 }
@@ -75,6 +76,7 @@ struct Tile {
     uint32_t dst[4];
     bool live[4];
     float4 pre[4];
+    template <bool RAGGED>
     __device__ __forceinline__ void setup(const LoudChunkArgs& a, uint32_t group, uint32_t c, uint32_t lane) {
         const uint32_t C = a.channels, row_bytes = 64u * C, per_group = 64u / C;
         const uint64_t frame0 = (uint64_t)c * a.block_frames;
@@ -83,7 +85,8 @@ struct Tile {
             const uint32_t byte = (lane + 64u * (uint32_t)n) * 16u;
             const uint32_t row = byte / row_bytes, inrow = byte % row_bytes;
             const uint64_t s = (uint64_t)group * per_group + row;
-            live[n] = s < a.n_streams && (!a.blocks_v || c < a.blocks_v[s]);  // (a stream's unused block slots hold anything)
+            live[n] = s < a.n_streams;
+            if constexpr (RAGGED) live[n] = live[n] && c < a.blocks_v[s];  // (a stream's unused block slots hold anything)
             src[n] = a.pcm + ((live[n] ? s : 0) * a.frames_total + frame0) * C + inrow / 4u;
             dst[n] = row * 17u * C + inrow / 4u;
         }
@@ -139,19 +142,23 @@ struct Direct {
 
 // ---- K-weighting: PASS 0 = zero-state end state of the block; PASS 1 = from the true start state: squared samples -> ring,
 // sub-block sums.  grid (slot groups, blocks), 64 threads: lane = slot of the group.
-template <int PASS, bool TILED, bool TAILS>
+template <int PASS, bool TILED, bool TAILS, bool RAGGED>
 __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) {
     __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     if (PASS == 1 && *a.bad != 0u) return;
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
-    const SlotCall sc = slot_live(a, chan) ? slot_call(a, chan >> a.slot_shift) : SlotCall{0ull, 0u, false};
-    const bool live = c < sc.blocks;
-    if (__ballot(live) == 0ull) return;  // (one wavefront per workgroup)
+    SlotCall sc = slot_call<false>(a, 0);
+    bool live = slot_live(a, chan);
+    if constexpr (RAGGED) {
+        sc = live ? slot_call(a, chan >> a.slot_shift) : SlotCall{0ull, 0u, false};
+        live = c < sc.blocks;
+        if (__ballot(live) == 0ull) return;  // (one wavefront per workgroup)
+    }
     Tile t;
     Direct dl;
-    if constexpr (TILED) t.setup(a, group, c, lane);
+    if constexpr (TILED) t.template setup<RAGGED>(a, group, c, lane);
     else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
@@ -252,6 +259,9 @@ __device__ __forceinline__ DD dd_madd(DD acc, double th, double tl, DD u) {  // 
     const double h = s + e;
     return {h, e - (h - s)};
 }
+// USE_DD = false (rates up to 96 kHz): the same scan in plain f64 on the high parts — there the products cancel to ~1e-3 of their size
+// and the f64 scan is 5e-6 dB or better (measured through the 1e-4 dB bar at 44.1 / 48 / 96 kHz); three times cheaper.
+template <bool USE_DD>
 __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, const double* __restrict__ Tp /* [2][6][4][4] */) {
     if (*a.bad != 0u) return;
     const uint32_t chan = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -277,7 +287,10 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) x[k] = dd_madd(x[k], Tp[k * 4 + m], Tl[k * 4 + m], carry[m]);
+                for (int m = 0; m < 4; ++m) {
+                    if constexpr (USE_DD) x[k] = dd_madd(x[k], Tp[k * 4 + m], Tl[k * 4 + m], carry[m]);
+                    else x[k].h += Tp[k * 4 + m] * carry[m].h;
+                }
             }
         }
 #pragma unroll
@@ -286,12 +299,15 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
             const double *Th = Tp + step * 16, *Tw = Tl + step * 16;
             DD up[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) up[k] = {shfl_up_f64(x[k].h, d), shfl_up_f64(x[k].l, d)};
+            for (int k = 0; k < 4; ++k) up[k] = {shfl_up_f64(x[k].h, d), USE_DD ? shfl_up_f64(x[k].l, d) : 0.0};
             if ((int)lane >= d) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) x[k] = dd_madd(x[k], Th[k * 4 + m], Tw[k * 4 + m], up[m]);
+                    for (int m = 0; m < 4; ++m) {
+                        if constexpr (USE_DD) x[k] = dd_madd(x[k], Th[k * 4 + m], Tw[k * 4 + m], up[m]);
+                        else x[k].h += Th[k * 4 + m] * up[m].h;
+                    }
                 }
             }
         }
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
             double start = shfl_up_f64(x[k].h, 1);
             if (lane == 0) start = carry[k].h;
             if (live) cf[k] = fabs(start) < 1.0e-30 ? 0.0 : start;  // denormal flush once per block (:281-285)
-            const double eh = shfl_f64(x[k].h, (int)last), el = shfl_f64(x[k].l, (int)last);
+            const double eh = shfl_f64(x[k].h, (int)last), el = USE_DD ? shfl_f64(x[k].l, (int)last) : 0.0;
             carry[k] = fabs(eh) < 1.0e-30 ? DD{0.0, 0.0} : DD{eh, el};
         }
     }
@@ -314,19 +330,23 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
 // ---- true peak of every block (TruePeakMeter::process, :123-151): grid (slot groups, blocks), lane = slot.  Bit-identical to
 // the sequential kernels: same samples, same tap order; the DL - 1 samples before the block come from the PCM of the call or,
 // for its first block, from the carried delay line.
-template <int DL, bool TILED>
+template <int DL, bool TILED, bool RAGGED>
 __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
     const uint32_t C = a.channels, L = a.block_frames, steps = L / STEP;
     const uint32_t chan = group * 64u + lane;
     const uint32_t s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
-    const SlotCall sc = slot_live(a, chan) ? slot_call(a, s) : SlotCall{0ull, 0u, false};
-    const bool live = c < sc.blocks;
-    if (__ballot(live) == 0ull) return;
+    SlotCall sc = slot_call<false>(a, 0);
+    bool live = slot_live(a, chan);
+    if constexpr (RAGGED) {
+        sc = live ? slot_call(a, s) : SlotCall{0ull, 0u, false};
+        live = c < sc.blocks;
+        if (__ballot(live) == 0ull) return;
+    }
     Tile t;
     Direct dl;
-    if constexpr (TILED) t.setup(a, group, c, lane);
+    if constexpr (TILED) t.template setup<RAGGED>(a, group, c, lane);
     else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
     constexpr int H = DL > 1 ? DL - 1 : 1;
@@ -427,6 +447,7 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
 
 // ---- rebuild Q from the squared-sample ring (after calls that went through the sequential kernels): sub-block sums of the
 // newest min(seen, ring_len) samples of every slot, then the same prefix.  grid (slot groups, sub-blocks), lane = slot.
+constexpr uint32_t kRebuildRows = 16;  // sub-blocks per workgroup of loud_rebuild_sub_kernel
 struct RebuildSpan {
     uint64_t first_sub, n;  // first whole sub-block in the ring, number of whole sub-blocks
     uint32_t avail;         // samples the ring still holds of sub-block first_sub - 1 (a ring length off the 64-sample grid)
@@ -438,29 +459,30 @@ __device__ __forceinline__ RebuildSpan rebuild_span(const LoudChunkArgs& a, uint
     return {first_sub, total > first_sub ? total - first_sub : 0u, (uint32_t)(first_sub * SUB - oldest)};
 }
 __global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, double* out /* [chan][stride] */, uint64_t stride, const uint32_t* only_if) {
-    if (only_if && *only_if == 0u) return;
+    if (only_if && *only_if == 0u) return;  // (the launch after every chunk-parallel call: kRebuildRows rows per workgroup keep it cheap)
     const uint32_t lane = threadIdx.x, group = blockIdx.x;
-    const uint64_t j = blockIdx.y;
     const uint32_t chan = group * 64u + lane;
     if (!slot_live(a, chan)) return;
     const RebuildSpan sp = rebuild_span(a, chan >> a.slot_shift);
-    // j == n: the sub-block before the first whole one; only its tails are needed (the longest window starts inside it)
-    const bool partial = j == sp.n;
-    if (j > sp.n || (partial && (sp.avail == 0u || !a.tails || sp.first_sub == 0u))) return;
     const double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
-    const uint64_t g = partial ? sp.first_sub - 1u : sp.first_sub + j;
-    const uint32_t i0 = partial ? SUB - sp.avail : 0u;
-    double sum = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
-    for (uint32_t i = i0; i < SUB; ++i) {
-        const double v = ring_col[((g * SUB + i) % a.ring_len) * kRow];
-        kbn(sum, c, v);
+    for (uint64_t j = (uint64_t)blockIdx.y * kRebuildRows; j < ((uint64_t)blockIdx.y + 1u) * kRebuildRows; ++j) {
+        // j == n: the sub-block before the first whole one; only its tails are needed (the longest window starts inside it)
+        const bool partial = j == sp.n;
+        if (j > sp.n || (partial && (sp.avail == 0u || !a.tails || sp.first_sub == 0u))) break;
+        const uint64_t g = partial ? sp.first_sub - 1u : sp.first_sub + j;
+        const uint32_t i0 = partial ? SUB - sp.avail : 0u;
+        double sum = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
+        for (uint32_t i = i0; i < SUB; ++i) {
+            const double v = ring_col[((g * SUB + i) % a.ring_len) * kRow];
+            kbn(sum, c, v);
 #pragma unroll
-        for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += a.tail_len[w] >= SUB - i ? v : 0.0;
-    }
-    if (!partial) out[(uint64_t)chan * stride + j] = sum + c;
-    if (a.tails) {
+            for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += a.tail_len[w] >= SUB - i ? v : 0.0;
+        }
+        if (!partial) out[(uint64_t)chan * stride + j] = sum + c;
+        if (a.tails) {
 #pragma unroll
-        for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (g & (a.q_len - 1u))] = tl[w];
+            for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (g & (a.q_len - 1u))] = tl[w];
+        }
     }
 }
 __global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, const double* sub, uint64_t stride, const uint32_t* only_if) {
@@ -563,7 +585,8 @@ void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const ui
     const uint32_t slots = a.n_streams << a.slot_shift, groups = (slots + 63u) / 64u;
     if (!a.blocks_v && a.frames_seen < SUB) return;
     const uint64_t rows = a.blocks_v ? stride + 1u : std::min<uint64_t>(a.frames_seen / SUB, stride) + 1u;
-    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)rows), dim3(64), 0, stream, a, scratch, stride, only_if);
+    hipLaunchKernelGGL(loud_rebuild_sub_kernel, dim3(groups, (uint32_t)((rows + kRebuildRows - 1u) / kRebuildRows)), dim3(64), 0, stream, a, scratch,
+                       stride, only_if);
     hipLaunchKernelGGL(loud_rebuild_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, scratch, stride, only_if);
 }
 
@@ -571,24 +594,39 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
     const uint32_t slots = a.n_streams << a.slot_shift, groups = (slots + 63u) / 64u;
     const dim3 grid(groups, a.n_blocks);
     const bool tiled = a.channels == 1 || a.channels == 2 || a.channels == 4 || a.channels == 8;  // 64 slots = whole streams
+    const bool ragged = a.blocks_v != nullptr;
+    auto with_shape = [&](auto kernel_of) {  // kernel_of(tiled, ragged) launches its instantiation
+        using T = std::true_type;
+        using F = std::false_type;
+        if (tiled) {
+            if (ragged) kernel_of(T{}, T{});
+            else kernel_of(T{}, F{});
+        } else {
+            if (ragged) kernel_of(F{}, T{});
+            else kernel_of(F{}, F{});
+        }
+    };
     auto filter = [&](auto pass) {
         constexpr int PASS = decltype(pass)::value;
-        if (PASS == 1 && a.tails) {
-            if (tiled) hipLaunchKernelGGL((loud_chunk_filter_kernel<1, true, true>), grid, dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL((loud_chunk_filter_kernel<1, false, true>), grid, dim3(64), 0, stream, a);
-        } else if (tiled) hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, true, false>), grid, dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, false, false>), grid, dim3(64), 0, stream, a);
+        with_shape([&](auto tiled_c, auto ragged_c) {
+            constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
+            if (PASS == 1 && a.tails) hipLaunchKernelGGL((loud_chunk_filter_kernel<1, TI, true, RG>), grid, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, TI, false, RG>), grid, dim3(64), 0, stream, a);
+        });
     };
     auto peak = [&](auto dl) {
         constexpr int DL = decltype(dl)::value;
-        if (tiled) hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, true>), grid, dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, false>), grid, dim3(64), 0, stream, a);
+        with_shape([&](auto tiled_c, auto ragged_c) {
+            constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
+            hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, TI, RG>), grid, dim3(64), 0, stream, a);
+        });
     };
     filter(std::integral_constant<int, 0>{});
     if (a.delay_len == 12) peak(std::integral_constant<int, 12>{});
     else if (a.delay_len == 24) peak(std::integral_constant<int, 24>{});
     else peak(std::integral_constant<int, 0>{});
-    hipLaunchKernelGGL(loud_scan_filter_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
+    if (a.scan_dd) hipLaunchKernelGGL(loud_scan_filter_kernel<true>, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
+    else hipLaunchKernelGGL(loud_scan_filter_kernel<false>, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
     filter(std::integral_constant<int, 1>{});
     hipLaunchKernelGGL(loud_scan_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a);
     const uint64_t snaps = (uint64_t)a.n_streams * a.n_blocks;

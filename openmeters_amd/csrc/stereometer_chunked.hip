@@ -47,7 +47,8 @@ struct Moments {
 }  // namespace
 
 // role 0: full-band correlator + low band (LP_low cascade); role 1: mid (HP_low, LP_high); role 2: high (HP_low, HP_high)
-template <bool PASS_B>
+// RAGGED: the per-stream values of a ragged call are compiled in only there (as per-lane values they cost the lock-step kernel 20 %)
+template <bool PASS_B, bool RAGGED>
 __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][ROW_FLOATS]
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
         const uint64_t item = item0 + row;
         live[n] = q < 512u && item < items;
         const uint64_t s = live[n] ? item / a.n_blocks : 0, c = live[n] ? item % a.n_blocks : 0;
-        live[n] = live[n] && (!a.blocks_v || c < a.blocks_v[s]);  // ragged calls: a stream's unused block slots hold anything
+        if constexpr (RAGGED) live[n] = live[n] && c < a.blocks_v[s];  // a stream's unused block slots hold anything
         src[n] = a.pcm + (s * a.frames_total + c * L) * 2u + part * 4u;
         dst[n] = row * ROW_FLOATS + part * 4u;
     }
@@ -99,9 +100,13 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     const uint64_t item = item0 + lane;
     const bool in_call = item < items;
     const uint64_t s = in_call ? item / a.n_blocks : 0, c = in_call ? item % a.n_blocks : 0;
-    const uint32_t blocks_s = in_call ? (a.blocks_v ? a.blocks_v[s] : a.n_blocks) : 0u;
-    const bool mine = c < blocks_s;
-    if (__ballot(mine) == 0ull) return;  // (the three wavefronts of the workgroup see the same 64 items)
+    uint32_t blocks_s = a.n_blocks;
+    bool mine = in_call;
+    if constexpr (RAGGED) {
+        blocks_s = in_call ? a.blocks_v[s] : 0u;
+        mine = c < blocks_s;
+        if (__ballot(mine) == 0ull) return;  // (the three wavefronts of the workgroup see the same 64 items)
+    }
     const bool bands = a.analyze_bands != 0;
     const BiquadCoef ca = role == 0 ? a.lp_lo : a.hp_lo, cb = role == 1 ? a.lp_hi : a.hp_hi;
     v2f z0[4], z1[4];  // role 0 uses elements 0, 1 (LP_low); roles 1, 2: 0, 1 = HP_low, 2, 3 = LP_high / HP_high
@@ -127,8 +132,11 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     float* hist_full = a.history + ((s * 4u) * (uint64_t)a.hist_frames) * 2u;
     const bool chunk_in_tail = PASS_B && mine && (c + 1u) * (uint64_t)L > tail_from;
     const bool wave_in_tail = __ballot(chunk_in_tail) != 0ull;
-    const uint64_t pos_full = a.start_v ? a.start_v[s * 4u] : a.hist_pos[0];
-    const uint64_t pos_band = a.start_v ? a.start_v[s * 4u + band_id] : a.hist_pos[band_id];
+    uint64_t pos_full = a.hist_pos[0], pos_band = a.hist_pos[band_id];
+    if constexpr (RAGGED) {
+        pos_full = a.start_v[s * 4u];
+        pos_band = a.start_v[s * 4u + band_id];
+    }
 
     issue(0);
     for (uint32_t step = 0; step < steps; ++step) {
@@ -345,11 +353,14 @@ void launch_stereometer_chunked(const StereoChunkArgs& a, const double* d_T, dou
     const uint32_t groups = (uint32_t)((items + 63) / 64);
     const uint32_t threads = 192u;  // without band analysis roles 1 and 2 only help staging the tiles
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
+    const bool ragged = a.blocks_v != nullptr;
     if (a.analyze_bands) {
-        hipLaunchKernelGGL(stereo_chunk_kernel<false>, dim3(groups), dim3(threads), lds, stream, a);
+        if (ragged) hipLaunchKernelGGL((stereo_chunk_kernel<false, true>), dim3(groups), dim3(threads), lds, stream, a);
+        else hipLaunchKernelGGL((stereo_chunk_kernel<false, false>), dim3(groups), dim3(threads), lds, stream, a);
         hipLaunchKernelGGL(stereo_scan_states_kernel, dim3((a.n_streams * 6u + 3u) / 4u), dim3(256), 0, stream, a, d_T);
     }
-    hipLaunchKernelGGL(stereo_chunk_kernel<true>, dim3(groups), dim3(threads), lds, stream, a);
+    if (ragged) hipLaunchKernelGGL((stereo_chunk_kernel<true, true>), dim3(groups), dim3(threads), lds, stream, a);
+    else hipLaunchKernelGGL((stereo_chunk_kernel<true, false>), dim3(groups), dim3(threads), lds, stream, a);
     hipLaunchKernelGGL(stereo_scan_moments_kernel, dim3((a.n_streams * 4u + 3u) / 4u), dim3(256), 0, stream, a, decay);
 }
 
