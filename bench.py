@@ -335,8 +335,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    # one event per step boundary on the step's stream (no synchronisation: the spread of the steps inside the timed region, read back
+    # after it — a 20-step run is a 40 ms sample of a clock that moves +-15 % box to box)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -347,6 +352,9 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_spread = {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "p95": step_ms[min(len(step_ms) - 1, int(0.95 * len(step_ms)))],
+                   "max": step_ms[-1], "unit": "ms", "note": "device time between consecutive step boundaries on the step's stream (HIP events)"}
     kernel_ms, launches = group.kernel_time()
     assert last is not None and last.n_columns == cols_per_step, (last.n_columns if last else None, cols_per_step)
     counts = torch.as_tensor(DeviceView(last.d_counts, (S, last.n_columns), "<i4"), device=device)
@@ -389,6 +397,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "step_ms_spread": step_spread,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
