@@ -129,7 +129,7 @@ LoudnessBank::LoudnessBank(const omx_loudness_config& cfg, uint32_t n_streams) :
 void LoudnessBank::clear_state(hipStream_t stream) {
     frames_seen_ = 0;
     if (state_.ptr) OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(LoudnessChannelState), stream));
-    if (ring_.ptr) OMX_HIP(hipMemsetAsync(ring_.ptr, 0, ring_.count * sizeof(double), stream));
+    if (ring_.ptr) OMX_HIP(hipMemsetAsync(ring_.ptr, 0, ring_.count * sizeof(RingT), stream));
     state_clean_ = true;
     q_valid_ = true;  // no samples yet: the running totals of the chunk-parallel path start from nothing
 }
@@ -315,7 +315,7 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
         q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_));
         OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
         tails_.release();
-        if (!state_clean_) q_valid_ = false;  // re-indexed: the totals come back from the squared-sample ring
+        if (!state_clean_) q_valid_ = false;  // re-indexed: the totals come back from the sample ring
     }
     ca.q_ring = q_ring_.ptr;
     ca.q_len = q_len_;

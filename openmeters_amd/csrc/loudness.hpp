@@ -9,6 +9,18 @@ constexpr int kLoudnessWindows = 4;
 constexpr int kTruePeakMaxDelay = 24;
 
 // Per-channel recurrent state (array of structs in HBM; loaded to registers for the whole call).
+// Ring element: the K-weighted sample as the reference rounds it to f32 before squaring (loudness/processor.rs:161, :276-277), 0 for a
+// non-finite one (WindowedMeans::push, dsp.rs:325-333).  What the windows sum is its square, exact in f64 — so the ring carries 4
+// bytes per sample where the squares took 8, and every reader squares on the way in (bit-identical sums).
+using RingT = float;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline double ring_square(RingT f) {
+    const double d = (double)f;
+    return d * d;
+}
+
 struct LoudnessChannelState {
     double sums[kLoudnessWindows][2];         // CompensatedPair::sums   [window][0 = live window, 1 = since refresh]
     double corrections[kLoudnessWindows][2];  // CompensatedPair::corrections
@@ -34,7 +46,7 @@ struct LoudnessArgs {
     uint64_t frames_seen;   // pushes since the state was created (head = frames_seen % ring_len)
     uint32_t slot_shift;    // log2 of the (stream, channel) slots per stream: 8, or the channel count itself when it is 1 / 2 / 4
                             // (a 2-channel bank would otherwise spend three quarters of its lanes and workgroups on dead slots)
-    double* ring;           // [slot group of 64][ring_len][64] squared K-weighted samples
+    RingT* ring;            // [slot group of 64][ring_len][64] K-weighted samples (f32; the windows sum their squares)
     LoudnessChannelState* state;  // [n_streams << slot_shift] (allocated for 8 slots per stream)
     float floor_db;
     omx_loudness_snapshot* snapshots;  // [n_streams][n_blocks]
@@ -63,7 +75,7 @@ struct LoudChunkArgs {
     uint32_t delay_len;
     uint64_t capacities[kLoudnessWindows];
     uint64_t ring_len, frames_seen;
-    double* ring;                  // the sequential kernels' ring: [group of 64 slots][ring slot][64]
+    RingT* ring;                   // the sequential kernels' ring: [group of 64 slots][ring slot][64]
     LoudnessChannelState* state;   // [slots]
     float floor_db;
     omx_loudness_snapshot* snapshots;
@@ -117,7 +129,7 @@ private:
     double b_[5], a_[5];
     uint64_t frames_seen_ = 0, ring_len_ = 0, last_blocks_ = 0;
     bool state_clean_ = false;
-    DeviceBuffer<double> ring_;
+    DeviceBuffer<RingT> ring_;
     DeviceBuffer<LoudnessChannelState> state_;
     OutBuffer<omx_loudness_snapshot> snapshots_;
     bool host_outputs_ = false;

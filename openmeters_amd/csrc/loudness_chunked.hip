@@ -13,7 +13,7 @@
 //                    Both are accurate to ~1e-15 of the window sum; they differ in the last bits only (bar: 1e-4 dB).
 //   true peak        (:123-151) 12- / 24-sample FIR memory: every block is computed from its own samples and the DL - 1
 //                    before them, in the reference's accumulation order -> bit-identical to the sequential kernels.
-// The squared samples still go to the f64 ring in the sequential kernels' layout, and the channel state (filter, KBN pairs,
+// The K-weighted samples still go to the ring in the sequential kernels' layout (f32, RingT: loudness.hpp), and the channel state (filter, KBN pairs,
 // delay line) is written back in their form, so calls may alternate between the two forms.
 // Shapes: any channel count (1, 2, 4, 8 through LDS tiles of whole streams; 3, 5, 6, 7 by per-lane reads), block_frames and the
 // sample counter multiples of 64; window lengths on the 64-sample grid (48 / 96 / 192 kHz) or off it (44.1 / 88.2 kHz: `tails`).  Non-finite PCM is detected in pass A; every later kernel then leaves the state alone and the caller runs
@@ -140,7 +140,7 @@ struct Direct {
 
 }  // namespace
 
-// ---- K-weighting: PASS 0 = zero-state end state of the block; PASS 1 = from the true start state: squared samples -> ring,
+// ---- K-weighting: PASS 0 = zero-state end state of the block; PASS 1 = from the true start state: samples -> ring,
 // sub-block sums.  grid (slot groups, blocks), 64 threads: lane = slot of the group.
 template <int PASS, bool TILED, bool TAILS, bool RAGGED>
 __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
         f3 = cf[3];
     }
     const double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
-    double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
+    RingT* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
     uint64_t pos = (sc.seen + (uint64_t)c * L) % a.ring_len;  // ring slot of the block's first sample
     // a call longer than the ring: only its newest ring_len samples are stored (an earlier block must not race a later one for a slot)
     const uint64_t idx0 = (uint64_t)c * L, frames_s = (uint64_t)sc.blocks * L, first_kept = frames_s > a.ring_len ? frames_s - a.ring_len : 0u;
@@ -208,8 +208,9 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             if constexpr (PASS == 1) {
                 const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
                 double value = filtered * filtered;
-                value = isfinite(value) ? value : 0.0;     // WindowedMeans::push (dsp.rs:325)
-                if (live && idx0 + (uint64_t)(step * STEP + f) >= first_kept) ring_col[pos * kRow] = value;
+                const bool finite = isfinite(value);
+                value = finite ? value : 0.0;              // WindowedMeans::push (dsp.rs:325)
+                if (live && idx0 + (uint64_t)(step * STEP + f) >= first_kept) ring_col[pos * kRow] = finite ? (RingT)filtered : (RingT)0;
                 pos = pos + 1u == a.ring_len ? 0u : pos + 1u;
                 kbn(ssum, scor, value);
                 if constexpr (TAILS) {
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
     }
 }
 
-// ---- rebuild Q from the squared-sample ring (after calls that went through the sequential kernels): sub-block sums of the
+// ---- rebuild Q from the sample ring (after calls that went through the sequential kernels): sub-block sums of the
 // newest min(seen, ring_len) samples of every slot, then the same prefix.  grid (slot groups, sub-blocks), lane = slot.
 constexpr uint32_t kRebuildRows = 16;  // sub-blocks per workgroup of loud_rebuild_sub_kernel
 struct RebuildSpan {
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, d
     const uint32_t chan = group * 64u + lane;
     if (!slot_live(a, chan)) return;
     const RebuildSpan sp = rebuild_span(a, chan >> a.slot_shift);
-    const double* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
+    const RingT* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
     for (uint64_t j = (uint64_t)blockIdx.y * kRebuildRows; j < ((uint64_t)blockIdx.y + 1u) * kRebuildRows; ++j) {
         // j == n: the sub-block before the first whole one; only its tails are needed (the longest window starts inside it)
         const bool partial = j == sp.n;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, d
         const uint32_t i0 = partial ? SUB - sp.avail : 0u;
         double sum = 0.0, c = 0.0, tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
         for (uint32_t i = i0; i < SUB; ++i) {
-            const double v = ring_col[((g * SUB + i) % a.ring_len) * kRow];
+            const double v = ring_square(ring_col[((g * SUB + i) % a.ring_len) * kRow]);
             kbn(sum, c, v);
 #pragma unroll
             for (int w = 0; w < kLoudnessWindows; ++w) tl[w] += a.tail_len[w] >= SUB - i ? v : 0.0;
@@ -550,10 +551,10 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
                 const uint64_t refresh = (P / a.capacities[w]) * a.capacities[w], refresh_sub = refresh / SUB;
                 double rbase;
                 if (refresh % SUB == 0u) rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
-                else {  // off the grid: the rest of that sub-block is still in the squared-sample ring (refresh > P - cap >= P - ring_len)
-                    const double* ring_col = a.ring + (uint64_t)(chan / kRow) * a.ring_len * kRow + chan % kRow;
+                else {  // off the grid: the rest of that sub-block is still in the sample ring (refresh > P - cap >= P - ring_len)
+                    const RingT* ring_col = a.ring + (uint64_t)(chan / kRow) * a.ring_len * kRow + chan % kRow;
                     double rest = 0.0;
-                    for (uint64_t i = refresh; i < (refresh_sub + 1u) * SUB; ++i) rest += ring_col[(i % a.ring_len) * kRow];
+                    for (uint64_t i = refresh; i < (refresh_sub + 1u) * SUB; ++i) rest += ring_square(ring_col[(i % a.ring_len) * kRow]);
                     rbase = q[refresh_sub & mask] - rest;
                 }
                 st.sums[w][0] = W;

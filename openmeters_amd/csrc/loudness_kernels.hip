@@ -1,12 +1,13 @@
 // K4 loudness_bs1770: BS.1770 K-weighting (one 4th-order f64 TDF-II), four Kahan-Babuska-Neumaier
-// sliding sums over a shared f64 ring, 4x / 2x polyphase true peak, per-block snapshot.
+// sliding sums over a shared ring of the f32 K-weighted samples (squared, exactly, by every reader), 4x / 2x polyphase true peak,
+// per-block snapshot.
 // reference src/visuals/loudness/processor.rs:123-162, :253-311 and src/dsp.rs:264-371.
 //
 // Four lanes per (stream, channel) — the recurrences are sequential in time — 32 lanes per stream, so
 // the position-weighted channel sum of a snapshot is an in-order shuffle walk.  The ring
 // is [slot][stream*8 + channel]: the slot index is identical for every channel of a lock-step bank
 // (lazy activation with leading zeros == eager state fed zeros, loudness/processor.rs:400-417), so
-// each expiring-value read and each ring write is one coalesced f64 row per wave.
+// each expiring-value read and each ring write is one coalesced f32 row per wave.
 // Built with -ffp-contract=off: the f64 filter and the KBN sums round exactly like the scalar code.
 #include <type_traits>
 
@@ -15,10 +16,10 @@
 namespace omx {
 
 // Ring layout: [group of 64 (stream, channel) slots][ring slot][64].  A workgroup's expiring-value reads and its ring writes then
-// walk five sequential 512-byte-row streams inside one contiguous region (the first layout, [ring slot][all slots], put every
+// walk five sequential 256-byte-row streams inside one contiguous region (the first layout, [ring slot][all slots], put every
 // access of a workgroup 64 KiB x n_streams / 1024 apart: one DRAM page and one TLB reach per 512 bytes).
 constexpr uint32_t kRingRow = 64;
-__device__ __forceinline__ double* ring_column(double* ring, uint32_t chan, uint64_t ring_len) {
+__device__ __forceinline__ RingT* ring_column(RingT* ring, uint32_t chan, uint64_t ring_len) {
     return ring + (uint64_t)(chan >> 6) * ring_len * kRingRow + (chan & 63u);
 }
 
@@ -58,15 +59,15 @@ struct LoudLane {
 // MODE 0: everything in one lane (K-weighting + window + true-peak phase);  MODE 1: K-weighting + window only (the true
 // peak of the call is computed by the true-peak workgroups of the same launch);  MODE 2: true peak only.
 template <int NB, int DL, int MODE>
-__device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)[NB], const double (&oldr)[NB], uint32_t unf, bool live,
-                                              const LoudnessArgs& a, double* ring_col, uint32_t row, uint32_t len, uint32_t cap,
+__device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)[NB], const RingT (&oldr)[NB], uint32_t unf, bool live,
+                                              const LoudnessArgs& a, RingT* ring_col, uint32_t row, uint32_t len, uint32_t cap,
                                               bool store_lane) {
     float x[NB];
     double old[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {  // the selects that loudness_fetch left out
         x[k] = live ? xr[k] : 0.0f;
-        old[k] = (live && (uint32_t)k >= unf) ? oldr[k] : 0.0;
+        old[k] = (live && (uint32_t)k >= unf) ? ring_square(oldr[k]) : 0.0;
     }
     float ext[NB + (DL > 0 ? DL - 1 : 0)];  // ext[NB-1-k] = x[k]; ext[NB + i] = hist[i]
 #pragma unroll
@@ -89,7 +90,8 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)
         const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
         double value = filtered * filtered;
         // ---- WindowedMeans::push for this lane's window (dsp.rs:324-357)
-        value = isfinite(value) ? value : 0.0;
+        const bool finite = isfinite(value);
+        value = finite ? value : 0.0;
         kbn_add(L.sum0, L.cor0, value);
         kbn_add(L.sum1, L.cor1, value);
         kbn_add(L.sum0, L.cor0, -old[k]);  // old[k] == 0.0 until the window is full: adding -0.0 changes nothing
@@ -101,7 +103,7 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)
             L.cor1 = 0.0;
             L.refresh = 0;
         }
-        if (store_lane) ring_col[(uint64_t)L.head * row] = value;
+        if (store_lane) ring_col[(uint64_t)L.head * row] = finite ? (RingT)filtered : (RingT)0;
         L.head = L.head + 1 == len ? 0 : L.head + 1;
         }
         // ---- TruePeakMeter::process (:123-150): window newest-first = ext[NB-1-k + i]
@@ -120,8 +122,8 @@ __device__ __forceinline__ void loudness_step(LoudLane<DL>& L, const float (&xr)
 }
 
 template <int NB, int DL, int MODE>
-__device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float (&x)[NB], double (&old)[NB], const float* pcm,
-                                               uint64_t frame0, uint32_t channels, const double* ring_col, uint32_t row, uint32_t len,
+__device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float (&x)[NB], RingT (&old)[NB], const float* pcm,
+                                               uint64_t frame0, uint32_t channels, const RingT* ring_col, uint32_t row, uint32_t len,
                                                uint32_t cap, uint32_t ahead, bool live) {
     // `ahead` = samples between the lane's cursor (head, unfilled) and the first sample fetched here
     uint32_t h = L.head + ahead;
@@ -136,7 +138,7 @@ __device__ __forceinline__ uint32_t loudness_fetch(const LoudLane<DL>& L, float 
         uint32_t pos = h + (uint32_t)k;
         pos = pos >= len ? pos - len : pos;
         const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
-        double ov = 0.0;
+        RingT ov = 0;
         if constexpr (MODE != 2) ov = ring_col[(uint64_t)idx * row];
         x[k] = xv;   // raw: the selects happen where the values are consumed (a select here would wait for the load)
         old[k] = ov;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     L.refresh = (uint32_t)(seen0 % a.capacities[r]);                                   // dsp.rs:363
     L.unfilled = seen0 >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - seen0);  // pushes until count >= cap
     uint64_t seen = seen0;
-    double* ring_col = ring_column(a.ring, live ? chan : 0, a.ring_len);  // dead lanes read column 0 (discarded) and never store
+    RingT* ring_col = ring_column(a.ring, live ? chan : 0, a.ring_len);  // dead lanes read column 0 (discarded) and never store
     const bool store_lane = live && r == 0;
     const uint32_t full = a.block_frames / B, tail = a.block_frames % B;
 
@@ -201,7 +203,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
         // full batches, two per iteration so the prefetch buffers swap roles without register copies: the loads of
         // batch n+1 are issued before batch n is computed (HBM round trip hidden behind ~8 samples of f64 work)
         float xa[B], xb[B];
-        double oa[B], ob[B];
+        RingT oa[B], ob[B];
         uint32_t ua = 0, ub = 0;
         if (full > 0) ua = loudness_fetch<B, DL, MODE>(L, xa, oa, pcm, f_blk, a.channels, ring_col, row, len, cap, 0, live);
         uint32_t q = 0;
@@ -215,7 +217,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
         if (q < full) loudness_step<B, DL, MODE>(L, xa, oa, ua, live, a, ring_col, row, len, cap, store_lane);
         for (uint32_t k = 0; k < tail; ++k) {  // block_frames % B leftover samples, one at a time
             float x1[1];
-            double o1[1];
+            RingT o1[1];
             const uint32_t u1 = loudness_fetch<1, DL, MODE>(L, x1, o1, pcm, f_blk + (uint64_t)full * B + k, a.channels, ring_col, row, len,
                                                             cap, 0, live);
             loudness_step<1, DL, MODE>(L, x1, o1, u1, live, a, ring_col, row, len, cap, store_lane);
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
         return;
     }
     __shared__ double vals[NBUF][NSUB * B][64];
+    __shared__ RingT vals_ring[NBUF][NSUB * B][64];  // the same samples as the ring stores them (read by the storing window wavefront only)
     __shared__ double mailbox[SIX ? 2 : 1][4][2][64];  // [round parity][window][sum, correction][lane]
     // wave-uniform by construction; readfirstlane tells the compiler, so that everything derived from the role (window length,
     // ring slots, refresh counters) lives in SGPRs and the ring accesses take the scalar-base + lane-offset form
@@ -363,7 +366,8 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
     // < 2^32 for any ring the host accepts) select the scalar-base + vector-offset addressing form — one VALU per access
     // instead of the seven of a per-lane 64-bit address
     char* group_bytes = reinterpret_cast<char*>(a.ring + (uint64_t)blockIdx.x * a.ring_len * kRingRow);
-    const uint32_t lane_bytes = lane * 8u;
+    const uint32_t lane_bytes = lane * (uint32_t)sizeof(RingT);
+    constexpr uint32_t kRowBytes = kRingRow * (uint32_t)sizeof(RingT);
     const uint32_t len = (uint32_t)a.ring_len;
 
     if (k_role) {
@@ -393,8 +397,10 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
                 f3 = a.b[4] * xd - a.a[4] * y;
                 const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
                 double value = filtered * filtered;
-                value = isfinite(value) ? value : 0.0;     // WindowedMeans::push (dsp.rs:325)
+                const bool finite = isfinite(value);
+                value = finite ? value : 0.0;              // WindowedMeans::push (dsp.rs:325)
                 vals[buf][sub * B + k][lane] = value;
+                vals_ring[buf][sub * B + k][lane] = finite ? (RingT)filtered : (RingT)0;
             }
             if ((batch + 1) % full == 0) {  // denormal flush after a block's last sample (:281-285)
                 if (fabs(f0) < 1.0e-30) f0 = 0.0;
@@ -515,9 +521,9 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
     uint32_t refresh = (uint32_t)(a.frames_seen % a.capacities[r]);
     uint32_t unfilled = a.frames_seen >= a.capacities[r] ? 0u : (uint32_t)(a.capacities[r] - a.frames_seen);
     uint64_t seen = a.frames_seen;
-    double o0[B], o1[B], o2[B], o3[B];  // expiring values, fetched four batches (32 samples, several HBM round trips) ahead
+    RingT o0[B], o1[B], o2[B], o3[B];  // expiring samples, fetched four batches (32 samples, several HBM round trips) ahead
     // expiring values of the batch that starts `ahead` samples from the cursor (dsp.rs:336-338); `batch` only gates the tail
-    auto fetch_old = [&](double (&old)[B], uint32_t ahead, uint64_t batch) -> uint32_t {
+    auto fetch_old = [&](RingT (&old)[B], uint32_t ahead, uint64_t batch) -> uint32_t {
         uint32_t h = head + ahead;
         h = h >= len ? h - len : h;
         const uint32_t unf = unfilled > ahead ? unfilled - ahead : 0u;
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
             const uint32_t idx = pos >= cap ? pos - cap : pos + len - cap;
             // the ring slot is wave-uniform and the workgroup's 64 columns are contiguous: scalar row address + lane offset
             // (the per-lane 64-bit address arithmetic was 7 VALU per load, a fifth of this wavefront's instructions)
-            old[k] = *reinterpret_cast<const double*>(group_bytes + (idx * (kRingRow * 8u) + lane_bytes));
+            old[k] = *reinterpret_cast<const RingT*>(group_bytes + (idx * kRowBytes + lane_bytes));
         }
         return batch < total ? unf : (uint32_t)B;  // first sample of the batch that has an expiring value
     };
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
     // instantiation is straight-line code.
     const bool store_wave = __builtin_amdgcn_readfirstlane((int)(r == 0)) != 0;
     uint32_t round_parity = 0;  // six-wave form: parity of the round being consumed (mailbox slot)
-    auto consume_as = [&](auto store_c, auto refresh_c, const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub) {
+    auto consume_as = [&](auto store_c, auto refresh_c, const RingT (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub) {
         constexpr bool STORE = decltype(store_c)::value, REFRESH = decltype(refresh_c)::value;
         // all B values of the batch in one burst of LDS reads (read-per-sample exposed the LDS latency at every sample)
         double batch[B];
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
 #pragma unroll
         for (int k = 0; k < B; ++k) {
             const double value = batch[k];
-            const double expiring = (live && (uint32_t)k >= first_valid) ? old[k] : 0.0;
+            const double expiring = (live && (uint32_t)k >= first_valid) ? ring_square(old[k]) : 0.0;
             kbn_add(sum0, cor0, value);
             if constexpr (!SIX) kbn_add(sum1, cor1, value);
             kbn_add(sum0, cor0, -expiring);
@@ -593,11 +599,12 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void loudness_roles_kernel(Loudnes
             }
             if constexpr (STORE) {
                 if (live)
-                    *reinterpret_cast<double*>(group_bytes + ((head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * (kRingRow * 8u) + lane_bytes)) = value;
+                    *reinterpret_cast<RingT*>(group_bytes + ((head + (uint32_t)k >= len ? head + (uint32_t)k - len : head + (uint32_t)k) * kRowBytes + lane_bytes)) =
+                        vals_ring[buf][sub * B + k][lane];
             }
         }
     };
-    auto consume = [&](const double (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
+    auto consume = [&](const RingT (&old)[B], uint32_t first_valid, uint32_t buf, uint32_t sub, uint64_t batch) {
         using T = std::true_type;
         using F = std::false_type;
         const bool may_refresh = refresh + (uint32_t)B >= cap;
@@ -675,7 +682,7 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
     }
     const bool split = force >= 0 ? force != 0 : (a.delay_len != 0 && grid <= 4096);
     // role-per-wavefront form (OMX_LOUDNESS_SPLIT=2 pins it, default when it applies): whole batches per block, 4x interpolator
-    const bool roles = a.ring_len * (uint64_t)(kRingRow * 8u) <= 0xFFFFFFFFull &&  // 32-bit byte offsets inside a group's ring
+    const bool roles = a.ring_len * (uint64_t)(kRingRow * sizeof(RingT)) <= 0xFFFFFFFFull &&  // 32-bit byte offsets inside a group's ring
                        (force == 2 || force == 3 || (force < 0 && grid <= 4096)) && min_cap >= 64 && a.block_frames % 32 == 0 && a.delay_len == 12;
     if (roles) {
         LoudnessArgs r = a;

@@ -76,19 +76,23 @@ def loudness(S=1024, C=8, blocks=64, reps=5, out=sys.stdout):
     dt = timed(run, reps)
     kms, _ = bank.kernel_time()
     cs = S * C * frames
-    # SURVEY §8(d) prices the REFERENCE formulation (sliding Kahan sums): 4 B PCM + 8 B ring write + 4 x 8 B expiring reads = 44 B per
-    # channel-sample.  The chunk-parallel form (loudness_chunked.hip, what a bank call of this size runs) needs no expiring reads:
-    # its compulsory traffic is 4 + 8 = 12 B, and it actually moves ~20.5 B (the PCM is read by three passes, + sub-block sums)
+    # SURVEY §8(d) prices the REFERENCE formulation (sliding Kahan sums over a ring of f64 squares): 4 B PCM + 8 B ring write + 4 x 8 B
+    # expiring reads = 44 B per channel-sample.  The chunk-parallel form (loudness_chunked.hip, what a bank call of this size runs)
+    # needs no expiring reads and its ring holds the f32 sample (the square is exact, loudness.hpp RingT): compulsory 4 + 4 = 8 B;
+    # it actually moves ~16.5 B (the PCM is read by three passes, + sub-block sums).  The roofline object below prices the 8 B.
     print(f"cfg3 loudness: {S}x{C}ch, {blocks} blocks/call: {dt*1e3:.2f} ms/call (kernel {kms:.2f} ms) -> {cs/dt/1e9:.2f} G channel-samples/s, "
-          f"{cs/dt/(S*C*FS):.0f}x real time; HBM: {cs*12/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s at this form's 12 B/channel-sample "
-          f"({cs*20.5/(kms*1e-3)/8e12*100:.1f}% counting its three PCM passes), {cs*44/(kms*1e-3)/8e12*100:.1f}% at the reference formulation's 44 B", file=out)
+          f"{cs/dt/(S*C*FS):.0f}x real time; HBM: {cs*8/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s at this form's 8 B/channel-sample "
+          f"({cs*16.5/(kms*1e-3)/8e12*100:.1f}% counting its three PCM passes), {cs*44/(kms*1e-3)/8e12*100:.1f}% at the reference formulation's 44 B", file=out)
     snap = bank.fetch(0, blocks - 1)
     print("   stream0 last snapshot:", snap.short_term_loudness, snap.momentary_loudness, snap.true_peak_db[:3], file=out)
     return {"workload": f"{S} streams x {C} ch, {blocks} blocks of 256 per call", "channel_samples_per_s": cs / dt, "x_real_time": cs / dt / (S * C * FS),
             "ms_per_call": dt * 1e3, "kernel_ms": kms, "form": "chunk-parallel (loudness_chunked.hip)",
-            "hbm_frac_compulsory_12B": cs * 12 / (kms * 1e-3) / 8e12, "hbm_frac_moved_20p5B": cs * 20.5 / (kms * 1e-3) / 8e12,
+            "hbm_frac_compulsory_8B": cs * 8 / (kms * 1e-3) / 8e12, "hbm_frac_moved_16p5B": cs * 16.5 / (kms * 1e-3) / 8e12,
             "hbm_frac_reference_formulation_44B": cs * 44 / (kms * 1e-3) / 8e12,
-            "roofline": roofline(cs * 44.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan", "loudness_"]),   # §8(d): 44 B per channel-sample + 104 B per snapshot
+            # algorithmic bytes of THIS formulation: 8 B per channel-sample (PCM in, f32 ring out) + 104 B per snapshot; SURVEY §8(d)'s
+            # 44 B belongs to the sliding-sum formulation (its fraction is the field above: >= 1.0 means this form beats what that
+            # formulation could do at the HBM peak)
+            "roofline": roofline(cs * 8.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan", "loudness_"]),
             "momentary_lufs_stream0": float(snap.momentary_loudness)}
 
 
