@@ -254,6 +254,9 @@ int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset);
 /* Number of 4096-point complex transforms the default reassigned 4096 kernel executes per frame (bench.py prices the
  * executed-flop fraction of the FP32 vector peak with it).  No device needed. */
 int omx_debug_transforms_per_frame(void);
+/* test hook, no device needed: the zero-input transition of the K-weighting TDF-II over `frames` samples and its powers 2, 4 ... 32 as
+ * the chunk-parallel loudness kernels take it — out[192] = [6][4][4] high parts, then [6][4][4] low parts (double-double pairs) */
+int omx_debug_k_weighting_transition(double sample_rate, uint64_t frames, double* out);
 /* same for the oscilloscope kernel with OMX_SCOPE_PHASES=1 (ring push, pre-FFT, FFTs, NSDF + peak, locate, snapshot) */
 int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset);
 /* test hook: StableTrigger::find_best (oscilloscope/processor.rs:441-484) of the wide-form trigger pass on caller-supplied host arrays

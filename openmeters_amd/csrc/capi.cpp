@@ -223,6 +223,11 @@ int omx_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len
     });
 }
 int omx_debug_transforms_per_frame(void) { return stft_reassigned_4096_transforms_per_frame(); }
+int omx_debug_k_weighting_transition(double sample_rate, uint64_t frames, double* out) {
+    if (!out || frames == 0 || !(sample_rate > 0.0)) return OMX_ERR_INVALID;
+    k_weighting_transition_debug(sample_rate, frames, out);
+    return OMX_NONE;
+}
 int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;
     REQUIRE_DEVICE();

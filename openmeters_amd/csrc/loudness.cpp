@@ -89,26 +89,37 @@ inline DD dd_mul_d(DD a, double b) {  // a * b, b an f64
 }  // namespace
 static std::vector<double> k_weighting_transitions(const double b[5], const double a[5], uint64_t frames) {
     (void)b;
-    DD P[4][4];
-    for (int m = 0; m < 4; ++m) {
-        DD f[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        f[m].h = 1.0;
-        for (uint64_t n = 0; n < frames; ++n) {
-            const DD y = f[0];
-            f[0] = dd_add(f[1], dd_mul_d(y, -a[1]));
-            f[1] = dd_add(f[2], dd_mul_d(y, -a[2]));
-            f[2] = dd_add(f[3], dd_mul_d(y, -a[3]));
-            f[3] = dd_mul_d(y, -a[4]);
-        }
-        for (int k = 0; k < 4; ++k) P[k][m] = f[k];
-    }
     std::vector<double> T(2 * 6 * 16, 0.0);
-    for (int p = 0; p < 6; ++p) {
+    auto store = [&](int p, const DD (&P)[4][4]) {
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) {
                 T[(size_t)p * 16 + (size_t)i * 4 + j] = P[i][j].h;
                 T[(size_t)(6 + p) * 16 + (size_t)i * 4 + j] = P[i][j].l;
             }
+    };
+    // Every power from its own recurrence (frames << p steps): squaring the pairs loses what the cancellation inside the product takes
+    // (2^-54 of the largest entry at 192 kHz by the fourth power, tests/test_cpu_boundary.py) — the recurrence does not cancel.
+    // Blocks beyond 128 k frames (4 M steps for the six powers) square the highest power they can afford instead.
+    DD P[4][4];
+    DD f[4][4];  // column m: the state that started as unit vector m
+    for (int m = 0; m < 4; ++m)
+        for (int k = 0; k < 4; ++k) f[m][k] = {k == m ? 1.0 : 0.0, 0.0};
+    uint64_t n = 0;
+    int p = 0;
+    for (; p < 6 && ((frames << p) <= (1ull << 22) || p == 0); ++p) {
+        for (; n < (frames << p); ++n)
+            for (int m = 0; m < 4; ++m) {
+                const DD y = f[m][0];
+                f[m][0] = dd_add(f[m][1], dd_mul_d(y, -a[1]));
+                f[m][1] = dd_add(f[m][2], dd_mul_d(y, -a[2]));
+                f[m][2] = dd_add(f[m][3], dd_mul_d(y, -a[3]));
+                f[m][3] = dd_mul_d(y, -a[4]);
+            }
+        for (int m = 0; m < 4; ++m)
+            for (int k = 0; k < 4; ++k) P[k][m] = f[m][k];
+        store(p, P);
+    }
+    for (; p < 6; ++p) {
         DD S[4][4];
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) {
@@ -117,8 +128,17 @@ static std::vector<double> k_weighting_transitions(const double b[5], const doub
                 S[i][j] = acc;
             }
         std::memcpy(P, S, sizeof(P));
+        store(p, P);
     }
     return T;
+}
+
+// test hook (omx_debug_k_weighting_transition, no device needed): the double-double block transition and its powers for a rate and block length
+void k_weighting_transition_debug(double sample_rate, uint64_t frames, double out[192]) {
+    double b[5], a[5];
+    k_weighting_coefficients(sample_rate, b, a);
+    const std::vector<double> t = k_weighting_transitions(b, a, frames);
+    std::memcpy(out, t.data(), 192 * sizeof(double));
 }
 
 LoudnessBank::LoudnessBank(const omx_loudness_config& cfg, uint32_t n_streams) : n_streams_(n_streams) {

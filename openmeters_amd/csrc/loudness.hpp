@@ -98,6 +98,7 @@ void launch_loudness_rebuild_q(const LoudChunkArgs& a, double* scratch, const ui
 
 void loudness_config_default(omx_loudness_config* c);
 void k_weighting_coefficients(double fs, double b[5], double a[5]);
+void k_weighting_transition_debug(double sample_rate, uint64_t frames, double out[192]);
 
 class LoudnessBank {
 public:

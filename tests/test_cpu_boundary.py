@@ -143,3 +143,55 @@ def test_generated_rust_ffi_layer_covers_the_header():
         body = re.search(r"pub struct " + m.group(3) + r" \{\n(.*?)\n\}", rs, flags=re.S).group(1)
         assert body.count("pub ") == n_fields, m.group(3)
     assert "define" not in rs and rs.count("#[repr(C)]") >= 30
+
+
+@pytest.mark.parametrize("rate,frames", [(48000.0, 256), (44100.0, 512), (96000.0, 1024), (192000.0, 1024)])
+def test_k_weighting_block_transition_is_exact_to_double_double(omx, rate, frames):
+    """Host logic of the chunk-parallel loudness form, no device: the block transition T = A^frames of the K-weighting TDF-II and its
+    powers (loudness.cpp: k_weighting_transitions, double-double recurrence + double-double squaring) against an 80-digit mpmath
+    evaluation of the same recurrence on the same f64 coefficients.  The entries reach 3e5 at 192 kHz and their products with the
+    state cancel to 1e-6 of their size (an f64 table put 1e-3 dB into a 15 Hz channel there), so every entry must be right to
+    ~1e-30 of the largest: hi + lo as two f64."""
+    import mpmath as mp
+    mp.mp.prec = 300
+    out = (C.c_double * 192)()
+    f = omx.fn("debug_k_weighting_transition", C.c_int, [C.c_double, C.c_uint64, C.POINTER(C.c_double)])
+    assert f(rate, frames, out) == 0
+    got = np.array(out[:]).reshape(2, 6, 4, 4)
+    # the f64 coefficients, as the library computes them (reference loudness/processor.rs:22-55)
+    import math
+    f0, g, q = 1681.974450955533, 3.999843853973347, 0.7071752369554196
+    k = math.tan(math.pi * f0 / rate)
+    vh = 10.0 ** (g / 20.0)
+    vb = vh ** 0.4996667741545416
+    a0 = 1.0 + k / q + k * k
+    pa = [1.0, 2.0 * (k * k - 1.0) / a0, (1.0 - k / q + k * k) / a0]
+    f0, q = 38.13547087602444, 0.5003270373238773
+    k = math.tan(math.pi * f0 / rate)
+    a0 = 1.0 + k / q + k * k
+    ra = [1.0, 2.0 * (k * k - 1.0) / a0, (1.0 - k / q + k * k) / a0]
+    a = [pa[0] * ra[0], pa[0] * ra[1] + pa[1] * ra[0], pa[0] * ra[2] + pa[1] * ra[1] + pa[2] * ra[0], pa[1] * ra[2] + pa[2] * ra[1], pa[2] * ra[2]]
+    am = [mp.mpf(v) for v in a]
+    T = mp.matrix(4, 4)
+    for m in range(4):
+        s = [mp.mpf(0)] * 4
+        s[m] = mp.mpf(1)
+        for _ in range(frames):   # one zero-input step (:153-162): y = f0; f0' = f1 - a1 y; f1' = f2 - a2 y; f2' = f3 - a3 y; f3' = -a4 y
+            y = s[0]
+            s = [s[1] - am[1] * y, s[2] - am[2] * y, s[3] - am[3] * y, -am[4] * y]
+        for r in range(4):
+            T[r, m] = s[r]
+    P = T
+    scale0 = max(abs(T[i, j]) for i in range(4) for j in range(4))
+    worst = mp.mpf(0)
+    for p in range(6):
+        for i in range(4):
+            for j in range(4):
+                pair = mp.mpf(float(got[0, p, i, j])) + mp.mpf(float(got[1, p, i, j]))
+                # what the scan adds is T^(2^p) x with |x| of the states' size whatever p: the error that matters is absolute, measured
+                # against the block transition's own largest entry (the higher powers decay to 1e-12 and are formed by squaring)
+                worst = max(worst, abs(pair - P[i, j]) / scale0)
+                assert abs(got[1, p, i, j]) <= abs(got[0, p, i, j]) * 2.0 ** -52 + 1e-300   # a normalised pair
+        P = P * P
+    print('worst error / max |T| = 2^%.1f' % float(mp.log(worst, 2)))
+    assert worst <= mp.mpf(2) ** -78   # measured 2^-92 ... 2^-83 (squared pairs instead of per-power recurrences: 2^-54 at 192 kHz); an f64 table is 2^-53
