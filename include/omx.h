@@ -103,6 +103,12 @@ void omx_positions_normalize(uint32_t channels, const uint8_t in[OMX_MAX_CHANNEL
 const char* omx_last_error(void);
 /* 1 if a gfx950 device is usable, else 0.  Never falls back to the CPU. */
 int omx_device_available(void);
+/* Number of HIP devices visible to the process (0 when there is none), and the device of the handles created from now on: a host
+ * without the HIP headers — the Rust service, one process per GPU — calls omx_set_device(LOCAL_RANK) once before it creates
+ * anything.  Handles and banks live on the device that was current at their creation; the stream argument of every call must belong
+ * to that device.  Returns 0, OMX_ERR_INVALID (index out of range) or OMX_ERR_NO_DEVICE (not a gfx950). */
+int omx_device_count(void);
+int omx_set_device(int index);
 /* Library version string. */
 const char* omx_version(void);
 

@@ -12,8 +12,34 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const std::string& last_error() { return g_last_error; }
 
+static int g_device_ready = 2;  // 2 = unknown
+
+// omx_device_count / omx_set_device: a host without the HIP headers (the Rust service, one process per GPU) picks its device here,
+// before it creates handles; handles live on the device that was current when they were created
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int select_device(int index) {
+    const int n = device_count();
+    if (index < 0 || index >= n) {
+        set_last_error("omx_set_device: index out of range (" + std::to_string(n) + " HIP devices visible)");
+        return n == 0 ? OMX_ERR_NO_DEVICE : OMX_ERR_INVALID;
+    }
+    if (hipSetDevice(index) != hipSuccess) {
+        set_last_error("hipSetDevice failed");
+        return OMX_ERR_BACKEND;
+    }
+    g_device_ready = 2;  // the architecture check runs again for the new device
+    return device_ready();
+}
+
 int device_ready() {
-    static int cached = 2;  // 2 = unknown
+    int& cached = g_device_ready;
     if (cached != 2) return cached;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

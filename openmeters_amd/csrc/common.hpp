@@ -20,6 +20,8 @@ namespace omx {
 // ---------------------------------------------------------------- errors
 void set_last_error(const std::string& msg);
 int device_ready();  // OMX_NONE when a gfx950 device is usable, else OMX_ERR_NO_DEVICE / OMX_ERR_BACKEND
+int device_count();
+int select_device(int index);
 
 struct BackendError {
     int status;

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(omx):
 
 def test_oracle_mirrors_the_single_stream_abi(oracle):
     for s in declared_symbols():
-        if "_bank_" in s or "_capture_group_" in s or "_debug_" in s or s in ("omx_last_error", "omx_device_available"):  # (many-stream forms)
+        if "_bank_" in s or "_capture_group_" in s or "_debug_" in s or s in ("omx_last_error", "omx_device_available", "omx_device_count", "omx_set_device"):  # (many-stream forms, device selection)
             continue
         assert hasattr(oracle.lib, "omxo_" + s[4:]), s
 
@@ -47,6 +47,20 @@ def test_no_cpu_fallback_without_a_device(omx):
     with pytest.raises(capi.OmxError) as e:
         capi.SpectrogramProcessor(omx, capi.SpectrogramConfig())
     assert e.value.status == capi.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_device_selection_entry_points(omx):
+    """omx_device_count / omx_set_device: on a GPU-less host 0 devices and OMX_ERR_NO_DEVICE; with a device, index 0 is accepted and an
+    index past the count is OMX_ERR_INVALID (nothing is selected)."""
+    import openmeters_amd
+    count = omx.fn("device_count", C.c_int, [])()
+    set_device = omx.fn("set_device", C.c_int, [C.c_int])
+    if not openmeters_amd.device_available():
+        assert count == 0 and set_device(0) == -4   # OMX_ERR_NO_DEVICE
+        return
+    assert count >= 1 and set_device(0) == 0
+    assert set_device(count) == -3 and set_device(-1) == -3   # OMX_ERR_INVALID
+    assert openmeters_amd.device_available()
 
 
 def test_pure_integer_helpers_work_without_a_device(omx, oracle):
