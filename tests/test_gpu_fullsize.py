@@ -236,3 +236,52 @@ def test_waveform_bank_1024_streams_partition_and_replication(omx, history):
     assert torch.equal(one, many)
     for s in (8, 9, 511, 1016, 1023):
         assert torch.equal(one[s], one[s % 8]), s
+
+
+def test_ragged_calls_with_equal_counts_are_bit_identical_to_lock_step_calls_at_bank_size(omx):
+    """The ragged entry points run the same kernels as the lock-step ones with per-stream counters compiled in (RAGGED template
+    parameters): given the same count for every stream they must reproduce the lock-step call BIT FOR BIT — loudness 1024 x 8 ch
+    (cfg3), stereometer + oscilloscope 256 streams (cfg4), two calls each so that the second starts from carried per-stream state."""
+    import torch
+    blocks = 40
+    frames = 256 * blocks
+    # ---- loudness, cfg3 shape
+    S, C = 1024, 8
+    distinct = np.stack([cfg3_pcm(s, 2 * frames, C) for s in range(8)])
+    d_all = torch.from_numpy(distinct).to("cuda:0").repeat(S // 8, 1, 1).contiguous()
+    a, b = banks.LoudnessBank(omx, LoudnessConfig(), S, C), banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    for call in range(2):
+        part = d_all[:, call * frames:(call + 1) * frames].contiguous()
+        pa = a.process_device(part.data_ptr(), 256, blocks, C, FS, capi.SURROUND)
+        ub = b.process_ragged(part.data_ptr(), 256, blocks, [blocks] * S, C, FS, capi.SURROUND)
+        assert a.last_form() == 2 and b.last_form() == 2
+        assert torch.equal(dview(torch, pa, (S, blocks, 30)), dview(torch, ub.d_snapshots, (S, blocks, 30))), call
+    del d_all, a, b
+    # ---- stereometer + oscilloscope, cfg4 shape
+    S = 256
+    distinct = np.stack([cfg4_pcm(s, 2 * frames) for s in range(32)])
+    d_all = torch.from_numpy(distinct).to("cuda:0").repeat(S // 32, 1, 1).contiguous()
+    pos = capi.positions_fallback(2)
+    scfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=2000)
+    ocfg = OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2, trigger_source=capi.CH_LEFT,
+                              channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT)
+    st_a, st_b = banks.StereometerBank(omx, scfg, S), banks.StereometerBank(omx, scfg, S)
+    sc_a, sc_b = banks.OscilloscopeBank(omx, ocfg, S), banks.OscilloscopeBank(omx, ocfg, S)
+    for call in range(2):
+        part = d_all[:, call * frames:(call + 1) * frames].contiguous()
+        ua = st_a.process_device(part.data_ptr(), 256, blocks, 2, FS, pos)
+        ub = st_b.process_ragged(part.data_ptr(), 256, blocks, [blocks] * S, 2, FS, pos)
+        assert st_a.last_form() == 2 and st_b.last_form() == 2
+        assert torch.equal(dview(torch, ua.d_correlations, (S, blocks, 4)), dview(torch, ub.d_correlations, (S, blocks, 4))), call
+        assert torch.equal(dview(torch, ua.d_produced, (S, blocks)), dview(torch, ub.d_produced, (S, blocks))), call
+        n = int(ua.target)
+        assert n == int(ub.target)
+        assert torch.equal(dview(torch, ua.d_points, (S, 4, n, 2)), dview(torch, ub.d_points, (S, 4, n, 2))), call
+        oa = sc_a.process_device(part.data_ptr(), 256, blocks, 2, FS, pos)
+        ob = sc_b.process_ragged(part.data_ptr(), 256, blocks, [blocks] * S, 2, FS, pos)
+        assert torch.equal(dview(torch, oa.d_headers, (S, blocks, 10)), dview(torch, ob.d_headers, (S, blocks, 10))), call
+        spc = dview(torch, oa.d_headers, (S, blocks, 10))[:, -1, 4]
+        m = int(spc.min())
+        assert m > 0
+        stride = int(oa.sample_stride)
+        assert torch.equal(dview(torch, oa.d_samples, (S, 2, stride))[:, :, :m], dview(torch, ob.d_samples, (S, 2, stride))[:, :, :m]), call
