@@ -401,8 +401,10 @@ void omx_loudness_bank_destroy(omx_loudness_bank* b);
 int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
 /* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_loudness_bank_set_option pins one):
  *   sequential kernels (sliding Kahan-Babuska-Neumaier sums in the reference's order) for single-stream handles, calls of fewer than
- *       8 blocks or fewer than 4096 (slot, block) items (slot = stream x channel), ragged calls and non-finite PCM;
- *   chunk-parallel kernels (window sums as differences of an f64 running total; K-weighting by a block scan) for calls of >= 8 blocks
+ *       8 blocks or fewer than 4096 (slot, block) items (slot = stream x channel; a ragged call counts the blocks its streams actually
+ *       run), streams whose sample counter is off the 64-sample grid, and non-finite PCM;
+ *   chunk-parallel kernels (window sums as differences of an f64 running total; K-weighting by a block scan) for lock-step AND ragged
+ *       calls of >= 8 blocks (ragged: max_blocks >= 8)
  *       and >= 4096 (slot, block) items whose block length is a multiple of 64 frames and which start at a multiple of 64 frames
  *       since the last reset: 1-8 channels, every sample rate (44.1 / 88.2 kHz windows are off the 64-sample grid: loudness_chunked.hip).
  *       Same quantities to ~1e-15 of a window sum; LUFS / RMS within 1e-4 dB of the sequential order (measured 1.5e-5), true peak
@@ -484,8 +486,8 @@ int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
 /* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_stereometer_bank_set_option pins one):
  *   sequential kernels — the reference's operation order: points bit-exact, rho error 0 against the CPU restatement —
  *       for single-stream handles, calls of fewer than 8 blocks or fewer than 512 (stream, block) items, channel counts other than 2,
- *       blocks that are not a multiple of 16 frames (or shorter than 32), ragged calls, and any call whose PCM is not finite;
- *   chunk-parallel kernels (every block of the call in parallel, block-boundary states by a scan) for 2-channel calls of
+ *       blocks that are not a multiple of 16 frames (or shorter than 32), and any call whose PCM is not finite;
+ *   chunk-parallel kernels (every block of the call in parallel, block-boundary states by a scan) for 2-channel lock-step AND ragged calls of
  *       >= 8 blocks and >= 512 (stream, block) items.  Same arithmetic, different evaluation order of the f32 band filters: points
  *       within 1e-4 of full scale (measured 2.9e-5), rho within 1e-6 on bands within 16 dB of the full level (measured 6e-8) and
  *       within the reference's own f32 filter noise elsewhere (tests/parity.py::check_chunked_rho).  NOT bit-identical to the
