@@ -47,6 +47,14 @@ def test_no_cpu_fallback_without_a_device(omx):
     with pytest.raises(capi.OmxError) as e:
         capi.SpectrogramProcessor(omx, capi.SpectrogramConfig())
     assert e.value.status == capi.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    # the many-stream banks and the capture group (VisualManager fan-out) refuse just as loudly
+    from openmeters_amd import banks, pipeline
+    for make in (lambda: banks.LoudnessBank(omx, capi.LoudnessConfig(), 4, 2), lambda: banks.StereometerBank(omx, capi.StereometerConfig(), 4),
+                 lambda: banks.OscilloscopeBank(omx, capi.OscilloscopeConfig(), 4),
+                 lambda: pipeline.CaptureGroup(omx, 4, spectrogram=capi.SpectrogramConfig(), loudness=capi.LoudnessConfig())):
+        with pytest.raises(capi.OmxError) as e:
+            make()
+        assert e.value.status == capi.ERR_NO_DEVICE
 
 
 def test_device_selection_entry_points(omx):
