@@ -2,6 +2,8 @@
 // length bookkeeping, config updates, EMA alpha) and src/dsp.rs:399-420 (RBJ Butterworth design).
 #include "stereometer.hpp"
 
+#include <cstdlib>
+
 namespace omx {
 
 constexpr float kBandSplitsHz[2] = {200.0f, 2000.0f};  // reference src/util/audio.rs:26
@@ -245,12 +247,22 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
     const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && items_live >= 512));
     last_form_ = chunked ? 2 : 1;
     auto run_chunked = [&]() {  // (after the plan kernel in a ragged call: the per-stream history positions are its output)
-        if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
-            transition_.upload(band_transitions(lp_lo, hp_lo, lp_hi, hp_hi, block_frames), stream);
+        // chunks shorter than blocks while the call has too few (stream, block) items to give every SIMD two wavefronts
+        static const int forced_cpb = [] {
+            const char* e = std::getenv("OMX_STEREO_CPB");  // tuning hook: 1 / 2 / 4
+            return e ? std::atoi(e) : 0;
+        }();
+        uint32_t cpb = 1;
+        while (cpb < 4 && (uint64_t)n_streams_ * n_blocks * cpb < 32768 && block_frames % (cpb * 2 * 16) == 0 && block_frames / (cpb * 2) >= 64) cpb *= 2;
+        if (forced_cpb == 1 || forced_cpb == 2 || forced_cpb == 4)
+            if (block_frames % ((uint64_t)forced_cpb * 16) == 0 && block_frames / forced_cpb >= 32) cpb = (uint32_t)forced_cpb;
+        const uint64_t chunk_frames = block_frames / cpb;
+        if (transition_rate_ != cfg_.sample_rate || transition_frames_ != chunk_frames) {
+            transition_.upload(band_transitions(lp_lo, hp_lo, lp_hi, hp_hi, chunk_frames), stream);
             transition_rate_ = cfg_.sample_rate;
-            transition_frames_ = block_frames;
+            transition_frames_ = chunk_frames;
         }
-        const uint64_t items = (uint64_t)n_streams_ * n_blocks;
+        const uint64_t items = (uint64_t)n_streams_ * n_blocks * cpb;
         chunk_state_.reserve((size_t)items * 3 * 16);
         chunk_moments_.reserve((size_t)items * 12);
         bad_.reserve(1);
@@ -260,8 +272,9 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         StereoChunkArgs ca{};
         ca.pcm = d_pcm;
         ca.frames_total = total;
-        ca.block_frames = (uint32_t)block_frames;
-        ca.n_blocks = (uint32_t)n_blocks;
+        ca.block_frames = (uint32_t)chunk_frames;
+        ca.n_blocks = (uint32_t)(n_blocks * cpb);
+        ca.cpb = cpb;
         ca.n_streams = n_streams_;
         ca.m00 = sa.fmt.m[0][0];
         ca.m10 = sa.fmt.m[1][0];
@@ -285,7 +298,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         ca.blocks_v = sa.blocks_v;
         ca.reset_v = sa.reset_v;
         ca.start_v = sa.start_v;
-        launch_stereometer_chunked(ca, transition_.ptr, std::pow(1.0 - alpha_, (double)block_frames), stream);
+        launch_stereometer_chunked(ca, transition_.ptr, std::pow(1.0 - alpha_, (double)chunk_frames), stream);
         OMX_HIP(hipGetLastError());
         // non-finite input / output breaks the linearity the chunks rely on (Biquad::process resets, dsp.rs:428-431): the
         // sequential kernel then redoes the whole call from the saved state (it exits at once when the flag is clear)

@@ -63,7 +63,8 @@ void launch_stereometer_points_ragged(const float* history, uint32_t n_streams, 
 struct StereoChunkArgs {
     const float* pcm;  // [n_streams][frames_total][2]
     uint64_t frames_total;
-    uint32_t block_frames, n_blocks, n_streams;
+    uint32_t block_frames, n_blocks, n_streams;  // chunk length, chunks per stream (= blocks x cpb), streams
+    uint32_t cpb;                                // chunks per block (1, 2 or 4): block_frames x cpb = the call's block length
     float m00, m10, m01, m11;  // stereo fold weights: left = (0 + s0 m00) + s1 m10, right = (0 + s0 m01) + s1 m11
     BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;
     uint32_t analyze_bands, emit_band_points;
@@ -72,7 +73,7 @@ struct StereoChunkArgs {
     float* history;
     uint32_t hist_frames;
     uint64_t hist_pos[4];
-    float* correlations;     // [n_streams][n_blocks][4]
+    float* correlations;     // [n_streams][n_blocks / cpb][4]: one row per BLOCK
     float* chunk_state;      // [n_streams * n_blocks][3 bands][8 states][2 channels]
     double* chunk_moments;   // [n_streams * n_blocks][4 bands][3]
     uint32_t* bad;           // set when a non-finite sample or filter output was seen: the caller re-runs the sequential kernel

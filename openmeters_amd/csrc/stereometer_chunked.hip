@@ -14,6 +14,9 @@
 // relative); the parity bars are rho <= 1e-6 and points <= 1e-6 (tests/test_gpu_parity_meters.py).  What is NOT linear — the
 // non-finite reset of Biquad::process — is detected (poison accumulator, non-finite input) and sends the WHOLE call through the
 // sequential kernel again from the saved state, so such input keeps the reference's behaviour exactly.
+// Chunks may be shorter than blocks (cpb = chunks per block: 2 or 4 when a call has too few (stream, block) items to fill the SIMDs,
+// e.g. 256 streams x 64 blocks = 256 workgroups of three wavefronts): every kernel then works on chunks, the correlations of a
+// block are those of its last chunk, and the once-per-block denormal flush is applied at block ends only.
 // Single-stream handles and short calls stay on the sequential kernels (bit-identical form, the A/B reference).
 #include "stereometer.hpp"
 
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
         const uint64_t item = item0 + row;
         live[n] = q < 512u && item < items;
         const uint64_t s = live[n] ? item / a.n_blocks : 0, c = live[n] ? item % a.n_blocks : 0;
-        if constexpr (RAGGED) live[n] = live[n] && c < a.blocks_v[s];  // a stream's unused block slots hold anything
+        if constexpr (RAGGED) live[n] = live[n] && c < a.blocks_v[s] * a.cpb;  // a stream's unused block slots hold anything
         src[n] = a.pcm + (s * a.frames_total + c * L) * 2u + part * 4u;
         dst[n] = row * ROW_FLOATS + part * 4u;
     }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
     uint32_t blocks_s = a.n_blocks;
     bool mine = in_call;
     if constexpr (RAGGED) {
-        blocks_s = in_call ? a.blocks_v[s] : 0u;
+        blocks_s = in_call ? a.blocks_v[s] * a.cpb : 0u;
         mine = c < blocks_s;
         if (__ballot(mine) == 0ull) return;  // (the three wavefronts of the workgroup see the same 64 items)
     }
@@ -228,7 +231,7 @@ template <int N>
 __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const double* __restrict__ Tp /* [6][8][8] powers 1,2,..32 */,
                                                  uint32_t s, uint32_t r, uint32_t ch, uint32_t lane) {
     StereoLaneState& st = a.state[(uint64_t)s * 4u + r + 1u];
-    const uint32_t nb = a.blocks_v ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t nb = a.blocks_v ? a.blocks_v[s] * a.cpb : a.n_blocks;  // chunks of this stream
     const bool reset = a.reset_v != nullptr && a.reset_v[s] != 0;  // reset_audio (:92-97) of this stream before its blocks
     double carry[N];
 #pragma unroll
@@ -273,9 +276,11 @@ __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const
             double start = shfl_up_f64(x[k], 1);
             if (lane == 0) start = carry[k];
             const float v = (float)start;
-            if (live) cs[2 * k + ch] = fabsf(v) < 1.0e-20f ? 0.0f : v;  // the block's TRUE start state replaces its zero-state end state
+            // (the flush belongs to block ends, :134-140: a chunk that starts inside a block takes its state unflushed)
+            const bool at_block = c % a.cpb == 0u;
+            if (live) cs[2 * k + ch] = at_block && fabsf(v) < 1.0e-20f ? 0.0f : v;  // the chunk's TRUE start state replaces its zero-state end state
             const float e = (float)shfl_f64(x[k], (int)last);
-            carry[k] = fabsf(e) < 1.0e-20f ? 0.0 : (double)e;            // the filters carry f32 states
+            carry[k] = (c0 + last + 1u) % a.cpb == 0u && fabsf(e) < 1.0e-20f ? 0.0 : (double)e;  // the filters carry f32 states
         }
     }
     if (lane == 0 && (nb != 0u || reset)) {
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void stereo_scan_moments_kernel(StereoChunkArg
     const uint32_t s = w >> 2, b = w & 3u;
     const bool active = b == 0 || a.analyze_bands != 0;
     StereoLaneState& st = a.state[(uint64_t)s * 4u + b];
-    const uint32_t nb = a.blocks_v ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t nb = a.blocks_v ? a.blocks_v[s] * a.cpb : a.n_blocks;  // chunks of this stream
     const bool reset = a.reset_v != nullptr && a.reset_v[s] != 0;
     double carry[3] = {reset ? 0.0 : st.moments[0], reset ? 0.0 : st.moments[1], reset ? 0.0 : st.moments[2]};
     double dp[6];  // decay^(2^k)
@@ -327,9 +332,10 @@ __global__ __launch_bounds__(256) void stereo_scan_moments_kernel(StereoChunkArg
                     if ((int)lane >= d) x[k] += dp[step] * up;
                 }
             }
+            const bool block_end = (c + 1u) % a.cpb == 0u;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                if (fabs(x[k]) < 1.0e-30) x[k] = 0.0;  // flush_denormals once per block (:134-136)
+                if (block_end && fabs(x[k]) < 1.0e-30) x[k] = 0.0;  // flush_denormals once per block (:134-136)
             const double denom = sqrt(x[1] * x[2]);  // Correlator::value (:48-56)
             if (denom > 1e-12) {
                 const double v = x[0] / denom;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void stereo_scan_moments_kernel(StereoChunkArg
 #pragma unroll
             for (int k = 0; k < 3; ++k) carry[k] = shfl_f64(x[k], (int)last);
         }
-        if (live) a.correlations[((uint64_t)s * a.n_blocks + c) * 4u + b] = value;
+        if (live && (c + 1u) % a.cpb == 0u) a.correlations[((uint64_t)s * (a.n_blocks / a.cpb) + c / a.cpb) * 4u + b] = value;
     }
     if (lane == 0 && (nb != 0u || reset)) {
         st.moments[0] = carry[0];
