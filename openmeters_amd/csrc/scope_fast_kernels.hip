@@ -18,7 +18,7 @@
 // reduction are fused (mean + peak of a span from its sum / max / min: |x - m| is monotone in x under rounding).
 //
 // Summation order (parity): sums over a span are taken per lane over elements lane, lane + 512, ... (sweeps: groups of four
-// consecutive elements, lane + 64 k), then by a DPP prefix scan in lane order, then over the wavefronts in index order.  That is
+// consecutive elements, lane + 64 k), then by a DPP prefix scan in lane order, then over the eight wavefronts as a three-level tree.  That is
 // neither the reference's sequential order (correlation_stats, :206-208) nor its four stride-4 chains (:210-227): a bit-equal
 // order would put a 1920-long dependent f32 chain in front of every search (7 us per block against the 4 us the whole block
 // takes here), see DESIGN §2 for what is checked instead (exact-arithmetic third leg, near-tie test).
@@ -142,10 +142,10 @@ __device__ __forceinline__ int reduce_lane(int m) {
 }
 
 // K reductions over the workgroup behind ONE barrier: lane 63 of every wavefront publishes its K results into one of two
-// alternating slot sets; after the barrier every thread combines the W wavefronts in index order.  A slot set is rewritten two
+// alternating slot sets; after the barrier every thread combines the W wavefronts (a tree for W = 8).  A slot set is rewritten two
 // reductions later, i.e. after another barrier every thread has passed: no trailing barrier.
 template <int W>
-struct RedSlots {
+struct alignas(16) RedSlots {
     float f[2][8][W];
     uint32_t u[2][W];
 };
@@ -170,11 +170,15 @@ struct Reducer {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int op = (OPS >> (2 * k)) & 3;
-            float r = slots->f[phase][k][0];
+            auto comb = [&](float x, float y) { return op == OP_SUM ? x + y : (op == OP_MAX ? fmaxf(x, y) : fminf(x, y)); };
+            float r;
+            if constexpr (W == 8) {  // two 16-byte reads and a three-level tree instead of eight reads and a seven-long chain
+                const v4f lo = *reinterpret_cast<const v4f*>(&slots->f[phase][k][0]), hi = *reinterpret_cast<const v4f*>(&slots->f[phase][k][4]);
+                r = comb(comb(comb(lo.x, lo.y), comb(lo.z, lo.w)), comb(comb(hi.x, hi.y), comb(hi.z, hi.w)));
+            } else {
+                r = slots->f[phase][k][0];
 #pragma unroll
-            for (int w = 1; w < W; ++w) {
-                const float o = slots->f[phase][k][w];
-                r = op == OP_SUM ? r + o : (op == OP_MAX ? fmaxf(r, o) : fminf(r, o));
+                for (int w = 1; w < W; ++w) r = comb(r, slots->f[phase][k][w]);
             }
             v[k] = uni(r);
         }
