@@ -407,8 +407,8 @@ int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
  *       calls of >= 8 blocks (ragged: max_blocks >= 8)
  *       and >= 4096 (slot, block) items whose block length is a multiple of 64 frames and which start at a multiple of 64 frames
  *       since the last reset: 1-8 channels, every sample rate (44.1 / 88.2 kHz windows are off the 64-sample grid: loudness_chunked.hip).
- *       Same quantities to ~1e-15 of a window sum; LUFS / RMS within 1e-4 dB of the sequential order (measured 1.5e-5), true peak
- *       bit-identical.  OMX_OPT_KERNEL_FORM = 1 pins the sequential kernels. */
+ *       Same quantities to ~1e-15 of a window sum (the K-weighting recurrence runs on fused multiply-adds there); LUFS / RMS within
+ *       1e-4 dB of the sequential order (measured 1.5e-5), true peak bit-identical.  OMX_OPT_KERNEL_FORM = 1 pins the sequential kernels. */
 /* test hook: which evaluation order the bank's last process call took — 1 = sequential kernels, 2 = chunk-parallel (0 = no call yet) */
 int omx_debug_loudness_bank_last_form(const omx_loudness_bank* b);
 int omx_loudness_bank_process(omx_loudness_bank* b, const float* pcm, int pcm_on_device,
@@ -488,8 +488,8 @@ int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
  *       for single-stream handles, calls of fewer than 8 blocks or fewer than 512 (stream, block) items, channel counts other than 2,
  *       blocks that are not a multiple of 16 frames (or shorter than 32), and any call whose PCM is not finite;
  *   chunk-parallel kernels (every block of the call in parallel, block-boundary states by a scan) for 2-channel lock-step AND ragged calls of
- *       >= 8 blocks and >= 512 (stream, block) items.  Same arithmetic, different evaluation order of the f32 band filters: points
- *       within 1e-4 of full scale (measured 2.9e-5), rho within 1e-6 on bands within 16 dB of the full level (measured 6e-8) and
+ *       >= 8 blocks and >= 512 (stream, block) items.  The same f32 band filters evaluated block-parallel on fused multiply-adds: points
+ *       within 1e-4 of full scale (measured 2.5e-5), rho within 1e-6 on bands within 16 dB of the full level (measured 6e-8) and
  *       within the reference's own f32 filter noise elsewhere (tests/parity.py::check_chunked_rho).  NOT bit-identical to the
  *       sequential order: a host that needs the reference's exact bits sets OMX_OPT_KERNEL_FORM = 1. */
 int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int pcm_on_device,
