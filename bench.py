@@ -250,10 +250,12 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (rank 0 joins after its N = 1 leg: the others wait for its store meanwhile — a generous rendezvous timeout)
+        from datetime import timedelta
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=timedelta(minutes=30))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(minutes=30))
 
     import openmeters_amd
     from openmeters_amd import capi
