@@ -248,10 +248,13 @@ int omx_spectrogram_bank_kernel_time(omx_spectrogram_bank* b, double* avg_ms, ui
 enum {
     OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
     OMX_OPT_FORCE_GENERIC = 2, /* value != 0: route through the generic any-size kernels (A/B checks) */
-    OMX_OPT_KERNEL_FORM = 3    /* spectrogram bank, reassigned 4096 / hop any: which of the equivalent kernel forms runs.
+    OMX_OPT_KERNEL_FORM = 3,   /* spectrogram bank, reassigned 4096 / hop any: which of the equivalent kernel forms runs.
                                 * 0 = tuned kernel (default); 1 = the previous tuned kernel (five transforms per frame);
                                 * 30 = size-templated kernel; 31 = three-kernel form through an HBM scratch.  All compute
                                 * the same columns (tests cross-check them); unknown values are rejected. */
+    OMX_OPT_LOUDNESS_REBASE_FRAMES = 4 /* loudness bank: frames after which the chunk-parallel form takes its running totals afresh from
+                                * the sample ring (default 2^22; they bound the absolute error of a window sum at ~1e-16 of the energy
+                                * played since — loudness_chunked.hip).  A test / tuning hook: results do not depend on it beyond 1e-6 dB */
 };
 /* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the phase-timing builds of the TUNING library
  * (`make TUNING=1`; setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store).

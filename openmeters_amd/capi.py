@@ -38,7 +38,7 @@ AVG_NONE, AVG_EXPONENTIAL, AVG_PEAK_HOLD = range(3)
 # TriggerMode (reference src/visuals/oscilloscope/processor.rs:21-25)
 TRIGGER_ZERO_CROSSING, TRIGGER_STABLE = range(2)
 COLUMN_REASSIGNED, COLUMN_CLASSIC = range(2)
-OPT_KERNEL_TIMING, OPT_FORCE_GENERIC, OPT_KERNEL_FORM = 1, 2, 3
+OPT_KERNEL_TIMING, OPT_FORCE_GENERIC, OPT_KERNEL_FORM, OPT_LOUDNESS_REBASE_FRAMES = 1, 2, 3, 4
 OPT_GROUP_STATS, OPT_GROUP_SHARED_INGEST = 16, 17
 VISUAL_SPECTROGRAM, VISUAL_SPECTRUM, VISUAL_LOUDNESS, VISUAL_STEREOMETER, VISUAL_OSCILLOSCOPE, VISUAL_WAVEFORM = 1, 2, 4, 8, 16, 32
 STATS_COLUMN_COUNT = 12

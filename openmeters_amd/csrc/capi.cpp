@@ -447,6 +447,10 @@ int omx_loudness_bank_set_option(omx_loudness_bank* b, uint32_t option, uint64_t
         b->impl.chunked_mode(value == 0 ? -1 : (value == 1 ? 0 : 1));
         return OMX_NONE;
     }
+    if (option == OMX_OPT_LOUDNESS_REBASE_FRAMES) {
+        b->impl.rebase_frames(value);
+        return OMX_NONE;
+    }
     return OMX_ERR_INVALID;
 }
 

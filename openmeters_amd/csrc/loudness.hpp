@@ -142,6 +142,8 @@ private:
     DeviceBuffer<uint32_t> bad_;
     bool q_valid_ = false;
     uint64_t q_len_ = 0;     // entries per slot of q_ring_ / tails_ (power of two, grows with the call size)
+    uint64_t q_age_ = 0;     // frames the running totals have accumulated since they were last taken from the ring
+    uint64_t rebase_frames_ = 1ull << 22;  // OMX_OPT_LOUDNESS_REBASE_FRAMES
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;
     int last_form_ = 0;      // 1 = sequential kernels, 2 = chunk-parallel (omx_debug_loudness_bank_last_form)
@@ -155,6 +157,7 @@ private:
     RaggedStaging r_staging_;
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }
+    void rebase_frames(uint64_t frames) { rebase_frames_ = frames; }
     int last_form() const { return last_form_; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: snapshots in pinned host memory
 };

@@ -679,6 +679,36 @@ def test_loudness_chunk_parallel_form_at_44100_alternates_with_the_sequential_fo
         at += block * n_blocks
 
 
+@pytest.mark.parametrize("rebase", [4096, 1 << 22])
+def test_loudness_chunk_parallel_form_keeps_its_accuracy_across_a_100_dB_drop_and_periodic_rebasing(omx, oracle, rebase):
+    """Window sums of the chunk-parallel form are differences of running totals: a loud passage followed by a very quiet one is the
+    case where the totals' size, not the window's, sets the error.  4 s at full scale, then a -100 dBFS tone: every snapshot of the
+    quiet passage within 1e-4 dB of the oracle — with the totals taken afresh from the sample ring every 4096 frames (the rebuild
+    path run dozens of times, OMX_OPT_LOUDNESS_REBASE_FRAMES) and with the default interval."""
+    S, C, block = 3, 2, 256
+    loud_blocks, quiet_blocks = 750, 300
+    t = np.arange(block * (loud_blocks + quiet_blocks)) / FS
+    pcm = np.empty((S, len(t), C), np.float32)
+    for s in range(S):
+        tone = np.sin(2 * np.pi * (500.0 + 37.0 * s) * t)
+        gain = np.where(np.arange(len(t)) < block * loud_blocks, 0.9, 1e-5)
+        pcm[s, :, 0] = (gain * tone).astype(np.float32)
+        pcm[s, :, 1] = (0.8 * gain * tone).astype(np.float32)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    bank.set_option(capi.OPT_LOUDNESS_REBASE_FRAMES, rebase)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig()) for _ in range(S)]
+    at = 0
+    for n_blocks in (250, 250, 250, 150, 150):
+        part = pcm[:, at:at + block * n_blocks]
+        assert bank.process_host(part, block, C, FS) is not None and bank.last_form() == 2
+        for s in range(S):
+            want = [refs[s].process_block(AudioBlock(part[s, k:k + block].reshape(-1), C, FS)) for k in range(0, block * n_blocks, block)]
+            for blk in sorted(set([0, 1, n_blocks // 3, n_blocks // 2, n_blocks - 2, n_blocks - 1])):
+                snapshots_close(bank.fetch(s, blk), want[blk])
+        at += block * n_blocks
+
+
 def test_loudness_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx):
     S, C, n_blocks = 4, 2, 16
     pcm = np.stack([cfg3_pcm(90 + s, 256 * n_blocks * 2, C) for s in range(S)])
