@@ -258,7 +258,7 @@ int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, ui
         case OMX_OPT_KERNEL_TIMING: b->impl.timer().enabled = value != 0; return OMX_NONE;
         case OMX_OPT_FORCE_GENERIC: b->impl.force_generic(value != 0); return OMX_NONE;
         case OMX_OPT_KERNEL_FORM:
-            if (value != 0 && value != 1 && value != 30 && value != 31) return OMX_ERR_INVALID;
+            if (value != 0 && value != 1 && value != 2 && value != 30 && value != 31) return OMX_ERR_INVALID;
             b->impl.kernel_form((int)value);
             return OMX_NONE;
         default: return OMX_ERR_INVALID;

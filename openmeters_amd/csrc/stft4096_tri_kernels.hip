@@ -1,0 +1,342 @@
+// K2 (round 4 form): the pair kernel's arithmetic at THREE workgroups per CU (reference spectrogram/processor.rs:318-348,
+// :439-488, :546-567).  Same four 4096-point transforms per column as stft4096_pair_kernels.hip; what changes is what a
+// workgroup holds while it runs them:
+//   * ONE padded 4096-complex LDS buffer, time-shared by the two chains of every dual transform.  The chains are staggered by
+//     half a pass: while chain a's values cross the buffer, chain b's butterflies run in registers, and the other way round — every
+//     barrier-to-barrier segment carries the LDS traffic of one chain and the arithmetic of the other.
+//   * <= 168 VGPR: nothing is prefetched across a transform (bin normalisation, the real-part samples and the time-weighted
+//     window are requested in the phase that consumes them — three wavefronts per SIMD cover that latency), column b's analytic
+//     slice waits in LDS (its imaginary half; the real half is re-read from the ring) instead of in 32 registers, and
+//     FFT(t w s) is windowed in the time domain (the reference's own twindow table, processor.rs:601-608) so that only ONE
+//     spectrum needs its neighbour bins (18 KiB of natural-order bins instead of 37).
+// LDS: 34 816 (buffer) + 16 384 (column b's imaginary half) + 2 048 (pass-2 twiddles) + 160 = 53 408 B -> three workgroups
+// (twelve wavefronts) per CU, where the pair kernel's 70 KiB / 254 VGPR allow two.
+#include "stft_kernels.hpp"
+
+#include "buffer_device.hpp"
+#include "fft_device.hpp"
+#include "reassign_device.hpp"
+#include "twiddle_run_device.hpp"
+
+namespace omx {
+
+namespace {
+
+__device__ __forceinline__ bool tri_block_to_stream_chunk(uint32_t n_streams, uint32_t chunks, uint32_t& s, uint32_t& chunk) {
+    const uint32_t b = blockIdx.x;  // block b runs on XCD b % 8; stream s is pinned to XCD s % 8 (same map as the pair kernel)
+    const uint32_t xcd = b & 7u, q = b >> 3;
+    s = (q / chunks) * 8u + xcd;
+    chunk = q % chunks;
+    return s < n_streams;
+}
+
+template <int TT>
+__device__ __forceinline__ v2f w8_at(v2f base) {  // exp(-2 pi i (j + 256 TT) / 8192) / 2 from thread j's table value
+    return rotate128<4 * TT>(base);
+}
+
+__device__ __forceinline__ void x_write1(const v2f (&v)[16], v2f* X, int j) {  // pass-1 outputs: y[16 j + t]
+    const int base = 17 * j;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[base + t] = v[DFT16_OUT(t)];
+}
+__device__ __forceinline__ void x_write2(const v2f (&v)[16], v2f* X, int j) {  // pass-2 outputs: z[(j / 16) 256 + j % 16 + 16 t]
+    const int base = (j >> 4) * 272 + (j & 15);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[base + 17 * t] = v[DFT16_OUT(t)];
+}
+__device__ __forceinline__ void x_read(v2f (&v)[16], const v2f* X, int j) {  // inputs of passes 2 and 3: element j + 256 t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = X[pad16(j + 256 * t)];
+}
+template <bool INV>
+__device__ __forceinline__ void twiddle2(v2f (&v)[16], const v2f* tw2, int j) {
+    const unsigned k = (unsigned)j & 15u;
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw2[k * (unsigned)t]);
+}
+template <bool INV>
+__device__ __forceinline__ void twiddle3(v2f (&v)[16], const v2f (&tw3)[15]) {
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw3[t - 1]);
+}
+__device__ __forceinline__ void natural(v2f (&v)[16]) {  // X[k] sits in v[DFT16_OUT(k)] after dft16: rename (constant indices, no moves)
+    v2f r[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) r[t] = v[DFT16_OUT(t)];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = r[t];
+}
+
+// Two 4096-point transforms through ONE buffer: x[j + 256 t] in a[t] / b[t] on entry, X[j + 256 t] on return.  The caller has a
+// barrier between its last use of X and this call; on return other wavefronts may still be reading X (chain b's pass-3 inputs).
+template <bool INV>
+__device__ __forceinline__ void tri_dual(v2f (&a)[16], v2f (&b)[16], v2f* X, const v2f* tw2, const v2f (&tw3)[15], int j) {
+    dft16<INV>(a);
+    x_write1(a, X, j);
+    __syncthreads();
+    x_read(a, X, j);
+    dft16<INV>(b);
+    __syncthreads();  // every pass-2 input of chain a is in registers
+    x_write1(b, X, j);
+    twiddle2<INV>(a, tw2, j);
+    __syncthreads();
+    x_read(b, X, j);
+    dft16<INV>(a);
+    __syncthreads();
+    x_write2(a, X, j);
+    twiddle2<INV>(b, tw2, j);
+    __syncthreads();
+    x_read(a, X, j);
+    dft16<INV>(b);
+    __syncthreads();
+    x_write2(b, X, j);
+    twiddle3<INV>(a, tw3);
+    __syncthreads();
+    x_read(b, X, j);
+    dft16<INV>(a);
+    natural(a);
+    twiddle3<INV>(b, tw3);
+    dft16<INV>(b);
+    natural(b);
+}
+
+}  // namespace
+
+constexpr size_t kTriLds = (size_t)FFT4096_LDS * sizeof(v2f) + 4096 * sizeof(float) + 256 * sizeof(v2f) + 36 * sizeof(uint32_t) + 4 * sizeof(float);
+
+__global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* X = reinterpret_cast<v2f*>(smem_raw);
+    float* imb = reinterpret_cast<float*>(X + FFT4096_LDS);        // [4096] Im analytic[2048 + i] of column b
+    v2f* tw2_lds = reinterpret_cast<v2f*>(imb + 4096);             // [256] exp(-2 pi i k / 256)
+    uint32_t* scan = reinterpret_cast<uint32_t*>(tw2_lds + 256);   // [9][4] wave counts
+    float* hil = reinterpret_cast<float*>(scan + 36);              // X[0]/2, X[4096]/2 of both columns
+
+    const uint32_t chunks = (a.n_cols + 1u) / 2u;
+    uint32_t s, chunk;
+    if (!tri_block_to_stream_chunk(a.n_streams, chunks, s, chunk)) return;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    const int lane = j & 63, wave = j >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint32_t mask32 = (uint32_t)(a.cap - 1);
+    const uint32_t bytemask = mask32 << 2;
+    const char* ring_bytes = reinterpret_cast<const char*>(ring);
+    const long long last_nonzero = a.last_nonzero[s];
+    const uint32_t* cols_p = a.cols;
+    const uint64_t* tails_p = a.tails;
+    const uint32_t n_cols_s = cols_p ? cols_p[s] : a.n_cols;
+    const uint64_t tail_s = tails_p ? tails_p[s] : a.tail;
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+
+    const uint32_t col0 = chunk * 2u;
+    if (col0 >= n_cols_s) return;
+    const bool have1 = col0 + 1u < n_cols_s;
+    const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
+    const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
+    uint32_t* count_a = a.counts + (uint64_t)s * a.n_cols + col0;
+    uint32_t* count_b = a.counts + (uint64_t)s * a.n_cols + col1;
+
+    const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
+    const uint32_t off_a = pa32 & mask32, hop_bytes = (pb32 - pa32) * 4u;
+    const bool direct = (uint64_t)off_a + (uint64_t)(pb32 - pa32) + 8192ull <= a.cap && ((p0a | p0b) & 1ull) == 0;
+    const GlobalBuffer windowb = global_buffer(ring + off_a, hop_bytes + 8192u * 4u);
+    const GlobalBuffer tw4096b = global_buffer(a.tw4096, 4096u * 8u), tw8192b = global_buffer(a.tw8192, 4096u * 8u),
+                       normb = global_buffer(a.bin_norm, 2049u * 4u), twinb = global_buffer(a.twindow, 4096u * 4u);
+
+    // ---- 1. packed real FFTs of the two 8192-sample windows ---------------------------------------------------------------
+    v2f va[16], vb[16];
+    if (direct) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            va[t] = load_v2f(windowb, ju * 8u, 2048u * (unsigned)t);
+            vb[t] = load_v2f(windowb, ju * 8u, hop_bytes + 2048u * (unsigned)t);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qa = pa32 + 2u * (ju + 256u * (unsigned)t), qb = pb32 + 2u * (ju + 256u * (unsigned)t);
+            va[t] = v2f{ring[qa & mask32], ring[(qa + 1u) & mask32]};
+            vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
+        }
+    }
+    v2f tw3[15];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) tw3[t - 1] = load_v2f(tw4096b, ju * 8u * (unsigned)t, 0);
+    tw2_lds[j] = a.tw256[ju];
+    const v2f w8_base = load_v2f(tw8192b, ju * 8u, 0);
+    const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;
+    if (silent_a && (silent_b || !have1)) {  // silent fast path (:307-316)
+        if (j == 0) {
+            *count_a = 0;
+            if (have1) *count_b = 0;
+        }
+        return;
+    }
+    tri_dual<false>(va, vb, X, tw2_lds, tw3, j);  // v[t] = Zf[j + 256 t]
+
+    // ---- 2. Hilbert transform with ONE half-length inverse per column, one column at a time through X ----------------------
+    const int part = (j ? pad16(4096 - j) : 4352) - 272 * 15;
+    auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const v2f z = v[t], zr = X[part + 272 * (15 - t)];
+            const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
+            v2f w8;
+            switch (t) {  // compile-time after unrolling
+                case 0: w8 = w8_at<0>(w8_base); break;
+                case 1: w8 = w8_at<1>(w8_base); break;
+                case 2: w8 = w8_at<2>(w8_base); break;
+                case 3: w8 = w8_at<3>(w8_base); break;
+                case 4: w8 = w8_at<4>(w8_base); break;
+                case 5: w8 = w8_at<5>(w8_base); break;
+                case 6: w8 = w8_at<6>(w8_base); break;
+                case 7: w8 = w8_at<7>(w8_base); break;
+                case 8: w8 = w8_at<8>(w8_base); break;
+                case 9: w8 = w8_at<9>(w8_base); break;
+                case 10: w8 = w8_at<10>(w8_base); break;
+                case 11: w8 = w8_at<11>(w8_base); break;
+                case 12: w8 = w8_at<12>(w8_base); break;
+                case 13: w8 = w8_at<13>(w8_base); break;
+                case 14: w8 = w8_at<14>(w8_base); break;
+                default: w8 = w8_at<15>(w8_base); break;
+            }
+            y[t] = cmulc(sum, w8) - cmul(dif, w8);
+            if (t == 0 && j == 0) y[t] = v2f{0.0f, 0.0f};
+        }
+    };
+    v2f ya[16], yb[16];
+    __syncthreads();  // pass 3 of chain b still reads X
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = va[t];
+    if (j == 0) {
+        hil[0] = (va[0].x + va[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (va[0].x - va[0].y) * 0.5f;  // X[4096] / 2
+        hil[2] = (vb[0].x + vb[0].y) * 0.5f;
+        hil[3] = (vb[0].x - vb[0].y) * 0.5f;
+    }
+    __syncthreads();
+    hilbert_spectrum(ya, va);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = vb[t];
+    __syncthreads();
+    hilbert_spectrum(yb, vb);
+    const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
+    __syncthreads();
+    tri_dual<true>(ya, yb, X, tw2_lds, tw3, j);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
+
+    // ---- 3. the analytic slices s[i] = analytic[2048 + i], i = j + 256 t ----------------------------------------------------
+    // real half of column a and the time-weighted window: requested here, consumed behind the two barriers of the gather
+    auto load_real_half = [&](float (&xr)[16], float (&twin)[16], uint32_t col_bytes, uint32_t p32) {
+        if (direct) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xr[t] = load_f32(windowb, ju * 4u, col_bytes + 8192u + 1024u * (unsigned)t);
+        } else {
+            const uint32_t q = p32 + 2048u + ju;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xr[t] = *reinterpret_cast<const float*>(ring_bytes + (((q + 256u * (unsigned)t) << 2) & bytemask));
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) twin[t] = load_f32(twinb, ju * 4u, 1024u * (unsigned)t);
+    };
+    float xra[16], twina[16];
+    load_real_half(xra, twina, 0u, pa32);
+    __syncthreads();
+    float* imag_a = reinterpret_cast<float*>(X);
+#pragma unroll
+    for (int t = 4; t < 12; ++t) {
+        *reinterpret_cast<v2f*>(imag_a + 2 * (j + 256 * t - 1024)) = ya[t];
+        *reinterpret_cast<v2f*>(imb + 2 * (j + 256 * t - 1024)) = yb[t];
+    }
+    __syncthreads();
+    const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / 4096.0f);
+    v2f* lin_z = X;  // [2306] natural-order bins of Z (slot 1 + k)
+
+    // ---- 4. per column: Z = FFT(s), T = FFT(t w s) as one dual transform; w and w' applied on the bins of Z -----------------
+    auto column = [&](const float (&xr)[16], const float (&twin)[16], const float* imag, float half_x0, float half_xn, bool silent, uint32_t col, uint32_t* count_out) {
+        v2f z[16], z2[16];
+        {
+            const float par = (j & 1) ? -half_xn : half_xn;  // (-1)^n: n = 2048 + i has j's parity
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                z[t] = v2f{4096.0f * xr[t] - half_x0 + par, imag[j + 256 * t]};
+                z2[t] = v2f{z[t].x * twin[t], z[t].y * twin[t]};
+            }
+        }
+        __syncthreads();  // the slice reads above / the previous column's neighbour reads still use X
+        tri_dual<false>(z, z2, X, tw2_lds, tw3, j);
+        float pn[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
+        __syncthreads();  // pass 3 still reads X
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lin_z[1 + j + 256 * t] = z[t];
+        if (wave_u == 0) lin_z[1 + j + 2048] = z[8];  // bins 2048 ... 2111: the Nyquist bin and its upper neighbour
+        if (j == 255) lin_z[0] = z[15];               // bin -1 = bin 4095
+        __syncthreads();
+        omx_spectrogram_point pts[9];
+        unsigned long long masks[9];
+        auto bins = [&](auto first, auto last) {
+            constexpr int T0 = decltype(first)::value, T1 = decltype(last)::value;
+            v2f nzm[T1 - T0], nzp[T1 - T0];
+#pragma unroll
+            for (int t = T0; t < T1; ++t) {
+                nzm[t - T0] = lin_z[j + 256 * t];
+                nzp[t - T0] = lin_z[j + 256 * t + 2];
+            }
+#pragma unroll
+            for (int t = T0; t < T1; ++t) {
+                const uint32_t bin = (uint32_t)(j + 256 * t);
+                const v2f zm = nzm[t - T0], zp = nzp[t - T0];
+                const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
+                const v2f bb{c0 * z[t].x + half_c1 * zs.x, c0 * z[t].y + half_c1 * zs.y};
+                const v2f bd{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / W) (Z[k-1] - Z[k+1])
+                const bool keep = reassign_flat(bin, bb, bd, z2[t], pn[t], rc, pts[t]) && (t < 8 || j == 0) && !silent;
+                masks[t] = __ballot(keep);
+                if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
+            }
+        };
+        bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        if (wave_u == 0) {
+            bins(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
+        } else {
+            masks[8] = 0ull;
+            if (lane == 0) scan[32 + wave] = 0u;
+        }
+        __syncthreads();
+        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        const uint32_t cnt = lane < 36 ? scan[lane] : 0u;
+        const uint32_t inc = wave_inclusive_sum(cnt);
+        const uint32_t exc = inc - cnt;
+        const uint32_t running = (uint32_t)__builtin_amdgcn_readlane((int)inc, 35);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, 4 * t + wave_u);
+            if ((masks[t] >> lane) & 1ull) {
+                const uint32_t pos = before + lanes_below(masks[t]);
+                *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
+            }
+        }
+        if (j == 0) *count_out = running;
+    };
+    column(xra, twina, imag_a, half_x0a, half_xna, silent_a, col0, count_a);
+    if (have1) {
+        float xrb[16], twinb_v[16];
+        load_real_half(xrb, twinb_v, hop_bytes, pb32);
+        column(xrb, twinb_v, imb, half_x0b, half_xnb, silent_b, col1, count_b);
+    }
+}
+
+void launch_stft_reassigned_4096_tri(const StftFastArgs& a, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kTriLds);
+    const uint32_t chunks = (a.n_cols + 1u) / 2u;
+    hipLaunchKernelGGL(stft_reassigned_4096_tri_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), kTriLds, stream, a);
+}
+
+}  // namespace omx

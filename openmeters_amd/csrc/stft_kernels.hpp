@@ -121,6 +121,7 @@ unsigned long long* k2_phase_buffer();  // device address of the phase counters 
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream);
 int stft_reassigned_4096_transforms_per_frame();  // of form 0
 void launch_stft_reassigned_4096_pair(const StftFastArgs& a, hipStream_t stream);  // stft4096_pair_kernels.hip
+void launch_stft_reassigned_4096_tri(const StftFastArgs& a, hipStream_t stream);   // stft4096_tri_kernels.hip (form 2)
 // tuning builds only (stft4096_swz_kernels.hip): the swizzled pair kernel and the one-column-per-workgroup kernel
 void launch_stft_reassigned_4096_swz_pair(const StftFastArgs& a, hipStream_t stream);
 void launch_stft_reassigned_4096_col(const StftFastArgs& a, hipStream_t stream);

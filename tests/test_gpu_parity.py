@@ -200,7 +200,7 @@ def test_spectrum_bank_all_hops_equal_per_block_snapshots(omx, oracle):
                 check_trace(got[0, wt], snaps[h].traces[0][wt])
 
 
-@pytest.mark.parametrize("form", [1, 30, 31])
+@pytest.mark.parametrize("form", [1, 2, 30, 31])
 def test_equivalent_kernel_forms_compute_the_same_columns(omx, oracle, form):
     """OMX_OPT_KERNEL_FORM: the previous tuned kernel (1), the size-templated kernel (30) and the three-kernel form (31)
     must produce the tuned kernel's columns: every form against the oracle at the usual bars, and against form 0 with the

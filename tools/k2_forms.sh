@@ -1,0 +1,7 @@
+#!/bin/bash
+# A/B the K2 kernel forms through the bench (run on the GPU box): OMX_K2_FORM = 0 pair kernel, 2 three-workgroups-per-CU kernel
+for rep in 1 2; do
+for f in ${FORMS:-0 2}; do
+  OMX_K2_FORM=$f python bench.py --steps ${STEPS:-50} --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('form $f', round(d['value']/1e6,2), 'Mframes/s ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4))"
+done
+done
