@@ -249,7 +249,8 @@ enum {
     OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
     OMX_OPT_FORCE_GENERIC = 2, /* value != 0: route through the generic any-size kernels (A/B checks) */
     OMX_OPT_KERNEL_FORM = 3,   /* spectrogram bank, reassigned 4096 / hop any: which of the equivalent kernel forms runs.
-                                * 0 = tuned kernel (default); 1 = the previous tuned kernel (five transforms per frame);
+                                * 0 = tuned kernel (default; round 4: three workgroups per CU); 1 = the round-1 kernel (five transforms
+                                * per frame); 2 = the round-2 pair kernel (two workgroups per CU, two LDS buffers);
                                 * 30 = size-templated kernel; 31 = three-kernel form through an HBM scratch.  All compute
                                 * the same columns (tests cross-check them); unknown values are rejected. */
     OMX_OPT_LOUDNESS_REBASE_FRAMES = 4 /* loudness bank: frames after which the chunk-parallel form takes its running totals afresh from

@@ -15,12 +15,23 @@
 
 #include "buffer_device.hpp"
 #include "fft_device.hpp"
+#include "fft_fused_device.hpp"
 #include "reassign_device.hpp"
 #include "twiddle_run_device.hpp"
 
 namespace omx {
 
 namespace {
+
+// TRI_KNOCK (pricing builds, WRONG columns): 1 no LDS traffic in the transforms, 2 no butterflies, 3 no barriers in the transforms, 4 no point stores
+#ifndef TRI_KNOCK
+#define TRI_KNOCK 0
+#endif
+#if TRI_KNOCK == 3
+#define TRI_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TRI_SYNC() __syncthreads()
+#endif
 
 __device__ __forceinline__ bool tri_block_to_stream_chunk(uint32_t n_streams, uint32_t chunks, uint32_t& s, uint32_t& chunk) {
     const uint32_t b = blockIdx.x;  // block b runs on XCD b % 8; stream s is pinned to XCD s % 8 (same map as the pair kernel)
@@ -35,30 +46,99 @@ __device__ __forceinline__ v2f w8_at(v2f base) {  // exp(-2 pi i (j + 256 TT) / 
     return rotate128<4 * TT>(base);
 }
 
+// Buffer layout.  TRI_SWZ (default): slot(n) = n ^ ((n >> 4) & 15), no padding — every access pattern of the three passes is
+// conflict-free under the gfx950 rules for the instructions hipcc picks here (single ds_read_b64: 32-lane groups over 64 banks;
+// ds_write_b64: 16-lane groups over 32 banks), and every address is one base register, an immediate offset and at most one v_xor.
+// The +1/16 padding of fft_device.hpp is conflict-free for 16-lane groups only: a 32-lane read spans 33 slots and pays a second cycle.
+#ifndef TRI_SWZ
+#define TRI_SWZ 0
+#endif
+#if TRI_SWZ
+constexpr int kTriSlots = 4096;
+__device__ __forceinline__ int xslot(int j) { return j ^ ((j >> 4) & 15); }  // slot of element j + 256 t = xslot(j) + 256 t
+// the 16 xor-ed write addresses are formed per call (one v_xor each): left to itself hipcc keeps all 32 of them in registers for the
+// whole kernel, which is what spills at 168
+__device__ __forceinline__ int per_call(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ void x_write1(const v2f (&v)[16], v2f* X, int j) {  // pass-1 outputs: y[16 j + t] -> slot 16 j + (t ^ (j & 15))
+    const int base = per_call(16 * j + (j & 15));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[base ^ t] = v[DFT16_OUT(t)];
+}
+__device__ __forceinline__ void x_write2(const v2f (&v)[16], v2f* X, int j) {  // pass-2 outputs: z[(j / 16) 256 + j % 16 + 16 t] -> ... + 16 t + ((j % 16) ^ t)
+    const int base = per_call((j >> 4) * 256 + (j & 15));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[(base ^ t) + 16 * t] = v[DFT16_OUT(t)];
+}
+#else
+constexpr int kTriSlots = FFT4096_LDS;
+__device__ __forceinline__ int xslot(int j) { return pad16(j); }  // pad16 is linear across multiples of 256: + 272 t
 __device__ __forceinline__ void x_write1(const v2f (&v)[16], v2f* X, int j) {  // pass-1 outputs: y[16 j + t]
     const int base = 17 * j;
+    if (TRI_KNOCK == 1) return;
 #pragma unroll
     for (int t = 0; t < 16; ++t) X[base + t] = v[DFT16_OUT(t)];
 }
 __device__ __forceinline__ void x_write2(const v2f (&v)[16], v2f* X, int j) {  // pass-2 outputs: z[(j / 16) 256 + j % 16 + 16 t]
     const int base = (j >> 4) * 272 + (j & 15);
+    if (TRI_KNOCK == 1) return;
 #pragma unroll
     for (int t = 0; t < 16; ++t) X[base + 17 * t] = v[DFT16_OUT(t)];
 }
+#endif
+constexpr int kTriStep = TRI_SWZ ? 256 : 272;  // slots between elements j + 256 t and j + 256 (t + 1)
 __device__ __forceinline__ void x_read(v2f (&v)[16], const v2f* X, int j) {  // inputs of passes 2 and 3: element j + 256 t
+    const int base = xslot(j);
+    if (TRI_KNOCK == 1) return;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = X[pad16(j + 256 * t)];
+    for (int t = 0; t < 16; ++t) v[t] = X[base + kTriStep * t];
+}
+// TRI_FUSED (default): the twiddle products ride the butterflies as fused multiply-adds (fft_fused_device.hpp: 269 packed
+// operations per 4096-point transform instead of 300)
+#ifndef TRI_FUSED
+#define TRI_FUSED 1
+#endif
+template <bool INV>
+__device__ __forceinline__ void plain16(v2f (&v)[16]) {
+    if (TRI_KNOCK == 2) return;
+#if TRI_FUSED
+    dft16_fused<INV>(v);
+#else
+    dft16<INV>(v);
+#endif
 }
 template <bool INV>
-__device__ __forceinline__ void twiddle2(v2f (&v)[16], const v2f* tw2, int j) {
+__device__ __forceinline__ void pass2_16(v2f (&v)[16], const v2f* tw2, int j) {  // exp(-+2 pi i (j % 16) t / 256) v[t], then the DFT
     const unsigned k = (unsigned)j & 15u;
+    if (TRI_KNOCK == 2) return;
+#if TRI_FUSED
+    v2f w[16];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) w[t] = tw2[k * (unsigned)t];
+    w[0] = w[1];
+    dft16_fused_tw<INV>(v, w);
+#else
 #pragma unroll
     for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw2[k * (unsigned)t]);
+    dft16<INV>(v);
+#endif
 }
 template <bool INV>
-__device__ __forceinline__ void twiddle3(v2f (&v)[16], const v2f (&tw3)[15]) {
+__device__ __forceinline__ void pass3_16(v2f (&v)[16], const v2f (&tw3)[15]) {  // exp(-+2 pi i j t / 4096) v[t], then the DFT
+    if (TRI_KNOCK == 2) return;
+#if TRI_FUSED
+    v2f w[16];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) w[t] = tw3[t - 1];
+    w[0] = w[1];
+    dft16_fused_tw<INV>(v, w);
+#else
 #pragma unroll
     for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw3[t - 1]);
+    dft16<INV>(v);
+#endif
 }
 __device__ __forceinline__ void natural(v2f (&v)[16]) {  // X[k] sits in v[DFT16_OUT(k)] after dft16: rename (constant indices, no moves)
     v2f r[16];
@@ -72,43 +152,45 @@ __device__ __forceinline__ void natural(v2f (&v)[16]) {  // X[k] sits in v[DFT16
 // barrier between its last use of X and this call; on return other wavefronts may still be reading X (chain b's pass-3 inputs).
 template <bool INV>
 __device__ __forceinline__ void tri_dual(v2f (&a)[16], v2f (&b)[16], v2f* X, const v2f* tw2, const v2f (&tw3)[15], int j) {
-    dft16<INV>(a);
+    plain16<INV>(a);
     x_write1(a, X, j);
-    __syncthreads();
+    TRI_SYNC();
     x_read(a, X, j);
-    dft16<INV>(b);
-    __syncthreads();  // every pass-2 input of chain a is in registers
+    plain16<INV>(b);
+    TRI_SYNC();  // every pass-2 input of chain a is in registers
     x_write1(b, X, j);
-    twiddle2<INV>(a, tw2, j);
-    __syncthreads();
+    pass2_16<INV>(a, tw2, j);
+    TRI_SYNC();
     x_read(b, X, j);
-    dft16<INV>(a);
-    __syncthreads();
+    TRI_SYNC();
     x_write2(a, X, j);
-    twiddle2<INV>(b, tw2, j);
-    __syncthreads();
+    pass2_16<INV>(b, tw2, j);
+    TRI_SYNC();
     x_read(a, X, j);
-    dft16<INV>(b);
-    __syncthreads();
+    TRI_SYNC();
     x_write2(b, X, j);
-    twiddle3<INV>(a, tw3);
-    __syncthreads();
-    x_read(b, X, j);
-    dft16<INV>(a);
+    pass3_16<INV>(a, tw3);
     natural(a);
-    twiddle3<INV>(b, tw3);
-    dft16<INV>(b);
+    TRI_SYNC();
+    x_read(b, X, j);
+    pass3_16<INV>(b, tw3);
     natural(b);
+}
+
+// one 12-byte point at slot `pos` of a column (a wavefront's kept points are contiguous: 768 B per store instruction).  Non-temporal
+// (`nt`) and write-through (`sc0 sc1`) stores measured 1.304 / 1.348 ms against 1.305 for the plain store: not used.
+__device__ __forceinline__ void store_point(omx_spectrogram_point* out, uint32_t pos, const omx_spectrogram_point& p) {
+    *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + __umul24(pos, 12u)) = p;
 }
 
 }  // namespace
 
-constexpr size_t kTriLds = (size_t)FFT4096_LDS * sizeof(v2f) + 4096 * sizeof(float) + 256 * sizeof(v2f) + 36 * sizeof(uint32_t) + 4 * sizeof(float);
+constexpr size_t kTriLds = (size_t)kTriSlots * sizeof(v2f) + 4096 * sizeof(float) + 256 * sizeof(v2f) + 36 * sizeof(uint32_t) + 4 * sizeof(float);
 
 __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* X = reinterpret_cast<v2f*>(smem_raw);
-    float* imb = reinterpret_cast<float*>(X + FFT4096_LDS);        // [4096] Im analytic[2048 + i] of column b
+    float* imb = reinterpret_cast<float*>(X + kTriSlots);        // [4096] Im analytic[2048 + i] of column b
     v2f* tw2_lds = reinterpret_cast<v2f*>(imb + 4096);             // [256] exp(-2 pi i k / 256)
     uint32_t* scan = reinterpret_cast<uint32_t*>(tw2_lds + 256);   // [9][4] wave counts
     float* hil = reinterpret_cast<float*>(scan + 36);              // X[0]/2, X[4096]/2 of both columns
@@ -178,11 +260,13 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     tri_dual<false>(va, vb, X, tw2_lds, tw3, j);  // v[t] = Zf[j + 256 t]
 
     // ---- 2. Hilbert transform with ONE half-length inverse per column, one column at a time through X ----------------------
-    const int part = (j ? pad16(4096 - j) : 4352) - 272 * 15;
+    // partner Zf[(4096 - k) & 4095] of k = j + 256 t: element (256 - j) + 256 (15 - t); thread 0's partners 4096 - 256 t sit one block
+    // higher, and its t = 0 read (one slot past the buffer, inside the allocation) is not used
+    const int part = j ? xslot(256 - j) : kTriStep;
     auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16]) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const v2f z = v[t], zr = X[part + 272 * (15 - t)];
+            const v2f z = v[t], zr = X[part + kTriStep * (15 - t)];
             const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
             v2f w8;
             switch (t) {  // compile-time after unrolling
@@ -210,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     v2f ya[16], yb[16];
     __syncthreads();  // pass 3 of chain b still reads X
 #pragma unroll
-    for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = va[t];
+    for (int t = 0; t < 16; ++t) X[xslot(j) + kTriStep * t] = va[t];
     if (j == 0) {
         hil[0] = (va[0].x + va[0].y) * 0.5f;  // X[0] / 2
         hil[1] = (va[0].x - va[0].y) * 0.5f;  // X[4096] / 2
@@ -221,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     hilbert_spectrum(ya, va);
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 16; ++t) X[pad16(j + 256 * t)] = vb[t];
+    for (int t = 0; t < 16; ++t) X[xslot(j) + kTriStep * t] = vb[t];
     __syncthreads();
     hilbert_spectrum(yb, vb);
     const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
@@ -230,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
 
     // ---- 3. the analytic slices s[i] = analytic[2048 + i], i = j + 256 t ----------------------------------------------------
     // real half of column a and the time-weighted window: requested here, consumed behind the two barriers of the gather
-    auto load_real_half = [&](float (&xr)[16], float (&twin)[16], uint32_t col_bytes, uint32_t p32) {
+    auto load_real_half = [&](float (&xr)[16], uint32_t col_bytes, uint32_t p32) {
         if (direct) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) xr[t] = load_f32(windowb, ju * 4u, col_bytes + 8192u + 1024u * (unsigned)t);
@@ -239,11 +323,14 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
 #pragma unroll
             for (int t = 0; t < 16; ++t) xr[t] = *reinterpret_cast<const float*>(ring_bytes + (((q + 256u * (unsigned)t) << 2) & bytemask));
         }
+    };
+    auto load_twindow = [&](float (&twin)[16]) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) twin[t] = load_f32(twinb, ju * 4u, 1024u * (unsigned)t);
     };
     float xra[16], twina[16];
-    load_real_half(xra, twina, 0u, pa32);
+    load_real_half(xra, 0u, pa32);
+    load_twindow(twina);
     __syncthreads();
     float* imag_a = reinterpret_cast<float*>(X);
 #pragma unroll
@@ -316,17 +403,19 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, 4 * t + wave_u);
-            if ((masks[t] >> lane) & 1ull) {
+            if (TRI_KNOCK != 4 && ((masks[t] >> lane) & 1ull)) {
                 const uint32_t pos = before + lanes_below(masks[t]);
-                *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + pos * 12u) = pts[t];
+                store_point(out, pos, pts[t]);
             }
         }
         if (j == 0) *count_out = running;
     };
     column(xra, twina, imag_a, half_x0a, half_xna, silent_a, col0, count_a);
     if (have1) {
+        // (requested ahead of column a's point stores — loads and stores retire through one in-order counter — this measured the same)
         float xrb[16], twinb_v[16];
-        load_real_half(xrb, twinb_v, hop_bytes, pb32);
+        load_real_half(xrb, hop_bytes, pb32);
+        load_twindow(twinb_v);
         column(xrb, twinb_v, imb, half_x0b, half_xnb, silent_b, col1, count_b);
     }
 }

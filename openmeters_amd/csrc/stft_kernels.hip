@@ -897,8 +897,8 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
             return e ? atoi(e) : -1;
         }();
         const int f = (form == 0 && env_form >= 0) ? env_form : form;
-        if (f == 2) { launch_stft_reassigned_4096_tri(a, stream); return; }   // three workgroups per CU (stft4096_tri_kernels.hip)
-        if (f == 0) { launch_stft_reassigned_4096_pair(a, stream); return; }
+        if (f == 0) { launch_stft_reassigned_4096_tri(a, stream); return; }   // round 4: three workgroups per CU (stft4096_tri_kernels.hip)
+        if (f == 2) { launch_stft_reassigned_4096_pair(a, stream); return; }  // round 2: two workgroups per CU, two LDS buffers
     }
 #ifdef OMX_TUNING
     // Tuning build only (make TUNING=1 -> libomx_hip_tuning.so, loaded through OMX_HIP_LIB): OMX_K2_VARIANT selects an A/B
