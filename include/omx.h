@@ -105,8 +105,10 @@ const char* omx_last_error(void);
 int omx_device_available(void);
 /* Number of HIP devices visible to the process (0 when there is none), and the device of the handles created from now on: a host
  * without the HIP headers — the Rust service, one process per GPU — calls omx_set_device(LOCAL_RANK) once before it creates
- * anything.  Handles and banks live on the device that was current at their creation; the stream argument of every call must belong
- * to that device.  Returns 0, OMX_ERR_INVALID (index out of range) or OMX_ERR_NO_DEVICE (not a gfx950). */
+ * anything.  The choice is PROCESS-wide: HIP's current device is per host thread, so every entry point of this library binds the
+ * calling thread to the selected device first (a capture thread and a UI thread of one host land on the same GPU).  Handles and
+ * banks live on that device; the stream argument of every call must belong to it.  One device per process: changing the device
+ * while handles exist is not supported.  Returns 0, OMX_ERR_INVALID (index out of range) or OMX_ERR_NO_DEVICE (not a gfx950). */
 int omx_device_count(void);
 int omx_set_device(int index);
 /* Library version string. */
@@ -253,9 +255,11 @@ enum {
                                 * per frame); 2 = the round-2 pair kernel (two workgroups per CU, two LDS buffers);
                                 * 30 = size-templated kernel; 31 = three-kernel form through an HBM scratch.  All compute
                                 * the same columns (tests cross-check them); unknown values are rejected. */
-    OMX_OPT_LOUDNESS_REBASE_FRAMES = 4 /* loudness bank: frames after which the chunk-parallel form takes its running totals afresh from
-                                * the sample ring (default 2^22; they bound the absolute error of a window sum at ~1e-16 of the energy
-                                * played since — loudness_chunked.hip).  A test / tuning hook: results do not depend on it beyond 1e-6 dB */
+    OMX_OPT_LOUDNESS_REBASE_FRAMES = 4 /* loudness bank: a call that finds the chunk-parallel form's running totals older than this many frames
+                                * takes them afresh from the sample ring first (default 2^22; checked once per call).  The totals are
+                                * double-double pairs, so a window sum — the difference of two of them — is good to ~1e-16 of itself whatever
+                                * the stream has played (90 s at full scale, then -100 dBFS: inside 1e-4 dB, tests/test_gpu_parity_meters.py);
+                                * the rebuild is a second line of defence and a test hook */
 };
 /* tuning aid: cycles per phase of the fused 4096 kernel, accumulated by the phase-timing builds of the TUNING library
  * (`make TUNING=1`; setup/load, FFT, Hilbert build, inverse FFT, gather+window, dual FFT, third FFT, reassign+store).

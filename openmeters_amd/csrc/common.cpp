@@ -4,6 +4,7 @@
 //   src/util/audio/window.rs:20-43, :90-109.
 #include "common.hpp"
 
+#include <atomic>
 #include <complex>
 
 namespace omx {
@@ -12,7 +13,19 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const std::string& last_error() { return g_last_error; }
 
-static int g_device_ready = 2;  // 2 = unknown
+static std::atomic<int> g_device_ready{2};    // 2 = unknown
+static std::atomic<int> g_selected_device{-1};  // omx_set_device's choice, process-wide (-1: the HIP default, device 0)
+static thread_local int tl_bound_device = -1;
+
+// hipSetDevice is per host thread: a capture thread and a UI thread of one host must both land on the device omx_set_device chose.
+// Every C-ABI entry passes through here (guarded(), device_ready()); one relaxed load when nothing changed.
+void bind_thread_device() {
+    const int want = g_selected_device.load(std::memory_order_relaxed);
+    if (want >= 0 && tl_bound_device != want) {
+        if (hipSetDevice(want) == hipSuccess) tl_bound_device = want;
+        else (void)hipGetLastError();
+    }
+}
 
 // omx_device_count / omx_set_device: a host without the HIP headers (the Rust service, one process per GPU) picks its device here,
 // before it creates handles; handles live on the device that was current when they were created
@@ -34,13 +47,19 @@ int select_device(int index) {
         set_last_error("hipSetDevice failed");
         return OMX_ERR_BACKEND;
     }
-    g_device_ready = 2;  // the architecture check runs again for the new device
+    tl_bound_device = index;
+    g_selected_device.store(index);
+    g_device_ready.store(2);  // the architecture check runs again for the new device
     return device_ready();
 }
 
 int device_ready() {
-    int& cached = g_device_ready;
-    if (cached != 2) return cached;
+    bind_thread_device();
+    struct Cached {  // (`return cached = x` below stores and returns)
+        int operator=(int v) { g_device_ready.store(v); return v; }
+    } cached;
+    const int known = g_device_ready.load();
+    if (known != 2) return known;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {

@@ -2,6 +2,7 @@
 // No DSP lives here: error reporting, device buffers, the per-call audio format, and the
 // closed-form coefficient tables that the reference also computes once per config on the host.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,9 +44,21 @@ struct BackendError {
 }
 
 // Runs `body` and converts BackendError into a negative omx_status: nothing unwinds across the C ABI.
+// Environment-variable A/B hooks exist in the tuning build only (make TUNING=1 -> libomx_hip_tuning.so): the product library reads no
+// tuning variable.  (OMX_WAVEFORM_SINGLE and OMX_SPLAT_FORM stay: the test suite cross-checks equivalent kernel forms through them.)
+inline const char* tuning_env(const char* name) {
+#ifdef OMX_TUNING
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+void bind_thread_device();  // the calling host thread onto the device omx_set_device selected (hipSetDevice is per thread)
 template <class F>
 inline int guarded(F&& body) {
     try {
+        bind_thread_device();
         return body();
     } catch (const BackendError& e) {
         return e.status;

@@ -332,12 +332,13 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
     while (q_need < ring_len_ / 64 + frames / 64 + 2) q_need *= 2;
     if (q_need > q_len_) {
         q_len_ = q_need;
-        q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_));
+        q_ring_.reserve((size_t)((uint64_t)n_streams_ * 8 * q_len_ * 2));  // high words, then low words
         OMX_HIP(hipMemsetAsync(q_ring_.ptr, 0, q_ring_.count * sizeof(double), stream));
         tails_.release();
         if (!state_clean_) q_valid_ = false;  // re-indexed: the totals come back from the sample ring
     }
     ca.q_ring = q_ring_.ptr;
+    ca.q_lo = q_ring_.ptr + (uint64_t)n_streams_ * 8 * q_len_;
     ca.q_len = q_len_;
     if (off_grid && !tails_.ptr) {
         tails_.reserve((size_t)((uint64_t)n_streams_ * 8 * kLoudnessWindows * q_len_));
@@ -354,9 +355,10 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
     ca.scan_dd = cfg_.sample_rate > 100000.0f ? 1u : 0u;
     rebuild_scratch_.reserve((size_t)(slots * (ring_len_ / 64 + 1)));
     // The running totals grow with everything a stream has played since its last reset, and a window sum is the difference of two
-    // of them: its absolute error is ~1e-16 of the TOTAL (an hour of full-scale audio: 4e-9, i.e. 0.01 dB on a -100 dBFS passage).
-    // Every `rebase_frames_` frames the totals are therefore taken afresh from the sample ring (exact; they then start at the oldest
-    // sample the ring holds): bounded at ~1e-10 whatever the uptime, for one pass over the ring per 87 s of audio.
+    // of them.  They are kept as double-double pairs (q_ring / q_lo), so the difference is exact to ~1e-16 of the WINDOW sum, not of
+    // the total (as plain f64 totals, 20 s at full scale put 5e-4 dB into a -100 dBFS passage that followed).  The periodic rebuild
+    // from the sample ring (every `rebase_frames_` frames; it restarts the totals at the oldest sample the ring holds) is kept as a
+    // second line of defence and as the test hook it always was.
     if (q_valid_ && q_age_ > rebase_frames_) q_valid_ = false;
     if (!q_valid_) {  // (also: earlier calls went through the sequential kernels)
         launch_loudness_rebuild_q(ca, rebuild_scratch_.ptr, nullptr, stream);

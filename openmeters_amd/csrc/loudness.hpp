@@ -81,7 +81,9 @@ struct LoudChunkArgs {
     omx_loudness_snapshot* snapshots;
     double* chunk_filter;          // [slots][n_blocks][4]: pass A's zero-state end states, then the true start states
     double* sub_sums;              // [slots][n_blocks * block_frames / 64]
-    double* q_ring;                // [slots][q_len]: running total of the squared samples at the end of every 64-sample sub-block
+    double* q_ring;                // [slots][q_len]: running total of the squared samples at the end of every 64-sample sub-block (high word)
+    double* q_lo;                  // [slots][q_len]: its low word — the totals are double-double, so that a window sum (a difference of two
+                                   // of them) is exact to ~1e-16 of ITSELF whatever the stream has played since its last reset
     uint64_t q_len;                // power of two
     double* tails;                 // [slots][windows][q_len]: sum of the last tail_len[w] samples of every sub-block; null when every
     uint32_t tail_len[kLoudnessWindows];  // tail_len[w] = capacities[w] % 64 is 0 (window starts on the sub-block grid)

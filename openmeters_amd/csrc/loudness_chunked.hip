@@ -434,7 +434,9 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
     const SlotCall sc = slot_call(a, chan >> a.slot_shift);
     const uint64_t n_sub = (uint64_t)sc.blocks * (a.block_frames / SUB), g0 = sc.seen / SUB;  // first new sub-block
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
-    double carry = g0 == 0 ? 0.0 : q[(g0 - 1u) & (a.q_len - 1u)];
+    double* ql = a.q_lo + (uint64_t)chan * a.q_len;
+    // the total so far as a double-double pair; the prefix of a sweep's 64 sub-block sums (<= 4096) is plain f64
+    double carry = g0 == 0 ? 0.0 : q[(g0 - 1u) & (a.q_len - 1u)], carry_lo = g0 == 0 ? 0.0 : ql[(g0 - 1u) & (a.q_len - 1u)];
     const double* sub = a.sub_sums + (uint64_t)chan * a.n_blocks * (a.block_frames / SUB);
     for (uint64_t j0 = 0; j0 < n_sub; j0 += 64u) {
         const uint64_t j = j0 + lane;
@@ -444,9 +446,14 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
             const double up = shfl_up_f64(x, d);
             if ((int)lane >= d) x += up;
         }
-        x += carry;
-        if (j < n_sub) q[(g0 + j) & (a.q_len - 1u)] = x;
-        carry = shfl_f64(x, 63);
+        const double hi = carry + x, bb = hi - carry;                 // two-sum (Knuth): hi + err == carry + x exactly
+        const double lo = ((carry - (hi - bb)) + (x - bb)) + carry_lo;
+        if (j < n_sub) {
+            q[(g0 + j) & (a.q_len - 1u)] = hi;
+            ql[(g0 + j) & (a.q_len - 1u)] = lo;
+        }
+        carry = shfl_f64(hi, 63);
+        carry_lo = shfl_f64(lo, 63);
     }
 }
 
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, co
     if (!slot_live(a, chan)) return;
     const RebuildSpan sp = rebuild_span(a, chan >> a.slot_shift);
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
+    double* ql = a.q_lo + (uint64_t)chan * a.q_len;
     double carry = 0.0;  // only differences of Q are used once the windows are full; before that first_sub == 0
     for (uint64_t j0 = 0; j0 < sp.n; j0 += 64u) {
         const uint64_t j = j0 + lane;
@@ -505,11 +513,17 @@ __global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, co
             const double up = shfl_up_f64(x, d);
             if ((int)lane >= d) x += up;
         }
-        x += carry;
-        if (j < sp.n) q[(sp.first_sub + j) & (a.q_len - 1u)] = x;
+        x += carry;  // (at most ring_len samples: plain f64 is exact enough here, the low words restart at 0)
+        if (j < sp.n) {
+            q[(sp.first_sub + j) & (a.q_len - 1u)] = x;
+            ql[(sp.first_sub + j) & (a.q_len - 1u)] = 0.0;
+        }
         carry = shfl_f64(x, 63);
     }
-    if (sp.first_sub > 0 && lane == 0) q[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+    if (sp.first_sub > 0 && lane == 0) {
+        q[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+        ql[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+    }
 }
 
 // ---- ragged calls: the per-stream sample counters move once every kernel above has read them
@@ -538,32 +552,46 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
     for (uint32_t ch = 0; ch < C; ++ch) {
         const uint32_t chan = (s << a.slot_shift) + ch;
         const double* q = a.q_ring + (uint64_t)chan * a.q_len;
-        const double q_end = q[(P / SUB - 1u) & mask];
+        const double* ql = a.q_lo + (uint64_t)chan * a.q_len;
+        const double q_end = q[(P / SUB - 1u) & mask], q_end_lo = ql[(P / SUB - 1u) & mask];
         double mean[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t m = min(P, a.capacities[w]);  // dsp.rs:367-370: min(count, cap), count itself saturates at the ring
             const uint64_t st = P - m, start_sub = st / SUB;  // st % 64 == (64 - tail_len[w]) % 64 once the window is full
-            double base;
-            if (st % SUB == 0u) base = start_sub == 0 ? 0.0 : q[(start_sub - 1u) & mask];
-            else base = q[start_sub & mask] - a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (start_sub & mask)];
-            const double W = q_end - base;
+            // window sum = difference of two double-double totals: high words first (exact to the difference's own last bit), then the low words
+            double base = 0.0, base_lo = 0.0, tail = 0.0;
+            if (st % SUB == 0u) {
+                if (start_sub != 0) {
+                    base = q[(start_sub - 1u) & mask];
+                    base_lo = ql[(start_sub - 1u) & mask];
+                }
+            } else {
+                base = q[start_sub & mask];
+                base_lo = ql[start_sub & mask];
+                tail = a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (start_sub & mask)];
+            }
+            const double W = ((q_end - base) + (q_end_lo - base_lo)) + tail;
             mean[w] = W / (double)max(m, (uint64_t)1);
             if (last) {  // the sequential kernels' state: live pair = the window sum, `since refresh` pair = sum since the last
                          // multiple of cap pushes (CompensatedPair::refresh, dsp.rs:287-289, :363); corrections folded in
                 LoudnessChannelState& st = a.state[chan];
                 const uint64_t refresh = (P / a.capacities[w]) * a.capacities[w], refresh_sub = refresh / SUB;
-                double rbase;
-                if (refresh % SUB == 0u) rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
-                else {  // off the grid: the rest of that sub-block is still in the sample ring (refresh > P - cap >= P - ring_len)
+                double rbase, rbase_lo = 0.0, radd = 0.0;
+                if (refresh % SUB == 0u) {
+                    rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
+                    rbase_lo = refresh_sub == 0 ? 0.0 : ql[(refresh_sub - 1u) & mask];
+                } else {  // off the grid: the rest of that sub-block is still in the sample ring (refresh > P - cap >= P - ring_len)
                     const RingT* ring_col = a.ring + (uint64_t)(chan / kRow) * a.ring_len * kRow + chan % kRow;
                     double rest = 0.0;
                     for (uint64_t i = refresh; i < (refresh_sub + 1u) * SUB; ++i) rest += ring_square(ring_col[(i % a.ring_len) * kRow]);
-                    rbase = q[refresh_sub & mask] - rest;
+                    rbase = q[refresh_sub & mask];
+                    radd = rest;
+                    rbase_lo = ql[refresh_sub & mask];
                 }
                 st.sums[w][0] = W;
                 st.corrections[w][0] = 0.0;
-                st.sums[w][1] = q_end - rbase;
+                st.sums[w][1] = ((q_end - rbase) + (q_end_lo - rbase_lo)) + radd;
                 st.corrections[w][1] = 0.0;
             }
         }

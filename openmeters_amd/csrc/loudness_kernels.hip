@@ -669,7 +669,7 @@ void launch_loudness(const LoudnessArgs& a, hipStream_t stream) {
     const bool batched = min_cap >= 16;
     // split roles while the single-role launch would leave SIMDs idle (one 64-lane workgroup per SIMD fills 1024 of them)
     static const int force = [] {
-        const char* e = getenv("OMX_LOUDNESS_SPLIT");  // 0 / 1 pins the form (A/B and tests)
+        const char* e = tuning_env("OMX_LOUDNESS_SPLIT");  // 0 / 1 pins the form (A/B and tests)
         return e ? atoi(e) : -1;
     }();
     if (a.blocks_v) {  // ragged banks: the lane-quad kernel (per-lane ring position, block count and reset flag); true peak in its own

@@ -234,7 +234,7 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     sa.headers = headers_.ptr;
     sa.samples = samples_.ptr;
     static const bool phase_timing = [] {
-        const char* e = getenv("OMX_SCOPE_PHASES");
+        const char* e = tuning_env("OMX_SCOPE_PHASES");
         return e && atoi(e) != 0;
     }();
     sa.phase_timing = phase_timing ? 1u : 0u;

@@ -22,6 +22,7 @@
 // neither the reference's sequential order (correlation_stats, :206-208) nor its four stride-4 chains (:210-227): a bit-equal
 // order would put a 1920-long dependent f32 chain in front of every search (7 us per block against the 4 us the whole block
 // takes here), see DESIGN §2 for what is checked instead (exact-arithmetic third leg, near-tie test).
+#include <mutex>
 #include "scope_device.hpp"
 
 #include "fft_device.hpp"
@@ -1440,19 +1441,18 @@ void launch_scope_rehome(const float* from, uint64_t from_cap, float* to, uint64
 void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     hipLaunchKernelGGL(scope_push2_kernel, dim3((uint32_t)((a.frames_total + 255) / 256), a.n_streams), dim3(256), 0, stream, a);
-    static bool attr_set = false;
+    static std::once_flag attr_once;  // (two host threads may race on the first launch; one device per process, omx.h)
     static int threads = 512;
-    if (!attr_set) {
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_estimate2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (const char* e = getenv("OMX_SCOPE_THREADS")) {  // tuning hook
+        if (const char* e = tuning_env("OMX_SCOPE_THREADS")) {  // tuning hook
             const int t = atoi(e);
             threads = t == 1024 || t == 256 ? t : 512;
         }
-        attr_set = true;
-    }
+    });
     if (a.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && a.est_view_count) {
         const size_t lds_est = (size_t)(2ull * FFT4096_LDS + a.max_period + 8ull) * sizeof(float);
         hipLaunchKernelGGL(scope_estimate2_kernel, dim3(a.n_streams, a.n_blocks, a.est_view_count), dim3(256), lds_est, stream, a);

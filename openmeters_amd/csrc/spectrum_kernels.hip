@@ -39,27 +39,27 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
     }
 }
 
+#ifndef SPEC_WIDE  // 1: four bins per thread and 16-byte row stores (default); 0: the bin-per-lane epilogue of rounds 1-3 (A/B)
+#define SPEC_WIDE 1
+#endif
+#ifndef SPEC_KNOCK  // pricing builds (WRONG rows): 1 no stores, 2 no transform, 3 no dB arithmetic
+#define SPEC_KNOCK 0
+#endif
+#ifndef SPEC_P  // hop pairs (F == 1) a workgroup runs one after the other: the row stores of one pair drain behind the loads and butterflies of the next
+#define SPEC_P 1
+#endif
 template <int LOGN>
-__global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
+__device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs& a, uint32_t s, uint32_t tr, uint32_t chunk, v2f* lds) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
-    extern __shared__ __attribute__((aligned(16))) unsigned char spectrum_smem[];
-    v2f* lds = reinterpret_cast<v2f*>(spectrum_smem);                 // [F][G::LDS]
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
     float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
-    const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F;
-    // XCD-aware map (as block_to_stream_column in stft_kernels.hip): block b runs on XCD b % 8 and every (stream, trace) is pinned to
-    // one XCD, so the 16 hops that share a sample find it in that XCD's L2 (chunk-fastest over all XCDs fetched the rings 8 times:
-    // 524 MB per launch against 67 MB of new samples)
-    const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
-    const uint32_t chunk = bq % chunks, st = (bq / chunks) * 8u + xcd;
-    if (st >= a.n_streams * a.n_traces) return;
-    const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
     // F == 1 (4096 points): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
     // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
     // exec-mask regions and per-lane 64-bit addresses
     const int fs = F == 1 ? 0 : (int)(threadIdx.x / T), jf = F == 1 ? (int)threadIdx.x : (int)(threadIdx.x % T), wf = jf >> 6;
-    const unsigned ju = (unsigned)jf;
+    unsigned ju = (unsigned)jf;
+    if (SPEC_P > 1) asm volatile("" : "+v"(ju));  // per pair: keeps the table loads of the loop's pairs from being hoisted into 90 more registers
     v2f* A = lds + fs * G::LDS;
     const uint32_t n_hops_s = spectrum_hops(a, s), pairs_s = (n_hops_s + 1) / 2;  // ragged banks: this stream's own hop count
     if (chunk * F >= pairs_s) return;  // (whole workgroup)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     // per-bin tables: issued before the last pass's butterflies would be ideal, but holding 18 more registers through the
     // transform costs the fourth resident workgroup (128-VGPR line); here they overlap the exchange below
     float norm[9], aw[9];
-    fftp_inplace<false, LOGN>(v, A, jf, tw);
+    if (SPEC_KNOCK != 2) fftp_inplace<false, LOGN>(v, A, jf, tw);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const unsigned k = (t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
@@ -129,6 +129,105 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
     for (int t = 0; t < 16; ++t) A[own_base + (T + T / 16) * t] = v[t];
     frame_sync<LOGN>();
     if (!in_range) return;
+#if SPEC_WIDE
+    // Epilogue, FOUR consecutive bins per thread and round (bins 4 j ... 4 j + 3, then 4 T + 4 j ...; thread 0 adds the Nyquist bin): every
+    // row is written by 16-byte stores — a wavefront moves 1 KiB per store instruction where the bin-per-lane order moved 256 B.
+    // The step writes 1.07 GB of rows (configs[1]); with 33 four-byte stores per thread the kernel spent 0.15 of its 0.42 ms
+    // issuing them (knock-out build), not moving them.  Both Z[k] and its partner now come from the natural-order copy.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // rows start at multiples of `bins` floats: 4-byte alignment only
+    float* out0 = nullptr;
+    if (a.fused_db)
+        out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
+    const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
+    float* pw = a.fused_db ? nullptr : a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
+    const bool write_a = a.emit_all || h0 + 1 == n_hops_s, write_b = has_b && (a.emit_all || h0 + 2 == n_hops_s);
+    auto split_power = [&](v2f z, v2f zr, float nrm, float& pa, float& pb) {
+        const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
+        const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
+        pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * nrm;
+        pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * nrm;
+    };
+    auto levels = [&](float p, float awk, float& wt, float& raw) {  // update_outputs with AveragingMode::None (:391-401), branch-free
+        const float db = SPEC_KNOCK == 3 ? p : fast_power_db(p);
+        const bool low = p < a.state_floor;
+        raw = low ? a.floor_db : fmaxf(db, a.floor_db);
+        wt = low ? a.floor_db : fmaxf(db + awk, a.floor_db);
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t k0 = (unsigned)r * 4u * (unsigned)T + 4u * ju;
+        const int zb = pad16((int)k0);                           // bins k0 ... k0 + 3 share a 16-group: consecutive slots
+        const int pb3 = pad16(N - (int)k0 - 4);                  // partners N - k0 - 1 ... N - k0 - 3 at pb3 + 3 ... pb3 + 1
+        const int p0 = (r == 0 && jf == 0) ? 0 : pad16(N - (int)k0);  // partner of k0 itself (bin 0 pairs with itself)
+        v2f z[4], zr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) z[c] = A[zb + c];
+        zr[0] = A[p0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) zr[c] = A[pb3 + 4 - c];
+        const float4 nrm = *reinterpret_cast<const float4*>(a.bin_norm + k0);
+        float pa[4], pb[4];
+        split_power(z[0], zr[0], nrm.x, pa[0], pb[0]);
+        split_power(z[1], zr[1], nrm.y, pa[1], pb[1]);
+        split_power(z[2], zr[2], nrm.z, pa[2], pb[2]);
+        split_power(z[3], zr[3], nrm.w, pa[3], pb[3]);
+        if (a.fused_db) {
+            const float4 aw = *reinterpret_cast<const float4*>(a.a_weighting_db + k0);
+            const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
+            f4u wt_a, raw_a, wt_b, raw_b;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float w0, r0, w1, r1;
+                levels(pa[c], awv[c], w0, r0);
+                levels(pb[c], awv[c], w1, r1);
+                wt_a[c] = w0;
+                raw_a[c] = r0;
+                wt_b[c] = w1;
+                raw_b[c] = r1;
+            }
+            if (SPEC_KNOCK == 1) {
+                if (wt_a[0] + raw_a[1] + wt_b[2] + raw_b[3] == 1.2345f) out0[k0] = wt_a[0];
+                continue;
+            }
+            // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
+            // a ragged call launches every hop and the stream's last one writes
+            if (write_a) {
+                *reinterpret_cast<f4u*>(out0 + k0) = wt_a;
+                *reinterpret_cast<f4u*>(out0 + a.bins + k0) = raw_a;
+            }
+            if (write_b) {
+                *reinterpret_cast<f4u*>(out0 + hop_stride + k0) = wt_b;
+                *reinterpret_cast<f4u*>(out0 + hop_stride + a.bins + k0) = raw_b;
+            }
+        } else {
+            *reinterpret_cast<f4u*>(pw + k0) = f4u{pa[0], pa[1], pa[2], pa[3]};
+            if (has_b) *reinterpret_cast<f4u*>(pw + a.bins + k0) = f4u{pb[0], pb[1], pb[2], pb[3]};
+        }
+    }
+    if (jf == 0) {  // Nyquist bin N / 2 pairs with itself
+        const uint32_t k = (unsigned)N / 2u;
+        const v2f z = A[pad16(N / 2)];
+        float pa, pb;
+        split_power(z, z, a.bin_norm[k], pa, pb);
+        if (a.fused_db) {
+            float w0, r0, w1, r1;
+            const float awk = a.a_weighting_db[k];
+            levels(pa, awk, w0, r0);
+            levels(pb, awk, w1, r1);
+            if (write_a && SPEC_KNOCK != 1) {
+                out0[k] = w0;
+                out0[a.bins + k] = r0;
+            }
+            if (write_b && SPEC_KNOCK != 1) {
+                out0[hop_stride + k] = w1;
+                out0[hop_stride + a.bins + k] = r1;
+            }
+        } else {
+            pw[k] = pa;
+            if (has_b) pw[a.bins + k] = pb;
+        }
+    }
+#else
     const int partner_base = pad16(jf == 0 ? N : N - jf);
     float* out0 = nullptr;
     if (a.fused_db)
@@ -147,12 +246,16 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
         const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
         const float pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t];
         if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
-            const float db_a = fast_power_db(pa), db_b = fast_power_db(pb);
+            const float db_a = SPEC_KNOCK == 3 ? pa : fast_power_db(pa), db_b = SPEC_KNOCK == 3 ? pb : fast_power_db(pb);
             const bool low_a = pa < a.state_floor, low_b = pb < a.state_floor;
             const float raw_a = low_a ? a.floor_db : fmaxf(db_a, a.floor_db), wt_a = low_a ? a.floor_db : fmaxf(db_a + aw[t], a.floor_db);
             const float raw_b = low_b ? a.floor_db : fmaxf(db_b, a.floor_db), wt_b = low_b ? a.floor_db : fmaxf(db_b + aw[t], a.floor_db);
             // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
             // a ragged call launches every hop and the stream's last one writes
+            if (SPEC_KNOCK == 1) {
+                if (wt_a + raw_a + wt_b + raw_b == 1.2345f) out0[k] = wt_a;
+                continue;
+            }
             if (a.emit_all || h0 + 1 == n_hops_s) {
                 out0[k] = wt_a;
                 out0[a.bins + k] = raw_a;
@@ -166,6 +269,30 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void spectrum_power_pow2_kernel(
             pw[k] = pa;
             if (has_b) pw[a.bins + k] = pb;
         }
+    }
+#endif
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(FftGeom<LOGN>::WG, (LOGN == 12 && SPEC_P > 1) ? 4 : 1) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, P = F == 1 ? SPEC_P : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char spectrum_smem[];
+    v2f* lds = reinterpret_cast<v2f*>(spectrum_smem);                 // [F][G::LDS] + tw2 + wave sums
+    const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F, groups = (chunks + P - 1) / P;
+    // XCD-aware map (as block_to_stream_column in stft_kernels.hip): block b runs on XCD b % 8 and every (stream, trace) is pinned to
+    // one XCD, so the 16 hops that share a sample find it in that XCD's L2 (chunk-fastest over all XCDs fetched the rings 8 times:
+    // 524 MB per launch against 67 MB of new samples)
+    const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
+    const uint32_t group = bq % groups, st = (bq / groups) * 8u + xcd;
+    if (st >= a.n_streams * a.n_traces) return;
+    const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
+#pragma unroll 1
+    for (uint32_t pp = 0; pp < (uint32_t)P; ++pp) {
+        const uint32_t chunk = group * P + pp;
+        if (chunk >= chunks) break;
+        if (pp) __syncthreads();  // the previous pair's partner reads
+        spectrum_power_pow2_body<LOGN>(a, s, tr, chunk, lds);
     }
 }
 
@@ -350,7 +477,9 @@ static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_tra
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_column_grid(stream_traces, (hop_pairs + F - 1) / F)), dim3(G::WG), lds, stream, a);
+    constexpr uint32_t P = F == 1 ? SPEC_P : 1;
+    const uint32_t chunks = (hop_pairs + F - 1) / F;
+    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_column_grid(stream_traces, (chunks + P - 1) / P)), dim3(G::WG), lds, stream, a);
 }
 
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream) {
@@ -359,7 +488,7 @@ void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t g
     const uint64_t pairs = (uint64_t)a.n_streams * a.n_traces * ((a.n_hops + 1) / 2);
     const uint32_t hop_pairs = (a.n_hops + 1) / 2, st = a.n_streams * a.n_traces;
     (void)pairs;
-    static const bool templated = [] { const char* e = getenv("OMX_SPECTRUM_TEMPLATED"); return e && atoi(e) == 1; }();  // A/B: the size-templated kernel
+    static const bool templated = [] { const char* e = tuning_env("OMX_SPECTRUM_TEMPLATED"); return e && atoi(e) == 1; }();  // A/B: the size-templated kernel
     if (fast4096 && a.fft_size == 16384 && !templated) launch_spectrum_16384(a, st, stream);
     else if (fast4096 && a.fft_size == 16384) launch_spectrum_pow2<14>(a, st, hop_pairs, stream);
     else if (fast4096 && a.fft_size == 8192) launch_spectrum_pow2<13>(a, st, hop_pairs, stream);

@@ -249,7 +249,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
     auto run_chunked = [&]() {  // (after the plan kernel in a ragged call: the per-stream history positions are its output)
         // chunks shorter than blocks while the call has too few (stream, block) items to give every SIMD two wavefronts
         static const int forced_cpb = [] {
-            const char* e = std::getenv("OMX_STEREO_CPB");  // tuning hook: 1 / 2 / 4
+            const char* e = tuning_env("OMX_STEREO_CPB");  // tuning hook: 1 / 2 / 4
             return e ? std::atoi(e) : 0;
         }();
         uint32_t cpb = 1;

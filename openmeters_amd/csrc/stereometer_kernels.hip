@@ -510,7 +510,7 @@ __global__ __launch_bounds__(320) void stereometer_roles_kernel(StereometerArgs 
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
     const uint32_t groups = (a.n_streams + 63) / 64;
-    static const bool no_roles = [] { const char* e = getenv("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
+    static const bool no_roles = [] { const char* e = tuning_env("OMX_STEREO_ROLES"); return e && atoi(e) == 0; }();
     if (a.fmt.channels == 2 && a.analyze_bands && a.block_frames % kStereoRound == 0 && !no_roles && !a.run_if && !a.blocks_v)
     {
         const size_t lds = (size_t)4 * kStereoRound * 64 * sizeof(v2f);  // 64 KiB

@@ -13,6 +13,8 @@
 // (twelve wavefronts) per CU, where the pair kernel's 70 KiB / 254 VGPR allow two.
 #include "stft_kernels.hpp"
 
+#include <mutex>
+
 #include "buffer_device.hpp"
 #include "fft_device.hpp"
 #include "fft_fused_device.hpp"
@@ -422,8 +424,11 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
 
 void launch_stft_reassigned_4096_tri(const StftFastArgs& a, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kTriLds);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kTriLds);
+    });
     const uint32_t chunks = (a.n_cols + 1u) / 2u;
     hipLaunchKernelGGL(stft_reassigned_4096_tri_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), kTriLds, stream, a);
 }

@@ -850,7 +850,7 @@ static void launch_k2_variant(const StftFastArgs& a, hipStream_t stream) {
 #ifdef OMX_TUNING
     // OMX_K2_LDS_PAD (bytes): occupancy experiment only — a larger LDS request lowers the workgroups per CU
     static const size_t env_pad = [] {
-        const char* e = getenv("OMX_K2_LDS_PAD");
+        const char* e = tuning_env("OMX_K2_LDS_PAD");
         return e ? (size_t)atol(e) : (size_t)0;
     }();
     pad = env_pad;
@@ -893,7 +893,7 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
 #endif
     if (a.win_terms == 2) {  // Hann / Hamming: two columns per workgroup, four transforms per column
         static const int env_form = [] {  // TEMP A/B hook
-            const char* e = getenv("OMX_K2_FORM");
+            const char* e = tuning_env("OMX_K2_FORM");
             return e ? atoi(e) : -1;
         }();
         const int f = (form == 0 && env_form >= 0) ? env_form : form;

@@ -1139,7 +1139,7 @@ static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
 // fft_size = 1024, 2048, 4096 or 8192 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-    static const bool one_column_slots = [] { const char* e = getenv("OMX_POW2_SINGLE"); return e && atoi(e) == 1; }();  // A/B: the one-column-per-slot kernel
+    static const bool one_column_slots = [] { const char* e = tuning_env("OMX_POW2_SINGLE"); return e && atoi(e) == 1; }();  // A/B: the one-column-per-slot kernel
     if (a.win_terms == 2 && !one_column_slots && (fft_size == 1024 || fft_size == 2048)) {  // Hann / Hamming: two columns per slot
         if (fft_size == 1024) launch_pow2_pair<10>(a, stream);
         else launch_pow2_pair<11>(a, stream);

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
 void launch_waveform(const WaveformArgs& a, hipStream_t stream) {
     if (a.n_streams == 0) return;
     static const bool pin_single = std::getenv("OMX_WAVEFORM_SINGLE") != nullptr;
-    static const bool ragged_single = std::getenv("OMX_WAVEFORM_RAGGED_SINGLE") != nullptr;  // A/B: ragged calls on the one-wavefront kernel
+    static const bool ragged_single = tuning_env("OMX_WAVEFORM_RAGGED_SINGLE") != nullptr;  // A/B: ragged calls on the one-wavefront kernel
     if (!pin_single && !(a.frames_v && (ragged_single || a.frames > 0xFFFFFFFFull)) && waveform_roles_applicable(a)) {
         launch_waveform_roles(a, stream);
         return;

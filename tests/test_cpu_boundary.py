@@ -161,10 +161,20 @@ def test_generated_rust_ffi_layer_covers_the_header():
         params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
         assert len([p for p in fns[s].split(",") if p.strip()]) == len(params), s
     for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", header, flags=re.S):
-        n_fields = len([f for f in m.group(2).split(";") if f.strip()])
+        # field NAMES in header order, multi-declarator fields (`T a, b;`) split: one `pub name: type,` line each
+        names = []
+        for f in m.group(2).split(";"):
+            for d in f.split(","):
+                d = " ".join(d.split())
+                if d:
+                    names.append(re.match(r"^.*?([A-Za-z_]\w*)(?:\[[^\]]+\])*$", d).group(1))
         body = re.search(r"pub struct " + m.group(3) + r" \{\n(.*?)\n\}", rs, flags=re.S).group(1)
-        assert body.count("pub ") == n_fields, m.group(3)
-    assert "define" not in rs and rs.count("#[repr(C)]") >= 30
+        got = re.findall(r"^    pub (?:r#)?(\w+): ([^\n]+),$", body, flags=re.M)
+        assert [g[0] for g in got] == names, (m.group(3), [g[0] for g in got], names)
+        assert len(got) == len(body.strip().split("\n")), m.group(3)   # nothing but well-formed field lines
+        for _, ty in got:   # no C type token, no stray comma survives into a Rust type
+            assert not re.search(r"\b(uint\d+_t|int\d+_t|float|double|unsigned|size_t|struct)\b|,", ty.replace("; ", ";")), (m.group(3), ty)
+    assert ",," not in rs and "define" not in rs and rs.count("#[repr(C)]") >= 30
 
 
 @pytest.mark.parametrize("rate,frames", [(48000.0, 256), (44100.0, 512), (96000.0, 1024), (192000.0, 1024)])

@@ -683,8 +683,9 @@ def test_loudness_chunk_parallel_form_at_44100_alternates_with_the_sequential_fo
 def test_loudness_chunk_parallel_form_keeps_its_accuracy_across_a_100_dB_drop_and_periodic_rebasing(omx, oracle, rebase):
     """Window sums of the chunk-parallel form are differences of running totals: a loud passage followed by a very quiet one is the
     case where the totals' size, not the window's, sets the error.  4 s at full scale, then a -100 dBFS tone: every snapshot of the
-    quiet passage within 1e-4 dB of the oracle — with the totals taken afresh from the sample ring every 4096 frames (the rebuild
-    path run dozens of times, OMX_OPT_LOUDNESS_REBASE_FRAMES) and with the default interval."""
+    quiet passage within 1e-4 dB of the oracle — with the totals taken afresh from the sample ring whenever a call finds them older
+    than 4096 frames (the rebuild path runs at the start of every call after the first, OMX_OPT_LOUDNESS_REBASE_FRAMES) and with the
+    default interval (no rebuild in this test: the double-double totals alone hold the bar)."""
     S, C, block = 3, 2, 256
     loud_blocks, quiet_blocks = 750, 300
     t = np.arange(block * (loud_blocks + quiet_blocks)) / FS
@@ -706,6 +707,38 @@ def test_loudness_chunk_parallel_form_keeps_its_accuracy_across_a_100_dB_drop_an
             want = [refs[s].process_block(AudioBlock(part[s, k:k + block].reshape(-1), C, FS)) for k in range(0, block * n_blocks, block)]
             for blk in sorted(set([0, 1, n_blocks // 3, n_blocks // 2, n_blocks - 2, n_blocks - 1])):
                 snapshots_close(bank.fetch(s, blk), want[blk])
+        at += block * n_blocks
+
+
+def test_loudness_chunk_parallel_form_after_ninety_seconds_at_full_scale(omx, oracle):
+    """as plain f64 running totals, 20 ... 90 s at full scale left 5e-4 ... 2e-3 dB in a -100 dBFS passage that followed (a
+    window sum is the difference of two totals of ~4e6, each good to 9e-10).  The totals are double-double pairs now: 90 s at 0.9 of
+    full scale with the periodic rebuild switched off, then the -100 dBFS tone, every compared snapshot within 1e-4 dB of the oracle."""
+    S, C, block = 2, 2, 256
+    loud_blocks, quiet_blocks = 16896, 512        # 90.1 s, 2.7 s
+    n = block * (loud_blocks + quiet_blocks)
+    t = np.arange(n) / FS
+    pcm = np.empty((S, n, C), np.float32)
+    for s in range(S):
+        tone = np.sin(2 * np.pi * (500.0 + 37.0 * s) * t)
+        gain = np.where(np.arange(n) < block * loud_blocks, 0.9, 1e-5)
+        pcm[s, :, 0] = (gain * tone).astype(np.float32)
+        pcm[s, :, 1] = (0.8 * gain * tone).astype(np.float32)
+    bank = banks.LoudnessBank(omx, LoudnessConfig(), S, C)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    bank.set_option(capi.OPT_LOUDNESS_REBASE_FRAMES, 1 << 40)
+    refs = [LoudnessProcessor(oracle, LoudnessConfig()) for _ in range(S)]
+    at = 0
+    calls = [1024] * (loud_blocks // 1024) + [256, 256]
+    for ci, n_blocks in enumerate(calls):
+        part = pcm[:, at:at + block * n_blocks]
+        assert bank.process_host(part, block, C, FS) is not None and bank.last_form() == 2
+        quiet = at >= block * loud_blocks
+        for s in range(S):
+            want = [refs[s].process_block(AudioBlock(part[s, k:k + block].reshape(-1), C, FS)) for k in range(0, block * n_blocks, block)]
+            if quiet or ci % 4 == 0:
+                for blk in sorted(set([0, 1, n_blocks // 3, n_blocks // 2, n_blocks - 2, n_blocks - 1])):
+                    snapshots_close(bank.fetch(s, blk), want[blk])
         at += block * n_blocks
 
 
