@@ -34,11 +34,35 @@ __device__ __forceinline__ v2f biquad_lr(const BiquadCoef& c, v2f& z0, v2f& z1, 
     // from the sequential order through the block-boundary states anyway, and both sit on the f32 noise floor of these sections
     // (1e-5 ... 2e-5 of full scale, tests/test_kat_stereometer.py): against the oracle the fused form measures points 2.5e-5 (unfused
     // 2.9e-5), rho 1.8e-7 on bands within 16 dB of the full level (the same).  The sequential kernels keep the reference's order.
+#ifdef STEREO_CHUNK_UNFUSED   // A/B build: the reference's statement order (dsp.rs:422-432), no fused multiply-add
+    const v2f out = c.b[0] * x + z0;
+    z0 = c.b[1] * x - c.a[0] * out + z1;
+    z1 = c.b[2] * x - c.a[1] * out;
+#else
     const v2f out = __builtin_elementwise_fma(v2f{c.b[0], c.b[0]}, x, z0);
     z0 = __builtin_elementwise_fma(v2f{-c.a[0], -c.a[0]}, out, __builtin_elementwise_fma(v2f{c.b[1], c.b[1]}, x, z1));
     z1 = __builtin_elementwise_fma(v2f{-c.a[1], -c.a[1]}, out, c.b[2] * x);
+#endif
     poison = __builtin_elementwise_fma(out, v2f{0.0f, 0.0f}, poison);  // NaN as soon as an output was inf / NaN
     return out;
+}
+
+// The LOW band's zero-state pass runs in f64 (round 4).  Its block-boundary states then follow the exact trajectory of the recurrence, and
+// pass B — f32, the reference's precision — restarts every block from a state that carries no rounding history of its own.  With f32
+// boundary states the low band's correlation sat 4 ... 16x further from exact arithmetic than the reference's own f32 evaluation
+// (tests/test_exact_f64.py, exact-f64 third leg: two independent f32 error processes — the zero-state pass's and pass B's — add up
+// in a band whose signal is 35 dB below the full level); with exact boundary states it is as close as the oracle.  Role 0 has two
+// sections where roles 1 and 2 have four, so the f64 sections (half rate) fill what was idle time of that wavefront in pass A.
+__device__ __forceinline__ void biquad_lr_f64(const BiquadCoef& c, double (&z0)[2], double (&z1)[2], double (&x)[2], double& poison) {
+    const double b0 = (double)c.b[0], b1 = (double)c.b[1], b2 = (double)c.b[2], a0 = (double)c.a[0], a1 = (double)c.a[1];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const double out = __builtin_fma(b0, x[ch], z0[ch]);
+        z0[ch] = __builtin_fma(-a0, out, __builtin_fma(b1, x[ch], z1[ch]));
+        z1[ch] = __builtin_fma(-a1, out, b2 * x[ch]);
+        poison = __builtin_fma(out, 0.0, poison);
+        x[ch] = out;
+    }
 }
 
 struct Moments {
@@ -120,14 +144,24 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) z0[e] = z1[e] = v2f{0.0f, 0.0f};
     float* cs = a.chunk_state + (item * 3u + role) * 16u;  // [8 states][2 channels] as 8 (L, R) pairs: z0[e], z1[e] interleaved
+    // the low band's slot holds its 8 boundary states as f64 ([z0[e], z1[e]] x (L, R), the same order); the other bands' 16 as f32
+    double* cs64 = reinterpret_cast<double*>(cs);
     if (PASS_B && mine && bands) {
+        if (role == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (role == 0 && e >= 2) break;
-            z0[e] = *reinterpret_cast<const v2f*>(cs + 4 * e);
-            z1[e] = *reinterpret_cast<const v2f*>(cs + 4 * e + 2);
+            for (int e = 0; e < 2; ++e) {
+                z0[e] = v2f{(float)cs64[4 * e], (float)cs64[4 * e + 1]};
+                z1[e] = v2f{(float)cs64[4 * e + 2], (float)cs64[4 * e + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0[e] = *reinterpret_cast<const v2f*>(cs + 4 * e);
+                z1[e] = *reinterpret_cast<const v2f*>(cs + 4 * e + 2);
+            }
         }
     }
+    double d0[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, d1[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, poison64 = 0.0;  // pass A, role 0: [section][channel]
     v2f poison{0.0f, 0.0f};
     Moments full, band;
     const double alpha = a.alpha;
@@ -158,7 +192,13 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
 #pragma unroll
         for (int f = 0; f < STEP; ++f) {
             v2f v = x[f];
-            if (bands) {
+            if (!PASS_B && role == 0) {   // (wave-uniform) the low band's zero-state pass in f64: only its end state is used
+                if (bands) {
+                    double xd[2] = {(double)v.x, (double)v.y};
+                    biquad_lr_f64(ca, d0[0], d1[0], xd, poison64);
+                    biquad_lr_f64(ca, d0[1], d1[1], xd, poison64);
+                }
+            } else if (bands) {
                 v = biquad_lr(ca, z0[0], z1[0], v, poison);
                 v = biquad_lr(ca, z0[1], z1[1], v, poison);
                 if (role != 0) {
@@ -189,14 +229,21 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
             }
         }
     }
-    if (!(poison.x == 0.0f && poison.y == 0.0f)) bad = 1u;
+    if (!(poison.x == 0.0f && poison.y == 0.0f) || !(poison64 == 0.0)) bad = 1u;
     if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
     if (!mine) return;
     if constexpr (!PASS_B) {
-        if (bands) {
+        if (bands && role == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cs64[4 * e] = d0[e][0];
+                cs64[4 * e + 1] = d0[e][1];
+                cs64[4 * e + 2] = d1[e][0];
+                cs64[4 * e + 3] = d1[e][1];
+            }
+        } else if (bands) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (role == 0 && e >= 2) break;
                 *reinterpret_cast<v2f*>(cs + 4 * e) = z0[e];
                 *reinterpret_cast<v2f*>(cs + 4 * e + 2) = z1[e];
             }
@@ -231,7 +278,8 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
 }
 
 // scan 1: wavefront = (stream, band 1..3, channel); states of one channel of one band: [z0[e], z1[e]] for e = 0..3 (band 1: e = 0, 1)
-template <int N>
+// F64IO (the low band): the zero-state end states arrive, and the true start states leave, as f64 in the same slots
+template <int N, bool F64IO>
 __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const double* __restrict__ Tp /* [6][8][8] powers 1,2,..32 */,
                                                  uint32_t s, uint32_t r, uint32_t ch, uint32_t lane) {
     StereoLaneState& st = a.state[(uint64_t)s * 4u + r + 1u];
@@ -244,9 +292,10 @@ __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const
         const uint32_t c = c0 + lane;
         const bool live = c < nb;
         float* cs = a.chunk_state + (((uint64_t)s * a.n_blocks + (live ? c : c0)) * 3u + r) * 16u;
+        double* cs64 = reinterpret_cast<double*>(cs);
         double x[N];
 #pragma unroll
-        for (int k = 0; k < N; ++k) x[k] = live ? (double)cs[2 * k + ch] : 0.0;
+        for (int k = 0; k < N; ++k) x[k] = !live ? 0.0 : F64IO ? cs64[2 * k + ch] : (double)cs[2 * k + ch];
         if (lane == 0) {  // x_0 += T carry
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -282,9 +331,16 @@ __device__ __forceinline__ void scan_states_wave(const StereoChunkArgs& a, const
             const float v = (float)start;
             // (the flush belongs to block ends, :134-140: a chunk that starts inside a block takes its state unflushed)
             const bool at_block = c % a.cpb == 0u;
-            if (live) cs[2 * k + ch] = at_block && fabsf(v) < 1.0e-20f ? 0.0f : v;  // the chunk's TRUE start state replaces its zero-state end state
-            const float e = (float)shfl_f64(x[k], (int)last);
-            carry[k] = (c0 + last + 1u) % a.cpb == 0u && fabsf(e) < 1.0e-20f ? 0.0 : (double)e;  // the filters carry f32 states
+            const bool flush = at_block && fabsf(v) < 1.0e-20f;
+            if (live) {  // the chunk's TRUE start state replaces its zero-state end state
+                if constexpr (F64IO) cs64[2 * k + ch] = flush ? 0.0 : start;
+                else cs[2 * k + ch] = flush ? 0.0f : v;
+            }
+            const double e64 = shfl_f64(x[k], (int)last);
+            const float e = (float)e64;
+            const bool flush_e = (c0 + last + 1u) % a.cpb == 0u && fabsf(e) < 1.0e-20f;
+            // between the sweeps of one call the low band keeps its f64 trajectory; what leaves the call is the filters' f32 state
+            carry[k] = flush_e ? 0.0 : (F64IO && c0 + 64u < nb) ? e64 : (double)e;
         }
     }
     if (lane == 0 && (nb != 0u || reset)) {
@@ -296,8 +352,8 @@ __global__ __launch_bounds__(256) void stereo_scan_states_kernel(StereoChunkArgs
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (w >= a.n_streams * 6u) return;
     const uint32_t s = w / 6u, r = (w % 6u) >> 1, ch = w & 1u;  // r = band - 1
-    if (r == 0) scan_states_wave<4>(a, T, s, r, ch, lane);
-    else scan_states_wave<8>(a, T + r * 384, s, r, ch, lane);
+    if (r == 0) scan_states_wave<4, true>(a, T, s, r, ch, lane);
+    else scan_states_wave<8, false>(a, T + r * 384, s, r, ch, lane);
 }
 
 // scan 2: wavefront = (stream, band 0..3); the three moments decay by (1 - alpha)^L per block

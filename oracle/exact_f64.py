@@ -343,3 +343,53 @@ class ScopeTraceExact:
         if cap is None:
             return float(max(max(self.base_frames - 1, 0), 1)), max(len(trace) - self.base_frames, 0), 0.0
         return cap
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Stereometer — an f64 restatement of the band split and the correlators (reference src/visuals/stereometer/processor.rs:34-61,
+# :99-182; src/dsp.rs:399-495).  The filter COEFFICIENTS are the reference's f32 values (Biquad::new evaluates them in f32, and a
+# pole pair at 200 Hz / 48 kHz turns a coefficient difference of 6e-8 into 1e-4 of response): what is exact here is the
+# RECURRENCE — scipy's f64 lfilter on the f32 samples — and the f64 moving averages of the correlators.  Third leg of the
+# chunk-parallel stereometer form (tests/test_exact_f64.py): the sequential f32 order of the reference and the re-ordered, fused
+# order of the kernels are two f32 evaluations of the same recurrence, each 1e-5 ... 2e-5 of full scale away from this one.
+class StereometerExact:
+    BAND_DISPLAY_GAIN = 0.8   # :8
+
+    def __init__(self, sample_rate=48000.0, segment_duration=0.02, target_sample_count=2000, correlation_window=0.05):
+        self.rate = float(sample_rate)
+        r32 = np.float32(sample_rate)
+        self.frames = int(max(np.round(r32 * np.float32(segment_duration)), 1.0))                    # :163
+        self.target = min(max(int(target_sample_count), 1), self.frames)
+        self.alpha = 1.0 - np.exp(-1.0 / max(float(r32) * float(np.float32(correlation_window)), 1.0))   # :210-212
+
+    def _biquad(self, highpass, f):   # Biquad::new (dsp.rs:402-420), every step in f32
+        f32 = np.float32
+        ratio = np.clip(f32(f) / f32(self.rate), f32(1e-6), f32(0.49))
+        ang = f32(6.2831855) * ratio
+        sin, cos = f32(np.sin(ang)), f32(np.cos(ang))
+        alpha = sin * f32(0.70710677)
+        gain, sign = (f32(1) + cos, f32(-1)) if highpass else (f32(1) - cos, f32(1))
+        inv = f32(1) / (f32(1) + alpha)
+        return (np.array([gain * f32(0.5) * inv, gain * inv * sign, gain * f32(0.5) * inv], np.float64),
+                np.array([1.0, f32(-2) * cos * inv, (f32(1) - alpha) * inv], np.float64))
+
+    def run(self, pcm_lr):
+        """pcm_lr [frames][2] f32, the whole stream from reset.  Returns (points [4][target][2], correlations [4]) as the snapshot
+        after the last frame would hold them: band order full, low, mid, high (ThreeBand<_, true>: the high band is cut from `above_low`)."""
+        from scipy.signal import lfilter
+
+        def lr4(c, v):
+            return lfilter(c[0], c[1], lfilter(c[0], c[1], v, axis=0), axis=0)
+        x = np.asarray(pcm_lr, np.float64)
+        above = lr4(self._biquad(True, 200.0), x)
+        bands = [x, lr4(self._biquad(False, 200.0), x), lr4(self._biquad(False, 2000.0), above), lr4(self._biquad(True, 2000.0), above)]
+        idx = (np.arange(self.target) * self.frames) // self.target                                  # :171 hist[i * frames / target]
+        points, rho = [], []
+        for b, v in enumerate(bands):
+            tail = v[-self.frames:]
+            points.append(tail[idx] * (1.0 if b == 0 else self.BAND_DISPLAY_GAIN))
+            l, r = v[:, 0], v[:, 1]
+            ema = [lfilter([self.alpha], [1.0, -(1.0 - self.alpha)], q)[-1] for q in (l * r, l * l, r * r)]   # :36-40 from zero moments
+            denom = np.sqrt(ema[1] * ema[2])
+            rho.append(0.0 if denom <= 1e-12 else float(np.clip(ema[0] / denom, -1.0, 1.0)))
+        return np.array(points), np.array(rho)

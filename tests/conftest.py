@@ -22,6 +22,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (gfx950) device")
 
 
+# ---- in-suite soak (tests/test_gpu_soak.py): seeds nobody picked.  The base changes from run to run (the clock) unless OMX_SOAK_SEED pins
+# it — set it to the value a failing run printed to reproduce that run.
+SOAK_BASE = int(os.environ.get("OMX_SOAK_SEED", "0")) or (int(__import__("time").time()) % 1_000_000 + 1)
+
+
+def soak_seeds(count, salt):
+    """`count` seeds for soak case number `salt`, disjoint from the suite's fixed seeds (those are < 1000)"""
+    return [SOAK_BASE * 1000 + salt * 40 + i for i in range(count)]
+
+
+def pytest_report_header(config):
+    return f"soak seed base (OMX_SOAK_SEED to reproduce): {SOAK_BASE}"
+
+
 def pytest_sessionfinish(session, exitstatus):
     path = os.environ.get("OMX_PARITY_REPORT")
     if path:

@@ -178,6 +178,51 @@ BAR_POWER, BAR_FREQ, BAR_TIME, BAR_ORPHAN = 1e-5, 1e-7, 1e-4, 3e-7
 BAR_FREQ_STRONG, BAR_TIME_STRONG = 1e-6, 5e-4   # measured 2.0e-7 / 6.7e-5 (profiles/parity_r02.txt)
 
 
+# ---- conditioning-derived bars (round 4).  A fixed bar is a statement about well-conditioned columns; a random sequence also produces
+# columns whose OWN f32 evaluation is unstable (a window on near-silence beside a loud passage: the analytic signal is computed over
+# 2W samples and its rounding noise scales with the loudest of them).  How unstable is measured, not guessed: the oracle
+# runs a second time on the same PCM with every non-zero sample moved by one f32 ulp (`ulp_perturbed`), and the distance between
+# its two outputs — `sens` — is the size of ONE realisation of input-rounding noise in that column.  HIP and oracle differ by the
+# rounding of ~5 transforms of log2 N = 10 ... 14 stages on either side, i.e. ~sqrt(2 * 5 * 12) = 11 independent realisations of that
+# size in quadrature: the bar of a column is fixed bar + CONDITIONING_K * sens with K = 16 (the implementation's own noise plus what the
+# column's conditioning makes of it).  The three soak columns that went over
+# the fixed bars in round 3 (f-hat 1.3x / 4.3x, power 1.2x) measured 1.0x ... 9x their sens and pass by this rule; the ledger records
+# err / bar, so a column that needs its conditioning term shows up as a ratio, not as a widened constant.
+CONDITIONING_K = 16.0
+
+
+def ulp_perturbed(pcm, rng):
+    """every non-zero f32 sample moved to a neighbouring float (zeros stay zero: silence detection and `stereo_channels` test bits)"""
+    x = np.ascontiguousarray(pcm, np.float32)
+    up = rng.integers(0, 2, x.shape).astype(bool)
+    y = np.where(up, np.nextafter(x, np.float32(np.inf)), np.nextafter(x, np.float32(-np.inf))).astype(np.float32)
+    y[x == 0.0] = 0.0
+    y[~np.isfinite(y) | (y == 0.0)] = x[~np.isfinite(y) | (y == 0.0)]   # (a sample one ulp from zero or from overflow stays put)
+    return y
+
+
+def conditioned_bar(name, err, fixed, sens, detail=None):
+    """bar(err / (fixed + K sens), 1): the fixed bar on well-conditioned columns, measured conditioning on top elsewhere.  Columns whose
+    conditioning term is below a tenth of the fixed bar are also entered under the plain fixed bar (ledger: what the bar measures
+    when conditioning plays no part)."""
+    limit = float(fixed) + CONDITIONING_K * float(sens)
+    bar(name + " / (bar + 16 x oracle's 1-ulp sensitivity)", float(err) / limit, 1.0, (err, fixed, sens, detail))
+    if CONDITIONING_K * float(sens) <= 0.1 * float(fixed):
+        bar(name + " [well-conditioned columns]", err, 1.1 * float(fixed), detail)
+
+
+def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag="reassigned (random sequences)", time_bar=BAR_TIME):
+    """one column against the oracle with conditioning-derived bars; `ora_perturbed` = the oracle's column for the ulp-perturbed input"""
+    m = reassigned_column_metrics(hip, ora, sample_rate, hop)
+    s = reassigned_column_metrics(ora_perturbed, ora, sample_rate, hop)
+    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER, s["power"], (m, s))
+    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ, s["freq"], (m, s))
+    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar, s["time"], (m, s))
+    conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN, s["orphan"], (m, s))
+    assert m["orphans"] <= 4 + s["orphans"], (m, s)
+    return m, s
+
+
 def check_reassigned_columns(got, want, sample_rate, hop, scale=1.0):
     """`scale` >= 1 loosens every float bar for ill-conditioned input (state-machine tests: a window on near-silence next to a
     loud passage, DESIGN §2 conditioning note)."""
@@ -258,12 +303,35 @@ def classic_column_metrics(hip, ora):
                 loud_code_diff=int(d[loud].max()) if loud.any() else 0)
 
 
+CODE_STEP = 10.0 ** (156.0 / 65535.0 / 10.0) - 1.0   # one u16 code in relative linear power: 5.48e-4
+FFT_NOISE_AMPLITUDE = 4e-7   # f32 transform noise per bin, relative to the column's largest amplitude: ~eps sqrt(log2 N) with the
+                             # two-columns-per-transform packing (each column sees the other's rounding); measured <= 1.2e-7
+
+
+def classic_noise_budget(p_rel):
+    """what the f32 transform noise n (amplitude, relative to the column's largest) may move a bin of relative linear power p_rel by:
+    2 sqrt(p) n + n^2"""
+    return 2.0 * np.sqrt(p_rel) * FFT_NOISE_AMPLITUDE + FFT_NOISE_AMPLITUDE ** 2
+
+
 def check_classic(got, want):
-    """fused-kernel bar: codes within 1 for every bin within 40 dB of the column maximum; below that, linear power within
-    6e-8 of the column maximum (= one code at -40 dB, where the two criteria meet) (an f32 FFT's own noise floor: the codes of bins 100 dB down are not reproducible between two
-    correct transforms, and the two-columns-per-FFT packing lets each column see the other's rounding noise)"""
+    """fused-kernel bars.  Codes are a quantiser's output: 1 is the smallest bar that can hold between two implementations at all (a
+    value within the arithmetic error of a code boundary lands on either side), and a difference of 2 needs |d dB| > 0.0024, i.e. 5.5e-4
+    relative.  (1) Every bin within 40 dB of the column maximum: |d code| <= 1.  (2) Below that the f32 transform noise (amplitude n
+    relative to the column's largest, shared by both columns of the packed transform) exceeds a code step from -57 dB down, and the codes
+    of bins 100 dB down are not reproducible between two correct transforms at all: a bin passes with |d code| <= 1, or with
+    |dP| <= 2 sqrt(P) n + n^2 for n = 4e-7.  The ledger records the largest |dP| / noise budget over the bins that needed rule two.
+    (The round-3 form of (2) — 6e-8 of the maximum, flat — was the code step AT -40 dB and sat at 1.1x its measured maximum for that
+    reason: the largest weak bins are the ones right below -40 dB, one code apart.)"""
     assert len(got) == len(want)
     for h, o in zip(got, want):
         m = classic_column_metrics(h, o)
         bar("classic (fused): |d code| within 40 dB of max", m["loud_code_diff"], 1, m)
-        bar("classic (fused): |dP| / max P below -40 dB", m["weak_power"], 6e-8, m)   # 6e-8 = one code at -40 dB
+        db_h, db_o = h.astype(np.float64) * (156.0 / 65535.0) - 144.0, o.astype(np.float64) * (156.0 / 65535.0) - 144.0
+        top = db_o.max()
+        p_h, p_o = 10.0 ** ((db_h - top) / 10.0), 10.0 ** ((db_o - top) / 10.0)
+        far = np.abs(h.astype(np.int64) - o.astype(np.int64)) > 1
+        ratio = float((np.abs(p_h - p_o)[far] / classic_noise_budget(np.maximum(p_h, p_o)[far])).max()) if far.any() else 0.0
+        bar("classic (fused): |dP| / f32 transform noise budget, bins more than one code apart", ratio, 1.0, m)
+
+

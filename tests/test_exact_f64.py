@@ -27,6 +27,7 @@ REASSIGNED_SHAPES = [(4096, 256, 1, 1), (2048, 64, 1, 1), (1024, 256, 2, 3), (40
                      (16384, 2048, 1, 2), (2048, 256, 8, 2), (1536, 384, 1, 1), (1000, 250, 3, 1)]   # the last two: lengths that are not powers of two   # W, hop, zp, window
 CLASSIC_SHAPES = [(1024, 256, 1, 1), (4096, 256, 1, 1), (2048, 128, 2, 3)]
 HALF_CODE_DB = 0.5 * 156.0 / 65535.0
+CLASSIC_ARITHMETIC_DB = 1e-4   # arithmetic error allowed on top of the quantiser's own half code
 # The reference's OWN f32 arithmetic is this far from exact arithmetic in t-hat on one shape of the list: Hamming (whose end points are
 # 0.08, a step for the time-weighted window t w) through 8x zero padding measures 1.08e-4 hops, against 3e-7 ... 6e-6 elsewhere.  The
 # bar on the ORACLE is therefore 2e-4 there; the HIP kernels (window applied on the bins, no t w table) measure 3.3e-6 on that shape
@@ -56,19 +57,31 @@ def reassigned_errors(api, W, hop, zp, kind, ncols=6, stream=3):
 
 
 def classic_errors(api, W, hop, zp, kind, ncols=6):
+    """(quantised, arithmetic) over every bin within 40 dB of the column maximum.
+      quantised : |dB(code) - dB(exact)|: half a code (0.00119 dB) by construction of a rounding quantiser, plus the arithmetic error
+      arithmetic: a LOWER bound of the arithmetic error alone, in dB: where the code differs from round(exact), the exact value's
+                  distance to the code boundary it was pushed across (0 when every code equals the exactly rounded one)."""
     pcm = cfg1_pcm(30000 + W + hop * (ncols - 1))[30000:]
     cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, window=kind, use_reassignment=False, history_length=8192)
     up = SpectrogramProcessor(api, cfg).process_block(AudioBlock(pcm.reshape(-1), 2, FS))
     assert len(up.new_columns) == ncols
     mid = mid_of(pcm)
-    worst = 0.0
+    worst, arith, moved = 0.0, 0.0, 0
     for c in range(ncols):
         p = ex.classic_column_power(mid[c * hop:], kind, W, zp)
         db_exact = 10.0 * np.log10(np.maximum(p, 1e-300))
-        db_code = np.asarray(up.new_columns[c], np.float64) * (156.0 / 65535.0) - 144.0
+        codes = np.asarray(up.new_columns[c], np.float64)
+        db_code = codes * (156.0 / 65535.0) - 144.0
         loud = db_exact >= db_exact.max() - 40.0
         worst = max(worst, float(np.abs(db_code - db_exact)[loud].max()))
-    return worst
+        u = (db_exact + 144.0) * (65535.0 / 156.0)                 # the exact level in (fractional) codes
+        off = (codes != np.round(u)) & loud
+        assert (np.abs(codes - np.round(u))[loud] <= 1).all()
+        if off.any():
+            boundary = np.minimum(codes, np.round(u))[off] + 0.5   # the boundary between the exact code and the one produced
+            arith = max(arith, float(np.abs(u[off] - boundary).max()) * 156.0 / 65535.0)
+            moved += int(off.sum())
+    return worst, arith, moved
 
 
 @pytest.mark.parametrize("W,hop,zp,kind", REASSIGNED_SHAPES)
@@ -80,7 +93,8 @@ def test_oracle_reassigned_column_is_within_1e5_of_exact_arithmetic(oracle, W, h
 
 @pytest.mark.parametrize("W,hop,zp,kind", CLASSIC_SHAPES)
 def test_oracle_classic_column_is_within_half_a_code_of_exact_arithmetic(oracle, W, hop, zp, kind):
-    assert classic_errors(oracle, W, hop, zp, kind) <= HALF_CODE_DB + 1e-4
+    quantised, arithmetic, _ = classic_errors(oracle, W, hop, zp, kind)
+    assert quantised <= HALF_CODE_DB + CLASSIC_ARITHMETIC_DB and arithmetic <= CLASSIC_ARITHMETIC_DB
 
 
 @pytest.mark.gpu
@@ -104,9 +118,15 @@ def test_hip_and_oracle_are_equally_close_to_exact_arithmetic_reassigned(omx, or
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,hop,zp,kind", CLASSIC_SHAPES)
 def test_hip_and_oracle_are_equally_close_to_exact_arithmetic_classic(omx, oracle, W, hop, zp, kind):
-    h, o = classic_errors(omx, W, hop, zp, kind), classic_errors(oracle, W, hop, zp, kind)
-    bar("hip vs exact f64: classic |d dB| within 40 dB of max", h, HALF_CODE_DB + 1e-4)
-    bar("oracle vs exact f64: classic |d dB| within 40 dB of max", o, HALF_CODE_DB + 1e-4)
+    """The quantised distance is half a code by construction (a rounding quantiser's own error: bar and measured maximum can only
+    coincide, 0.00129 against 0.00118 in round 3); what the implementations are responsible for is the ARITHMETIC part, bounded from
+    below by the codes that differ from the exactly rounded ones: bar 1e-4 dB (2.3e-5 relative power), with its measured margin in
+    the ledger."""
+    (hq, ha, _), (oq, oa, _) = classic_errors(omx, W, hop, zp, kind), classic_errors(oracle, W, hop, zp, kind)
+    bar("hip vs exact f64: classic |d dB| within 40 dB of max (half a code by construction + arithmetic)", hq, HALF_CODE_DB + CLASSIC_ARITHMETIC_DB)
+    bar("oracle vs exact f64: classic |d dB| within 40 dB of max (half a code by construction + arithmetic)", oq, HALF_CODE_DB + CLASSIC_ARITHMETIC_DB)
+    bar("hip vs exact f64: classic arithmetic error (codes moved across a boundary), dB", ha, CLASSIC_ARITHMETIC_DB)
+    bar("oracle vs exact f64: classic arithmetic error (codes moved across a boundary), dB", oa, CLASSIC_ARITHMETIC_DB)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -168,3 +188,70 @@ def test_hip_scope_capture_position_is_as_close_to_exact_arithmetic_as_the_oracl
     assert m_o == 0 and m_h == 0
     bar("scope capture (HIP vs exact f64): |d position| samples", worst_h, 3e-4)
     bar("scope capture: HIP error / max(oracle error, 5e-5 samples)", worst_h / max(worst_o, 5e-5), 2.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Stereometer: the chunk-parallel (and fused) band split of the HIP product against exact arithmetic, next to the oracle's own
+# distance (the default bank form moved further from the reference's operation order for speed; this leg says
+# whether it moved further from the TRUTH).
+def stereo_exact_case(s, blocks=64):
+    from golden_inputs import cfg4_pcm
+    from openmeters_amd.capi import StereometerConfig
+    cfg = StereometerConfig(analyze_bands=True, emit_band_points=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=960)
+    pcm = cfg4_pcm(s, 256 * blocks)
+    if s % 3 == 1:
+        pcm = (pcm * np.float32(0.05)).astype(np.float32)     # a quiet stream: absolute errors scale with the level
+    want_points, want_rho = ex.StereometerExact(FS, 0.02, 960, 0.05).run(pcm)
+    return cfg, pcm, want_points, want_rho
+
+
+def stereo_distance(points, rho, want_points, want_rho):
+    """(max |d point| over the four bands, max |d rho| over the bands that hold signal)"""
+    dp = max(float(np.abs(np.asarray(points[b], np.float64) - want_points[b]).max()) for b in range(4))
+    return dp, float(np.abs(np.asarray(rho, np.float64) - want_rho).max())
+
+
+@pytest.mark.parametrize("s", [30, 31, 32, 35])
+def test_oracle_stereometer_is_close_to_exact_arithmetic(oracle, s):
+    from openmeters_amd.capi import StereometerProcessor
+    cfg, pcm, want_points, want_rho = stereo_exact_case(s)
+    p = StereometerProcessor(oracle, cfg)
+    for k in range(0, len(pcm), 256):
+        w = p.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+    dp, dr = stereo_distance(w.points, w.correlations, want_points, want_rho)
+    level = float(np.abs(pcm).max())
+    assert dp <= 1e-4 * level and dr <= 2e-5, (dp, dr, level)    # measured 1.0e-5 ... 1.9e-5 of the level; rho 7e-7 ... 5.4e-6 (low band)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s", [30, 31, 32, 35])
+def test_hip_chunk_parallel_stereometer_is_as_close_to_exact_arithmetic_as_the_oracle(omx, oracle, s):
+    """|HIP - exact| <= 2 |oracle - exact| on the band points and on the correlations, for the chunk-parallel form the banks run by
+    default (fused multiply-adds in the band sections) and for the sequential form (the reference's order: its distance IS the
+    oracle's).  Floors: 2e-6 of the stream's level for points (a tenth of the oracle's typical distance), 2e-7 for rho.
+    Round 4 record: with f32 block-boundary states the chunk-parallel form FAILED this on the low band (rho 3.4e-6 ... 1.2e-5 from
+    exact against the oracle's 7e-7 ... 5.4e-6; without the fused multiply-adds 1e-5 ... 3e-5, so un-fusing was not the cure); its
+    zero-state pass and boundary states are f64 since, and it measures 1.2e-7 ... 2.0e-7 — closer than the reference's own arithmetic."""
+    from openmeters_amd import banks, capi
+    from openmeters_amd.capi import StereometerProcessor
+    cfg, pcm, want_points, want_rho = stereo_exact_case(s)
+    p = StereometerProcessor(oracle, cfg)
+    for k in range(0, len(pcm), 256):
+        w = p.process_block(AudioBlock(pcm[k:k + 256].reshape(-1), 2, FS))
+    o_dp, o_dr = stereo_distance(w.points, w.correlations, want_points, want_rho)
+    level = float(np.abs(pcm).max())
+    n_blocks = len(pcm) // 256
+    for form, name in ((2, "chunk-parallel"), (1, "sequential")):
+        bank = banks.StereometerBank(omx, cfg, 1)
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        bank.process_host(pcm[None], 256, 2, FS)
+        assert bank.last_form() == form
+        rho, produced = bank.fetch(0, n_blocks - 1)
+        assert produced
+        h_dp, h_dr = stereo_distance([bank.fetch_points(0, b) for b in range(4)], rho, want_points, want_rho)
+        bar(f"stereometer ({name}) vs exact f64: |d point| / level", h_dp / level, 1e-4)
+        bar(f"stereometer ({name}) vs exact f64: |d rho|", h_dr, 2e-5)
+        bar(f"stereometer ({name}): hip / oracle distance ratio from exact (points)", max(h_dp, 2e-6 * level) / max(o_dp, 2e-6 * level), 2.0)
+        bar(f"stereometer ({name}): hip / oracle distance ratio from exact (rho)", max(h_dr, 2e-7) / max(o_dr, 2e-7), 2.0)
+    bar("stereometer oracle vs exact f64: |d point| / level", o_dp / level, 1e-4)
+    bar("stereometer oracle vs exact f64: |d rho|", o_dr, 2e-5)
