@@ -336,6 +336,7 @@ typedef struct omx_spectrum_bank_update {
 int omx_spectrum_bank_create(const omx_spectrum_config* cfg, uint32_t n_streams, int emit_all_hops,
                              omx_spectrum_bank** out);
 void omx_spectrum_bank_destroy(omx_spectrum_bank* b);
+int omx_spectrum_bank_update_config(omx_spectrum_bank* b, const omx_spectrum_config* cfg); /* update_config of every stream's processor (spectrum/processor.rs:300-320) */
 int omx_spectrum_bank_reset_audio(omx_spectrum_bank* b);
 int omx_spectrum_bank_process(omx_spectrum_bank* b, const float* pcm, int pcm_on_device,
                               uint64_t frames, uint32_t channels, float sample_rate,
@@ -490,6 +491,7 @@ typedef struct omx_stereometer_bank_update {
 int omx_stereometer_bank_create(const omx_stereometer_config* cfg, uint32_t n_streams,
                                 omx_stereometer_bank** out);
 void omx_stereometer_bank_destroy(omx_stereometer_bank* b);
+int omx_stereometer_bank_update_config(omx_stereometer_bank* b, const omx_stereometer_config* cfg); /* update_config of every stream's processor (stereometer/processor.rs:183-207) */
 int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
 /* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_stereometer_bank_set_option pins one):
  *   sequential kernels — the reference's operation order: points bit-exact, rho error 0 against the CPU restatement —
@@ -638,6 +640,7 @@ typedef struct omx_waveform_bank_update {
 } omx_waveform_bank_update;
 int omx_waveform_bank_create(const omx_waveform_config* cfg, uint32_t n_streams, omx_waveform_bank** out);
 void omx_waveform_bank_destroy(omx_waveform_bank* b);
+int omx_waveform_bank_update_config(omx_waveform_bank* b, const omx_waveform_config* cfg); /* update_config of every stream's processor (waveform/processor.rs:336-352) */
 int omx_waveform_bank_reset_audio(omx_waveform_bank* b);
 int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on_device, uint64_t frames,
                               uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS],
@@ -725,6 +728,7 @@ typedef struct omx_oscilloscope_bank_update {
 int omx_oscilloscope_bank_create(const omx_oscilloscope_config* cfg, uint32_t n_streams,
                                  omx_oscilloscope_bank** out);
 void omx_oscilloscope_bank_destroy(omx_oscilloscope_bank* b);
+int omx_oscilloscope_bank_update_config(omx_oscilloscope_bank* b, const omx_oscilloscope_config* cfg); /* update_config of every stream's processor (oscilloscope/processor.rs:752-759) */
 int omx_oscilloscope_bank_reset_audio(omx_oscilloscope_bank* b);
 int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, int pcm_on_device,
                                   uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
@@ -924,6 +928,19 @@ typedef struct omx_capture_group_update {
     omx_waveform_bank_update waveform;
     const float* d_stats_rows;       /* [n_streams][OMX_STATS_COLUMNS], or NULL (OMX_OPT_GROUP_STATS off / a visual it needs disabled) */
 } omx_capture_group_update;
+/* what omx_capture_group_ingest_ragged leaves behind: every enabled bank's own ragged update (per-stream counts in device memory) */
+typedef struct omx_capture_group_ragged_update {
+    uint32_t produced;               /* OMX_VISUAL_* bits: which visuals produced an update for at least one capture */
+    uint32_t _pad;
+    uint64_t block_frames;           /* how the block-based visuals saw the call: capture s ran frames[s] / block_frames blocks ... */
+    uint64_t max_blocks;             /* ... of at most frames_capacity / block_frames */
+    omx_spectrogram_ragged_update spectrogram;
+    omx_spectrum_ragged_update spectrum;
+    omx_loudness_ragged_update loudness;
+    omx_stereometer_ragged_update stereometer;
+    omx_oscilloscope_ragged_update oscilloscope;
+    omx_waveform_ragged_update waveform;
+} omx_capture_group_ragged_update;
 typedef struct omx_capture_group omx_capture_group;
 void omx_capture_group_config_default(omx_capture_group_config* out); /* every visual's default config, none enabled, 1 stream */
 int omx_capture_group_create(const omx_capture_group_config* cfg, omx_capture_group** out);
@@ -932,6 +949,33 @@ int omx_capture_group_reset_audio(omx_capture_group* g);              /* VisualM
 int omx_capture_group_set_option(omx_capture_group* g, uint32_t option, uint64_t value); /* OMX_OPT_GROUP_*, OMX_OPT_KERNEL_TIMING */
 int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t frames, uint32_t channels, float sample_rate,
                              const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_update* out);
+/* ---- the rest of VisualManager (registry.rs:266-277, :343-365, :396-418) ----
+ * set_enabled: `visual` is ONE OMX_VISUAL_* bit.  A disabled visual is skipped by ingest and keeps its state (Entry.enabled gates
+ *   module.ingest, :413-417); enabling prepares it (Entry::set_enabled -> module.prepare(), :272-277) — a visual that was not in
+ *   cfg->visuals at creation gets its bank here, from the config the group holds for it.
+ * update_config: Entry::apply_settings -> processor.update_config (:54-58, :266-270).  `config` points to the omx_<visual>_config of
+ *   that visual (omx_spectrogram_config for OMX_VISUAL_SPECTROGRAM, ...); it takes effect between two ingest calls exactly as
+ *   omx_<visual>_bank_update_config does (a spectrogram hop change mid-stream keeps the pending samples, `reset` is carried into the
+ *   next update).  OMX_VISUAL_LOUDNESS -> OMX_ERR_INVALID: LoudnessProcessor has no update_config (loudness/processor.rs:225-253).
+ *   The config of a disabled / not yet created visual is stored and used when it is enabled.
+ * note_format: ingest_samples' format-generation rule (:400-406): the host passes AudioFormat.generation before the ingest of a
+ *   chunk; a value different from the previous one resets every visual first (returns 1), the first value and equal values do
+ *   nothing (0).  omx_capture_group_reset_audio forgets the generation (format_generation = None, :361).
+ * ingest_ragged: per-capture frame counts and per-capture reset flags — one VisualManager per capture in the reference, each fed by
+ *   its own batcher and reset on its own.  `pcm` is device memory [n_streams][frames_capacity][channels]; capture s delivers its
+ *   first frames[s] <= frames_capacity frames (0: nothing arrived) after reset_audio() where reset_mask[s] != 0 (reset_mask may be
+ *   NULL).  frames[] / reset_mask[] are HOST arrays.  Counts must be multiples of block_frames (the batcher's quantum: it hands out
+ *   1 ... 4 of them per chunk, meter.rs:40-69); the block-based visuals run capture s for frames[s] / block_frames blocks.  Every
+ *   enabled bank goes through its own omx_<visual>_bank_process_ragged: per stream the results equal a single-stream handle fed the
+ *   same sequence.  After the first ragged call the group's positions are per capture: omx_capture_group_ingest is refused
+ *   (OMX_ERR_INVALID) until omx_capture_group_reset_audio.  Summary rows (OMX_OPT_GROUP_STATS) are a lock-step feature. */
+int omx_capture_group_set_enabled(omx_capture_group* g, uint32_t visual, int enabled);
+int omx_capture_group_enabled(const omx_capture_group* g);            /* OMX_VISUAL_* bits ingest currently feeds */
+int omx_capture_group_update_config(omx_capture_group* g, uint32_t visual, const void* config, void* stream);
+int omx_capture_group_note_format(omx_capture_group* g, uint64_t generation);
+int omx_capture_group_ingest_ragged(omx_capture_group* g, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                    const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                    const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_ragged_update* out);
 /* average duration of the spectrogram bank's column kernel since the last call (OMX_OPT_KERNEL_TIMING), as
  * omx_spectrogram_bank_kernel_time */
 int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t* launches);

@@ -198,6 +198,10 @@ class _BlockBank:
     def reset_audio(self):
         self.api.check(self.api.fn(f"{self._family}_bank_reset_audio", C.c_int, [C.c_void_p])(self._h))
 
+    def update_config(self, config):
+        c = config.to_c()
+        self.api.check(self.api.fn(f"{self._family}_bank_update_config", C.c_int, [C.c_void_p, C.c_void_p])(self._h, C.byref(c)))
+
     def _pcm(self, pcm, channels):
         pcm = np.ascontiguousarray(pcm, np.float32).reshape(self.n_streams, -1, channels)
         return pcm

@@ -319,6 +319,13 @@ int omx_spectrum_bank_create(const omx_spectrum_config* cfg, uint32_t n_streams,
     });
 }
 void omx_spectrum_bank_destroy(omx_spectrum_bank* b) { delete b; }
+int omx_spectrum_bank_update_config(omx_spectrum_bank* b, const omx_spectrum_config* cfg) {
+    if (!b || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.update_config(*cfg, nullptr);
+        return (int)OMX_NONE;
+    });
+}
 int omx_spectrum_bank_reset_audio(omx_spectrum_bank* b) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] {
@@ -519,6 +526,13 @@ int omx_stereometer_bank_create(const omx_stereometer_config* cfg, uint32_t n_st
     });
 }
 void omx_stereometer_bank_destroy(omx_stereometer_bank* b) { delete b; }
+int omx_stereometer_bank_update_config(omx_stereometer_bank* b, const omx_stereometer_config* cfg) {
+    if (!b || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.update_config(*cfg);
+        return (int)OMX_NONE;
+    });
+}
 int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] {
@@ -647,6 +661,13 @@ int omx_oscilloscope_bank_create(const omx_oscilloscope_config* cfg, uint32_t n_
     });
 }
 void omx_oscilloscope_bank_destroy(omx_oscilloscope_bank* b) { delete b; }
+int omx_oscilloscope_bank_update_config(omx_oscilloscope_bank* b, const omx_oscilloscope_config* cfg) {
+    if (!b || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.update_config(*cfg);
+        return (int)OMX_NONE;
+    });
+}
 int omx_oscilloscope_bank_reset_audio(omx_oscilloscope_bank* b) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] {
@@ -762,6 +783,13 @@ int omx_waveform_bank_create(const omx_waveform_config* cfg, uint32_t n_streams,
     });
 }
 void omx_waveform_bank_destroy(omx_waveform_bank* b) { delete b; }
+int omx_waveform_bank_update_config(omx_waveform_bank* b, const omx_waveform_config* cfg) {
+    if (!b || !cfg) return OMX_ERR_INVALID;
+    return guarded([&] {
+        b->impl.update_config(*cfg);
+        return (int)OMX_NONE;
+    });
+}
 int omx_waveform_bank_reset_audio(omx_waveform_bank* b) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] {
@@ -824,6 +852,27 @@ int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t fr
                              const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_update* out) {
     if (!g || (!pcm && frames) || !positions) return OMX_ERR_INVALID;
     return guarded([&] { return g->impl.ingest(pcm, frames, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out); });
+}
+int omx_capture_group_set_enabled(omx_capture_group* g, uint32_t visual, int enabled) {
+    if (!g) return OMX_ERR_INVALID;
+    return guarded([&] { return g->impl.set_enabled(visual, enabled != 0); });
+}
+int omx_capture_group_enabled(const omx_capture_group* g) { return g ? (int)g->impl.enabled() : OMX_ERR_INVALID; }
+int omx_capture_group_update_config(omx_capture_group* g, uint32_t visual, const void* config, void* stream) {
+    if (!g || !config) return OMX_ERR_INVALID;
+    return guarded([&] { return g->impl.update_config(visual, config, static_cast<hipStream_t>(stream)); });
+}
+int omx_capture_group_note_format(omx_capture_group* g, uint64_t generation) {
+    if (!g) return OMX_ERR_INVALID;
+    return guarded([&] { return g->impl.note_format_generation(generation) ? 1 : 0; });
+}
+int omx_capture_group_ingest_ragged(omx_capture_group* g, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                    const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                    const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_capture_group_ragged_update* out) {
+    if (!g || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return g->impl.ingest_ragged(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out);
+    });
 }
 int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t* launches) {
     if (!g || !avg_ms || !g->impl.spectrogram()) return OMX_ERR_INVALID;

@@ -15,14 +15,23 @@ void capture_group_config_default(omx_capture_group_config* c) {
     waveform_config_default(&c->waveform);
 }
 
+constexpr uint32_t kAllVisuals = OMX_VISUAL_SPECTROGRAM | OMX_VISUAL_SPECTRUM | OMX_VISUAL_LOUDNESS | OMX_VISUAL_STEREOMETER |
+                                 OMX_VISUAL_OSCILLOSCOPE | OMX_VISUAL_WAVEFORM;
+
+void CaptureGroup::ensure_bank(uint32_t visual) {
+    const uint32_t S = cfg_.n_streams;
+    if (visual == OMX_VISUAL_SPECTROGRAM && !spectrogram_) spectrogram_.reset(new SpectrogramBank(cfg_.spectrogram, S));
+    if (visual == OMX_VISUAL_SPECTRUM && !spectrum_) spectrum_.reset(new SpectrumBank(cfg_.spectrum, S, cfg_.spectrum_emit_all_hops != 0));
+    if (visual == OMX_VISUAL_LOUDNESS && !loudness_) loudness_.reset(new LoudnessBank(cfg_.loudness, S));
+    if (visual == OMX_VISUAL_STEREOMETER && !stereometer_) stereometer_.reset(new StereometerBank(cfg_.stereometer, S));
+    if (visual == OMX_VISUAL_OSCILLOSCOPE && !oscilloscope_) oscilloscope_.reset(new OscilloscopeBank(cfg_.oscilloscope, S));
+    if (visual == OMX_VISUAL_WAVEFORM && !waveform_) waveform_.reset(new WaveformBank(cfg_.waveform, S));
+}
+
 CaptureGroup::CaptureGroup(const omx_capture_group_config& cfg) : cfg_(cfg) {
-    const uint32_t S = cfg.n_streams;
-    if (cfg.visuals & OMX_VISUAL_SPECTROGRAM) spectrogram_.reset(new SpectrogramBank(cfg.spectrogram, S));
-    if (cfg.visuals & OMX_VISUAL_SPECTRUM) spectrum_.reset(new SpectrumBank(cfg.spectrum, S, cfg.spectrum_emit_all_hops != 0));
-    if (cfg.visuals & OMX_VISUAL_LOUDNESS) loudness_.reset(new LoudnessBank(cfg.loudness, S));
-    if (cfg.visuals & OMX_VISUAL_STEREOMETER) stereometer_.reset(new StereometerBank(cfg.stereometer, S));
-    if (cfg.visuals & OMX_VISUAL_OSCILLOSCOPE) oscilloscope_.reset(new OscilloscopeBank(cfg.oscilloscope, S));
-    if (cfg.visuals & OMX_VISUAL_WAVEFORM) waveform_.reset(new WaveformBank(cfg.waveform, S));
+    enabled_ = cfg.visuals & kAllVisuals;
+    for (uint32_t bit = 1; bit <= OMX_VISUAL_WAVEFORM; bit <<= 1)
+        if (enabled_ & bit) ensure_bank(bit);
     for (int i = 0; i < 2; ++i) {
         OMX_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
         OMX_HIP(hipEventCreateWithFlags(&join_[i], hipEventDisableTiming));
@@ -49,6 +58,97 @@ void CaptureGroup::reset_audio() {  // registry.rs:360-365: every module's reset
     if (oscilloscope_) oscilloscope_->reset_audio();
     if (waveform_) waveform_->reset_audio();
     holds_valid_ = false;  // LoudnessState::reset_audio: fresh PeakHolds (loudness/state.rs:153-160)
+    clock_ = 0.0;          // ... on a fresh sample clock
+    ragged_ = false;       // a bank-wide reset returns every bank to lock-step positions
+    have_generation_ = false;  // registry.rs:361 format_generation = None
+}
+
+int CaptureGroup::set_enabled(uint32_t visual, bool on) {
+    if (visual == 0 || (visual & (visual - 1)) != 0 || !(visual & kAllVisuals)) {
+        set_last_error("capture group: `visual` must be exactly one OMX_VISUAL_* bit");
+        return OMX_ERR_INVALID;
+    }
+    if (on) {
+        if (ragged_ && !(enabled_ & visual)) {
+            // a bank that has not seen the group's ragged calls holds lock-step positions: its first ragged call switches it over on
+            // its own (every bank's process_ragged does), so nothing to do here beyond creating it
+        }
+        ensure_bank(visual);  // Entry::set_enabled: module.prepare()
+        enabled_ |= visual;
+    } else {
+        enabled_ &= ~visual;
+    }
+    return OMX_NONE;
+}
+
+int CaptureGroup::update_config(uint32_t visual, const void* config, hipStream_t stream) {
+    if (!config) return OMX_ERR_INVALID;
+    switch (visual) {
+        case OMX_VISUAL_SPECTROGRAM:
+            cfg_.spectrogram = *static_cast<const omx_spectrogram_config*>(config);
+            if (spectrogram_) spectrogram_->update_config(cfg_.spectrogram, stream);
+            return OMX_NONE;
+        case OMX_VISUAL_SPECTRUM:
+            cfg_.spectrum = *static_cast<const omx_spectrum_config*>(config);
+            if (spectrum_) spectrum_->update_config(cfg_.spectrum, stream);
+            return OMX_NONE;
+        case OMX_VISUAL_STEREOMETER:
+            cfg_.stereometer = *static_cast<const omx_stereometer_config*>(config);
+            if (stereometer_) stereometer_->update_config(cfg_.stereometer);
+            return OMX_NONE;
+        case OMX_VISUAL_OSCILLOSCOPE:
+            cfg_.oscilloscope = *static_cast<const omx_oscilloscope_config*>(config);
+            if (oscilloscope_) oscilloscope_->update_config(cfg_.oscilloscope);
+            return OMX_NONE;
+        case OMX_VISUAL_WAVEFORM:
+            cfg_.waveform = *static_cast<const omx_waveform_config*>(config);
+            if (waveform_) waveform_->update_config(cfg_.waveform);
+            return OMX_NONE;
+        case OMX_VISUAL_LOUDNESS:
+            set_last_error("capture group: LoudnessProcessor has no update_config (loudness/processor.rs:225-253)");
+            return OMX_ERR_INVALID;
+        default:
+            set_last_error("capture group: `visual` must be exactly one OMX_VISUAL_* bit");
+            return OMX_ERR_INVALID;
+    }
+}
+
+bool CaptureGroup::note_format_generation(uint64_t generation) {
+    const bool changed = have_generation_ && generation_ != generation;
+    if (changed) reset_audio();
+    have_generation_ = true;
+    generation_ = generation;
+    return changed;
+}
+
+uint64_t CaptureGroup::block_frames_for(float sample_rate) const {
+    // how the block-based visuals see a call (meter.rs:16-25: the batcher hands out blocks of round(256 fs / 48000) frames)
+    const float sr = sanitize_sample_rate(sample_rate);
+    return cfg_.block_frames ? cfg_.block_frames : (uint64_t)std::max(1.0, std::round(256.0 * (double)sr / 48000.0));
+}
+
+// Runs `body` between the fork of the side streams and their join onto the caller's stream; the join is enqueued on every path out
+// of `body`, so an error inside it (a failed launch, a refused shape) never leaves the caller's stream unordered against side
+// streams that may still be reading the caller's PCM.
+template <class Body>
+static int forked(hipStream_t stream, hipStream_t (&side)[2], hipEvent_t fork, hipEvent_t (&join)[2], bool (&used)[2], Body&& body) {
+    OMX_HIP(hipEventRecord(fork, stream));
+    auto rejoin = [&] {
+        for (int i = 0; i < 2; ++i)
+            if (used[i]) {
+                (void)hipEventRecord(join[i], side[i]);
+                (void)hipStreamWaitEvent(stream, join[i], 0);
+            }
+    };
+    int rc;
+    try {
+        rc = body();
+    } catch (...) {
+        rejoin();
+        throw;
+    }
+    rejoin();
+    return rc;
 }
 
 void CaptureGroup::set_timing(bool on) {
@@ -65,9 +165,19 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
         if (out) *out = up;
         return OMX_NONE;
     }
-    // how the block-based visuals see the call (meter.rs:16-25: the batcher hands out blocks of round(256 fs / 48000) frames)
+    if (ragged_) {
+        set_last_error("capture group: per-capture positions are in use (omx_capture_group_ingest_ragged); lock-step calls resume after reset_audio");
+        return OMX_ERR_INVALID;
+    }
+    // entry.enabled (registry.rs:413-417): a disabled visual's bank is skipped and keeps its state
+    SpectrogramBank* spectrogram = (enabled_ & OMX_VISUAL_SPECTROGRAM) ? spectrogram_.get() : nullptr;
+    SpectrumBank* spectrum = (enabled_ & OMX_VISUAL_SPECTRUM) ? spectrum_.get() : nullptr;
+    LoudnessBank* loudness = (enabled_ & OMX_VISUAL_LOUDNESS) ? loudness_.get() : nullptr;
+    StereometerBank* stereometer = (enabled_ & OMX_VISUAL_STEREOMETER) ? stereometer_.get() : nullptr;
+    OscilloscopeBank* oscilloscope = (enabled_ & OMX_VISUAL_OSCILLOSCOPE) ? oscilloscope_.get() : nullptr;
+    WaveformBank* waveform = (enabled_ & OMX_VISUAL_WAVEFORM) ? waveform_.get() : nullptr;
     const float sr = sanitize_sample_rate(sample_rate);
-    uint64_t block = cfg_.block_frames ? cfg_.block_frames : (uint64_t)std::max(1.0, std::round(256.0 * (double)sr / 48000.0));
+    uint64_t block = block_frames_for(sample_rate);
     uint64_t n_blocks = frames / block;
     if (n_blocks == 0 || n_blocks * block != frames) {
         block = frames;
@@ -75,115 +185,194 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
     }
     up.n_blocks = n_blocks;
     up.block_frames = block;
-    const bool stats = stats_ && spectrogram_ && loudness_ && stereometer_;
+    const bool stats = stats_ && spectrogram && loudness && stereometer;
     if (stats) {
         rows_.reserve((size_t)S * OMX_STATS_COLUMNS);
         OMX_HIP(hipMemsetAsync(rows_.ptr, 0, (size_t)S * OMX_STATS_COLUMNS * sizeof(float), stream));  // ahead of the fork
     }
-    OMX_HIP(hipEventRecord(fork_, stream));
     int worst = OMX_NONE;
     auto note = [&](int rc, uint32_t bit) {
         if (rc < 0) worst = worst < 0 ? worst : rc;
         else if (rc == OMX_PRODUCED) up.produced |= bit;
     };
-
-    // ---- the caller's stream: the banks that keep pending audio, fed by one projection of the block
-    {
-        IngestSlots sg, sp;
-        int rc_sg = OMX_NONE, rc_sp = OMX_NONE;
-        if (spectrogram_) rc_sg = spectrogram_->push_begin(frames, channels, sample_rate, stream, sg);
-        if (spectrum_) rc_sp = spectrum_->push_begin(frames, channels, sample_rate, stream, sp);
-        if (rc_sg < 0) note(rc_sg, 0);
-        if (rc_sp < 0) note(rc_sp, 0);
-        const AudioFormatArgs fmt = make_format(channels, positions);
-        const bool both = rc_sg == OMX_PRODUCED && rc_sp == OMX_PRODUCED && sg.count && sp.count;
-        if (both && shared_ingest_ && sg.skip == sp.skip && sg.count == sp.count && sg.n + sp.n <= OMX_INGEST_MAX_OUT) {
-            const IngestSlots* two[2] = {&sg, &sp};
-            launch_ingest_slots(d_pcm, frames, fmt, two, 2, S, stream);
-            up.ingest_launches += 1;
-        } else {
-            if (rc_sg == OMX_PRODUCED && sg.count) {
-                const IngestSlots* one[1] = {&sg};
-                launch_ingest_slots(d_pcm, frames, fmt, one, 1, S, stream);
-                up.ingest_launches += 1;
-            }
-            if (rc_sp == OMX_PRODUCED && sp.count) {
-                const IngestSlots* one[1] = {&sp};
-                launch_ingest_slots(d_pcm, frames, fmt, one, 1, S, stream);
-                up.ingest_launches += 1;
-            }
-        }
-        if (rc_sg == OMX_PRODUCED) {
-            spectrogram_->push_end(sg);
-            note(spectrogram_->process_pushed(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
-        }
-        if (rc_sp == OMX_PRODUCED) {
-            spectrum_->push_end(sp);
-            note(spectrum_->process_pushed(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
-        }
-    }
-
-    // ---- side stream 0: loudness (+ its summary columns), waveform
     bool used[2] = {false, false};
-    if (loudness_ || waveform_) {
-        used[0] = true;
-        OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
-        if (loudness_) {
-            const int rc = loudness_->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[0], &up.d_loudness);
-            note(rc, OMX_VISUAL_LOUDNESS);
-            if (stats && rc == OMX_PRODUCED && up.d_loudness) {
-                // K9: true-peak bars + their peak holds on the sample clock (loudness/state.rs:36-60, 178-217)
-                if (!holds_valid_) {
-                    holds_.reserve((size_t)S * 3);
-                    launch_peak_holds_reset(holds_.ptr, (uint64_t)S * 3, clock_, side_[0]);
-                    holds_valid_ = true;
+    forked(stream, side_, fork_, join_, used, [&] {
+        // ---- the caller's stream: the banks that keep pending audio, fed by one projection of the block
+        {
+            IngestSlots sg, sp;
+            int rc_sg = OMX_NONE, rc_sp = OMX_NONE;
+            if (spectrogram) rc_sg = spectrogram->push_begin(frames, channels, sample_rate, stream, sg);
+            if (spectrum) rc_sp = spectrum->push_begin(frames, channels, sample_rate, stream, sp);
+            if (rc_sg < 0) note(rc_sg, 0);
+            if (rc_sp < 0) note(rc_sp, 0);
+            const AudioFormatArgs fmt = make_format(channels, positions);
+            const bool both = rc_sg == OMX_PRODUCED && rc_sp == OMX_PRODUCED && sg.count && sp.count;
+            if (both && shared_ingest_ && sg.skip == sp.skip && sg.count == sp.count && sg.n + sp.n <= OMX_INGEST_MAX_OUT) {
+                const IngestSlots* two[2] = {&sg, &sp};
+                launch_ingest_slots(d_pcm, frames, fmt, two, 2, S, stream);
+                up.ingest_launches += 1;
+            } else {
+                if (rc_sg == OMX_PRODUCED && sg.count) {
+                    const IngestSlots* one[1] = {&sg};
+                    launch_ingest_slots(d_pcm, frames, fmt, one, 1, S, stream);
+                    up.ingest_launches += 1;
                 }
-                meters_.reserve((size_t)S * n_blocks);
-                const double dt = (double)block / (double)sr;
-                launch_loudness_meters(up.d_loudness, S, n_blocks, OMX_METER_TRUE_PEAK, OMX_METER_LUFS_SHORT_TERM, clock_, dt, holds_.ptr,
-                                       meters_.ptr, side_[0]);
-                clock_ += (double)n_blocks * dt;
-                launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, side_[0]);
+                if (rc_sp == OMX_PRODUCED && sp.count) {
+                    const IngestSlots* one[1] = {&sp};
+                    launch_ingest_slots(d_pcm, frames, fmt, one, 1, S, stream);
+                    up.ingest_launches += 1;
+                }
+            }
+            if (rc_sg == OMX_PRODUCED) {
+                spectrogram->push_end(sg);
+                note(spectrogram->process_pushed(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
+            }
+            if (rc_sp == OMX_PRODUCED) {
+                spectrum->push_end(sp);
+                note(spectrum->process_pushed(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
             }
         }
-        if (waveform_) note(waveform_->process(d_pcm, true, frames, channels, sample_rate, positions, side_[0], &up.waveform), OMX_VISUAL_WAVEFORM);
-        OMX_HIP(hipGetLastError());
-        OMX_HIP(hipEventRecord(join_[0], side_[0]));
-    }
-    // ---- side stream 1: stereometer (+ its summary columns), oscilloscope
-    if (stereometer_ || oscilloscope_) {
-        used[1] = true;
-        OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
-        if (stereometer_) {
-            const int rc = stereometer_->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1], &up.stereometer);
-            note(rc, OMX_VISUAL_STEREOMETER);
-            if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations)
-                launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, side_[1]);
-        }
-        if (oscilloscope_) {
-            const int rc = oscilloscope_->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1]);
-            note(rc, OMX_VISUAL_OSCILLOSCOPE);
-            if (rc == OMX_PRODUCED) {
-                up.oscilloscope.n_streams = S;
-                up.oscilloscope.n_blocks = n_blocks;
-                up.oscilloscope.epoch = oscilloscope_->epoch();
-                up.oscilloscope.sample_stride = kScopeTarget;
-                up.oscilloscope.d_headers = reinterpret_cast<const omx_oscilloscope_block_header*>(oscilloscope_->d_headers());
-                up.oscilloscope.d_samples = oscilloscope_->d_samples();
+        // ---- side stream 0: loudness (+ its summary columns), waveform
+        if (loudness || waveform) {
+            used[0] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
+            if (loudness) {
+                const int rc = loudness->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[0], &up.d_loudness);
+                note(rc, OMX_VISUAL_LOUDNESS);
+                if (stats && rc == OMX_PRODUCED && up.d_loudness) {
+                    // K9: true-peak bars + their peak holds on the sample clock (loudness/state.rs:36-60, 178-217)
+                    if (!holds_valid_) {
+                        holds_.reserve((size_t)S * 3);
+                        launch_peak_holds_reset(holds_.ptr, (uint64_t)S * 3, clock_, side_[0]);
+                        holds_valid_ = true;
+                    }
+                    meters_.reserve((size_t)S * n_blocks);
+                    const double dt = (double)block / (double)sr;
+                    launch_loudness_meters(up.d_loudness, S, n_blocks, OMX_METER_TRUE_PEAK, OMX_METER_LUFS_SHORT_TERM, clock_, dt, holds_.ptr,
+                                           meters_.ptr, side_[0]);
+                    clock_ += (double)n_blocks * dt;
+                    launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, side_[0]);
+                }
             }
+            if (waveform) note(waveform->process(d_pcm, true, frames, channels, sample_rate, positions, side_[0], &up.waveform), OMX_VISUAL_WAVEFORM);
+            OMX_HIP(hipGetLastError());
         }
-        OMX_HIP(hipGetLastError());
-        OMX_HIP(hipEventRecord(join_[1], side_[1]));
-    }
-    // ---- join; the spectrogram's summary columns follow its kernel on the caller's stream
-    for (int i = 0; i < 2; ++i)
-        if (used[i]) OMX_HIP(hipStreamWaitEvent(stream, join_[i], 0));
+        // ---- side stream 1: stereometer (+ its summary columns), oscilloscope
+        if (stereometer || oscilloscope) {
+            used[1] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
+            if (stereometer) {
+                const int rc = stereometer->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1], &up.stereometer);
+                note(rc, OMX_VISUAL_STEREOMETER);
+                if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations)
+                    launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, side_[1]);
+            }
+            if (oscilloscope) {
+                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1]);
+                note(rc, OMX_VISUAL_OSCILLOSCOPE);
+                if (rc == OMX_PRODUCED) {
+                    up.oscilloscope.n_streams = S;
+                    up.oscilloscope.n_blocks = n_blocks;
+                    up.oscilloscope.epoch = oscilloscope->epoch();
+                    up.oscilloscope.sample_stride = kScopeTarget;
+                    up.oscilloscope.d_headers = reinterpret_cast<const omx_oscilloscope_block_header*>(oscilloscope->d_headers());
+                    up.oscilloscope.d_samples = oscilloscope->d_samples();
+                }
+            }
+            OMX_HIP(hipGetLastError());
+        }
+        return (int)OMX_NONE;
+    });
+    // ---- joined; the spectrogram's summary columns follow its kernel on the caller's stream
     if (stats) {
         if ((up.produced & OMX_VISUAL_SPECTROGRAM) && up.spectrogram.d_counts)
             launch_stats_spectrogram(up.spectrogram.d_counts, S, up.spectrogram.n_columns, rows_.ptr, stream);
         OMX_HIP(hipGetLastError());
         up.d_stats_rows = rows_.ptr;
     }
+    if (out) *out = up;
+    if (worst < 0) return worst;
+    return up.produced ? OMX_PRODUCED : OMX_NONE;
+}
+
+// Per-capture ingest: capture s delivers frames[s] <= frames_capacity frames this call (0 = nothing arrived) and is reset first where
+// reset_mask[s] != 0 — one VisualManager per capture in the reference, each fed by its own DspBatcher and reset on its own
+// (registry.rs:360-365, :396-418; meter.rs:27-80).  Every enabled bank takes the call through its own ragged entry point (per-stream
+// positions on the device); the block-based visuals see capture s as frames[s] / block_frames blocks, so the counts must be multiples
+// of block_frames — which is what the batcher hands out (256-frame quanta at 48 kHz, up to four per catch-up chunk).
+int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels_in,
+                                float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                omx_capture_group_ragged_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    const uint32_t S = cfg_.n_streams;
+    omx_capture_group_ragged_update up;
+    std::memset(&up, 0, sizeof(up));
+    const uint64_t block = block_frames_for(sample_rate);
+    if (frames_capacity == 0 || frames_capacity % block != 0) {
+        set_last_error("capture group ingest_ragged: frames_capacity must be a positive multiple of block_frames");
+        return OMX_ERR_INVALID;
+    }
+    const uint64_t max_blocks = frames_capacity / block;
+    blocks_scratch_.resize(S);
+    for (uint32_t s = 0; s < S; ++s) {
+        if (frames[s] > frames_capacity || frames[s] % block != 0) {
+            set_last_error("capture group ingest_ragged: frames[s] must be a multiple of block_frames, at most frames_capacity");
+            return OMX_ERR_INVALID;
+        }
+        blocks_scratch_[s] = (uint32_t)(frames[s] / block);
+    }
+    up.block_frames = block;
+    up.max_blocks = max_blocks;
+    SpectrogramBank* spectrogram = (enabled_ & OMX_VISUAL_SPECTROGRAM) ? spectrogram_.get() : nullptr;
+    SpectrumBank* spectrum = (enabled_ & OMX_VISUAL_SPECTRUM) ? spectrum_.get() : nullptr;
+    LoudnessBank* loudness = (enabled_ & OMX_VISUAL_LOUDNESS) ? loudness_.get() : nullptr;
+    StereometerBank* stereometer = (enabled_ & OMX_VISUAL_STEREOMETER) ? stereometer_.get() : nullptr;
+    OscilloscopeBank* oscilloscope = (enabled_ & OMX_VISUAL_OSCILLOSCOPE) ? oscilloscope_.get() : nullptr;
+    WaveformBank* waveform = (enabled_ & OMX_VISUAL_WAVEFORM) ? waveform_.get() : nullptr;
+    ragged_ = true;
+    if (reset_mask)   // LoudnessState::reset_audio of the reset captures: the summary-row peak holds restart with the next lock-step epoch
+        for (uint32_t s = 0; s < S; ++s)
+            if (reset_mask[s]) holds_valid_ = false;
+    int worst = OMX_NONE;
+    auto note = [&](int rc, uint32_t bit) {
+        if (rc < 0) worst = worst < 0 ? worst : rc;
+        else if (rc == OMX_PRODUCED) up.produced |= bit;
+    };
+    bool used[2] = {false, false};
+    forked(stream, side_, fork_, join_, used, [&] {
+        if (spectrogram)
+            note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrogram),
+                 OMX_VISUAL_SPECTROGRAM);
+        if (spectrum)
+            note(spectrum->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrum),
+                 OMX_VISUAL_SPECTRUM);
+        if (loudness || waveform) {
+            used[0] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
+            if (loudness)
+                note(loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions, side_[0],
+                                              &up.loudness),
+                     OMX_VISUAL_LOUDNESS);
+            if (waveform)
+                note(waveform->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, side_[0], &up.waveform),
+                     OMX_VISUAL_WAVEFORM);
+            OMX_HIP(hipGetLastError());
+        }
+        if (stereometer || oscilloscope) {
+            used[1] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
+            if (stereometer)
+                note(stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
+                                                 side_[1], &up.stereometer),
+                     OMX_VISUAL_STEREOMETER);
+            if (oscilloscope)
+                note(oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
+                                                  side_[1], &up.oscilloscope),
+                     OMX_VISUAL_OSCILLOSCOPE);
+            OMX_HIP(hipGetLastError());
+        }
+        return (int)OMX_NONE;
+    });
     if (out) *out = up;
     if (worst < 0) return worst;
     return up.produced ? OMX_PRODUCED : OMX_NONE;

@@ -2,6 +2,7 @@
 // every enabled visual's bank, one shared projection for the banks that keep pending audio, meter banks on side streams, summary rows.
 #pragma once
 #include <memory>
+#include <vector>
 
 #include "loudness.hpp"
 #include "oscilloscope.hpp"
@@ -22,6 +23,17 @@ public:
     CaptureGroup(const CaptureGroup&) = delete;
     CaptureGroup& operator=(const CaptureGroup&) = delete;
     void reset_audio();
+    // VisualManager::set_enabled (registry.rs:272-277, :349-352): a disabled visual is skipped by ingest and keeps its state; enabling
+    // one prepares it (its bank is created here on first use)
+    int set_enabled(uint32_t visual, bool on);
+    uint32_t enabled() const { return enabled_; }
+    // Entry::apply_settings -> processor.update_config (registry.rs:54-58, :266-270): `config` is the omx_<visual>_config of that visual
+    int update_config(uint32_t visual, const void* config, hipStream_t stream);
+    // ingest_samples' format-generation rule (registry.rs:400-406): a generation that differs from the last one resets every visual
+    bool note_format_generation(uint64_t generation);
+    // per-capture frame counts and reset flags (one VisualManager per capture in the reference, each fed and reset on its own)
+    int ingest_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                      float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_capture_group_ragged_update* out);
     void set_stats(bool on) { stats_ = on; }
     void set_shared_ingest(bool on) { shared_ingest_ = on; }
     void set_timing(bool on);
@@ -30,7 +42,14 @@ public:
     SpectrogramBank* spectrogram() { return spectrogram_.get(); }
 
 private:
+    void ensure_bank(uint32_t visual);
+    uint64_t block_frames_for(float sample_rate) const;
     omx_capture_group_config cfg_;
+    uint32_t enabled_ = 0;       // OMX_VISUAL_* bits ingest feeds
+    bool ragged_ = false;        // per-capture positions (after the first ingest_ragged, until reset_audio)
+    bool have_generation_ = false;
+    uint64_t generation_ = 0;
+    std::vector<uint32_t> blocks_scratch_;
     std::unique_ptr<SpectrogramBank> spectrogram_;
     std::unique_ptr<SpectrumBank> spectrum_;
     std::unique_ptr<LoudnessBank> loudness_;

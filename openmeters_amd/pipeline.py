@@ -29,8 +29,20 @@ class CCaptureGroupUpdate(C.Structure):
                 ("d_stats_rows", C.c_void_p)]
 
 
+class CCaptureGroupRaggedUpdate(C.Structure):
+    _fields_ = [("produced", C.c_uint32), ("_pad", C.c_uint32), ("block_frames", C.c_uint64), ("max_blocks", C.c_uint64),
+                ("spectrogram", capi.CSpectrogramRaggedUpdate), ("spectrum", capi.CSpectrumRaggedUpdate), ("loudness", capi.CLoudnessRaggedUpdate),
+                ("stereometer", banks.CStereometerRaggedUpdate), ("oscilloscope", banks.COscilloscopeRaggedUpdate),
+                ("waveform", capi.CWaveformRaggedUpdate)]
+
+
+_CONFIG_OF = {capi.VISUAL_SPECTROGRAM: "spectrogram", capi.VISUAL_SPECTRUM: "spectrum", capi.VISUAL_LOUDNESS: "loudness",
+              capi.VISUAL_STEREOMETER: "stereometer", capi.VISUAL_OSCILLOSCOPE: "oscilloscope", capi.VISUAL_WAVEFORM: "waveform"}
+
+
 class CaptureGroup:
-    """omx_capture_group: `n_streams` captures in lock step, one bank per enabled visual."""
+    """omx_capture_group: `n_streams` captures, one bank per enabled visual — VisualManager's ingest_samples, set_enabled,
+    apply_module_settings -> update_config and reset_audio (registry.rs:266-277, :343-365, :396-418)."""
 
     def __init__(self, api: capi.Api, n_streams: int, *, spectrogram: Optional[capi.SpectrogramConfig] = None,
                  spectrum: Optional[capi.SpectrumConfig] = None, loudness: Optional[capi.LoudnessConfig] = None,
@@ -80,6 +92,36 @@ class CaptureGroup:
         self.api.check(f(self._h, C.c_void_p(device_ptr), frames, channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
+    def set_enabled(self, visual: int, on: bool):
+        self.api.check(self.api.fn("capture_group_set_enabled", C.c_int, [C.c_void_p, C.c_uint32, C.c_int])(self._h, visual, int(on)))
+
+    def enabled(self) -> int:
+        return int(self.api.fn("capture_group_enabled", C.c_int, [C.c_void_p])(self._h))
+
+    def update_config(self, visual: int, config, stream: int = 0):
+        """`config`: the capi.<Visual>Config of that visual (update_config of its processor between two ingest calls)"""
+        c = config.to_c()
+        self.api.check(self.api.fn("capture_group_update_config", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p])(
+            self._h, visual, C.byref(c), C.c_void_p(stream or 0)))
+
+    def note_format(self, generation: int) -> bool:
+        rc = self.api.fn("capture_group_note_format", C.c_int, [C.c_void_p, C.c_uint64])(self._h, generation)
+        self.api.check(rc)
+        return rc == 1
+
+    def ingest_ragged(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                      positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0) -> CCaptureGroupRaggedUpdate:
+        """capture s delivers its first frames[s] frames of [n_streams][frames_capacity][channels] (device memory)"""
+        out = CCaptureGroupRaggedUpdate()
+        n = self.n_streams
+        fr = (C.c_uint32 * n)(*[int(x) for x in frames])
+        mk = (C.c_uint8 * n)(*[int(x) for x in reset_mask]) if reset_mask is not None else None
+        f = self.api.fn("capture_group_ingest_ragged", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
+                                                                 _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr, mk, channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0),
+                         C.byref(out)))
+        return out
+
     def kernel_time(self):
         ms, n = C.c_double(), C.c_uint64()
         self.api.check(self.api.fn("capture_group_kernel_time", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)])(
@@ -124,4 +166,4 @@ class FullPipeline:
         return up, stats_rows_tensor(torch, device, up, self.n_streams)
 
 
-__all__ = ["CaptureGroup", "CCaptureGroupUpdate", "FullPipeline", "stats_rows_tensor", "gather_stats", "shard_streams", "STATS_COLUMNS"]
+__all__ = ["CaptureGroup", "CCaptureGroupUpdate", "CCaptureGroupRaggedUpdate", "FullPipeline", "stats_rows_tensor", "gather_stats", "shard_streams", "STATS_COLUMNS"]

@@ -76,3 +76,33 @@ def test_c99_capture_group_drives_three_visuals_with_one_ingest_per_block(tmp_pa
     v = parse(r.stdout.strip())
     assert v["columns"] == (9 * 2048 - 2048) // 256 + 1
     assert v["worst_lufs"] < 1e-4 and v["worst_rho"] < 1e-6 and v["rho_full"] < -0.99
+
+
+MANAGER_SRC = os.path.join(ROOT, "tests", "c_abi", "group_manager.c")
+
+
+def build_manager(tmp_path):
+    out = str(tmp_path / "group_manager")
+    libdir, oradir = os.path.join(ROOT, "openmeters_amd", "csrc"), os.path.join(ROOT, "oracle")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), MANAGER_SRC, "-o", out,
+           "-L", libdir, "-lomx_hip", "-L", oradir, "-lomx_oracle", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath," + oradir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
+def test_c99_visual_manager_host_builds_against_the_header(tmp_path, omx, oracle):
+    """set_enabled / update_config / note_format / ingest_ragged are reachable from plain C (product and oracle linked side by side)"""
+    assert os.path.exists(build_manager(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c99_capture_group_behaves_like_one_visual_manager_per_capture(tmp_path, omx, oracle):
+    """group_manager.c: four captures with uneven per-call frame counts, a visual toggled off and on, another created by set_enabled,
+    the spectrogram's hop changed mid-stream, one capture reset alone, a format-generation reset — every capture against single-stream
+    ORACLE handles fed the same sequence: column counts and `reset` flags exact, LUFS within 1e-4 dB, correlations within 1e-6"""
+    r = subprocess.run([build_manager(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    v = parse(r.stdout.strip())
+    assert v["columns"] > 100 and v["blocks"] > 60 and v["rho_checks"] > 100
+    assert v["worst_lufs"] < 1e-4 and v["worst_rho"] < 1e-6

@@ -282,6 +282,134 @@ def test_capture_group_all_six_visuals_equal_their_banks(omx):
             assert torch.equal(dview(torch, u.waveform.d_columns, (S, nc, 4, 11)), dview(torch, r_wf.d_columns, (S, nc, 4, 11)))
 
 
+def test_capture_group_ragged_ingest_with_toggles_and_config_changes_equals_its_banks(omx):
+    """The group as VisualManager (registry.rs:266-277, :343-365, :396-418) with per-capture frame counts: all six visuals against six
+    banks driven through their own ragged entry points with the same per-capture counts and reset flags — the device outputs of
+    every call bit for bit — while visuals are switched off and on (a disabled one sits the call out and keeps its state), the
+    spectrogram's hop and the stereometer's correlation window change mid-stream, one capture is reset alone, and a format-generation
+    change resets everything (after which lock-step ingest works again until the next ragged call)."""
+    import torch
+    from openmeters_amd import banks
+    from openmeters_amd.pipeline import CaptureGroup
+    from test_gpu_fullsize import dview
+    dev = torch.device("cuda", 0)
+    S, block, maxb = 5, 256, 4
+    cap = block * maxb
+    rng = np.random.default_rng(2024)
+    total = cap * 24
+    n = torch.arange(total, device=dev, dtype=torch.float64)
+    feed = torch.empty((S, total, 2), device=dev, dtype=torch.float32)
+    for s in range(S):
+        tone = (0.6 * torch.sin(2 * np.pi * (220.0 + 55.0 * s) * n / 48000.0) + 0.05 * torch.sin(2 * np.pi * 2500.0 * n / 48000.0)).to(torch.float32)
+        feed[s, :, 0] = tone
+        feed[s, :, 1] = -0.7 * tone
+    pos = capi.positions_fallback(2)
+    cfgs = dict(spectrogram=SpectrogramConfig(fft_size=2048, hop_size=256, history_length=8192), spectrum=capi.SpectrumConfig(fft_size=4096, hop_size=1024),
+                loudness=LoudnessConfig(), stereometer=StereometerConfig(analyze_bands=True),
+                oscilloscope=capi.OscilloscopeConfig(trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT),
+                waveform=capi.WaveformConfig(analyze_bands=True))
+    group = CaptureGroup(omx, S, block_frames=block, **{k: v for k, v in cfgs.items() if k != "oscilloscope"})
+    assert group.enabled() == capi.VISUAL_SPECTROGRAM | capi.VISUAL_SPECTRUM | capi.VISUAL_LOUDNESS | capi.VISUAL_STEREOMETER | capi.VISUAL_WAVEFORM
+    group.update_config(capi.VISUAL_OSCILLOSCOPE, cfgs["oscilloscope"])   # stored: the bank does not exist yet
+    sg, sp = banks.SpectrogramBank(omx, cfgs["spectrogram"], S), banks.SpectrumBank(omx, cfgs["spectrum"], S)
+    ld, st = banks.LoudnessBank(omx, cfgs["loudness"], S, 2), banks.StereometerBank(omx, cfgs["stereometer"], S)
+    sc, wf = banks.OscilloscopeBank(omx, cfgs["oscilloscope"], S), banks.WaveformBank(omx, cfgs["waveform"], S)
+    on = dict(stereometer=True, oscilloscope=False, waveform=True)
+    at = [0] * S
+    generation = 3
+    for call in range(16):
+        if call == 2:
+            group.set_enabled(capi.VISUAL_OSCILLOSCOPE, True)     # created and prepared here
+            on["oscilloscope"] = True
+        if call == 4:
+            group.set_enabled(capi.VISUAL_STEREOMETER, False)
+            group.set_enabled(capi.VISUAL_WAVEFORM, False)
+            on["stereometer"] = on["waveform"] = False
+        if call == 7:
+            group.set_enabled(capi.VISUAL_STEREOMETER, True)
+            group.set_enabled(capi.VISUAL_WAVEFORM, True)
+            on["stereometer"] = on["waveform"] = True
+        if call == 6:
+            cfgs["spectrogram"] = SpectrogramConfig(fft_size=2048, hop_size=128, history_length=8192)
+            group.update_config(capi.VISUAL_SPECTROGRAM, cfgs["spectrogram"])
+            sg.update_config(cfgs["spectrogram"])
+        if call == 9:
+            cfgs["stereometer"] = StereometerConfig(analyze_bands=True, correlation_window=0.1)
+            group.update_config(capi.VISUAL_STEREOMETER, cfgs["stereometer"])
+            st.update_config(cfgs["stereometer"])
+        mask = np.zeros(S, np.uint8)
+        if call == 10:
+            mask[3] = 1
+        if call == 12:
+            generation += 1
+        was_reset = group.note_format(generation)
+        assert was_reset == (call == 12)
+        if was_reset:
+            for b in (sg, sp, ld, st, sc, wf):
+                b.reset_audio()
+            # lock-step positions again: one lock-step call goes through (and equals the banks'), the next ragged call switches back
+            chunk = torch.stack([feed[s, at[s]:at[s] + cap] for s in range(S)]).contiguous()
+            u = group.ingest(chunk.data_ptr(), cap, 2, 48000.0, pos)
+            r_ld = ld.process_device(chunk.data_ptr(), block, maxb, 2, 48000.0, pos)
+            sg.process_device(chunk.data_ptr(), cap, 2, 48000.0, pos)
+            sp.process_device(chunk.data_ptr(), cap, 2, 48000.0, pos)
+            st.process_device(chunk.data_ptr(), block, maxb, 2, 48000.0, pos)
+            sc.process_device(chunk.data_ptr(), block, maxb, 2, 48000.0, pos)
+            wf.process_device(chunk.data_ptr(), cap, 2, 48000.0, pos)
+            torch.cuda.synchronize()
+            assert torch.equal(dview(torch, u.d_loudness, (S, maxb, 30)), dview(torch, r_ld, (S, maxb, 30)))
+            at = [a + cap for a in at]
+        frames = (rng.integers(0, maxb + 1, S) * block).astype(np.uint32)
+        frames[rng.integers(0, S)] = 0
+        if call == 0:
+            frames[:] = cap
+        chunk = torch.zeros((S, cap, 2), device=dev, dtype=torch.float32)
+        for s in range(S):
+            chunk[s, :frames[s]] = feed[s, at[s]:at[s] + int(frames[s])]
+            at[s] += int(frames[s])
+        nb = (frames // block).astype(np.uint32)
+        u = group.ingest_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, reset_mask=mask)
+        with pytest.raises(capi.OmxError):
+            group.ingest(chunk.data_ptr(), cap, 2, 48000.0, pos)
+        r_sg = sg.process_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
+        r_sp = sp.process_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
+        r_ld = ld.process_ragged(chunk.data_ptr(), block, maxb, nb, 2, 48000.0, pos, mask)
+        # a disabled visual is not fed; a per-capture reset still reaches it with its next call, so the twin bank sits the call out
+        # too and gets the mask it missed OR-ed into its next one
+        r_st = st.process_ragged(chunk.data_ptr(), block, maxb, nb, 2, 48000.0, pos, mask) if on["stereometer"] else None
+        r_sc = sc.process_ragged(chunk.data_ptr(), block, maxb, nb, 2, 48000.0, pos, mask) if on["oscilloscope"] else None
+        r_wf = wf.process_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, mask) if on["waveform"] else None
+        torch.cuda.synchronize()
+        assert int(u.block_frames) == block and int(u.max_blocks) == maxb
+        mc = int(r_sg.max_columns)
+        assert int(u.spectrogram.max_columns) == mc
+        assert torch.equal(dview(torch, u.spectrogram.d_n_columns, (S,)), dview(torch, r_sg.d_n_columns, (S,)))
+        assert torch.equal(dview(torch, u.spectrogram.d_reset, (S,)), dview(torch, r_sg.d_reset, (S,)))
+        if mc:
+            stride = int(r_sg.column_stride)
+            assert torch.equal(dview(torch, u.spectrogram.d_counts, (S, mc)), dview(torch, r_sg.d_counts, (S, mc)))
+            ca = dview(torch, r_sg.d_counts, (S, mc)).cpu().numpy()
+            pa, pb = dview(torch, u.spectrogram.d_points, (S, mc, stride, 3)), dview(torch, r_sg.d_points, (S, mc, stride, 3))
+            for s in range(S):
+                for c in range(mc):
+                    assert torch.equal(pa[s, c, :ca[s, c]], pb[s, c, :ca[s, c]]), (call, s, c)
+        assert torch.equal(dview(torch, u.loudness.d_n_blocks, (S,)), dview(torch, r_ld.d_n_blocks, (S,)))
+        la, lb = dview(torch, u.loudness.d_snapshots, (S, maxb, 30)), dview(torch, r_ld.d_snapshots, (S, maxb, 30))
+        for s in range(S):
+            assert torch.equal(la[s, :nb[s]], lb[s, :nb[s]]), (call, s)
+        assert bool(u.produced & capi.VISUAL_STEREOMETER) <= on["stereometer"]
+        if on["stereometer"]:
+            ra, rb = dview(torch, u.stereometer.d_correlations, (S, maxb, 4)), dview(torch, r_st.d_correlations, (S, maxb, 4))
+            for s in range(S):
+                assert torch.equal(ra[s, :nb[s]], rb[s, :nb[s]]), (call, s)
+        if on["oscilloscope"]:
+            ha, hb = dview(torch, u.oscilloscope.d_headers, (S, maxb, 10)), dview(torch, r_sc.d_headers, (S, maxb, 10))
+            for s in range(S):
+                assert torch.equal(ha[s, :nb[s]], hb[s, :nb[s]]), (call, s)
+        if on["waveform"]:
+            assert torch.equal(dview(torch, u.waveform.d_n_columns, (S,)), dview(torch, r_wf.d_n_columns, (S,)))
+
+
 def test_rccl_all_gather_of_the_summary_rows_runs_at_world_size_one():
     """K8 on the hardware this box has: `nccl` (= RCCL) initialised at world size 1, the capture group's summary rows pushed through
     all_gather_into_tensor on a side stream (sharding.gather_stats(always_collective=True)) while the next step's kernels are enqueued
