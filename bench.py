@@ -422,7 +422,7 @@ def main():
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": "stft_reassigned_4096_pair_kernel",
+            "kernel": "stft_reassigned_4096_tri_kernel",
             "kernel_ms": kernel_ms,
             "launches_timed": launches,
             "bytes_per_frame": bytes_per_frame,
@@ -467,6 +467,8 @@ def main():
                 sec.update(bench_meters.reference_defaults(out=sys.stderr))   # the reference's default shapes (2048 / 64, 16384 / 1024)
                 if config == "cfg2":
                     sec["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
+                import bench_stream
+                sec["streaming_256"] = bench_stream.streaming(out=sys.stderr)   # the reference's own cadence: one batcher block per call
                 result["secondary"] = sec
             except Exception as e:  # the headline line must survive a failure here
                 result["secondary"] = {"error": repr(e)}

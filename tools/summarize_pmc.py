@@ -50,13 +50,13 @@ if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         kernel_ms, transforms = line["roofline"]["kernel_ms"], line["roofline"].get("transforms_per_frame")
     except Exception:
         pass
-    rec = {"kernel": "stft_reassigned_4096_pair_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
+    rec = {"kernel": "stft_reassigned_4096_tri_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE x2)",
            "launches": len(traffic["FETCH_SIZE"]), "commit": commit, "kernel_ms": kernel_ms, "transforms_per_frame": transforms,
            "workload": {"config": "cfg2", "streams_per_gpu": 64, "columns_per_step_per_gpu": 65536}}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
-    lines.append(f"== HBM traffic per launch (stft_reassigned_4096_pair_kernel): {rec['hbm_bytes_per_launch'] / 1e9:.3f} GB ==")
+    lines.append(f"== HBM traffic per launch (stft_reassigned_4096_tri_kernel): {rec['hbm_bytes_per_launch'] / 1e9:.3f} GB ==")
 txt = "\n".join(lines)
 print(txt)
 with open(os.path.join(out, "summary.txt"), "w") as fh:
