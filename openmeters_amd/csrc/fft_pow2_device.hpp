@@ -6,6 +6,7 @@
 // the 4096-point code: thread jf holds x[jf + T u] in v[u] on entry and X[jf + T u] in v[u] on return.
 #pragma once
 #include "fft_device.hpp"
+#include "fft_fused_device.hpp"
 
 namespace omx {
 
@@ -57,6 +58,55 @@ __device__ __forceinline__ void dft8(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f& a4
 }
 
 // Twiddles: pass 2 from a 256-entry table (LDS copy), pass 3 resident in VGPRs.
+// FFTP_FUSED (default): the twiddle products of every radix-16 pass ride the butterflies as fused multiply-adds
+// (fft_fused_device.hpp: 75 / 97 packed operations per 16-point DFT without / with outer twiddles instead of 80 / 110)
+#ifndef FFTP_FUSED
+#define FFTP_FUSED 1
+#endif
+template <bool INV>
+__device__ __forceinline__ void fftp_dft16(v2f (&v)[16]) {
+#if FFTP_FUSED
+    dft16_fused<INV>(v);
+#else
+    dft16<INV>(v);
+#endif
+}
+// v[t] *= w(t) for t = 1 ... 15, then the DFT; `w` is called once per t
+template <bool INV, class W>
+__device__ __forceinline__ void fftp_tw_dft16(v2f (&v)[16], W&& w) {
+#if FFTP_FUSED
+    v2f ww[16];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) ww[t] = w(t);
+    ww[0] = ww[1];
+    dft16_fused_tw<INV>(v, ww);
+#else
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], w(t));
+    dft16<INV>(v);
+#endif
+}
+template <bool INV, class W>
+__device__ __forceinline__ void fftp_tw_dft16_dual(v2f (&a)[16], v2f (&b)[16], W&& w) {
+#if FFTP_FUSED
+    v2f ww[16];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) ww[t] = w(t);
+    ww[0] = ww[1];
+    dft16_fused_tw<INV>(a, ww);
+    dft16_fused_tw<INV>(b, ww);
+#else
+#pragma unroll
+    for (int t = 1; t < 16; ++t) {
+        const v2f x = w(t);
+        a[t] = twmul<INV>(a[t], x);
+        b[t] = twmul<INV>(b[t], x);
+    }
+    dft16<INV>(a);
+    dft16<INV>(b);
+#endif
+}
+
 template <int LOGN>
 struct TwiddlesPow2 {
     using G = FftGeom<LOGN>;
@@ -75,7 +125,7 @@ struct TwiddlesPow2 {
 
 template <bool INV, int LOGN>
 __device__ __forceinline__ void fftp_pass1(v2f (&v)[16], v2f* lds, int jf) {
-    dft16<INV>(v);
+    fftp_dft16<INV>(v);
     const int base = 17 * jf;  // pad16(16 jf + t)
 #pragma unroll
     for (int t = 0; t < 16; ++t) lds[base + t] = v[DFT16_OUT(t)];
@@ -87,9 +137,7 @@ __device__ __forceinline__ void fftp_pass2(const v2f* src, v2f* dst, int jf, con
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = src[pad16(jf + G::T * t)];
     const unsigned k = (unsigned)jf & 15u;
-#pragma unroll
-    for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw.tw2[k * (unsigned)t]);
-    dft16<INV>(v);
+    fftp_tw_dft16<INV>(v, [&](int t) { return tw.tw2[k * (unsigned)t]; });
     const int base = (jf >> 4) * 272 + (int)k;
 #pragma unroll
     for (int t = 0; t < 16; ++t) dst[base + 17 * t] = v[DFT16_OUT(t)];
@@ -100,13 +148,15 @@ __device__ __forceinline__ void fftp_pass3(v2f (&out)[16], const v2f* lds, int j
     v2f v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = lds[pad16(jf + G::T * u)];
-#pragma unroll
-    for (int u = G::M; u < 16; ++u) v[u] = twmul<INV>(v[u], tw.tw3[u - 1]);
     if constexpr (G::R3 == 16) {
-        dft16<INV>(v);
+        fftp_tw_dft16<INV>(v, [&](int t) { return tw.tw3[t - 1]; });
 #pragma unroll
         for (int t = 0; t < 16; ++t) out[t] = v[DFT16_OUT(t)];
-    } else if constexpr (G::R3 == 8) {
+        return;
+    }
+#pragma unroll
+    for (int u = G::M; u < 16; ++u) v[u] = twmul<INV>(v[u], tw.tw3[u - 1]);
+    if constexpr (G::R3 == 8) {
         dft8<INV>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14]);
         dft8<INV>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]);
 #pragma unroll
@@ -155,9 +205,7 @@ __device__ __forceinline__ void fftp_mid3_inplace(v2f* buf, int jf, const Twiddl
 #pragma unroll
     for (int t = 0; t < 16; ++t) a[t] = buf[pad16(jf + G::T * t)];
     const unsigned k = (unsigned)jf & 255u;
-#pragma unroll
-    for (int t = 1; t < 16; ++t) a[t] = twmul<INV>(a[t], tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)]);
-    dft16<INV>(a);
+    fftp_tw_dft16<INV>(a, [&](int t) { return tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)]; });
     frame_sync<LOGN>();
     const int base = (jf >> 8) * 4352 + (int)k + (int)(k >> 4);  // pad16(4096 q + k + 256 t) = 4352 q + k + k/16 + 272 t
 #pragma unroll
@@ -187,9 +235,7 @@ __device__ __forceinline__ void fftp_inplace(v2f (&v)[16], v2f* buf, int jf, con
 #pragma unroll
         for (int t = 0; t < 16; ++t) a[t] = buf[pad16(jf + G::T * t)];
         const unsigned k = (unsigned)jf & 15u;
-#pragma unroll
-        for (int t = 1; t < 16; ++t) a[t] = twmul<INV>(a[t], tw.tw2[k * (unsigned)t]);
-        dft16<INV>(a);
+        fftp_tw_dft16<INV>(a, [&](int t) { return tw.tw2[k * (unsigned)t]; });
         frame_sync<LOGN>();
         const int base = (jf >> 4) * 272 + (int)k;
 #pragma unroll
@@ -217,14 +263,7 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
             b[t] = B[pad16(jf + G::T * t)];
         }
         const unsigned k = (unsigned)jf & 15u;
-#pragma unroll
-        for (int t = 1; t < 16; ++t) {
-            const v2f w = tw.tw2[k * (unsigned)t];
-            a[t] = twmul<INV>(a[t], w);
-            b[t] = twmul<INV>(b[t], w);
-        }
-        dft16<INV>(a);
-        dft16<INV>(b);
+        fftp_tw_dft16_dual<INV>(a, b, [&](int t) { return tw.tw2[k * (unsigned)t]; });
         frame_sync<LOGN>();
         const int base = (jf >> 4) * 272 + (int)k;
 #pragma unroll
@@ -242,14 +281,7 @@ __device__ __forceinline__ void fftp_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, 
             b[t] = B[pad16(jf + G::T * t)];
         }
         const unsigned k = (unsigned)jf & 255u;
-#pragma unroll
-        for (int t = 1; t < 16; ++t) {
-            const v2f w = tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)];
-            a[t] = twmul<INV>(a[t], w);
-            b[t] = twmul<INV>(b[t], w);
-        }
-        dft16<INV>(a);
-        dft16<INV>(b);
+        fftp_tw_dft16_dual<INV>(a, b, [&](int t) { return tw.twN[(k * (unsigned)t) * (unsigned)(G::N / 4096)]; });
         frame_sync<LOGN>();
         const int base = (jf >> 8) * 4352 + (int)k + (int)(k >> 4);
 #pragma unroll

@@ -25,7 +25,7 @@ namespace omx {
 
 namespace {
 
-// TRI_KNOCK (pricing builds, WRONG columns): 1 no LDS traffic in the transforms, 2 no butterflies, 3 no barriers in the transforms, 4 no point stores
+// TRI_KNOCK (pricing builds, WRONG columns): 1 no LDS traffic in the transforms, 2 no butterflies, 3 no barriers in the transforms, 4 no point stores, 5 no Hilbert-spectrum arithmetic, 6 no reassignment arithmetic, 7 no window / table loads, 8 no Hilbert LDS round trip
 #ifndef TRI_KNOCK
 #define TRI_KNOCK 0
 #endif
@@ -232,7 +232,13 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
 
     // ---- 1. packed real FFTs of the two 8192-sample windows ---------------------------------------------------------------
     v2f va[16], vb[16];
-    if (direct) {
+    if (TRI_KNOCK == 7) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            va[t] = v2f{(float)(j + t) * 1e-4f, (float)(j - t) * 1e-4f};
+            vb[t] = v2f{(float)(j + 2 * t) * 1e-4f, (float)(j - 3 * t) * 1e-4f};
+        }
+    } else if (direct) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             va[t] = load_v2f(windowb, ju * 8u, 2048u * (unsigned)t);
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16]) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const v2f z = v[t], zr = X[part + kTriStep * (15 - t)];
+            const v2f z = v[t], zr = TRI_KNOCK == 8 ? v[15 - t] : X[part + kTriStep * (15 - t)];
             const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
             v2f w8;
             switch (t) {  // compile-time after unrolling
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
                 case 14: w8 = w8_at<14>(w8_base); break;
                 default: w8 = w8_at<15>(w8_base); break;
             }
-            y[t] = cmulc(sum, w8) - cmul(dif, w8);
+            y[t] = TRI_KNOCK == 5 ? sum + dif : cmulc(sum, w8) - cmul(dif, w8);
             if (t == 0 && j == 0) y[t] = v2f{0.0f, 0.0f};
         }
     };
@@ -383,7 +389,15 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
                 const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
                 const v2f bb{c0 * z[t].x + half_c1 * zs.x, c0 * z[t].y + half_c1 * zs.y};
                 const v2f bd{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / W) (Z[k-1] - Z[k+1])
-                const bool keep = reassign_flat(bin, bb, bd, z2[t], pn[t], rc, pts[t]) && (t < 8 || j == 0) && !silent;
+                bool keep;
+                if (TRI_KNOCK == 6) {
+                    pts[t].time_offset = bb.x;
+                    pts[t].freq_hz = bd.y + z2[t].x;
+                    pts[t].power = pn[t];
+                    keep = (t < 8 || j == 0) && !silent;
+                } else {
+                    keep = reassign_flat(bin, bb, bd, z2[t], pn[t], rc, pts[t]) && (t < 8 || j == 0) && !silent;
+                }
                 masks[t] = __ballot(keep);
                 if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
             }
