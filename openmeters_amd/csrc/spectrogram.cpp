@@ -301,6 +301,17 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
         fa.win_terms = (cfg_.window == OMX_WINDOW_HANN || cfg_.window == OMX_WINDOW_HAMMING) ? 2u : 0u;
         fa.win_c0 = cfg_.window == OMX_WINDOW_HANN ? 0.5f : 25.0f / 46.0f;
         fa.win_c1 = cfg_.window == OMX_WINDOW_HANN ? -0.5f : -21.0f / 46.0f;
+        {   // WindowKind::coefficients (window.rs:24-31), the reference's f32 constants
+            static const float kCos[5][4] = {{1.0f, 0.0f, 0.0f, 0.0f},
+                                             {0.5f, -0.5f, 0.0f, 0.0f},
+                                             {25.0f / 46.0f, -21.0f / 46.0f, 0.0f, 0.0f},
+                                             {0.42f, -0.5f, 0.08f, 0.0f},
+                                             {0.35875f, -0.48829f, 0.14128f, -0.01168f}};
+            static const uint32_t kTerms[5] = {1, 2, 2, 3, 4};
+            const uint32_t wk = cfg_.window <= OMX_WINDOW_BLACKMAN_HARRIS ? cfg_.window : OMX_WINDOW_HANN;
+            for (int m = 0; m < 4; ++m) fa.cos_c[m] = kCos[wk][m];
+            fa.cos_terms = kTerms[wk];
+        }
         fa.points = d_points_.ptr;
         fa.counts = d_counts_.ptr;
         const bool cross_check = kernel_form_ == 30;  // OMX_OPT_KERNEL_FORM: 4096 through the size-templated kernel

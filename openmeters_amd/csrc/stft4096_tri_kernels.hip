@@ -189,6 +189,10 @@ __device__ __forceinline__ void store_point(omx_spectrogram_point* out, uint32_t
 
 constexpr size_t kTriLds = (size_t)kTriSlots * sizeof(v2f) + 4096 * sizeof(float) + 256 * sizeof(v2f) + 36 * sizeof(uint32_t) + 4 * sizeof(float);
 
+// TERMS = cosine terms of the window (1 rectangular, 2 Hann / Hamming, 3 Blackman, 4 Blackman-Harris): with Z = FFT(s)
+//   FFT(w s)[k]  = c0 Z[k] + sum_m c_m / 2 (Z[k-m] + Z[k+m]),      FFT(w' s)[k] = i sum_m c_m (pi m / W) (Z[k-m] - Z[k+m])
+// (w' = the spectral derivative of w, processor.rs:569-599 = - sum_m c_m (2 pi m / W) sin(2 pi m n / W) exactly), m = 1 ... TERMS - 1
+template <int TERMS>
 __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* X = reinterpret_cast<v2f*>(smem_raw);
@@ -347,8 +351,15 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
         *reinterpret_cast<v2f*>(imb + 2 * (j + 256 * t - 1024)) = yb[t];
     }
     __syncthreads();
-    const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / 4096.0f);
-    v2f* lin_z = X;  // [2306] natural-order bins of Z (slot 1 + k)
+    constexpr int REACH = TERMS > 1 ? TERMS - 1 : 1;  // neighbour bins on either side (the natural-order copy always keeps 3)
+    const float c0 = a.cos_c[0];
+    float half_c[REACH], dscale[REACH];
+#pragma unroll
+    for (int m = 1; m <= REACH; ++m) {
+        half_c[m - 1] = TERMS > 1 ? 0.5f * a.cos_c[m] : 0.0f;
+        dscale[m - 1] = TERMS > 1 ? a.cos_c[m] * ((float)m * 3.14159265358979323846f / 4096.0f) : 0.0f;
+    }
+    v2f* lin_z = X;  // natural-order bins -3 ... 2111 of Z (slot 3 + k)
 
     // ---- 4. per column: Z = FFT(s), T = FFT(t w s) as one dual transform; w and w' applied on the bins of Z -----------------
     auto column = [&](const float (&xr)[16], const float (&twin)[16], const float* imag, float half_x0, float half_xn, bool silent, uint32_t col, uint32_t* count_out) {
@@ -368,27 +379,42 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
         for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
         __syncthreads();  // pass 3 still reads X
 #pragma unroll
-        for (int t = 0; t < 8; ++t) lin_z[1 + j + 256 * t] = z[t];
-        if (wave_u == 0) lin_z[1 + j + 2048] = z[8];  // bins 2048 ... 2111: the Nyquist bin and its upper neighbour
-        if (j == 255) lin_z[0] = z[15];               // bin -1 = bin 4095
+        for (int t = 0; t < 8; ++t) lin_z[3 + j + 256 * t] = z[t];
+        if (wave_u == 0) lin_z[3 + j + 2048] = z[8];  // bins 2048 ... 2111: the Nyquist bin and its upper neighbours
+        if (j >= 253) lin_z[j - 253] = z[15];         // bins -3 ... -1 = bins 4093 ... 4095
         __syncthreads();
         omx_spectrogram_point pts[9];
         unsigned long long masks[9];
         auto bins = [&](auto first, auto last) {
             constexpr int T0 = decltype(first)::value, T1 = decltype(last)::value;
-            v2f nzm[T1 - T0], nzp[T1 - T0];
+            v2f nzm[T1 - T0][REACH], nzp[T1 - T0][REACH];
+            if constexpr (TERMS > 1) {
 #pragma unroll
-            for (int t = T0; t < T1; ++t) {
-                nzm[t - T0] = lin_z[j + 256 * t];
-                nzp[t - T0] = lin_z[j + 256 * t + 2];
+                for (int t = T0; t < T1; ++t)
+#pragma unroll
+                    for (int m = 1; m <= REACH; ++m) {
+                        nzm[t - T0][m - 1] = lin_z[3 + j + 256 * t - m];
+                        nzp[t - T0][m - 1] = lin_z[3 + j + 256 * t + m];
+                    }
             }
 #pragma unroll
             for (int t = T0; t < T1; ++t) {
                 const uint32_t bin = (uint32_t)(j + 256 * t);
-                const v2f zm = nzm[t - T0], zp = nzp[t - T0];
-                const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
-                const v2f bb{c0 * z[t].x + half_c1 * zs.x, c0 * z[t].y + half_c1 * zs.y};
-                const v2f bd{-dscale * zd.y, dscale * zd.x};  // i c1 (pi / W) (Z[k-1] - Z[k+1])
+                v2f bb{c0 * z[t].x, c0 * z[t].y}, bd{0.0f, 0.0f};
+                if constexpr (TERMS == 2) {  // (the statement order of the two-term form this kernel started with: bit-equal columns)
+                    const v2f zm = nzm[t - T0][0], zp = nzp[t - T0][0];
+                    const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
+                    bb = v2f{c0 * z[t].x + half_c[0] * zs.x, c0 * z[t].y + half_c[0] * zs.y};
+                    bd = v2f{-dscale[0] * zd.y, dscale[0] * zd.x};  // i c1 (pi / W) (Z[k-1] - Z[k+1])
+                } else if constexpr (TERMS > 2) {
+#pragma unroll
+                    for (int m = 1; m <= REACH; ++m) {
+                        const v2f zm = nzm[t - T0][m - 1], zp = nzp[t - T0][m - 1];
+                        const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
+                        bb = v2f{bb.x + half_c[m - 1] * zs.x, bb.y + half_c[m - 1] * zs.y};
+                        bd = v2f{bd.x - dscale[m - 1] * zd.y, bd.y + dscale[m - 1] * zd.x};
+                    }
+                }
                 bool keep;
                 if (TRI_KNOCK == 6) {
                     pts[t].time_offset = bb.x;
@@ -402,8 +428,19 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
                 if (lane == 0) scan[t * 4 + wave] = (uint32_t)__popcll(masks[t]);
             }
         };
-        bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        if constexpr (TERMS <= 2) {  // four bins at a time: 16 registers of neighbours in flight
+            bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        } else {                     // 2 (TERMS - 1) neighbours per bin: one bin at a time stays inside 168 registers
+            bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            bins(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            bins(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+            bins(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{});
+            bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+            bins(std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{});
+            bins(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{});
+            bins(std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{});
+        }
         if (wave_u == 0) {
             bins(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
         } else {
@@ -436,15 +473,25 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     }
 }
 
-void launch_stft_reassigned_4096_tri(const StftFastArgs& a, hipStream_t stream) {
-    if (a.n_cols == 0 || a.n_streams == 0) return;
+template <int TERMS>
+static void launch_tri(const StftFastArgs& a, hipStream_t stream) {
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_4096_tri_kernel<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kTriLds);
     });
     const uint32_t chunks = (a.n_cols + 1u) / 2u;
-    hipLaunchKernelGGL(stft_reassigned_4096_tri_kernel, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), kTriLds, stream, a);
+    hipLaunchKernelGGL(stft_reassigned_4096_tri_kernel<TERMS>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(256), kTriLds, stream, a);
+}
+
+void launch_stft_reassigned_4096_tri(const StftFastArgs& a, hipStream_t stream) {
+    if (a.n_cols == 0 || a.n_streams == 0) return;
+    switch (a.cos_terms) {
+        case 1: launch_tri<1>(a, stream); break;
+        case 2: launch_tri<2>(a, stream); break;
+        case 3: launch_tri<3>(a, stream); break;
+        default: launch_tri<4>(a, stream); break;
+    }
 }
 
 }  // namespace omx

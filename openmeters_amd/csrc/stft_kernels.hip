@@ -891,14 +891,16 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
         if (swz_variant == 51) { launch_stft_reassigned_4096_col(a, stream); return; }
     }
 #endif
-    if (a.win_terms == 2) {  // Hann / Hamming: two columns per workgroup, four transforms per column
-        static const int env_form = [] {  // TEMP A/B hook
+    {
+        static const int env_form = [] {  // tuning build: OMX_K2_FORM = 2 pins the pair kernel (tools/k2_forms.sh)
             const char* e = tuning_env("OMX_K2_FORM");
             return e ? atoi(e) : -1;
         }();
         const int f = (form == 0 && env_form >= 0) ? env_form : form;
-        if (f == 0) { launch_stft_reassigned_4096_tri(a, stream); return; }   // round 4: three workgroups per CU (stft4096_tri_kernels.hip)
-        if (f == 2) { launch_stft_reassigned_4096_pair(a, stream); return; }  // round 2: two workgroups per CU, two LDS buffers
+        // round 4: three workgroups per CU, every window of the reference applied on the bins (stft4096_tri_kernels.hip)
+        if (f == 0 && a.cos_terms >= 1 && a.cos_terms <= 4) { launch_stft_reassigned_4096_tri(a, stream); return; }
+        // round 2: two workgroups per CU, two LDS buffers (Hann / Hamming)
+        if (f == 2 && a.win_terms == 2) { launch_stft_reassigned_4096_pair(a, stream); return; }
     }
 #ifdef OMX_TUNING
     // Tuning build only (make TUNING=1 -> libomx_hip_tuning.so, loaded through OMX_HIP_LIB): OMX_K2_VARIANT selects an A/B

@@ -105,6 +105,10 @@ struct StftFastArgs {
     // bins; win_terms = 2 for those, otherwise the kernels that window in the time domain run
     float win_c0, win_c1;
     uint32_t win_terms;
+    // every window of the reference is a cosine sum w[n] = sum_m c_m cos(2 pi m n / W) of 1 ... 4 terms (window.rs:20-43: rectangular,
+    // Hann, Hamming, Blackman, Blackman-Harris): the three-workgroups-per-CU kernel (stft4096_tri_kernels.hip) serves all five
+    float cos_c[4];
+    uint32_t cos_terms;  // 1 ... 4 (0: not a cosine sum, never the case for WindowKind)
     // ragged banks (per-stream frame counts): tail and column count of every stream, written by spectrogram_plan_kernel; the
     // scalar `tail` / `n_cols` above then hold nothing / the layout stride (columns per stream slot of points / counts / codes)
     const uint64_t* tails;
