@@ -4,6 +4,7 @@
 // operation order per bin (reference src/visuals/spectrogram/processor.rs:318-348, 439-488, 546-567):
 //   packed real FFT of the 2N-sample window -> Hilbert with one half-length inverse -> analytic slice ->
 //   three windowed FFTs (w, w', t w) -> per-bin reassignment -> ordered compaction.
+#include <mutex>
 #include <cstdlib>
 
 #include "fft_pow2_device.hpp"
@@ -1137,9 +1138,349 @@ static void launch_pow2(const StftFastArgs& a, hipStream_t stream) {
 }
 
 // fft_size = 1024, 2048, 4096 or 8192 (`a.tw4096` = exp(-2 pi i k / N), `a.tw8192` = exp(-2 pi i k / 2N), N entries each)
+
+// ================================================================================================
+// K2p-tri (round 4): the three-workgroups-per-CU form of stft4096_tri_kernels.hip for W = F = 1024 / 2048 — the reference's default
+// spectrogram shape is 2048 / hop 64.  A frame slot (T = N/16 threads) carries two consecutive columns through ONE padded LDS buffer
+// time-shared by the two chains of every dual transform (staggered by half a pass), column b's analytic slice waits in LDS as its
+// imaginary half, FFT(t w s) is windowed in the time domain (twindow) and every window of the reference (a cosine sum of TERMS
+// terms) is applied on the bins of Z: 51 KiB of LDS and <= 168 VGPR per 256-thread workgroup -> three workgroups per CU where the
+// pair kernel above (two buffers per slot, 246 VGPR) fits two.
+// ================================================================================================
+// the Hilbert spectrum of element jf + T t, t = TT ... 15, with its 2N-point twiddle formed on the spot from the thread's table value
+// (a resident run of sixteen would cost 32 registers across the phase)
+template <int TT, int PS>
+__device__ __forceinline__ void hilbert_steps_impl(v2f (&y)[16], const v2f (&v)[16], const v2f* Xp, v2f w8_base, int jf) {
+    if constexpr (TT < 16) {
+        const v2f w8 = rotate128<4 * TT>(w8_base);
+        const v2f z = v[TT], zr = Xp[PS * (15 - TT)];
+        const v2f sum{z.x + zr.x, z.y - zr.y}, dif{z.x - zr.x, z.y + zr.y};
+        y[TT] = cmulc(sum, w8) - cmul(dif, w8);
+        if (TT == 0 && jf == 0) y[TT] = v2f{0.0f, 0.0f};
+        hilbert_steps_impl<TT + 1, PS>(y, v, Xp, w8_base, jf);
+    }
+}
+
+template <bool INV, int LOGN>
+__device__ __forceinline__ void tri_last_pass(v2f (&v)[16], const TwiddlesPow2<LOGN>& tw) {  // fftp_pass3's arithmetic, inputs already in registers
+    using G = FftGeom<LOGN>;
+#pragma unroll
+    for (int u = G::M; u < 16; ++u) v[u] = twmul<INV>(v[u], tw.tw3[u - 1]);
+    if constexpr (G::R3 == 8) {
+        dft8<INV>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14]);
+        dft8<INV>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]);
+    } else {
+        static_assert(G::R3 == 4, "1024 / 2048 points");
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dft4<INV>(v[m], v[m + 4], v[m + 8], v[m + 12]);
+    }
+}
+// two N-point transforms through ONE buffer: x[jf + T t] in a[t] / b[t] on entry, X[jf + T t] on return; the caller has a sync
+// between its last use of X and this call, and on return other threads may still be reading X (chain b's last-pass inputs)
+template <bool INV, int LOGN>
+__device__ __forceinline__ void tri_dual_pow2(v2f (&a)[16], v2f (&b)[16], v2f* X, int jf, const TwiddlesPow2<LOGN>& tw) {
+    using G = FftGeom<LOGN>;
+    constexpr int T = G::T, PS = T + T / 16;
+    const unsigned k = (unsigned)jf & 15u;
+    auto write1 = [&](const v2f (&v)[16]) {
+        const int base = 17 * jf;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) X[base + t] = v[DFT16_OUT(t)];
+    };
+    auto write2 = [&](const v2f (&v)[16]) {
+        const int base = (jf >> 4) * 272 + (int)k;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) X[base + 17 * t] = v[DFT16_OUT(t)];
+    };
+    auto read = [&](v2f (&v)[16]) {
+        const int base = pad16(jf);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = X[base + PS * t];
+    };
+    fftp_dft16<INV>(a);
+    write1(a);
+    frame_sync<LOGN>();
+    read(a);
+    fftp_dft16<INV>(b);
+    frame_sync<LOGN>();  // every pass-2 input of chain a is in registers
+    write1(b);
+    fftp_tw_dft16<INV>(a, [&](int t) { return tw.tw2[k * (unsigned)t]; });
+    frame_sync<LOGN>();
+    read(b);
+    frame_sync<LOGN>();
+    write2(a);
+    fftp_tw_dft16<INV>(b, [&](int t) { return tw.tw2[k * (unsigned)t]; });
+    frame_sync<LOGN>();
+    read(a);
+    frame_sync<LOGN>();
+    write2(b);
+    tri_last_pass<INV, LOGN>(a, tw);
+    frame_sync<LOGN>();
+    read(b);
+    tri_last_pass<INV, LOGN>(b, tw);
+}
+
+template <int LOGN, int TERMS>
+__global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFastArgs a) {
+    using G = FftGeom<LOGN>;
+    constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64, PS = T + T / 16;
+    static_assert(LOGN == 10 || LOGN == 11, "1024 / 2048 points");
+    constexpr int SLOT_FLOATS = 2 * G::LDS + N;  // the transform buffer, then Im analytic[N/2 + i] of column b
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    v2f* tw2_lds = reinterpret_cast<v2f*>(lds + F * SLOT_FLOATS);      // [256]
+    uint32_t* scan_all = reinterpret_cast<uint32_t*>(tw2_lds + 256);   // [F][9][WPF]
+    float* hil_all = reinterpret_cast<float*>(scan_all + F * 9 * WPF); // [F][4]
+
+    const uint32_t pairs = (a.n_cols + 1u) / 2u, chunks = (pairs + F - 1) / F;
+    const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
+    const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
+    if (s >= a.n_streams) return;
+    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    const unsigned ju = (unsigned)jf;
+    const int lane = threadIdx.x & 63, wf = jf >> 6;
+    const int wf_u = __builtin_amdgcn_readfirstlane(wf);
+    v2f* X = reinterpret_cast<v2f*>(lds + fs * SLOT_FLOATS);
+    float* imb = lds + fs * SLOT_FLOATS + 2 * G::LDS;
+    uint32_t* scan = scan_all + fs * 9 * WPF;
+    float* hil = hil_all + fs * 4;
+    const uint32_t n_cols_s = stft_cols(a, s), pairs_s = (n_cols_s + 1u) / 2u;
+    if (chunk * F >= pairs_s) return;  // (whole workgroup: every slot is past this stream's columns)
+    const uint32_t pair_raw = chunk * F + (uint32_t)fs;
+    const bool in_range = pair_raw < pairs_s;
+    const uint32_t pair = in_range ? pair_raw : pairs_s - 1u;  // idle slots shadow the last pair (syncs stay uniform)
+    const uint32_t col0 = 2u * pair;
+    const bool have1 = col0 + 1u < n_cols_s;
+    const uint32_t col1 = have1 ? col0 + 1u : col0;  // an odd tail computes column 0 twice and stores it once
+
+    const float* ring = a.ring + (uint64_t)s * a.cap;
+    const uint32_t mask32 = (uint32_t)(a.cap - 1);
+    const long long last_nonzero = a.last_nonzero[s];
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t tail_s = stft_tail(a, s);
+    const uint64_t p0a = tail_s + (uint64_t)col0 * a.hop, p0b = tail_s + (uint64_t)col1 * a.hop;
+    // silent fast path (:307-316).  The first slot's first column has the smallest p0: if it is silent, every column here is.
+    const uint64_t p0_first = tail_s + (uint64_t)(2u * chunk * F) * a.hop;
+    if (last_nonzero < (long long)p0_first) {
+        if (jf == 0 && in_range) {
+            a.counts[(uint64_t)s * a.n_cols + col0] = 0;
+            if (have1) a.counts[(uint64_t)s * a.n_cols + col1] = 0;
+        }
+        return;
+    }
+    const bool silent_a = last_nonzero < (long long)p0a, silent_b = last_nonzero < (long long)p0b;  // computed anyway, emitted empty
+
+    TwiddlesPow2<LOGN> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);  // `tw4096` carries exp(-2 pi i k / N) for this N
+    if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
+    const v2f w8_base = a.tw8192[ju];  // exp(-2 pi i jf / 2N) / 2
+
+    // ---- 1. packed real FFTs of the two 2N-sample windows ------------------------------------------------------------------------------
+    const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
+    v2f va[16], vb[16];
+    if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            va[t] = *reinterpret_cast<const v2f*>(ring + ((pa32 + 2u * (ju + (unsigned)T * (unsigned)t)) & mask32));
+            vb[t] = *reinterpret_cast<const v2f*>(ring + ((pb32 + 2u * (ju + (unsigned)T * (unsigned)t)) & mask32));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t qa = pa32 + 2u * (ju + (unsigned)T * (unsigned)t), qb = pb32 + 2u * (ju + (unsigned)T * (unsigned)t);
+            va[t] = v2f{ring[qa & mask32], ring[(qa + 1u) & mask32]};
+            vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
+        }
+    }
+    __syncthreads();  // tw2_lds (shared by every slot)
+    tri_dual_pow2<false, LOGN>(va, vb, X, jf, tw);  // v[t] = Zf[jf + T t]
+
+    // ---- 2. Hilbert transform with one half-length inverse per column, one column at a time through X ----------------------------------
+    const int part = (jf ? pad16(N - jf) : N + N / 16) - PS * 15;  // (thread 0, t = 0: one slot past X, inside imb; not used)
+    auto hilbert_spectrum = [&](v2f (&y)[16], const v2f (&v)[16]) {
+        hilbert_steps_impl<0, PS>(y, v, X + part, w8_base, jf);
+    };
+    v2f ya[16], yb[16];
+    frame_sync<LOGN>();  // the last pass of chain b still reads X
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[pad16(jf) + PS * t] = va[t];
+    if (jf == 0) {
+        hil[0] = (va[0].x + va[0].y) * 0.5f;  // X[0] / 2
+        hil[1] = (va[0].x - va[0].y) * 0.5f;  // X[N] / 2
+        hil[2] = (vb[0].x + vb[0].y) * 0.5f;
+        hil[3] = (vb[0].x - vb[0].y) * 0.5f;
+    }
+    frame_sync<LOGN>();
+    hilbert_spectrum(ya, va);
+    frame_sync<LOGN>();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) X[pad16(jf) + PS * t] = vb[t];
+    frame_sync<LOGN>();
+    hilbert_spectrum(yb, vb);
+    const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
+    frame_sync<LOGN>();
+    tri_dual_pow2<true, LOGN>(ya, yb, X, jf, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = jf + T t
+
+    // ---- 3. analytic slices s[i] = analytic[N/2 + i], i = jf + T t -------------------------------------------------------------------------
+    auto load_real_half = [&](float (&xr)[16], uint32_t p32) {
+        const uint32_t q0 = p32 + (uint32_t)(N / 2) + ju;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xr[t] = ring[(q0 + (unsigned)T * (unsigned)t) & mask32];
+    };
+    auto load_twindow = [&](float (&twin)[16]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) twin[t] = a.twindow[ju + (unsigned)T * (unsigned)t];
+    };
+    float xra[16], twina[16];
+    load_real_half(xra, pa32);
+    load_twindow(twina);
+    frame_sync<LOGN>();
+    float* imag_a = reinterpret_cast<float*>(X);
+#pragma unroll
+    for (int t = 4; t < 12; ++t) {
+        *reinterpret_cast<v2f*>(imag_a + 2 * (jf + T * t - N / 4)) = ya[t];
+        *reinterpret_cast<v2f*>(imb + 2 * (jf + T * t - N / 4)) = yb[t];
+    }
+    frame_sync<LOGN>();
+    constexpr int REACH = TERMS > 1 ? TERMS - 1 : 1;
+    const float c0 = a.cos_c[0];
+    float half_c[REACH], dscale[REACH];
+#pragma unroll
+    for (int m = 1; m <= REACH; ++m) {
+        half_c[m - 1] = TERMS > 1 ? 0.5f * a.cos_c[m] : 0.0f;
+        dscale[m - 1] = TERMS > 1 ? a.cos_c[m] * ((float)m * 3.14159265358979323846f / (float)N) : 0.0f;
+    }
+    v2f* lin_z = X;  // natural-order bins -3 ... N/2 + T of Z (slot 3 + k)
+
+    // ---- 4. per column: Z = FFT(s), FFT(t w s) as one dual transform; w and w' applied on the bins of Z ------------------------------------
+    auto column = [&](const float (&xr)[16], const float (&twin)[16], const float* imag, float half_x0, float half_xn, bool silent, bool store,
+                      uint32_t col) {
+        v2f z[16], z2[16];
+        {
+            const float par = (jf & 1) ? -half_xn : half_xn;  // (-1)^n: n = N/2 + i has jf's parity
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                z[t] = v2f{(float)N * xr[t] - half_x0 + par, imag[jf + T * t]};
+                z2[t] = v2f{z[t].x * twin[t], z[t].y * twin[t]};
+            }
+        }
+        frame_sync<LOGN>();  // the slice reads above / the previous column's neighbour reads still use X
+        tri_dual_pow2<false, LOGN>(z, z2, X, jf, tw);
+        float pn[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+        frame_sync<LOGN>();  // the last pass still reads X
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lin_z[3 + jf + T * t] = z[t];
+        if (wf_u == 0) lin_z[3 + jf + 8 * T] = z[8];  // bins N/2 ... N/2 + 63: the Nyquist bin and its upper neighbours
+        if (jf >= T - 3) lin_z[jf - (T - 3)] = z[15];  // bins -3 ... -1 = bins N - 3 ... N - 1
+        frame_sync<LOGN>();
+        omx_spectrogram_point pts[9];
+        unsigned long long masks[9];
+        auto bins = [&](auto first, auto last) {
+            constexpr int T0 = decltype(first)::value, T1 = decltype(last)::value;
+            v2f nzm[T1 - T0][REACH], nzp[T1 - T0][REACH];
+            if constexpr (TERMS > 1) {
+#pragma unroll
+                for (int t = T0; t < T1; ++t)
+#pragma unroll
+                    for (int m = 1; m <= REACH; ++m) {
+                        nzm[t - T0][m - 1] = lin_z[3 + jf + T * t - m];
+                        nzp[t - T0][m - 1] = lin_z[3 + jf + T * t + m];
+                    }
+            }
+#pragma unroll
+            for (int t = T0; t < T1; ++t) {
+                const uint32_t bin = ju + (unsigned)T * (unsigned)t;
+                v2f bb{c0 * z[t].x, c0 * z[t].y}, bd{0.0f, 0.0f};
+                if constexpr (TERMS == 2) {
+                    const v2f zm = nzm[t - T0][0], zp = nzp[t - T0][0];
+                    const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
+                    bb = v2f{c0 * z[t].x + half_c[0] * zs.x, c0 * z[t].y + half_c[0] * zs.y};
+                    bd = v2f{-dscale[0] * zd.y, dscale[0] * zd.x};  // i c1 (pi / N) (Z[k-1] - Z[k+1])
+                } else if constexpr (TERMS > 2) {
+#pragma unroll
+                    for (int m = 1; m <= REACH; ++m) {
+                        const v2f zm = nzm[t - T0][m - 1], zp = nzp[t - T0][m - 1];
+                        const v2f zs{zm.x + zp.x, zm.y + zp.y}, zd{zm.x - zp.x, zm.y - zp.y};
+                        bb = v2f{bb.x + half_c[m - 1] * zs.x, bb.y + half_c[m - 1] * zs.y};
+                        bd = v2f{bd.x - dscale[m - 1] * zd.y, bd.y + dscale[m - 1] * zd.x};
+                    }
+                }
+                const bool keep = reassign_flat(bin, bb, bd, z2[t], pn[t], rc, pts[t]) && (t < 8 || jf == 0) && !silent;
+                masks[t] = __ballot(keep);
+                if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
+            }
+        };
+        if constexpr (TERMS <= 2) {
+            bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        } else {
+            bins(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            bins(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            bins(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+            bins(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        }
+        if (wf_u == 0) {
+            bins(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
+        } else {
+            masks[8] = 0ull;
+            if (lane == 0) scan[8 * WPF + wf] = 0u;
+        }
+        frame_sync<LOGN>();
+        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        const uint32_t running = store_ordered<WPF>(masks, pts, scan, lane, wf, store, out);
+        if (jf == 0 && store) a.counts[(uint64_t)s * a.n_cols + col] = running;
+    };
+    column(xra, twina, imag_a, half_x0a, half_xna, silent_a, in_range, col0);
+    {
+        float xrb[16], twinb[16];
+        load_real_half(xrb, pb32);
+        load_twindow(twinb);
+        column(xrb, twinb, imb, half_x0b, half_xnb, silent_b, in_range && have1, col1);
+    }
+}
+
+template <int LOGN, int TERMS>
+static void launch_pow2_tri_terms(const StftFastArgs& a, hipStream_t stream) {
+    using G = FftGeom<LOGN>;
+    constexpr int F = G::FRAMES, WPF = G::T / 64;
+    const size_t lds = (size_t)F * (2 * G::LDS + G::N) * sizeof(float) + 256 * sizeof(v2f) + (size_t)F * 9 * WPF * sizeof(uint32_t) +
+                       (size_t)F * 4 * sizeof(float);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_reassigned_pow2_tri_kernel<LOGN, TERMS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    const uint32_t pairs = (a.n_cols + 1u) / 2u;
+    hipLaunchKernelGGL((stft_reassigned_pow2_tri_kernel<LOGN, TERMS>), dim3(stream_column_grid(a.n_streams, (pairs + F - 1) / F)), dim3(256), lds,
+                       stream, a);
+}
+template <int LOGN>
+static void launch_pow2_tri(const StftFastArgs& a, hipStream_t stream) {
+    switch (a.cos_terms) {
+        case 1: launch_pow2_tri_terms<LOGN, 1>(a, stream); break;
+        case 2: launch_pow2_tri_terms<LOGN, 2>(a, stream); break;
+        case 3: launch_pow2_tri_terms<LOGN, 3>(a, stream); break;
+        default: launch_pow2_tri_terms<LOGN, 4>(a, stream); break;
+    }
+}
+
 void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
     static const bool one_column_slots = [] { const char* e = tuning_env("OMX_POW2_SINGLE"); return e && atoi(e) == 1; }();  // A/B: the one-column-per-slot kernel
+#ifdef POW2_FORCE_PAIR  // A/B build (tools/build_ab.sh): the round-2 pair kernel
+    static const bool pair_form = true;
+#else
+    static const bool pair_form = [] { const char* e = tuning_env("OMX_POW2_PAIR"); return e && atoi(e) == 1; }();  // tuning build
+#endif
+    if (a.cos_terms >= 1 && a.cos_terms <= 4 && !one_column_slots && !pair_form && (fft_size == 1024 || fft_size == 2048)) {
+        // round 4: three workgroups per CU, every window of the reference on the bins
+        if (fft_size == 1024) launch_pow2_tri<10>(a, stream);
+        else launch_pow2_tri<11>(a, stream);
+        return;
+    }
     if (a.win_terms == 2 && !one_column_slots && (fft_size == 1024 || fft_size == 2048)) {  // Hann / Hamming: two columns per slot
         if (fft_size == 1024) launch_pow2_pair<10>(a, stream);
         else launch_pow2_pair<11>(a, stream);
