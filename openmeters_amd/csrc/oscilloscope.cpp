@@ -141,9 +141,14 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     // (stream, block, view) in parallel, and one workgroup per stream runs the stateful trigger pass in timeline order.
     const uint64_t total_frames = block_frames * n_blocks;
     const bool wide = fft_size == 8192 && scope_trigger_lds_bytes(max_kernel, max_period) <= 152 * 1024 && total_frames <= (1ull << 22);
+    // 54.6 ... 218 kHz (88.2 / 96 / 176.4 / 192 kHz): the autocorrelation is a 16 384- or 32 768-point transform.  Pushed-first form too:
+    // estimates by scope_estimate_big_kernel (LDS transforms), then the one-workgroup-per-stream kernel on those estimates (round 4;
+    // before, that kernel ran a radix-2 transform in global memory per block: 21x the 48 kHz time per block at 96 kHz)
+    const bool big = !wide && (fft_size == 16384 || fft_size == 32768) && total_frames <= (1ull << 22);
+    const bool pushed_first = wide || big;
     const uint64_t cap = std::max<uint64_t>(  // never shrinks: call shapes may alternate
-        cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(wide ? total_frames : block_frames, 4096)));
-    if (ragged_ && !wide && (cap != cap_ || !rings_.ptr))
+        cap_, next_pow2((uint64_t)history_frames + std::max<uint64_t>(pushed_first ? total_frames : block_frames, 4096)));
+    if (ragged_ && !pushed_first && (cap != cap_ || !rings_.ptr))
         unsupported("oscilloscope process_ragged: block_frames grew beyond the ring sized at the first ragged call");
     if (cap != cap_ || !rings_.ptr) {
         DeviceBuffer<float> bigger;
@@ -171,15 +176,15 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     if (fft_size != fft_size_) {
         fft_size_ = fft_size;
         tw_fft_.upload(twiddle_table(fft_size, fft_size / 2), stream);
-        if (fft_size == 8192) {
+        if (fft_size == 8192 || fft_size == 16384 || fft_size == 32768) {  // the LDS transforms: exp(-2 pi i k / 256), exp(-2 pi i k / M), M = fft_size / 2
             tw256_.upload(twiddle_table(256, 256), stream);
-            tw4096_.upload(twiddle_table(4096, 4096), stream);
+            tw4096_.upload(twiddle_table(fft_size / 2, fft_size / 2), stream);
         }
     }
     const uint64_t scratch_stride = scope_scratch_floats(max_kernel, 0, probe_frames, max_period);
     scratch_.reserve((size_t)(scratch_stride * n_streams_));
     const bool fft_in_lds = (uint64_t)fft_size * sizeof(v2f) <= 64 * 1024;
-    if (!fft_in_lds) fft_global_.reserve((size_t)n_streams_ * fft_size * 2);
+    if (!fft_in_lds && !big) fft_global_.reserve((size_t)n_streams_ * fft_size * 2);
     if (pending_unlock_) {
         OMX_HIP(hipMemsetAsync(trig_.ptr, 0, trig_.count * sizeof(ScopeTriggerState), stream));
         pending_unlock_ = false;
@@ -226,11 +231,13 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     sa.fft_size = fft_size;
     sa.log_fft = log2_exact(fft_size);
     sa.tw_fft = reinterpret_cast<const v2f*>(tw_fft_.ptr);
-    sa.fft_global = fft_in_lds ? nullptr : reinterpret_cast<v2f*>(fft_global_.ptr);
+    sa.fft_global = (fft_in_lds || big) ? nullptr : reinterpret_cast<v2f*>(fft_global_.ptr);
     const bool fast_acf = fft_size_ == 8192 && fft_in_lds && tw4096_.ptr;
-    sa.tw256 = fast_acf ? reinterpret_cast<const v2f*>(tw256_.ptr) : nullptr;
-    sa.tw4096 = fast_acf ? reinterpret_cast<const v2f*>(tw4096_.ptr) : nullptr;
+    sa.tw256 = (fast_acf || big) ? reinterpret_cast<const v2f*>(tw256_.ptr) : nullptr;
+    sa.tw4096 = (fast_acf || big) ? reinterpret_cast<const v2f*>(tw4096_.ptr) : nullptr;
     sa.lds_scratch = (fast_acf && scope_lds_scratch_bytes(max_kernel, sa.max_period, sa.probe_frames) <= 150 * 1024) ? 1u : 0u;
+    sa.pre_pushed = big ? 1u : 0u;
+    if (big) sa.lds_scratch = scope_locate_lds_bytes(max_kernel, sa.max_period) <= 150 * 1024 ? 2u : 0u;  // 96 kHz: 134 KiB; 192 kHz: global scratch
     sa.headers = headers_.ptr;
     sa.samples = samples_.ptr;
     static const bool phase_timing = [] {
@@ -258,13 +265,14 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
         sa.blocks_v = r_blocks_.ptr;
         sa.reset_v = r_mask_.ptr;
         sa.epoch_v = r_epoch_.ptr;
-        if (wide) {
+        if (pushed_first) {
             estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
             sa.estimates = estimates_.ptr;
             sa.est_view_count = 0;
             for (int t = 0; t < kScopeTraces; ++t)
                 if (t < 2 ? active[t] : separate) sa.est_views[sa.est_view_count++] = (uint32_t)t;
-            launch_oscilloscope_fast(sa, stream);
+            if (wide) launch_oscilloscope_fast(sa, stream);
+            else launch_oscilloscope_big(sa, stream);
         } else {
             launch_oscilloscope(sa, stream);
         }
@@ -280,7 +288,7 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
         }
         return OMX_PRODUCED;
     }
-    if (wide) {
+    if (pushed_first) {
         estimates_.reserve((size_t)n_streams_ * n_blocks * kScopeTraces);
         sa.estimates = estimates_.ptr;
         // the views a block of this call can ask an estimate for (:683-700): the linked view alone while every pushed trace holds
@@ -300,7 +308,8 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
             for (int t = 0; t < kScopeTraces; ++t)
                 if (t < 2 ? active[t] : separate) sa.est_views[sa.est_view_count++] = (uint32_t)t;
         }
-        launch_oscilloscope_fast(sa, stream);
+        if (wide) launch_oscilloscope_fast(sa, stream);
+        else launch_oscilloscope_big(sa, stream);
     } else {
         launch_oscilloscope(sa, stream);
     }

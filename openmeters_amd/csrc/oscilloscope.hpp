@@ -75,6 +75,7 @@ struct ScopeArgs {
     ScopeEstimate* estimates;    // [n_streams][n_blocks][kScopeTraces] or nullptr (single-pass form)
     uint32_t est_view_count;     // wide form: the views whose estimate a block of this call can ask for (grid z of the estimate kernel)
     uint32_t est_views[kScopeTraces];
+    uint32_t pre_pushed;         // one-workgroup-per-stream kernel: the call's frames are in the rings already and a.estimates holds every estimate
     // ragged banks (per-stream block counts; nullptr = lock-step; single-pass form only): stream s runs blocks_v[s] <= n_blocks
     // blocks from its own ring positions pos_v[s][trace] = {head, len} (head / len above are then unused), after a
     // clear_history() of its own when reset_v[s] != 0 (its epoch_v[s] then advances)
@@ -84,12 +85,15 @@ struct ScopeArgs {
     uint64_t* epoch_v;           // [n_streams]
 };
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
+uint64_t scope_locate_lds_bytes(uint32_t max_kernel, uint32_t max_period);
 constexpr int SCOPE_PHASES = 10;
 void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);
 void scope_fast_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset);  // the wide form's trigger kernel
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream);
 // wide form (scope_fast_kernels.hip): push / estimate / trigger kernels; a.estimates != nullptr, rings hold history + the call
 void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream);
+// fft_size 16384 / 32768: push / big estimate kernels, then the single-pass kernel on precomputed estimates (a.pre_pushed = 1)
+void launch_oscilloscope_big(const ScopeArgs& a, hipStream_t stream);
 uint64_t scope_trigger_lds_bytes(uint32_t max_kernel, uint32_t max_period);
 // tests: the trigger pass' find_best on caller-supplied device arrays (work[len + search], template[len]); scores[search + 1]
 void launch_scope_find_best_debug(const float* d_work, const float* d_tmpl, uint32_t len, uint32_t search, float period, uint32_t* d_best_off,

@@ -751,7 +751,13 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         sc.scores = scratch + off;     off += (uint64_t)max(ms, 256u) + 8;
         sc.energy = scratch + off;
         sc.partials = partials;
-        if (a.lds_scratch) {
+        if (a.lds_scratch == 2) {
+            // pre-pushed form: the estimate arrays are not used here, the whole dynamic region is the locate layout
+            float* lds_f = reinterpret_cast<float*>(smem_raw);
+            sc.work = lds_f;
+            sc.candidate = sc.work + a.max_kernel + ms + 8;
+            sc.scores = sc.candidate + a.max_kernel + 8;
+        } else if (a.lds_scratch) {
             // The hot arrays live in LDS (the global copies above stay allocated as the fallback layout).  Two phases alias the
             // same dynamic region:  estimate_period  [ 4096-point FFT buffer | nsdf | energy ]
             //                       locate           [ work | candidate | scores ]
@@ -796,8 +802,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     PhaseClock pc;
     pc.start(a.phase_timing != 0);
     for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
-        // ---- push projected frames (:657-681)
-        for (uint32_t f = tid; f < a.block_frames; f += 256) {
+        // ---- push projected frames (:657-681) — unless scope_push2_kernel has put the whole call into the rings already
+        for (uint32_t f = a.pre_pushed ? a.block_frames : tid; f < a.block_frames; f += 256) {
             const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
             float left = 0.0f, right = 0.0f;
             for (uint32_t c = 0; c < a.fmt.channels; ++c) {
@@ -838,7 +844,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         // ---- captures (:683-700)
         auto capture = [&](int view_index, int trig_index) -> Capture {
             const View& trace = views[view_index];
-            const ScopeEstimate* pre = nullptr;  // (estimates ahead of the trigger pass: the wide form, scope_fast_kernels.hip)
+            // estimates ahead of the trigger pass (scope_estimate_big_kernel: fft_size 16384 / 32768), else computed here
+            const ScopeEstimate* pre = a.pre_pushed && a.estimates ? a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view_index : nullptr;
             if (a.trigger_mode == OMX_TRIGGER_ZERO_CROSSING) return zero_crossing_capture(trace, a.base_frames, a.max_period, sh);
             if (trace.n >= a.base_frames) {
                 float* reference = a.reference + ((uint64_t)s * kScopeTraces + trig_index) * a.max_kernel;
@@ -943,6 +950,12 @@ uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint3
     return std::max(estimate, locate) * sizeof(float);
 }
 
+// bytes of the locate layout alone (work | candidate | scores): the pre-pushed form, whose estimates come from another kernel
+uint64_t scope_locate_lds_bytes(uint32_t max_kernel, uint32_t max_period) {
+    const uint32_t ms = (uint32_t)std::ceil((float)max_period * 1.5f) + 2;
+    return ((max_kernel + ms + 8ull) + (max_kernel + 8ull) + (std::max(ms, 256u) + 8ull)) * sizeof(float);
+}
+
 void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset) {
     OMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scope_phase_cycles), SCOPE_PHASES * sizeof(unsigned long long)));
     if (reset) {
@@ -953,8 +966,9 @@ void scope_phase_cycles(unsigned long long out[SCOPE_PHASES], bool reset) {
 
 void launch_oscilloscope(const ScopeArgs& a, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_blocks == 0) return;
-    size_t lds = a.fft_global ? 0 : (size_t)a.fft_size * sizeof(v2f);
-    if (a.lds_scratch) lds = std::max(lds, (size_t)scope_lds_scratch_bytes(a.max_kernel, a.max_period, a.probe_frames));
+    size_t lds = (a.fft_global || a.pre_pushed) ? 0 : (size_t)a.fft_size * sizeof(v2f);
+    if (a.lds_scratch == 2) lds = (size_t)scope_locate_lds_bytes(a.max_kernel, a.max_period);
+    else if (a.lds_scratch) lds = std::max(lds, (size_t)scope_lds_scratch_bytes(a.max_kernel, a.max_period, a.probe_frames));
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(oscilloscope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);

@@ -26,6 +26,7 @@
 #include "scope_device.hpp"
 
 #include "fft_device.hpp"
+#include "fft_pow2_device.hpp"
 
 #include <type_traits>
 
@@ -1404,6 +1405,243 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
     if (tid == 0) *out = res;
 }
 
+
+// ---------------------------------------------------------------- scope_estimate_big_kernel (round 4)
+// The same estimate for the rates whose autocorrelation is a 16 384- or 32 768-point transform (54.6 ... 109 kHz: 88.2 / 96 kHz;
+// 109 ... 218 kHz: 176.4 / 192 kHz) — until round 3 these configurations ran a radix-2 transform in GLOBAL memory inside the
+// one-workgroup-per-stream kernel (96 kHz: 27.9 ms per 256 x 64-block call against 1.3 ms at 48 kHz).  M = fft_size / 2 complex
+// points per (stream, block, view) as one size-templated LDS transform each way (fft_pow2_device.hpp: T = M / 16 threads,
+// four radix-16 passes in place), real-input packing as in scope_estimate2_kernel.  The NSDF denominators of a thread's own lags
+// wait in registers (the energy prefix shares the transform buffer and is dead before the transform starts; the NSDF takes the
+// buffer over after the inverse), so the kernel needs the padded M-point buffer and nothing else: 70 KiB / 139 KiB.
+template <int LOGM>
+__global__ __launch_bounds__(FftGeom<LOGM>::T) void scope_estimate_big_kernel(ScopeArgs a) {
+    using G = FftGeom<LOGM>;
+    constexpr int M = G::N, T = G::T, W = T / 64;
+    static_assert(G::FRAMES == 1 && (LOGM == 13 || LOGM == 14), "8192 / 16384 complex points, one transform per workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ RedSlots<W> slots;
+    __shared__ v2f tw2_lds[256];
+    const unsigned tid = threadIdx.x;
+    const uint32_t s = blockIdx.x, blk = blockIdx.y, view = a.est_views[blockIdx.z];
+    const bool ragged = a.blocks_v != nullptr;
+    ScopeEstimate* out = a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view;
+    if (ragged && blk >= a.blocks_v[s]) return;
+    // which captures the trigger pass will attempt after this block (:683-700), from the deque lengths alone
+    const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;
+    auto on = [&](int t) { return t < 2 ? a.trace_channel[t] != OMX_CHANNEL_NONE : a.separate_source != 0; };
+    auto len0 = [&](int t) -> uint64_t { return ragged ? (reset_stream ? 0ull : a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1]) : a.len[t]; };
+    auto len_after = [&](int t) -> uint64_t {
+        return on(t) ? min(len0(t) + (uint64_t)(blk + 1) * a.block_frames, (uint64_t)a.history_frames) : 0ull;
+    };
+    const int linked_view = a.matching_trace >= 0 ? a.matching_trace : (a.separate_source ? 2 : -1);
+    bool needed = false;
+    if (a.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && on((int)view)) {
+        const bool linked_runs = linked_view >= 0 && len_after(linked_view) >= a.base_frames;
+        if ((int)view == linked_view) needed = linked_runs;
+        else if (view < 2) needed = !linked_runs && len_after((int)view) >= a.base_frames;
+    }
+    const ScopeEstimate none{0, 0.0f, 0.0f, 0.0f};
+    if (!needed) {
+        if (tid == 0) *out = none;
+        return;
+    }
+    Reducer<W> red{&slots, 0};
+    v2f* fft = reinterpret_cast<v2f*>(smem_raw);
+    float* E = reinterpret_cast<float*>(smem_raw);  // energy prefix (n + 1 <= 2 M + 1 floats), dead before the transform starts; then the NSDF
+    TwiddlesPow2<LOGM> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, tid);  // `tw4096` carries exp(-2 pi i k / M) for this M
+    if (tid < 256) tw2_lds[tid] = a.tw256[tid];
+
+    const uint64_t n_trace = len_after((int)view);
+    const uint64_t head0 = ragged ? a.pos_v[((uint64_t)s * kScopeTraces + view) * 2] : a.head[view];
+    const uint64_t head = head0 + (uint64_t)(blk + 1) * a.block_frames;
+    const uint32_t n = (uint32_t)min((uint64_t)a.probe_frames, n_trace);
+    const float* ring = a.rings + ((uint64_t)s * kScopeTraces + view) * a.cap;
+    const uint32_t mask = (uint32_t)(a.cap - 1), start = (uint32_t)((head - n) & (a.cap - 1));
+    float last_peak = 0.0f;
+    if (n < 3) {  // (:308-313: the estimator is not run, last_peak = 0)
+        if (tid == 0) *out = none;
+        return;
+    }
+    const int j = (int)tid;
+    v2f v[16];
+    float r3[3] = {0.0f, NEG_INF, -NEG_INF};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t i0 = 2u * (uint32_t)(j + T * t);
+        const float x0 = i0 < n ? ring[(start + i0) & mask] : 0.0f;
+        const float x1 = i0 + 1u < n ? ring[(start + i0 + 1u) & mask] : 0.0f;
+        v[t] = v2f{x0, x1};
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t i0 = 2u * (uint32_t)(j + T * t);
+        if (i0 < n) {
+            r3[0] += v[t].x;
+            r3[1] = fmaxf(r3[1], v[t].x);
+            r3[2] = fminf(r3[2], v[t].x);
+        }
+        if (i0 + 1u < n) {
+            r3[0] += v[t].y;
+            r3[1] = fmaxf(r3[1], v[t].y);
+            r3[2] = fminf(r3[2], v[t].y);
+        }
+    }
+    red.template run<3, (OP_SUM) | (OP_MAX << 2) | (OP_MIN << 4)>(r3);
+    const float mean = r3[0] / (float)n;
+    last_peak = fmaxf(fabsf(r3[1] - mean), fabsf(r3[2] - mean));  // max |x - mean| (:98-101): attained at an extreme of x
+    const float rate = a.sample_rate;
+    const uint32_t min_period = f2u(fmaxf(roundf(rate / MAX_HZ), 2.0f));
+    const uint32_t max_period = min(f2u(roundf(rate / MIN_HZ)), n / 2);
+    if (last_peak < MIN_SIGNAL_PEAK || max_period <= min_period + 1) {
+        if (tid == 0) *out = ScopeEstimate{0, 0.0f, 0.0f, last_peak};
+        return;
+    }
+    const uint32_t max_lag = max_period;
+    // compute_periodicity (:133-181): centred samples (the transform's input) and their squares in index order
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t i0 = 2u * (uint32_t)(j + T * t);
+        v[t].x = i0 < n ? v[t].x - mean : 0.0f;
+        v[t].y = i0 + 1u < n ? v[t].y - mean : 0.0f;
+        *reinterpret_cast<v2f*>(E + i0) = v2f{v[t].x * v[t].x, v[t].y * v[t].y};  // E[i] <- c_i^2 for now
+    }
+    __syncthreads();
+    {   // E[i + 1] = c_i^2 + E[i] (:141-146): per-thread chunks, a wave scan of the chunk sums, the wavefronts in order; in place
+        const uint32_t chunk = (n + (uint32_t)T - 1u) / (uint32_t)T;  // <= 32 (n <= 2 M)
+        const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+        auto scan = [&](auto ctag) {
+            constexpr int C = decltype(ctag)::value;
+            float sq[C];
+            float local = 0.0f;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                sq[q] = (uint32_t)q < chunk && i < hi ? E[i] : 0.0f;
+                local = sq[q] + local;
+            }
+            const float incl = wave_scan<OP_SUM>(local);  // inclusive over the wavefront
+            const unsigned lane = tid & 63u, wave = wave_index();
+            if (lane == 63) slots.f[red.phase][0][wave] = incl;
+            __syncthreads();  // (also: every chunk is in registers)
+            float base = incl - local;
+            for (unsigned w = 0; w < wave; ++w) base += slots.f[red.phase][0][w];
+            red.phase ^= 1;
+            if (tid == 0) E[0] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const uint32_t i = lo + (uint32_t)q;
+                if ((uint32_t)q < chunk && i < hi) {
+                    base = sq[q] + base;
+                    E[1 + i] = base;
+                }
+            }
+        };
+        if (chunk <= 20) scan(std::integral_constant<int, 20>{});
+        else scan(std::integral_constant<int, 32>{});
+    }
+    __syncthreads();
+    const float total_energy = E[n];
+    // the denominators of this thread's own lags tau = 2 (j + T t) + h <= max_lag <= M: t <= M / (2 T) = 8
+    constexpr int TD = 9;
+    float den[TD][2];
+#pragma unroll
+    for (int t = 0; t < TD; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t tau = 2u * (uint32_t)(j + T * t) + (uint32_t)h;
+            den[t][h] = tau <= max_lag ? E[n - tau] + (total_energy - E[tau]) : 0.0f;
+        }
+    if (total_energy <= F32_EPS) {  // (:168)
+        if (tid == 0) *out = ScopeEstimate{0, 0.0f, 0.0f, last_peak};
+        return;
+    }
+    __syncthreads();  // E is dead: the transform buffer takes its place
+    // autocorrelation of the zero-padded real probe through two M-point transforms (derivation: scope_estimate2_kernel)
+    fftp_inplace<false, LOGM>(v, fft, j, tw);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) fft[pad16(j + T * t)] = v[t];
+    __syncthreads();
+    v2f y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t k = (uint32_t)(j + T * t);
+        const v2f z = v[t];
+        const v2f zr = fft[pad16((int)(((uint32_t)M - k) & ((uint32_t)M - 1u)))];
+        const v2f zc{zr.x, -zr.y};                       // conj Zr
+        const v2f e = (z + zc) * 0.5f;                    // (Z + conj Zr) / 2
+        const v2f d = (z - zc) * 0.5f;                    // (Z - conj Zr) / 2
+        const v2f o{d.y, -d.x};                           // ... / i
+        const v2f w = a.tw_fft[k];                        // exp(-2 pi i k / 2M)
+        const v2f wo = cmul(o, w);                        // w^k O
+        const v2f xp = e + wo, xm = e - wo;               // X[k], X[k + M]
+        const v2f sqp = xp * xp, sqm = xm * xm;
+        const float p0 = sqp.x + sqp.y, p1 = sqm.x + sqm.y;  // P[k], P[k + M]
+        const float sum = p0 + p1, dif = p0 - p1;
+        y[t] = v2f{sum + dif * w.y, dif * w.x};
+    }
+    __syncthreads();
+    fftp_inplace<true, LOGM>(y, fft, j, tw);  // y[t] = (acf[2m], acf[2m + 1]), m = j + T t
+    __syncthreads();  // the last pass still reads the buffer: the NSDF takes it over
+    float* nsdf_w = reinterpret_cast<float*>(smem_raw);
+    const float norm = 1.0f / (float)(2 * M);
+#pragma unroll
+    for (int t = 0; t < TD; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t tau = 2u * (uint32_t)(j + T * t) + (uint32_t)h;
+            if (tau > max_lag) continue;
+            const float acf = h ? y[t].y : y[t].x;
+            nsdf_w[tau] = den[t][h] > F32_EPS ? 2.0f * acf * norm / den[t][h] : 0.0f;
+        }
+    __syncthreads();
+    const float* nsdf = nsdf_w;
+    // first tau >= 1 with nsdf <= 0 (:110)
+    uint32_t zc = 0xFFFFFFFFu;
+    for (uint32_t tau = 1 + tid; tau <= max_period; tau += T)
+        if (nsdf[tau] <= 0.0f) {
+            zc = tau;
+            break;
+        }
+    zc = red.template run_u32<false>(zc);
+    ScopeEstimate res{0, 0.0f, 0.0f, last_peak};
+    const uint32_t first_tau = max(min_period, zc);
+    if (zc != 0xFFFFFFFFu && first_tau < max_period) {
+        auto is_candidate = [&](uint32_t tau) {
+            return nsdf[tau] >= MIN_PERIODICITY && nsdf[tau] >= nsdf[tau - 1] && nsdf[tau] >= nsdf[tau + 1];
+        };
+        uint32_t bestk = 0u, besttau = 0u;
+        for (uint32_t tau = first_tau + tid; tau < max_period; tau += T)
+            if (is_candidate(tau)) {
+                const uint32_t k = total_order_key(nsdf[tau]);
+                if (k >= bestk) {
+                    bestk = k;
+                    besttau = tau;
+                }
+            }
+        const uint32_t kmax = red.template run_u32<true>(bestk);
+        const uint32_t best = red.template run_u32<true>(bestk == kmax && kmax != 0u ? besttau : 0u);
+        if (kmax != 0u) {
+            const float cutoff = nsdf[best] * PEAK_CUTOFF;
+            uint32_t peak = 0xFFFFFFFFu;
+            for (uint32_t tau = first_tau + tid; tau <= best; tau += T)
+                if (is_candidate(tau) && nsdf[tau] >= cutoff) {
+                    peak = tau;
+                    break;
+                }
+            peak = red.template run_u32<false>(peak);
+            if (peak == 0xFFFFFFFFu) peak = best;
+            res.some = 1;
+            res.period = parabolic_refine(nsdf[peak - 1], nsdf[peak], nsdf[peak + 1], peak);
+            res.confidence = rclamp(nsdf[peak], 0.0f, 1.0f);
+        }
+    }
+    if (tid == 0) *out = res;
+}
+
 // ring re-homing on growth: the newest `history` samples of every trace keep their absolute positions, only the modulus changes
 __global__ __launch_bounds__(256) void scope_rehome_kernel(const float* from, uint64_t from_cap, float* to, uint64_t to_cap,
                                                            const uint64_t* pos_v, ScopeArgs a) {
@@ -1466,6 +1704,31 @@ void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(scope_trigger_kernel<1024>, dim3(a.n_streams), dim3(1024), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
     else
         hipLaunchKernelGGL(scope_trigger_kernel<512>, dim3(a.n_streams), dim3(512), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
+}
+
+
+// fft_size 16384 / 32768 (88.2 ... 192 kHz): every block pushed first, the period estimates of all (stream, block, view) by
+// scope_estimate_big_kernel, then the one-workgroup-per-stream kernel of round 1 (oscilloscope_kernels.hip) with pre_pushed = 1: it
+// takes its estimates from a.estimates and runs only the stateful part
+void launch_oscilloscope_big(const ScopeArgs& a, hipStream_t stream) {
+    if (a.n_streams == 0 || a.n_blocks == 0) return;
+    hipLaunchKernelGGL(scope_push2_kernel, dim3((uint32_t)((a.frames_total + 255) / 256), a.n_streams), dim3(256), 0, stream, a);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_estimate_big_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(FftGeom<13>::LDS * sizeof(v2f)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_estimate_big_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(FftGeom<14>::LDS * sizeof(v2f)));
+    });
+    if (a.trigger_mode != OMX_TRIGGER_ZERO_CROSSING && a.est_view_count) {
+        if (a.fft_size == 16384)
+            hipLaunchKernelGGL(scope_estimate_big_kernel<13>, dim3(a.n_streams, a.n_blocks, a.est_view_count), dim3(FftGeom<13>::T),
+                               FftGeom<13>::LDS * sizeof(v2f), stream, a);
+        else
+            hipLaunchKernelGGL(scope_estimate_big_kernel<14>, dim3(a.n_streams, a.n_blocks, a.est_view_count), dim3(FftGeom<14>::T),
+                               FftGeom<14>::LDS * sizeof(v2f), stream, a);
+    }
+    launch_oscilloscope(a, stream);
 }
 
 }  // namespace omx
