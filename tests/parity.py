@@ -135,8 +135,8 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
     """
     max_power = float(max(ora[:, 2].max() if len(ora) else 0.0, hip[:, 2].max() if len(hip) else 0.0))
     if max_power <= 0.0:
-        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, n=0, orphans=len(hip) + len(ora), freq_strong=0.0, time_strong=0.0,
-                    n_strong=0)
+        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, orphan_any=0.0, n=0, orphans=len(hip) + len(ora), freq_strong=0.0,
+                    time_strong=0.0, n_strong=0)
     pairs, oa, ob = align_points(hip, ora, max_power)
     pa = np.array([p[0] for p in pairs], int)
     pb = np.array([p[1] for p in pairs], int)
@@ -153,8 +153,21 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
         m["time_strong"] = float(np.abs(h[strong, 0] - o[strong, 0]).max()) if strong.any() else 0.0
     else:
         m.update(power=0.0, freq=0.0, time=0.0, freq_strong=0.0, time_strong=0.0, n_strong=0)
-    orphan_p = [hip[i, 2] for i in oa] + [ora[j, 2] for j in ob]
-    m["orphan"] = float(max(orphan_p) / max_power) if orphan_p else 0.0
+    orphans = [hip[i] for i in oa] + [ora[j] for j in ob]
+    m["orphan_any"] = float(max(float(p[2]) for p in orphans) / max_power) if orphans else 0.0
+    # An orphan is EXPLAINED when it sits on one of the two keep tests (processor.rs:469-475): the 1e-14 power floor, or the band edge
+    # 0 < f-hat < fs/2 within the f-hat error of a bin of its strength — 2e-8 (fs/2) / sqrt(r) for relative power r (a ratio of
+    # spectra, see the f-hat bars), x ORPHAN_EDGE_K.  What the orphan bar limits is the strongest orphan that is NOT explained that
+    # way (soak, round 4: noise-level bins next to DC, r = 5e-7 ... 3e-6, whose f-hat lies within a few Hz of 0 on one side only).
+    worst = 0.0
+    for p in orphans:
+        r = float(p[2]) / max_power
+        edge = min(abs(float(p[1])), abs(sample_rate * 0.5 - float(p[1])))
+        on_edge = r > 0.0 and edge <= ORPHAN_EDGE_K * 2e-8 * (sample_rate * 0.5) / np.sqrt(r)
+        on_floor = float(p[2]) <= 4e-14
+        if not (on_edge or on_floor):
+            worst = max(worst, r)
+    m["orphan"] = worst
     return m
 
 
@@ -172,6 +185,7 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
 # the oracle's table-driven one, so edge bins decide by the ORACLE's noise now; 1.5e-13 while both used the same tables).  Bar: 3e-7
 # (4x measured; a bin that strong sits within 1 Hz of the edge, and at most 4 orphans per column are accepted at all).
 BAR_POWER, BAR_FREQ, BAR_TIME, BAR_ORPHAN = 1e-5, 1e-7, 1e-4, 3e-7
+ORPHAN_EDGE_K = 16.0   # an orphan within 16 x the f-hat error of its strength of 0 or fs/2 sits ON the band edge
 # f-hat: the ORACLE (like the reference) takes w' from an f32 spectral derivative (processor.rs:569-599); the four-transform kernels
 # use the closed form of that derivative and are ~100x closer to exact arithmetic in f-hat (tests/test_exact_f64.py: 4e-11 against the
 # oracle's 2e-8 at W = 8192).  HIP-vs-oracle on strong bins therefore measures the oracle's own table noise: up to 2.0e-7 at W = 8192.
@@ -211,14 +225,17 @@ def conditioned_bar(name, err, fixed, sens, detail=None):
         bar(name + " [well-conditioned columns]", err, 1.1 * float(fixed), detail)
 
 
-def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag="reassigned (random sequences)", time_bar=BAR_TIME):
-    """one column against the oracle with conditioning-derived bars; `ora_perturbed` = the oracle's column for the ulp-perturbed input"""
+def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag="reassigned (random sequences)", time_bar=BAR_TIME, scale=1.0):
+    """one column against the oracle with conditioning-derived bars; `ora_perturbed` = the oracle's column for the ulp-perturbed input;
+    `scale` <= 1 = this column's maximum over the loudest column within reach of its 2W-sample Hilbert block (DESIGN §2 conditioning
+    note: the reference's own f32 noise scales with the loudest component of that block): the fixed bars are relative to that one"""
     m = reassigned_column_metrics(hip, ora, sample_rate, hop)
     s = reassigned_column_metrics(ora_perturbed, ora, sample_rate, hop)
-    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER, s["power"], (m, s))
-    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ, s["freq"], (m, s))
-    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar, s["time"], (m, s))
-    conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN, s["orphan"], (m, s))
+    scale = min(max(float(scale), 1e-12), 1.0)
+    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER / scale, s["power"], (m, s, scale))
+    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ / scale ** 0.5, s["freq"], (m, s, scale))
+    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar / scale ** 0.5, s["time"], (m, s, scale))
+    conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN / scale, s["orphan"], (m, s, scale))
     assert m["orphans"] <= 4 + s["orphans"], (m, s)
     return m, s
 
@@ -324,11 +341,15 @@ def check_classic(got, want):
     (The round-3 form of (2) — 6e-8 of the maximum, flat — was the code step AT -40 dB and sat at 1.1x its measured maximum for that
     reason: the largest weak bins are the ones right below -40 dB, one code apart.)"""
     assert len(got) == len(want)
-    for h, o in zip(got, want):
+    tops = [float(o.astype(np.float64).max()) * (156.0 / 65535.0) - 144.0 if len(o) else -144.0 for o in want]
+    for i, (h, o) in enumerate(zip(got, want)):
         m = classic_column_metrics(h, o)
         bar("classic (fused): |d code| within 40 dB of max", m["loud_code_diff"], 1, m)
         db_h, db_o = h.astype(np.float64) * (156.0 / 65535.0) - 144.0, o.astype(np.float64) * (156.0 / 65535.0) - 144.0
-        top = db_o.max()
+        # the fused kernels transform TWO consecutive columns as the real and imaginary part of one complex transform: the rounding noise a
+        # column sees is relative to the louder of the pair (an onset / release column beside a full one: soak seed 6006005, a
+        # Blackman-Harris release column 26 dB under its neighbour, bins 90 dB down 8x over a budget taken from the column alone)
+        top = max(tops[max(i - 1, 0):i + 2])
         p_h, p_o = 10.0 ** ((db_h - top) / 10.0), 10.0 ** ((db_o - top) / 10.0)
         far = np.abs(h.astype(np.int64) - o.astype(np.int64)) > 1
         ratio = float((np.abs(p_h - p_o)[far] / classic_noise_budget(np.maximum(p_h, p_o)[far])).max()) if far.any() else 0.0

@@ -141,22 +141,36 @@ def test_silent_and_mixed_streams_in_one_bank(omx):
     assert len(bank.fetch_column(2, 1, capi.COLUMN_REASSIGNED, 2049)) == 0  # front moved past the last non-zero
 
 
-def check_trace(x, y, floor=-100.0):
+def check_trace(x, y, floor=-100.0, flush_ties=0):
     """dB traces.  The bound that always holds is the linear-power one (relative to the trace maximum, but not below -60 dB:
     a trace of near-silence is all f32 FFT noise).  dB differences are only meaningful away from (a) the f32 noise floor
     60 / 80 dB under the maximum and (b) the display / state floor, where `update_outputs` flushes a smoothed state to zero
-    (spectrum/processor.rs:366-389) — a discontinuity of a few dB that a last-bit difference can trip on either side."""
+    (spectrum/processor.rs:366-389) — a discontinuity of a few dB that a last-bit difference can trip on either side.
+    `flush_ties` (averaging modes only): that flush acts on the STATE, so a bin whose power sat within rounding of the state floor one
+    hop ago re-seeds on one side and keeps averaging on the other, and shows dBs of difference at whatever level it has now (soak
+    seed 972183085: p = 7.46e-11 against a state floor of 7.46e-11, bin at -75 dB one hop later).  Up to `flush_ties` bins per trace
+    may therefore leave the dB bars — the linear-power bar still binds them — and the ledger counts how many did."""
     x, y = x.astype(np.float64), y.astype(np.float64)
     px, py = 10.0 ** (x / 10.0), 10.0 ** (y / 10.0)
     ref = max(py.max(), 1e-6)
     bar("spectrum: |d 10^(dB/10)| / max", np.abs(px - py).max() / ref, 1e-5)
     clear = (y > floor + 12.0) & (x > floor + 12.0)   # a flushed state re-seeds (:366-369): its bin needs a few hops to re-converge
+    d = np.abs(x - y)
+    near = clear & (y > y.max() - 80.0)
+    ties = 0
+    if flush_ties and near.any():
+        over = np.flatnonzero(near & (d > 0.01))
+        if 0 < len(over) <= flush_ties:
+            ties = len(over)
+            clear = clear.copy()
+            clear[over] = False
+            near = clear & (y > y.max() - 80.0)
+        bar("spectrum (averaging modes): bins beyond the dB bars through a state-flush tie, per trace", ties, flush_ties)
     loud = clear & (y > y.max() - 60.0)
     if loud.any():
-        bar("spectrum: |d dB| within 60 dB of max", np.abs(x[loud] - y[loud]).max(), 0.01)   # measured 2.1e-3 (profiles/parity_r*.txt)
-    near = clear & (y > y.max() - 80.0)
+        bar("spectrum: |d dB| within 60 dB of max", d[loud].max(), 0.01)   # measured 2.1e-3 (profiles/parity_r*.txt)
     if near.any():
-        assert np.abs(x - y)[near].max() <= 0.1
+        assert d[near].max() <= 0.1
 
 
 @pytest.mark.parametrize("mode,param", [(capi.AVG_NONE, 0.0), (capi.AVG_EXPONENTIAL, 0.5), (capi.AVG_PEAK_HOLD, 12.0)])

@@ -37,6 +37,7 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
     c = SpectrogramProcessor(oracle, cfg)
     prng = np.random.default_rng(seed + 7919)
     rate, channels, t0, produced = 48000.0, 2, 0, 0
+    recent = []   # column maxima of the last few columns (earlier updates included)
     for step in range(45):
         op = rng.random()
         if op < 0.08:
@@ -76,11 +77,24 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
         if w.new_columns[0].ndim == 2:   # reassigned
             assert g.reassigned_power_scale == w.reassigned_power_scale
             assert len(w2.new_columns) == len(w.new_columns)
-            for h, o, o2 in zip(g.new_columns, w.new_columns, w2.new_columns):
+            # f32 conditioning of the reference algorithm itself: the analytic signal is computed over the 2W-sample block
+            # around a column's window (W/2 samples before it, W/2 after), so its rounding noise — and the absolute noise of the
+            # oracle's f32 derivative-window table — scale with the strongest component in that BLOCK; a column whose own window
+            # sits on near-silence beside a loud passage (an onset or a release) carries them at a level unrelated to its own
+            # maximum.  The fixed part of every bar is therefore relative to the loudest column within the block's reach on EITHER
+            # side (amplitude-like quantities by the square root); tools/onset_exact.py measures HIP closer to exact f64 than the
+            # oracle on such columns (f-hat 4.4e-7 against 8.7e-7 for a Blackman-Harris onset).
+            maxima = [float(o[:, 2].max()) if len(o) else 0.0 for o in w.new_columns]
+            reach = 2 * w.fft_size // max(w.hop_size, 1) + 2
+            for i, (h, o, o2) in enumerate(zip(g.new_columns, w.new_columns, w2.new_columns)):
+                col_max = maxima[i]
+                if col_max > 0.0:
+                    recent.append(col_max)
+                    del recent[:-reach]
                 if len(o) == 0 or len(h) == 0:
                     assert len(o) < 8 and len(h) < 8   # silent / floor-level column on both sides
                     continue
-                if o[:, 2].max() < 1e-10:   # strongest bin within 40 dB of the 1e-14 floor: which floor-level bins survive
+                if col_max < 1e-10:   # strongest bin within 40 dB of the 1e-14 floor: which floor-level bins survive
                     assert abs(len(o) - len(h)) <= max(4, len(o) // 4)   # is rounding noise on both sides
                     continue
                 # random shapes include ill-conditioned ones (rectangular window: w' = 0 and a time-weighted spectrum made of
@@ -91,10 +105,11 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
                 t_bar = (1e-3 if cfg.window == capi.WINDOW_RECTANGULAR else 3e-4) * span
                 m = reassigned_column_metrics(h, o, rate, w.hop_size)
                 sn = reassigned_column_metrics(o2 if len(o2) else o, o, rate, w.hop_size)
+                scale = min(1.0, col_max / max(max(recent), max(maxima[i:i + reach + 1])))   # <= 1: this column against its block's loudest
                 tag = "spectrogram sequences"
-                conditioned_bar(f"{tag}: |dP| / max P", m["power"], 1e-5, sn["power"], (seed, step, m, sn))
-                conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], 3e-7, sn["freq"], (seed, step, m, sn))
-                conditioned_bar(f"{tag}: r |dt| hops", m["time"], t_bar, sn["time"], (seed, step, m, sn))
+                conditioned_bar(f"{tag}: |dP| / max P", m["power"], 1e-5 / scale, sn["power"], (seed, step, m, sn, scale))
+                conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], 3e-7 / scale ** 0.5, sn["freq"], (seed, step, m, sn, scale))
+                conditioned_bar(f"{tag}: r |dt| hops", m["time"], t_bar / scale ** 0.5, sn["time"], (seed, step, m, sn, scale))
                 # a bin present on one side only must sit on the 1e-14 keep-floor (relative to a weak column that is > 1e-8)
                 # ... or on the 0 < f < fs/2 edge of the keep test (a bin whose reassigned frequency sits at 0 or Nyquist)
                 # ... or be no stronger than what the oracle itself gains / loses under the one-ulp perturbation
@@ -148,7 +163,7 @@ def test_meter_processors_random_block_sequences(omx, oracle, seed):
             for tr in range(2):
                 for k in range(2):
                     if len(sw.traces[tr][k]):
-                        check_trace(sg.traces[tr][k], sw.traces[tr][k])
+                        check_trace(sg.traces[tr][k], sw.traces[tr][k], flush_ties=0 if sc.averaging_mode == capi.AVG_NONE else 2)
         if lw is not None:
             assert lg.channel_count == lw.channel_count and lg.positions == lw.positions
             assert abs(lg.momentary_loudness - lw.momentary_loudness) <= 1e-4 and abs(lg.short_term_loudness - lw.short_term_loudness) <= 1e-4
@@ -303,6 +318,7 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
     prng = np.random.default_rng(seed + 7919)
     feeds2 = [ulp_perturbed(f, prng) for f in feeds]
     refs2 = [SpectrogramProcessor(oracle, cfg) for _ in range(S)] if reassign else None
+    recent = [[] for _ in range(S)]   # per stream: column maxima within reach of a column's Hilbert block (earlier calls included)
     at = [0] * S
     pos = capi.positions_fallback(2)
     # two lock-step calls first: the switch to per-stream positions must carry the common state over
@@ -344,9 +360,15 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
             kind = capi.COLUMN_REASSIGNED if reassign else capi.COLUMN_CLASSIC
             got = [bank.fetch_column(s, c, kind, up.column_stride) for c in range(want_cols)]
             if reassign:
-                for h, o, o2 in zip(got, w.new_columns, w2.new_columns):
-                    if len(o) and o[:, 2].max() > 1e-8:   # (round 3: every bar x 30 flat; now each column's own measured conditioning)
-                        check_reassigned_conditioned(h, o, o2 if len(o2) else o, 48000.0, hop, tag="ragged bank sequences")
+                maxima = [float(o[:, 2].max()) if len(o) else 0.0 for o in w.new_columns]
+                reach = 2 * W // hop + 2
+                for i, (h, o, o2) in enumerate(zip(got, w.new_columns, w2.new_columns)):
+                    if maxima[i] > 0.0:
+                        recent[s].append(maxima[i])
+                        del recent[s][:-reach]
+                    if len(o) and maxima[i] > 1e-8:   # (round 3: every bar x 30 flat; now each column's measured conditioning + its block's loudest)
+                        scale = maxima[i] / max(max(recent[s]), max(maxima[i:i + reach + 1]))
+                        check_reassigned_conditioned(h, o, o2 if len(o2) else o, 48000.0, hop, tag="ragged bank sequences", scale=scale)
             elif up.fft_size in (1024, 2048, 4096, 8192, 16384):
                 check_classic(got, w.new_columns)
             produced += want_cols
