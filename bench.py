@@ -467,6 +467,7 @@ def main():
                 sec.update(bench_meters.reference_defaults(out=sys.stderr))   # the reference's default shapes (2048 / 64, 16384 / 1024)
                 if config == "cfg2":
                     sec["cfg5_shard"] = bench_pipeline.shard_pipeline(out=sys.stderr)
+                sec["waveform_1024"] = bench_meters.waveform(sizes=(1024,), out=sys.stderr)   # §8f rank 3, with its roofline objects
                 import bench_stream
                 sec["streaming_256"] = bench_stream.streaming(out=sys.stderr)   # the reference's own cadence: one batcher block per call
                 result["secondary"] = sec

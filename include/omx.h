@@ -587,7 +587,7 @@ int omx_oscilloscope_last_capture(const omx_oscilloscope* h, uint32_t* start, fl
  * Waveform — reference src/visuals/waveform/processor.rs
  * ===================================================================== */
 
-/* reference :31-40 WaveformConfig */
+/* reference :32-40 WaveformConfig */
 typedef struct omx_waveform_config {
     float sample_rate;
     float scroll_speed;
@@ -604,7 +604,7 @@ typedef struct omx_wave_column {
     float rms_db[2][3];
 } omx_wave_column;
 
-/* reference :66-76 WaveformUpdate: `columns` = n_columns frames of 4 WaveColumns (Left, Right, Mid, Side) */
+/* reference :65-76 WaveformPreview / WaveformUpdate: `columns` = n_columns frames of 4 WaveColumns (Left, Right, Mid, Side) */
 typedef struct omx_waveform_update {
     uint64_t n_columns;
     const omx_wave_column* columns; /* [n_columns][4] */
@@ -617,13 +617,13 @@ typedef struct omx_waveform_update {
 
 typedef struct omx_waveform omx_waveform;
 void omx_waveform_config_default(omx_waveform_config* out);
-int omx_waveform_create(const omx_waveform_config* cfg, omx_waveform** out);            /* ::new :147-159 */
+int omx_waveform_create(const omx_waveform_config* cfg, omx_waveform** out);            /* ::new :135-147 */
 void omx_waveform_destroy(omx_waveform* h);
-int omx_waveform_get_config(const omx_waveform* h, omx_waveform_config* out);           /* ::config :161-163 */
+int omx_waveform_get_config(const omx_waveform* h, omx_waveform_config* out);           /* ::config :149-151 */
 int omx_waveform_update_config(omx_waveform* h, const omx_waveform_config* cfg);        /* :336-352 */
-int omx_waveform_reset_audio(omx_waveform* h);                                          /* :165-167 */
-int omx_waveform_prepare(omx_waveform* h);                                              /* :169-173 */
-int omx_waveform_process_block(omx_waveform* h, const omx_block* block, omx_waveform_update* out); /* :308-334 */
+int omx_waveform_reset_audio(omx_waveform* h);                                          /* :153-155 */
+int omx_waveform_prepare(omx_waveform* h);                                              /* :157-161 */
+int omx_waveform_process_block(omx_waveform* h, const omx_block* block, omx_waveform_update* out); /* :306-334 */
 
 typedef struct omx_waveform_bank omx_waveform_bank;
 /* One block per call for every stream.  d_columns: omx_wave_column [n_streams][n_columns][4] (already capped to the

@@ -22,7 +22,7 @@ stream = torch.cuda.current_stream().cuda_stream
 HBM_PEAK_GBS = 8000.0
 
 
-def meter_traffic(kernel_substrings):
+def meter_traffic(kernel_substrings, match_all=False):
     """Measured HBM bytes per call of the kernels whose names contain one of `kernel_substrings`, from the newest
     profiles/*_meters_traffic.json (written by tools/profile_meters_pmc.sh: FETCH_SIZE / WRITE_SIZE passes, (2 F + W) * 1024 per
     MI355X_MICROARCH.md); None when there is no such record.  An echo tagged with its source, never a measurement of this run."""
@@ -35,7 +35,7 @@ def meter_traffic(kernel_substrings):
             continue
         total, used = 0.0, []
         for name, v in rec.get("kernels", {}).items():
-            if any(k in name for k in kernel_substrings):
+            if (all if match_all else any)(k in name for k in kernel_substrings):
                 total += v["hbm_bytes_per_launch"] * v.get("launches_per_call", 1)
                 used.append(name)
         if used:
@@ -43,11 +43,11 @@ def meter_traffic(kernel_substrings):
     return None
 
 
-def roofline(alg_bytes, ms, kernels):
+def roofline(alg_bytes, ms, kernels, match_all=False):
     """SURVEY §8(d) bytes of one call against the HBM peak; `traffic` = the counters' bytes for the same kernels (see meter_traffic)"""
     return {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": alg_bytes, "ms_per_call": ms,
-            "traffic": meter_traffic(kernels)}
+            "traffic": meter_traffic(kernels, match_all)}
 
 
 def timed(fn, reps):
@@ -165,11 +165,12 @@ def reference_defaults(S=64, out=sys.stdout):
     return res
 
 
-def waveform(blocks=64, reps=5, out=sys.stdout):
-    """the waveform bank (band analysis on; with and without RMS history), 256-frame blocks x `blocks` per call."""
+def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096)):
+    """the waveform bank (band analysis on; with and without RMS history), 256-frame blocks x `blocks` per call.
+    `sizes` = the bank sizes run (tools/profile_meters_pmc.sh profiles ONE size per pass so that its traffic record is per launch)."""
     frames = 256 * blocks
     res = {}
-    for S in (64, 1024, 4096):
+    for S in sizes:
         g = torch.Generator(device=dev).manual_seed(S)
         pcm = (torch.rand((S, frames, 2), device=dev, generator=g) - 0.5).contiguous()
         pos = capi.positions_fallback(2)
@@ -180,18 +181,22 @@ def waveform(blocks=64, reps=5, out=sys.stdout):
             dt = timed(run, reps)
             print(f"waveform: {S} streams, history={int(history)}, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
                   f"{frames/dt/FS:.0f}x real time per stream", file=out)
-            res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3}
+            # §8(d)-style algorithmic bytes: C * 4 B of PCM in per frame + 4 columns x 44 B out per emitted column (scroll 300 / s: one per 160 frames)
+            alg = S * frames * 2 * 4.0 + S * (frames / 160.0) * 4 * 44.0
+            res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3,
+                                                           "roofline": roofline(alg, dt * 1e3, [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", f"@{S}"], match_all=True)}
             bank.close()
     return res
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "waveform":
-        waveform()
+        waveform(sizes=tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (64, 1024, 4096))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "scope":  # cfg4's two banks only (tools/profile_scope_sq.sh)
         scope_stereo()
         sys.exit(0)
     loudness()
     scope_stereo()
-    waveform()
+    if not (len(sys.argv) > 1 and sys.argv[1] == "nowave"):
+        waveform()

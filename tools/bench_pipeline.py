@@ -48,6 +48,14 @@ def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
               f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
               f"rho mean {float(table[:, 3].mean()):.3f}", file=out)
         res[mode] = {"ms_per_step": ms, "stft_frames_per_s": S * (frames // 256) / (ms * 1e-3), "x_real_time": frames / 48000.0 / (ms * 1e-3)}
+        if mode == "group":
+            # the step's algorithmic bytes: K2 26 640 B per STFT frame (PCM hop in, 2049 points out) + the loudness form's
+            # 8 B per channel-sample + the stereometer's 16 B per stereo frame (the PCM itself is counted once, with K2)
+            cols = S * (frames // 256)
+            alg = cols * 26640.0 + S * frames * 2 * 8.0 + S * frames * 16.0 - 2 * S * frames * 2 * 4.0
+            res[mode]["roofline"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                     "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_step": alg, "ms_per_step": ms,
+                                     "traffic": None}
         del pipe
     return res
 

@@ -2,6 +2,10 @@
 TAG=${1:-r13}; PTAG=${2:-r03}
 export OMX_PROFILE_COMMIT=${3:-unknown}
 bash tools/profile_bench.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+# the traffic records first, copied to profiles/ on this box, so that the bench lines below echo records of THIS commit
+cp gpurun_out/$TAG/traffic.json profiles/${TAG}_traffic.json
+bash tools/profile_meters_pmc.sh ${TAG}_meters > gpurun_out/${TAG}_meters_pmc.txt 2>&1
+cp gpurun_out/${TAG}_meters/meters_traffic.json profiles/${TAG}_meters_traffic.json
 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.log
 python bench.py --config cfg5 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench_line_cfg5.json 2> gpurun_out/${TAG}_bench_line_cfg5.log
 {
@@ -12,9 +16,17 @@ echo "== tools/bench_meters.py =="; python tools/bench_meters.py 2>&1 | grep -v 
 echo "== tools/bench_meters.py waveform, OMX_WAVEFORM_SINGLE=1 (the one-wavefront kernel) =="; OMX_WAVEFORM_SINGLE=1 python tools/bench_meters.py waveform 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_pipeline.py (capture group against separate bank calls) =="; python tools/bench_pipeline.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/latency_c.sh (single-stream handles, host in / host out, 256-frame blocks) =="; bash tools/latency_c.sh 2>&1 | tail -7
+echo "== tools/bench_windows.py (4096 / 256 per window kind; form 1 = the round-1 five-transform kernel) =="; python tools/bench_windows.py 2>&1 | grep 4096
+echo "== tools/bench_scope_rates.py =="; python tools/bench_scope_rates.py 2>&1 | grep oscillo
+echo "== tools/bench_stream.py --each (the reference's cadence: one batcher block per call) =="; python tools/bench_stream.py --each 2>&1 | grep captures
+echo "== tools/bench_stream.py --frames 1024 =="; python tools/bench_stream.py --frames 1024 --calls 100 2>&1 | grep captures
 echo "== tools/determinism_stress.py 16 300 =="; python tools/determinism_stress.py 16 300 2>&1 | tail -1
 } > gpurun_out/${TAG}_other_shapes.txt 2>&1
 { echo "# tools/bench_ragged.py: the ragged entry points against the lock-step ones at equal work (every stream gets the same count)"; python tools/bench_ragged.py 2>&1 | grep -v amdgpu.ids; } > gpurun_out/${TAG}_ragged.txt
 python tools/parity_report.py $PTAG > gpurun_out/${TAG}_parity.log 2>&1
 cp profiles/parity_${PTAG}.txt gpurun_out/parity_${PTAG}.txt; tail -3 gpurun_out/${TAG}_parity.log
 head -c 600 gpurun_out/${TAG}_bench_line.json
+
+# kernel trace of the streaming cadence (1024 captures x one 256-frame block per call, six visuals)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stream -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_stream.py --calls 200 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stream.log 2>&1 )
+cp gpurun_out/${TAG}_stream/t_kernel_stats.csv gpurun_out/${TAG}_stream_kernel_stats.csv 2>/dev/null
