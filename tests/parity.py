@@ -215,13 +215,13 @@ def ulp_perturbed(pcm, rng):
     return y
 
 
-def conditioned_bar(name, err, fixed, sens, detail=None):
+def conditioned_bar(name, err, fixed, sens, detail=None, plain=True):
     """bar(err / (fixed + K sens), 1): the fixed bar on well-conditioned columns, measured conditioning on top elsewhere.  Columns whose
     conditioning term is below a tenth of the fixed bar are also entered under the plain fixed bar (ledger: what the bar measures
-    when conditioning plays no part)."""
+    when conditioning plays no part; `plain` False = `fixed` is already scaled by a louder neighbour, not a plain bar)."""
     limit = float(fixed) + CONDITIONING_K * float(sens)
     bar(name + " / (bar + 16 x oracle's 1-ulp sensitivity)", float(err) / limit, 1.0, (err, fixed, sens, detail))
-    if CONDITIONING_K * float(sens) <= 0.1 * float(fixed):
+    if plain and CONDITIONING_K * float(sens) <= 0.1 * float(fixed):
         bar(name + " [well-conditioned columns]", err, 1.1 * float(fixed), detail)
 
 
@@ -232,9 +232,9 @@ def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag=
     m = reassigned_column_metrics(hip, ora, sample_rate, hop)
     s = reassigned_column_metrics(ora_perturbed, ora, sample_rate, hop)
     scale = min(max(float(scale), 1e-12), 1.0)
-    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER / scale, s["power"], (m, s, scale))
-    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ / scale ** 0.5, s["freq"], (m, s, scale))
-    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar / scale ** 0.5, s["time"], (m, s, scale))
+    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER / scale, s["power"], (m, s, scale), plain=scale >= 0.999)
+    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ / scale ** 0.5, s["freq"], (m, s, scale), plain=scale >= 0.999)
+    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar / scale ** 0.5, s["time"], (m, s, scale), plain=scale >= 0.999)
     conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN / scale, s["orphan"], (m, s, scale))
     assert m["orphans"] <= 4 + s["orphans"], (m, s)
     return m, s
