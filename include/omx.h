@@ -664,6 +664,19 @@ typedef struct omx_waveform_ragged_update {
 int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
                                      const uint8_t* reset_mask, uint32_t channels, float sample_rate,
                                      const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_waveform_ragged_update* out);
+/* WHICH EVALUATION ORDER A LOCK-STEP CALL GETS (OMX_OPT_KERNEL_FORM; default 0 = by call shape):
+ *   1 = the sequential kernels only: the reference's operation order on every value, bit-identical to it
+ *       (`waveform/processor.rs:252-291`);
+ *   2 = the chunk-parallel form (waveform_chunked.hip) whenever the shape allows: 2 channels, device PCM, band analysis on, an even
+ *       frame count >= 1024, at most ~4000 columns in the call.  The band filters restart every 64 ... 256 frames from states
+ *       obtained by a scan (one f32 rounding each; the low band's in f64), the window means are differences of double-double
+ *       running totals: min / max fields bit-identical, colour bands and RMS history within the bars of
+ *       tests/test_gpu_parity_meters.py of the sequential order.  Non-finite or absurdly large (> 1e18) samples send the whole call
+ *       through the sequential kernels.  By shape (0) it serves calls of >= 4 M stream-frames (1024 streams x 4096 frames).
+ * Ragged calls and single-stream handles always run the sequential kernels. */
+int omx_waveform_bank_set_option(omx_waveform_bank* b, uint32_t option, uint64_t value);
+/* test hook: 1 = the bank's last lock-step call ran the sequential kernels alone, 2 = the chunk-parallel form (0 = no call yet) */
+int omx_debug_waveform_bank_last_form(const omx_waveform_bank* b);
 int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns /* [n_columns][4] */,
                             omx_wave_column* preview /* [4] or NULL */);
 

@@ -437,6 +437,14 @@ class WaveformBank(_BlockBank):
                          channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
+    def set_option(self, option: int, value: int):
+        """OMX_OPT_KERNEL_FORM: 0 by call shape, 1 sequential kernels, 2 chunk-parallel form where it applies"""
+        self.api.check(self.api.fn("waveform_bank_set_option", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64])(self._h, option, value))
+
+    def last_form(self) -> int:
+        """1 = the last lock-step call ran the sequential kernels alone, 2 = the chunk-parallel form (omx_debug_waveform_bank_last_form)."""
+        return self.api.fn("debug_waveform_bank_last_form", C.c_int, [C.c_void_p])(self._h)
+
     def fetch(self, stream_index, n_columns, with_preview=False):
         cols = np.zeros((max(n_columns, 1), 4, 11), np.float32)
         prev = np.zeros((4, 11), np.float32) if with_preview else None

@@ -814,6 +814,11 @@ int omx_waveform_bank_process(omx_waveform_bank* b, const float* pcm, int pcm_on
         return b->impl.process(pcm, pcm_on_device != 0, frames, channels, sample_rate, positions, static_cast<hipStream_t>(stream), out);
     });
 }
+int omx_waveform_bank_set_option(omx_waveform_bank* b, uint32_t option, uint64_t value) {
+    if (!b || option != OMX_OPT_KERNEL_FORM || value > 2) return OMX_ERR_INVALID;
+    b->impl.set_form((uint32_t)value);
+    return OMX_NONE;
+}
 int omx_waveform_bank_fetch(omx_waveform_bank* b, uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview) {
     if (!b) return OMX_ERR_INVALID;
     return guarded([&] { return b->impl.fetch(stream_index, columns, preview, b->impl.last_stream()); });
@@ -884,3 +889,4 @@ int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t
 
 }  // extern "C"
 int omx_debug_stereometer_bank_last_form(const omx_stereometer_bank* b) { return b ? b->impl.last_form() : OMX_ERR_INVALID; }
+int omx_debug_waveform_bank_last_form(const omx_waveform_bank* b) { return b ? (int)b->impl.last_form() : OMX_ERR_INVALID; }

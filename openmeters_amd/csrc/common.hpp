@@ -215,6 +215,30 @@ struct RaggedStaging {
     }
 };
 
+// A small per-call host structure (a plan: cut lists, column tables) on its way to the device, same double-buffering as above
+struct BlobStaging {
+    PinnedBuffer<uint8_t> buf[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int next = 0;
+    BlobStaging() = default;
+    BlobStaging(const BlobStaging&) = delete;
+    BlobStaging& operator=(const BlobStaging&) = delete;
+    ~BlobStaging() {
+        for (auto& e : done)
+            if (e) (void)hipEventDestroy(e);
+    }
+    void upload(const void* src, size_t bytes, void* d_dst, hipStream_t stream) {
+        const int b = next;
+        next ^= 1;
+        if (done[b]) OMX_HIP(hipEventSynchronize(done[b]));
+        else OMX_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        buf[b].reserve(bytes);
+        std::memcpy(buf[b].ptr, src, bytes);
+        OMX_HIP(hipMemcpyAsync(d_dst, buf[b].ptr, bytes, hipMemcpyHostToDevice, stream));
+        OMX_HIP(hipEventRecord(done[b], stream));
+    }
+};
+
 struct EventTimer {  // HIP-event timing of one kernel family on its launch stream
     hipEvent_t start = nullptr, stop = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

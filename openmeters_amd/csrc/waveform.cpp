@@ -1,6 +1,8 @@
 // Host side of the waveform path: reference src/visuals/waveform/processor.rs:31-52 (config normalisation), :147-211
 // (lifecycle), :308-352 (process_block / update_config).  The fractional column phase is advanced on the host with the
 // reference's exact f64 add / compare / subtract sequence so the number of emitted columns is known before launch.
+#include <algorithm>
+
 #include "waveform.hpp"
 
 namespace omx {
@@ -203,11 +205,14 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
     // fractional column phase (:253-254, :287-291), exactly as the reference accumulates it
     double phase = column_phase_;
     uint64_t n_emit = 0;
+    std::vector<uint32_t> column_ends;  // the frames columns end at (the chunk-parallel form's plan)
+    const bool record_ends = frames <= 0x7FFFFFFFull;
     for (uint64_t f = 0; f < frames; ++f) {
         phase += step;
         if (phase >= 1.0) {
             ++n_emit;
             phase -= 1.0;
+            if (record_ends) column_ends.push_back((uint32_t)f);
         }
     }
     const uint64_t kept = std::min<uint64_t>(n_emit, cfg_.max_columns);  // cap_pending_columns (:293-298)
@@ -244,6 +249,10 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
     wa.columns = columns_.ptr;
     wa.preview = preview_.ptr;
     wa.write_preview = progress > 0.0f ? 1 : 0;
+    // chunk-parallel evaluation for bank-sized calls (waveform_chunked.hip); the sequential kernels — bit-identical to the reference's
+    // order — serve everything else and are the fallback when the chunk form meets non-finite input
+    last_form_ = 1;
+    if (record_ends && channels == 2 && run_chunked(wa, column_ends, stream)) last_form_ = 2;
     launch_waveform(wa, stream);
     OMX_HIP(hipGetLastError());
     column_phase_ = phase;
@@ -261,6 +270,195 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
     }
     reset_pending_ = false;
     return OMX_PRODUCED;
+}
+
+// Zero-input transition of the band filters over `frames` frames and its powers 2, 4 ... 32, in f64 from the f32 coefficients: column m
+// of T is the state after `frames` steps of Biquad::process (dsp.rs:422-432) with x = 0 started from the unit state e_m.  State
+// order: low [LP z0, z1]; mid [HP_low z0, z1, LP_high z0, z1]; high [HP_high z0, z1].  Layout [band][power][4][4].
+static std::vector<double> wave_transitions(const BiquadCoef& lp_lo, const BiquadCoef& hp_lo, const BiquadCoef& lp_hi, const BiquadCoef& hp_hi,
+                                            uint32_t frames) {
+    std::vector<double> T(3 * 6 * 16, 0.0);
+    const BiquadCoef* first[3] = {&lp_lo, &hp_lo, &hp_hi};
+    const BiquadCoef* second[3] = {nullptr, &lp_hi, nullptr};
+    for (int band = 0; band < 3; ++band) {
+        const int n = second[band] ? 4 : 2;
+        for (int m = 0; m < n; ++m) {
+            double z[4] = {0, 0, 0, 0};
+            z[m] = 1.0;
+            for (uint32_t f = 0; f < frames; ++f) {
+                double x = 0.0;
+                for (int e = 0; e < n / 2; ++e) {
+                    const BiquadCoef& c = e == 0 ? *first[band] : *second[band];
+                    const double out = (double)c.b[0] * x + z[2 * e];
+                    z[2 * e] = (double)c.b[1] * x - (double)c.a[0] * out + z[2 * e + 1];
+                    z[2 * e + 1] = (double)c.b[2] * x - (double)c.a[1] * out;
+                    x = out;
+                }
+            }
+            for (int k = 0; k < n; ++k) T[(size_t)band * 96 + (size_t)k * 4 + m] = z[k];
+        }
+        for (int p = 1; p < 6; ++p) {  // repeated squaring (the scan's doubling steps)
+            const double* prev = T.data() + (size_t)band * 96 + (size_t)(p - 1) * 16;
+            double* next = T.data() + (size_t)band * 96 + (size_t)p * 16;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    long double acc = 0.0L;
+                    for (int k = 0; k < 4; ++k) acc += (long double)prev[i * 4 + k] * (long double)prev[k * 4 + j];
+                    next[i * 4 + j] = (double)acc;
+                }
+        }
+    }
+    return T;
+}
+
+// The chunk-parallel form of one lock-step call (waveform_chunked.hip): builds the plan — cuts, segments, column table — and enqueues
+// its kernels.  Returns false when the call's shape is not served (the caller then runs the sequential kernel alone); after a true
+// return the caller still launches the sequential kernel, predicated on the `bad` flag (wa.run_if).
+bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream) {
+    const uint64_t frames = wa.frames;
+    if (form_ == 1 || !analysis_ || frames % 2 != 0 || frames < 1024 || frames > 0x3FFFFFFFull) return false;
+    if (color_len_ < 64 || slow_len_ < 64 || slow_len_ > 0x3FFFFFFFu) return false;
+    if (form_ != 2 && (uint64_t)n_streams_ * frames < (4ull << 20)) return false;  // small calls: the sequential kernels' latency is lower
+    const bool history = wa.track_history != 0;
+    uint32_t C = 256;
+    // enough (chunk, 64 streams) workgroups of three wavefronts to fill the SIMDs several times over: 131072 items = 2048 workgroups
+    static const uint64_t want_items = [] {
+        const char* e = tuning_env("OMX_WAVE_CHUNK_ITEMS");  // tuning hook
+        return e ? (uint64_t)std::atoll(e) : 131072ull;
+    }();
+    while (C > 64 && (uint64_t)n_streams_ * ((frames + C - 1) / C) < want_items) C /= 2;
+    const uint32_t n_chunks = (uint32_t)((frames + C - 1) / C);
+    const int64_t F = (int64_t)frames;
+    const uint64_t P0 = pushes_, Pend = pushes_ + frames;
+    const uint32_t nwin = history ? 3u : 1u;
+    const int64_t caps[3] = {(int64_t)color_len_, (int64_t)color_len_, (int64_t)slow_len_};
+    const uint64_t ring_len[3] = {color_len_, slow_len_, slow_len_};  // buffer length of the WindowedMeans the window lives in
+    const int64_t maxcap = history ? (int64_t)slow_len_ : (int64_t)color_len_;
+    const uint64_t n_emit = wa.n_emit, first_kept = wa.first_kept, kept = n_emit - first_kept;
+
+    // ---- cuts
+    std::vector<int32_t> cuts;
+    cuts.reserve(column_ends.size() + (size_t)(kept + 1) * nwin + n_chunks + (size_t)(maxcap / 256) + 16);
+    cuts.push_back(-1);
+    cuts.push_back((int32_t)-maxcap);
+    for (int64_t g = -1 - 256; g > -maxcap; g -= 256) cuts.push_back((int32_t)g);  // a grid over the rings' contents (parallelism of the old sums)
+    for (uint32_t c = 1; c <= n_chunks; ++c) cuts.push_back((int32_t)(std::min<int64_t>((int64_t)c * C, F) - 1));
+    for (uint32_t f : column_ends) cuts.push_back((int32_t)f);
+    auto add_windows = [&](int64_t f) {
+        for (uint32_t w = 0; w < nwin; ++w) cuts.push_back((int32_t)(f - caps[w]));
+    };
+    for (uint64_t q = first_kept; q < n_emit; ++q) add_windows((int64_t)column_ends[q]);
+    add_windows(F - 1);
+    int64_t refresh_cut[3];
+    for (uint32_t w = 0; w < nwin; ++w) {  // refresh_counts (dsp.rs:346-352): the pair restarts at every multiple of the capacity
+        const uint64_t r = Pend / (uint64_t)caps[w] * (uint64_t)caps[w];
+        refresh_cut[w] = (int64_t)r - (int64_t)P0 - 1;
+        cuts.push_back((int32_t)refresh_cut[w]);
+    }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    const uint32_t n_segs = (uint32_t)cuts.size() - 1;
+    if (n_segs > 4096) return false;  // (thousands of columns per call: the plan's scratch grows with segments x streams)
+    auto index_of = [&](int64_t cut) { return (uint32_t)(std::lower_bound(cuts.begin(), cuts.end(), (int32_t)cut) - cuts.begin()); };
+    const uint32_t n_old = index_of(-1);
+
+    // ---- plan blob: cuts, first segment of every chunk, column table
+    std::vector<uint32_t> chunk_seg(n_chunks);
+    for (uint32_t c = 0; c < n_chunks; ++c) chunk_seg[c] = index_of((int64_t)c * C - 1);
+    std::vector<WaveEval> evals((size_t)kept + 1);
+    auto fill = [&](WaveEval& ev, int64_t f) {
+        ev.idx_end = index_of(f);
+        for (uint32_t w = 0; w < 3; ++w) {
+            const uint32_t ww = w < nwin ? w : 0u;
+            ev.idx_start[w] = index_of(f - caps[ww]);
+            ev.idx_refresh[w] = ev.idx_end;
+            const uint64_t pushes = P0 + (uint64_t)f + 1;
+            ev.count[w] = (uint32_t)std::max<uint64_t>(std::min(std::min(pushes, ring_len[ww]), (uint64_t)caps[ww]), 1);
+        }
+    };
+    for (uint64_t i = 0; i < kept; ++i) {
+        const uint64_t q = first_kept + i;
+        WaveEval& ev = evals[(size_t)i];
+        fill(ev, (int64_t)column_ends[q]);
+        ev.mm_from = (q == 0 ? n_old : index_of((int64_t)column_ends[q - 1])) - n_old;
+        ev.mm_to = ev.idx_end - n_old;
+        ev.out = (uint32_t)i;
+        ev.carry = q == 0 ? 1u : 0u;
+    }
+    {
+        WaveEval& ev = evals[(size_t)kept];
+        fill(ev, F - 1);
+        for (uint32_t w = 0; w < nwin; ++w) ev.idx_refresh[w] = index_of(refresh_cut[w]);
+        ev.mm_from = (n_emit == 0 ? n_old : index_of((int64_t)column_ends[n_emit - 1])) - n_old;
+        ev.mm_to = ev.idx_end - n_old;
+        ev.out = 0xFFFFFFFFu;
+        ev.carry = n_emit == 0 ? 1u : 0u;
+    }
+    const size_t cuts_bytes = cuts.size() * sizeof(int32_t), seg_bytes = chunk_seg.size() * sizeof(uint32_t);
+    const size_t evals_bytes = evals.size() * sizeof(WaveEval);
+    std::vector<uint8_t> blob(cuts_bytes + seg_bytes + evals_bytes);
+    std::memcpy(blob.data(), cuts.data(), cuts_bytes);
+    std::memcpy(blob.data() + cuts_bytes, chunk_seg.data(), seg_bytes);
+    std::memcpy(blob.data() + cuts_bytes + seg_bytes, evals.data(), evals_bytes);
+    plan_.reserve(blob.size() + 4096);
+    plan_staging_.upload(blob.data(), blob.size(), plan_.ptr, stream);
+
+    if (transition_rate_ != cfg_.sample_rate || transition_frames_ != C) {
+        transition_.upload(wave_transitions(wa.lp_lo, wa.hp_lo, wa.lp_hi, wa.hp_hi, C), stream);
+        transition_rate_ = cfg_.sample_rate;
+        transition_frames_ = C;
+    }
+    const uint64_t per_cut = (uint64_t)n_streams_ * 24;
+    const uint64_t segs_room = (n_segs + 1 + 63) / 64 * 64 + 64;  // (the count moves by a few from call to call: no reallocation for that)
+    chunk_state_.reserve((size_t)((uint64_t)n_chunks * n_streams_ * 3 * 8));
+    seg_sum_.reserve((size_t)(segs_room * per_cut));
+    seg_mm_.reserve((size_t)(segs_room * n_streams_ * 12));
+    prefix_.reserve((size_t)(segs_room * per_cut * 2));
+    plan_.reserve(blob.size() + 4096);
+    bad_.reserve(1);
+    OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
+
+    WaveChunkArgs ca{};
+    ca.pcm = wa.pcm;
+    ca.frames = frames;
+    ca.n_streams = n_streams_;
+    ca.m00 = wa.fmt.m[0][0];
+    ca.m10 = wa.fmt.m[1][0];
+    ca.m01 = wa.fmt.m[0][1];
+    ca.m11 = wa.fmt.m[1][1];
+    ca.lp_lo = wa.lp_lo;
+    ca.hp_lo = wa.hp_lo;
+    ca.lp_hi = wa.lp_hi;
+    ca.hp_hi = wa.hp_hi;
+    ca.history = history ? 1u : 0u;
+    ca.chunk_frames = C;
+    ca.n_chunks = n_chunks;
+    ca.pushes0 = P0;
+    ca.color_len = color_len_;
+    ca.slow_len = slow_len_;
+    ca.color_ring = color_ring_.ptr;
+    ca.hist_ring = hist_ring_.ptr;
+    ca.state = state_.ptr;
+    ca.cuts = reinterpret_cast<const int32_t*>(plan_.ptr);
+    ca.n_segs = n_segs;
+    ca.n_old_segs = n_old;
+    ca.chunk_seg = reinterpret_cast<const uint32_t*>(plan_.ptr + cuts_bytes);
+    ca.evals = reinterpret_cast<const WaveEval*>(plan_.ptr + cuts_bytes + seg_bytes);
+    ca.n_evals = (uint32_t)evals.size();
+    ca.chunk_state = chunk_state_.ptr;
+    ca.seg_sum = seg_sum_.ptr;
+    ca.seg_mm = seg_mm_.ptr;
+    ca.prefix_hi = prefix_.ptr;
+    ca.prefix_lo = prefix_.ptr + (uint64_t)(n_segs + 1) * per_cut;
+    ca.bad = bad_.ptr;
+    ca.columns = wa.columns;
+    ca.preview = wa.preview;
+    ca.n_kept = kept;
+    ca.write_preview = wa.write_preview;
+    launch_waveform_chunked(ca, transition_.ptr, stream);
+    OMX_HIP(hipGetLastError());
+    wa.run_if = bad_.ptr;
+    return true;
 }
 
 int WaveformBank::fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream) {

@@ -45,8 +45,50 @@ struct WaveformArgs {
     uint32_t* cols_v;
     float* progress_v;
     uint64_t max_cols;
+    const uint32_t* run_if;  // fallback launch of the chunk-parallel path: run only when *run_if != 0
 };
 void launch_waveform(const WaveformArgs& a, hipStream_t stream);
+
+// ---- chunk-parallel form (waveform_chunked.hip; lock-step bank calls)
+struct WaveEval {  // one kept column, or (out = 0xFFFFFFFF) the pseudo-column at the end of the call
+    uint32_t idx_end;         // cut index of the column's last frame
+    uint32_t idx_start[3];    // cut index of (last frame - window length): colour, fast history, slow history
+    uint32_t idx_refresh[3];  // (pseudo-column) cut index of the windows' last CompensatedPair refresh
+    uint32_t count[3];        // WindowedMeans::mean's divisor (dsp.rs:367-370)
+    uint32_t mm_from, mm_to;  // the column's segments [from, to), counted from the first segment of the call
+    uint32_t out;             // kept-column index
+    uint32_t carry;           // the column began before this call: merge the carried column state
+};
+struct WaveChunkArgs {
+    const float* pcm;  // [n_streams][frames][2]
+    uint64_t frames;
+    uint32_t n_streams;
+    float m00, m10, m01, m11;  // the two-channel fold
+    BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;
+    uint32_t history;
+    uint32_t chunk_frames, n_chunks;
+    uint64_t pushes0;  // tracker pushes before the call
+    uint32_t color_len, slow_len;
+    float* color_ring;
+    float* hist_ring;
+    WaveLaneState* state;
+    const int32_t* cuts;        // [n_segs + 1] ascending, call-relative frame indices (negative: before the call)
+    uint32_t n_segs, n_old_segs;
+    const uint32_t* chunk_seg;  // [n_chunks] first segment of a chunk
+    const WaveEval* evals;
+    uint32_t n_evals;           // the kernel's share of the list (columns first, the pseudo-column last)
+    float* chunk_state;         // [n_chunks][n_streams][3][8]
+    double* seg_sum;            // [n_segs][n_streams][24]: series (|v| gain, v^2) x channel x band
+    float* seg_mm;              // [new segments][n_streams][4][min, max, last]
+    double* prefix_hi;          // [n_segs + 1][n_streams][24]
+    double* prefix_lo;
+    uint32_t* bad;
+    omx_wave_column* columns;   // [n_streams][n_kept][4]
+    omx_wave_column* preview;
+    uint64_t n_kept;
+    uint32_t write_preview;
+};
+void launch_waveform_chunked(const WaveChunkArgs& a, const double* d_T, hipStream_t stream);
 // role-per-wavefront form (waveform_roles_kernels.hip); launch_waveform picks it whenever it applies (OMX_WAVEFORM_SINGLE=1 pins
 // the one-wavefront kernel: A/B runs and the bit-identity test)
 bool waveform_roles_applicable(const WaveformArgs& a);
@@ -75,6 +117,8 @@ public:
     int fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream);
     hipStream_t last_stream() const { return last_stream_; }
     uint64_t last_columns() const { return last_cols_; }
+    void set_form(uint32_t form) { form_ = form; }  // OMX_OPT_KERNEL_FORM: 0 by call shape, 1 sequential, 2 chunk-parallel where it applies
+    uint32_t last_form() const { return last_form_; }
 
 private:
     void rebuild();
@@ -108,6 +152,17 @@ private:
     DeviceBuffer<float> r_progress_;
     DeviceBuffer<uint8_t> r_mask_;
     RaggedStaging r_staging_;
+    // chunk-parallel form
+    bool run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream);
+    uint32_t form_ = 0, last_form_ = 0;
+    DeviceBuffer<double> transition_;
+    float transition_rate_ = 0.0f;
+    uint32_t transition_frames_ = 0;
+    BlobStaging plan_staging_;
+    DeviceBuffer<uint8_t> plan_;
+    DeviceBuffer<float> chunk_state_, seg_mm_;
+    DeviceBuffer<double> seg_sum_, prefix_;
+    DeviceBuffer<uint32_t> bad_;
 };
 
 }  // namespace omx

@@ -21,6 +21,7 @@ using namespace wf;
 // ANALYZE / HISTORY: the configuration's band analysis and RMS history, compile-time so that a frame's code is one basic block
 template <int B, bool ANALYZE, bool HISTORY>
 __global__ __launch_bounds__(64) void waveform_kernel(WaveformArgs a) {
+    if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path: the PCM was finite
     // ragged banks: one stream per workgroup (lanes 0 ... 15), so that its frame count, push count and column phase are
     // workgroup-uniform like the lock-step kernel arguments they replace
     const bool ragged = a.frames_v != nullptr;

@@ -55,6 +55,7 @@ constexpr uint32_t kStage = 64;  // frames of PCM per LDS refill
 // frame counts every batch is the straight-line one, as in the lock-step kernel.
 template <int B, int NSUB, bool HISTORY, bool RAGGED>
 __global__ __launch_bounds__(HISTORY ? 448 : 320) void waveform_roles_kernel(WaveformArgs a) {
+    if (a.run_if && *a.run_if == 0u) return;  // fallback launch of the chunk-parallel path: the PCM was finite (workgroup-uniform)
     constexpr int R = B * NSUB;
     constexpr int NW = HISTORY ? 3 : 1, NV = HISTORY ? 2 : 1;
     static_assert(kStage % R == 0, "a round never straddles two PCM refills");

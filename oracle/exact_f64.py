@@ -393,3 +393,56 @@ class StereometerExact:
             denom = np.sqrt(ema[1] * ema[2])
             rho.append(0.0 if denom <= 1e-12 else float(np.clip(ema[0] / denom, -1.0, 1.0)))
         return np.array(points), np.array(rho)
+
+
+# ---- the waveform's band colours and RMS history in f64 (reference src/visuals/waveform/processor.rs:78-121, :213-291;
+# src/dsp.rs:298-371, :399-495).  As for the stereometer above: the filter COEFFICIENTS are the reference's f32 values, the
+# RECURRENCE runs in f64 (scipy lfilter), the window means are plain f64 means of the last `len` tracker inputs (the reference keeps
+# them compensated: exact).  Third leg of the waveform bank's chunk-parallel form (tests/test_exact_f64.py): the reference's
+# sequential f32 order and the chunk form — f32 filters restarted every 64 ... 256 frames from scanned states — are two f32
+# evaluations of this recurrence.  Finite two-channel (FL, FR) input only; min / max fields are not modelled (bit-exact elsewhere).
+class WaveformExact:
+    GAINS = (1.0, 0.7, 2.0)   # BAND_COLOR_GAINS (:22), as f32 values
+
+    def __init__(self, sample_rate=48000.0, scroll_speed=300.0):
+        self.rate = float(np.float32(sample_rate))
+        self.step = min(max(float(np.float32(scroll_speed)) / float(np.float32(sample_rate)), 0.0), 1.0)   # :253-254
+        f32 = np.float32
+        ref = min(f32(sample_rate), f32(1.0e6))
+        self.color_len = max(int(np.round(f32(2048) * ref / f32(44100.0))), 1)    # window_len (:78-82)
+        self.slow_len = max(int(np.round(f32(16384) * ref / f32(44100.0))), 1)
+
+    _biquad = StereometerExact._biquad
+
+    def run(self, pcm_lr):
+        """pcm_lr [frames][2] f32, the whole stream from reset.  Returns (column end frames, colour [cols][4][3], power [cols][4][2][3]):
+        the colour bands and the mean band powers (fast, slow window) of every column the stream emits."""
+        from scipy.signal import lfilter
+        x = np.asarray(pcm_lr, np.float64)
+        f = lambda c, v: lfilter(c[0], c[1], v, axis=0)
+        above = f(self._biquad(True, 200.0), x)
+        sides = np.stack([f(self._biquad(False, 200.0), x), f(self._biquad(False, 2000.0), above), f(self._biquad(True, 2000.0), x)], axis=-1)  # [frames][L/R][band]
+        l, r = sides[:, 0], sides[:, 1]
+        bands = np.stack([l, r, (l + r) * 0.5, (l - r) * 0.5], axis=1)               # [frames][channel][band] (:262-268)
+        gains = np.array([float(np.float32(g)) for g in self.GAINS])
+        colour = np.abs(bands) * gains
+        power = bands * bands
+        zero = np.zeros((1,) + colour.shape[1:])
+        # running totals in extended precision (x87, 64-bit mantissa): a window 120 dB below the passage before it is still resolved to
+        # ~1e-6 of its own sum (the product keeps double-double totals for the same reason)
+        ld = np.longdouble
+        cc = np.concatenate([zero.astype(ld), np.cumsum(colour.astype(ld), axis=0)])
+        cp = np.concatenate([zero.astype(ld), np.cumsum(power.astype(ld), axis=0)])
+        ends, phase = [], 0.0
+        for k in range(x.shape[0]):
+            phase += self.step
+            if phase >= 1.0:
+                ends.append(k)
+                phase -= 1.0
+        ends = np.array(ends, np.int64)
+
+        def mean(c, cap):
+            hi = ends + 1
+            lo = np.maximum(hi - cap, 0)
+            return ((c[hi] - c[lo]) / np.maximum(np.minimum(hi, cap), 1)[:, None, None]).astype(np.float64)
+        return ends, mean(cc, self.color_len), np.stack([mean(cp, self.color_len), mean(cp, self.slow_len)], axis=2)

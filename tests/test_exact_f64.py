@@ -255,3 +255,77 @@ def test_hip_chunk_parallel_stereometer_is_as_close_to_exact_arithmetic_as_the_o
         bar(f"stereometer ({name}): hip / oracle distance ratio from exact (rho)", max(h_dr, 2e-7) / max(o_dr, 2e-7), 2.0)
     bar("stereometer oracle vs exact f64: |d point| / level", o_dp / level, 1e-4)
     bar("stereometer oracle vs exact f64: |d rho|", o_dr, 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Waveform: the chunk-parallel form of the bank (waveform_chunked.hip) against exact arithmetic, next to the oracle's own distance.
+# A rounding of a DF2T state of the 200 Hz sections excites the all-pole response 1 / A(z), whose peak is ~ fs / (2 pi e fc 0.707)
+# = 20 at 48 kHz and which lasts ~100 frames: every f32 evaluation of these bands — the reference's sequential one included — sits
+# ~1e-6 ... 1e-5 of the band's level away from the f64 recurrence.  What is asked of the chunk form is that it sits no further.
+def wave_exact_case(s, frames=16384 * 2):
+    from golden_inputs import cfg4_pcm
+    pcm = cfg4_pcm(s, frames)
+    if s % 3 == 1:
+        pcm = (pcm * np.float32(0.05)).astype(np.float32)
+    ends, colour, power = ex.WaveformExact(FS, 300.0).run(pcm)
+    return pcm, ends, colour, power
+
+
+def wave_distance(columns, colour, power):
+    """columns [cols][4][11] f32 (min, max, colour x3, rms dB fast x3, slow x3) against the exact colour [cols][4][3] and mean power
+    [cols][4][2][3].  Returns (max |d colour| / max colour, max |d power| / loudest channel of the band and window); powers below the
+    -140 dB floor of the dB fields are not compared."""
+    c = np.asarray(columns[:, :, 2:5], np.float64)
+    dc = float(np.abs(c - colour).max() / colour.max())
+    p = 10.0 ** (np.asarray(columns[:, :, 5:], np.float64).reshape(-1, 4, 2, 3) / 10.0)
+    top = power.max(axis=1, keepdims=True)
+    live = power > 1e-13
+    dp = float((np.abs(p - power) / top)[live].max())
+    return dc, dp
+
+
+def run_wave_oracle(oracle, pcm, block):
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=4096, analyze_bands=True, track_history=True)
+    p = WaveformProcessor(oracle, cfg)
+    cols = [p.process_block(AudioBlock(pcm[k:k + block].reshape(-1), 2, FS)).columns for k in range(0, len(pcm), block)]
+    return np.concatenate([c for c in cols if len(c)])
+
+
+@pytest.mark.parametrize("s", [40, 41, 44])
+def test_oracle_waveform_is_close_to_exact_arithmetic(oracle, s):
+    pcm, ends, colour, power = wave_exact_case(s)
+    cols = run_wave_oracle(oracle, pcm, 4096)
+    assert len(cols) == len(ends)
+    dc, dp = wave_distance(cols, colour, power)
+    print("oracle waveform distance from exact", s, dc, dp)
+    assert dc <= 1e-5 and dp <= 1e-4, (dc, dp)   # measured colour 1.0e-6 ... 2.9e-6, power 8e-6 ... 5.5e-5 (the 200 Hz sections' f32 noise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s", [40, 41, 44])
+def test_hip_chunk_parallel_waveform_is_as_close_to_exact_arithmetic_as_the_oracle(omx, oracle, s):
+    """|HIP - exact| <= 2 |oracle - exact| on the colour bands and on the history powers, for the chunk-parallel form and for the
+    sequential form (the reference's order: its distance IS the oracle's).  Floors: 1e-6 (colour), 2e-6 (power)."""
+    from openmeters_amd import banks, capi
+    from openmeters_amd.capi import WaveformConfig
+    pcm, ends, colour, power = wave_exact_case(s)
+    o_dc, o_dp = wave_distance(run_wave_oracle(oracle, pcm, 4096), colour, power)
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=4096, analyze_bands=True, track_history=True)
+    for form, name in ((2, "chunk-parallel"), (1, "sequential")):
+        bank = banks.WaveformBank(omx, cfg, 1)
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        got = []
+        for k in range(0, len(pcm), 4096):
+            up = bank.process_host(pcm[None, k:k + 4096], 2, FS)
+            assert bank.last_form() == form
+            got.append(bank.fetch(0, int(up.n_columns))[0])
+        got = np.concatenate([g for g in got if len(g)])
+        assert len(got) == len(ends)
+        h_dc, h_dp = wave_distance(got, colour, power)
+        bar(f"waveform ({name}) vs exact f64: |d colour| / max colour", h_dc, 1e-5)
+        bar(f"waveform ({name}) vs exact f64: |d power| / loudest channel of the band", h_dp, 1e-4)
+        bar(f"waveform ({name}): hip / oracle distance ratio from exact (colour)", max(h_dc, 1e-6) / max(o_dc, 1e-6), 2.0)
+        bar(f"waveform ({name}): hip / oracle distance ratio from exact (power)", max(h_dp, 2e-6) / max(o_dp, 2e-6), 2.0)
+    bar("waveform oracle vs exact f64: |d colour| / max colour", o_dc, 1e-5)
+    bar("waveform oracle vs exact f64: |d power| / loudest channel of the band", o_dp, 1e-4)

@@ -217,8 +217,9 @@ def test_waveform_bank_1024_streams_partition_and_replication(omx, history):
     d_pcm = torch.from_numpy(pcm).to("cuda:0")
     pos = capi.positions_fallback(2)
 
-    def run(cuts):
+    def run(cuts, form=1):
         bank = banks.WaveformBank(omx, cfg, S)
+        bank.set_option(capi.OPT_KERNEL_FORM, form)   # 1: the sequential kernels this test is about (by shape the single call would go chunk-parallel)
         cols, at = [], 0
         for n in cuts:
             part = d_pcm[:, at:at + n].contiguous()
@@ -236,6 +237,22 @@ def test_waveform_bank_1024_streams_partition_and_replication(omx, history):
     assert torch.equal(one, many)
     for s in (8, 9, 511, 1016, 1023):
         assert torch.equal(one[s], one[s % 8]), s
+    # the chunk-parallel form (waveform_chunked.hip) at the same size: min / max bit-identical to the sequential kernels', colour bands and
+    # history within the fixed part of the three-way bars of tests/test_gpu_parity_meters.py (steady signal: the oracle itself is that
+    # close to exact), identical streams identical bits, and its own partition (chunk-parallel calls handing over to each other)
+    chunk = run([frames], form=2)
+    assert torch.equal(chunk[..., :2], one[..., :2])
+    c64, o64 = chunk.view(torch.float32).double(), one.view(torch.float32).double()   # (run() returns the f32 bits as i32)
+    top = o64[..., 2:5].amax(dim=2, keepdim=True).clamp_min(1e-30)
+    assert float(((c64[..., 2:5] - o64[..., 2:5]).abs() / top).max()) <= 4e-5
+    if history:
+        pc, po = 10.0 ** (c64[..., 5:] / 10.0), 10.0 ** (o64[..., 5:] / 10.0)
+        assert float(((pc - po).abs() / po.amax(dim=2, keepdim=True)).max()) <= 8e-5
+    for s in (8, 9, 511, 1016, 1023):
+        assert torch.equal(chunk[s], chunk[s % 8]), s
+    parts = run([2048, 1024, 2928], form=2)
+    assert torch.equal(parts[..., :2], one[..., :2])
+    assert float(((parts.view(torch.float32).double()[..., 2:5] - o64[..., 2:5]).abs() / top).max()) <= 4e-5
 
 
 def test_ragged_calls_with_equal_counts_are_bit_identical_to_lock_step_calls_at_bank_size(omx):

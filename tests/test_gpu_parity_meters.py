@@ -9,6 +9,9 @@ glibc by <= 2 ulp):
                                   possible because tree reductions replace the reference's sequential sums);
                                   resampled trace within 1e-4 of the oracle where start/frac agree
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -765,3 +768,142 @@ def test_loudness_chunk_parallel_form_hands_non_finite_input_to_the_sequential_k
                     assert ga.short_term_loudness == gb.short_term_loudness or (np.isnan(ga.short_term_loudness) and np.isnan(gb.short_term_loudness))
                 elif s in (0, 2):   # streams that never saw a non-finite sample
                     snapshots_close(ga, gb)
+
+
+# ---- K10c: the waveform bank's chunk-parallel form (waveform_chunked.hip) ------------------------------------------------------
+# Bars.  min / max: a reduction of the same samples — bit-identical.  Colour bands and RMS history: the band filters restart every
+# 64 ... 256 frames from scanned states that carry one f32 rounding each (the low band's none).  A rounding of a DF2T state of a
+# 200 Hz section excites the all-pole response 1 / A(z) — a near-double pole: (n + 1) r^n, peak fs / (2 pi e 0.707 fc) = 20 at
+# 48 kHz — and the SAME mechanism acts on every step of the reference's own sequential f32 evaluation.  How far an f32 evaluation of
+# these recurrences sits from the f64 recurrence therefore depends on the passage: ~1e-6 of the band's level on steady signal,
+# and growing like eta t^1.5 ... eta t^2 / 2 through a free decay (t frames after a 120 dB drop the ringing that fills the fast
+# window is 1e-3 away from exact in EITHER evaluation).  The bars are three-way, per call and per (field, band):
+#     D_o  = |oracle - exact|, D_ho = |HIP - oracle|, D_h = |HIP - exact|     (exact = oracle/exact_f64.py::WaveformExact, f64 recurrence)
+#     each as the maximum over the call's columns and channels of the difference relative to the loudest channel of that column;
+#     D_ho <= FIX + 3 D_o   and   D_h <= FIX + 2 D_o,   FIX = 1e-5 (colour: the north star's tolerance), 2e-5 (power: its square).
+# The sequential form's bars (1e-6, 2e-4 dB against the oracle; measured 0 and 1.1e-5) are unchanged.
+WAVE_FIX_COLOUR, WAVE_FIX_POWER = 1e-5, 2e-5
+
+
+def check_wave_three_way(tag, got, want, exact_colour, exact_power, history, detail=None):
+    """got / want: [cols][4][11] f32 columns of the HIP bank and of the oracle; exact_*: the f64 recurrence's colour [cols][4][3] and
+    mean powers [cols][4][2][3] for the same columns"""
+    def three(g, o, e, fix, name):
+        top = np.maximum(e.max(axis=1, keepdims=True), 1e-300)
+        for band in range(3):
+            sl = (..., band)
+            d_o = float((np.abs(o - e) / top)[sl].max())
+            d_ho = float((np.abs(g - o) / top)[sl].max())
+            d_h = float((np.abs(g - e) / top)[sl].max())
+            bar(f"{tag}: {name} |HIP - oracle| / (fix + 3 |oracle - exact|)", d_ho / (fix + 3.0 * d_o), 1.0, (detail, band, d_ho, d_o))
+            bar(f"{tag}: {name} |HIP - exact| / (fix + 2 |oracle - exact|)", d_h / (fix + 2.0 * d_o), 1.0, (detail, band, d_h, d_o))
+            if d_o <= fix:   # ledger: what the plain tolerance measures where the reference itself is that close to exact
+                bar(f"{tag}: {name} |HIP - oracle| where |oracle - exact| <= fix", d_ho, 4.0 * fix, (detail, band))
+    g64, o64 = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    three(g64[:, :, 2:5], o64[:, :, 2:5], exact_colour, WAVE_FIX_COLOUR, "colour")
+    if history:
+        pg = 10.0 ** (g64[:, :, 5:].reshape(-1, 4, 2, 3) / 10.0)
+        po = 10.0 ** (o64[:, :, 5:].reshape(-1, 4, 2, 3) / 10.0)
+        live = exact_power.max(axis=1, keepdims=True) > 1e-13    # (the dB fields stop at -140 dB)
+        for w, wname in enumerate(("fast", "slow")):
+            keep = live[:, 0, w].any(axis=-1)
+            if keep.any():
+                three(pg[keep][:, :, w], po[keep][:, :, w], exact_power[keep][:, :, w], WAVE_FIX_POWER, f"{wname} history power")
+
+
+def _wave_exact(pcm_stream, rate):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import exact_f64 as ex
+    return ex.WaveformExact(rate, 300.0).run(pcm_stream)
+
+
+@pytest.mark.parametrize("rate,history", [(48000.0, True), (48000.0, False), (44100.0, True), (96000.0, False)])
+def test_waveform_chunk_parallel_form_matches_per_stream_oracle(omx, oracle, rate, history):
+    """lock-step calls of mixed sizes with OMX_OPT_KERNEL_FORM = 2: calls of >= 1024 even frames take the chunk-parallel form, the
+    others the sequential kernels — every hand-over of filter states, rings, compensated pairs and the open column goes both ways"""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    S = 5
+    cfg = WaveformConfig(sample_rate=rate, scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=history)
+    sizes = [4096, 256, 2048, 1000, 8192, 1024, 3001, 1536, 16384, 512, 2050]
+    pcm = np.stack([cfg4_pcm(40 + s, sum(sizes)) for s in range(S)])
+    pcm[1, 9000:12000] *= np.float32(1e-4)   # a quiet passage inside one stream
+    exact = [_wave_exact(pcm[s], rate) for s in range(S)]
+    bank = banks.WaveformBank(omx, cfg, S)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
+    at, total, forms = 0, 0, []
+    for n in sizes:
+        chunk = pcm[:, at:at + n]
+        at += n
+        up = bank.process_host(chunk, 2, rate)
+        forms.append(bank.last_form())
+        for s, r in enumerate(refs):
+            w = r.process_block(AudioBlock(chunk[s].reshape(-1), 2, rate))
+            assert up.n_columns == len(w.columns) and bool(up.reset) == w.reset and bool(up.preview_some) == (w.preview is not None)
+            got, prev = bank.fetch(s, int(up.n_columns), with_preview=True)
+            assert np.array_equal(got[:, :, :2], w.columns[:, :, :2]), (n, s)   # min / max
+            if len(got):
+                cols = slice(total, total + len(got))
+                check_wave_three_way("waveform (chunk-parallel)", got, w.columns, exact[s][1][cols], exact[s][2][cols], history, (n, s))
+            if w.preview is not None:
+                assert np.array_equal(prev[:, :2], w.preview[:, :2]), (n, s)
+                # (the preview column is compared with the oracle's under the widest column bar of the call: no exact twin is kept)
+                assert np.abs(prev[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-4 * max(1e-30, np.abs(w.preview[:, 2:5]).max()), (n, s)
+        total += int(up.n_columns)
+    assert forms == [2 if (n >= 1024 and n % 2 == 0) else 1 for n in sizes]
+    assert total > 100 and total == len(exact[0][0])
+
+
+def test_waveform_chunk_parallel_form_quiet_window_after_a_loud_passage(omx, oracle):
+    """a window mean is a difference of two running totals: 1 s at full scale, then -120 dBFS — the history means fall by 120 dB
+    and must still be those of the reference's compensated sums (a plain f64 difference would leave ~1e-13 of the loud total, 20 dB
+    ABOVE the quiet passage's own mean power).  The calls around the drop also hold the free decay of the 200 Hz sections, where
+    every f32 evaluation is ~1e-3 from exact: the three-way bar follows the oracle's own distance."""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=True)
+    n = 16384
+    rng = np.random.default_rng(5)
+    loud = rng.uniform(-1.0, 1.0, (3 * n, 2)).astype(np.float32)
+    quiet = (rng.uniform(-1.0, 1.0, (4 * n, 2)) * 1e-6).astype(np.float32)
+    pcm = np.concatenate([loud, quiet])[None]
+    _, e_colour, e_power = _wave_exact(pcm[0], FS)
+    bank = banks.WaveformBank(omx, cfg, 1)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    ref = WaveformProcessor(oracle, cfg)
+    floor_seen, total = 0.0, 0
+    for k in range(0, pcm.shape[1], n):
+        up = bank.process_host(pcm[:, k:k + n], 2, FS)
+        assert bank.last_form() == 2
+        w = ref.process_block(AudioBlock(pcm[0, k:k + n].reshape(-1), 2, FS))
+        got, _ = bank.fetch(0, int(up.n_columns))
+        assert np.array_equal(got[:, :, :2], w.columns[:, :, :2])
+        cols = slice(total, total + len(got))
+        check_wave_three_way("waveform (chunk-parallel, 120 dB drop)", got, w.columns, e_colour[cols], e_power[cols], True, k)
+        total += len(got)
+        floor_seen = min(floor_seen, float(w.columns[:, :, 5:].min()))
+    assert floor_seen < -110.0
+
+
+def test_waveform_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx, oracle):
+    """NaN / inf / absurdly large samples: the chunk-parallel form raises its flag before it has written anything but scratch and
+    the sequential kernels do the call — bit-identical to the sequential form, continuity rules of :275-291 included"""
+    from openmeters_amd.capi import WaveformConfig
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=True)
+    S, n = 3, 4096
+    pcm = np.stack([cfg4_pcm(60 + s, 4 * n) for s in range(S)])
+    pcm[1, n + 100, 0] = np.nan
+    pcm[2, n + 3000, 1] = np.inf
+    pcm[0, 2 * n + 17, 0] = np.float32(1e30)
+    a, b = banks.WaveformBank(omx, cfg, S), banks.WaveformBank(omx, cfg, S)
+    a.set_option(capi.OPT_KERNEL_FORM, 2)
+    b.set_option(capi.OPT_KERNEL_FORM, 1)
+    for k in range(0, 4 * n, n):
+        ua, ub = a.process_host(pcm[:, k:k + n], 2, FS), b.process_host(pcm[:, k:k + n], 2, FS)
+        assert ua.n_columns == ub.n_columns
+        for s in range(S):
+            ga, pa = a.fetch(s, int(ua.n_columns), with_preview=True)
+            gb, pb = b.fetch(s, int(ub.n_columns), with_preview=True)
+            assert np.array_equal(ga[:, :, :2].view(np.uint32), gb[:, :, :2].view(np.uint32)), (k, s)
+            fin = np.isfinite(gb[:, :, 2:5])
+            assert np.array_equal(fin, np.isfinite(ga[:, :, 2:5]))
+            assert np.abs(ga[:, :, 2:5][fin] - gb[:, :, 2:5][fin]).max(initial=0.0) <= 4.0 * WAVE_FIX_COLOUR * max(1.0, np.abs(gb[:, :, 2:5][fin]).max(initial=0.0))

@@ -165,7 +165,7 @@ def reference_defaults(S=64, out=sys.stdout):
     return res
 
 
-def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096)):
+def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096), histories=(False, True)):
     """the waveform bank (band analysis on; with and without RMS history), 256-frame blocks x `blocks` per call.
     `sizes` = the bank sizes run (tools/profile_meters_pmc.sh profiles ONE size per pass so that its traffic record is per launch)."""
     frames = 256 * blocks
@@ -174,7 +174,7 @@ def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096)):
         g = torch.Generator(device=dev).manual_seed(S)
         pcm = (torch.rand((S, frames, 2), device=dev, generator=g) - 0.5).contiguous()
         pos = capi.positions_fallback(2)
-        for history in (False, True):
+        for history in histories:
             bank = banks.WaveformBank(api, capi.WaveformConfig(analyze_bands=True, track_history=history), S)
             run = lambda: bank.process_device(pcm.data_ptr(), frames, 2, FS, pos, stream)
             run()
@@ -183,15 +183,20 @@ def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096)):
                   f"{frames/dt/FS:.0f}x real time per stream", file=out)
             # §8(d)-style algorithmic bytes: C * 4 B of PCM in per frame + 4 columns x 44 B out per emitted column (scroll 300 / s: one per 160 frames)
             alg = S * frames * 2 * 4.0 + S * (frames / 160.0) * 4 * 44.0
+            chunked = bank.last_form() == 2   # waveform_chunked.hip: seven launches per call, all named wave_*
+            names = ["wave_", f"@{S}"] if chunked else [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", f"@{S}"]
             res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3,
-                                                           "roofline": roofline(alg, dt * 1e3, [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", f"@{S}"], match_all=True)}
+                                                           "form": "chunk-parallel (waveform_chunked.hip)" if chunked else "sequential (waveform_roles_kernels.hip)",
+                                                           "roofline": roofline(alg, dt * 1e3, names, match_all=True)}
             bank.close()
     return res
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "waveform":
-        waveform(sizes=tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (64, 1024, 4096))
+        # waveform [sizes] [0 | 1]: the bank sizes, and RMS history off / on only (the PMC passes profile ONE configuration per process)
+        waveform(sizes=tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (64, 1024, 4096),
+                 histories=(bool(int(sys.argv[3])),) if len(sys.argv) > 3 else (False, True))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "scope":  # cfg4's two banks only (tools/profile_scope_sq.sh)
         scope_stereo()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the cfg3 / cfg4 meter kernels and of the waveform bank at ONE size
-# (1024 streams: a per-launch record); outputs under gpurun_out/$1
+# (1024 streams, the default configuration — RMS history off: a per-launch record); outputs under gpurun_out/$1
 set -u
 TAG=${1:-meters_pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -8,8 +8,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py nowave > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py nowave > $OUT/write.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/wf_fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 > $OUT/wf_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wf_write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 > $OUT/wf_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/wf_fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $OUT/wf_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wf_write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $OUT/wf_write.log 2>&1
 python3 - <<PY
 import csv, glob, os
 from collections import defaultdict
