@@ -410,7 +410,7 @@ bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& co
     }
     const uint64_t per_cut = (uint64_t)n_streams_ * 24;
     const uint64_t segs_room = (n_segs + 1 + 63) / 64 * 64 + 64;  // (the count moves by a few from call to call: no reallocation for that)
-    chunk_state_.reserve((size_t)((uint64_t)n_chunks * n_streams_ * 3 * 8));
+    chunk_state_.reserve((size_t)((uint64_t)n_chunks * n_streams_ * 3 * 16));
     seg_sum_.reserve((size_t)(segs_room * per_cut));
     seg_mm_.reserve((size_t)(segs_room * n_streams_ * 12));
     prefix_.reserve((size_t)(segs_room * per_cut * 2));

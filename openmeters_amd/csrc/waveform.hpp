@@ -77,7 +77,7 @@ struct WaveChunkArgs {
     const uint32_t* chunk_seg;  // [n_chunks] first segment of a chunk
     const WaveEval* evals;
     uint32_t n_evals;           // the kernel's share of the list (columns first, the pseudo-column last)
-    float* chunk_state;         // [n_chunks][n_streams][3][8]
+    float* chunk_state;         // [n_chunks][n_streams][3][16 floats]: low / mid band 4 / 8 f64 states, high band 4 f32
     double* seg_sum;            // [n_segs][n_streams][24]: series (|v| gain, v^2) x channel x band
     float* seg_mm;              // [new segments][n_streams][4][min, max, last]
     double* prefix_hi;          // [n_segs + 1][n_streams][24]

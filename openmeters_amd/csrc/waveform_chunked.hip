@@ -5,7 +5,7 @@
 // reference, and latency-bound: one workgroup of 5 wavefronts per four streams, ~300 cycles per frame (2.4 ms for 1024 streams x
 // 16 384 frames, 0.8 % of HBM).  Everything on this path except the non-finite resets is linear in its state or a plain sum:
 //
-//   pass A   per (chunk, stream): the band filters from a ZERO state over the chunk -> zero-state end state (the low band in f64:
+//   pass A   per (chunk, stream): the band filters from a ZERO state over the chunk -> zero-state end state (the low and mid bands in f64:
 //            stereometer_chunked.hip explains why); non-finite or absurdly large input raises `bad`                    (parallel)
 //   scan     per (stream, band, side): true start state of every chunk, s_{c+1} = T s_c + e_c, T = the C-frame zero-input
 //            transition of the cascade (host, f64) — wave-parallel over the chunks
@@ -27,7 +27,7 @@
 // The only subtraction — running total at a window's end minus running total at its start — is done in double-double, so a
 // quiet window after a loud passage is as exact as the reference's compensated sum.
 //
-// Not bit-identical to the sequential order: the chunk start states carry one f32 rounding each (low band: none), every band value
+// Not bit-identical to the sequential order: pass B restarts every chunk from the (exact, for the low and mid bands) scanned state rounded to f32, every band value
 // after it differs by ~1e-7 relative, and the window means by less (they average).  Bars: tests/test_gpu_parity_meters.py.
 // min / max fields are bit-identical (a reduction of the same samples).  What is NOT linear — Biquad::process' non-finite reset,
 // the non-finite rules of the trackers and of the min / max state machine — never runs here: `bad` sends the whole call through
@@ -125,18 +125,22 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     const bool mine = s < a.n_streams;
     const BiquadCoef ca = a.hp_lo, cb = role == 0 ? a.lp_lo : (role == 1 ? a.lp_hi : a.hp_hi);
     v2f za0{0.0f, 0.0f}, za1{0.0f, 0.0f}, zb0{0.0f, 0.0f}, zb1{0.0f, 0.0f};  // stage A (mid band only), stage B
-    double d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};                            // pass A, role 0
-    float* cs = a.chunk_state + (((uint64_t)c * a.n_streams + (mine ? s : 0u)) * 3u + role) * 8u;
+    // pass A, roles 0 and 1 (the bands with a 200 Hz section): f64 — their chunk-boundary states follow the exact trajectory of the
+    // recurrence, and pass B (f32, the reference's precision) restarts every chunk from a state without rounding history.  With f32
+    // boundary states the mid band sat 3 ... 4x further from the f64 recurrence than the reference's own evaluation after level
+    // steps (tests/test_gpu_parity_meters.py, random sequences; the stereometer's low band taught the same in stereometer_chunked.hip)
+    double da0[2] = {0.0, 0.0}, da1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+    float* cs = a.chunk_state + (((uint64_t)c * a.n_streams + (mine ? s : 0u)) * 3u + role) * 16u;
     double* cs64 = reinterpret_cast<double*>(cs);
-    if (PASS_B && mine) {  // the chunk's true start state ([state k][side]: role 0 as f64 LP z0, z1; role 1: A z0, A z1, B z0, B z1)
+    if (PASS_B && mine) {  // the chunk's true start state ([state k][side]: role 0 LP z0, z1; role 1 A z0, A z1, B z0, B z1 — f64; role 2 f32)
         if (role == 0) {
             zb0 = v2f{(float)cs64[0], (float)cs64[1]};
             zb1 = v2f{(float)cs64[2], (float)cs64[3]};
         } else if (role == 1) {
-            za0 = v2f{cs[0], cs[1]};
-            za1 = v2f{cs[2], cs[3]};
-            zb0 = v2f{cs[4], cs[5]};
-            zb1 = v2f{cs[6], cs[7]};
+            za0 = v2f{(float)cs64[0], (float)cs64[1]};
+            za1 = v2f{(float)cs64[2], (float)cs64[3]};
+            zb0 = v2f{(float)cs64[4], (float)cs64[5]};
+            zb1 = v2f{(float)cs64[6], (float)cs64[7]};
         } else {
             zb0 = v2f{cs[0], cs[1]};
             zb1 = v2f{cs[2], cs[3]};
@@ -185,8 +189,9 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
         for (int f = 0; f < STEP; ++f) {
             if ((uint32_t)f < nf) {
             v2f v = x[f];
-            if (!PASS_B && role == 0) {  // (wave-uniform) the low band's zero-state pass in f64: only its end state is used
+            if (!PASS_B && role != 2) {  // (wave-uniform) the zero-state pass of the low and mid bands in f64: only the end state is used
                 double xd[2] = {(double)v.x, (double)v.y};
+                if (role == 1) biquad_lr_f64(ca, da0, da1, xd);
                 biquad_lr_f64(cb, d0, d1, xd);
             } else {
             if (role == 1) v = biquad_lr(ca, za0, za1, v);
@@ -285,8 +290,8 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
         if (role == 0) {
             cs64[0] = d0[0]; cs64[1] = d0[1]; cs64[2] = d1[0]; cs64[3] = d1[1];
         } else if (role == 1) {
-            cs[0] = za0.x; cs[1] = za0.y; cs[2] = za1.x; cs[3] = za1.y;
-            cs[4] = zb0.x; cs[5] = zb0.y; cs[6] = zb1.x; cs[7] = zb1.y;
+            cs64[0] = da0[0]; cs64[1] = da0[1]; cs64[2] = da1[0]; cs64[3] = da1[1];
+            cs64[4] = d0[0]; cs64[5] = d0[1]; cs64[6] = d1[0]; cs64[7] = d1[1];
         } else {
             cs[0] = zb0.x; cs[1] = zb0.y; cs[2] = zb1.x; cs[3] = zb1.y;
         }
@@ -337,7 +342,7 @@ __device__ __forceinline__ void scan_wave(const WaveChunkArgs& a, const double* 
     for (uint32_t c0 = 0; c0 < nb; c0 += 64u) {
         const uint32_t c = c0 + lane;
         const bool live = c < nb;
-        float* cs = a.chunk_state + (((uint64_t)(live ? c : c0) * a.n_streams + s) * 3u + role) * 8u;
+        float* cs = a.chunk_state + (((uint64_t)(live ? c : c0) * a.n_streams + s) * 3u + role) * 16u;
         double* cs64 = reinterpret_cast<double*>(cs);
         double x[N];
 #pragma unroll
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void wave_scan_states_kernel(WaveChunkArgs a, 
     if (w >= a.n_streams * 6u) return;
     const uint32_t s = w / 6u, role = (w % 6u) >> 1, side = w & 1u;
     if (role == 0) scan_wave<2, true>(a, T, s, role, side, lane);
-    else if (role == 1) scan_wave<4, false>(a, T + 96, s, role, side, lane);
+    else if (role == 1) scan_wave<4, true>(a, T + 96, s, role, side, lane);
     else scan_wave<2, false>(a, T + 192, s, role, side, lane);
 }
 

@@ -1,11 +1,12 @@
 """In-suite soak: the randomised sequences of tests/test_gpu_state_machine.py on seeds NOBODY picked — the base
-changes from run to run (tests/conftest.py: SOAK_BASE, printed in the report header; OMX_SOAK_SEED=<base> reproduces a run).  54
-sequences per run: six seeds for each of the nine cases of tools/soak_ragged.py (which remains the long-running form of the same
+changes from run to run (tests/conftest.py: SOAK_BASE, printed in the report header; OMX_SOAK_SEED=<base> reproduces a run).  60
+sequences per run: six seeds for each of ten cases — the nine of tools/soak_ragged.py (which remains the long-running form of the same
 thing: 4 950 sequences in round 3).  Green here means the bars hold by RULE — conditioning-derived for the reassigned columns
 (parity.conditioned_bar), the half-integer rule for the oscilloscope's integer geometry — not by choice of seed."""
 import pytest
 
 import conftest
+import test_gpu_parity_meters as m
 import test_gpu_state_machine as t
 from openmeters_amd import capi
 
@@ -66,3 +67,8 @@ def test_soak_ragged_oscilloscope(omx, oracle, seed):
 def test_soak_ragged_spectrogram_bank(omx, oracle, seed):
     W, hop, reassign = ((1024, 256, True), (4096, 256, True), (2048, 64, True), (1024, 300, False), (2048, 777, True), (4096, 100, True))[seed % 6]
     t.test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx, oracle, seed, W, hop, reassign)
+
+
+@pytest.mark.parametrize("seed", conftest.soak_seeds(N, 9))
+def test_soak_waveform_chunk_parallel(omx, oracle, seed):
+    m.test_waveform_chunk_parallel_random_sequences(omx, oracle, seed)
