@@ -144,6 +144,10 @@ struct BigScratch {
     uint32_t first;   // first frame (item = stream * n_cols + column) of this chunk
     uint32_t count;   // frames in this chunk
 };
+// zero padding beyond 16384 points: zp W-point transforms of modulated slices per spectrum (stft_pow2_kernels.hip)
+uint64_t stft_residue_scratch_bytes_per_frame(uint32_t window, uint32_t fft_size);
+bool launch_stft_reassigned_residue(const StftFastArgs& a, uint32_t window, uint32_t zp, const v2f* twF, void* scratch, uint32_t first, uint32_t count,
+                                    hipStream_t stream);
 void launch_hilbert_16k(const StftFastArgs& a, const BigScratch& sc, bool imag_only, hipStream_t stream);   // stft16384_kernels.hip
 void launch_windowed_reassign_16k(const StftFastArgs& a, const BigScratch& sc, bool imag_only, hipStream_t stream);
 void launch_windowed_16k(const StftFastArgs& a, const BigScratch& sc, hipStream_t stream);

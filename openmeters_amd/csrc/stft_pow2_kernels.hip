@@ -1111,6 +1111,132 @@ bool launch_stft_reassigned_zp_16384(const StftFastArgs& a, uint32_t window, con
         default: return false;
     }
 }
+// ================================================================================================
+// Zero padding beyond 16384 points (the GUI offers up to 32x of 1024 ... 16384-point windows: F = zp W up to 524288,
+// reference src/ui/settings/spectrogram.rs:13, processor.rs:231).  A W-sample slice zero-padded to F = zp W points is zp
+// independent W-point transforms of modulated copies of the slice:
+//     X[zp q + r] = sum_n x[n] e^{-2 pi i n (zp q + r) / F} = FFT_W( x[n] e^{-2 pi i n r / F} )[q],     r = 0 ... zp - 1
+// so no transform here is longer than the window.  Same three steps as above:
+//   hilbert_big_kernel        analytic slice of every frame -> scratch                                        (unchanged)
+//   windowed_residue_kernel   workgroup = (frame, window w / w' / t w, residue r): window x modulation in the time domain
+//                             (processor.rs:334-342, :569-608), one W-point transform, bins zp q + r of that spectrum's row
+//   reassign_stream_kernel    per-bin reassignment + ordered compaction over the F / 2 + 1 bins, 1024 at a time
+// ================================================================================================
+template <int LOGW>
+__global__ __launch_bounds__(FftGeom<LOGW>::WG) void windowed_residue_kernel(StftFastArgs a, BigScratch sc, const v2f* __restrict__ twF, uint32_t zp) {
+    using G = FftGeom<LOGW>;
+    constexpr int N = G::N, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* buf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = buf + G::LDS;
+    const uint32_t item = sc.first + blockIdx.x, q = blockIdx.y, r = blockIdx.z;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    if (col >= stft_cols(a, s) || a.last_nonzero[s] < (long long)(stft_tail(a, s) + (uint64_t)col * a.hop)) return;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    TwiddlesPow2<LOGW> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);  // exp(-2 pi i k / W)
+    for (unsigned i = threadIdx.x; i < 256u; i += (unsigned)T) tw2_lds[i] = a.tw256[i];
+    const uint32_t F = (uint32_t)N * zp;
+    const v2f* sv = sc.sv + (uint64_t)blockIdx.x * N;
+    const float* win = q == 1 ? a.dwindow : a.window;
+    const float center = (float)(N - 1) * 0.5f;
+    v2f v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const uint32_t i = ju + (unsigned)T * (unsigned)u;
+        const v2f x = sv[i];
+        float w = win[i];
+        if (q == 2) w = ((float)i - center) * w;  // compute_time_weighted (:601-608)
+        const v2f m = twF[(i * r) & (F - 1u)];     // exp(-2 pi i n r / F)
+        v[u] = cmul(v2f{x.x * w, x.y * w}, m);
+    }
+    __syncthreads();  // tw2_lds
+    fftp_inplace<false, LOGW>(v, buf, j, tw);
+    v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * (F / 2u + 1u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out[(uint64_t)(ju + (unsigned)T * (unsigned)u) * zp + r] = v[u];   // bin zp q + r, q < W / 2
+    if (j == 0 && r == 0) out[F / 2u] = v[8];                                                          // q = W / 2: the Nyquist bin
+}
+
+__global__ __launch_bounds__(1024) void reassign_stream_kernel(StftFastArgs a, BigScratch sc, uint32_t bins) {
+    __shared__ uint32_t scan[16];
+    const uint32_t item = sc.first + blockIdx.x;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    const unsigned ju = threadIdx.x;
+    const int lane = (int)(ju & 63u), wf = (int)(ju >> 6);
+    uint32_t* count_out = a.counts + (uint64_t)s * a.n_cols + col;
+    if (col >= stft_cols(a, s) || a.last_nonzero[s] < (long long)(stft_tail(a, s) + (uint64_t)col * a.hop)) {
+        if (ju == 0) *count_out = 0;
+        return;
+    }
+    const ReassignConsts rc{a.bin_hz, a.max_hz, a.inv_2pi, a.inv_hop, a.latency_hops};
+    const uint64_t per = (uint64_t)sc.count * bins;
+    const v2f* sb = sc.spec + (uint64_t)blockIdx.x * bins;
+    omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+    uint32_t running = 0;
+    for (uint32_t b0 = 0; b0 < bins; b0 += 1024u) {
+        const uint32_t bin = b0 + ju;
+        const bool valid = bin < bins;
+        const uint32_t bc = valid ? bin : 0u;
+        omx_spectrogram_point pt;
+        const bool keep = reassign_flat(bc, sb[bc], sb[per + bc], sb[2 * per + bc], a.bin_norm[bc], rc, pt) && valid;
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) scan[wf] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = running, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = scan[w];
+            if (w < wf) before += c;
+            total += c;
+        }
+        if (keep) {
+            const uint32_t pos = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + (uint64_t)pos * 12u) = pt;
+        }
+        running += total;
+        __syncthreads();  // scan[] is rewritten by the next tile
+    }
+    if (ju == 0) *count_out = running;
+}
+
+uint64_t stft_residue_scratch_bytes_per_frame(uint32_t window, uint32_t fft_size) {
+    return ((uint64_t)window + 3ull * ((uint64_t)fft_size / 2 + 1)) * sizeof(v2f);
+}
+template <int LOGW>
+static void launch_residue(const StftFastArgs& a, const v2f* twF, uint32_t zp, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {
+    using GW = FftGeom<LOGW>;
+    BigScratch sc{};
+    sc.sv = reinterpret_cast<v2f*>(scratch);
+    sc.spec = sc.sv + (uint64_t)count * GW::N;
+    sc.first = first;
+    sc.count = count;
+    const size_t lds_w = (size_t)(GW::LDS + 256) * sizeof(v2f) + 2 * sizeof(float);
+    static std::once_flag attr_once;  // (one per window size)
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hilbert_big_kernel<LOGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(windowed_residue_kernel<LOGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+    });
+    if constexpr (LOGW == 14) launch_hilbert_16k(a, sc, false, stream);
+    else hipLaunchKernelGGL(hilbert_big_kernel<LOGW>, dim3(count), dim3(GW::T), lds_w, stream, a, sc);
+    hipLaunchKernelGGL(windowed_residue_kernel<LOGW>, dim3(count, 3, zp), dim3(GW::T), lds_w, stream, a, sc, twF, zp);
+    hipLaunchKernelGGL(reassign_stream_kernel, dim3(count), dim3(1024), 0, stream, a, sc, (uint32_t)GW::N * zp / 2u + 1u);
+}
+// window 1024 ... 16384 zero-padded to zp * window > 16384 points; frames [first, first + count) of the call
+bool launch_stft_reassigned_residue(const StftFastArgs& a, uint32_t window, uint32_t zp, const v2f* twF, void* scratch, uint32_t first, uint32_t count,
+                                    hipStream_t stream) {
+    if (count == 0) return true;
+    switch (window) {
+        case 1024: launch_residue<10>(a, twF, zp, scratch, first, count, stream); return true;
+        case 2048: launch_residue<11>(a, twF, zp, scratch, first, count, stream); return true;
+        case 4096: launch_residue<12>(a, twF, zp, scratch, first, count, stream); return true;
+        case 8192: launch_residue<13>(a, twF, zp, scratch, first, count, stream); return true;
+        case 16384: launch_residue<14>(a, twF, zp, scratch, first, count, stream); return true;
+        default: return false;
+    }
+}
 // tuning only (OMX_K2_VARIANT=31): the 4096-point shape through the same three kernels, to price the fused kernel against
 // simple high-occupancy ones
 void launch_stft_reassigned_4096_split(const StftFastArgs& a, void* scratch, uint32_t first, uint32_t count, hipStream_t stream) {

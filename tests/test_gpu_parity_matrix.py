@@ -47,6 +47,42 @@ def test_reassigned_big_transforms_every_window_kind(omx, oracle, window, W, zp,
     check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop, scale=2.0 if (window == capi.WINDOW_HAMMING and zp == 8) else 1.0)
 
 
+@pytest.mark.parametrize("W,zp,hop", [(1024, 32, 256), (2048, 16, 64), (2048, 32, 64), (4096, 8, 256), (8192, 4, 512), (16384, 2, 1024), (4096, 32, 256),
+                                      (16384, 8, 2048)])
+def test_reassigned_transforms_beyond_16384_points(omx, oracle, W, zp, hop):
+    """zero padding to F = zp W > 16384 points (the GUI reaches 524288): zp W-point transforms of modulated slices per spectrum
+    (stft_pow2_kernels.hip, windowed_residue_kernel) against the oracle's single F-point transforms"""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, zero_padding_factor=zp, use_reassignment=True, history_length=16)
+    pcm = stream_pcm(6, 2 * W + hop * 2)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert g.fft_size == w.fft_size == W * zp
+    assert len(g.new_columns) == len(w.new_columns) == 3 and g.reassigned_power_scale == w.reassigned_power_scale
+    check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop)
+
+
+@pytest.mark.parametrize("window", WINDOWS)
+def test_reassigned_transforms_beyond_16384_points_every_window_kind_in_a_bank(omx, oracle, window):
+    """2048 x 16 in a bank of three streams (one of them silent: empty columns), every window kind (the residue form windows in the
+    time domain from the reference's tables)"""
+    from openmeters_amd import banks
+    W, zp, hop, S, ncols = 2048, 16, 128, 3, 4
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, window=window, zero_padding_factor=zp, use_reassignment=True, history_length=16)
+    pcm = np.stack([stream_pcm(7 + s, 2 * W + hop * (ncols - 1)) for s in range(S)])
+    pcm[1] = 0.0
+    bank = banks.SpectrogramBank(omx, cfg, S)
+    up = bank.process_host(pcm, 2, 48000.0)
+    assert up.n_columns == ncols
+    for s in range(S):
+        want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(pcm[s].reshape(-1), 2, 48000.0)).new_columns
+        got = [bank.fetch_column(s, c, capi.COLUMN_REASSIGNED, W * zp // 2 + 1) for c in range(ncols)]
+        assert [len(c) for c in got] == [len(c) for c in want] or s != 1
+        if s == 1:
+            assert all(len(c) == 0 for c in got)
+        else:
+            check_reassigned_columns(got, want, 48000.0, hop)
+
+
 @pytest.mark.parametrize("window", WINDOWS)
 def test_classic_and_spectrum_every_window_kind(omx, oracle, window):
     pcm = stream_pcm(4, 4096 + 256 * 7)
