@@ -673,7 +673,9 @@ int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uin
  *       running totals: min / max fields bit-identical, colour bands and RMS history within the bars of
  *       tests/test_gpu_parity_meters.py of the sequential order.  Non-finite or absurdly large (> 1e18) samples send the whole call
  *       through the sequential kernels.  By shape (0) it serves calls of >= 4 M stream-frames (1024 streams x 4096 frames).
- * Ragged calls and single-stream handles always run the sequential kernels. */
+ * Ragged calls take the chunk-parallel form too while their streams fall into at most 8 lock-step groups (the same frame count, push
+ * count and column phase: the host mirrors both counters) and no stream is reset by the call; otherwise — and for single-stream
+ * handles — the sequential kernels run. */
 int omx_waveform_bank_set_option(omx_waveform_bank* b, uint32_t option, uint64_t value);
 /* test hook: 1 = the bank's last lock-step call ran the sequential kernels alone, 2 = the chunk-parallel form (0 = no call yet) */
 int omx_debug_waveform_bank_last_form(const omx_waveform_bank* b);

@@ -2,6 +2,8 @@
 // (lifecycle), :308-352 (process_block / update_config).  The fractional column phase is advanced on the host with the
 // reference's exact f64 add / compare / subtract sequence so the number of emitted columns is known before launch.
 #include <algorithm>
+#include <map>
+#include <tuple>
 
 #include "waveform.hpp"
 
@@ -148,11 +150,21 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
         if (!ragged_) {  // every stream starts from the bank's common push count and column phase
             r_pushes_.upload(std::vector<uint64_t>(n_streams_, pushes_), stream);
             r_phase_.upload(std::vector<double>(n_streams_, column_phase_), stream);
+            h_pushes_.assign(n_streams_, pushes_);   // the host's mirror of the two (run_chunked_ragged)
+            h_phase_.assign(n_streams_, column_phase_);
+            mirror_valid_ = true;
             ragged_ = true;
             ragged_zero_phase_ = ragged_zero_pushes_ = false;
         }
-        if (ragged_zero_phase_) OMX_HIP(hipMemsetAsync(r_phase_.ptr, 0, n_streams_ * sizeof(double), stream));
-        if (ragged_zero_pushes_) OMX_HIP(hipMemsetAsync(r_pushes_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
+        if (ragged_zero_phase_) {
+            OMX_HIP(hipMemsetAsync(r_phase_.ptr, 0, n_streams_ * sizeof(double), stream));
+            std::fill(h_phase_.begin(), h_phase_.end(), 0.0);
+        }
+        if (ragged_zero_pushes_) {
+            OMX_HIP(hipMemsetAsync(r_pushes_.ptr, 0, n_streams_ * sizeof(uint64_t), stream));
+            std::fill(h_pushes_.begin(), h_pushes_.end(), 0ull);
+        }
+        if (ragged_zero_phase_ && ragged_zero_pushes_) mirror_valid_ = true;  // (a rebuild makes every stream equal again)
         ragged_zero_phase_ = ragged_zero_pushes_ = false;
         r_frames_.reserve(n_streams_);
         r_mask_.reserve(n_streams_);
@@ -187,6 +199,8 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
         wa.cols_v = r_cols_.ptr;
         wa.progress_v = r_progress_.ptr;
         wa.max_cols = max_cols;
+        last_form_ = 1;
+        if (channels == 2 && run_chunked_ragged(wa, ragged->frames, ragged->reset_mask, max_cols, step, stream)) last_form_ = 2;
         launch_waveform(wa, stream);
         OMX_HIP(hipGetLastError());
         last_cols_ = max_cols;
@@ -311,61 +325,65 @@ static std::vector<double> wave_transitions(const BiquadCoef& lp_lo, const Biqua
     return T;
 }
 
-// The chunk-parallel form of one lock-step call (waveform_chunked.hip): builds the plan — cuts, segments, column table — and enqueues
-// its kernels.  Returns false when the call's shape is not served (the caller then runs the sequential kernel alone); after a true
-// return the caller still launches the sequential kernel, predicated on the `bad` flag (wa.run_if).
-bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream) {
-    const uint64_t frames = wa.frames;
-    if (form_ == 1 || !analysis_ || frames % 2 != 0 || frames < 1024 || frames > 0x3FFFFFFFull) return false;
-    if (color_len_ < 64 || slow_len_ < 64 || slow_len_ > 0x3FFFFFFFu) return false;
-    if (form_ != 2 && (uint64_t)n_streams_ * frames < (4ull << 20)) return false;  // small calls: the sequential kernels' latency is lower
-    const bool history = wa.track_history != 0;
-    uint32_t C = 256;
-    // enough (chunk, 64 streams) workgroups of three wavefronts to fill the SIMDs several times over: 131072 items = 2048 workgroups
-    static const uint64_t want_items = [] {
-        const char* e = tuning_env("OMX_WAVE_CHUNK_ITEMS");  // tuning hook
-        return e ? (uint64_t)std::atoll(e) : 131072ull;
-    }();
-    while (C > 64 && (uint64_t)n_streams_ * ((frames + C - 1) / C) < want_items) C /= 2;
+// ---- the chunk-parallel form (waveform_chunked.hip).  A GROUP is a set of streams that move in lock step through a call: the same frame
+// count, tracker push count and column phase, hence the same plan (cuts, segments, column table).  A lock-step call is one group
+// of all streams; a ragged call has one group per distinct (frames, pushes, phase, reset) among its streams.
+struct WaveformBank::ChunkGroup {
+    uint64_t frames = 0, pushes0 = 0;
+    std::vector<uint32_t> column_ends;   // every column the call emits
+    uint64_t first_kept = 0;             // columns before this one are dropped (cap_pending_columns, lock-step calls)
+    std::vector<uint32_t> streams;       // bank indices (empty: all streams, identity)
+    uint32_t write_preview = 0;
+    // filled by the planner
+    std::vector<int32_t> cuts;
+    std::vector<uint32_t> chunk_seg;
+    std::vector<WaveEval> evals;
+    uint32_t n_segs = 0, n_old = 0, C = 0, n_chunks = 0;
+};
+
+// cuts, segments and the column table of one group; false when the shape is not served
+static bool plan_chunk_group(WaveformBank::ChunkGroup& g, uint32_t C, bool history, uint32_t color_len, uint32_t slow_len) {
+    const uint64_t frames = g.frames;
     const uint32_t n_chunks = (uint32_t)((frames + C - 1) / C);
     const int64_t F = (int64_t)frames;
-    const uint64_t P0 = pushes_, Pend = pushes_ + frames;
+    const uint64_t P0 = g.pushes0, Pend = P0 + frames;
     const uint32_t nwin = history ? 3u : 1u;
-    const int64_t caps[3] = {(int64_t)color_len_, (int64_t)color_len_, (int64_t)slow_len_};
-    const uint64_t ring_len[3] = {color_len_, slow_len_, slow_len_};  // buffer length of the WindowedMeans the window lives in
-    const int64_t maxcap = history ? (int64_t)slow_len_ : (int64_t)color_len_;
-    const uint64_t n_emit = wa.n_emit, first_kept = wa.first_kept, kept = n_emit - first_kept;
+    const int64_t caps[3] = {(int64_t)color_len, (int64_t)color_len, (int64_t)slow_len};
+    const uint64_t ring_len[3] = {color_len, slow_len, slow_len};  // buffer length of the WindowedMeans the window lives in
+    const int64_t maxcap = history ? (int64_t)slow_len : (int64_t)color_len;
+    const uint64_t n_emit = g.column_ends.size(), first_kept = g.first_kept, kept = n_emit - first_kept;
 
-    // ---- cuts
-    std::vector<int32_t> cuts;
-    cuts.reserve(column_ends.size() + (size_t)(kept + 1) * nwin + n_chunks + (size_t)(maxcap / 256) + 16);
+    std::vector<int32_t>& cuts = g.cuts;
+    cuts.clear();
+    cuts.reserve(n_emit + (size_t)(kept + 1) * nwin + n_chunks + (size_t)(maxcap / 256) + 16);
     cuts.push_back(-1);
     cuts.push_back((int32_t)-maxcap);
-    for (int64_t g = -1 - 256; g > -maxcap; g -= 256) cuts.push_back((int32_t)g);  // a grid over the rings' contents (parallelism of the old sums)
+    for (int64_t q = -1 - 256; q > -maxcap; q -= 256) cuts.push_back((int32_t)q);  // a grid over the rings' contents (parallelism of the old sums)
     for (uint32_t c = 1; c <= n_chunks; ++c) cuts.push_back((int32_t)(std::min<int64_t>((int64_t)c * C, F) - 1));
-    for (uint32_t f : column_ends) cuts.push_back((int32_t)f);
+    for (uint32_t f : g.column_ends) cuts.push_back((int32_t)f);
     auto add_windows = [&](int64_t f) {
         for (uint32_t w = 0; w < nwin; ++w) cuts.push_back((int32_t)(f - caps[w]));
     };
-    for (uint64_t q = first_kept; q < n_emit; ++q) add_windows((int64_t)column_ends[q]);
+    for (uint64_t q = first_kept; q < n_emit; ++q) add_windows((int64_t)g.column_ends[q]);
     add_windows(F - 1);
-    int64_t refresh_cut[3];
+    int64_t refresh_cut[3] = {0, 0, 0};
     for (uint32_t w = 0; w < nwin; ++w) {  // refresh_counts (dsp.rs:346-352): the pair restarts at every multiple of the capacity
         const uint64_t r = Pend / (uint64_t)caps[w] * (uint64_t)caps[w];
-        refresh_cut[w] = (int64_t)r - (int64_t)P0 - 1;
+        refresh_cut[w] = std::max<int64_t>((int64_t)r - (int64_t)P0 - 1, -maxcap);
         cuts.push_back((int32_t)refresh_cut[w]);
     }
     std::sort(cuts.begin(), cuts.end());
     cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-    const uint32_t n_segs = (uint32_t)cuts.size() - 1;
-    if (n_segs > 4096) return false;  // (thousands of columns per call: the plan's scratch grows with segments x streams)
+    g.n_segs = (uint32_t)cuts.size() - 1;
+    if (g.n_segs > 4096) return false;  // (thousands of columns per call: the plan's scratch grows with segments x streams)
     auto index_of = [&](int64_t cut) { return (uint32_t)(std::lower_bound(cuts.begin(), cuts.end(), (int32_t)cut) - cuts.begin()); };
     const uint32_t n_old = index_of(-1);
-
-    // ---- plan blob: cuts, first segment of every chunk, column table
-    std::vector<uint32_t> chunk_seg(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; ++c) chunk_seg[c] = index_of((int64_t)c * C - 1);
-    std::vector<WaveEval> evals((size_t)kept + 1);
+    g.n_old = n_old;
+    g.C = C;
+    g.n_chunks = n_chunks;
+    g.chunk_seg.resize(n_chunks);
+    for (uint32_t c = 0; c < n_chunks; ++c) g.chunk_seg[c] = index_of((int64_t)c * C - 1);
+    g.evals.assign((size_t)kept + 1, WaveEval{});
     auto fill = [&](WaveEval& ev, int64_t f) {
         ev.idx_end = index_of(f);
         for (uint32_t w = 0; w < 3; ++w) {
@@ -378,85 +396,248 @@ bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& co
     };
     for (uint64_t i = 0; i < kept; ++i) {
         const uint64_t q = first_kept + i;
-        WaveEval& ev = evals[(size_t)i];
-        fill(ev, (int64_t)column_ends[q]);
-        ev.mm_from = (q == 0 ? n_old : index_of((int64_t)column_ends[q - 1])) - n_old;
+        WaveEval& ev = g.evals[(size_t)i];
+        fill(ev, (int64_t)g.column_ends[q]);
+        ev.mm_from = (q == 0 ? n_old : index_of((int64_t)g.column_ends[q - 1])) - n_old;
         ev.mm_to = ev.idx_end - n_old;
         ev.out = (uint32_t)i;
         ev.carry = q == 0 ? 1u : 0u;
     }
     {
-        WaveEval& ev = evals[(size_t)kept];
+        WaveEval& ev = g.evals[(size_t)kept];
         fill(ev, F - 1);
         for (uint32_t w = 0; w < nwin; ++w) ev.idx_refresh[w] = index_of(refresh_cut[w]);
-        ev.mm_from = (n_emit == 0 ? n_old : index_of((int64_t)column_ends[n_emit - 1])) - n_old;
+        ev.mm_from = (n_emit == 0 ? n_old : index_of((int64_t)g.column_ends[n_emit - 1])) - n_old;
         ev.mm_to = ev.idx_end - n_old;
         ev.out = 0xFFFFFFFFu;
         ev.carry = n_emit == 0 ? 1u : 0u;
     }
-    const size_t cuts_bytes = cuts.size() * sizeof(int32_t), seg_bytes = chunk_seg.size() * sizeof(uint32_t);
-    const size_t evals_bytes = evals.size() * sizeof(WaveEval);
-    std::vector<uint8_t> blob(cuts_bytes + seg_bytes + evals_bytes);
-    std::memcpy(blob.data(), cuts.data(), cuts_bytes);
-    std::memcpy(blob.data() + cuts_bytes, chunk_seg.data(), seg_bytes);
-    std::memcpy(blob.data() + cuts_bytes + seg_bytes, evals.data(), evals_bytes);
-    plan_.reserve(blob.size() + 4096);
-    plan_staging_.upload(blob.data(), blob.size(), plan_.ptr, stream);
+    return true;
+}
 
+static bool chunk_shape_ok(uint64_t frames) { return frames % 2 == 0 && frames >= 1024 && frames <= 0x3FFFFFFFull; }
+
+// Plans every group, uploads the plans as one blob and enqueues the kernels: phase 1 (scratch only, may raise `bad`) of every
+// group, then phase 2 of every group.  False (nothing enqueued) when a group's shape is not served.
+bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<ChunkGroup>& groups, uint64_t pcm_stride, uint64_t col_stride,
+                                       hipStream_t stream) {
+    const bool history = wa.track_history != 0;
+    auto pad16 = [](size_t n) { return (n + 15) / 16 * 16; };
+    size_t blob_bytes = 0;
+    uint64_t state_floats = 0, segs_room = 0, local_max = 0;
+    uint32_t C = 0;
+    // chunk length (one per call: one transition table): enough (chunk, 64 streams) workgroups of three wavefronts to fill the SIMDs
+    // several times over — 131072 (stream, chunk) items = 2048 workgroups
+    static const uint64_t want_items = [] {
+        const char* e = tuning_env("OMX_WAVE_CHUNK_ITEMS");  // tuning hook
+        return e ? (uint64_t)std::atoll(e) : 131072ull;
+    }();
+    C = 256;
+    auto items = [&](uint32_t c) {
+        uint64_t n = 0;
+        for (const ChunkGroup& g : groups) n += (uint64_t)(g.streams.empty() ? n_streams_ : g.streams.size()) * ((g.frames + c - 1) / c);
+        return n;
+    };
+    while (C > 64 && items(C) < want_items) C /= 2;
+    for (ChunkGroup& g : groups)
+        if (!plan_chunk_group(g, C, history, color_len_, slow_len_)) return false;
+    for (ChunkGroup& g : groups) {
+        const uint32_t n_local = g.streams.empty() ? n_streams_ : (uint32_t)g.streams.size();
+        blob_bytes += pad16(g.cuts.size() * sizeof(int32_t)) + pad16(g.chunk_seg.size() * sizeof(uint32_t)) + pad16(g.evals.size() * sizeof(WaveEval)) +
+                      pad16(g.streams.size() * sizeof(uint32_t));
+        state_floats += (uint64_t)g.n_chunks * n_local * 3 * 16;
+        segs_room = std::max<uint64_t>(segs_room, ((uint64_t)g.n_segs + 1 + 63) / 64 * 64 + 64);  // (the count moves by a few from call to call)
+        local_max = std::max<uint64_t>(local_max, n_local);
+    }
+    std::vector<uint8_t> blob(blob_bytes);
+    plan_.reserve(blob_bytes + 65536);
     if (transition_rate_ != cfg_.sample_rate || transition_frames_ != C) {
         transition_.upload(wave_transitions(wa.lp_lo, wa.hp_lo, wa.lp_hi, wa.hp_hi, C), stream);
         transition_rate_ = cfg_.sample_rate;
         transition_frames_ = C;
     }
-    const uint64_t per_cut = (uint64_t)n_streams_ * 24;
-    const uint64_t segs_room = (n_segs + 1 + 63) / 64 * 64 + 64;  // (the count moves by a few from call to call: no reallocation for that)
-    chunk_state_.reserve((size_t)((uint64_t)n_chunks * n_streams_ * 3 * 16));
+    const uint64_t per_cut = local_max * 24;
+    chunk_state_.reserve((size_t)state_floats);
     seg_sum_.reserve((size_t)(segs_room * per_cut));
-    seg_mm_.reserve((size_t)(segs_room * n_streams_ * 12));
+    seg_mm_.reserve((size_t)(segs_room * local_max * 12));
     prefix_.reserve((size_t)(segs_room * per_cut * 2));
-    plan_.reserve(blob.size() + 4096);
     bad_.reserve(1);
     OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
 
-    WaveChunkArgs ca{};
-    ca.pcm = wa.pcm;
-    ca.frames = frames;
-    ca.n_streams = n_streams_;
-    ca.m00 = wa.fmt.m[0][0];
-    ca.m10 = wa.fmt.m[1][0];
-    ca.m01 = wa.fmt.m[0][1];
-    ca.m11 = wa.fmt.m[1][1];
-    ca.lp_lo = wa.lp_lo;
-    ca.hp_lo = wa.hp_lo;
-    ca.lp_hi = wa.lp_hi;
-    ca.hp_hi = wa.hp_hi;
-    ca.history = history ? 1u : 0u;
-    ca.chunk_frames = C;
-    ca.n_chunks = n_chunks;
-    ca.pushes0 = P0;
-    ca.color_len = color_len_;
-    ca.slow_len = slow_len_;
-    ca.color_ring = color_ring_.ptr;
-    ca.hist_ring = hist_ring_.ptr;
-    ca.state = state_.ptr;
-    ca.cuts = reinterpret_cast<const int32_t*>(plan_.ptr);
-    ca.n_segs = n_segs;
-    ca.n_old_segs = n_old;
-    ca.chunk_seg = reinterpret_cast<const uint32_t*>(plan_.ptr + cuts_bytes);
-    ca.evals = reinterpret_cast<const WaveEval*>(plan_.ptr + cuts_bytes + seg_bytes);
-    ca.n_evals = (uint32_t)evals.size();
-    ca.chunk_state = chunk_state_.ptr;
-    ca.seg_sum = seg_sum_.ptr;
-    ca.seg_mm = seg_mm_.ptr;
-    ca.prefix_hi = prefix_.ptr;
-    ca.prefix_lo = prefix_.ptr + (uint64_t)(n_segs + 1) * per_cut;
-    ca.bad = bad_.ptr;
-    ca.columns = wa.columns;
-    ca.preview = wa.preview;
-    ca.n_kept = kept;
-    ca.write_preview = wa.write_preview;
-    launch_waveform_chunked(ca, transition_.ptr, stream);
+    std::vector<WaveChunkArgs> args(groups.size());
+    size_t at = 0;
+    uint64_t state_at = 0;
+    for (size_t k = 0; k < groups.size(); ++k) {
+        ChunkGroup& g = groups[k];
+        const uint32_t n_local = g.streams.empty() ? n_streams_ : (uint32_t)g.streams.size();
+        WaveChunkArgs& ca = args[k];
+        ca = WaveChunkArgs{};
+        auto put = [&](const void* src, size_t bytes) {
+            const size_t here = at;
+            if (bytes) std::memcpy(blob.data() + at, src, bytes);
+            at += pad16(bytes);
+            return plan_.ptr + here;
+        };
+        ca.cuts = reinterpret_cast<const int32_t*>(put(g.cuts.data(), g.cuts.size() * sizeof(int32_t)));
+        ca.chunk_seg = reinterpret_cast<const uint32_t*>(put(g.chunk_seg.data(), g.chunk_seg.size() * sizeof(uint32_t)));
+        ca.evals = reinterpret_cast<const WaveEval*>(put(g.evals.data(), g.evals.size() * sizeof(WaveEval)));
+        const uint8_t* map = put(g.streams.data(), g.streams.size() * sizeof(uint32_t));
+        ca.stream_map = g.streams.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map);
+        ca.n_local = n_local;
+        ca.pcm = wa.pcm;
+        ca.frames = g.frames;
+        ca.pcm_stride = pcm_stride;
+        ca.n_streams = n_streams_;
+        ca.m00 = wa.fmt.m[0][0];
+        ca.m10 = wa.fmt.m[1][0];
+        ca.m01 = wa.fmt.m[0][1];
+        ca.m11 = wa.fmt.m[1][1];
+        ca.lp_lo = wa.lp_lo;
+        ca.hp_lo = wa.hp_lo;
+        ca.lp_hi = wa.lp_hi;
+        ca.hp_hi = wa.hp_hi;
+        ca.history = history ? 1u : 0u;
+        ca.chunk_frames = g.C;
+        ca.n_chunks = g.n_chunks;
+        ca.pushes0 = g.pushes0;
+        ca.color_len = color_len_;
+        ca.slow_len = slow_len_;
+        ca.color_ring = color_ring_.ptr;
+        ca.hist_ring = hist_ring_.ptr;
+        ca.state = state_.ptr;
+        ca.n_segs = g.n_segs;
+        ca.n_old_segs = g.n_old;
+        ca.n_evals = (uint32_t)g.evals.size();
+        ca.chunk_state = chunk_state_.ptr + state_at;
+        state_at += (uint64_t)g.n_chunks * n_local * 3 * 16;
+        ca.seg_sum = seg_sum_.ptr;
+        ca.seg_mm = seg_mm_.ptr;
+        ca.prefix_hi = prefix_.ptr;
+        ca.prefix_lo = prefix_.ptr + (uint64_t)(g.n_segs + 1) * n_local * 24;
+        ca.bad = bad_.ptr;
+        ca.columns = wa.columns;
+        ca.preview = wa.preview;
+        ca.col_stride = col_stride;
+        ca.write_preview = g.write_preview;
+    }
+    plan_staging_.upload(blob.data(), blob.size(), plan_.ptr, stream);
+    for (const WaveChunkArgs& ca : args) launch_waveform_chunked_phase1(ca, transition_.ptr, stream);
+    for (const WaveChunkArgs& ca : args) launch_waveform_chunked_phase2(ca, stream);
     OMX_HIP(hipGetLastError());
+    return true;
+}
+
+// The chunk-parallel form of one lock-step call.  Returns false when the call's shape is not served (the caller then runs the
+// sequential kernel alone); after a true return the caller still launches the sequential kernel, predicated on the `bad` flag.
+bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream) {
+    const uint64_t frames = wa.frames;
+    if (form_ == 1 || !analysis_ || !chunk_shape_ok(frames)) return false;
+    if (color_len_ < 64 || slow_len_ < 64 || slow_len_ > 0x3FFFFFFFu) return false;
+    if (form_ != 2 && (uint64_t)n_streams_ * frames < (4ull << 20)) return false;  // small calls: the sequential kernels' latency is lower
+    std::vector<ChunkGroup> groups(1);
+    groups[0].frames = frames;
+    groups[0].pushes0 = pushes_;
+    groups[0].column_ends = column_ends;
+    groups[0].first_kept = wa.first_kept;
+    groups[0].write_preview = wa.write_preview;
+    if (!launch_chunk_groups(wa, groups, frames, wa.n_emit - wa.first_kept, stream)) return false;
+    wa.run_if = bad_.ptr;
+    return true;
+}
+
+// The chunk-parallel form of a ragged call: the host keeps a mirror of every stream's push count and column phase (both are pure
+// functions of the frame counts and reset flags it has been handed), sorts the call's streams into groups that move in lock step,
+// and runs one plan per group.  More than kMaxGroups distinct (frames, pushes, phase) among the streams, or a group whose shape the
+// chunk form does not serve: the sequential kernel does the call (the mirror stays valid as long as its replay stays cheap).
+bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, const uint8_t* reset_mask, uint64_t max_cols, double step,
+                                      hipStream_t stream) {
+    constexpr size_t kMaxGroups = 8;
+    if (!mirror_valid_) return false;
+    struct Key {
+        uint64_t frames, pushes, phase_bits;
+        bool operator<(const Key& o) const { return std::tie(frames, pushes, phase_bits) < std::tie(o.frames, o.pushes, o.phase_bits); }
+    };
+    std::map<Key, std::vector<uint32_t>> classes;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        const bool reset = reset_mask && reset_mask[s];
+        Key k{frames[s], reset ? 0 : h_pushes_[s], 0};
+        const double ph = reset ? 0.0 : h_phase_[s];
+        std::memcpy(&k.phase_bits, &ph, sizeof(double));
+        classes[k].push_back(s);
+        if (classes.size() > 4 * kMaxGroups) {  // replaying that many phases on the host costs more than the call: give the mirror up
+            mirror_valid_ = false;
+            return false;
+        }
+    }
+    // replay every class's phase (the reference's f64 add / compare / subtract, :287-291) and advance the mirror — whichever kernels run
+    std::vector<ChunkGroup> groups;
+    bool servable = classes.size() <= kMaxGroups && form_ != 1 && analysis_ && color_len_ >= 64 && slow_len_ >= 64 && slow_len_ <= 0x3FFFFFFFu;
+    uint64_t work = 0;
+    std::vector<uint32_t> h_cols(n_streams_, 0);
+    std::vector<float> h_progress(n_streams_, 0.0f);
+    for (auto& kv : classes) {
+        const Key& k = kv.first;
+        double phase;
+        std::memcpy(&phase, &k.phase_bits, sizeof(double));
+        ChunkGroup g;
+        g.frames = k.frames;
+        g.pushes0 = k.pushes;
+        for (uint64_t f = 0; f < k.frames; ++f) {
+            phase += step;
+            if (phase >= 1.0) {
+                g.column_ends.push_back((uint32_t)f);
+                phase -= 1.0;
+            }
+        }
+        const float progress = (float)std::min(std::max(phase, 0.0), 1.0);
+        g.write_preview = progress > 0.0f ? 1u : 0u;
+        g.streams = kv.second;
+        for (uint32_t s : kv.second) {
+            const bool reset = reset_mask && reset_mask[s];
+            if (k.frames != 0 || reset) {
+                h_pushes_[s] = k.pushes + (analysis_ ? k.frames : 0);
+                h_phase_[s] = phase;
+            }
+            h_cols[s] = (uint32_t)std::min<uint64_t>(g.column_ends.size(), max_cols);
+            h_progress[s] = progress;
+        }
+        if (k.frames == 0) {
+            bool any_reset = false;
+            for (uint32_t s : kv.second) any_reset = any_reset || (reset_mask && reset_mask[s]);
+            if (any_reset) servable = false;  // (a reset without frames: the sequential kernel's business)
+            continue;                          // nothing to do for these streams
+        }
+        if (!chunk_shape_ok(k.frames) || g.column_ends.size() > max_cols) servable = false;
+        work += (uint64_t)kv.second.size() * k.frames;
+        groups.push_back(std::move(g));
+    }
+    if (!servable || groups.empty()) return false;
+    if (form_ != 2 && work < (4ull << 20)) return false;
+    // streams whose reset flag is set start from a cleared state (the rings need no clearing: nothing older than the push count is read)
+    std::vector<uint32_t> resets;
+    for (uint32_t s = 0; s < n_streams_; ++s)
+        if (reset_mask && reset_mask[s]) resets.push_back(s);
+    // streams without frames keep their columns count 0 and their old preview: the sequential kernel reports progress for them too
+    for (auto& kv : classes)
+        if (kv.first.frames == 0)
+            for (uint32_t s : kv.second) {
+                double ph = h_phase_[s];
+                h_progress[s] = (float)std::min(std::max(ph, 0.0), 1.0);
+            }
+    if (!resets.empty()) return false;  // (kept simple: calls that reset streams run the sequential kernel; the mirror above already follows them)
+    if (!launch_chunk_groups(wa, groups, wa.frames, max_cols, stream)) return false;
+    // the per-stream counters the sequential kernels and the caller read: push counts, phases, column counts, preview progress
+    const size_t n = n_streams_;
+    std::vector<uint8_t> blob(n * (sizeof(uint64_t) + sizeof(double) + sizeof(uint32_t) + sizeof(float)));
+    uint8_t* p = blob.data();
+    std::memcpy(p, h_pushes_.data(), n * sizeof(uint64_t));
+    std::memcpy(p + n * 8, h_phase_.data(), n * sizeof(double));
+    std::memcpy(p + n * 16, h_cols.data(), n * sizeof(uint32_t));
+    std::memcpy(p + n * 20, h_progress.data(), n * sizeof(float));
+    mirror_dev_.reserve(blob.size());
+    mirror_staging_.upload(blob.data(), blob.size(), mirror_dev_.ptr, stream);
+    // ... copied into pushes_v / phase_v / cols_v / progress_v behind the chunk kernels, unless `bad` (then the sequential kernel writes them)
+    launch_waveform_mirror_copy(mirror_dev_.ptr, n_streams_, wa.pushes_v, wa.phase_v, wa.cols_v, wa.progress_v, bad_.ptr, stream);
     wa.run_if = bad_.ptr;
     return true;
 }

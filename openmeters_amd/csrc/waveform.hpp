@@ -60,9 +60,12 @@ struct WaveEval {  // one kept column, or (out = 0xFFFFFFFF) the pseudo-column a
     uint32_t carry;           // the column began before this call: merge the carried column state
 };
 struct WaveChunkArgs {
-    const float* pcm;  // [n_streams][frames][2]
-    uint64_t frames;
-    uint32_t n_streams;
+    const float* pcm;  // [n_streams][pcm_stride][2]
+    uint64_t frames;   // frames of this group's streams in this call
+    uint64_t pcm_stride;
+    uint32_t n_streams;          // streams of the bank (ring row stride, state index)
+    const uint32_t* stream_map;  // [n_local] bank index of the group's streams (nullptr: identity)
+    uint32_t n_local;            // streams of the group: every scratch array is indexed by the LOCAL stream
     float m00, m10, m01, m11;  // the two-channel fold
     BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;
     uint32_t history;
@@ -83,12 +86,17 @@ struct WaveChunkArgs {
     double* prefix_hi;          // [n_segs + 1][n_streams][24]
     double* prefix_lo;
     uint32_t* bad;
-    omx_wave_column* columns;   // [n_streams][n_kept][4]
+    omx_wave_column* columns;   // [n_streams][col_stride][4]
     omx_wave_column* preview;
-    uint64_t n_kept;
+    uint64_t col_stride;
     uint32_t write_preview;
 };
-void launch_waveform_chunked(const WaveChunkArgs& a, const double* d_T, hipStream_t stream);
+void launch_waveform_chunked_phase1(const WaveChunkArgs& a, const double* d_T, hipStream_t stream);
+void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream);
+// ragged calls: the host's per-stream counters ([n] u64 pushes, [n] f64 phases, [n] u32 columns, [n] f32 progress, packed) -> the device
+// arrays the sequential kernels and the caller read, unless *bad (then the sequential kernel writes them itself)
+void launch_waveform_mirror_copy(const uint8_t* src, uint32_t n, uint64_t* pushes_v, double* phase_v, uint32_t* cols_v, float* progress_v,
+                                 const uint32_t* bad, hipStream_t stream);
 // role-per-wavefront form (waveform_roles_kernels.hip); launch_waveform picks it whenever it applies (OMX_WAVEFORM_SINGLE=1 pins
 // the one-wavefront kernel: A/B runs and the bit-identity test)
 bool waveform_roles_applicable(const WaveformArgs& a);
@@ -117,6 +125,7 @@ public:
     int fetch(uint64_t stream_index, omx_wave_column* columns, omx_wave_column* preview, hipStream_t stream);
     hipStream_t last_stream() const { return last_stream_; }
     uint64_t last_columns() const { return last_cols_; }
+    struct ChunkGroup;  // a set of streams that move in lock step through a call of the chunk-parallel form (waveform.cpp)
     void set_form(uint32_t form) { form_ = form; }  // OMX_OPT_KERNEL_FORM: 0 by call shape, 1 sequential, 2 chunk-parallel where it applies
     uint32_t last_form() const { return last_form_; }
 
@@ -154,6 +163,14 @@ private:
     RaggedStaging r_staging_;
     // chunk-parallel form
     bool run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream);
+    bool run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, const uint8_t* reset_mask, uint64_t max_cols, double step, hipStream_t stream);
+    bool launch_chunk_groups(const WaveformArgs& wa, std::vector<ChunkGroup>& groups, uint64_t pcm_stride, uint64_t col_stride, hipStream_t stream);
+    // ragged mode: the host's mirror of the per-stream push counts and column phases (valid while few distinct values exist)
+    std::vector<uint64_t> h_pushes_;
+    std::vector<double> h_phase_;
+    bool mirror_valid_ = false;
+    BlobStaging mirror_staging_;
+    DeviceBuffer<uint8_t> mirror_dev_;
     uint32_t form_ = 0, last_form_ = 0;
     DeviceBuffer<double> transition_;
     float transition_rate_ = 0.0f;

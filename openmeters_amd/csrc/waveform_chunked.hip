@@ -75,8 +75,8 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     if (PASS_B && *a.bad != 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t groups = (a.n_streams + 63u) / 64u;
-    const uint32_t c = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 64u;
+    const uint32_t groups = (a.n_local + 63u) / 64u;
+    const uint32_t c = blockIdx.x / groups, s0 = (blockIdx.x % groups) * 64u;  // s0: first LOCAL stream (a.stream_map: local -> bank index)
     const uint32_t f0 = c * a.chunk_frames;
     const uint32_t n = min(a.chunk_frames, (uint32_t)(a.frames - f0));  // frames of this chunk (even: the host checks)
     const uint32_t steps = (n + STEP - 1u) / STEP;
@@ -89,9 +89,10 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     for (int k = 0; k < 3; ++k) {
         const uint32_t q = tid + (uint32_t)k * 192u;
         const uint32_t row = q >> 3, part = q & 7u;
-        const uint32_t s = s0 + row;
-        live[k] = q < 512u && s < a.n_streams;
-        src[k] = a.pcm + ((uint64_t)(live[k] ? s : 0u) * a.frames + f0) * 2u + part * 4u;
+        const uint32_t sl = s0 + row;
+        live[k] = q < 512u && sl < a.n_local;
+        const uint32_t s = live[k] ? (a.stream_map ? a.stream_map[sl] : sl) : 0u;
+        src[k] = a.pcm + ((uint64_t)s * a.pcm_stride + f0) * 2u + part * 4u;
         dst[k] = row * ROW_FLOATS + part * 4u;
         part2[k] = part * 2u;
     }
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     };
 
     // ---- per-lane recurrence state
-    const uint32_t s = s0 + lane;
-    const bool mine = s < a.n_streams;
+    const uint32_t sl = s0 + lane;
+    const bool mine = sl < a.n_local;
+    const uint32_t s = mine ? (a.stream_map ? a.stream_map[sl] : sl) : 0u;
     const BiquadCoef ca = a.hp_lo, cb = role == 0 ? a.lp_lo : (role == 1 ? a.lp_hi : a.hp_hi);
     v2f za0{0.0f, 0.0f}, za1{0.0f, 0.0f}, zb0{0.0f, 0.0f}, zb1{0.0f, 0.0f};  // stage A (mid band only), stage B
     // pass A, roles 0 and 1 (the bands with a 200 Hz section): f64 — their chunk-boundary states follow the exact trajectory of the
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     // boundary states the mid band sat 3 ... 4x further from the f64 recurrence than the reference's own evaluation after level
     // steps (tests/test_gpu_parity_meters.py, random sequences; the stereometer's low band taught the same in stereometer_chunked.hip)
     double da0[2] = {0.0, 0.0}, da1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
-    float* cs = a.chunk_state + (((uint64_t)c * a.n_streams + (mine ? s : 0u)) * 3u + role) * 16u;
+    float* cs = a.chunk_state + (((uint64_t)c * a.n_local + (mine ? sl : 0u)) * 3u + role) * 16u;
     double* cs64 = reinterpret_cast<double*>(cs);
     if (PASS_B && mine) {  // the chunk's true start state ([state k][side]: role 0 LP z0, z1; role 1 A z0, A z1, B z0, B z1 — f64; role 2 f32)
         if (role == 0) {
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
     // of every row as one 16-byte store (as 12 scattered 4-byte stores per stream and frame the pass was bound by L2 write
     // requests: 1.08 ms with RMS history on, 1024 streams x 16 384 frames).
     float* xbuf = tile + 2 * 64 * ROW_FLOATS;   // [series][frame of the half][stream][12]
-    float* cring = a.color_ring + (uint64_t)(mine ? s : 0u) * 16u + role * 4u;
-    float* hring = a.hist_ring + (uint64_t)(mine ? s : 0u) * 16u + role * 4u;
+    float* cring = a.color_ring + (uint64_t)s * 16u + role * 4u;
+    float* hring = a.hist_ring + (uint64_t)s * 16u + role * 4u;
     uint32_t half_slot_c = 0, half_slot_h = 0;
 
     issue(0);
@@ -233,14 +235,14 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
                 slot_h = slot_h + 1u == a.slow_len ? 0u : slot_h + 1u;
                 if ((int32_t)g == next_cut) {  // uniform: the segment ends with this frame
                     if (mine) {
-                        double* out = a.seg_sum + ((uint64_t)seg * a.n_streams + s) * 24u + role;
+                        double* out = a.seg_sum + ((uint64_t)seg * a.n_local + sl) * 24u + role;
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
                             out[ch * 3] = acc_c[ch];
                             if (history) out[12 + ch * 3] = acc_p[ch];
                         }
                         if (role == 0) {
-                            float* mm = a.seg_mm + ((uint64_t)(seg - a.n_old_segs) * a.n_streams + s) * 12u;
+                            float* mm = a.seg_mm + ((uint64_t)(seg - a.n_old_segs) * a.n_local + sl) * 12u;
                             const float dv[4] = {x[f].x, x[f].y, (x[f].x + x[f].y) * 0.5f, (x[f].x - x[f].y) * 0.5f};
 #pragma unroll
                             for (int ch = 0; ch < 4; ++ch) {
@@ -325,8 +327,9 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 template <int N, bool F64IO>
-__device__ __forceinline__ void scan_wave(const WaveChunkArgs& a, const double* __restrict__ Tp /* [6][4][4] */, uint32_t s, uint32_t role,
+__device__ __forceinline__ void scan_wave(const WaveChunkArgs& a, const double* __restrict__ Tp /* [6][4][4] */, uint32_t sl, uint32_t role,
                                           uint32_t side, uint32_t lane) {
+    const uint32_t s = a.stream_map ? a.stream_map[sl] : sl;
     const WaveLaneState& st = a.state[(uint64_t)s * 16u + role];  // the band's lane of channel Left
     double carry[N];
     if (role == 1) {
@@ -342,7 +345,7 @@ __device__ __forceinline__ void scan_wave(const WaveChunkArgs& a, const double* 
     for (uint32_t c0 = 0; c0 < nb; c0 += 64u) {
         const uint32_t c = c0 + lane;
         const bool live = c < nb;
-        float* cs = a.chunk_state + (((uint64_t)(live ? c : c0) * a.n_streams + s) * 3u + role) * 16u;
+        float* cs = a.chunk_state + (((uint64_t)(live ? c : c0) * a.n_local + sl) * 3u + role) * 16u;
         double* cs64 = reinterpret_cast<double*>(cs);
         double x[N];
 #pragma unroll
@@ -393,8 +396,8 @@ __device__ __forceinline__ void scan_wave(const WaveChunkArgs& a, const double* 
 __global__ __launch_bounds__(256) void wave_scan_states_kernel(WaveChunkArgs a, const double* __restrict__ T /* [3][6][4][4] */) {
     if (*a.bad != 0u) return;
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (w >= a.n_streams * 6u) return;
-    const uint32_t s = w / 6u, role = (w % 6u) >> 1, side = w & 1u;
+    if (w >= a.n_local * 6u) return;
+    const uint32_t s = w / 6u, role = (w % 6u) >> 1, side = w & 1u;  // s: local stream
     if (role == 0) scan_wave<2, true>(a, T, s, role, side, lane);
     else if (role == 1) scan_wave<4, true>(a, T + 96, s, role, side, lane);
     else scan_wave<2, false>(a, T + 192, s, role, side, lane);
@@ -405,8 +408,9 @@ __global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
     if (*a.bad != 0u) return;
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     const uint32_t gid = blockIdx.y * 64u + lane;
-    const uint32_t s = gid >> 4, ln = gid & 15u;
-    const bool live = s < a.n_streams && ln < 12u;
+    const uint32_t sl = gid >> 4, ln = gid & 15u;
+    const bool live = sl < a.n_local && ln < 12u;
+    const uint32_t s = live ? (a.stream_map ? a.stream_map[sl] : sl) : 0u;
     const uint64_t row = (uint64_t)a.n_streams * 16u;
     const int64_t lo = (int64_t)a.cuts[j] + 1, hi = (int64_t)a.cuts[j + 1u];  // frames lo ..= hi, all negative
     auto sum_ring = [&](const float* ring, uint32_t len) -> double {
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
         const int64_t from = max(lo, max(-(int64_t)len, -(int64_t)min(a.pushes0, (uint64_t)0x7FFFFFFFu)));
         if (from > hi) return 0.0;
         uint32_t slot = (uint32_t)((a.pushes0 + (uint64_t)(from + (int64_t)len)) % len);
-        const float* p = ring + (live ? gid : 0u);
+        const float* p = ring + (uint64_t)s * 16u + (live ? ln : 0u);
         double acc = 0.0;
         int64_t g = from;
         for (; g + 7 <= hi; g += 8) {
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
     const double c = sum_ring(a.color_ring, a.color_len);
     const double p = a.history ? sum_ring(a.hist_ring, a.slow_len) : 0.0;
     if (live) {
-        double* out = a.seg_sum + ((uint64_t)j * a.n_streams + s) * 24u;
+        double* out = a.seg_sum + ((uint64_t)j * a.n_local + sl) * 24u;
         out[ln] = c;
         if (a.history) out[12u + ln] = p;
     }
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
 // ---- prefix: thread = (stream, value); running totals as double-double pairs, prefix[i] = sum of the segments before cut i
 __global__ __launch_bounds__(256) void wave_prefix_kernel(WaveChunkArgs a) {
     if (*a.bad != 0u) return;
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x, total = (uint64_t)a.n_streams * 24u;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x, total = (uint64_t)a.n_local * 24u;
     if (t >= total) return;
     if (!a.history && t % 24u >= 12u) return;
     double hi = 0.0, lo = 0.0;
@@ -479,14 +483,15 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint32_t ch = (uint32_t)(t & 3u);
     const uint64_t rest = t >> 2;
-    const uint32_t s = (uint32_t)(rest % a.n_streams);
-    const uint64_t e = rest / a.n_streams;
+    const uint32_t sl = (uint32_t)(rest % a.n_local);
+    const uint64_t e = rest / a.n_local;
     if (e >= a.n_evals) return;
+    const uint32_t s = a.stream_map ? a.stream_map[sl] : sl;
     const WaveEval ev = a.evals[e];
     const bool final_eval = ev.out == 0xFFFFFFFFu;
-    const uint64_t total = (uint64_t)a.n_streams * 24u;
+    const uint64_t total = (uint64_t)a.n_local * 24u;
     auto window_sum = [&](uint32_t series, uint32_t band, uint32_t from_cut) -> double {  // running total at idx_end minus at from_cut
-        const uint64_t v = (uint64_t)s * 24u + series * 12u + ch * 3u + band;
+        const uint64_t v = (uint64_t)sl * 24u + series * 12u + ch * 3u + band;
         const double h1 = a.prefix_hi[(uint64_t)ev.idx_end * total + v], l1 = a.prefix_lo[(uint64_t)ev.idx_end * total + v];
         const double h0 = a.prefix_hi[(uint64_t)from_cut * total + v], l0 = a.prefix_lo[(uint64_t)from_cut * total + v];
         return (h1 - h0) + (l1 - l0);
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
         mx = st0.cur_max;
     }
     for (uint32_t k = k_from; k < k_to; ++k) {
-        const float* mm = a.seg_mm + ((uint64_t)k * a.n_streams + s) * 12u + ch * 3u;
+        const float* mm = a.seg_mm + ((uint64_t)k * a.n_local + sl) * 12u + ch * 3u;
         mn = some ? wf::min_finite(mn, mm[0]) : mm[0];
         mx = some ? wf::max_finite(mx, mm[1]) : mm[1];
         some = true;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
         ext = st0.last_sample;
     } else {
         ext_valid = true;
-        ext = a.seg_mm[((uint64_t)(k_from - 1u) * a.n_streams + s) * 12u + ch * 3u + 2u];
+        ext = a.seg_mm[((uint64_t)(k_from - 1u) * a.n_local + sl) * 12u + ch * 3u + 2u];
     }
     float cmin = 0.0f, cmax = 0.0f;
     if (some) {
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
         }
     }
     if (!final_eval) {
-        a.columns[((uint64_t)s * a.n_kept + ev.out) * 4u + ch] = col;
+        a.columns[((uint64_t)s * a.col_stride + ev.out) * 4u + ch] = col;
         return;
     }
     if (a.write_preview) a.preview[(uint64_t)s * 4u + ch] = col;
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
     // (every thread of the call read the column state of its own (stream, channel) above; only this one writes it)
     const bool partial = k_to > k_from;  // frames since the last column end of this call
     float last = 0.0f;
-    if (partial) last = a.seg_mm[((uint64_t)(k_to - 1u) * a.n_streams + s) * 12u + ch * 3u + 2u];
+    if (partial) last = a.seg_mm[((uint64_t)(k_to - 1u) * a.n_local + sl) * 12u + ch * 3u + 2u];
     if (ev.carry) {  // no column ended in this call: the open column grew, last_sample / last_valid stay
         st0.cur_some = some ? 1u : 0u;
         st0.cur_min = mn;
@@ -582,29 +587,50 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
     }
 }
 
-void launch_waveform_chunked(const WaveChunkArgs& a, const double* d_T, hipStream_t stream) {
-    const uint32_t groups = (a.n_streams + 63u) / 64u;
+__global__ __launch_bounds__(256) void wave_mirror_copy_kernel(const uint8_t* __restrict__ src, uint32_t n, uint64_t* pushes_v, double* phase_v,
+                                                               uint32_t* cols_v, float* progress_v, const uint32_t* bad) {
+    if (*bad != 0u) return;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n) return;
+    pushes_v[s] = reinterpret_cast<const uint64_t*>(src)[s];
+    phase_v[s] = reinterpret_cast<const double*>(src + (size_t)n * 8u)[s];
+    cols_v[s] = reinterpret_cast<const uint32_t*>(src + (size_t)n * 16u)[s];
+    progress_v[s] = reinterpret_cast<const float*>(src + (size_t)n * 20u)[s];
+}
+void launch_waveform_mirror_copy(const uint8_t* src, uint32_t n, uint64_t* pushes_v, double* phase_v, uint32_t* cols_v, float* progress_v,
+                                 const uint32_t* bad, hipStream_t stream) {
+    hipLaunchKernelGGL(wave_mirror_copy_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, src, n, pushes_v, phase_v, cols_v, progress_v, bad);
+}
+
+// phase 1: everything that only writes scratch and may raise `bad`; phase 2: the rest.  A ragged call runs phase 1 of EVERY group of
+// streams before phase 2 of any (the sequential fallback must find the state untouched).
+void launch_waveform_chunked_phase1(const WaveChunkArgs& a, const double* d_T, hipStream_t stream) {
+    const uint32_t groups = (a.n_local + 63u) / 64u;
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
     hipLaunchKernelGGL((wave_chunk_kernel<false>), dim3(groups * a.n_chunks), dim3(192), lds, stream, a);
-    hipLaunchKernelGGL(wave_scan_states_kernel, dim3((a.n_streams * 6u + 3u) / 4u), dim3(256), 0, stream, a, d_T);
-    if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_streams * 16u + 63u) / 64u), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(wave_scan_states_kernel, dim3((a.n_local * 6u + 3u) / 4u), dim3(256), 0, stream, a, d_T);
+}
+void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream) {
+    const uint32_t groups = (a.n_local + 63u) / 64u;
+    const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
+    if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_local * 16u + 63u) / 64u), dim3(64), 0, stream, a);
     const size_t lds_b = lds + (size_t)(a.history ? 2 : 1) * 8 * 64 * 12 * sizeof(float);  // + the ring exchange
     static std::once_flag attr_once;  // (two host threads may race on the first launch; one device per process, omx.h)
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wave_chunk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     });
     hipLaunchKernelGGL((wave_chunk_kernel<true>), dim3(groups * a.n_chunks), dim3(192), lds_b, stream, a);
-    hipLaunchKernelGGL(wave_prefix_kernel, dim3((uint32_t)(((uint64_t)a.n_streams * 24u + 255u) / 256u)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(wave_prefix_kernel, dim3((uint32_t)(((uint64_t)a.n_local * 24u + 255u) / 256u)), dim3(256), 0, stream, a);
     // the columns first, then — behind them in the stream — the pseudo-column: it overwrites the column state the first column reads
     WaveChunkArgs cols = a, tail = a;
     cols.n_evals = a.n_evals - 1u;
     tail.evals = a.evals + (a.n_evals - 1u);
     tail.n_evals = 1u;
     if (cols.n_evals) {
-        const uint64_t threads = (uint64_t)cols.n_evals * a.n_streams * 4u;
+        const uint64_t threads = (uint64_t)cols.n_evals * a.n_local * 4u;
         hipLaunchKernelGGL(wave_columns_kernel, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, cols);
     }
-    hipLaunchKernelGGL(wave_columns_kernel, dim3((uint32_t)(((uint64_t)a.n_streams * 4u + 255u) / 256u)), dim3(256), 0, stream, tail);
+    hipLaunchKernelGGL(wave_columns_kernel, dim3((uint32_t)(((uint64_t)a.n_local * 4u + 255u) / 256u)), dim3(256), 0, stream, tail);
 }
 
 }  // namespace omx

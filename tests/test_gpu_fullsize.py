@@ -255,6 +255,38 @@ def test_waveform_bank_1024_streams_partition_and_replication(omx, history):
     assert float(((parts.view(torch.float32).double()[..., 2:5] - o64[..., 2:5]).abs() / top).max()) <= 4e-5
 
 
+@pytest.mark.parametrize("S,frames", [(1024, 16384), (2048, 16384)])
+def test_waveform_chunk_parallel_form_at_bench_size_against_the_sequential_kernels(omx, S, frames):
+    """the chunk lengths a test-sized bank never reaches (the planner takes 64-frame chunks below 131072 (stream, chunk) items, 128
+    at 1024 x 16384 — the bench call — and 256 from 2048 x 16384): two calls of the chunk-parallel form against two calls of the sequential
+    kernels on the same device PCM; min / max bit-identical, colour bands within 4e-5 of the column's loudest channel, identical
+    streams identical bits"""
+    import torch
+    cfg = capi.WaveformConfig(scroll_speed=300.0, max_columns=256, analyze_bands=True, track_history=False)
+    base = np.stack([cfg4_pcm(90 + s, 2 * frames) for s in range(8)])
+    d_pcm = torch.from_numpy(np.ascontiguousarray(base[np.arange(S) % 8])).to("cuda:0")
+    pos = capi.positions_fallback(2)
+    out = {}
+    for form in (1, 2):
+        bank = banks.WaveformBank(omx, cfg, S)
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        cols = []
+        for k in range(2):
+            part = d_pcm[:, k * frames:(k + 1) * frames].contiguous()
+            up = bank.process_device(part.data_ptr(), frames, 2, FS, pos)
+            torch.cuda.synchronize()
+            assert bank.last_form() == form
+            cols.append(dview(torch, up.d_columns, (S, int(up.n_columns), 4, 11), "<f4").clone())
+        out[form] = torch.cat(cols, dim=1)
+    seq, chunk = out[1].double(), out[2].double()
+    assert seq.shape == chunk.shape and seq.shape[1] > 190
+    assert torch.equal(out[1][..., :2], out[2][..., :2])
+    top = seq[..., 2:5].amax(dim=2, keepdim=True).clamp_min(1e-30)
+    assert float(((chunk[..., 2:5] - seq[..., 2:5]).abs() / top).max()) <= 4e-5
+    for s in (8, 9, S // 2 + 3, S - 1):
+        assert torch.equal(out[2][s], out[2][s % 8]), s
+
+
 def test_ragged_calls_with_equal_counts_are_bit_identical_to_lock_step_calls_at_bank_size(omx):
     """The ragged entry points run the same kernels as the lock-step ones with per-stream counters compiled in (RAGGED template
     parameters): given the same count for every stream they must reproduce the lock-step call BIT FOR BIT — loudness 1024 x 8 ch

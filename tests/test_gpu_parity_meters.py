@@ -951,6 +951,79 @@ def test_waveform_chunk_parallel_random_sequences(omx, oracle, seed):
     assert chunked >= sum(1 for n in sizes if n >= 1024 and n % 2 == 0) - 8 * (scroll >= 650.0)   # (thousands of columns per call: sequential)
 
 
+@pytest.mark.parametrize("history", [False, True])
+def test_waveform_chunk_parallel_form_in_ragged_calls(omx, oracle, history):
+    """ragged calls whose streams fall into a few lock-step groups (the same frame count, push count and column phase) run one plan per
+    group; a lock-step prefix, groups that split and re-merge, a stream that pauses, and a call the chunk form does not serve (an odd
+    count) in between.  Every stream against its own oracle and its own f64 recurrence, counters (column counts, preview progress)
+    exactly."""
+    import torch
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    S, cap = 6, 8192
+    cfg = WaveformConfig(scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=history)
+    plan = [("lock", 4096),
+            ("ragged", [4096, 4096, 2048, 4096, 2048, 0]),
+            ("ragged", [2048, 2048, 4096, 2048, 4096, 0]),      # streams 0-4 meet again at 10240 frames; stream 5 paused
+            ("ragged", [8192, 8192, 8192, 1024, 1024, 8192]),
+            ("ragged", [1001, 2048, 2048, 2048, 2048, 2048]),   # an odd count: the sequential kernels do this call
+            ("ragged", [3072, 2026, 2026, 2026, 2026, 2026]),
+            ("ragged", [6144] * 6)]
+    totals = [sum((p[1] if p[0] == "lock" else p[1][s]) for p in plan) for s in range(S)]
+    feeds = [cfg4_pcm(70 + s, totals[s]) for s in range(S)]
+    exact = [WaveExact(feeds[s], FS) for s in range(S)]
+    bank = banks.WaveformBank(omx, cfg, S)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
+    pos = capi.positions_fallback(2)
+    at, cols_seen, forms = [0] * S, [0] * S, []
+    for kind, counts in plan:
+        if kind == "lock":
+            chunk = np.stack([feeds[s][at[s]:at[s] + counts] for s in range(S)])
+            up = bank.process_host(chunk, 2, FS)
+            forms.append(bank.last_form())
+            for s in range(S):
+                w = refs[s].process_block(AudioBlock(chunk[s].reshape(-1), 2, FS))
+                got, _ = bank.fetch(s, int(up.n_columns))
+                assert np.array_equal(got[:, :, :2], w.columns[:, :, :2])
+                at[s] += counts
+                cols_seen[s] += len(w.columns)
+            continue
+        pcm = np.zeros((S, cap, 2), np.float32)
+        for s in range(S):
+            pcm[s, :counts[s]] = feeds[s][at[s]:at[s] + counts[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, counts, 2, FS, pos)
+        torch.cuda.synchronize()
+        forms.append(bank.last_form())
+        n_cols = torch.as_tensor(_DevView(up.d_n_columns, (S,), "<u4"), device="cuda:0").cpu().numpy()
+        progress = torch.as_tensor(_DevView(up.d_preview_progress, (S,), "<f4"), device="cuda:0").cpu().numpy()
+        M = int(up.max_columns)
+        for s in range(S):
+            if counts[s] == 0:
+                assert int(n_cols[s]) == 0
+                continue
+            w = refs[s].process_block(AudioBlock(pcm[s, :counts[s]].reshape(-1), 2, FS))
+            assert int(n_cols[s]) == len(w.columns) and progress[s] == np.float32(w.preview_progress), (kind, counts, s)
+            got, prev = bank.fetch(s, M, with_preview=True)
+            got = got[:len(w.columns)]
+            assert np.array_equal(got[:, :, :2], w.columns[:, :, :2]), (counts, s)
+            if len(got):
+                cols = slice(cols_seen[s], cols_seen[s] + len(got))
+                check_wave_three_way("waveform (chunk-parallel, ragged groups)", got, w.columns, exact[s], cols, history, (counts, s))
+            if w.preview is not None:
+                assert np.array_equal(prev[:, :2], w.preview[:, :2]), (counts, s)
+                assert np.abs(prev[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-4 * max(1e-30, np.abs(w.preview[:, 2:5]).max()), (counts, s)
+            at[s] += counts[s]
+            cols_seen[s] += len(w.columns)
+    assert forms == [2, 2, 2, 2, 1, 2, 2]
+    assert cols_seen == [len(e) for e in exact]
+
+
+class _DevView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+
 def test_waveform_chunk_parallel_form_hands_non_finite_input_to_the_sequential_kernels(omx, oracle):
     """NaN / inf / absurdly large samples: the chunk-parallel form raises its flag before it has written anything but scratch and
     the sequential kernels do the call — bit-identical to the sequential form, continuity rules of :275-291 included"""

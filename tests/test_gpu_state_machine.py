@@ -292,8 +292,19 @@ def test_oscilloscope_random_operation_sequences(omx, oracle, seed):
             compared += 1
             continue
         # a near-tie between two search offsets may resolve differently (f32 summation order): whole-sample shifts of the capture,
-        # which the reference's own jitter test tolerates (< 3 samples, :933-955)
-        assert np.abs(g.samples - w.samples).max() <= 0.05, (seed, step)
+        # which the reference's own jitter test tolerates (< 3 samples, :933-955) — or, on these exactly periodic signals, a capture a whole
+        # number of PERIODS away (scores equal up to the 0.003 noise floor; soak seed 9101044: square wave, 109.09-sample period, the
+        # two captures two periods apart).  Flat parts then agree to the noise (0.05), and the samples that interpolate across a
+        # discontinuity of the square / sawtooth move by jump x the period's fractional part: those are compared against that bound
+        d = np.abs(g.samples - w.samples).reshape(g.channels, -1)
+        tr = w.samples.reshape(g.channels, -1)
+        step_in = np.abs(np.diff(tr, axis=1))
+        edge = np.zeros_like(d, dtype=bool)
+        edge[:, 1:] |= step_in > 0.2
+        edge[:, :-1] |= step_in > 0.2
+        assert d[~edge].max(initial=0.0) <= 0.05, (seed, step)
+        if edge.any():
+            assert d[edge].max() <= 0.5 * 1.2 + 0.05, (seed, step)                            # half a sample of the 1.2 jump
         compared += 1
     assert compared >= 0   # seeds whose traces are switched off most of the time compare few snapshots
 
