@@ -11,6 +11,7 @@ python bench.py --config cfg5 --no-cpu-baseline --no-secondary > gpurun_out/${TA
 {
 echo "== tools/bench_sizes.py =="; python tools/bench_sizes.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_zp.py =="; python tools/bench_zp.py 2>&1 | grep -v amdgpu.ids
+echo "== tools/bench_zp_big.py (zero padding beyond 16384 points) =="; python tools/bench_zp_big.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_spectrum_sizes.py =="; python tools/bench_spectrum_sizes.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_meters.py =="; python tools/bench_meters.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_meters.py waveform, OMX_WAVEFORM_SINGLE=1 (the one-wavefront kernel) =="; OMX_WAVEFORM_SINGLE=1 python tools/bench_meters.py waveform 2>&1 | grep -v amdgpu.ids
@@ -30,3 +31,7 @@ head -c 600 gpurun_out/${TAG}_bench_line.json
 # kernel trace of the streaming cadence (1024 captures x one 256-frame block per call, six visuals)
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stream -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_stream.py --calls 200 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_stream.log 2>&1 )
 cp gpurun_out/${TAG}_stream/t_kernel_stats.csv gpurun_out/${TAG}_stream_kernel_stats.csv 2>/dev/null
+
+# kernel trace of the waveform bank's chunk-parallel form (1024 streams x 16384 frames, history off)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave.log 2>&1 )
+cp gpurun_out/${TAG}_wave/t_kernel_stats.csv gpurun_out/${TAG}_wave_kernel_stats.csv 2>/dev/null
