@@ -185,9 +185,11 @@ void SpectrogramBank::rebuild_fft(hipStream_t stream) {  // :229-279
                (((W == 1024 || W == 2048 || W == 4096) && (fft_size_ == 2048 || fft_size_ == 4096 || fft_size_ == 8192)) ||
                 ((W == 1024 || W == 2048 || W == 4096 || W == 8192) && fft_size_ == 16384));
     // ... or, for transforms beyond 16384 points, through zp W-point transforms of modulated slices (launch_stft_reassigned_residue)
-    fast_zpr_ = reassign && W < fft_size_ && fft_size_ > 16384 && fft_size_ <= (size_t(1) << 19) && (fft_size_ & (fft_size_ - 1)) == 0 &&
-                (W == 1024 || W == 2048 || W == 4096 || W == 8192 || W == 16384);
-    if (fast_zpr_) fast_zp_ = true;  // (same tables; the dispatch below tells them apart)
+    const bool residue_shape = W < fft_size_ && fft_size_ > 16384 && fft_size_ <= (size_t(1) << 19) && (fft_size_ & (fft_size_ - 1)) == 0 &&
+                               (W == 1024 || W == 2048 || W == 4096 || W == 8192 || W == 16384);
+    fast_zpr_ = reassign && residue_shape;
+    classic_zpr_ = !reassign && residue_shape;
+    if (fast_zpr_ || classic_zpr_) fast_zp_ = true;  // (same tables; the dispatch below tells them apart)
     if (fast_classic_zp) {
         fast4096_ = true;
         d_tw256_.upload(twiddle_table(256, 256), stream);
@@ -337,6 +339,8 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
             for (uint64_t first = 0; first < total; first += chunk)
                 (void)launch_stft_reassigned_residue(fa, (uint32_t)W, (uint32_t)(fft_size_ / W), reinterpret_cast<const v2f*>(d_twF_.ptr), d_workspace_.ptr,
                                                      (uint32_t)first, (uint32_t)std::min(chunk, total - first), stream);
+        } else if (classic_zpr_) {
+            (void)launch_stft_classic_residue(fa, d_codes_.ptr, (uint32_t)W, (uint32_t)(fft_size_ / W), reinterpret_cast<const v2f*>(d_twF_.ptr), stream);
         } else if (fast_zp_ && fft_size_ == 16384) {
             const uint64_t total = (uint64_t)n_streams_ * n_cols, chunk = std::min<uint64_t>(total, 1024);
             d_workspace_.reserve((size_t)(chunk * stft_big_scratch_bytes_per_frame() / sizeof(float)));

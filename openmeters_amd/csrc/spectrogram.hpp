@@ -49,7 +49,7 @@ private:
     omx_spectrogram_config cfg_{};
     uint32_t n_streams_;
     int kernel_form_ = 0;  // OMX_OPT_KERNEL_FORM
-    bool prepared_ = false, reset_ = true, fast4096_ = false, fast_zp_ = false, fast_zpr_ = false, force_generic_ = false;
+    bool prepared_ = false, reset_ = true, fast4096_ = false, fast_zp_ = false, fast_zpr_ = false, classic_zpr_ = false, force_generic_ = false;
     size_t fft_size_ = 0, hilbert_len_ = 0;
     float power_scale_ = 1.0f;
     // pending audio: absolute sample counters shared by all streams (lock-step pushes)

@@ -146,6 +146,7 @@ struct BigScratch {
 };
 // zero padding beyond 16384 points: zp W-point transforms of modulated slices per spectrum (stft_pow2_kernels.hip)
 uint64_t stft_residue_scratch_bytes_per_frame(uint32_t window, uint32_t fft_size);
+bool launch_stft_classic_residue(const StftFastArgs& a, uint16_t* codes, uint32_t window, uint32_t zp, const v2f* twF, hipStream_t stream);
 bool launch_stft_reassigned_residue(const StftFastArgs& a, uint32_t window, uint32_t zp, const v2f* twF, void* scratch, uint32_t first, uint32_t count,
                                     hipStream_t stream);
 void launch_hilbert_16k(const StftFastArgs& a, const BigScratch& sc, bool imag_only, hipStream_t stream);   // stft16384_kernels.hip

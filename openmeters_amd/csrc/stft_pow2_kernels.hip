@@ -1202,6 +1202,86 @@ __global__ __launch_bounds__(1024) void reassign_stream_kernel(StftFastArgs a, B
     if (ju == 0) *count_out = running;
 }
 
+// Classic (non-reassigned) columns beyond 16384 points (processor.rs:350-380): the same decomposition on the DC-removed windowed REAL
+// slice — workgroup = (column, residue r): (x - mean) w e^{-2 pi i n r / F}, one W-point transform, bins zp q + r <= F / 2 -> u16 codes.
+// (The modulated slice is complex: the two-columns-per-transform packing of stft_classic_pow2_kernel does not apply.)
+template <int LOGW>
+__global__ __launch_bounds__(FftGeom<LOGW>::WG) void classic_residue_kernel(StftFastArgs a, uint16_t* __restrict__ codes, const v2f* __restrict__ twF,
+                                                                           uint32_t zp) {
+    using G = FftGeom<LOGW>;
+    constexpr int N = G::N, T = G::T, WPF = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* buf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* tw2_lds = buf + G::LDS;
+    float* wave_sum = reinterpret_cast<float*>(tw2_lds + 256);  // [WPF]
+    const uint32_t item = blockIdx.x, r = blockIdx.y;
+    const uint32_t s = item / a.n_cols, col = item % a.n_cols;
+    if (col >= stft_cols(a, s)) return;
+    const int j = threadIdx.x;
+    const unsigned ju = threadIdx.x;
+    const char* ring_bytes = reinterpret_cast<const char*>(a.ring + (uint64_t)s * a.cap);
+    const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;
+    const uint32_t p32 = (uint32_t)(stft_tail(a, s) + (uint64_t)col * a.hop);
+    const uint32_t F = (uint32_t)N * zp;
+    TwiddlesPow2<LOGW> tw;
+    tw.tw2 = tw2_lds;
+    tw.load(a.tw4096, ju);  // exp(-2 pi i k / W)
+    for (unsigned i = threadIdx.x; i < 256u; i += (unsigned)T) tw2_lds[i] = a.tw256[i];
+    float x[16];
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        x[t] = *reinterpret_cast<const float*>(ring_bytes + (((p32 + ju + (unsigned)T * (unsigned)t) << 2) & bytemask));
+        sum += x[t];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((j & 63) == 0) wave_sum[j >> 6] = sum;
+    __syncthreads();  // wave sums, tw2_lds
+    float total = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) total += wave_sum[i];
+    const float mean = total / (float)N;  // window.rs:80-84 (tree order, as in the fused classic kernel)
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const uint32_t i = ju + (unsigned)T * (unsigned)t;
+        const float xw = (x[t] - mean) * a.window[i];
+        const v2f m = twF[(i * r) & (F - 1u)];
+        v[t] = v2f{xw * m.x, xw * m.y};
+    }
+    fftp_inplace<false, LOGW>(v, buf, j, tw);
+    uint16_t* out = codes + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        if (u == 8 && (j != 0 || r != 0)) break;  // q = W / 2 is the Nyquist bin, residue 0 only
+        const uint32_t k = (ju + (unsigned)T * (unsigned)u) * zp + r;
+        const v2f z = v[u];
+        out[k] = classic_code((z.x * z.x + z.y * z.y) * a.bin_norm[k]);
+    }
+}
+template <int LOGW>
+static void launch_classic_residue_w(const StftFastArgs& a, uint16_t* codes, const v2f* twF, uint32_t zp, hipStream_t stream) {
+    using G = FftGeom<LOGW>;
+    const size_t lds = (size_t)(G::LDS + 256) * sizeof(v2f) + 16 * sizeof(float);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(classic_residue_kernel<LOGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    hipLaunchKernelGGL(classic_residue_kernel<LOGW>, dim3(a.n_streams * a.n_cols, zp), dim3(G::T), lds, stream, a, codes, twF, zp);
+}
+bool launch_stft_classic_residue(const StftFastArgs& a, uint16_t* codes, uint32_t window, uint32_t zp, const v2f* twF, hipStream_t stream) {
+    if (a.n_streams == 0 || a.n_cols == 0) return true;
+    switch (window) {
+        case 1024: launch_classic_residue_w<10>(a, codes, twF, zp, stream); return true;
+        case 2048: launch_classic_residue_w<11>(a, codes, twF, zp, stream); return true;
+        case 4096: launch_classic_residue_w<12>(a, codes, twF, zp, stream); return true;
+        case 8192: launch_classic_residue_w<13>(a, codes, twF, zp, stream); return true;
+        case 16384: launch_classic_residue_w<14>(a, codes, twF, zp, stream); return true;
+        default: return false;
+    }
+}
+
 uint64_t stft_residue_scratch_bytes_per_frame(uint32_t window, uint32_t fft_size) {
     return ((uint64_t)window + 3ull * ((uint64_t)fft_size / 2 + 1)) * sizeof(v2f);
 }

@@ -61,6 +61,21 @@ def test_reassigned_transforms_beyond_16384_points(omx, oracle, W, zp, hop):
     check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop)
 
 
+@pytest.mark.parametrize("W,zp,hop,window", [(1024, 32, 256, capi.WINDOW_HANN), (2048, 16, 512, capi.WINDOW_BLACKMAN_HARRIS), (4096, 8, 1024, capi.WINDOW_HAMMING),
+                                             (16384, 4, 4096, capi.WINDOW_HANN), (8192, 32, 2048, capi.WINDOW_BLACKMAN)])
+def test_classic_transforms_beyond_16384_points(omx, oracle, W, zp, hop, window):
+    """classic (non-reassigned) columns zero-padded to F = zp W > 16384 points: classic_residue_kernel against the oracle's F-point real
+    transform, at the fused classic kernels' bars (codes within 40 dB of the maximum at most one apart, weaker bins inside the f32
+    transform noise budget)"""
+    cfg = SpectrogramConfig(fft_size=W, hop_size=hop, window=window, zero_padding_factor=zp, use_reassignment=False, history_length=16)
+    pcm = stream_pcm(8, W + hop * 3)
+    blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
+    g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
+    assert g.fft_size == w.fft_size == W * zp and len(g.new_columns) == len(w.new_columns) == 4
+    assert all(len(c) == W * zp // 2 + 1 for c in g.new_columns)
+    check_classic(g.new_columns, w.new_columns)
+
+
 @pytest.mark.parametrize("window", WINDOWS)
 def test_reassigned_transforms_beyond_16384_points_every_window_kind_in_a_bank(omx, oracle, window):
     """2048 x 16 in a bank of three streams (one of them silent: empty columns), every window kind (the residue form windows in the
