@@ -846,7 +846,8 @@ def test_waveform_chunk_parallel_form_matches_per_stream_oracle(omx, oracle, rat
     others the sequential kernels — every hand-over of filter states, rings, compensated pairs and the open column goes both ways"""
     from openmeters_amd.capi import WaveformConfig, WaveformProcessor
     S = 5
-    cfg = WaveformConfig(sample_rate=rate, scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=history)
+    # (96 kHz: max_columns = 16 — the long calls emit more columns than that and keep the newest, cap_pending_columns :293-298)
+    cfg = WaveformConfig(sample_rate=rate, scroll_speed=300.0, max_columns=16 if rate == 96000.0 else 1024, analyze_bands=True, track_history=history)
     sizes = [4096, 256, 2048, 1000, 8192, 1024, 3001, 1536, 16384, 512, 2050]
     pcm = np.stack([cfg4_pcm(40 + s, sum(sizes)) for s in range(S)])
     pcm[1, 9000:12000] *= np.float32(1e-4)   # a quiet passage inside one stream
@@ -865,14 +866,16 @@ def test_waveform_chunk_parallel_form_matches_per_stream_oracle(omx, oracle, rat
             assert up.n_columns == len(w.columns) and bool(up.reset) == w.reset and bool(up.preview_some) == (w.preview is not None)
             got, prev = bank.fetch(s, int(up.n_columns), with_preview=True)
             assert np.array_equal(got[:, :, :2], w.columns[:, :, :2]), (n, s)   # min / max
+            emitted = int(np.count_nonzero((exact[s].ends >= at - n) & (exact[s].ends < at)))   # columns ending inside this call
+            assert len(got) == min(emitted, cfg.max_columns), (n, s)
             if len(got):
-                cols = slice(total, total + len(got))
+                cols = slice(total + emitted - len(got), total + emitted)                          # the newest max_columns of them are kept
                 check_wave_three_way("waveform (chunk-parallel)", got, w.columns, exact[s], cols, history, (n, s))
             if w.preview is not None:
                 assert np.array_equal(prev[:, :2], w.preview[:, :2]), (n, s)
                 # (the preview column is compared with the oracle's under the widest column bar of the call: no exact twin is kept)
                 assert np.abs(prev[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-4 * max(1e-30, np.abs(w.preview[:, 2:5]).max()), (n, s)
-        total += int(up.n_columns)
+        total += emitted
     assert forms == [2 if (n >= 1024 and n % 2 == 0) else 1 for n in sizes]
     assert total > 100 and total == len(exact[0])
 
