@@ -117,6 +117,100 @@ __global__ __launch_bounds__(256) void ingest_project_kernel(IngestArgs a) {
     }
 }
 
+// Two-channel blocks, four consecutive frames per lane and round: the PCM arrives as two 16-byte loads per lane and every ring receives one
+// 16-byte store per lane (the one-frame-per-lane kernel above issues 4-byte stores, 32 per thread for two rings: at cfg2's
+// 134 MB in / 2 x 67 MB out it ran at 3.2 TB/s).  Same arithmetic per frame, same rings, same newest-non-zero position.
+constexpr int INGEST4_ROUNDS = 4;  // 4 rounds x 4 frames x 256 threads = the same 4096 frames per workgroup
+__global__ __launch_bounds__(256) void ingest_project4_kernel(IngestArgs a) {
+    __shared__ long long wave_best[4];
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const uint32_t s = blockIdx.y;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * INGEST_FRAMES_PER_WG;
+    const uint64_t skip_s = a.skips ? a.skips[s] : a.skip, count_s = a.counts ? a.counts[s] : a.count,
+                   head_s = a.heads ? a.heads[s] : (a.per_out ? a.head_o[0] : a.head);
+    const uint64_t row_last = a.frames_total ? a.frames_total - 1 : 0;
+    const float* row = a.pcm + (uint64_t)s * a.frames_total * 2;
+    long long best = -1;
+    f4u lo[INGEST4_ROUNDS], hi[INGEST4_ROUNDS];
+    uint64_t idx0[INGEST4_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < INGEST4_ROUNDS; ++k) {  // every load up front; a lane whose four frames are not all inside the row reads clamped singles
+        idx0[k] = wg_base + (uint64_t)k * 1024 + 4u * threadIdx.x;
+        const uint64_t f = skip_s + idx0[k];
+        if (f + 3 <= row_last) {
+            lo[k] = *reinterpret_cast<const f4u*>(row + f * 2);
+            hi[k] = *reinterpret_cast<const f4u*>(row + f * 2 + 4);
+        } else {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v2f p = *reinterpret_cast<const v2f*>(row + min(f + (uint64_t)j, row_last) * 2);
+                t[2 * j] = p.x;
+                t[2 * j + 1] = p.y;
+            }
+            lo[k] = f4u{t[0], t[1], t[2], t[3]};
+            hi[k] = f4u{t[4], t[5], t[6], t[7]};
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < INGEST4_ROUNDS; ++k) {
+        const float fr[8] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, hi[k].z, hi[k].w};
+        float left[4], right[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // dsp.rs:223-249: left = (0.0 + s0*w00) + s1*w10
+            left[j] = 0.0f + fr[2 * j] * a.fmt.m[0][0];
+            right[j] = 0.0f + fr[2 * j] * a.fmt.m[0][1];
+            left[j] = left[j] + fr[2 * j + 1] * a.fmt.m[1][0];
+            right[j] = right[j] + fr[2 * j + 1] * a.fmt.m[1][1];
+        }
+        const uint32_t n_live = idx0[k] >= count_s ? 0u : (uint32_t)min((uint64_t)4, count_s - idx0[k]);
+        float out0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+            if (o >= a.n_out) break;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a.project[o] == OMX_PROJECT_RAW ? fr[2 * j] : project_lr(a.project[o], left[j], right[j]);
+            if (o == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out0[j] = v[j];
+            }
+            const uint64_t cap = a.per_out ? a.cap_o[o] : a.cap, head = a.per_out ? a.head_o[o] : head_s;
+            float* ring = a.ring[o] + (uint64_t)s * cap;
+            const uint64_t p = (head + idx0[k]) & (cap - 1);
+            if (n_live == 4u && p + 3 < cap) {
+                *reinterpret_cast<f4u*>(ring + p) = f4u{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < n_live) ring[(head + idx0[k] + (uint64_t)j) & (cap - 1)] = v[j];
+            }
+        }
+        // audio_last_nonzero (:423-425, :432-434): the newest non-zero sample of this round
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const unsigned long long nz = __ballot((uint32_t)j < n_live && out0[j] != 0.0f);
+            if (nz != 0ull) {
+                const long long cand = (long long)(head_s + wg_base + (uint64_t)k * 1024 + 4u * ((threadIdx.x & ~63u) + (uint32_t)(63 - __clzll((long long)nz))) + (uint32_t)j);
+                best = cand > best ? cand : best;
+            }
+        }
+    }
+    if (a.partial_nonzero) {
+        if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long m = wave_best[0];
+            for (int w = 1; w < 4; ++w) m = wave_best[w] > m ? wave_best[w] : m;
+            if (gridDim.x == 1 && a.last_nonzero) {
+                if (m > a.last_nonzero[s]) a.last_nonzero[s] = m;
+            } else {
+                a.partial_nonzero[(uint64_t)s * gridDim.x + blockIdx.x] = m;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void ingest_finalize_kernel(const long long* partial, uint32_t n_partials,
                                                              long long* last_nonzero) {
     const uint32_t s = blockIdx.x;
@@ -138,7 +232,9 @@ uint32_t ingest_partials_per_stream(uint64_t count) { return (uint32_t)((count +
 void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) {
     if (a.count == 0 || n_streams == 0) return;
     const uint32_t wgs = ingest_partials_per_stream(a.count);
-    hipLaunchKernelGGL(ingest_project_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
+    static const bool one_frame_form = tuning_env("OMX_INGEST_SINGLE") != nullptr;  // tuning hook: A/B against the one-frame-per-lane kernel
+    if (a.fmt.channels == 2 && !one_frame_form) hipLaunchKernelGGL(ingest_project4_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(ingest_project_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, a);
     if (a.partial_nonzero && a.last_nonzero && wgs > 1)
         hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, a.partial_nonzero, wgs, a.last_nonzero);
 }
