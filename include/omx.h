@@ -672,7 +672,9 @@ int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uin
  *       obtained by a scan (one f32 rounding each; the low band's in f64), the window means are differences of double-double
  *       running totals: min / max fields bit-identical, colour bands and RMS history within the bars of
  *       tests/test_gpu_parity_meters.py of the sequential order.  Non-finite or absurdly large (> 1e18) samples send the whole call
- *       through the sequential kernels.  By shape (0) it serves calls of >= 4 M stream-frames (1024 streams x 4096 frames).
+ *       through the sequential kernels.  By shape (0) it serves calls of >= 2048 frames (the sequential kernels cost ~146 ns per frame
+ *       whatever the bank size; the chunk form ~0.2 ms of launches plus its work): the reference's cadence — one 256-frame block per
+ *       call — and every call shorter than 2048 frames stay bit-identical.
  * Ragged calls take the chunk-parallel form too while their streams fall into at most 8 lock-step groups (the same frame count, push
  * count and column phase: the host mirrors both counters) and no stream is reset by the call; otherwise — and for single-stream
  * handles — the sequential kernels run. */

@@ -533,7 +533,10 @@ bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& co
     const uint64_t frames = wa.frames;
     if (form_ == 1 || !analysis_ || !chunk_shape_ok(frames)) return false;
     if (color_len_ < 64 || slow_len_ < 64 || slow_len_ > 0x3FFFFFFFu) return false;
-    if (form_ != 2 && (uint64_t)n_streams_ * frames < (4ull << 20)) return false;  // small calls: the sequential kernels' latency is lower
+    // by shape: the sequential kernels take ~146 ns per frame whatever the bank size (up to 1024 streams), the chunk form ~0.2 ms of
+    // launches plus its work — it wins from ~2000 frames per call on (tools/bench_wave_forms.py: 1 stream x 16 384 frames 2.33 -> 0.32 ms,
+    // 64 x 65 536 9.3 -> 0.47 ms, 1024 x 1024 0.17 -> 0.22 ms)
+    if (form_ != 2 && frames < 2048) return false;
     std::vector<ChunkGroup> groups(1);
     groups[0].frames = frames;
     groups[0].pushes0 = pushes_;
@@ -612,7 +615,10 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
         groups.push_back(std::move(g));
     }
     if (!servable || groups.empty()) return false;
-    if (form_ != 2 && work < (4ull << 20)) return false;
+    uint64_t longest = 0;
+    for (const ChunkGroup& g : groups) longest = std::max(longest, g.frames);
+    if (form_ != 2 && longest < 2048) return false;  // (the lock-step rule: short calls stay on the sequential kernels)
+    (void)work;
     // streams whose reset flag is set start from a cleared state (the rings need no clearing: nothing older than the push count is read)
     std::vector<uint32_t> resets;
     for (uint32_t s = 0; s < n_streams_; ++s)
