@@ -409,13 +409,12 @@ int omx_loudness_bank_create(const omx_loudness_config* cfg, uint32_t n_streams,
 void omx_loudness_bank_destroy(omx_loudness_bank* b);
 int omx_loudness_bank_reset_audio(omx_loudness_bank* b);
 /* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_loudness_bank_set_option pins one):
- *   sequential kernels (sliding Kahan-Babuska-Neumaier sums in the reference's order) for single-stream handles, calls of fewer than
- *       8 blocks or fewer than 4096 (slot, block) items (slot = stream x channel; a ragged call counts the blocks its streams actually
- *       run), streams whose sample counter is off the 64-sample grid, and non-finite PCM;
- *   chunk-parallel kernels (window sums as differences of an f64 running total; K-weighting by a block scan) for lock-step AND ragged
- *       calls of >= 8 blocks (ragged: max_blocks >= 8)
- *       and >= 4096 (slot, block) items whose block length is a multiple of 64 frames and which start at a multiple of 64 frames
- *       since the last reset: 1-8 channels, every sample rate (44.1 / 88.2 kHz windows are off the 64-sample grid: loudness_chunked.hip).
+ *   sequential kernels (sliding Kahan-Babuska-Neumaier sums in the reference's order) for single-stream handles (one block per call),
+ *       calls of fewer than 4 blocks, streams whose sample counter is off the 64-sample grid, and non-finite PCM;
+ *   chunk-parallel kernels (window sums as differences of a double-double running total; K-weighting by a block scan) for lock-step AND
+ *       ragged calls of >= 4 blocks (ragged: max_blocks >= 4) WHATEVER the bank size (the sequential kernels cost ~37 us per block however
+ *       few streams there are: one stream x 64 blocks 2.37 -> 0.12 ms), whose block length is a multiple of 64 frames and which start
+ *       at a multiple of 64 frames since the last reset: 1-8 channels, every sample rate (44.1 / 88.2 kHz windows are off the 64-sample grid: loudness_chunked.hip).
  *       Same quantities to ~1e-15 of a window sum (the K-weighting recurrence runs on fused multiply-adds there); LUFS / RMS within
  *       1e-4 dB of the sequential order (measured 1.5e-5), true peak bit-identical.  OMX_OPT_KERNEL_FORM = 1 pins the sequential kernels. */
 /* test hook: which evaluation order the bank's last process call took — 1 = sequential kernels, 2 = chunk-parallel (0 = no call yet) */
@@ -495,10 +494,10 @@ int omx_stereometer_bank_update_config(omx_stereometer_bank* b, const omx_stereo
 int omx_stereometer_bank_reset_audio(omx_stereometer_bank* b);
 /* WHICH EVALUATION ORDER A CALL GETS (default, OMX_OPT_KERNEL_FORM = 0; omx_stereometer_bank_set_option pins one):
  *   sequential kernels — the reference's operation order: points bit-exact, rho error 0 against the CPU restatement —
- *       for single-stream handles, calls of fewer than 8 blocks or fewer than 512 (stream, block) items, channel counts other than 2,
+ *       for single-stream handles (one block per call), calls of fewer than 4 blocks, channel counts other than 2,
  *       blocks that are not a multiple of 16 frames (or shorter than 32), and any call whose PCM is not finite;
  *   chunk-parallel kernels (every block of the call in parallel, block-boundary states by a scan) for 2-channel lock-step AND ragged calls of
- *       >= 8 blocks and >= 512 (stream, block) items.  The same f32 band filters evaluated block-parallel on fused multiply-adds: points
+ *       >= 4 blocks WHATEVER the bank size (one stream x 64 blocks 1.75 -> 0.10 ms).  The same f32 band filters evaluated block-parallel on fused multiply-adds: points
  *       within 1e-4 of full scale (measured 2.5e-5), rho within 1e-6 on bands within 16 dB of the full level (measured 6e-8) and
  *       within the reference's own f32 filter noise elsewhere (tests/parity.py::check_chunked_rho).  NOT bit-identical to the
  *       sequential order: a host that needs the reference's exact bits sets OMX_OPT_KERNEL_FORM = 1. */

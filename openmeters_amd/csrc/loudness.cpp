@@ -4,6 +4,12 @@
 
 namespace omx {
 
+// By shape, a bank call of this many blocks takes the chunk-parallel form WHATEVER the bank size: the sequential kernels cost ~37 us per
+// block however few streams there are (one wavefront per 64 slots walks the frames), the chunk form ~0.12 ms of launches plus its
+// work (tools/bench_meter_forms.py: 1 stream x 64 blocks 2.37 -> 0.12 ms, 16 streams x 8 blocks 0.30 -> 0.12 ms; until round 4 the rule
+// also asked for >= 4096 (slot, block) items, i.e. it left small banks on the slow side by 20x).
+constexpr uint64_t kChunkedFromBlocks = 4;
+
 constexpr float kLoudnessDefaultFloor = -99.9f;                           // :11
 constexpr float kLoudnessWindowsSecs[4] = {3.0f, 0.4f, 0.3f, 1.0f};       // :13
 constexpr size_t kTruePeakTaps = 48;                                      // :75
@@ -202,15 +208,12 @@ int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint
     la.reset_v = r_mask_.ptr;
     // the host's mirror of the per-stream counters decides the form: every stream on the 64-sample sub-block grid
     bool grid_ok = block_frames % 64 == 0 && max_blocks >= 2;
-    uint64_t items = 0;
     for (uint32_t s = 0; s < n_streams_; ++s) {
         if (reset_mask && reset_mask[s]) h_seen_[s] = 0;
         grid_ok = grid_ok && h_seen_[s] % 64 == 0;
         h_seen_[s] += (uint64_t)n_blocks[s] * block_frames;
-        items += n_blocks[s];
     }
-    items <<= la.slot_shift;
-    const bool chunked = grid_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (max_blocks >= 8 && items >= 4096));
+    const bool chunked = grid_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || max_blocks >= kChunkedFromBlocks);
     last_form_ = chunked ? 2 : 1;
     timer_.begin(stream);
     if (chunked) {
@@ -401,8 +404,7 @@ int LoudnessBank::process(const float* pcm, bool pcm_on_device, uint64_t block_f
     fill_args(la, d_pcm, block_frames, n_blocks, channels, positions);
     // chunk-parallel evaluation for bank-sized calls (loudness_chunked.hip): every block of the call in parallel
     const bool shape_ok = block_frames % 64 == 0 && n_blocks >= 2 && frames_seen_ % 64 == 0;
-    const uint64_t slots = (uint64_t)n_streams_ << la.slot_shift;
-    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && slots * n_blocks >= 4096));
+    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || n_blocks >= kChunkedFromBlocks);
     timer_.begin(stream);
     last_form_ = chunked ? 2 : 1;
     if (chunked) {

@@ -239,12 +239,10 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
     // chunk-parallel evaluation for bank-sized calls (stereometer_chunked.hip); everything else — single-stream handles, short
     // calls, other channel counts — stays on the sequential kernels, whose results are bit-identical to the reference's order
     const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
-    uint64_t items_live = (uint64_t)n_streams_ * n_blocks;
-    if (ragged) {
-        items_live = 0;
-        for (uint32_t s = 0; s < n_streams_; ++s) items_live += ragged->n_blocks[s];
-    }
-    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || (n_blocks >= 8 && items_live >= 512));
+    // by shape: whatever the bank size — the sequential kernels cost ~27 us per block however few streams there are, the chunk form ~0.08 ms
+    // of launches plus its work (tools/bench_meter_forms.py: 1 stream x 64 blocks 1.75 -> 0.10 ms, 16 x 8 0.23 -> 0.07 ms; until round 4
+    // the rule also asked for >= 512 (stream, block) items)
+    const bool chunked = shape_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || n_blocks >= 4);
     last_form_ = chunked ? 2 : 1;
     auto run_chunked = [&]() {  // (after the plan kernel in a ragged call: the per-stream history positions are its output)
         // chunks shorter than blocks while the call has too few (stream, block) items to give every SIMD two wavefronts

@@ -141,6 +141,7 @@ def test_stereometer_bank_and_surround_fold(omx, oracle):
     cfg = StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=2000)
     pcm = np.stack([cfg4_pcm(s, 256 * blocks) for s in range(S)])
     bank = banks.StereometerBank(omx, cfg, S)
+    bank.set_option(capi.OPT_KERNEL_FORM, 1)   # the sequential kernels' bar below (by shape a 10-block call takes the chunk-parallel form)
     bank.process_host(pcm, 256, 2, FS)
     for s in (0, 5, 11):
         p = StereometerProcessor(oracle, cfg)

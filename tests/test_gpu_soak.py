@@ -48,7 +48,7 @@ def test_soak_ragged_stereometer(omx, oracle, seed):
     if seed % 2:   # chunk-parallel form, 2 channels
         t.test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, 2, seed % 3 != 2, seed % 3 == 0, 2)
     else:          # sequential form
-        t.test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, 2 if seed % 4 else 6, True, True, 0)
+        t.test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, 2 if seed % 4 else 6, True, True, 1)
 
 
 @pytest.mark.parametrize("seed", conftest.soak_seeds(N, 6))

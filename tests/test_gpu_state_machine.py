@@ -751,13 +751,14 @@ def test_ragged_oscilloscope_bank_random_per_stream_block_counts_match_per_strea
     bank.process_host(chunk, block, 2, 48000.0)
 
 
-@pytest.mark.parametrize("seed,C,bands,points,form", [(1, 2, True, True, 0), (2, 2, True, False, 0), (3, 2, False, False, 0), (4, 6, True, True, 0),
+@pytest.mark.parametrize("seed,C,bands,points,form", [(1, 2, True, True, 1), (2, 2, True, False, 1), (3, 2, False, False, 1), (4, 6, True, True, 1),
                                                       (5, 2, True, True, 2), (6, 2, True, False, 2), (7, 2, False, False, 2)])
 def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream_oracles(omx, oracle, seed, C, bands, points, form):
     """Per-stream independence of the stereometer bank: every stream gets its own random block counts and its own reset_audio()
     calls; stream s must behave like a single StereometerProcessor fed the same blocks — `produced` per block (the history deque
     fills per stream), correlations at the 1e-6 bar, the points of the stream's last block bit-exact (per-stream ring positions),
     filters / correlators carried per stream and cleared by the stream's own reset only.  Two lock-step calls first.
+    form 1 pins the sequential kernels (by shape, calls with room for four or more blocks take the chunk-parallel form whatever the bank size);
     form 2 pins the chunk-parallel kernels (stereometer_chunked.hip with per-stream block counts, reset flags and history positions)."""
     import torch
     from openmeters_amd.capi import StereometerConfig, StereometerProcessor
