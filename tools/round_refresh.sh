@@ -15,6 +15,7 @@ echo "== tools/bench_zp_big.py (zero padding beyond 16384 points) =="; python to
 echo "== tools/bench_spectrum_sizes.py =="; python tools/bench_spectrum_sizes.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_meters.py =="; python tools/bench_meters.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/bench_meters.py waveform, OMX_WAVEFORM_SINGLE=1 (the one-wavefront kernel) =="; OMX_WAVEFORM_SINGLE=1 python tools/bench_meters.py waveform 2>&1 | grep -v amdgpu.ids
+echo "== tools/bench_meter_forms.py / bench_wave_forms.py (sequential kernels against the chunk-parallel forms over bank and call sizes) =="; python tools/bench_meter_forms.py 2>&1 | grep streams; python tools/bench_wave_forms.py 2>&1 | grep streams
 echo "== tools/bench_pipeline.py (capture group against separate bank calls) =="; python tools/bench_pipeline.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/latency_c.sh (single-stream handles, host in / host out, 256-frame blocks) =="; bash tools/latency_c.sh 2>&1 | tail -7
 echo "== tools/bench_windows.py (4096 / 256 per window kind; form 1 = the round-1 five-transform kernel) =="; python tools/bench_windows.py 2>&1 | grep 4096
