@@ -675,8 +675,8 @@ int omx_waveform_bank_process_ragged(omx_waveform_bank* b, const float* pcm, uin
  *       whatever the bank size; the chunk form ~0.2 ms of launches plus its work): the reference's cadence — one 256-frame block per
  *       call — and every call shorter than 2048 frames stay bit-identical.
  * Ragged calls take the chunk-parallel form too while their streams fall into at most 8 lock-step groups (the same frame count, push
- * count and column phase: the host mirrors both counters) and no stream is reset by the call; otherwise — and for single-stream
- * handles — the sequential kernels run. */
+ * count and column phase: the host mirrors both counters; a stream the call resets joins the group of fresh streams); otherwise the
+ * sequential kernels run. */
 int omx_waveform_bank_set_option(omx_waveform_bank* b, uint32_t option, uint64_t value);
 /* test hook: 1 = the bank's last lock-step call ran the sequential kernels alone, 2 = the chunk-parallel form (0 = no call yet) */
 int omx_debug_waveform_bank_last_form(const omx_waveform_bank* b);

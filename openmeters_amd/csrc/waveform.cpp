@@ -552,6 +552,7 @@ bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& co
 // functions of the frame counts and reset flags it has been handed), sorts the call's streams into groups that move in lock step,
 // and runs one plan per group.  More than kMaxGroups distinct (frames, pushes, phase) among the streams, or a group whose shape the
 // chunk form does not serve: the sequential kernel does the call (the mirror stays valid as long as its replay stays cheap).
+// Streams flagged in reset_mask join the group of (frames, 0, 0) after their state has been cleared.
 bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, const uint8_t* reset_mask, uint64_t max_cols, double step,
                                       hipStream_t stream) {
     constexpr size_t kMaxGroups = 8;
@@ -575,8 +576,8 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
     // replay every class's phase (the reference's f64 add / compare / subtract, :287-291) and advance the mirror — whichever kernels run
     std::vector<ChunkGroup> groups;
     bool servable = classes.size() <= kMaxGroups && form_ != 1 && analysis_ && color_len_ >= 64 && slow_len_ >= 64 && slow_len_ <= 0x3FFFFFFFu;
-    uint64_t work = 0;
-    std::vector<uint32_t> h_cols(n_streams_, 0);
+    uint64_t longest = 0;
+    std::vector<uint32_t> h_cols(n_streams_, 0), resets;
     std::vector<float> h_progress(n_streams_, 0.0f);
     for (auto& kv : classes) {
         const Key& k = kv.first;
@@ -592,45 +593,30 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
                 phase -= 1.0;
             }
         }
-        const float progress = (float)std::min(std::max(phase, 0.0), 1.0);
+        const float progress = (float)std::min(std::max(phase, 0.0), 1.0);  // (a stream without frames reports its standing phase)
         g.write_preview = progress > 0.0f ? 1u : 0u;
         g.streams = kv.second;
         for (uint32_t s : kv.second) {
-            const bool reset = reset_mask && reset_mask[s];
-            if (k.frames != 0 || reset) {
-                h_pushes_[s] = k.pushes + (analysis_ ? k.frames : 0);
-                h_phase_[s] = phase;
-            }
+            if (reset_mask && reset_mask[s]) resets.push_back(s);
+            h_pushes_[s] = k.pushes + (analysis_ ? k.frames : 0);
+            h_phase_[s] = phase;
             h_cols[s] = (uint32_t)std::min<uint64_t>(g.column_ends.size(), max_cols);
             h_progress[s] = progress;
         }
-        if (k.frames == 0) {
-            bool any_reset = false;
-            for (uint32_t s : kv.second) any_reset = any_reset || (reset_mask && reset_mask[s]);
-            if (any_reset) servable = false;  // (a reset without frames: the sequential kernel's business)
-            continue;                          // nothing to do for these streams
-        }
+        if (k.frames == 0) continue;  // nothing to compute for these streams (a reset among them is applied below)
         if (!chunk_shape_ok(k.frames) || g.column_ends.size() > max_cols) servable = false;
-        work += (uint64_t)kv.second.size() * k.frames;
+        longest = std::max(longest, k.frames);
         groups.push_back(std::move(g));
     }
     if (!servable || groups.empty()) return false;
-    uint64_t longest = 0;
-    for (const ChunkGroup& g : groups) longest = std::max(longest, g.frames);
     if (form_ != 2 && longest < 2048) return false;  // (the lock-step rule: short calls stay on the sequential kernels)
-    (void)work;
-    // streams whose reset flag is set start from a cleared state (the rings need no clearing: nothing older than the push count is read)
-    std::vector<uint32_t> resets;
-    for (uint32_t s = 0; s < n_streams_; ++s)
-        if (reset_mask && reset_mask[s]) resets.push_back(s);
-    // streams without frames keep their columns count 0 and their old preview: the sequential kernel reports progress for them too
-    for (auto& kv : classes)
-        if (kv.first.frames == 0)
-            for (uint32_t s : kv.second) {
-                double ph = h_phase_[s];
-                h_progress[s] = (float)std::min(std::max(ph, 0.0), 1.0);
-            }
-    if (!resets.empty()) return false;  // (kept simple: calls that reset streams run the sequential kernel; the mirror above already follows them)
+    // reset_audio of single streams (:153-155 -> rebuild): their state is cleared before anything reads it (the rings need no clearing:
+    // nothing older than the push count — now 0 — is read).  Harmless should the call fall back: the sequential kernel clears them too.
+    if (!resets.empty()) {
+        reset_list_.reserve(resets.size());
+        reset_staging_.upload(resets.data(), resets.size() * sizeof(uint32_t), reset_list_.ptr, stream);
+        launch_waveform_reset_streams(state_.ptr, reset_list_.ptr, (uint32_t)resets.size(), stream);
+    }
     if (!launch_chunk_groups(wa, groups, wa.frames, max_cols, stream)) return false;
     // the per-stream counters the sequential kernels and the caller read: push counts, phases, column counts, preview progress
     const size_t n = n_streams_;

@@ -95,6 +95,8 @@ void launch_waveform_chunked_phase1(const WaveChunkArgs& a, const double* d_T, h
 void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream);
 // ragged calls: the host's per-stream counters ([n] u64 pushes, [n] f64 phases, [n] u32 columns, [n] f32 progress, packed) -> the device
 // arrays the sequential kernels and the caller read, unless *bad (then the sequential kernel writes them itself)
+// reset_audio of the listed streams: their 16 lane states cleared (filters, compensated pairs, the open column)
+void launch_waveform_reset_streams(WaveLaneState* state, const uint32_t* streams, uint32_t n, hipStream_t stream);
 void launch_waveform_mirror_copy(const uint8_t* src, uint32_t n, uint64_t* pushes_v, double* phase_v, uint32_t* cols_v, float* progress_v,
                                  const uint32_t* bad, hipStream_t stream);
 // role-per-wavefront form (waveform_roles_kernels.hip); launch_waveform picks it whenever it applies (OMX_WAVEFORM_SINGLE=1 pins
@@ -169,8 +171,9 @@ private:
     std::vector<uint64_t> h_pushes_;
     std::vector<double> h_phase_;
     bool mirror_valid_ = false;
-    BlobStaging mirror_staging_;
+    BlobStaging mirror_staging_, reset_staging_;
     DeviceBuffer<uint8_t> mirror_dev_;
+    DeviceBuffer<uint32_t> reset_list_;
     uint32_t form_ = 0, last_form_ = 0;
     DeviceBuffer<double> transition_;
     float transition_rate_ = 0.0f;

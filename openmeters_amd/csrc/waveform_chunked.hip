@@ -597,6 +597,18 @@ __global__ __launch_bounds__(256) void wave_mirror_copy_kernel(const uint8_t* __
     cols_v[s] = reinterpret_cast<const uint32_t*>(src + (size_t)n * 16u)[s];
     progress_v[s] = reinterpret_cast<const float*>(src + (size_t)n * 20u)[s];
 }
+__global__ __launch_bounds__(256) void wave_reset_streams_kernel(WaveLaneState* state, const uint32_t* __restrict__ streams, uint32_t n) {
+    constexpr uint32_t kWords = sizeof(WaveLaneState) * 16u / 4u;  // 32-bit words of one stream's 16 lane states
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint64_t)n * kWords) return;
+    const uint32_t s = streams[t / kWords];
+    reinterpret_cast<uint32_t*>(state + (uint64_t)s * 16u)[t % kWords] = 0u;
+}
+void launch_waveform_reset_streams(WaveLaneState* state, const uint32_t* streams, uint32_t n, hipStream_t stream) {
+    if (n == 0) return;
+    const uint64_t threads = (uint64_t)n * (sizeof(WaveLaneState) * 16u / 4u);
+    hipLaunchKernelGGL(wave_reset_streams_kernel, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, state, streams, n);
+}
 void launch_waveform_mirror_copy(const uint8_t* src, uint32_t n, uint64_t* pushes_v, double* phase_v, uint32_t* cols_v, float* progress_v,
                                  const uint32_t* bad, hipStream_t stream) {
     hipLaunchKernelGGL(wave_mirror_copy_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, src, n, pushes_v, phase_v, cols_v, progress_v, bad);

@@ -977,7 +977,9 @@ def test_waveform_chunk_parallel_form_in_ragged_calls(omx, oracle, history):
             ("ragged", [8192, 8192, 8192, 1024, 1024, 8192]),
             ("ragged", [1001, 2048, 2048, 2048, 2048, 2048]),   # an odd count: the sequential kernels do this call
             ("ragged", [3072, 2026, 2026, 2026, 2026, 2026]),
-            ("ragged", [6144] * 6)]
+            ("ragged", [6144] * 6),
+            ("ragged", [4096, 4096, 4096, 0, 4096, 4096], [0, 1, 0, 1, 0, 0]),   # reset_audio of stream 1 (with frames) and of stream 3 (without)
+            ("ragged", [4096] * 6)]
     totals = [sum((p[1] if p[0] == "lock" else p[1][s]) for p in plan) for s in range(S)]
     feeds = [cfg4_pcm(70 + s, totals[s]) for s in range(S)]
     exact = [WaveExact(feeds[s], FS) for s in range(S)]
@@ -986,7 +988,9 @@ def test_waveform_chunk_parallel_form_in_ragged_calls(omx, oracle, history):
     refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
     pos = capi.positions_fallback(2)
     at, cols_seen, forms = [0] * S, [0] * S, []
-    for kind, counts in plan:
+    for entry in plan:
+        kind, counts = entry[0], entry[1]
+        mask = entry[2] if len(entry) > 2 else None
         if kind == "lock":
             chunk = np.stack([feeds[s][at[s]:at[s] + counts] for s in range(S)])
             up = bank.process_host(chunk, 2, FS)
@@ -1002,9 +1006,14 @@ def test_waveform_chunk_parallel_form_in_ragged_calls(omx, oracle, history):
         for s in range(S):
             pcm[s, :counts[s]] = feeds[s][at[s]:at[s] + counts[s]]
         d_pcm = torch.from_numpy(pcm).to("cuda:0")
-        up = bank.process_ragged(d_pcm.data_ptr(), cap, counts, 2, FS, pos)
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, counts, 2, FS, pos, mask)
         torch.cuda.synchronize()
         forms.append(bank.last_form())
+        for s in range(S):
+            if mask and mask[s]:   # the stream starts over: its oracle, and the f64 recurrence from here on
+                refs[s].reset_audio()
+                exact[s] = WaveExact(feeds[s][at[s]:], FS)
+                cols_seen[s] = 0
         n_cols = torch.as_tensor(_DevView(up.d_n_columns, (S,), "<u4"), device="cuda:0").cpu().numpy()
         progress = torch.as_tensor(_DevView(up.d_preview_progress, (S,), "<f4"), device="cuda:0").cpu().numpy()
         M = int(up.max_columns)
@@ -1025,7 +1034,7 @@ def test_waveform_chunk_parallel_form_in_ragged_calls(omx, oracle, history):
                 assert np.abs(prev[:, 2:5] - w.preview[:, 2:5]).max() <= 1e-4 * max(1e-30, np.abs(w.preview[:, 2:5]).max()), (counts, s)
             at[s] += counts[s]
             cols_seen[s] += len(w.columns)
-    assert forms == [2, 2, 2, 2, 1, 2, 2]
+    assert forms == [2, 2, 2, 2, 1, 2, 2, 2, 2]
     assert cols_seen == [len(e) for e in exact]
 
 
