@@ -769,6 +769,10 @@ int omx_oscilloscope_bank_process_ragged(omx_oscilloscope_bank* b, const float* 
                                          const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_ragged_update* out);
 int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
                                 omx_oscilloscope_block_header* header, float* samples);
+/* test hook (88.2 ... 192 kHz: the wide trigger pass runs on less LDS than its worst case and hands a stream's blocks over to the
+ * one-workgroup-per-stream kernel from the first block whose arrays do not fit): the block at which stream `stream_index` was handed over in
+ * the bank's last call — the call's block count when it never was — or -1 when the call did not run that form */
+long long omx_debug_oscilloscope_bank_resume_block(const omx_oscilloscope_bank* b, uint32_t stream_index);
 
 /* ===================================================================== *
  * State-side summary reductions — the small per-snapshot

@@ -391,6 +391,10 @@ class OscilloscopeBank(_BlockBank):
                          channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
+    def resume_block(self, stream_index: int) -> int:
+        """test hook: the block at which the capped wide trigger pass handed the stream over in the last call (omx_debug_oscilloscope_bank_resume_block)"""
+        return int(self.api.fn("debug_oscilloscope_bank_resume_block", C.c_longlong, [C.c_void_p, C.c_uint32])(self._h, stream_index))
+
     def fetch(self, stream_index, block, with_samples=False):
         hdr = COscilloscopeBlockHeader()
         buf = np.zeros((2, 4096), np.float32) if with_samples else None

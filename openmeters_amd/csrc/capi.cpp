@@ -889,4 +889,13 @@ int omx_capture_group_kernel_time(omx_capture_group* g, double* avg_ms, uint64_t
 
 }  // extern "C"
 int omx_debug_stereometer_bank_last_form(const omx_stereometer_bank* b) { return b ? b->impl.last_form() : OMX_ERR_INVALID; }
+long long omx_debug_oscilloscope_bank_resume_block(const omx_oscilloscope_bank* b, uint32_t stream_index) {
+    if (!b) return -1;
+    long long v = -1;
+    (void)guarded([&] {
+        v = b->impl.debug_resume_block(stream_index);
+        return (int)OMX_NONE;
+    });
+    return v;
+}
 int omx_debug_waveform_bank_last_form(const omx_waveform_bank* b) { return b ? (int)b->impl.last_form() : OMX_ERR_INVALID; }

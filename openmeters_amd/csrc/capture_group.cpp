@@ -32,7 +32,7 @@ CaptureGroup::CaptureGroup(const omx_capture_group_config& cfg) : cfg_(cfg) {
     enabled_ = cfg.visuals & kAllVisuals;
     for (uint32_t bit = 1; bit <= OMX_VISUAL_WAVEFORM; bit <<= 1)
         if (enabled_ & bit) ensure_bank(bit);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSideStreams; ++i) {
         OMX_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
         OMX_HIP(hipEventCreateWithFlags(&join_[i], hipEventDisableTiming));
     }
@@ -40,7 +40,7 @@ CaptureGroup::CaptureGroup(const omx_capture_group_config& cfg) : cfg_(cfg) {
 }
 
 CaptureGroup::~CaptureGroup() {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSideStreams; ++i) {
         if (side_[i]) {
             (void)hipStreamSynchronize(side_[i]);
             (void)hipStreamDestroy(side_[i]);
@@ -131,10 +131,11 @@ uint64_t CaptureGroup::block_frames_for(float sample_rate) const {
 // of `body`, so an error inside it (a failed launch, a refused shape) never leaves the caller's stream unordered against side
 // streams that may still be reading the caller's PCM.
 template <class Body>
-static int forked(hipStream_t stream, hipStream_t (&side)[2], hipEvent_t fork, hipEvent_t (&join)[2], bool (&used)[2], Body&& body) {
+static int forked(hipStream_t stream, hipStream_t (&side)[kSideStreams], hipEvent_t fork, hipEvent_t (&join)[kSideStreams], bool (&used)[kSideStreams],
+                  Body&& body) {
     OMX_HIP(hipEventRecord(fork, stream));
     auto rejoin = [&] {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kSideStreams; ++i)
             if (used[i]) {
                 (void)hipEventRecord(join[i], side[i]);
                 (void)hipStreamWaitEvent(stream, join[i], 0);
@@ -195,7 +196,7 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
         if (rc < 0) worst = worst < 0 ? worst : rc;
         else if (rc == OMX_PRODUCED) up.produced |= bit;
     };
-    bool used[2] = {false, false};
+    bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
         // ---- the caller's stream: the banks that keep pending audio, fed by one projection of the block
         {
@@ -232,11 +233,14 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
                 note(spectrum->process_pushed(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
             }
         }
-        // ---- side stream 0: loudness (+ its summary columns), waveform
-        if (loudness || waveform) {
+        // ---- one side stream per meter bank (round 4: until then loudness + waveform and stereometer + oscilloscope shared one each, and
+        //      at the reference's cadence — one 256-frame block per call, kernels of 50 ... 100 us on a few dozen workgroups — the
+        //      longer pair was the call's critical path)
+        // ---- side stream 0: loudness (+ its summary columns)
+        if (loudness) {
             used[0] = true;
             OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
-            if (loudness) {
+            {
                 const int rc = loudness->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[0], &up.d_loudness);
                 note(rc, OMX_VISUAL_LOUDNESS);
                 if (stats && rc == OMX_PRODUCED && up.d_loudness) {
@@ -254,21 +258,33 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
                     launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, side_[0]);
                 }
             }
-            if (waveform) note(waveform->process(d_pcm, true, frames, channels, sample_rate, positions, side_[0], &up.waveform), OMX_VISUAL_WAVEFORM);
             OMX_HIP(hipGetLastError());
         }
-        // ---- side stream 1: stereometer (+ its summary columns), oscilloscope
-        if (stereometer || oscilloscope) {
+        // ---- side stream 3: waveform
+        if (waveform) {
+            used[3] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[3], fork_, 0));
+            note(waveform->process(d_pcm, true, frames, channels, sample_rate, positions, side_[3], &up.waveform), OMX_VISUAL_WAVEFORM);
+            OMX_HIP(hipGetLastError());
+        }
+        // ---- side stream 1: stereometer (+ its summary columns)
+        if (stereometer) {
             used[1] = true;
             OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
-            if (stereometer) {
+            {
                 const int rc = stereometer->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1], &up.stereometer);
                 note(rc, OMX_VISUAL_STEREOMETER);
                 if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations)
                     launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, side_[1]);
             }
-            if (oscilloscope) {
-                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1]);
+            OMX_HIP(hipGetLastError());
+        }
+        // ---- side stream 2: oscilloscope
+        if (oscilloscope) {
+            used[2] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[2], fork_, 0));
+            {
+                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[2]);
                 note(rc, OMX_VISUAL_OSCILLOSCOPE);
                 if (rc == OMX_PRODUCED) {
                     up.oscilloscope.n_streams = S;
@@ -338,7 +354,7 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         if (rc < 0) worst = worst < 0 ? worst : rc;
         else if (rc == OMX_PRODUCED) up.produced |= bit;
     };
-    bool used[2] = {false, false};
+    bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
         if (spectrogram)
             note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrogram),
@@ -346,29 +362,35 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         if (spectrum)
             note(spectrum->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrum),
                  OMX_VISUAL_SPECTRUM);
-        if (loudness || waveform) {
+        if (loudness) {
             used[0] = true;
             OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
-            if (loudness)
-                note(loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions, side_[0],
-                                              &up.loudness),
-                     OMX_VISUAL_LOUDNESS);
-            if (waveform)
-                note(waveform->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, side_[0], &up.waveform),
-                     OMX_VISUAL_WAVEFORM);
+            note(loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions, side_[0],
+                                          &up.loudness),
+                 OMX_VISUAL_LOUDNESS);
             OMX_HIP(hipGetLastError());
         }
-        if (stereometer || oscilloscope) {
+        if (waveform) {
+            used[3] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[3], fork_, 0));
+            note(waveform->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, side_[3], &up.waveform),
+                 OMX_VISUAL_WAVEFORM);
+            OMX_HIP(hipGetLastError());
+        }
+        if (stereometer) {
             used[1] = true;
             OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
-            if (stereometer)
-                note(stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
-                                                 side_[1], &up.stereometer),
-                     OMX_VISUAL_STEREOMETER);
-            if (oscilloscope)
-                note(oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
-                                                  side_[1], &up.oscilloscope),
-                     OMX_VISUAL_OSCILLOSCOPE);
+            note(stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
+                                             side_[1], &up.stereometer),
+                 OMX_VISUAL_STEREOMETER);
+            OMX_HIP(hipGetLastError());
+        }
+        if (oscilloscope) {
+            used[2] = true;
+            OMX_HIP(hipStreamWaitEvent(side_[2], fork_, 0));
+            note(oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
+                                              side_[2], &up.oscilloscope),
+                 OMX_VISUAL_OSCILLOSCOPE);
             OMX_HIP(hipGetLastError());
         }
         return (int)OMX_NONE;

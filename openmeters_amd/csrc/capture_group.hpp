@@ -16,6 +16,8 @@ namespace omx {
 
 void capture_group_config_default(omx_capture_group_config* c);
 
+constexpr int kSideStreams = 4;  // one per meter bank
+
 class CaptureGroup {
 public:
     explicit CaptureGroup(const omx_capture_group_config& cfg);
@@ -56,8 +58,8 @@ private:
     std::unique_ptr<StereometerBank> stereometer_;
     std::unique_ptr<OscilloscopeBank> oscilloscope_;
     std::unique_ptr<WaveformBank> waveform_;
-    hipStream_t side_[2] = {nullptr, nullptr};
-    hipEvent_t fork_ = nullptr, join_[2] = {nullptr, nullptr};
+    hipStream_t side_[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};  // loudness, stereometer, oscilloscope, waveform
+    hipEvent_t fork_ = nullptr, join_[kSideStreams] = {nullptr, nullptr, nullptr, nullptr};
     bool stats_ = false, shared_ingest_ = true;
     // K9 state of the summary rows: the three peak holds per stream and the sample clock of the next applied snapshot
     DeviceBuffer<omx_peak_hold> holds_;

@@ -60,6 +60,14 @@ void OscilloscopeBank::clear_history() {  // :714-723
     }
 }
 
+long long OscilloscopeBank::debug_resume_block(uint32_t s) const {
+    if (!last_capped_ || s >= n_streams_) return -1;
+    uint32_t v = 0;
+    OMX_HIP(hipMemcpyAsync(&v, resume_blk_.ptr + s, sizeof(v), hipMemcpyDeviceToHost, last_launch_stream_));
+    OMX_HIP(hipStreamSynchronize(last_launch_stream_));
+    return (long long)v;
+}
+
 void OscilloscopeBank::reset_audio() {  // :593-600 (epoch survives the snapshot reset)
     clear_history();
     ragged_ = false;  // (lengths are zero: the positions are common again)
@@ -246,6 +254,17 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     }();
     sa.phase_timing = phase_timing ? 1u : 0u;
     sa.estimates = nullptr;
+    if (big) {  // the wide trigger pass on capped LDS + hand-over (scope_fast_kernels.hip: launch_oscilloscope_big)
+        static const bool legacy = tuning_env("OMX_SCOPE_BIG_LEGACY") != nullptr;  // tuning hook: A/B against the per-stream kernel alone
+        if (!legacy) {
+            resume_blk_.reserve(n_streams_);
+            resume_pos_.reserve((size_t)n_streams_ * kScopeTraces * 2);
+            sa.resume_blk = resume_blk_.ptr;
+            sa.resume_pos = resume_pos_.ptr;
+        }
+    }
+    last_capped_ = sa.resume_blk != nullptr;
+    last_launch_stream_ = stream;
     if (ragged) {
         if (!ragged_) {  // every stream starts from the bank's common positions
             std::vector<uint64_t> seed((size_t)n_streams_ * kScopeTraces * 2);

@@ -83,6 +83,12 @@ struct ScopeArgs {
     const uint32_t* blocks_v;    // [n_streams]
     const uint8_t* reset_v;      // [n_streams]
     uint64_t* epoch_v;           // [n_streams]
+    // wide trigger pass with LESS LDS than its worst case (round 4: 88.2 ... 192 kHz, whose worst-case arrays exceed a CU's 160 KiB): it runs
+    // the blocks of a stream while their arrays fit and hands the rest to the one-workgroup-per-stream kernel
+    uint32_t ref_cap;            // floats of the resident-reference region (0: max_kernel, no hand-over)
+    uint32_t* resume_blk;        // [n_streams] first block the capped pass did not run (the stream's block count: it ran them all), or nullptr
+    uint64_t* resume_pos;        // [n_streams][kScopeTraces][2] ring {head, len} in front of that block
+    uint32_t resume_mode;        // one-workgroup-per-stream kernel: continue at resume_blk[s] from resume_pos (state already past a reset)
 };
 uint64_t scope_lds_scratch_bytes(uint32_t max_kernel, uint32_t max_period, uint32_t probe_frames);
 uint64_t scope_locate_lds_bytes(uint32_t max_kernel, uint32_t max_period);
@@ -127,6 +133,9 @@ public:
     uint64_t last_blocks() const { return last_blocks_; }
     hipStream_t last_stream() const { return last_stream_; }
     const ScopeBlockHeader* d_headers() const { return headers_.ptr; }
+    // test hook: the block at which the capped wide trigger pass handed stream s over in the last call (its block count: never), or -1
+    // when the call did not run that form
+    long long debug_resume_block(uint32_t s) const;
     const float* d_samples() const { return samples_.ptr; }
     void host_outputs(bool on) { host_outputs_ = on; }  // single-stream handles: headers / samples in pinned host memory
 
@@ -157,6 +166,10 @@ private:
     DeviceBuffer<ScopeTriggerState> trig_;
     OutBuffer<ScopeBlockHeader> headers_;
     DeviceBuffer<ScopeEstimate> estimates_;
+    DeviceBuffer<uint32_t> resume_blk_;   // capped wide trigger pass: where the per-stream kernel takes over
+    DeviceBuffer<uint64_t> resume_pos_;
+    bool last_capped_ = false;
+    hipStream_t last_launch_stream_ = nullptr;
     hipStream_t last_stream_ = nullptr;
     // ragged mode: per-stream ring positions and epochs on the device
     bool ragged_ = false;

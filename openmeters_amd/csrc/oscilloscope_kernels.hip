@@ -781,8 +781,13 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     }
     // ragged banks: the stream's own block count, ring positions and reset flag (workgroup-uniform: one workgroup per stream)
     const bool ragged = a.blocks_v != nullptr;
-    const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;  // clear_history (:714-723) of this stream
+    // resume_mode: the capped wide trigger pass (scope_fast_kernels.hip) ran the stream's blocks up to resume_blk[s]; this kernel takes
+    // the rest from the positions it left (its reset, if any, is already in the state)
+    const bool resume = a.resume_mode != 0;
+    const bool reset_stream = !resume && ragged && a.reset_v != nullptr && a.reset_v[s] != 0;  // clear_history (:714-723) of this stream
     const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t first_blk = resume ? a.resume_blk[s] : 0u;
+    if (first_blk >= n_blocks_s && resume) return;  // (workgroup-uniform; nothing left for this stream)
     if (tid < kScopeTraces) {
         ScopeTriggerState t0;
         memset(&t0, 0, sizeof(t0));
@@ -796,12 +801,16 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     for (int t = 0; t < kScopeTraces; ++t) {
         head[t] = ragged ? a.pos_v[((uint64_t)s * kScopeTraces + t) * 2] : a.head[t];
         len[t] = ragged ? (reset_stream ? 0ull : a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1]) : a.len[t];
+        if (resume) {
+            head[t] = a.resume_pos[((uint64_t)s * kScopeTraces + t) * 2];
+            len[t] = a.resume_pos[((uint64_t)s * kScopeTraces + t) * 2 + 1];
+        }
     }
     const bool active[2] = {a.trace_channel[0] != OMX_CHANNEL_NONE, a.trace_channel[1] != OMX_CHANNEL_NONE};
 
     PhaseClock pc;
     pc.start(a.phase_timing != 0);
-    for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
+    for (uint32_t blk = first_blk; blk < n_blocks_s; ++blk) {
         // ---- push projected frames (:657-681) — unless scope_push2_kernel has put the whole call into the rings already
         for (uint32_t f = a.pre_pushed ? a.block_frames : tid; f < a.block_frames; f += 256) {
             const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;

@@ -836,6 +836,60 @@ __host__ __device__ inline TriggerLayout trigger_layout(uint32_t max_kernel, uin
 
 }  // namespace
 
+// StableTrigger::capture's unlock (:298-304) + stabilize (:336-356) as a pure function of the trigger's registers and the block's
+// estimate: the registers after the step, and the estimate `locate` is called with (some = 0: no capture from locate)
+__device__ __forceinline__ Estimate stabilise(TrigRegs& r, const ScopeEstimate& pre, uint32_t probe_len) {
+    if (probe_len > 0 && pre.last_peak < MIN_SIGNAL_PEAK) {  // unlock
+        r.has_period = 0;
+        r.missed_periods = 0;
+        r.ref_len = 0;
+        r.reference_period = 0.0f;
+        r.mean = 0.0f;
+    }
+    Estimate est{pre.some, pre.period, pre.confidence};
+    if (!est.some) {
+        if (r.has_period) {
+            r.missed_periods = r.missed_periods >= 255 ? 255 : r.missed_periods + 1;
+            if (r.missed_periods > MAX_MISSED_PERIODS) {
+                r.has_period = 0;
+                r.missed_periods = 0;
+                r.ref_len = 0;
+                r.reference_period = 0.0f;
+                r.mean = 0.0f;
+            } else {
+                est = Estimate{1, r.period, 0.0f};
+            }
+        }
+    } else {
+        r.missed_periods = 0;
+        if (r.has_period) {
+            const float q = est.period / r.period;
+            if (q >= 0.9f && q <= 1.1f) est.period = r.period + 0.35f * (est.period - r.period);
+        }
+        r.has_period = 1;
+        r.period = est.period;
+    }
+    return est;
+}
+
+// whether `locate` for this estimate fits its arrays (raw span, mean-removed span, one template copy) into `dyn_floats` and its kernel
+// into the reference region: the head of locate (:358-372), without side effects
+__device__ __forceinline__ bool locate_fits(uint32_t n, float est_period, uint32_t cycles, float rate, uint32_t dyn_floats, uint32_t ref_cap) {
+    const float period = fmaxf(est_period, 1.0f);
+    const float span = period * (float)max(cycles, 1u);
+    const uint32_t frames = f2u(ceilf(span)) + 1;
+    const uint32_t len = trigger_kernel_len(period, rate);
+    const uint32_t before = len / 2, after = len - before;
+    const uint32_t tail = max(frames, after);
+    if (n < tail) return true;  // (locate returns before it touches LDS)
+    const uint32_t right = n - tail;
+    if (right < before) return true;
+    uint32_t search = max(f2u(roundf(period * SEARCH_PERIODS)), 1u);
+    search = min(min(search, len / 2), right - before);
+    const uint32_t span4 = (len + search + 8 + 3) & ~3u, len4 = (len + 12 + 3) & ~3u;
+    return 2u * span4 + len4 <= dyn_floats && len <= ref_cap;
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t lds_floats) {
     constexpr int W = T / 64;
@@ -849,11 +903,13 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
     const unsigned tid = threadIdx.x;
     const uint32_t s = blockIdx.x;
     Ctx<T> c;
+    // (ref_cap != 0: launched with less LDS than the worst case — blocks whose arrays do not fit are handed over, see below)
+    const uint32_t ref_cap = a.ref_cap ? a.ref_cap : a.max_kernel;
     {
-        const TriggerLayout l = trigger_layout(a.max_kernel, a.max_period);
+        const uint32_t ref_floats = a.ref_cap ? ((a.ref_cap + 8 + 3) & ~3u) : trigger_layout(a.max_kernel, a.max_period).ref;
         c.ref = lds_f;
-        c.dyn = lds_f + l.ref;
-        c.dyn_floats = lds_floats - l.ref;
+        c.dyn = lds_f + ref_floats;
+        c.dyn_floats = lds_floats - ref_floats;
         c.raw = c.work = c.tmpl = c.dyn;
         c.tmpl_stride = 0;
     }
@@ -882,6 +938,7 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
     __shared__ unsigned long long phase_acc[SCOPE_PHASES];
     c.pc.start(a.phase_timing != 0, phase_acc);
 
+    uint32_t blocks_run = n_blocks_s;
     for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
         const uint32_t par = blk & 1u;
         if (tid < kScopeTraces) {  // the block's frames are in the rings already (scope_push_kernel)
@@ -896,6 +953,36 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
             if (tid < cnt) (&est_lds[0][0])[tid] = src[tid];
         }
         lds_barrier();  // positions, estimates; and the previous block is through with every LDS array
+        if (a.resume_blk != nullptr && stable) {
+            // Capped LDS: will every capture of this block (the job loop below, dry) fit its arrays?  Decided before anything of the block
+            // is touched — the trigger records, the resident reference — from values every thread holds alike; a block that does not fit
+            // ends this kernel's part of the stream, the one-workgroup-per-stream kernel continues from here (oscilloscope_kernels.hip).
+            bool fits = true;
+            const bool linked_runs = linked_view >= 0 && uni((uint32_t)s_len[par][linked_view]) >= a.base_frames;
+            for (int job = 0; job < 3; ++job) {
+                int view_index, trig_index;
+                if (job == 0) {
+                    if (linked_view < 0) continue;
+                    view_index = linked_view;
+                    trig_index = 2;
+                } else {
+                    if (!(job == 1 ? active0 : active1) || linked_runs) continue;
+                    view_index = trig_index = job - 1;
+                }
+                const uint32_t n = uni((uint32_t)s_len[par][view_index]);
+                if (n < a.base_frames) continue;
+                TrigRegs r = load_trig_uniform(trig[trig_index]);
+                fits = fits && r.ref_len <= ref_cap;  // the learnt reference itself
+                const ScopeEstimate& pl = est_lds[blk % kEstChunk][view_index];
+                const ScopeEstimate pre{uni(pl.some), uni(pl.period), uni(pl.confidence), uni(pl.last_peak)};
+                const Estimate est = stabilise(r, pre, min(a.probe_frames, n));
+                if (est.some) fits = fits && locate_fits(n, est.period, a.num_cycles, a.sample_rate, c.dyn_floats, ref_cap);
+            }
+            if (!fits) {
+                blocks_run = blk;
+                break;
+            }
+        }
         auto view_of = [&](int t) {
             return View{rings + (uint64_t)t * a.cap, uni((uint32_t)((s_head[par][t] - s_len[par][t]) & mask)), (uint32_t)mask, uni((uint32_t)s_len[par][t])};
         };
@@ -954,36 +1041,14 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
                 }
                 c.pc.mark(0);  // bookkeeping
                 const uint32_t probe_len = min(a.probe_frames, trace.n);
-                if (probe_len > 0 && pre.last_peak < MIN_SIGNAL_PEAK) {  // unlock (:298-304)
-                    has_period = 0;
-                    missed = 0;
-                    ref_len = 0;
-                    reference_period = 0.0f;
-                    mean = 0.0f;
-                }
-                Estimate est{pre.some, pre.period, pre.confidence};  // stabilize (:336-356)
-                if (!est.some) {
-                    if (has_period) {
-                        missed = missed >= 255 ? 255 : missed + 1;
-                        if (missed > MAX_MISSED_PERIODS) {
-                            has_period = 0;
-                            missed = 0;
-                            ref_len = 0;
-                            reference_period = 0.0f;
-                            mean = 0.0f;
-                        } else {
-                            est = Estimate{1, period, 0.0f};
-                        }
-                    }
-                } else {
-                    missed = 0;
-                    if (has_period) {
-                        const float r = est.period / period;
-                        if (r >= 0.9f && r <= 1.1f) est.period = period + 0.35f * (est.period - period);
-                    }
-                    has_period = 1;
-                    period = est.period;
-                }
+                TrigRegs regs{has_period, period, missed, reference_period, mean, ref_len};
+                const Estimate est = stabilise(regs, pre, probe_len);
+                has_period = regs.has_period;
+                period = regs.period;
+                missed = regs.missed_periods;
+                reference_period = regs.reference_period;
+                mean = regs.mean;
+                ref_len = regs.ref_len;
                 if (est.some) cap = locate(c, ref_len, reference_period, mean, trace, est, a.num_cycles, a.sample_rate);
                 if (!cap.some) {
                     cap.some = 1;
@@ -1058,10 +1123,15 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
     }
     if (tid < kScopeTraces) {
         a.trig[(uint64_t)s * kScopeTraces + tid] = trig[tid];
+        const uint32_t last = (blocks_run & 1u) ^ 1u;  // parity of the last block run (1 = the initial slot when none ran)
         if (ragged) {
-            const uint32_t last = (n_blocks_s & 1u) ^ 1u;  // parity of the last block run (1 = the initial slot when none ran)
             a.pos_v[((uint64_t)s * kScopeTraces + tid) * 2] = s_head[last][tid];
             a.pos_v[((uint64_t)s * kScopeTraces + tid) * 2 + 1] = s_len[last][tid];
+        }
+        if (a.resume_blk != nullptr) {  // where the one-workgroup-per-stream kernel takes over (nowhere: blocks_run == the stream's count)
+            a.resume_pos[((uint64_t)s * kScopeTraces + tid) * 2] = s_head[last][tid];
+            a.resume_pos[((uint64_t)s * kScopeTraces + tid) * 2 + 1] = s_len[last][tid];
+            if (tid == 0) a.resume_blk[s] = blocks_run;
         }
     }
     if (ragged && tid == 0 && reset_stream) a.epoch_v[s] += 1;
@@ -1728,7 +1798,23 @@ void launch_oscilloscope_big(const ScopeArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(scope_estimate_big_kernel<14>, dim3(a.n_streams, a.n_blocks, a.est_view_count), dim3(FftGeom<14>::T),
                                FftGeom<14>::LDS * sizeof(v2f), stream, a);
     }
-    launch_oscilloscope(a, stream);
+    if (a.resume_blk == nullptr) {  // (round-4 first form, kept for A/B: the one-workgroup-per-stream kernel runs every block)
+        launch_oscilloscope(a, stream);
+        return;
+    }
+    // the wide trigger pass on 152 KiB of LDS: the kernel is max(40 ms, two periods) long (:184-189), so at 192 kHz every signal above
+    // 50 Hz fits (5 len + 36 floats: reference, raw span, mean-removed span, template); what does not is handed over block by block
+    static std::once_flag trig_once;
+    std::call_once(trig_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scope_trigger_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    });
+    ScopeArgs w = a;
+    const uint32_t lds_floats = 152 * 1024 / sizeof(float);
+    w.ref_cap = std::min<uint32_t>(a.max_kernel, (lds_floats - 36u) / 5u);
+    hipLaunchKernelGGL(scope_trigger_kernel<512>, dim3(a.n_streams), dim3(512), (size_t)lds_floats * sizeof(float), stream, w, lds_floats);
+    ScopeArgs r = a;
+    r.resume_mode = 1;
+    launch_oscilloscope(r, stream);
 }
 
 }  // namespace omx
