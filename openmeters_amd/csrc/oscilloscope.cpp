@@ -254,9 +254,13 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     }();
     sa.phase_timing = phase_timing ? 1u : 0u;
     sa.estimates = nullptr;
-    if (big) {  // the wide trigger pass on capped LDS + hand-over (scope_fast_kernels.hip: launch_oscilloscope_big)
-        static const bool legacy = tuning_env("OMX_SCOPE_BIG_LEGACY") != nullptr;  // tuning hook: A/B against the per-stream kernel alone
-        if (!legacy) {
+    // the wide trigger pass on capped LDS + hand-over (scope_fast_kernels.hip: launch_oscilloscope_big).  At 48 kHz the worst case fits a CU
+    // and the capped form (64 KiB, tuning hook OMX_SCOPE_WIDE_CAPPED) measured 3 % slower at cfg4 and 3 ... 8 % slower at the streaming
+    // cadence: the dry run and the hand-over launch cost more than the freed LDS returns
+    static const bool wide_capped = tuning_env("OMX_SCOPE_WIDE_CAPPED") != nullptr;
+    if (big || (wide && wide_capped)) {
+        static const bool legacy = tuning_env("OMX_SCOPE_BIG_LEGACY") != nullptr;   // tuning hook: A/B against the per-stream kernel alone
+        if (!(big && legacy)) {
             resume_blk_.reserve(n_streams_);
             resume_pos_.reserve((size_t)n_streams_ * kScopeTraces * 2);
             sa.resume_blk = resume_blk_.ptr;

@@ -1767,7 +1767,24 @@ void launch_oscilloscope_fast(const ScopeArgs& a, hipStream_t stream) {
     }
     const TriggerLayout l = trigger_layout(a.max_kernel, a.max_period);
     const uint32_t len4 = (a.max_kernel + 12 + 3) & ~3u;
-    const uint32_t lds_floats = std::min<uint32_t>(l.ref + l.dyn_min + 3 * len4, 152 * 1024 / sizeof(float));  // + ~5 KiB of static LDS <= 160 KiB
+    uint32_t lds_floats = std::min<uint32_t>(l.ref + l.dyn_min + 3 * len4, 152 * 1024 / sizeof(float));  // + ~5 KiB of static LDS <= 160 KiB
+    if (a.resume_blk != nullptr) {
+        // capped form (see launch_oscilloscope_big): 64 KiB instead of the 105 ... 150 KiB worst case — the kernel is max(40 ms, two periods)
+        // long, 1920 samples at 48 kHz for everything above 50 Hz (5 len + 36 floats = 38 KiB; the cap admits periods up to 1634 samples,
+        // 29 Hz) — so two trigger workgroups share a CU, or one leaves room for the other meters' kernels; blocks that do not fit are
+        // handed to the one-workgroup-per-stream kernel
+        ScopeArgs w = a;
+        lds_floats = 64 * 1024 / sizeof(float);
+        w.ref_cap = std::min<uint32_t>(a.max_kernel, (lds_floats - 36u) / 5u);
+        hipLaunchKernelGGL(scope_trigger_kernel<512>, dim3(a.n_streams), dim3(512), (size_t)lds_floats * sizeof(float), stream, w, lds_floats);
+        ScopeArgs r = a;
+        r.resume_mode = 1;
+        r.pre_pushed = 1;
+        r.fft_global = nullptr;
+        r.lds_scratch = scope_locate_lds_bytes(a.max_kernel, a.max_period) <= 150 * 1024 ? 2u : 0u;
+        launch_oscilloscope(r, stream);
+        return;
+    }
     if (threads == 256)
         hipLaunchKernelGGL(scope_trigger_kernel<256>, dim3(a.n_streams), dim3(256), (size_t)lds_floats * sizeof(float), stream, a, lds_floats);
     else if (threads == 1024)
