@@ -1243,7 +1243,17 @@ __global__ __launch_bounds__(256) void scope_push2_kernel(ScopeArgs a) {
 //   D[tau] = E[n - tau] + (E[n] - E[tau]) -> their own 9.6 KiB                             [scan + two barriers]
 //   autocorrelation = IFFT_4096(packed |FFT_8192|^2) through one 4096-point transform each way (as in round 1)
 //   nsdf[tau] written over D[tau]; zero crossing, best candidate, first candidate within the cutoff [three reductions]
+#ifdef OMX_EST_PHASES
+#define EST_T0 long long est_t = clock64(); long long est_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define EST_MARK(i) { const long long now = clock64(); est_ph[i] += now - est_t; est_t = now; }
+#define EST_REPORT if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 40) printf("estimate2 phases: load+reduce %lld | squares+scan %lld | D %lld | fwd %lld | power %lld | inv %lld | nsdf %lld | zero crossing %lld | candidates %lld\n", est_ph[0], est_ph[1], est_ph[2], est_ph[3], est_ph[4], est_ph[5], est_ph[6], est_ph[7], est_ph[8]);
+#else
+#define EST_T0
+#define EST_MARK(i)
+#define EST_REPORT
+#endif
 __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
+    EST_T0
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ RedSlots<4> slots;
     __shared__ v2f tw2_lds[256];
@@ -1319,6 +1329,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         }
     }
     red.run<3, (OP_SUM) | (OP_MAX << 2) | (OP_MIN << 4)>(r3);
+    EST_MARK(0)
     const float mean = r3[0] / (float)n;
     last_peak = fmaxf(fabsf(r3[1] - mean), fabsf(r3[2] - mean));  // max |x - mean| (:98-101): attained at an extreme of x
     const float rate = a.sample_rate;
@@ -1374,6 +1385,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         else scan(std::integral_constant<int, 32>{});
     }
     __syncthreads();
+    EST_MARK(1)
     const float total_energy = E[n];
     for (uint32_t tau = tid; tau <= max_lag; tau += 256) D[tau] = E[n - tau] + (total_energy - E[tau]);
     if (total_energy <= F32_EPS) {  // (:168)
@@ -1381,6 +1393,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         return;
     }
     __syncthreads();  // E is dead: the transform buffer takes its place
+    EST_MARK(2)
     // Autocorrelation of the zero-padded real probe through two 4096-point transforms (:147-160 computes FFT_8192(x + 0i),
     // |.|^2, IFFT_8192, real part):  z[m] = x[2m] + i x[2m+1];  Z = FFT_4096(z);  E, O = even / odd sample spectra;
     //   X[k] = E + w^k O, X[k+N] = E - w^k O;  P = |X|^2 (real, P[2N-k] = P[k]);
@@ -1391,6 +1404,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
     for (int t = 0; t < 16; ++t) w8[t] = a.tw_fft[(uint32_t)(j + 256 * t)];  // exp(-2 pi i k / 8192), wanted after the forward transform
     fft4096t<false, false>(v, fft, fft, j, tw);
     __syncthreads();
+    EST_MARK(3)
 #pragma unroll
     for (int t = 0; t < 16; ++t) fft[pad16(j + 256 * t)] = v[t];
     __syncthreads();
@@ -1414,7 +1428,9 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         y[t] = v2f{sum + dif * w.y, dif * w.x};
     }
     __syncthreads();
+    EST_MARK(4)
     fft4096t<true, false>(y, fft, fft, j, tw);  // y[t] = (acf[2m], acf[2m + 1]), m = j + 256 t
+    EST_MARK(5)
     const float norm = 1.0f / 8192.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -1429,6 +1445,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
         }
     }
     __syncthreads();
+    EST_MARK(6)
     const float* nsdf = D;
     // first tau >= 1 with nsdf <= 0 (:110)
     uint32_t zc = 0xFFFFFFFFu;
@@ -1438,6 +1455,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
             break;
         }
     zc = red.run_u32<false>(zc);
+    EST_MARK(7)
     ScopeEstimate res{0, 0.0f, 0.0f, last_peak};
     const uint32_t first_tau = max(min_period, zc);
     if (zc != 0xFFFFFFFFu && first_tau < max_period) {
@@ -1472,6 +1490,8 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
             res.confidence = rclamp(nsdf[peak], 0.0f, 1.0f);
         }
     }
+    EST_MARK(8)
+    EST_REPORT
     if (tid == 0) *out = res;
 }
 
