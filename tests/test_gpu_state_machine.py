@@ -830,7 +830,7 @@ def test_ragged_stereometer_bank_random_per_stream_block_counts_match_per_stream
             if int(nb[s]) == 0 and (int(nb.max()) > 0 or mask.any()):
                 assert bank.fetch_points(s, 0).shape[0] == 0      # no block, no snapshot
             at[s] += int(nb[s]) * block
-    assert compared > 100 and produced_n > 10   # (sanity of the sequence: resets before the history fills leave few snapshots — seed 12080200: 38)
+    assert compared > 50 and produced_n > 10   # (sanity of the sequence, not of the product: seed 12080200 compares 95 blocks, 38 of them with snapshots)
     chunk = np.stack([f[:block] for f in feeds])
     with pytest.raises(capi.OmxError):
         bank.process_host(chunk, block, C, 48000.0, pos)
