@@ -470,6 +470,8 @@ def main():
                 sec["waveform_1024"] = bench_meters.waveform(sizes=(1024,), out=sys.stderr)   # §8f rank 3, with its roofline objects
                 import bench_stream
                 sec["streaming_256"] = bench_stream.streaming(out=sys.stderr)   # the reference's own cadence: one batcher block per call
+                import bench_scope_rates
+                sec["oscilloscope_rates"] = bench_scope_rates.rates(which=(96000.0, 192000.0), out=sys.stderr)   # cfg4's bank at the high rates
                 result["secondary"] = sec
             except Exception as e:  # the headline line must survive a failure here
                 result["secondary"] = {"error": repr(e)}
