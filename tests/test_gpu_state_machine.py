@@ -302,7 +302,10 @@ def test_oscilloscope_random_operation_sequences(omx, oracle, seed):
         edge = np.zeros_like(d, dtype=bool)
         edge[:, 1:] |= step_in > 0.2
         edge[:, :-1] |= step_in > 0.2
-        assert d[~edge].max(initial=0.0) <= 0.05, (seed, step)
+        # (off the discontinuities a capture up to one sample away moves a value by the trace's own step there: seed 15025045, a 1760 Hz sine
+        # — 0.138 per sample — locked on a 15-cycle period, the two sides one sine cycle (27.27 samples) apart: 0.146)
+        smooth = step_in[step_in <= 0.2]
+        assert d[~edge].max(initial=0.0) <= max(0.05, 1.1 * float(smooth.max(initial=0.0))), (seed, step)
         if edge.any():
             assert d[edge].max() <= 1.2 + 0.05, (seed, step)   # the jump itself: the periods' fractional parts add up over the periods skipped (seeds 12020041, 12037042)
         compared += 1
