@@ -45,7 +45,15 @@ def align_points(a, b, max_power, band_extra=8):
     is monotone; a point present on one side only (a bin on the 1e-14 keep-floor or on the 0 < f < fs/2 edge) is a gap.
       pair cost = |dP| / max P  +  1e-3 r |df| / 24 kHz     (r = sqrt(P / max P): the reassigned frequency of a weak bin is noise;
                                                              the term only breaks ties between otherwise equal alignments)
-      gap cost  = P / max P + 1e-9   (the constant keeps floor-level bins with noisy frequencies paired rather than dropped)
+      gap cost  = GAP P / max P + 1e-9,  GAP = 0.75          (the constant keeps floor-level bins with noisy frequencies paired rather
+                                                             than dropped)
+    Why GAP < 1: with GAP = 1 the costs tie BY CONSTRUCTION whenever a point X present on one side only is followed by a monotone
+    run of points up to some y — "gap X" costs P(X); "pair everything from X to y shifted by one, gap y" costs the telescoping sum
+    |P(y) - P(X)| plus P(y), which is P(X) again when the run descends — and the parity error of the run's powers decided (soak seed
+    16016002: a point at fs/2 - 0.07 Hz kept by one side only beside a neighbour 38 dB weaker, read as a 38-hop t-hat error; the last
+    bins below fs/2 of the Hamming x 8 zero-padding column of the matrix tests, read as r |dt| = 1e-4 and the reason that shape ran
+    on doubled bars).  With GAP < 1 the shifted alignment costs (1 - GAP) |P(X) - P(y)| more (descending) or (1 + GAP) of it
+    (ascending).  Two points pair unless one is more than 7x the other in power (then both are orphans and the orphan bars judge them).
     Exact pairs cost ~0, so whenever the lists agree up to a few floor-level orphans that alignment wins; a greedy merge
     (the first version) could slip by one entry behind such an orphan and then "pair" neighbours whose powers happen to lie
     within the tolerance of each other.
@@ -55,6 +63,7 @@ def align_points(a, b, max_power, band_extra=8):
     n, m = len(a), len(b)
     if n == 0 or m == 0:
         return [], list(range(n)), list(range(m))
+    GAP = 0.75
     inv = 1.0 / max_power
     pa = [float(x) * inv for x in a[:, 2]]
     pb = [float(x) * inv for x in b[:, 2]]
@@ -69,13 +78,13 @@ def align_points(a, b, max_power, band_extra=8):
     for k in range(width):
         j = k - band
         if 0 <= j <= m:
-            prev[k] = sum(pb[:j]) + 1e-9 * j
+            prev[k] = GAP * sum(pb[:j]) + 1e-9 * j
     back.append([2] * width)  # row 0: only gaps in b
     for i in range(1, n + 1):
         cur = [INF] * width
         bk = [0] * width
         ai_p, ai_f = pa[i - 1], fa[i - 1]
-        gap_a = ai_p + 1e-9
+        gap_a = GAP * ai_p + 1e-9
         for k in range(width):
             j = i + k - band
             if j < 0 or j > m:
@@ -96,7 +105,7 @@ def align_points(a, b, max_power, band_extra=8):
                         best, how = c, 3
                 # b[j-1] unmatched: from (i, j-1): k - 1 in the current row
                 if k >= 1 and cur[k - 1] < INF:
-                    c = cur[k - 1] + pb[j - 1] + 1e-9
+                    c = cur[k - 1] + GAP * pb[j - 1] + 1e-9
                     if c < best:
                         best, how = c, 2
             cur[k], bk[k] = best, how

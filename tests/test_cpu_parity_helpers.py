@@ -44,3 +44,24 @@ def test_alignment_of_empty_and_one_sided_columns():
     assert align_points(c, c[:0], 1.0) == ([], [0, 1, 2, 3, 4], [])
     pairs, oa, ob = align_points(c, c[1:], float(c[:, 2].max()))
     assert oa == [0] and not ob and pairs == [(i + 1, i) for i in range(4)]
+
+
+def test_alignment_gaps_the_strong_point_kept_by_one_side_only():
+    """soak seed 16016002: the last bins below fs/2 of a quiet column; one side keeps a point at fs/2 - 0.07 Hz (the other side's
+    f-hat sits on the far side of the keep test) next to a neighbour 38 dB weaker whose power differs by parity-level rounding.  The
+    power costs of "gap the strong point" and "pair it with the weak neighbour, gap that one" tie by construction."""
+    rng = np.random.default_rng(6)
+    ora = column(rng, 300)
+    top = float(ora[:, 2].max())
+    ora[-3:] = np.array([[-58.4, 22016.7, 1.4144e-11 * top / 1.137e-6], [-76.5, 22039.8, 1.1000e-11 * top / 1.137e-6],
+                         [-32.46, 22046.7, 2.126e-10 * top / 1.137e-6]], np.float32)
+    extra = np.array([-38.6, 22049.93, 4.147e-10 * top / 1.137e-6], np.float32)
+    for sign in (1.0, -1.0):
+        hip = ora.copy()
+        hip[-2, 2] *= np.float32(1.0 + sign * 1.5e-3)     # the weak neighbour, off by what a quiet column's bars allow
+        with_extra = np.insert(ora, len(ora) - 1, extra, axis=0)
+        pairs, oa, ob = align_points(hip, with_extra, top)
+        assert oa == [] and ob == [len(ora) - 1], (sign, oa, ob)
+        assert all(i == j if j < len(ora) - 1 else i == j - 1 for i, j in pairs)
+        pairs, oa, ob = align_points(with_extra, hip, top)
+        assert ob == [] and oa == [len(ora) - 1], (sign, oa, ob)

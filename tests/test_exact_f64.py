@@ -28,11 +28,9 @@ REASSIGNED_SHAPES = [(4096, 256, 1, 1), (2048, 64, 1, 1), (1024, 256, 2, 3), (40
 CLASSIC_SHAPES = [(1024, 256, 1, 1), (4096, 256, 1, 1), (2048, 128, 2, 3)]
 HALF_CODE_DB = 0.5 * 156.0 / 65535.0
 CLASSIC_ARITHMETIC_DB = 1e-4   # arithmetic error allowed on top of the quantiser's own half code
-# The reference's OWN f32 arithmetic is this far from exact arithmetic in t-hat on one shape of the list: Hamming (whose end points are
-# 0.08, a step for the time-weighted window t w) through 8x zero padding measures 1.08e-4 hops, against 3e-7 ... 6e-6 elsewhere.  The
-# bar on the ORACLE is therefore 2e-4 there; the HIP kernels (window applied on the bins, no t w table) measure 3.3e-6 on that shape
-# and keep the 1e-4 bar.  The HIP-vs-oracle comparison of that shape (test_gpu_parity_matrix.py) carries the same factor.
-ORACLE_TIME_BAR = {(2048, 256, 8, 2): 2e-4}
+# (Until round 4 one shape carried a doubled t-hat bar on the oracle: Hamming through 8x zero padding "measured" 1.08e-4 hops.  That was
+# the column ALIGNMENT, not arithmetic: two bins below fs/2 kept by one side only, and a cost tie that paired their neighbours one bin
+# apart (parity.align_points, "Why GAP < 1").  Aligned properly the shape measures 6e-6 like the others.)
 
 
 def mid_of(pcm):
@@ -87,7 +85,7 @@ def classic_errors(api, W, hop, zp, kind, ncols=6):
 @pytest.mark.parametrize("W,hop,zp,kind", REASSIGNED_SHAPES)
 def test_oracle_reassigned_column_is_within_1e5_of_exact_arithmetic(oracle, W, hop, zp, kind):
     e = reassigned_errors(oracle, W, hop, zp, kind)
-    assert e["power"] <= 1e-5 and e["freq"] <= 1e-7 and e["time"] <= ORACLE_TIME_BAR.get((W, hop, zp, kind), 1e-4), e
+    assert e["power"] <= 1e-5 and e["freq"] <= 1e-7 and e["time"] <= 1e-4, e
     assert e["power"] <= 5e-6, e      # measured 2.6e-7 ... 1.7e-6 up to 8192 points, 3.8e-6 at 16384 (f32 radix-2, 14 stages)
 
 
@@ -104,7 +102,7 @@ def test_hip_and_oracle_are_equally_close_to_exact_arithmetic_reassigned(omx, or
     for who, e in (("hip", h), ("oracle", o)):
         bar(f"{who} vs exact f64: |dP| / max P", e["power"], 1e-5)
         bar(f"{who} vs exact f64: r |df| / (fs/2)", e["freq"], 1e-7)
-        bar(f"{who} vs exact f64: r |dt| hops", e["time"], ORACLE_TIME_BAR.get((W, hop, zp, kind), 1e-4) if who == "oracle" else 1e-4)
+        bar(f"{who} vs exact f64: r |dt| hops", e["time"], 1e-4)
     # the product must not be the noisier implementation: its distance from exact arithmetic within 2x of the oracle's.  (The
     # other direction is recorded, not limited: the fused kernels take fewer rounding steps than the oracle's radix-2 transforms,
     # and the four-transform kernels use the closed-form derivative window instead of an f32 table — in f-hat they sit one to two

@@ -43,8 +43,7 @@ def test_reassigned_big_transforms_every_window_kind(omx, oracle, window, W, zp,
     blk = AudioBlock(pcm.reshape(-1), 2, 48000.0)
     g, w = SpectrogramProcessor(omx, cfg).process_block(blk), SpectrogramProcessor(oracle, cfg).process_block(blk)
     assert len(g.new_columns) == len(w.new_columns) == 3 and g.reassigned_power_scale == w.reassigned_power_scale
-    # Hamming through 8x zero padding: the ORACLE's t-hat is 1.08e-4 hops from exact arithmetic (HIP 3.3e-6), see tests/test_exact_f64.py
-    check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop, scale=2.0 if (window == capi.WINDOW_HAMMING and zp == 8) else 1.0)
+    check_reassigned_columns(g.new_columns, w.new_columns, 48000.0, hop)
 
 
 @pytest.mark.parametrize("W,zp,hop", [(1024, 32, 256), (2048, 16, 64), (2048, 32, 64), (4096, 8, 256), (8192, 4, 512), (16384, 2, 1024), (4096, 32, 256),
