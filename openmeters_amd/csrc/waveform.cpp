@@ -412,6 +412,7 @@ static bool plan_chunk_group(WaveformBank::ChunkGroup& g, uint32_t C, bool histo
         ev.out = 0xFFFFFFFFu;
         ev.carry = n_emit == 0 ? 1u : 0u;
     }
+    cuts.push_back(INT32_MAX);  // (pass B looks up the cut after the one it has just reached: one entry behind the last, never reached)
     return true;
 }
 
