@@ -15,8 +15,9 @@ class Spy:
 import builtins
 src = open(os.path.join(ROOT, "tests", "test_gpu_state_machine.py")).read()
 # run the test body with the last assert replaced by a print
-body = src.replace("        assert d[~edge].max(initial=0.0) <= 0.05, (seed, step)",
+body = src.replace("        assert d[~edge].max(initial=0.0) <= max(0.05, 1.1 * float(smooth.max(initial=0.0))), (seed, step)",
                    "        if d.max() > 0.01: print('step', step, 'max diff', d.max(), 'non-edge max', d[~edge].max(initial=0.0), 'at', np.unravel_index(d.argmax(), d.shape), 'spc', g.samples_per_channel, 'rate', ra, rb, 'frames', frames, 'kind', kind, 'cfg', cfg)\n        if d[~edge].max(initial=0.0) > 0.05:\n            np.save('/tmp/scope_g.npy', g.samples); np.save('/tmp/scope_w.npy', w.samples)")
+assert body != src, 'the assert this script replaces has changed'
 ns = {}
 exec(compile(body, "sm", "exec"), ns)
 ns["test_oscilloscope_random_operation_sequences"](omx, oracle, seed)
