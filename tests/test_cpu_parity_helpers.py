@@ -65,3 +65,41 @@ def test_alignment_gaps_the_strong_point_kept_by_one_side_only():
         assert all(i == j if j < len(ora) - 1 else i == j - 1 for i, j in pairs)
         pairs, oa, ob = align_points(with_extra, hip, top)
         assert ob == [] and oa == [len(ora) - 1], (sign, oa, ob)
+
+
+def test_alignment_recovers_the_bins_of_real_columns_with_one_sided_orphans():
+    """Ground truth from the exact-f64 leg (it knows every point's bin): one list is the column, the other one the same column with
+    parity-like noise, minus floor-level points (power within 20 % of the 1e-14 keep floor: either side may lose them) and minus
+    three of the first / last six points on ONE side (the 0 < f-hat < fs/2 keep test).  Every pair must join equal bins.  (With gap
+    cost = P, before round 4's fix, these trials produce hundreds of pairs one bin apart: the tie of the docstring.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import exact_f64 as ex
+    from signals import exp_sweep, xorshift32_noise
+
+    for W, zp, hop, kind in ((2048, 2, 64, 4), (1024, 1, 256, 1), (512, 1, 64, 0), (2048, 8, 256, 2)):
+        for seed in (0, 4):
+            for quiet in (False, True):
+                rng = np.random.default_rng(seed)
+                n = 2 * W + hop   # (the mid channel of test_gpu_parity.stream_pcm)
+                left = (exp_sweep(n + 20000, phase0=2 * np.pi * seed / 64) + xorshift32_noise(0x9E3779B9 ^ seed, n + 20000, 1e-3))[20000:]
+                mid = ((left + np.float32(0.8) * left) * np.float32(0.5)).astype(np.float64)
+                if quiet:   # a quiet window beside a loud passage: leakage skirts, the shape the soak finding came from
+                    mid[: len(mid) // 2 + W // 3] *= 1e-3
+                pts, bins = ex.reassigned_column(mid, kind, W, zp, hop, 48000.0)
+                top = float(pts[:, 2].max())
+                keep_a, keep_b = np.ones(len(pts), bool), np.ones(len(pts), bool)
+                floor = pts[:, 2] < 1.2e-14
+                keep_b &= ~(floor & (rng.random(len(pts)) < 0.3))
+                keep_a &= ~(floor & (rng.random(len(pts)) < 0.1))
+                side = keep_a if rng.random() < 0.5 else keep_b
+                side[rng.choice(np.r_[0:6, len(pts) - 6:len(pts)], 3, replace=False)] = False
+                a, b = pts[keep_a].copy(), pts[keep_b].copy()
+                b[:, 2] *= 1.0 + 1e-4 * rng.standard_normal(len(b))
+                b[:, 1] += rng.standard_normal(len(b)) * 1e-6 / np.sqrt(np.maximum(b[:, 2] / top, 1e-12))
+                b[:, 0] += rng.standard_normal(len(b)) * 1e-4
+                ba, bb = bins[keep_a], bins[keep_b]
+                pairs, oa, ob = align_points(a.astype(np.float32), b.astype(np.float32), top)
+                assert all(ba[i] == bb[j] for i, j in pairs), (W, zp, hop, kind, seed, quiet)
+                assert len(oa) + len(ob) == len(set(ba) ^ set(bb))
