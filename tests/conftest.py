@@ -32,6 +32,12 @@ def soak_seeds(count, salt):
     return [SOAK_BASE * 1000 + salt * 40 + i for i in range(count)]
 
 
+def pytest_collection_modifyitems(config, items):
+    """The soak cases run LAST: their seeds are new in every run, so under `-x` a seed that trips a bar stops the session only after
+    every fixed-seed test has been run and reported."""
+    items.sort(key=lambda item: item.fspath.basename == "test_gpu_soak.py")   # (stable: everything else keeps its order)
+
+
 def pytest_report_header(config):
     return f"soak seed base (OMX_SOAK_SEED to reproduce): {SOAK_BASE}"
 
