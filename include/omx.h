@@ -437,6 +437,15 @@ typedef struct omx_loudness_ragged_update {
 int omx_loudness_bank_process_ragged(omx_loudness_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
                                      const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
                                      const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_loudness_ragged_update* out);
+/* Chunk call — exactly what VisualManager::ingest_samples does with a batcher chunk (registry.rs:396-418; meter.rs:40-69 hands out
+ * chunks of 1 ... 4 quanta, each as ONE call): capture s delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing
+ * arrived: block.is_empty()), so a 1024-frame catch-up chunk is ONE process_block — one true-peak take over the whole chunk
+ * (loudness/processor.rs:287-311) — next to a capture that delivered 256.  `pcm` is device memory [n_streams][frames_capacity][channels];
+ * frames[] / reset_mask[] are host arrays.  d_snapshots is [n_streams][1] (max_blocks = 1), d_n_blocks[s] = frames[s] != 0.  Ragged
+ * bookkeeping as omx_loudness_bank_process_ragged (the two may be mixed); sequential kernels (the reference's order). */
+int omx_loudness_bank_process_chunks(omx_loudness_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                         const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                         const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_loudness_ragged_update* out);
 int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block,
                             omx_loudness_snapshot* dst);
 int omx_loudness_bank_kernel_time(omx_loudness_bank* b, double* avg_ms, uint64_t* launches);
@@ -525,6 +534,13 @@ typedef struct omx_stereometer_ragged_update {
 int omx_stereometer_bank_process_ragged(omx_stereometer_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
                                         const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
                                         const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_stereometer_ragged_update* out);
+/* Chunk call — exactly what VisualManager::ingest_samples does with a batcher chunk (registry.rs:396-418; meter.rs:40-69): capture s
+ * delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing arrived); `pcm` is device memory
+ * [n_streams][frames_capacity][channels].  Outputs as omx_stereometer_bank_process_ragged with max_blocks = 1 (one correlation row, one
+ * produced flag per stream); sequential kernels (the reference's order); may be mixed with process_ragged calls. */
+int omx_stereometer_bank_process_chunks(omx_stereometer_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                            const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                            const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_stereometer_ragged_update* out);
 int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block,
                                float correlations[4], uint32_t* produced);
 /* decimated points of one band of the newest snapshot (`stereometer/processor.rs:152-170`) -> dst[2 * n_pairs] (l, r);
@@ -767,6 +783,14 @@ typedef struct omx_oscilloscope_ragged_update {
 int omx_oscilloscope_bank_process_ragged(omx_oscilloscope_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
                                          const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
                                          const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_ragged_update* out);
+/* Chunk call — exactly what VisualManager::ingest_samples does with a batcher chunk (registry.rs:396-418; meter.rs:40-69): capture s
+ * delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing arrived) and gets ONE trigger evaluation — one
+ * StableTrigger state update (period smoothing, reference EMA, missed-hold counter; oscilloscope/processor.rs:611-712) — however
+ * many quanta the chunk holds.  `pcm` is device memory [n_streams][frames_capacity][channels].  Outputs as
+ * omx_oscilloscope_bank_process_ragged with max_blocks = 1.  Keep frames_capacity constant over a bank's chunk calls (it sizes the rings). */
+int omx_oscilloscope_bank_process_chunks(omx_oscilloscope_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                             const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                             const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_ragged_update* out);
 int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,
                                 omx_oscilloscope_block_header* header, float* samples);
 /* test hook (88.2 ... 192 kHz: the wide trigger pass runs on less LDS than its worst case and hands a stream's blocks over to the
@@ -907,9 +931,13 @@ int omx_spectrogram_history_splat(omx_spectrogram_history* h, float reassigned_p
  *       mean points per column, points of the newest column, held true-peak bar left / right (2 s hold, 60 dB/s: loudness/state.rs:36-60).
  * A multi-GPU host all-gathers `d_stats_rows` itself (ncclAllGather on its communicator; INTEGRATION.md shows the call): the library
  * does not link RCCL.
- * `pcm` is device memory [n_streams][frames][channels].  The block-based visuals see the call as frames / block_frames blocks of
- * block_frames frames (one snapshot per block, as if VisualManager had been fed block by block) when block_frames divides frames,
- * else as one block.
+ * `pcm` is device memory [n_streams][frames][channels].  One call = ONE AudioBlock of `frames` frames to every visual, exactly as
+ * ingest_samples builds it (registry.rs:407-417) from whatever chunk DspBatcher::push handed over — 256 frames at the regular cadence,
+ * 512 / 768 / 1024 when catching up after a stall, each chunk as ONE call (meter.rs:61-64): one oscilloscope trigger evaluation
+ * (oscilloscope/processor.rs:611-712), one true-peak take (loudness/processor.rs:287-311), one stereo_channels scan (dsp.rs:190-213)
+ * over the whole chunk.  A host that queues chunks and replays several of them in one call sets cfg.block_frames = B explicitly: a call
+ * whose `frames` is a multiple of B is then seen by the block-based visuals (Loudness, Stereometer, Oscilloscope) as frames / B blocks
+ * of B frames, one snapshot per block, as if ingest had been called once per block (update.n_blocks / block_frames say which).
  * ===================================================================== */
 enum {
     OMX_VISUAL_SPECTROGRAM = 1,
@@ -927,7 +955,8 @@ enum {
 typedef struct omx_capture_group_config {
     uint32_t n_streams;
     uint32_t visuals;                /* OMX_VISUAL_* bits */
-    uint32_t block_frames;           /* 0 = the batcher's quantum, round(256 * sample_rate / 48000) (meter.rs:16-25) */
+    uint32_t block_frames;           /* 0 (default) = every ingest call is one block, the reference's partition; B > 0 = replay mode:
+                                        a call of k * B frames is k blocks of B frames to the block-based visuals */
     uint32_t spectrum_emit_all_hops; /* as omx_spectrum_bank_create */
     omx_spectrogram_config spectrogram;
     omx_spectrum_config spectrum;
@@ -952,8 +981,9 @@ typedef struct omx_capture_group_update {
 typedef struct omx_capture_group_ragged_update {
     uint32_t produced;               /* OMX_VISUAL_* bits: which visuals produced an update for at least one capture */
     uint32_t _pad;
-    uint64_t block_frames;           /* how the block-based visuals saw the call: capture s ran frames[s] / block_frames blocks ... */
-    uint64_t max_blocks;             /* ... of at most frames_capacity / block_frames */
+    uint64_t block_frames;           /* how the block-based visuals saw the call: 0 = capture s ran ONE block of frames[s] frames
+                                        (max_blocks = 1); B = cfg.block_frames: capture s ran frames[s] / B blocks ... */
+    uint64_t max_blocks;             /* ... of at most frames_capacity / B */
     omx_spectrogram_ragged_update spectrogram;
     omx_spectrum_ragged_update spectrum;
     omx_loudness_ragged_update loudness;
@@ -984,10 +1014,13 @@ int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t fr
  * ingest_ragged: per-capture frame counts and per-capture reset flags — one VisualManager per capture in the reference, each fed by
  *   its own batcher and reset on its own.  `pcm` is device memory [n_streams][frames_capacity][channels]; capture s delivers its
  *   first frames[s] <= frames_capacity frames (0: nothing arrived) after reset_audio() where reset_mask[s] != 0 (reset_mask may be
- *   NULL).  frames[] / reset_mask[] are HOST arrays.  Counts must be multiples of block_frames (the batcher's quantum: it hands out
- *   1 ... 4 of them per chunk, meter.rs:40-69); the block-based visuals run capture s for frames[s] / block_frames blocks.  Every
- *   enabled bank goes through its own omx_<visual>_bank_process_ragged: per stream the results equal a single-stream handle fed the
- *   same sequence.  After the first ragged call the group's positions are per capture: omx_capture_group_ingest is refused
+ *   NULL).  frames[] / reset_mask[] are HOST arrays.  What capture s delivers is ONE block of frames[s] frames — the chunk its batcher
+ *   handed over, whole (meter.rs:40-69: 1 ... 4 quanta per chunk; registry.rs:407-417: one AudioBlock per call) — so captures that
+ *   deliver 256, 768 and 1024 frames in the same call each get one process_block of that length (the block-based banks go through
+ *   omx_<visual>_bank_process_chunks).  With cfg.block_frames = B != 0 (replay mode) the counts must be multiples of B and capture s
+ *   runs frames[s] / B blocks (omx_<visual>_bank_process_ragged).  Per stream the results equal a single-stream handle fed the same
+ *   sequence of blocks.  A per-capture reset reaches the banks of DISABLED visuals too (VisualManager::reset_audio resets every
+ *   entry, :360-365): it is applied by the bank's next call after the visual is enabled again.  After the first ragged call the group's positions are per capture: omx_capture_group_ingest is refused
  *   (OMX_ERR_INVALID) until omx_capture_group_reset_audio.  Summary rows (OMX_OPT_GROUP_STATS) are a lock-step feature. */
 int omx_capture_group_set_enabled(omx_capture_group* g, uint32_t visual, int enabled);
 int omx_capture_group_enabled(const omx_capture_group* g);            /* OMX_VISUAL_* bits ingest currently feeds */

@@ -253,6 +253,19 @@ class LoudnessBank(_BlockBank):
                          channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
+    def process_chunks(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """VisualManager::ingest_samples per capture (registry.rs:396-418): stream s delivers ONE block of frames[s] (<= frames_capacity)
+        frames — a batcher chunk, whole; pcm = device f32 [n_streams][frames_capacity][channels].  fetch(s, 0) where frames[s] != 0."""
+        out = capi.CLoudnessRaggedUpdate()
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
+        f = self.api.fn("loudness_bank_process_chunks", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
     def fetch(self, stream_index, block) -> capi.LoudnessSnapshot:
         out = capi.CLoudnessSnapshot()
         self.api.check(self.api.fn("loudness_bank_fetch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p])(
@@ -316,6 +329,19 @@ class StereometerBank(_BlockBank):
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
                          C.c_void_p])
         self.api.check(f(self._h, C.c_void_p(device_ptr), block_frames, max_blocks, nb.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
+    def process_chunks(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """VisualManager::ingest_samples per capture (registry.rs:396-418): stream s delivers ONE block of frames[s] (<= frames_capacity)
+        frames — a batcher chunk, whole; pcm = device f32 [n_streams][frames_capacity][channels].  fetch(s, 0) where frames[s] != 0."""
+        out = CStereometerRaggedUpdate()
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
+        f = self.api.fn("stereometer_bank_process_chunks", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
                          channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
@@ -388,6 +414,19 @@ class OscilloscopeBank(_BlockBank):
                         [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p,
                          C.c_void_p])
         self.api.check(f(self._h, C.c_void_p(device_ptr), block_frames, max_blocks, nb.ctypes.data, mask.ctypes.data if mask is not None else None,
+                         channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
+        return out
+
+    def process_chunks(self, device_ptr: int, frames_capacity: int, frames: Sequence[int], channels: int, sample_rate: float,
+                       positions: Sequence[int], reset_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        """VisualManager::ingest_samples per capture (registry.rs:396-418): stream s delivers ONE block of frames[s] (<= frames_capacity)
+        frames — a batcher chunk, whole; pcm = device f32 [n_streams][frames_capacity][channels].  fetch(s, 0) where frames[s] != 0."""
+        out = COscilloscopeRaggedUpdate()
+        fr = _per_stream(frames, self.n_streams, np.uint32, "frames")
+        mask = _per_stream(reset_mask, self.n_streams, np.uint8, "reset_mask") if reset_mask is not None else None
+        f = self.api.fn("oscilloscope_bank_process_chunks", C.c_int,
+                        [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, _u8x8, C.c_void_p, C.c_void_p])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mask.ctypes.data if mask is not None else None,
                          channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 

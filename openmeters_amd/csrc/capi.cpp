@@ -432,6 +432,15 @@ int omx_loudness_bank_process_ragged(omx_loudness_bank* b, const float* pcm, uin
                                       static_cast<hipStream_t>(stream), out);
     });
 }
+int omx_loudness_bank_process_chunks(omx_loudness_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                         const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                         const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_loudness_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_chunks(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
+    });
+}
 int omx_loudness_bank_fetch(omx_loudness_bank* b, uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst) {
     if (!b || !dst) return OMX_ERR_INVALID;
     return guarded([&] { return b->impl.fetch(stream_index, block, dst, b->impl.last_stream()); });
@@ -556,6 +565,15 @@ int omx_stereometer_bank_process(omx_stereometer_bank* b, const float* pcm, int 
     return guarded([&] {
         return b->impl.process(pcm, pcm_on_device != 0, block_frames, n_blocks, channels, sample_rate, positions,
                                static_cast<hipStream_t>(stream), out);
+    });
+}
+int omx_stereometer_bank_process_chunks(omx_stereometer_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                            const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                            const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_stereometer_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_chunks(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
     });
 }
 int omx_stereometer_bank_fetch(omx_stereometer_bank* b, uint64_t stream_index, uint64_t block, float correlations[4],
@@ -700,6 +718,15 @@ int omx_oscilloscope_bank_process(omx_oscilloscope_bank* b, const float* pcm, in
             out->sample_stride = kScopeTarget;
         }
         return rc;
+    });
+}
+int omx_oscilloscope_bank_process_chunks(omx_oscilloscope_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
+                                             const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                                             const uint8_t positions[OMX_MAX_CHANNELS], void* stream, omx_oscilloscope_ragged_update* out) {
+    if (!b || !pcm || !frames || !positions) return OMX_ERR_INVALID;
+    return guarded([&] {
+        return b->impl.process_chunks(pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions,
+                                      static_cast<hipStream_t>(stream), out);
     });
 }
 int omx_oscilloscope_bank_fetch(omx_oscilloscope_bank* b, uint64_t stream_index, uint64_t block,

@@ -60,6 +60,7 @@ void CaptureGroup::reset_audio() {  // registry.rs:360-365: every module's reset
     holds_valid_ = false;  // LoudnessState::reset_audio: fresh PeakHolds (loudness/state.rs:153-160)
     clock_ = 0.0;          // ... on a fresh sample clock
     ragged_ = false;       // a bank-wide reset returns every bank to lock-step positions
+    for (auto& p : pending_reset_) p.clear();  // every bank, enabled or not, has just been reset
     have_generation_ = false;  // registry.rs:361 format_generation = None
 }
 
@@ -121,10 +122,30 @@ bool CaptureGroup::note_format_generation(uint64_t generation) {
     return changed;
 }
 
-uint64_t CaptureGroup::block_frames_for(float sample_rate) const {
-    // how the block-based visuals see a call (meter.rs:16-25: the batcher hands out blocks of round(256 fs / 48000) frames)
-    const float sr = sanitize_sample_rate(sample_rate);
-    return cfg_.block_frames ? cfg_.block_frames : (uint64_t)std::max(1.0, std::round(256.0 * (double)sr / 48000.0));
+// The reset mask a bank's ragged call gets: the caller's mask, OR-ed with the per-capture resets that passed while the visual was
+// disabled.  A disabled bank that exists only records the mask (VisualManager::reset_audio reaches every entry, registry.rs:360-365;
+// Entry.enabled gates ingest alone, :413-417).  Returns nullptr when there is nothing to reset.
+const uint8_t* CaptureGroup::mask_for(int vi, bool bank_enabled, bool bank_exists, const uint8_t* reset_mask) {
+    const uint32_t S = cfg_.n_streams;
+    std::vector<uint8_t>& pend = pending_reset_[vi];
+    if (!bank_exists) return nullptr;  // created on enable, from nothing: no state a reset could clear
+    if (!bank_enabled) {
+        if (reset_mask) {
+            bool any = false;
+            for (uint32_t s = 0; s < S; ++s) any = any || reset_mask[s] != 0;
+            if (any) {
+                if (pend.empty()) pend.assign(S, 0);
+                for (uint32_t s = 0; s < S; ++s) pend[s] |= reset_mask[s] ? 1 : 0;
+            }
+        }
+        return nullptr;
+    }
+    if (pend.empty()) return reset_mask;
+    std::vector<uint8_t>& m = mask_scratch_[vi];
+    m.assign(S, 0);
+    for (uint32_t s = 0; s < S; ++s) m[s] = (pend[s] || (reset_mask && reset_mask[s])) ? 1 : 0;
+    pend.clear();
+    return m.data();
 }
 
 // Runs `body` between the fork of the side streams and their join onto the caller's stream; the join is enqueued on every path out
@@ -178,11 +199,13 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
     OscilloscopeBank* oscilloscope = (enabled_ & OMX_VISUAL_OSCILLOSCOPE) ? oscilloscope_.get() : nullptr;
     WaveformBank* waveform = (enabled_ & OMX_VISUAL_WAVEFORM) ? waveform_.get() : nullptr;
     const float sr = sanitize_sample_rate(sample_rate);
-    uint64_t block = block_frames_for(sample_rate);
-    uint64_t n_blocks = frames / block;
-    if (n_blocks == 0 || n_blocks * block != frames) {
-        block = frames;
-        n_blocks = 1;
+    // registry.rs:407-417: ONE AudioBlock of `frames` frames to every visual, whatever the chunk the batcher handed over (256 ... 1024
+    // frames at 48 kHz, meter.rs:61-64) — one trigger evaluation, one true-peak take, one stereo_channels scan per call.  A host that
+    // queues several chunks and replays them in one call says so with cfg.block_frames (then: frames / block_frames blocks).
+    uint64_t block = frames, n_blocks = 1;
+    if (cfg_.block_frames != 0 && frames % cfg_.block_frames == 0) {
+        block = cfg_.block_frames;
+        n_blocks = frames / block;
     }
     up.n_blocks = n_blocks;
     up.block_frames = block;
@@ -314,8 +337,9 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
 // Per-capture ingest: capture s delivers frames[s] <= frames_capacity frames this call (0 = nothing arrived) and is reset first where
 // reset_mask[s] != 0 — one VisualManager per capture in the reference, each fed by its own DspBatcher and reset on its own
 // (registry.rs:360-365, :396-418; meter.rs:27-80).  Every enabled bank takes the call through its own ragged entry point (per-stream
-// positions on the device); the block-based visuals see capture s as frames[s] / block_frames blocks, so the counts must be multiples
-// of block_frames — which is what the batcher hands out (256-frame quanta at 48 kHz, up to four per catch-up chunk).
+// positions on the device).  What capture s delivers is ONE block (registry.rs:407-417: one AudioBlock per ingest_samples call, whatever
+// the chunk length — the block-based banks go through process_chunks); with cfg.block_frames != 0 it is frames[s] / block_frames blocks
+// of block_frames frames (a host replaying queued quanta), and the counts must then be multiples of it.
 int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels_in,
                                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                 omx_capture_group_ragged_update* out) {
@@ -323,28 +347,38 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     const uint32_t S = cfg_.n_streams;
     omx_capture_group_ragged_update up;
     std::memset(&up, 0, sizeof(up));
-    const uint64_t block = block_frames_for(sample_rate);
+    const bool chunks = cfg_.block_frames == 0;  // the reference's partition: one block per capture per call
+    const uint64_t block = chunks ? frames_capacity : cfg_.block_frames;
     if (frames_capacity == 0 || frames_capacity % block != 0) {
-        set_last_error("capture group ingest_ragged: frames_capacity must be a positive multiple of block_frames");
+        set_last_error("capture group ingest_ragged: frames_capacity must be a positive multiple of cfg.block_frames");
         return OMX_ERR_INVALID;
     }
-    const uint64_t max_blocks = frames_capacity / block;
+    const uint64_t max_blocks = chunks ? 1 : frames_capacity / block;
     blocks_scratch_.resize(S);
     for (uint32_t s = 0; s < S; ++s) {
-        if (frames[s] > frames_capacity || frames[s] % block != 0) {
-            set_last_error("capture group ingest_ragged: frames[s] must be a multiple of block_frames, at most frames_capacity");
+        if (frames[s] > frames_capacity || (!chunks && frames[s] % block != 0)) {
+            set_last_error(chunks ? "capture group ingest_ragged: frames[s] > frames_capacity"
+                                  : "capture group ingest_ragged: frames[s] must be a multiple of cfg.block_frames, at most frames_capacity");
             return OMX_ERR_INVALID;
         }
-        blocks_scratch_[s] = (uint32_t)(frames[s] / block);
+        blocks_scratch_[s] = chunks ? (frames[s] != 0 ? 1u : 0u) : (uint32_t)(frames[s] / block);
     }
-    up.block_frames = block;
+    up.block_frames = chunks ? 0 : block;
     up.max_blocks = max_blocks;
-    SpectrogramBank* spectrogram = (enabled_ & OMX_VISUAL_SPECTROGRAM) ? spectrogram_.get() : nullptr;
-    SpectrumBank* spectrum = (enabled_ & OMX_VISUAL_SPECTRUM) ? spectrum_.get() : nullptr;
-    LoudnessBank* loudness = (enabled_ & OMX_VISUAL_LOUDNESS) ? loudness_.get() : nullptr;
-    StereometerBank* stereometer = (enabled_ & OMX_VISUAL_STEREOMETER) ? stereometer_.get() : nullptr;
-    OscilloscopeBank* oscilloscope = (enabled_ & OMX_VISUAL_OSCILLOSCOPE) ? oscilloscope_.get() : nullptr;
-    WaveformBank* waveform = (enabled_ & OMX_VISUAL_WAVEFORM) ? waveform_.get() : nullptr;
+    auto bank_on = [&](uint32_t bit) { return (enabled_ & bit) != 0; };
+    SpectrogramBank* spectrogram = bank_on(OMX_VISUAL_SPECTROGRAM) ? spectrogram_.get() : nullptr;
+    SpectrumBank* spectrum = bank_on(OMX_VISUAL_SPECTRUM) ? spectrum_.get() : nullptr;
+    LoudnessBank* loudness = bank_on(OMX_VISUAL_LOUDNESS) ? loudness_.get() : nullptr;
+    StereometerBank* stereometer = bank_on(OMX_VISUAL_STEREOMETER) ? stereometer_.get() : nullptr;
+    OscilloscopeBank* oscilloscope = bank_on(OMX_VISUAL_OSCILLOSCOPE) ? oscilloscope_.get() : nullptr;
+    WaveformBank* waveform = bank_on(OMX_VISUAL_WAVEFORM) ? waveform_.get() : nullptr;
+    // per bank: the caller's mask plus the resets it missed while disabled; disabled banks that exist record this call's mask
+    const uint8_t* m_sg = mask_for(0, spectrogram != nullptr, spectrogram_ != nullptr, reset_mask);
+    const uint8_t* m_sp = mask_for(1, spectrum != nullptr, spectrum_ != nullptr, reset_mask);
+    const uint8_t* m_ld = mask_for(2, loudness != nullptr, loudness_ != nullptr, reset_mask);
+    const uint8_t* m_st = mask_for(3, stereometer != nullptr, stereometer_ != nullptr, reset_mask);
+    const uint8_t* m_os = mask_for(4, oscilloscope != nullptr, oscilloscope_ != nullptr, reset_mask);
+    const uint8_t* m_wf = mask_for(5, waveform != nullptr, waveform_ != nullptr, reset_mask);
     ragged_ = true;
     if (reset_mask)   // LoudnessState::reset_audio of the reset captures: the summary-row peak holds restart with the next lock-step epoch
         for (uint32_t s = 0; s < S; ++s)
@@ -357,39 +391,44 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
         if (spectrogram)
-            note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrogram),
+            note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, &up.spectrogram),
                  OMX_VISUAL_SPECTROGRAM);
         if (spectrum)
-            note(spectrum->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, stream, &up.spectrum),
+            note(spectrum->process_ragged(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions, stream, &up.spectrum),
                  OMX_VISUAL_SPECTRUM);
         if (loudness) {
             used[0] = true;
             OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
-            note(loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions, side_[0],
-                                          &up.loudness),
+            note(chunks ? loudness->process_chunks(d_pcm, frames_capacity, frames, m_ld, channels, sample_rate, positions, side_[0], &up.loudness)
+                        : loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_ld, channels, sample_rate, positions,
+                                                   side_[0], &up.loudness),
                  OMX_VISUAL_LOUDNESS);
             OMX_HIP(hipGetLastError());
         }
         if (waveform) {
             used[3] = true;
             OMX_HIP(hipStreamWaitEvent(side_[3], fork_, 0));
-            note(waveform->process_ragged(d_pcm, frames_capacity, frames, reset_mask, channels, sample_rate, positions, side_[3], &up.waveform),
+            note(waveform->process_ragged(d_pcm, frames_capacity, frames, m_wf, channels, sample_rate, positions, side_[3], &up.waveform),
                  OMX_VISUAL_WAVEFORM);
             OMX_HIP(hipGetLastError());
         }
         if (stereometer) {
             used[1] = true;
             OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
-            note(stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
-                                             side_[1], &up.stereometer),
+            note(chunks ? stereometer->process_chunks(d_pcm, frames_capacity, frames, m_st, channels, sample_rate, positions, side_[1],
+                                                      &up.stereometer)
+                        : stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_st, channels, sample_rate, positions,
+                                                      side_[1], &up.stereometer),
                  OMX_VISUAL_STEREOMETER);
             OMX_HIP(hipGetLastError());
         }
         if (oscilloscope) {
             used[2] = true;
             OMX_HIP(hipStreamWaitEvent(side_[2], fork_, 0));
-            note(oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), reset_mask, channels, sample_rate, positions,
-                                              side_[2], &up.oscilloscope),
+            note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, side_[2],
+                                                       &up.oscilloscope)
+                        : oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_os, channels, sample_rate, positions,
+                                                       side_[2], &up.oscilloscope),
                  OMX_VISUAL_OSCILLOSCOPE);
             OMX_HIP(hipGetLastError());
         }

@@ -45,13 +45,17 @@ public:
 
 private:
     void ensure_bank(uint32_t visual);
-    uint64_t block_frames_for(float sample_rate) const;
     omx_capture_group_config cfg_;
     uint32_t enabled_ = 0;       // OMX_VISUAL_* bits ingest feeds
     bool ragged_ = false;        // per-capture positions (after the first ingest_ragged, until reset_audio)
     bool have_generation_ = false;
     uint64_t generation_ = 0;
     std::vector<uint32_t> blocks_scratch_;
+    // per-capture resets a disabled visual has not seen yet (VisualManager::reset_audio resets every entry, enabled or not,
+    // registry.rs:360-365): OR-ed into the bank's next ragged call; index = log2(OMX_VISUAL_* bit)
+    std::vector<uint8_t> pending_reset_[6];
+    std::vector<uint8_t> mask_scratch_[6];
+    const uint8_t* mask_for(int visual_index, bool bank_enabled, bool bank_exists, const uint8_t* reset_mask);
     std::unique_ptr<SpectrogramBank> spectrogram_;
     std::unique_ptr<SpectrumBank> spectrum_;
     std::unique_ptr<LoudnessBank> loudness_;

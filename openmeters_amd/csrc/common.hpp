@@ -187,6 +187,7 @@ inline void copy_out(void* dst, const void* src, size_t bytes, bool pinned, hipS
 // previous one are still in flight (practically never), instead of synchronising the stream on every call.
 struct RaggedStaging {
     PinnedBuffer<uint32_t> counts[2];
+    PinnedBuffer<uint32_t> lengths[2];
     PinnedBuffer<uint8_t> mask[2];
     hipEvent_t done[2] = {nullptr, nullptr};
     int next = 0;
@@ -199,7 +200,9 @@ struct RaggedStaging {
     }
     // counts_in[n] -> d_counts, mask_in[n] (nullptr = all zero) -> d_mask, asynchronously on `stream`; the caller's arrays are free
     // again when this returns
-    void upload(const uint32_t* counts_in, const uint8_t* mask_in, uint32_t n, uint32_t* d_counts, uint8_t* d_mask, hipStream_t stream) {
+    // lengths_in (chunk calls: one block of lengths_in[s] frames per stream) -> d_lengths the same way when both are given
+    void upload(const uint32_t* counts_in, const uint8_t* mask_in, uint32_t n, uint32_t* d_counts, uint8_t* d_mask, hipStream_t stream,
+                const uint32_t* lengths_in = nullptr, uint32_t* d_lengths = nullptr) {
         const int b = next;
         next ^= 1;
         if (done[b]) OMX_HIP(hipEventSynchronize(done[b]));
@@ -211,6 +214,11 @@ struct RaggedStaging {
         else std::memset(mask[b].ptr, 0, n);
         OMX_HIP(hipMemcpyAsync(d_counts, counts[b].ptr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         OMX_HIP(hipMemcpyAsync(d_mask, mask[b].ptr, n, hipMemcpyHostToDevice, stream));
+        if (lengths_in && d_lengths) {
+            lengths[b].reserve(n);
+            std::memcpy(lengths[b].ptr, lengths_in, (size_t)n * sizeof(uint32_t));
+            OMX_HIP(hipMemcpyAsync(d_lengths, lengths[b].ptr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
         OMX_HIP(hipEventRecord(done[b], stream));
     }
 };

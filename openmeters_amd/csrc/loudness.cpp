@@ -168,18 +168,48 @@ void LoudnessBank::reset_audio() {  // :234-236 every ChannelState back to defau
 int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks,
                                  const uint8_t* reset_mask, uint32_t channels_in, float sample_rate,
                                  const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_loudness_ragged_update* out) {
-    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
-    last_stream_ = stream;
     if (block_frames == 0 || block_frames > 0xFFFFFFFFull || max_blocks > 0xFFFFFFFFull) {
         set_last_error("loudness process_ragged: block_frames must be in 1 ... 2^32 - 1");
         return OMX_ERR_INVALID;
     }
-    bool any = false, any_reset = false;
-    for (uint32_t s = 0; s < n_streams_; ++s) {
+    for (uint32_t s = 0; s < n_streams_; ++s)
         if (n_blocks[s] > max_blocks) {
             set_last_error("loudness process_ragged: n_blocks[s] > max_blocks");
             return OMX_ERR_INVALID;
         }
+    return ragged_impl(d_pcm, block_frames * std::max<uint64_t>(max_blocks, 1), block_frames, nullptr, max_blocks, n_blocks, reset_mask, channels_in,
+                       sample_rate, positions, stream, out);
+}
+
+// One block per capture, each of its own length: what VisualManager::ingest_samples hands LoudnessProcessor::process_block
+// (registry.rs:396-418) when every capture has its own batcher (meter.rs:40-69: 1 ... 4 quanta per chunk, ONE call per chunk).
+int LoudnessBank::process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                 uint32_t channels_in, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                 omx_loudness_ragged_update* out) {
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
+        set_last_error("loudness process_chunks: frames_capacity must be in 1 ... 2^32 - 1");
+        return OMX_ERR_INVALID;
+    }
+    h_blocks_.resize(n_streams_);
+    uint64_t longest = 1;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (frames[s] > frames_capacity) {
+            set_last_error("loudness process_chunks: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
+        h_blocks_[s] = frames[s] != 0 ? 1u : 0u;  // block.is_empty(): nothing happens
+        longest = std::max<uint64_t>(longest, frames[s]);
+    }
+    return ragged_impl(d_pcm, frames_capacity, longest, frames, 1, h_blocks_.data(), reset_mask, channels_in, sample_rate, positions, stream, out);
+}
+
+int LoudnessBank::ragged_impl(const float* d_pcm, uint64_t row_frames, uint64_t block_frames, const uint32_t* frames_v, uint64_t max_blocks,
+                              const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels_in, float sample_rate,
+                              const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_loudness_ragged_update* out) {
+    const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
+    last_stream_ = stream;
+    bool any = false, any_reset = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
         any = any || n_blocks[s] != 0;
         any_reset = any_reset || (reset_mask && reset_mask[s]);
     }
@@ -198,20 +228,23 @@ int LoudnessBank::process_ragged(const float* d_pcm, uint64_t block_frames, uint
     // per-stream counts / flags: pinned staging -> device (the caller's arrays are borrowed for the call only)
     r_blocks_.reserve(n_streams_);
     r_mask_.reserve(n_streams_);
-    r_staging_.upload(n_blocks, reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
+    if (frames_v) r_frames_.reserve(n_streams_);
+    r_staging_.upload(n_blocks, reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, frames_v, frames_v ? r_frames_.ptr : nullptr);
     const uint64_t slots = std::max<uint64_t>(max_blocks, 1);
     snapshots_.reserve((size_t)(n_streams_ * slots), false);
     LoudnessArgs la{};
     fill_args(la, d_pcm, block_frames, slots, channels, positions);
+    la.frames_total = row_frames;
     la.seen_v = r_seen_.ptr;
     la.blocks_v = r_blocks_.ptr;
     la.reset_v = r_mask_.ptr;
+    la.frames_v = frames_v ? r_frames_.ptr : nullptr;
     // the host's mirror of the per-stream counters decides the form: every stream on the 64-sample sub-block grid
-    bool grid_ok = block_frames % 64 == 0 && max_blocks >= 2;
+    bool grid_ok = !frames_v && block_frames % 64 == 0 && max_blocks >= 2;
     for (uint32_t s = 0; s < n_streams_; ++s) {
         if (reset_mask && reset_mask[s]) h_seen_[s] = 0;
         grid_ok = grid_ok && h_seen_[s] % 64 == 0;
-        h_seen_[s] += (uint64_t)n_blocks[s] * block_frames;
+        h_seen_[s] += (uint64_t)n_blocks[s] * (frames_v ? frames_v[s] : block_frames);
     }
     const bool chunked = grid_ok && chunked_mode_ != 0 && (chunked_mode_ == 1 || max_blocks >= kChunkedFromBlocks);
     last_form_ = chunked ? 2 : 1;

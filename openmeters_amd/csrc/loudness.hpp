@@ -59,6 +59,9 @@ struct LoudnessArgs {
     uint64_t* seen_v;
     const uint32_t* blocks_v;
     const uint8_t* reset_v;
+    // chunk calls (process_chunks): stream s's blocks are frames_v[s] frames long (nullptr = block_frames for every stream); its row of
+    // `pcm` is frames_total frames long whatever it delivers
+    const uint32_t* frames_v;
 };
 void launch_loudness(const LoudnessArgs& a, hipStream_t stream);
 
@@ -115,6 +118,10 @@ public:
     int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
                        uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                        omx_loudness_ragged_update* out);
+    // Chunk call (include/omx.h: omx_loudness_bank_process_chunks; VisualManager::ingest_samples, registry.rs:396-418): stream s
+    // delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing arrived); one snapshot slot per stream.
+    int process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_loudness_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t block, omx_loudness_snapshot* dst, hipStream_t stream);
     EventTimer& timer() { return timer_; }
     hipStream_t last_stream() const { return last_stream_; }
@@ -125,6 +132,10 @@ private:
     void run_chunked(LoudnessArgs& la, hipStream_t stream);
     void fill_args(LoudnessArgs& la, const float* d_pcm, uint64_t block_frames, uint64_t n_blocks, uint32_t channels,
                    const uint8_t positions[OMX_MAX_CHANNELS]);
+    // the two ragged entry points: `frames_v` null = n_blocks[s] blocks of block_frames, else one block of frames_v[s] where n_blocks[s] != 0
+    int ragged_impl(const float* d_pcm, uint64_t row_frames, uint64_t block_frames, const uint32_t* frames_v, uint64_t max_blocks,
+                    const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
+                    const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_loudness_ragged_update* out);
 
     omx_loudness_config cfg_{};
     uint32_t n_streams_;
@@ -154,8 +165,9 @@ private:
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_seen_;
     std::vector<uint64_t> h_seen_;  // the host's mirror of r_seen_ (the call arguments determine it)
-    DeviceBuffer<uint32_t> r_blocks_;
+    DeviceBuffer<uint32_t> r_blocks_, r_frames_;
     DeviceBuffer<uint8_t> r_mask_;
+    std::vector<uint32_t> h_blocks_;
     RaggedStaging r_staging_;
 public:
     void chunked_mode(int mode) { chunked_mode_ = mode; }

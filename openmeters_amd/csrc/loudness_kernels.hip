@@ -159,6 +159,8 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     const bool reset = ragged && in_bank && a.reset_v != nullptr && a.reset_v[s] != 0;
     const uint64_t seen0 = ragged ? ((in_bank && !reset) ? a.seen_v[s] : 0ull) : a.frames_seen;
     const uint32_t n_blocks_s = ragged ? (in_bank ? a.blocks_v[s] : 0u) : a.n_blocks;
+    // chunk calls: the stream's own block length (per-lane trip counts in the batch loops below; nothing in them crosses lanes)
+    const uint32_t block_frames_s = (a.frames_v != nullptr && in_bank) ? a.frames_v[s] : a.block_frames;
     LoudLane<DL> L;
     L.sum0 = L.sum1 = L.cor0 = L.cor1 = 0.0;
 #pragma unroll
@@ -196,10 +198,10 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
     uint64_t seen = seen0;
     RingT* ring_col = ring_column(a.ring, live ? chan : 0, a.ring_len);  // dead lanes read column 0 (discarded) and never store
     const bool store_lane = live && r == 0;
-    const uint32_t full = a.block_frames / B, tail = a.block_frames % B;
+    const uint32_t full = block_frames_s / B, tail = block_frames_s % B;
 
     for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
-        const uint64_t f_blk = (uint64_t)blk * a.block_frames;
+        const uint64_t f_blk = (uint64_t)blk * block_frames_s;
         // full batches, two per iteration so the prefetch buffers swap roles without register copies: the loads of
         // batch n+1 are issued before batch n is computed (HBM round trip hidden behind ~8 samples of f64 work)
         float xa[B], xb[B];
@@ -222,7 +224,7 @@ __device__ __forceinline__ void loudness_body(const LoudnessArgs& a, uint32_t gi
                                                             cap, 0, live);
             loudness_step<1, DL, MODE>(L, x1, o1, u1, live, a, ring_col, row, len, cap, store_lane);
         }
-        seen += a.block_frames;
+        seen += block_frames_s;
 
         // ---- end of block: denormal flush (:281-285) and snapshot (:287-310)
         const int lane = threadIdx.x;

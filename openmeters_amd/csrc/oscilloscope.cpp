@@ -107,6 +107,35 @@ int OscilloscopeBank::process_ragged(const float* d_pcm, uint64_t block_frames, 
     return process_impl(d_pcm, true, block_frames, std::max<uint64_t>(max_blocks, 1), channels, sample_rate, positions, stream, &rc);
 }
 
+// One block per capture, each of its own length: what VisualManager::ingest_samples hands OscilloscopeProcessor::process_block
+// (registry.rs:396-418) when every capture has its own batcher (meter.rs:40-69: 1 ... 4 quanta per chunk, ONE call per chunk) — one
+// trigger evaluation and one StableTrigger state update per chunk (oscilloscope/processor.rs:611-712).
+int OscilloscopeBank::process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                     uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                     omx_oscilloscope_ragged_update* out) {
+    if (frames_capacity == 0 || frames_capacity > 0x7FFFFFFFull) {
+        set_last_error("oscilloscope process_chunks: frames_capacity must be in 1 ... 2^31 - 1");
+        return OMX_ERR_INVALID;
+    }
+    h_blocks_.resize(n_streams_);
+    bool any = false;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (frames[s] > frames_capacity) {
+            set_last_error("oscilloscope process_chunks: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
+        h_blocks_[s] = frames[s] != 0 ? 1u : 0u;  // block.is_empty(): nothing happens
+        any = any || frames[s] != 0 || (reset_mask && reset_mask[s]);
+    }
+    last_stream_ = stream;
+    if (!any) return OMX_NONE;
+    RaggedCall rc{h_blocks_.data(), reset_mask, out};
+    rc.frames_v = frames;
+    rc.row_frames = frames_capacity;
+    // the rings are sized by the longest block a chunk call can carry, so that a later, longer chunk never has to grow them
+    return process_impl(d_pcm, true, frames_capacity, 1, channels, sample_rate, positions, stream, &rc);
+}
+
 int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
                                    float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                    const RaggedCall* ragged) {
@@ -199,7 +228,8 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
     }
     headers_.reserve((size_t)(n_streams_ * n_blocks), host_outputs_ && n_streams_ * n_blocks <= 4096);
     samples_.reserve((size_t)n_streams_ * 2 * kScopeTarget, host_outputs_ && n_streams_ <= 4);
-    const uint64_t total = block_frames * n_blocks;
+    const bool chunk_call = ragged && ragged->frames_v;
+    const uint64_t total = chunk_call ? ragged->row_frames : block_frames * n_blocks;  // frames per row of `pcm`
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * total * channels;
@@ -283,7 +313,10 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
         }
         r_blocks_.reserve(n_streams_);
         r_mask_.reserve(n_streams_);
-        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
+        if (chunk_call) r_frames_.reserve(n_streams_);
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, ragged->frames_v,
+                          chunk_call ? r_frames_.ptr : nullptr);
+        sa.frames_v = chunk_call ? r_frames_.ptr : nullptr;
         sa.pos_v = r_pos_.ptr;
         sa.blocks_v = r_blocks_.ptr;
         sa.reset_v = r_mask_.ptr;

@@ -83,6 +83,9 @@ struct ScopeArgs {
     const uint32_t* blocks_v;    // [n_streams]
     const uint8_t* reset_v;      // [n_streams]
     uint64_t* epoch_v;           // [n_streams]
+    // chunk calls (process_chunks): stream s's blocks are frames_v[s] frames long (nullptr = block_frames for every stream); its row
+    // of `pcm` is frames_total frames long whatever it delivers
+    const uint32_t* frames_v;    // [n_streams]
     // wide trigger pass with LESS LDS than its worst case (round 4: 88.2 ... 192 kHz, whose worst-case arrays exceed a CU's 160 KiB): it runs
     // the blocks of a stream while their arrays fit and hands the rest to the one-workgroup-per-stream kernel
     uint32_t ref_cap;            // floats of the resident-reference region (0: max_kernel, no hand-over)
@@ -126,6 +129,10 @@ public:
     int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
                        uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                        omx_oscilloscope_ragged_update* out);
+    // Chunk call (include/omx.h: omx_oscilloscope_bank_process_chunks; VisualManager::ingest_samples, registry.rs:396-418): stream s
+    // delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing arrived): one trigger evaluation, one header slot per stream.
+    int process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_oscilloscope_ragged_update* out);
     int fetch_header(uint64_t stream_index, uint64_t block, ScopeBlockHeader* dst, hipStream_t stream);
     int fetch_samples(uint64_t stream_index, float* dst, uint64_t count, hipStream_t stream);
     uint64_t epoch() const { return epoch_; }
@@ -146,6 +153,8 @@ private:
         const uint32_t* n_blocks;
         const uint8_t* reset_mask;
         omx_oscilloscope_ragged_update* out;
+        const uint32_t* frames_v = nullptr;  // chunk calls: per-stream block length, rows of `pcm` row_frames apart
+        uint64_t row_frames = 0;
     };
     int process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels, float sample_rate,
                      const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, const RaggedCall* ragged);
@@ -174,7 +183,8 @@ private:
     // ragged mode: per-stream ring positions and epochs on the device
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_pos_, r_epoch_;
-    DeviceBuffer<uint32_t> r_blocks_;
+    DeviceBuffer<uint32_t> r_blocks_, r_frames_;
+    std::vector<uint32_t> h_blocks_;
     DeviceBuffer<uint8_t> r_mask_;
     RaggedStaging r_staging_;
 };

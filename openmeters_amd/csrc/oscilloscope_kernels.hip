@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     const bool resume = a.resume_mode != 0;
     const bool reset_stream = !resume && ragged && a.reset_v != nullptr && a.reset_v[s] != 0;  // clear_history (:714-723) of this stream
     const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t block_frames_s = a.frames_v != nullptr ? a.frames_v[s] : a.block_frames;  // chunk calls: the stream's own block length
     const uint32_t first_blk = resume ? a.resume_blk[s] : 0u;
     if (first_blk >= n_blocks_s && resume) return;  // (workgroup-uniform; nothing left for this stream)
     if (tid < kScopeTraces) {
@@ -812,8 +813,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
     pc.start(a.phase_timing != 0);
     for (uint32_t blk = first_blk; blk < n_blocks_s; ++blk) {
         // ---- push projected frames (:657-681) — unless scope_push2_kernel has put the whole call into the rings already
-        for (uint32_t f = a.pre_pushed ? a.block_frames : tid; f < a.block_frames; f += 256) {
-            const float* frame = pcm + ((uint64_t)blk * a.block_frames + f) * a.fmt.channels;
+        for (uint32_t f = a.pre_pushed ? block_frames_s : tid; f < block_frames_s; f += 256) {
+            const float* frame = pcm + ((uint64_t)blk * block_frames_s + f) * a.fmt.channels;
             float left = 0.0f, right = 0.0f;
             for (uint32_t c = 0; c < a.fmt.channels; ++c) {
                 const float v = frame[c];
@@ -838,8 +839,8 @@ __global__ __launch_bounds__(256) void oscilloscope_kernel(ScopeArgs a) {
         for (int t = 0; t < kScopeTraces; ++t) {
             const bool on = t < 2 ? active[t] : a.separate_source != 0;
             if (on) {
-                head[t] += a.block_frames;
-                len[t] = min(len[t] + (uint64_t)a.block_frames, (uint64_t)a.history_frames);
+                head[t] += block_frames_s;
+                len[t] = min(len[t] + (uint64_t)block_frames_s, (uint64_t)a.history_frames);
             } else {
                 len[t] = 0;
             }

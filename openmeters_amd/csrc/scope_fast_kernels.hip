@@ -921,6 +921,7 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
     const bool ragged = a.blocks_v != nullptr;
     const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;  // clear_history (:714-723) of this stream
     const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t block_frames_s = a.frames_v != nullptr ? a.frames_v[s] : a.block_frames;  // chunk calls: the stream's own block length
     if (tid < kScopeTraces) {
         const ScopeTriggerState* src = a.trig + (uint64_t)s * kScopeTraces + tid;
         store_trig(trig[tid], reset_stream ? TrigRegs{0, 0.0f, 0, 0.0f, 0.0f, 0} : load_trig(*src));
@@ -943,8 +944,8 @@ __global__ __launch_bounds__(T) void scope_trigger_kernel(ScopeArgs a, uint32_t 
         const uint32_t par = blk & 1u;
         if (tid < kScopeTraces) {  // the block's frames are in the rings already (scope_push_kernel)
             const bool on = tid == 0 ? active0 : (tid == 1 ? active1 : a.separate_source != 0);
-            s_head[par][tid] = s_head[par ^ 1u][tid] + (on ? a.block_frames : 0u);
-            s_len[par][tid] = on ? min(s_len[par ^ 1u][tid] + (uint64_t)a.block_frames, (uint64_t)a.history_frames) : 0ull;
+            s_head[par][tid] = s_head[par ^ 1u][tid] + (on ? block_frames_s : 0u);
+            s_len[par][tid] = on ? min(s_len[par ^ 1u][tid] + (uint64_t)block_frames_s, (uint64_t)a.history_frames) : 0ull;
         }
         if (stable && blk % kEstChunk == 0) {  // the next 64 blocks' estimates (the barrier below publishes them)
             const uint32_t cnt = min(kEstChunk, n_blocks_s - blk) * kScopeTraces;
@@ -1215,7 +1216,7 @@ void launch_scope_find_best_debug(const float* d_work, const float* d_tmpl, uint
 __global__ __launch_bounds__(256) void scope_push2_kernel(ScopeArgs a) {
     const uint32_t s = blockIdx.y;
     const uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t frames_s = a.blocks_v ? (uint64_t)a.blocks_v[s] * a.block_frames : a.frames_total;
+    const uint64_t frames_s = a.blocks_v ? (uint64_t)a.blocks_v[s] * (a.frames_v != nullptr ? a.frames_v[s] : a.block_frames) : a.frames_total;
     if (f >= frames_s) return;
     const float* frame = a.pcm + ((uint64_t)s * a.frames_total + f) * a.fmt.channels;
     float left = 0.0f, right = 0.0f;
@@ -1262,12 +1263,13 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
     const bool ragged = a.blocks_v != nullptr;
     ScopeEstimate* out = a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view;
     if (ragged && blk >= a.blocks_v[s]) return;
+    const uint32_t block_frames_s = a.frames_v != nullptr ? a.frames_v[s] : a.block_frames;  // chunk calls: the stream's own block length
     // which captures the trigger pass will attempt after this block (:683-700), from the deque lengths alone
     const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;
     auto on = [&](int t) { return t < 2 ? a.trace_channel[t] != OMX_CHANNEL_NONE : a.separate_source != 0; };
     auto len0 = [&](int t) -> uint64_t { return ragged ? (reset_stream ? 0ull : a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1]) : a.len[t]; };
     auto len_after = [&](int t) -> uint64_t {
-        return on(t) ? min(len0(t) + (uint64_t)(blk + 1) * a.block_frames, (uint64_t)a.history_frames) : 0ull;
+        return on(t) ? min(len0(t) + (uint64_t)(blk + 1) * block_frames_s, (uint64_t)a.history_frames) : 0ull;
     };
     const int linked_view = a.matching_trace >= 0 ? a.matching_trace : (a.separate_source ? 2 : -1);
     bool needed = false;
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
 
     const uint64_t n_trace = len_after((int)view);
     const uint64_t head0 = ragged ? a.pos_v[((uint64_t)s * kScopeTraces + view) * 2] : a.head[view];
-    const uint64_t head = head0 + (uint64_t)(blk + 1) * a.block_frames;
+    const uint64_t head = head0 + (uint64_t)(blk + 1) * block_frames_s;
     const uint32_t n = (uint32_t)min((uint64_t)a.probe_frames, n_trace);
     const float* ring = a.rings + ((uint64_t)s * kScopeTraces + view) * a.cap;
     const uint32_t mask = (uint32_t)(a.cap - 1), start = (uint32_t)((head - n) & (a.cap - 1));  // 32-bit index arithmetic per load
@@ -1517,12 +1519,13 @@ __global__ __launch_bounds__(FftGeom<LOGM>::T) void scope_estimate_big_kernel(Sc
     const bool ragged = a.blocks_v != nullptr;
     ScopeEstimate* out = a.estimates + ((uint64_t)s * a.n_blocks + blk) * kScopeTraces + view;
     if (ragged && blk >= a.blocks_v[s]) return;
+    const uint32_t block_frames_s = a.frames_v != nullptr ? a.frames_v[s] : a.block_frames;  // chunk calls: the stream's own block length
     // which captures the trigger pass will attempt after this block (:683-700), from the deque lengths alone
     const bool reset_stream = ragged && a.reset_v != nullptr && a.reset_v[s] != 0;
     auto on = [&](int t) { return t < 2 ? a.trace_channel[t] != OMX_CHANNEL_NONE : a.separate_source != 0; };
     auto len0 = [&](int t) -> uint64_t { return ragged ? (reset_stream ? 0ull : a.pos_v[((uint64_t)s * kScopeTraces + t) * 2 + 1]) : a.len[t]; };
     auto len_after = [&](int t) -> uint64_t {
-        return on(t) ? min(len0(t) + (uint64_t)(blk + 1) * a.block_frames, (uint64_t)a.history_frames) : 0ull;
+        return on(t) ? min(len0(t) + (uint64_t)(blk + 1) * block_frames_s, (uint64_t)a.history_frames) : 0ull;
     };
     const int linked_view = a.matching_trace >= 0 ? a.matching_trace : (a.separate_source ? 2 : -1);
     bool needed = false;
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(FftGeom<LOGM>::T) void scope_estimate_big_kernel(Sc
 
     const uint64_t n_trace = len_after((int)view);
     const uint64_t head0 = ragged ? a.pos_v[((uint64_t)s * kScopeTraces + view) * 2] : a.head[view];
-    const uint64_t head = head0 + (uint64_t)(blk + 1) * a.block_frames;
+    const uint64_t head = head0 + (uint64_t)(blk + 1) * block_frames_s;
     const uint32_t n = (uint32_t)min((uint64_t)a.probe_frames, n_trace);
     const float* ring = a.rings + ((uint64_t)s * kScopeTraces + view) * a.cap;
     const uint32_t mask = (uint32_t)(a.cap - 1), start = (uint32_t)((head - n) & (a.cap - 1));

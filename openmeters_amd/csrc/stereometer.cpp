@@ -157,6 +157,35 @@ int StereometerBank::process_ragged(const float* d_pcm, uint64_t block_frames, u
     return process_impl(d_pcm, true, block_frames, std::max<uint64_t>(max_blocks, 1), channels, sample_rate, positions, stream, nullptr, &rc);
 }
 
+// One block per capture, each of its own length: what VisualManager::ingest_samples hands StereometerProcessor::process_block
+// (registry.rs:396-418) when every capture has its own batcher (meter.rs:40-69: 1 ... 4 quanta per chunk, ONE call per chunk).
+int StereometerBank::process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                    uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                    omx_stereometer_ragged_update* out) {
+    if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
+        set_last_error("stereometer process_chunks: frames_capacity must be in 1 ... 2^32 - 1");
+        return OMX_ERR_INVALID;
+    }
+    h_blocks_.resize(n_streams_);
+    bool any = false;
+    uint64_t longest = 1;
+    for (uint32_t s = 0; s < n_streams_; ++s) {
+        if (frames[s] > frames_capacity) {
+            set_last_error("stereometer process_chunks: frames[s] > frames_capacity");
+            return OMX_ERR_INVALID;
+        }
+        h_blocks_[s] = frames[s] != 0 ? 1u : 0u;  // block.is_empty(): nothing happens
+        longest = std::max<uint64_t>(longest, frames[s]);
+        any = any || frames[s] != 0 || (reset_mask && reset_mask[s]);
+    }
+    last_stream_ = stream;
+    if (!any) return OMX_NONE;
+    RaggedCall rc{h_blocks_.data(), reset_mask, out};
+    rc.frames_v = frames;
+    rc.row_frames = frames_capacity;
+    return process_impl(d_pcm, true, longest, 1, channels, sample_rate, positions, stream, nullptr, &rc);
+}
+
 int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels_in,
                                   float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                   omx_stereometer_bank_update* out, const RaggedCall* ragged) {
@@ -205,7 +234,8 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
             OMX_HIP(hipMemsetAsync(state_.ptr + (size_t)s * 4 + 1, 0, 3 * sizeof(StereoLaneState), stream));
         pending_band_reset_ = false;
     }
-    const uint64_t total = block_frames * n_blocks;
+    const bool chunk_call = ragged && ragged->frames_v;
+    const uint64_t total = chunk_call ? ragged->row_frames : block_frames * n_blocks;  // frames per row of `pcm`
     const float* d_pcm = pcm;
     if (!pcm_on_device) {
         const size_t n = (size_t)n_streams_ * total * channels;
@@ -238,7 +268,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
     sa.correlations = correlations_.ptr;
     // chunk-parallel evaluation for bank-sized calls (stereometer_chunked.hip); everything else — single-stream handles, short
     // calls, other channel counts — stays on the sequential kernels, whose results are bit-identical to the reference's order
-    const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2;
+    const bool shape_ok = channels == 2 && block_frames % 16 == 0 && block_frames >= 32 && n_blocks >= 2 && !chunk_call;
     // by shape: whatever the bank size — the sequential kernels cost ~27 us per block however few streams there are, the chunk form ~0.08 ms
     // of launches plus its work (tools/bench_meter_forms.py: 1 stream x 64 blocks 1.75 -> 0.10 ms, 16 x 8 0.23 -> 0.07 ms; until round 4
     // the rule also asked for >= 512 (stream, block) items)
@@ -321,7 +351,9 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         r_mask_.reserve(n_streams_);
         r_start_.reserve((size_t)n_streams_ * 4);
         r_valid_.reserve((size_t)n_streams_ * 4);
-        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream);
+        if (chunk_call) r_frames_.reserve(n_streams_);
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, ragged->frames_v,
+                          chunk_call ? r_frames_.ptr : nullptr);
         produced_.reserve((size_t)(n_streams_ * n_blocks));
         StereoPlanArgs pa{};
         pa.n_streams = n_streams_;
@@ -331,6 +363,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         pa.analyze_bands = cfg_.analyze_bands;
         pa.emit_band_points = cfg_.emit_band_points;
         pa.blocks = r_blocks_.ptr;
+        pa.frames = chunk_call ? r_frames_.ptr : nullptr;
         pa.reset = r_mask_.ptr;
         pa.pos = r_pos_.ptr;
         pa.len = r_len_.ptr;
@@ -344,6 +377,7 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
         sa.blocks_v = r_blocks_.ptr;
         sa.reset_v = r_mask_.ptr;
         sa.start_v = r_start_.ptr;
+        sa.frames_v = chunk_call ? r_frames_.ptr : nullptr;
         OMX_HIP(hipMemsetAsync(correlations_.ptr, 0, (size_t)(n_streams_ * n_blocks * 4) * sizeof(float), stream));  // slots past a stream's own blocks
         if (chunked) run_chunked();
         launch_stereometer(sa, stream);

@@ -39,6 +39,9 @@ struct StereometerArgs {
     const uint32_t* blocks_v;
     const uint8_t* reset_v;
     const uint64_t* start_v;  // [n_streams][4], written by stereometer_ragged_plan_kernel
+    // chunk calls (process_chunks): stream s's blocks are frames_v[s] frames long (nullptr = block_frames for every stream); its row
+    // of `pcm` is frames_total frames long whatever it delivers
+    const uint32_t* frames_v;
 };
 void launch_stereometer(const StereometerArgs& a, hipStream_t stream);
 // ragged banks: the bookkeeping of one call for every stream (one lane per stream) — the positions its history pushes start from, the
@@ -47,6 +50,7 @@ void launch_stereometer(const StereometerArgs& a, hipStream_t stream);
 struct StereoPlanArgs {
     uint32_t n_streams, max_blocks, block_frames, hist_frames, analyze_bands, emit_band_points;
     const uint32_t* blocks;   // [n_streams]
+    const uint32_t* frames;   // [n_streams] per-stream block length (chunk calls), or nullptr = block_frames
     const uint8_t* reset;     // [n_streams]
     uint64_t* pos;            // [n_streams][4] in / out
     uint64_t* len;            // [n_streams][4] in / out
@@ -110,6 +114,10 @@ public:
     int process_ragged(const float* d_pcm, uint64_t block_frames, uint64_t max_blocks, const uint32_t* n_blocks, const uint8_t* reset_mask,
                        uint32_t channels, float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                        omx_stereometer_ragged_update* out);
+    // Chunk call (include/omx.h: omx_stereometer_bank_process_chunks; VisualManager::ingest_samples, registry.rs:396-418): stream s
+    // delivers ONE block of frames[s] <= frames_capacity frames (0 = nothing arrived); one output slot per stream.
+    int process_chunks(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                       float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_stereometer_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t block, float correlations[4], uint32_t* produced, hipStream_t stream);
     int fetch_points(uint64_t stream_index, uint32_t band, float* dst, uint64_t* n_pairs, hipStream_t stream);
     hipStream_t last_stream() const { return last_stream_; }
@@ -122,6 +130,8 @@ private:
         const uint32_t* n_blocks;
         const uint8_t* reset_mask;
         omx_stereometer_ragged_update* out;
+        const uint32_t* frames_v = nullptr;  // chunk calls: per-stream block length, rows of `pcm` row_frames apart
+        uint64_t row_frames = 0;
     };
     int process_impl(const float* pcm, bool pcm_on_device, uint64_t block_frames, uint64_t n_blocks, uint32_t channels, float sample_rate,
                      const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_stereometer_bank_update* out, const RaggedCall* ragged);
@@ -153,8 +163,9 @@ private:
     bool ragged_ = false;
     uint32_t ragged_zero_mask_ = 0;  // bands whose deques a config change emptied (applied by the next plan kernel)
     DeviceBuffer<uint64_t> r_pos_, r_len_, r_start_;
-    DeviceBuffer<uint32_t> r_blocks_, r_valid_;
+    DeviceBuffer<uint32_t> r_blocks_, r_valid_, r_frames_;
     DeviceBuffer<uint8_t> r_mask_;
+    std::vector<uint32_t> h_blocks_;
     RaggedStaging r_staging_;
     float transition_rate_ = 0.0f;
     uint64_t transition_frames_ = 0;

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
     // then has a per-lane trip count)
     const bool ragged = a.blocks_v != nullptr;
     const uint32_t n_blocks_s = ragged ? a.blocks_v[s] : a.n_blocks;
+    const uint32_t block_frames_s = a.frames_v != nullptr ? a.frames_v[s] : a.block_frames;  // chunk calls: the stream's own block length
     StereoLaneState st_mem = (a.state_in ? a.state_in : a.state)[gid];
     if (ragged && a.reset_v != nullptr && a.reset_v[s] != 0) memset(&st_mem, 0, sizeof(st_mem));  // reset_audio (:92-97) of this stream
     StereoRegs st = load_regs(st_mem);
@@ -157,15 +158,15 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
             has_pend = false;
         }
     };
-    const bool contiguous_batches = a.block_frames % BATCH == 0;
+    const bool contiguous_batches = block_frames_s % BATCH == 0;
     for (uint32_t blk = 0; blk < n_blocks_s; ++blk) {
         if (active) {
-            const float* base = pcm + (uint64_t)blk * a.block_frames * channels;
+            const float* base = pcm + (uint64_t)blk * block_frames_s * channels;
             uint32_t f = 0;
             if constexpr (CH == 2) {
                 auto batches = [&](auto use_a_c, auto use_b_c, auto push_c) {
                     constexpr bool UA = decltype(use_a_c)::value, UB = decltype(use_b_c)::value, PUSH = decltype(push_c)::value;
-                    for (; f + BATCH <= a.block_frames; f += BATCH) {
+                    for (; f + BATCH <= block_frames_s; f += BATCH) {
                         float2 x[BATCH];
                         if (!have_next) {
 #pragma unroll
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
                         // the next batch's frames are requested before this batch is computed (one wavefront per SIMD: nothing
                         // else hides the round trip).  Blocks are contiguous, so the prefetch runs across block boundaries; past
                         // the end of the call it re-reads the current batch (unconditional load, selected address).
-                        const uint64_t g = (uint64_t)blk * a.block_frames + f + BATCH;
+                        const uint64_t g = (uint64_t)blk * block_frames_s + f + BATCH;
                         have_next = contiguous_batches && g + BATCH <= a.frames_total;
                         const float* nxt = pcm + 2u * (have_next ? g : g - BATCH);
 #pragma unroll
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256) void stereometer_kernel(StereometerArgs a) {
                 else if (use_a) push_history ? batches(T{}, F{}, T{}) : batches(T{}, F{}, F{});
                 else if (!use_b) push_history ? batches(F{}, F{}, T{}) : batches(F{}, F{}, F{});
             }
-            if (f < a.block_frames) flush_pending();
-            for (; f < a.block_frames; ++f) {
+            if (f < block_frames_s) flush_pending();
+            for (; f < block_frames_s; ++f) {
                 const float* frame = base + (uint64_t)f * channels;
                 float left = 0.0f, right = 0.0f;  // dsp.rs:223-249 stereo fold
                 for (uint32_t c = 0; c < channels; ++c) {
@@ -593,10 +594,11 @@ __global__ __launch_bounds__(64) void stereometer_ragged_plan_kernel(StereoPlanA
     if (s >= a.n_streams) return;
     const bool reset = a.reset != nullptr && a.reset[s] != 0;
     const uint32_t nb = a.blocks[s];
-    const uint64_t frames = a.hist_frames, pushed = (uint64_t)nb * a.block_frames;
+    const uint64_t block_frames_s = a.frames != nullptr ? a.frames[s] : a.block_frames;
+    const uint64_t frames = a.hist_frames, pushed = (uint64_t)nb * block_frames_s;
     uint64_t len0 = (reset || (a.zero_len_mask & 1u)) ? 0ull : a.len[s * 4];
     for (uint32_t blk = 0; blk < a.max_blocks; ++blk) {  // :116, :129, :146-150: produced iff the full-band deque is full
-        if (blk < nb) len0 = min(len0 + (uint64_t)a.block_frames, frames);
+        if (blk < nb) len0 = min(len0 + block_frames_s, frames);
         a.produced[(uint64_t)s * a.max_blocks + blk] = (blk < nb && len0 >= frames) ? 1u : 0u;
     }
     const bool produced_last = nb != 0 && len0 >= frames;
