@@ -139,6 +139,26 @@ static std::vector<double> k_weighting_transitions(const double b[5], const doub
     return T;
 }
 
+// The zero-state end state of a block is linear in its samples: f_L = sum_k A^(L-1-k) B x_k, with one step of the TDF-II written as
+// f' = A f + B x (B_i = b_i - a_i b_0: y = b_0 x + f_0 substituted).  W[k][i] = (A^(L-1-k) B)_i, from the zero-input recurrence in
+// double-double arithmetic, rounded to f64.  The device evaluates the four dot products in the pass that computes the true peak
+// (no recurrence, no second K-weighting pass over the PCM): loudness_chunked.hip.
+static std::vector<double> k_weighting_zero_state_weights(const double b[5], const double a[5], uint64_t frames) {
+    std::vector<double> W((size_t)frames * 4);
+    DD g[4];
+    for (int i = 0; i < 4; ++i) g[i] = dd_add(DD{b[i + 1], 0.0}, dd_mul_d(DD{b[0], 0.0}, -a[i + 1]));
+    for (uint64_t n = 0; n < frames; ++n) {
+        const uint64_t k = frames - 1 - n;
+        for (int i = 0; i < 4; ++i) W[(size_t)k * 4 + i] = g[i].h;
+        const DD y = g[0];
+        g[0] = dd_add(g[1], dd_mul_d(y, -a[1]));
+        g[1] = dd_add(g[2], dd_mul_d(y, -a[2]));
+        g[2] = dd_add(g[3], dd_mul_d(y, -a[3]));
+        g[3] = dd_mul_d(y, -a[4]);
+    }
+    return W;
+}
+
 // test hook (omx_debug_k_weighting_transition, no device needed): the double-double block transition and its powers for a rate and block length
 void k_weighting_transition_debug(double sample_rate, uint64_t frames, double out[192]) {
     double b[5], a[5];
@@ -329,6 +349,7 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
     for (int w = 0; w < 4; ++w) off_grid = off_grid || la.capacities[w] % 64 != 0;
     if (transition_rate_ != cfg_.sample_rate || transition_frames_ != block_frames) {
         transition_.upload(k_weighting_transitions(b_, a_, block_frames), stream);
+        zs_weights_.upload(k_weighting_zero_state_weights(b_, a_, block_frames), stream);
         transition_rate_ = cfg_.sample_rate;
         transition_frames_ = block_frames;
     }
@@ -386,6 +407,7 @@ void LoudnessBank::run_chunked(LoudnessArgs& la, hipStream_t stream) {
     bad_.reserve(1);
     OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
     ca.chunk_filter = chunk_filter_.ptr;
+    ca.zs_weights = zs_weights_.ptr;
     ca.sub_sums = sub_sums_.ptr;
     ca.bad = bad_.ptr;
     ca.scan_dd = cfg_.sample_rate > 100000.0f ? 1u : 0u;

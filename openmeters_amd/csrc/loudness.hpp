@@ -82,6 +82,7 @@ struct LoudChunkArgs {
     LoudnessChannelState* state;   // [slots]
     float floor_db;
     omx_loudness_snapshot* snapshots;
+    const double* zs_weights;      // [block_frames][4]: W[k] = A^(L-1-k) B, the zero-state end state's weight on sample k of a block
     double* chunk_filter;          // [slots][n_blocks][4]: pass A's zero-state end states, then the true start states
     double* sub_sums;              // [slots][n_blocks * block_frames / 64]
     double* q_ring;                // [slots][q_len]: running total of the squared samples at the end of every 64-sample sub-block (high word)
@@ -151,7 +152,7 @@ private:
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
     // chunk-parallel path
-    DeviceBuffer<double> chunk_filter_, sub_sums_, q_ring_, tails_, transition_, rebuild_scratch_;
+    DeviceBuffer<double> chunk_filter_, sub_sums_, q_ring_, tails_, transition_, zs_weights_, rebuild_scratch_;
     DeviceBuffer<uint32_t> bad_;
     bool q_valid_ = false;
     uint64_t q_len_ = 0;     // entries per slot of q_ring_ / tails_ (power of two, grows with the call size)

@@ -26,6 +26,7 @@ namespace omx {
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // two independent f32 lanes of a v_pk_*_f32 instruction
 constexpr uint32_t kRow = 64;        // ring row = 64 slots (loudness_kernels.hip)
 constexpr int STEP = 16;             // frames per staged PCM tile
 constexpr uint32_t SUB = 64;         // samples per sub-block sum
@@ -48,6 +49,14 @@ __device__ __forceinline__ SlotCall slot_call(const LoudChunkArgs& a, uint32_t s
     if (!RAGGED || !a.blocks_v) return {a.frames_seen, a.n_blocks, false};  // (RAGGED = false: wave-uniform values, scalar registers)
     const bool reset = a.reset_v && a.reset_v[s] != 0;
     return {reset ? 0ull : a.seen_v[s], a.blocks_v[s], reset};
+}
+// Slot of sub-block `g` in a per-slot running-total ring of q_len entries (q_ring, q_lo, tails).  Four interleaved sub-rings by g % 4:
+// a snapshot reads the totals at block boundaries minus per-window constants — with 256-frame blocks every 4th entry — and lane =
+// block, so consecutive lanes read consecutive entries of ONE sub-ring (in natural order they were 32 bytes apart: 8 of every 32 bytes
+// fetched were used, 164 MB per cfg3 call).  The writers (lane = sub-block) cover four 128-byte runs per store instead of one 512-byte run.
+__device__ __forceinline__ uint64_t q_slot(uint64_t g, uint64_t q_len) {
+    const uint64_t i = g & (q_len - 1u);
+    return (i & 3u) * (q_len >> 2) + (i >> 2);
 }
 __device__ __forceinline__ void kbn(double& sum, double& corr, double v) {  // dsp.rs:277-285
     const double next = sum + v;
@@ -171,11 +180,18 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     }
     const double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
     RingT* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
-    uint64_t pos = (sc.seen + (uint64_t)c * L) % a.ring_len;  // ring slot of the block's first sample
-    // a call longer than the ring: only its newest ring_len samples are stored (an earlier block must not race a later one for a slot)
+    const uint32_t ring_len = (uint32_t)a.ring_len;  // (window_length of a 3 s window: < 2^32 at any rate)
+    uint32_t pos = (uint32_t)((sc.seen + (uint64_t)c * L) % a.ring_len);  // ring slot of the block's first sample
+    // a call longer than the ring: only its newest ring_len samples are stored (an earlier block must not race a later one for a slot).
+    // keep_from = the first sample of THIS block that is stored (0 in every call that fits the ring)
     const uint64_t idx0 = (uint64_t)c * L, frames_s = (uint64_t)sc.blocks * L, first_kept = frames_s > a.ring_len ? frames_s - a.ring_len : 0u;
+    const uint32_t keep_from = first_kept > idx0 ? (uint32_t)min(first_kept - idx0, (uint64_t)L) : 0u;
     double* sub = a.sub_sums + ((uint64_t)chan * a.n_blocks + c) * (L / SUB);
-    double ssum = 0.0, scor = 0.0;
+    // Sub-block sums: 64 non-negative squares, two plain f64 accumulators (even / odd samples).  Plain summation is exact to 64 ulp of the
+    // SUB-BLOCK's own sum (7e-15) — what the window sums need: they are differences of double-double running totals of these values, so
+    // a loud passage's rounding never reaches a quiet window (until round 5 a Kahan-Babuska-Neumaier pair: 10 instructions per sample
+    // for digits below the f32 rounding of the samples themselves).
+    double acc0 = 0.0, acc1 = 0.0;
     // window lengths off the 64-sample grid (44.1 / 88.2 kHz): the sum of the LAST cap_w % 64 samples of every sub-block, so that a
     // window starting inside sub-block g is Q[end] - (Q[g] - tail_w[g])
     double tl[kLoudnessWindows] = {0.0, 0.0, 0.0, 0.0};
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             bad |= dl.take(x);
             if (step + 1u < steps) dl.issue(step + 1u, C);
         }
+        RingT out[STEP];
 #pragma unroll
         for (int f = 0; f < STEP; ++f) {  // k_weighted (:153-162)
             // Fused multiply-adds (9 operations per sample where the reference's unfused statement order takes 17): this form is not
@@ -210,13 +227,13 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             f2 = fma(-a3, y, fma(b3, xd, f3));
             f3 = fma(-a4, y, b4 * xd);
             if constexpr (PASS == 1) {
-                const double filtered = (double)(float)y;  // rounded to f32 before squaring (:161, :276-277)
-                double value = filtered * filtered;
-                const bool finite = isfinite(value);
-                value = finite ? value : 0.0;              // WindowedMeans::push (dsp.rs:325)
-                if (live && idx0 + (uint64_t)(step * STEP + f) >= first_kept) ring_col[pos * kRow] = finite ? (RingT)filtered : (RingT)0;
-                pos = pos + 1u == a.ring_len ? 0u : pos + 1u;
-                kbn(ssum, scor, value);
+                const float y32 = (float)y;                // rounded to f32 before squaring (:161, :276-277)
+                const bool finite = isfinite(y32);         // the square of a finite f32 is a finite f64 (WindowedMeans::push, dsp.rs:325)
+                out[f] = finite ? (RingT)y32 : (RingT)0;
+                const double filtered = (double)out[f];
+                const double value = filtered * filtered;
+                if (f & 1) acc1 += value;
+                else acc0 += value;
                 if constexpr (TAILS) {
                     const int lim = (int)SUB - STEP * (int)(step % (SUB / STEP)) - f;  // samples from this one to the sub-block's end
 #pragma unroll
@@ -225,14 +242,30 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             }
         }
         if constexpr (PASS == 1) {
+            // ring stores of the step: one branch for the common case (every sample kept, no wrap inside the step)
+            const uint32_t k0 = step * STEP;
+            if (live) {
+                if (k0 >= keep_from && pos + (uint32_t)STEP <= ring_len) {
+                    RingT* dst = ring_col + (uint64_t)pos * kRow;
+#pragma unroll
+                    for (int f = 0; f < STEP; ++f) dst[(uint32_t)f * kRow] = out[f];
+                } else {
+#pragma unroll
+                    for (int f = 0; f < STEP; ++f) {
+                        const uint32_t pf = pos + (uint32_t)f >= ring_len ? pos + (uint32_t)f - ring_len : pos + (uint32_t)f;
+                        if (k0 + (uint32_t)f >= keep_from) ring_col[(uint64_t)pf * kRow] = out[f];
+                    }
+                }
+            }
+            pos = pos + (uint32_t)STEP >= ring_len ? pos + (uint32_t)STEP - ring_len : pos + (uint32_t)STEP;
             if ((step + 1u) % (SUB / STEP) == 0u) {
                 const uint32_t j = (step + 1u) / (SUB / STEP) - 1u;
-                if (live) sub[j] = ssum + scor;
-                ssum = scor = 0.0;
+                if (live) sub[j] = acc0 + acc1;
+                acc0 = acc1 = 0.0;
                 if constexpr (TAILS) {
 #pragma unroll
                     for (int w = 0; w < kLoudnessWindows; ++w) {
-                        if (live) tails[(uint64_t)w * a.q_len + ((g_first + j) & (a.q_len - 1u))] = tl[w];
+                        if (live) tails[(uint64_t)w * a.q_len + q_slot(g_first + j, a.q_len)] = tl[w];
                         tl[w] = 0.0;
                     }
                 }
@@ -246,6 +279,17 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             cf[1] = f1;
             cf[2] = f2;
             cf[3] = f3;
+        }
+    } else {
+        // the true-peak delay line the next call starts from (TruePeakMeter::delay, :123-133): the newest delay_len - 1 samples of the
+        // stream's last block, newest first, straight from the PCM (L >= 64 > delay_len); `peak` is taken at every snapshot (:301).
+        // Written here because this pass runs only when pass A left the non-finite flag clear.
+        if (live && c + 1u == sc.blocks) {
+            LoudnessChannelState& st = a.state[chan];
+            const uint32_t s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
+            const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)(c + 1u) * L) * C + ch;
+            for (uint32_t i = 0; i + 1u < a.delay_len; ++i) st.delay[i] = *(p - (int64_t)(i + 1u) * C);
+            st.peak = 0.0f;
         }
     }
 }
@@ -332,9 +376,15 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
     }
 }
 
-// ---- true peak of every block (TruePeakMeter::process, :123-151): grid (slot groups, blocks), lane = slot.  Bit-identical to
-// the sequential kernels: same samples, same tap order; the DL - 1 samples before the block come from the PCM of the call or,
-// for its first block, from the carried delay line.
+// ---- pass A: everything about a block that needs no state — grid (slot groups, blocks), lane = slot.
+//   true peak of the block (TruePeakMeter::process, :123-151), bit-identical to the sequential kernels: same samples, same tap order;
+//     the DL - 1 samples before the block come from the PCM of the call or, for its first block, from the carried delay line;
+//   zero-state end state of the K-weighting filter (k_weighted, :153-162) as four dot products with the host's weights
+//     W[k] = A^(L-1-k) B (loudness.cpp: k_weighting_zero_state_weights) — until round 5 a K-weighting pass of its own over the PCM
+//     (a 9-FMA dependent chain per sample, 0.15 of the call's 0.69 ms at cfg3); here four independent FMAs per sample on the tile the
+//     interpolator has in registers anyway;
+//   the non-finite flag (a call with a NaN / Inf sample is redone by the sequential kernels).
+// The carried delay line is written by pass B (which runs only when the flag stayed clear).
 template <int DL, bool TILED, bool RAGGED>
 __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
@@ -369,60 +419,92 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
         }
     }
     float peak = 0.0f;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;  // zero-state end state of the block
+    uint32_t bad = 0;
     if constexpr (TILED) t.issue(0, C);
     else dl.issue(0, C);
     for (uint32_t step = 0; step < steps; ++step) {
         float ext[STEP + H];  // ext[STEP - 1 - k] = x[k]; ext[STEP + i] = hist[i]
         if constexpr (TILED) {
-            (void)t.stage(tile[step & 1u]);
+            bad |= t.stage(tile[step & 1u]);
             if (step + 1u < steps) t.issue(step + 1u, C);
             __syncthreads();
             const float* row = tile[step & 1u] + rd;
 #pragma unroll
-            for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = live ? row[k * C] : 0.0f;
+            for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = row[k * C];  // (no select: Tile::stage zeroes the rows of dead streams, and a
+                                                                             //  dead lane's peak is never written)
         } else {
             float x[STEP];
-            (void)dl.take(x);
+            bad |= dl.take(x);
             if (step + 1u < steps) dl.issue(step + 1u, C);
 #pragma unroll
             for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = x[k];
         }
 #pragma unroll
         for (int i = 0; i < H; ++i) ext[STEP + i] = hist[i];
+        {   // zero-state end state: z += W[k] x[k] (wave-uniform weights: scalar loads)
+            const double* w = a.zs_weights + (uint64_t)step * (STEP * 4);
 #pragma unroll
-        for (int k = 0; k < STEP; ++k) {
-            peak = fmaxf(peak, fabsf(ext[STEP - 1 - k]));
+            for (int k = 0; k < STEP; ++k) {
+                const double xd = (double)ext[STEP - 1 - k];
+                z0 = fma(w[k * 4 + 0], xd, z0);
+                z1 = fma(w[k * 4 + 1], xd, z1);
+                z2 = fma(w[k * 4 + 2], xd, z2);
+                z3 = fma(w[k * 4 + 3], xd, z3);
+            }
+        }
+        // The interpolator is 36 (4x) / 24 (2x) multiply-THEN-add pairs per sample — the reference does not fuse them
+        // (`output[phase] += sample * coefficients[phase]`, :139-143), so neither does this — i.e. 72 / 48 VALU instructions per sample
+        // when issued one float at a time (round 4: 79 measured).  Two samples half a tile apart are independent sums over the same
+        // taps: as lanes .x / .y of v_pk_mul_f32 / v_pk_add_f32 each keeps its own products and its own accumulation order (bit-
+        // identical peaks) at half the instruction count.  The leading `0.0 + p` of every sum is dropped: it can only turn -0.0 into
+        // +0.0, and only |o| is used.
+        constexpr int HALF = STEP / 2;
+        v2f pair[HALF + H];  // pair[j] = {ext[j], ext[j + HALF]}: window position j of the newer and of the older half
+#pragma unroll
+        for (int j = 0; j < HALF + H; ++j) pair[j] = v2f{ext[j], ext[j + HALF]};
+        // (three phases of one window position = three independent chains, written side by side: a dependent v_pk_*_f32 waits
+        // 8 cycles, an independent one issues after 4 — tools/microbench/issue_rate.hip — and the scheduler keeps source order)
+#pragma unroll
+        for (int m = 0; m < HALF; ++m) {
+            peak = fmaxf(fmaxf(peak, fabsf(ext[m])), fabsf(ext[m + HALF]));  // (max(max(a, |b|), |c|): one v_max3_f32)
             if constexpr (DL == 12) {
+                v2f o0 = pair[m] * v2f{a.fir4[0][0], a.fir4[0][0]};
+                v2f o1 = pair[m] * v2f{a.fir4[0][1], a.fir4[0][1]};
+                v2f o2 = pair[m] * v2f{a.fir4[0][2], a.fir4[0][2]};
 #pragma unroll
-                for (int ph = 0; ph < 3; ++ph) {
-                    float o = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) o += ext[STEP - 1 - k + i] * a.fir4[i][ph];
-                    peak = fmaxf(peak, fabsf(o));
+                for (int i = 1; i < 12; ++i) {
+                    const v2f p0 = pair[m + i] * v2f{a.fir4[i][0], a.fir4[i][0]};
+                    const v2f p1 = pair[m + i] * v2f{a.fir4[i][1], a.fir4[i][1]};
+                    const v2f p2 = pair[m + i] * v2f{a.fir4[i][2], a.fir4[i][2]};
+                    o0 = o0 + p0;
+                    o1 = o1 + p1;
+                    o2 = o2 + p2;
                 }
+                peak = fmaxf(fmaxf(peak, fabsf(o0.x)), fabsf(o0.y));
+                peak = fmaxf(fmaxf(peak, fabsf(o1.x)), fabsf(o1.y));
+                peak = fmaxf(fmaxf(peak, fabsf(o2.x)), fabsf(o2.y));
             } else if constexpr (DL == 24) {
-                float o = 0.0f;
+                v2f o = pair[m] * v2f{a.fir2[0], a.fir2[0]};
 #pragma unroll
-                for (int i = 0; i < 24; ++i) o += ext[STEP - 1 - k + i] * a.fir2[i];
-                peak = fmaxf(peak, fabsf(o));
+                for (int i = 1; i < 24; ++i) o = o + pair[m + i] * v2f{a.fir2[i], a.fir2[i]};
+                peak = fmaxf(fmaxf(peak, fabsf(o.x)), fabsf(o.y));
             }
         }
 #pragma unroll
         for (int i = 0; i < H; ++i) hist[i] = ext[i];
     }
+    if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
     if (!live) return;
     omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + c;
     snap->true_peak_db[ch] = power_to_db(peak * peak, a.floor_db);
     if (ch == 0)
         for (uint32_t i = C; i < OMX_MAX_CHANNELS; ++i) snap->true_peak_db[i] = a.floor_db;  // with_floor (:197-207)
-    if (c + 1u == sc.blocks && *a.bad == 0u) {  // (pass A, which sets the flag, ran before this kernel)
-        LoudnessChannelState& st = a.state[chan];
-        if constexpr (DL > 1) {
-#pragma unroll
-            for (int i = 0; i < H; ++i) st.delay[i] = hist[i];
-        }
-        st.peak = 0.0f;
-    }
+    double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + c) * 4u;
+    cf[0] = z0;
+    cf[1] = z1;
+    cf[2] = z2;
+    cf[3] = z3;
 }
 
 // ---- prefix of the sub-block sums: Q[g] = sum of every squared sample up to the end of sub-block g since the last reset.
@@ -436,7 +518,7 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
     double* q = a.q_ring + (uint64_t)chan * a.q_len;
     double* ql = a.q_lo + (uint64_t)chan * a.q_len;
     // the total so far as a double-double pair; the prefix of a sweep's 64 sub-block sums (<= 4096) is plain f64
-    double carry = g0 == 0 ? 0.0 : q[(g0 - 1u) & (a.q_len - 1u)], carry_lo = g0 == 0 ? 0.0 : ql[(g0 - 1u) & (a.q_len - 1u)];
+    double carry = g0 == 0 ? 0.0 : q[q_slot(g0 - 1u, a.q_len)], carry_lo = g0 == 0 ? 0.0 : ql[q_slot(g0 - 1u, a.q_len)];
     const double* sub = a.sub_sums + (uint64_t)chan * a.n_blocks * (a.block_frames / SUB);
     for (uint64_t j0 = 0; j0 < n_sub; j0 += 64u) {
         const uint64_t j = j0 + lane;
@@ -449,8 +531,8 @@ __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
         const double hi = carry + x, bb = hi - carry;                 // two-sum (Knuth): hi + err == carry + x exactly
         const double lo = ((carry - (hi - bb)) + (x - bb)) + carry_lo;
         if (j < n_sub) {
-            q[(g0 + j) & (a.q_len - 1u)] = hi;
-            ql[(g0 + j) & (a.q_len - 1u)] = lo;
+            q[q_slot(g0 + j, a.q_len)] = hi;
+            ql[q_slot(g0 + j, a.q_len)] = lo;
         }
         carry = shfl_f64(hi, 63);
         carry_lo = shfl_f64(lo, 63);
@@ -493,7 +575,7 @@ __global__ __launch_bounds__(64) void loud_rebuild_sub_kernel(LoudChunkArgs a, d
         if (!partial) out[(uint64_t)chan * stride + j] = sum + c;
         if (a.tails) {
 #pragma unroll
-            for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (g & (a.q_len - 1u))] = tl[w];
+            for (int w = 0; w < kLoudnessWindows; ++w) a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + q_slot(g, a.q_len)] = tl[w];
         }
     }
 }
@@ -515,14 +597,14 @@ __global__ __launch_bounds__(256) void loud_rebuild_q_kernel(LoudChunkArgs a, co
         }
         x += carry;  // (at most ring_len samples: plain f64 is exact enough here, the low words restart at 0)
         if (j < sp.n) {
-            q[(sp.first_sub + j) & (a.q_len - 1u)] = x;
-            ql[(sp.first_sub + j) & (a.q_len - 1u)] = 0.0;
+            q[q_slot(sp.first_sub + j, a.q_len)] = x;
+            ql[q_slot(sp.first_sub + j, a.q_len)] = 0.0;
         }
         carry = shfl_f64(x, 63);
     }
     if (sp.first_sub > 0 && lane == 0) {
-        q[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
-        ql[(sp.first_sub - 1u) & (a.q_len - 1u)] = 0.0;
+        q[q_slot(sp.first_sub - 1u, a.q_len)] = 0.0;
+        ql[q_slot(sp.first_sub - 1u, a.q_len)] = 0.0;
     }
 }
 
@@ -536,24 +618,24 @@ __global__ __launch_bounds__(256) void loud_chunk_advance_kernel(LoudChunkArgs a
 }
 
 // ---- snapshots (loudness/processor.rs:287-310) and the write-back of the KBN pairs: thread = (stream, block)
-__global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs a) {
+__global__ __launch_bounds__(512) void loud_chunk_snapshot_kernel(LoudChunkArgs a) {
+    // workgroup = one stream x 64 consecutive blocks; wavefront = channel slot, lane = block (until round 5: one thread per (stream, block)
+    // walking the channels one after the other — 1024 wavefronts, each a chain of 8 x 10 dependent-latency loads: 67 us at cfg3)
+    __shared__ double part[OMX_MAX_CHANNELS][64][2];
     if (*a.bad != 0u) return;
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= (uint64_t)a.n_streams * a.n_blocks) return;
-    const uint32_t s = (uint32_t)(i / a.n_blocks), c = (uint32_t)(i % a.n_blocks);
+    const uint32_t lane = threadIdx.x & 63u, ch = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x, c = blockIdx.y * 64u + lane;
     const uint32_t C = a.channels;
     const SlotCall sc = slot_call(a, s);
-    if (c >= sc.blocks) return;
+    const bool on = c < sc.blocks && c < a.n_blocks;
     const uint64_t P = sc.seen + (uint64_t)(c + 1u) * a.block_frames;  // pushes at the end of this block
-    const uint64_t mask = a.q_len - 1u;
-    omx_loudness_snapshot* snap = a.snapshots + i;
-    double short_term = 0.0, momentary = 0.0;
+    omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + c;
     const bool last = c + 1u == sc.blocks;
-    for (uint32_t ch = 0; ch < C; ++ch) {
+    if (on && ch < C) {
         const uint32_t chan = (s << a.slot_shift) + ch;
         const double* q = a.q_ring + (uint64_t)chan * a.q_len;
         const double* ql = a.q_lo + (uint64_t)chan * a.q_len;
-        const double q_end = q[(P / SUB - 1u) & mask], q_end_lo = ql[(P / SUB - 1u) & mask];
+        const double q_end = q[q_slot(P / SUB - 1u, a.q_len)], q_end_lo = ql[q_slot(P / SUB - 1u, a.q_len)];
         double mean[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -563,13 +645,13 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
             double base = 0.0, base_lo = 0.0, tail = 0.0;
             if (st % SUB == 0u) {
                 if (start_sub != 0) {
-                    base = q[(start_sub - 1u) & mask];
-                    base_lo = ql[(start_sub - 1u) & mask];
+                    base = q[q_slot(start_sub - 1u, a.q_len)];
+                    base_lo = ql[q_slot(start_sub - 1u, a.q_len)];
                 }
             } else {
-                base = q[start_sub & mask];
-                base_lo = ql[start_sub & mask];
-                tail = a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + (start_sub & mask)];
+                base = q[q_slot(start_sub, a.q_len)];
+                base_lo = ql[q_slot(start_sub, a.q_len)];
+                tail = a.tails[((uint64_t)chan * kLoudnessWindows + w) * a.q_len + q_slot(start_sub, a.q_len)];
             }
             const double W = ((q_end - base) + (q_end_lo - base_lo)) + tail;
             mean[w] = W / (double)max(m, (uint64_t)1);
@@ -579,15 +661,15 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
                 const uint64_t refresh = (P / a.capacities[w]) * a.capacities[w], refresh_sub = refresh / SUB;
                 double rbase, rbase_lo = 0.0, radd = 0.0;
                 if (refresh % SUB == 0u) {
-                    rbase = refresh_sub == 0 ? 0.0 : q[(refresh_sub - 1u) & mask];
-                    rbase_lo = refresh_sub == 0 ? 0.0 : ql[(refresh_sub - 1u) & mask];
+                    rbase = refresh_sub == 0 ? 0.0 : q[q_slot(refresh_sub - 1u, a.q_len)];
+                    rbase_lo = refresh_sub == 0 ? 0.0 : ql[q_slot(refresh_sub - 1u, a.q_len)];
                 } else {  // off the grid: the rest of that sub-block is still in the sample ring (refresh > P - cap >= P - ring_len)
                     const RingT* ring_col = a.ring + (uint64_t)(chan / kRow) * a.ring_len * kRow + chan % kRow;
                     double rest = 0.0;
                     for (uint64_t i = refresh; i < (refresh_sub + 1u) * SUB; ++i) rest += ring_square(ring_col[(i % a.ring_len) * kRow]);
-                    rbase = q[refresh_sub & mask];
+                    rbase = q[q_slot(refresh_sub, a.q_len)];
                     radd = rest;
-                    rbase_lo = ql[refresh_sub & mask];
+                    rbase_lo = ql[q_slot(refresh_sub, a.q_len)];
                 }
                 st.sums[w][0] = W;
                 st.corrections[w][0] = 0.0;
@@ -595,10 +677,17 @@ __global__ __launch_bounds__(256) void loud_chunk_snapshot_kernel(LoudChunkArgs 
                 st.corrections[w][1] = 0.0;
             }
         }
-        short_term += mean[0] * a.weights[ch];  // position-weighted, channel order (:292-296)
-        momentary += mean[1] * a.weights[ch];
+        part[ch][lane][0] = mean[0];
+        part[ch][lane][1] = mean[1];
         snap->rms_fast_db[ch] = power_to_db((float)mean[2], a.floor_db);
         snap->rms_slow_db[ch] = power_to_db((float)mean[3], a.floor_db);
+    }
+    __syncthreads();
+    if (!on || ch != 0) return;
+    double short_term = 0.0, momentary = 0.0;
+    for (uint32_t k = 0; k < C; ++k) {  // position-weighted, channel order (:292-296)
+        short_term += part[k][lane][0] * a.weights[k];
+        momentary += part[k][lane][1] * a.weights[k];
     }
     snap->short_term_loudness = ms_to_lufs(short_term, a.floor_db);
     snap->momentary_loudness = ms_to_lufs(momentary, a.floor_db);
@@ -654,7 +743,6 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
             hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, TI, RG>), grid, dim3(64), 0, stream, a);
         });
     };
-    filter(std::integral_constant<int, 0>{});
     if (a.delay_len == 12) peak(std::integral_constant<int, 12>{});
     else if (a.delay_len == 24) peak(std::integral_constant<int, 24>{});
     else peak(std::integral_constant<int, 0>{});
@@ -662,8 +750,7 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
     else hipLaunchKernelGGL(loud_scan_filter_kernel<false>, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
     filter(std::integral_constant<int, 1>{});
     hipLaunchKernelGGL(loud_scan_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a);
-    const uint64_t snaps = (uint64_t)a.n_streams * a.n_blocks;
-    hipLaunchKernelGGL(loud_chunk_snapshot_kernel, dim3((uint32_t)((snaps + 255u) / 256u)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(loud_chunk_snapshot_kernel, dim3(a.n_streams, (a.n_blocks + 63u) / 64u), dim3(64u << a.slot_shift), 0, stream, a);
     if (a.blocks_v) hipLaunchKernelGGL(loud_chunk_advance_kernel, dim3((a.n_streams + 255u) / 256u), dim3(256), 0, stream, a);
 }
 

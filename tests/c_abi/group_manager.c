@@ -1,12 +1,12 @@
 /* Plain C99 host of the capture group as VisualManager (include/omx.h: omx_capture_group_set_enabled / _update_config / _note_format /
  * _ingest_ragged; reference src/visuals/registry.rs:266-277, :343-365, :396-418).  Four captures, each with its own frame counts per
- * call (0 ... 4 batcher quanta, uneven), a visual toggled off and on again, a second visual created by set_enabled, the spectrogram's
+ * call (a batcher chunk of 0 ... 4 quanta, uneven, delivered WHOLE as one block: meter.rs:61-64, registry.rs:407-417), a visual toggled off and on again, a second visual created by set_enabled, the spectrogram's
  * hop changed mid-stream, one capture reset on its own and a format-generation change that resets all of them.  Every capture is
  * compared, call by call, with single-stream handles of the CPU ORACLE (libomx_oracle.so, prefix omxo_, declared by hand below:
  * the public header only declares the product) fed exactly the same sequence:
  *   spectrogram  column count and `reset` flag per call exact, point counts within 4 per column
- *   loudness     momentary / short-term LUFS of every block within 1e-4 dB
- *   stereometer  the four correlations of every block within 1e-6 (ragged calls run the reference's operation order)
+ *   loudness     momentary / short-term LUFS and true peak of every chunk (= block) within 1e-4 dB
+ *   stereometer  the four correlations of every chunk within 1e-6 (chunk calls run the reference's operation order)
  * Exit code 0 = every call succeeded and every comparison held; prints the largest differences. */
 #include <math.h>
 #include <stdio.h>
@@ -70,7 +70,7 @@ int main(void) {
     omx_capture_group_config_default(&cfg);
     cfg.n_streams = S;
     cfg.visuals = OMX_VISUAL_SPECTROGRAM | OMX_VISUAL_LOUDNESS; /* the stereometer joins later through set_enabled */
-    cfg.block_frames = BLOCK;
+    cfg.block_frames = 0;  /* the reference's partition: what a capture delivers in one call is one AudioBlock */
     cfg.spectrogram.fft_size = 1024;
     cfg.spectrogram.hop_size = 256;
     cfg.spectrogram.use_reassignment = 1;
@@ -145,14 +145,14 @@ int main(void) {
         omx_capture_group_ragged_update up;
         CHECK(omx_capture_group_ingest_ragged(g, (const float*)d_pcm, CAP, frames, mask, CH, 48000.0f, positions, NULL, &up));
         if (hipDeviceSynchronize() != 0) return 2;
-        EXPECT(up.block_frames == BLOCK && up.max_blocks == MAXB);
+        EXPECT(up.block_frames == 0 && up.max_blocks == 1);
         EXPECT(omx_capture_group_ingest(g, (const float*)d_pcm, CAP, CH, 48000.0f, positions, NULL, NULL) == OMX_ERR_INVALID);
         if (hipMemcpy(ncols, up.spectrogram.d_n_columns, sizeof(ncols), 2) != 0) return 2;
         if (hipMemcpy(resets, up.spectrogram.d_reset, sizeof(resets), 2) != 0) return 2;
         EXPECT(up.spectrogram.max_columns <= 16);
         if (up.spectrogram.max_columns && hipMemcpy(counts, up.spectrogram.d_counts, sizeof(uint32_t) * S * up.spectrogram.max_columns, 2) != 0) return 2;
-        if (hipMemcpy(snaps, up.loudness.d_snapshots, sizeof(omx_loudness_snapshot) * S * MAXB, 2) != 0) return 2;
-        if (stereo_on && hipMemcpy(rho, up.stereometer.d_correlations, sizeof(float) * S * MAXB * 4, 2) != 0) return 2;
+        if (hipMemcpy(snaps, up.loudness.d_snapshots, sizeof(omx_loudness_snapshot) * S, 2) != 0) return 2;
+        if (stereo_on && hipMemcpy(rho, up.stereometer.d_correlations, sizeof(float) * S * 4, 2) != 0) return 2;
         EXPECT(((up.produced & OMX_VISUAL_STEREOMETER) != 0) <= stereo_on);
         /* ---- the same sequence through one oracle handle per capture and visual */
         for (int s = 0; s < S; ++s) {
@@ -182,25 +182,29 @@ int main(void) {
                 EXPECT(llabs(a - b) <= 4);
             }
             columns += want_cols;
-            for (uint32_t b = 0; b < frames[s] / BLOCK; ++b) {
+            {   /* the chunk, whole, to the block-based visuals: one process_block each */
                 omx_loudness_snapshot ls;
                 omx_stereometer_snapshot ss;
                 memset(&ls, 0, sizeof(ls));
                 memset(&ss, 0, sizeof(ss));
-                fill_block(&blk, mine + (size_t)b * BLOCK * CH, BLOCK, positions);
+                fill_block(&blk, mine, frames[s], positions);
                 CHECK(omxo_loudness_process_block(ld[s], &blk, &ls));
-                const omx_loudness_snapshot* got = snaps + (size_t)s * MAXB + b;
+                const omx_loudness_snapshot* got = snaps + (size_t)s;
                 double d = fabs((double)got->momentary_loudness - (double)ls.momentary_loudness);
                 if (d > worst_lufs) worst_lufs = d;
                 d = fabs((double)got->short_term_loudness - (double)ls.short_term_loudness);
                 if (d > worst_lufs) worst_lufs = d;
+                for (int k = 0; k < CH; ++k) {  /* ONE true-peak take over the whole chunk (loudness/processor.rs:301) */
+                    d = fabs((double)got->true_peak_db[k] - (double)ls.true_peak_db[k]);
+                    if (d > worst_lufs) worst_lufs = d;
+                }
                 ++blocks;
                 if (stereo_on) {  /* a disabled visual is not fed: its oracle twin sits the call out as well */
                     const int produced = omxo_stereometer_process_block(st[s], &blk, &ss);
                     CHECK(produced);
                     if (produced > 0)
                         for (int k = 0; k < 4; ++k) {
-                            d = fabs((double)rho[((size_t)s * MAXB + b) * 4 + k] - (double)ss.correlations[k]);
+                            d = fabs((double)rho[(size_t)s * 4 + k] - (double)ss.correlations[k]);
                             if (d > worst_rho) worst_rho = d;
                             ++rho_checks;
                         }

@@ -198,6 +198,9 @@ if __name__ == "__main__":
         waveform(sizes=tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (64, 1024, 4096),
                  histories=(bool(int(sys.argv[3])),) if len(sys.argv) > 3 else (False, True))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loudness":  # cfg3 only (kernel traces of the loudness call)
+        loudness(reps=int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "scope":  # cfg4's two banks only (tools/profile_scope_sq.sh)
         scope_stereo()
         sys.exit(0)

@@ -28,7 +28,7 @@ def default_configs():
 def run(api, streams, frames, calls, visuals, warmup=40):
     dev = torch.device("cuda", 0)
     cfgs = {k: v for k, v in default_configs().items() if k in visuals}
-    group = CaptureGroup(api, streams, block_frames=256, **cfgs)
+    group = CaptureGroup(api, streams, **cfgs)   # block_frames = 0: every call is ONE block, the reference's partition (registry.rs:407-417)
     pos = capi.positions_fallback(2)
     n = torch.arange(frames * 8, device=dev, dtype=torch.float32)
     base = (0.4 * torch.sin(2 * torch.pi * 440.0 * n / 48000.0))[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :]
@@ -54,7 +54,7 @@ def streaming(streams=1024, calls=200, out=sys.stdout):
     for frames, key in ((256, "block_256"), (1024, "catch_up_1024")):
         us = run(api, streams, frames, calls if frames == 256 else max(calls // 4, 20), list(NAMES.values()))
         audio_us = frames / 48000.0 * 1e6
-        rec[key] = {"us_per_call": round(us, 1), "x_real_time": round(audio_us / us, 2), "blocks_per_s": round(streams * (frames // 256) / us * 1e6)}
+        rec[key] = {"us_per_call": round(us, 1), "x_real_time": round(audio_us / us, 2), "chunks_per_s": round(streams / us * 1e6)}
         print(f"streaming: {streams} captures x {frames} frames, six visuals: {us:.1f} us per call = {audio_us / us:.1f}x real time", file=out)
     return rec
 

@@ -10,7 +10,7 @@ import bench_stream as bs
 api = openmeters_amd.api()
 dev = torch.device("cuda", 0)
 streams, frames = 1024, 256
-group = CaptureGroup(api, streams, block_frames=256, **bs.default_configs())
+group = CaptureGroup(api, streams, **bs.default_configs())
 pos = capi.positions_fallback(2)
 pcm = (torch.rand((streams, frames * 8, 2), device=dev) - 0.5).contiguous()
 chunks = [pcm[:, k * frames:(k + 1) * frames].contiguous() for k in range(8)]
