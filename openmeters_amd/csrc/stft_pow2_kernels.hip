@@ -7,6 +7,7 @@
 #include <mutex>
 #include <cstdlib>
 
+#include "buffer_device.hpp"
 #include "fft_pow2_device.hpp"
 #include "reassign_device.hpp"
 #include "twiddle_run_device.hpp"
@@ -1442,7 +1443,9 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
     const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
     const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
     if (s >= a.n_streams) return;
-    const int fs = threadIdx.x / T, jf = threadIdx.x % T;
+    // the frame slot is wave-uniform (T = 64 or 128 threads per slot): taken through readfirstlane so that everything derived from it —
+    // column indices, ring offsets, the buffer descriptors of the loads below — lives in scalar registers
+    const int fs = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T)), jf = threadIdx.x % T;
     const unsigned ju = (unsigned)jf;
     const int lane = threadIdx.x & 63, wf = jf >> 6;
     const int wf_u = __builtin_amdgcn_readfirstlane(wf);
@@ -1484,8 +1487,21 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
 
     // ---- 1. packed real FFTs of the two 2N-sample windows ------------------------------------------------------------------------------
     const uint32_t pa32 = (uint32_t)p0a, pb32 = (uint32_t)p0b;
+    // Buffer-addressed loads (buffer_device.hpp) while the two windows lie in one piece of the ring: one per-lane byte offset and scalar
+    // steps instead of a 64-bit vector address per load — the addresses of the 96 ring / table loads are what spilled here (48 ... 76 B
+    // of scratch per lane until round 5, profiles/r14_kernel_resources.txt)
+    const uint32_t off_a = pa32 & mask32, hop_bytes = (pb32 - pa32) * 4u;
+    const bool direct = (uint64_t)off_a + (uint64_t)(pb32 - pa32) + 2ull * N <= a.cap && ((p0a | p0b) & 1ull) == 0;
+    const GlobalBuffer windowb = global_buffer(ring + off_a, hop_bytes + 2u * (uint32_t)N * 4u);
+    const GlobalBuffer normb = global_buffer(a.bin_norm, (uint32_t)(N / 2 + 1) * 4u), twinb = global_buffer(a.twindow, (uint32_t)N * 4u);
     v2f va[16], vb[16];
-    if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
+    if (direct) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            va[t] = load_v2f(windowb, ju * 8u, 8u * (unsigned)T * (unsigned)t);
+            vb[t] = load_v2f(windowb, ju * 8u, hop_bytes + 8u * (unsigned)T * (unsigned)t);
+        }
+    } else if (((p0a | p0b) & 1ull) == 0) {  // pairs are 8-byte aligned and never straddle the ring wrap
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             va[t] = *reinterpret_cast<const v2f*>(ring + ((pa32 + 2u * (ju + (unsigned)T * (unsigned)t)) & mask32));
@@ -1529,17 +1545,22 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
     tri_dual_pow2<true, LOGN>(ya, yb, X, jf, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = jf + T t
 
     // ---- 3. analytic slices s[i] = analytic[N/2 + i], i = jf + T t -------------------------------------------------------------------------
-    auto load_real_half = [&](float (&xr)[16], uint32_t p32) {
-        const uint32_t q0 = p32 + (uint32_t)(N / 2) + ju;
+    auto load_real_half = [&](float (&xr)[16], uint32_t col_bytes, uint32_t p32) {
+        if (direct) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xr[t] = ring[(q0 + (unsigned)T * (unsigned)t) & mask32];
+            for (int t = 0; t < 16; ++t) xr[t] = load_f32(windowb, ju * 4u, col_bytes + 2u * (uint32_t)N + 4u * (unsigned)T * (unsigned)t);
+        } else {
+            const uint32_t q0 = p32 + (uint32_t)(N / 2) + ju;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xr[t] = ring[(q0 + (unsigned)T * (unsigned)t) & mask32];
+        }
     };
     auto load_twindow = [&](float (&twin)[16]) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) twin[t] = a.twindow[ju + (unsigned)T * (unsigned)t];
+        for (int t = 0; t < 16; ++t) twin[t] = load_f32(twinb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
     };
     float xra[16], twina[16];
-    load_real_half(xra, pa32);
+    load_real_half(xra, 0u, pa32);
     load_twindow(twina);
     frame_sync<LOGN>();
     float* imag_a = reinterpret_cast<float*>(X);
@@ -1575,7 +1596,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
         tri_dual_pow2<false, LOGN>(z, z2, X, jf, tw);
         float pn[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) pn[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
+        for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 4u * (unsigned)T * (unsigned)t);  // (t = 8, jf > 0: past the table, reads 0, not used)
         frame_sync<LOGN>();  // the last pass still reads X
 #pragma unroll
         for (int t = 0; t < 8; ++t) lin_z[3 + jf + T * t] = z[t];
@@ -1642,7 +1663,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
     column(xra, twina, imag_a, half_x0a, half_xna, silent_a, in_range, col0);
     {
         float xrb[16], twinb[16];
-        load_real_half(xrb, pb32);
+        load_real_half(xrb, hop_bytes, pb32);
         load_twindow(twinb);
         column(xrb, twinb, imb, half_x0b, half_xnb, silent_b, in_range && have1, col1);
     }
