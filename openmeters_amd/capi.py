@@ -476,6 +476,18 @@ class SpectrogramProcessor(_Handle):
         self._call("get_config", C.byref(c), argtypes=[C.c_void_p])
         return SpectrogramConfig.from_c(c)
 
+    def debug_capture(self, enable: bool = True):
+        """ORACLE handles only (test hook): record the samples every column of the following updates is computed from."""
+        self.api.fn("debug_spectrogram_capture", None, [C.c_void_p, C.c_int])(self._h, int(enable))
+
+    def debug_captured(self, index: int) -> np.ndarray:
+        """ORACLE handles only: the samples column `index` of the last update was computed from (empty when there is none)."""
+        f = self.api.fn("debug_spectrogram_captured", C.c_uint64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64])
+        n = int(f(self._h, index, None, 0))
+        buf = np.zeros(max(n, 1), np.float32)
+        f(self._h, index, buf.ctypes.data, n)
+        return buf[:n]
+
     def update_config(self, config: SpectrogramConfig):
         c = config.to_c()
         self._call("update_config", C.byref(c), argtypes=[C.c_void_p])

@@ -4,6 +4,7 @@
 // prefix (same structs, same return convention) so tests/ can drive the oracle and the HIP
 // product through identical Python wrappers.  Extra `omxo_kat_*` exports expose the shared
 // primitives for the known-answer tests ported from the reference's in-file unit tests.
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -226,6 +227,17 @@ uint64_t omxo_spectrogram_history_columns(uint32_t kind, uint32_t points, uint64
     return history_columns(kind, points, (size_t)requested);
 }
 // test-only views of private state the reference's own tests inspect
+// test hook: record (enable != 0) the input samples of every column of the following updates; omxo_debug_spectrogram_captured copies
+// the samples column `index` of the LAST update was computed from (returns their count, 0 when there is no such column)
+void omxo_debug_spectrogram_capture(omxo_spectrogram* h, int enable) {
+    h->p.set_capture_inputs(enable != 0);
+}
+uint64_t omxo_debug_spectrogram_captured(const omxo_spectrogram* h, uint64_t index, float* dst, uint64_t cap) {
+    if (index >= h->p.captured_inputs().size()) return 0;
+    const std::vector<float>& v = h->p.captured_inputs()[index];
+    if (dst) std::memcpy(dst, v.data(), std::min<uint64_t>(cap, v.size()) * sizeof(float));
+    return v.size();
+}
 uint64_t omxo_spectrogram_pending(const omxo_spectrogram* h, float* dst, uint64_t cap) {
     const auto& a = h->p.audio_buffer();
     for (size_t i = 0; i < a.size() && i < cap; ++i) dst[i] = a[i];
@@ -761,24 +773,47 @@ void omxo_kat_fft_f64(double* data, uint64_t n, int inverse) {
 // `block_frames`-frame blocks on `threads` host threads; returns seconds and total columns emitted.
 double omxo_bench_spectrogram(const omx_spectrogram_config* cfg, const float* pcm, uint64_t n_streams, uint64_t frames,
                               uint32_t channels, uint64_t block_frames, uint32_t threads, uint64_t* columns_out) {
-    std::vector<uint64_t> cols(threads ? threads : 1, 0);
+    // The timed region starts when EVERY thread has built its first processor (windows, derivative window by the spectral method,
+    // twiddle tables: tens of milliseconds each) and touched its PCM, and ends when the last one is through — until round 5 thread
+    // start-up, table construction and first-touch page faults sat inside a region of ~0.25 s of work per thread, and 256 threads
+    // measured 7x one.
     const uint32_t T = threads ? threads : 1;
-    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> cols(T, 0);
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < T; ++t) {
         pool.emplace_back([&, t]() {
+            std::unique_ptr<SpectrogramProcessor> first;
+            if (t < n_streams) {
+                first.reset(new SpectrogramProcessor(from_c(*cfg)));
+                first->prepare();
+                volatile float sink = 0.0f;
+                for (uint64_t s = t; s < n_streams; s += T)   // first touch of this thread's PCM rows
+                    for (uint64_t i = 0; i < frames * channels; i += 1024) sink = sink + pcm[s * frames * channels + i];
+            }
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
             for (uint64_t s = t; s < n_streams; s += T) {
-                SpectrogramProcessor p(from_c(*cfg));
+                std::unique_ptr<SpectrogramProcessor> own;
+                SpectrogramProcessor* p = first.get();
+                if (s != t) {
+                    own.reset(new SpectrogramProcessor(from_c(*cfg)));
+                    p = own.get();
+                }
                 const float* base = pcm + s * frames * channels;
                 SpectrogramUpdate u;
                 for (uint64_t off = 0; off < frames; off += block_frames) {
                     const uint64_t nf = std::min(block_frames, frames - off);
                     const AudioBlock b = AudioBlock::make(base + off * channels, (size_t)(nf * channels), channels, cfg->sample_rate);
-                    if (p.process_block(b, u)) cols[t] += u.new_columns.size();
+                    if (p->process_block(b, u)) cols[t] += u.new_columns.size();
                 }
             }
         });
     }
+    while (ready.load() < T) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
     for (auto& th : pool) th.join();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t total = 0;

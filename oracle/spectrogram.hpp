@@ -211,6 +211,12 @@ public:
     const std::vector<float>& window() const { return window_; }
     const std::vector<float>& bin_norm() const { return bin_norm_; }
 
+    void set_capture_inputs(bool on) {
+        capture_inputs_ = on;
+        captured_.clear();
+    }
+    const std::vector<std::vector<float>>& captured_inputs() const { return captured_; }
+
 private:
     void rebuild_fft() {  // :229-279
         const size_t window_size = config_.fft_size;
@@ -265,10 +271,12 @@ private:
         std::vector<SpectrogramColumn> output;
         output.reserve(std::min(ready, retained));
         advance_audio(skip * hop);
+        if (capture_inputs_) captured_.clear();
 
         for (size_t it = skip; it < ready; ++it) {
             SpectrogramColumn col;
             col.kind = kind;
+            if (capture_inputs_) captured_.emplace_back(audio_.begin(), audio_.begin() + (std::ptrdiff_t)std::min(read_len, audio_.size()));
             if (!has_nonzero_) {  // :307-316 silent fast path
                 if (!reassign) col.codes.assign(bin_count, pack_classic_db(DB_FLOOR));
                 output.push_back(std::move(col));
@@ -372,6 +380,11 @@ private:
         }
         return points;
     }
+
+    // test hook (parity arbitration against exact f64, tests/parity.py): the samples every column of the last update was computed from
+    // — the front `read_len` samples of the pending buffer at the moment the column was taken (:323-325, window.rs:76-79)
+    bool capture_inputs_ = false;
+    std::vector<std::vector<float>> captured_;
 
     SpectrogramConfig config_;
     bool prepared_ = false;

@@ -28,6 +28,28 @@ def bar(name, err, limit, detail=None):
     return err
 
 
+# ---- exemption ledger (round 5, VERDICT r4 "parity governance").  A check that passes only THROUGH a rule that is not the plain fixed bar
+# — the conditioning term, a louder neighbour's scale, an explained orphan, the bins 0-3 allowance, the per-trace dB exceptions — is
+# counted here under the rule's name, next to how many checks the rule was consulted for.  Two consequences are enforced:
+#   * the fixed-seed suite must need NO exemption (tests/conftest.py fails the session otherwise: EXEMPTIONS_ALLOWED is switched on by
+#     the soak module only), so a rule can only ever act on the clock-seeded soak cases;
+#   * a reassigned column that needs one is arbitrated in-suite against exact f64 arithmetic (`arbitrate_reassigned`): |HIP - exact|
+#     <= max(fixed bar, 2 |oracle - exact|) on the metric concerned — a rule cannot hide a HIP-side error.
+EXEMPTIONS = {}              # rule -> [checks that needed it, checks it was consulted for]
+EXEMPTIONS_ALLOWED = False   # True while a soak case runs (tests/test_gpu_soak.py)
+FIXED_SEED_EXEMPTIONS = []   # (rule, detail) of exemptions used while EXEMPTIONS_ALLOWED was off
+
+
+def exemption(rule, used, detail=None):
+    rec = EXEMPTIONS.setdefault(rule, [0, 0])
+    rec[1] += 1
+    if used:
+        rec[0] += 1
+        if not EXEMPTIONS_ALLOWED:
+            FIXED_SEED_EXEMPTIONS.append((rule, detail))
+    return bool(used)
+
+
 def write_ledger(path):
     with open(path, "w") as fh:
         fh.write("# measured maxima of every float parity bar of `pytest -m gpu` on this box (HIP product vs CPU oracle / fixtures)\n")
@@ -36,6 +58,11 @@ def write_ledger(path):
             limit, worst, n = LEDGER[name]
             ratio = f"{limit / worst:9.1f}" if worst > 0 else "      inf"
             fh.write(f"{name:<60} {limit:10.3g} {worst:14.3e} {n:8d} {ratio}\n")
+        fh.write("#\n# exemptions: checks that passed only through a rule other than the plain fixed bar (needed / consulted)\n")
+        for rule in sorted(EXEMPTIONS):
+            used, n = EXEMPTIONS[rule]
+            fh.write(f"exemption: {rule:<80} {used:8d} / {n:8d}\n")
+        fh.write(f"exemptions needed by fixed-seed tests (must be 0): {len(FIXED_SEED_EXEMPTIONS)}\n")
 
 
 def align_points(a, b, max_power, band_extra=8):
@@ -144,8 +171,8 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
     """
     max_power = float(max(ora[:, 2].max() if len(ora) else 0.0, hip[:, 2].max() if len(hip) else 0.0))
     if max_power <= 0.0:
-        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, orphan_any=0.0, n=0, orphans=len(hip) + len(ora), freq_strong=0.0,
-                    time_strong=0.0, n_strong=0)
+        return dict(power=0.0, freq=0.0, time=0.0, orphan=0.0, orphan_any=0.0, orphan_explained=0.0, n=0, orphans=len(hip) + len(ora),
+                    freq_strong=0.0, time_strong=0.0, n_strong=0)
     pairs, oa, ob = align_points(hip, ora, max_power)
     pa = np.array([p[0] for p in pairs], int)
     pb = np.array([p[1] for p in pairs], int)
@@ -169,6 +196,7 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
     # spectra, see the f-hat bars), x ORPHAN_EDGE_K.  What the orphan bar limits is the strongest orphan that is NOT explained that
     # way (soak, round 4: noise-level bins next to DC, r = 5e-7 ... 3e-6, whose f-hat lies within a few Hz of 0 on one side only).
     worst = 0.0
+    explained_over = 0.0   # the strongest orphan that passes only because it is "explained" (it would fail the plain orphan bar)
     for p in orphans:
         r = float(p[2]) / max_power
         edge = min(abs(float(p[1])), abs(sample_rate * 0.5 - float(p[1])))
@@ -176,7 +204,10 @@ def reassigned_column_metrics(hip, ora, sample_rate, hop):
         on_floor = float(p[2]) <= 4e-14
         if not (on_edge or on_floor):
             worst = max(worst, r)
+        elif r > BAR_ORPHAN:
+            explained_over = max(explained_over, r)
     m["orphan"] = worst
+    m["orphan_explained"] = explained_over
     return m
 
 
@@ -224,28 +255,62 @@ def ulp_perturbed(pcm, rng):
     return y
 
 
-def conditioned_bar(name, err, fixed, sens, detail=None, plain=True):
+def conditioned_bar(name, err, fixed, sens, detail=None, plain=True, base=None):
     """bar(err / (fixed + K sens), 1): the fixed bar on well-conditioned columns, measured conditioning on top elsewhere.  Columns whose
     conditioning term is below a tenth of the fixed bar are also entered under the plain fixed bar (ledger: what the bar measures
-    when conditioning plays no part; `plain` False = `fixed` is already scaled by a louder neighbour, not a plain bar)."""
+    when conditioning plays no part; `plain` False = `fixed` is already scaled by a louder neighbour, not a plain bar; `base` = the
+    bar before that scaling).  Returns the exemptions the check needed: a subset of {"conditioning", "scale"}."""
     limit = float(fixed) + CONDITIONING_K * float(sens)
     bar(name + " / (bar + 16 x oracle's 1-ulp sensitivity)", float(err) / limit, 1.0, (err, fixed, sens, detail))
     if plain and CONDITIONING_K * float(sens) <= 0.1 * float(fixed):
         bar(name + " [well-conditioned columns]", err, 1.1 * float(fixed), detail)
+    base = float(fixed) if base is None else float(base)
+    used = set()
+    if exemption("conditioning term (16 x the oracle's 1-ulp sensitivity) over the fixed bar", float(err) > float(fixed), (name, err, fixed, sens)):
+        used.add("conditioning")
+    if exemption("fixed bar relative to a louder column within reach", base < float(err) <= float(fixed), (name, err, base, fixed)):
+        used.add("scale")
+    return used
 
 
-def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag="reassigned (random sequences)", time_bar=BAR_TIME, scale=1.0):
+def arbitrate_reassigned(tag, hip, ora, exact, sample_rate, hop, metrics, fixed):
+    """A column that passed through an exemption, judged against exact f64 arithmetic (`exact`: oracle/exact_f64.reassigned_column of the
+    samples the oracle computed it from): for every metric in `metrics` (power / freq / time / orphan), |HIP - exact| must be within
+    max(its fixed bar, 2 |oracle - exact|).  The ledger records the ratio."""
+    he = reassigned_column_metrics(hip, exact, sample_rate, hop)
+    oe = reassigned_column_metrics(ora, exact, sample_rate, hop)
+    for k in metrics:
+        limit = max(float(fixed[k]), 2.0 * float(oe[k]))
+        bar(f"{tag}: exempted columns, |HIP - exact f64| / max(fixed bar, 2 |oracle - exact f64|)", float(he[k]) / limit, 1.0, (k, he, oe, fixed))
+    return he, oe
+
+
+def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag="reassigned (random sequences)", time_bar=BAR_TIME, scale=1.0,
+                                 exact=None):
     """one column against the oracle with conditioning-derived bars; `ora_perturbed` = the oracle's column for the ulp-perturbed input;
     `scale` <= 1 = this column's maximum over the loudest column within reach of its 2W-sample Hilbert block (DESIGN §2 conditioning
-    note: the reference's own f32 noise scales with the loudest component of that block): the fixed bars are relative to that one"""
+    note: the reference's own f32 noise scales with the loudest component of that block): the fixed bars are relative to that one;
+    `exact` = the column in exact f64 arithmetic, or a callable returning it (evaluated only when the column needs an exemption)"""
     m = reassigned_column_metrics(hip, ora, sample_rate, hop)
     s = reassigned_column_metrics(ora_perturbed, ora, sample_rate, hop)
     scale = min(max(float(scale), 1e-12), 1.0)
-    conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER / scale, s["power"], (m, s, scale), plain=scale >= 0.999)
-    conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ / scale ** 0.5, s["freq"], (m, s, scale), plain=scale >= 0.999)
-    conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar / scale ** 0.5, s["time"], (m, s, scale), plain=scale >= 0.999)
-    conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN / scale, s["orphan"], (m, s, scale))
+    needed = []
+    if conditioned_bar(f"{tag}: |dP| / max P", m["power"], BAR_POWER / scale, s["power"], (m, s, scale), plain=scale >= 0.999, base=BAR_POWER):
+        needed.append("power")
+    if conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ / scale ** 0.5, s["freq"], (m, s, scale), plain=scale >= 0.999, base=BAR_FREQ):
+        needed.append("freq")
+    if conditioned_bar(f"{tag}: r |dt| hops", m["time"], time_bar / scale ** 0.5, s["time"], (m, s, scale), plain=scale >= 0.999, base=time_bar):
+        needed.append("time")
+    if conditioned_bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN / scale, s["orphan"], (m, s, scale), base=BAR_ORPHAN):
+        needed.append("orphan")
+    if exemption("orphan explained by the keep tests (1e-14 floor / band edge) above the plain orphan bar", m["orphan_explained"] > BAR_ORPHAN, m):
+        needed.append("orphan")
     assert m["orphans"] <= 4 + s["orphans"], (m, s)
+    if needed and exact is not None:
+        ex = exact() if callable(exact) else exact
+        if ex is not None:
+            arbitrate_reassigned(tag, hip, ora, ex, sample_rate, hop, sorted(set(needed)),
+                                 dict(power=BAR_POWER, freq=BAR_FREQ, time=time_bar, orphan=BAR_ORPHAN))
     return m, s
 
 
@@ -261,6 +326,7 @@ def check_reassigned_columns(got, want, sample_rate, hop, scale=1.0):
         bar(f"{tag}: r |df| / (fs/2)", m["freq"], BAR_FREQ * scale, m)
         bar(f"{tag}: r |dt| hops", m["time"], BAR_TIME * scale, m)
         bar(f"{tag}: orphan P / max P", m["orphan"], BAR_ORPHAN * scale, m)
+        exemption("orphan explained by the keep tests (1e-14 floor / band edge) above the plain orphan bar", m["orphan_explained"] > BAR_ORPHAN * scale, m)
         bar(f"{tag}: |df| / (fs/2), P >= 1e-4 max", m["freq_strong"], BAR_FREQ_STRONG * scale, m)
         bar(f"{tag}: |dt| hops, P >= 1e-4 max", m["time_strong"], BAR_TIME_STRONG * scale, m)
         assert m["orphans"] <= 4, m
@@ -371,8 +437,15 @@ def check_classic(got, want):
         # i.e. the rounding of the mean times the window's line — with the rectangular window bin 0 is exactly that and nothing else.  The
         # reference sums the mean sequentially in f32, the kernels as a tree: what is left there is rounding residue on both sides (soak seed
         # 12072005: rectangular 1024, oracle -104 dB under the column maximum, HIP below the -140 dB floor).  Allowance: 1e-9 of the maximum.
+        plain_budget = budget.copy()
         budget[:4] = np.maximum(budget[:4], 1e-9)
-        ratio = float((np.abs(p_h - p_o)[far] / budget[far]).max()) if far.any() else 0.0
+        dp = np.abs(p_h - p_o)
+        exemption("classic: 1e-9 allowance on the window's own lines (bins 0 ... 3)", bool((far[:4] & (dp[:4] > plain_budget[:4])).any()), m)
+        if far.any() and top != tops[i]:   # the budget taken from the column alone
+            own = classic_noise_budget(np.maximum(p_h, p_o) * 10.0 ** ((top - tops[i]) / 10.0), 2 * (len(o) - 1)) * 10.0 ** ((tops[i] - top) / 10.0)
+            own[:4] = np.maximum(own[:4], 1e-9)
+            exemption("classic: noise budget relative to the louder column of the transformed pair", bool((dp[far] > own[far]).any()), m)
+        ratio = float((dp[far] / budget[far]).max()) if far.any() else 0.0
         bar("classic (fused): |dP| / f32 transform noise budget, bins more than one code apart", ratio, 1.0, m)
 
 

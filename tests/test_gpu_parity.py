@@ -18,7 +18,7 @@ import openmeters_amd
 from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, SpectrogramConfig, SpectrogramProcessor, SpectrumConfig,
                                  SpectrumProcessor)
-from parity import bar, check_classic, check_reassigned_columns, classic_column_metrics, reassigned_column_metrics
+from parity import bar, exemption, check_classic, check_reassigned_columns, classic_column_metrics, reassigned_column_metrics
 from signals import exp_sweep, xorshift32_noise
 
 pytestmark = pytest.mark.gpu
@@ -166,6 +166,7 @@ def check_trace(x, y, floor=-100.0, flush_ties=0):
             clear[over] = False
             near = clear & (y > y.max() - 80.0)
         bar("spectrum (averaging modes): bins beyond the dB bars through a state-flush tie, per trace", ties, flush_ties)
+        exemption("spectrum: bins that leave the dB bars through a state-flush tie (averaging modes)", ties > 0, (ties, flush_ties))
     loud = clear & (y > y.max() - 60.0)
     if loud.any():
         bar("spectrum: |d dB| within 60 dB of max", d[loud].max(), 0.01)   # measured 2.1e-3 (profiles/parity_r*.txt)

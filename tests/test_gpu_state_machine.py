@@ -8,7 +8,7 @@ from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
                                  SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
                                  WaveformProcessor)
-from parity import (bar, check_chunked_rho, check_classic, check_reassigned_conditioned, classic_column_metrics, conditioned_bar,
+from parity import (arbitrate_reassigned, bar, check_chunked_rho, check_classic, check_reassigned_conditioned, classic_column_metrics, conditioned_bar,
                     reassigned_column_metrics, stereometer_band_rms, ulp_perturbed)
 from test_gpu_parity import check_trace
 
@@ -24,7 +24,22 @@ def signal(rng, frames, channels, t0, rate, silent):
     return out.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.exemptions_allowed
+def test_spectrogram_sequence_with_a_quiet_column_beside_a_loud_passage_is_arbitrated_by_exact_f64(omx, oracle):
+    """The mechanism behind the `fixed bar relative to a louder column within reach` rule, pinned (parity governance: no rule without a
+    reproducer).  Sequence 4 contains columns whose own window sits on near-silence right after a loud passage: the analytic signal is
+    computed over the 2W-sample block around the window, so both implementations carry rounding noise at the LOUD passage's level —
+    |dP| = 3.3e-5 of such a column's own maximum.  The ten columns that need the rule are judged against exact f64 arithmetic computed
+    from the very samples the oracle used (oracle hook omxo_debug_spectrogram_captured): |HIP - exact| <= max(fixed bar, 2 |oracle -
+    exact|); measured 0.46 of that."""
+    import parity
+    name = "spectrogram sequences: exempted columns, |HIP - exact f64| / max(fixed bar, 2 |oracle - exact f64|)"
+    before = parity.LEDGER.get(name, [0, 0, 0])[2]
+    test_spectrogram_random_operation_sequences(omx, oracle, 4)
+    assert parity.LEDGER.get(name, [0, 0, 0])[2] > before, "the sequence no longer exercises the rule: pick the reproducer again"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 6, 7])
 def test_spectrogram_random_operation_sequences(omx, oracle, seed):
     rng = np.random.default_rng(seed)
     sizes = [256, 512, 1024, 2048, 4096]
@@ -35,6 +50,7 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
     # the measured conditioning of each column (parity.conditioned_bar): bars are max(fixed bar, 16 x that), so a column whose own
     # f32 evaluation is unstable passes by a rule, and the seeds need not avoid it
     c = SpectrogramProcessor(oracle, cfg)
+    b.debug_capture(True)   # the samples behind every oracle column: a column that needs an exemption is arbitrated against exact f64
     prng = np.random.default_rng(seed + 7919)
     rate, channels, t0, produced = 48000.0, 2, 0, 0
     recent = []   # column maxima of the last few columns (earlier updates included)
@@ -107,9 +123,21 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
                 sn = reassigned_column_metrics(o2 if len(o2) else o, o, rate, w.hop_size)
                 scale = min(1.0, col_max / max(max(recent), max(maxima[i:i + reach + 1])))   # <= 1: this column against its block's loudest
                 tag = "spectrogram sequences"
-                conditioned_bar(f"{tag}: |dP| / max P", m["power"], 1e-5 / scale, sn["power"], (seed, step, m, sn, scale))
-                conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], 3e-7 / scale ** 0.5, sn["freq"], (seed, step, m, sn, scale))
-                conditioned_bar(f"{tag}: r |dt| hops", m["time"], t_bar / scale ** 0.5, sn["time"], (seed, step, m, sn, scale))
+                needed = []
+                if conditioned_bar(f"{tag}: |dP| / max P", m["power"], 1e-5 / scale, sn["power"], (seed, step, m, sn, scale), base=1e-5):
+                    needed.append("power")
+                if conditioned_bar(f"{tag}: r |df| / (fs/2)", m["freq"], 3e-7 / scale ** 0.5, sn["freq"], (seed, step, m, sn, scale), base=3e-7):
+                    needed.append("freq")
+                if conditioned_bar(f"{tag}: r |dt| hops", m["time"], t_bar / scale ** 0.5, sn["time"], (seed, step, m, sn, scale), base=t_bar):
+                    needed.append("time")
+                if needed:   # no rule without a referee: the same column in exact f64 arithmetic, from the samples the oracle used
+                    eff = b.config()
+                    block = b.debug_captured(i)
+                    if len(block) >= 2 * eff.fft_size:
+                        import exact_f64
+                        ex, _ = exact_f64.reassigned_column(block, window_kind=eff.window, window_size=eff.fft_size,
+                                                            zero_padding=eff.zero_padding_factor, hop=w.hop_size, sample_rate=rate)
+                        arbitrate_reassigned(tag, h, o, ex.astype(np.float32), rate, w.hop_size, needed, dict(power=1e-5, freq=3e-7, time=t_bar))
                 # a bin present on one side only must sit on the 1e-14 keep-floor (relative to a weak column that is > 1e-8)
                 # ... or on the 0 < f < fs/2 edge of the keep test (a bin whose reassigned frequency sits at 0 or Nyquist)
                 # ... or be no stronger than what the oracle itself gains / loses under the one-ulp perturbation
@@ -327,6 +355,8 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
     cfg = SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=reassign, history_length=5 if seed % 2 else 8192)
     bank = banks.SpectrogramBank(omx, cfg, S)
     refs = [SpectrogramProcessor(oracle, cfg) for _ in range(S)]
+    for r in refs:
+        r.debug_capture(True)   # (arbitration of exempted columns against exact f64: parity.check_reassigned_conditioned(exact=...))
     feeds = [_stream_signal(rng, 60000) for _ in range(S)]
     # conditioning leg (parity.conditioned_bar): per-stream oracles on the same feeds moved by one f32 ulp per sample
     prng = np.random.default_rng(seed + 7919)
@@ -382,7 +412,15 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
                         del recent[s][:-reach]
                     if len(o) and maxima[i] > 1e-8:   # (round 3: every bar x 30 flat; now each column's measured conditioning + its block's loudest)
                         scale = maxima[i] / max(max(recent[s]), max(maxima[i:i + reach + 1]))
-                        check_reassigned_conditioned(h, o, o2 if len(o2) else o, 48000.0, hop, tag="ragged bank sequences", scale=scale)
+                        def exact_column(s=s, i=i):
+                            import exact_f64
+                            block = refs[s].debug_captured(i)
+                            if len(block) < 2 * W:
+                                return None
+                            return exact_f64.reassigned_column(block, window_kind=cfg.window, window_size=W, zero_padding=1, hop=hop,
+                                                               sample_rate=48000.0)[0].astype(np.float32)
+                        check_reassigned_conditioned(h, o, o2 if len(o2) else o, 48000.0, hop, tag="ragged bank sequences", scale=scale,
+                                                     exact=exact_column)
             elif up.fft_size in (1024, 2048, 4096, 8192, 16384):
                 check_classic(got, w.new_columns)
             produced += want_cols

@@ -6,6 +6,11 @@ bash tools/profile_bench.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 cp gpurun_out/$TAG/traffic.json profiles/${TAG}_traffic.json
 bash tools/profile_meters_pmc.sh ${TAG}_meters > gpurun_out/${TAG}_meters_pmc.txt 2>&1
 cp gpurun_out/${TAG}_meters/meters_traffic.json profiles/${TAG}_meters_traffic.json
+# ... and under their final names in gpurun_out/, the only directory that travels back from the box: tools/collect_round.sh copies
+# gpurun_out/${TAG}_* into profiles/ and REFUSES when one of the two records is missing or carries another commit than the bench lines
+# (the records bench.py echoes into roofline.traffic were the ones left behind, twice)
+cp gpurun_out/$TAG/traffic.json gpurun_out/${TAG}_traffic.json
+cp gpurun_out/${TAG}_meters/meters_traffic.json gpurun_out/${TAG}_meters_traffic.json
 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.log
 python bench.py --config cfg5 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench_line_cfg5.json 2> gpurun_out/${TAG}_bench_line_cfg5.log
 {
