@@ -147,11 +147,92 @@ struct Direct {
     }
 };
 
+
+// ---- true peak of STEP samples (TruePeakMeter::process, :123-151).  ext[STEP - 1 - k] = x[k] on entry; hist[i] = the i-th newest sample
+// before them (updated on return).  The interpolator is 36 (4x) / 24 (2x) multiply-THEN-add pairs per sample — the reference does not
+// fuse them (`output[phase] += sample * coefficients[phase]`, :139-143), so neither does this — i.e. 72 / 48 VALU instructions per sample
+// when issued one float at a time (round 4: 79 measured).  Two samples half a tile apart are independent sums over the same taps: as
+// lanes .x / .y of v_pk_mul_f32 / v_pk_add_f32 each keeps its own products and its own accumulation order (bit-identical peaks) at
+// half the instruction count.  The leading `0.0 + p` of every sum is dropped: it can only turn -0.0 into +0.0, and only |o| is used.
+template <int DL>
+struct TruePeak {
+    static constexpr int H = DL > 1 ? DL - 1 : 1;
+    // the DL - 1 samples before block c: from the carried delay line (first block) or from the PCM of the call
+    static __device__ __forceinline__ void load_history(float (&hist)[H], const LoudChunkArgs& a, uint32_t chan, uint32_t s, uint32_t ch, uint32_t c,
+                                                        bool reset, bool live) {
+#pragma unroll
+        for (int i = 0; i < H; ++i) hist[i] = 0.0f;
+        if (DL > 1 && live) {
+            if (c == 0) {
+#pragma unroll
+                for (int i = 0; i < H; ++i) hist[i] = reset ? 0.0f : a.state[chan].delay[i];
+            } else {
+                const uint32_t C = a.channels;
+                const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)c * a.block_frames) * C + ch;
+#pragma unroll
+                for (int i = 0; i < H; ++i) hist[i] = *(p - (int64_t)(i + 1) * C);  // L >= 64 > DL: inside the call
+            }
+        }
+    }
+    // (A/B of where the taps live, round 5: as kernel arguments they are scalars and a packed operand needs the splat {t, t} in an SGPR
+    // pair — 72 SGPRs for the 4x interpolator, which beside pass B's K-weighting coefficients overflows the scalar file: 208
+    // v_readlane_b32 per 16 samples fetch spilled SGPRs back, 158 VGPRs.  The alternatives measured worse: all 36 taps as VGPR pairs
+    // read through op_sel 226 VGPRs; one phase's 12 taps at a time over eight position chains 183 VGPRs and dependent-issue stalls.)
+    static __device__ __forceinline__ void step(float (&ext)[STEP + H], float (&hist)[H], float& peak, const LoudChunkArgs& a) {
+#pragma unroll
+        for (int i = 0; i < H; ++i) ext[STEP + i] = hist[i];
+        constexpr int HALF = STEP / 2;
+        v2f pair[HALF + H];  // pair[j] = {ext[j], ext[j + HALF]}: window position j of the newer and of the older half
+#pragma unroll
+        for (int j = 0; j < HALF + H; ++j) pair[j] = v2f{ext[j], ext[j + HALF]};
+        // (three phases of one window position = three independent chains, written side by side: a dependent v_pk_*_f32 waits
+        // 8 cycles, an independent one issues after 4 — tools/microbench/issue_rate.hip — and the scheduler keeps source order)
+#pragma unroll
+        for (int m = 0; m < HALF; ++m) {
+            peak = fmaxf(fmaxf(peak, fabsf(ext[m])), fabsf(ext[m + HALF]));  // (max(max(a, |b|), |c|): one v_max3_f32)
+            if constexpr (DL == 12) {
+                v2f o0 = pair[m] * v2f{a.fir4[0][0], a.fir4[0][0]};
+                v2f o1 = pair[m] * v2f{a.fir4[0][1], a.fir4[0][1]};
+                v2f o2 = pair[m] * v2f{a.fir4[0][2], a.fir4[0][2]};
+#pragma unroll
+                for (int i = 1; i < 12; ++i) {
+                    const v2f p0 = pair[m + i] * v2f{a.fir4[i][0], a.fir4[i][0]};
+                    const v2f p1 = pair[m + i] * v2f{a.fir4[i][1], a.fir4[i][1]};
+                    const v2f p2 = pair[m + i] * v2f{a.fir4[i][2], a.fir4[i][2]};
+                    o0 = o0 + p0;
+                    o1 = o1 + p1;
+                    o2 = o2 + p2;
+                }
+                peak = fmaxf(fmaxf(peak, fabsf(o0.x)), fabsf(o0.y));
+                peak = fmaxf(fmaxf(peak, fabsf(o1.x)), fabsf(o1.y));
+                peak = fmaxf(fmaxf(peak, fabsf(o2.x)), fabsf(o2.y));
+            } else if constexpr (DL == 24) {
+                v2f o = pair[m] * v2f{a.fir2[0], a.fir2[0]};
+#pragma unroll
+                for (int i = 1; i < 24; ++i) o = o + pair[m + i] * v2f{a.fir2[i], a.fir2[i]};
+                peak = fmaxf(fmaxf(peak, fabsf(o.x)), fabsf(o.y));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < H; ++i) hist[i] = ext[i];
+    }
+    static __device__ __forceinline__ void store(const LoudChunkArgs& a, uint32_t s, uint32_t ch, uint32_t c, float peak) {
+        omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + c;
+        snap->true_peak_db[ch] = power_to_db(peak * peak, a.floor_db);
+        if (ch == 0)
+            for (uint32_t i = a.channels; i < OMX_MAX_CHANNELS; ++i) snap->true_peak_db[i] = a.floor_db;  // with_floor (:197-207)
+    }
+};
+
 }  // namespace
 
 // ---- K-weighting: PASS 0 = zero-state end state of the block; PASS 1 = from the true start state: samples -> ring,
 // sub-block sums.  grid (slot groups, blocks), 64 threads: lane = slot of the group.
-template <int PASS, bool TILED, bool TAILS, bool RAGGED>
+// PK >= 0 (PASS 1 only): the block's true peak is computed here as well, on the tile this pass has in registers, with delay length PK (0,
+// 12 or 24).  Pass B is bound by its memory traffic (1.18 GB per cfg3 call at 5.3 TB/s, VALU 40 % busy) and the interpolator is pure
+// VALU work on data already in registers: inside this kernel the two overlap, where in pass A the interpolator was a VALU-bound kernel
+// of its own (0.23 ms) in front of a memory-bound one (0.23 ms).
+template <int PASS, bool TILED, bool TAILS, bool RAGGED, int PK = -1>
 __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) {
     __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     if (PASS == 1 && *a.bad != 0u) return;
@@ -178,7 +259,13 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
         f2 = cf[2];
         f3 = cf[3];
     }
-    const double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
+    double b0 = a.b[0], b1 = a.b[1], b2 = a.b[2], b3 = a.b[3], b4 = a.b[4], a1 = a.a[1], a2 = a.a[2], a3 = a.a[3], a4 = a.a[4];
+#ifndef LOUD_COEF_VGPR
+#define LOUD_COEF_VGPR 0
+#endif
+    if constexpr (PK > 0 && LOUD_COEF_VGPR) {  // beside the interpolator's 72 tap SGPRs the nine coefficients go to vector registers (18 fewer scalars to spill)
+        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
+    }
     RingT* ring_col = a.ring + (uint64_t)group * a.ring_len * kRow + lane;
     const uint32_t ring_len = (uint32_t)a.ring_len;  // (window_length of a 3 s window: < 2^32 at any rate)
     uint32_t pos = (uint32_t)((sc.seen + (uint64_t)c * L) % a.ring_len);  // ring slot of the block's first sample
@@ -198,6 +285,10 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
     const uint64_t g_first = sc.seen / SUB + (uint64_t)c * (L / SUB);
     double* tails = TAILS && live ? a.tails + (uint64_t)chan * kLoudnessWindows * a.q_len : nullptr;
     uint32_t bad = 0;
+    using TP = TruePeak<(PK > 0 ? PK : 0)>;
+    float hist[TP::H];
+    float peak = 0.0f;
+    if constexpr (PK >= 0) TP::load_history(hist, a, chan, chan >> a.slot_shift, chan & ((1u << a.slot_shift) - 1u), c, sc.reset, live);
     if constexpr (TILED) t.issue(0, C);
     else dl.issue(0, C);
     for (uint32_t step = 0; step < steps; ++step) {
@@ -212,6 +303,13 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
         } else {
             bad |= dl.take(x);
             if (step + 1u < steps) dl.issue(step + 1u, C);
+        }
+        if constexpr (PK >= 0) {
+            float ext[STEP + TP::H];
+#pragma unroll
+            for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = x[k];
+            TP::step(ext, hist, peak, a);
+            __builtin_amdgcn_sched_barrier(0);  // the interpolator's 70 registers are dead from here: keep the recurrence below out of its live range
         }
         RingT out[STEP];
 #pragma unroll
@@ -281,15 +379,10 @@ __global__ __launch_bounds__(64) void loud_chunk_filter_kernel(LoudChunkArgs a) 
             cf[3] = f3;
         }
     } else {
-        // the true-peak delay line the next call starts from (TruePeakMeter::delay, :123-133): the newest delay_len - 1 samples of the
-        // stream's last block, newest first, straight from the PCM (L >= 64 > delay_len); `peak` is taken at every snapshot (:301).
-        // Written here because this pass runs only when pass A left the non-finite flag clear.
-        if (live && c + 1u == sc.blocks) {
-            LoudnessChannelState& st = a.state[chan];
-            const uint32_t s = chan >> a.slot_shift, ch = chan & ((1u << a.slot_shift) - 1u);
-            const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)(c + 1u) * L) * C + ch;
-            for (uint32_t i = 0; i + 1u < a.delay_len; ++i) st.delay[i] = *(p - (int64_t)(i + 1u) * C);
-            st.peak = 0.0f;
+        // (the true-peak delay line the next call starts from is written by the snapshot kernel, the last of the call: block 0 of THIS
+        // pass still reads the carried one)
+        if constexpr (PK >= 0) {
+            if (live) TP::store(a, chan >> a.slot_shift, chan & ((1u << a.slot_shift) - 1u), c, peak);
         }
     }
 }
@@ -385,7 +478,7 @@ __global__ __launch_bounds__(256) void loud_scan_filter_kernel(LoudChunkArgs a, 
 //     interpolator has in registers anyway;
 //   the non-finite flag (a call with a NaN / Inf sample is redone by the sequential kernels).
 // The carried delay line is written by pass B (which runs only when the flag stayed clear).
-template <int DL, bool TILED, bool RAGGED>
+template <int DL, bool TILED, bool RAGGED, bool PEAK>
 __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     __shared__ float tile[TILED ? 2 : 1][TILED ? 64 * 17 : 1];
     const uint32_t lane = threadIdx.x, group = blockIdx.x, c = blockIdx.y;
@@ -404,20 +497,10 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     if constexpr (TILED) t.template setup<RAGGED>(a, group, c, lane);
     else dl.setup(a, chan, live, (uint64_t)c * L);
     const uint32_t rd = (lane / C) * 17u * C + (lane % C);
-    constexpr int H = DL > 1 ? DL - 1 : 1;
+    using TP = TruePeak<DL>;
+    constexpr int H = TP::H;
     float hist[H];  // hist[0] = newest sample before the block
-#pragma unroll
-    for (int i = 0; i < H; ++i) hist[i] = 0.0f;
-    if (DL > 1 && live) {
-        if (c == 0) {
-#pragma unroll
-            for (int i = 0; i < H; ++i) hist[i] = sc.reset ? 0.0f : a.state[chan].delay[i];
-        } else {
-            const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)c * L) * C + ch;
-#pragma unroll
-            for (int i = 0; i < H; ++i) hist[i] = *(p - (int64_t)(i + 1) * C);  // L >= 64 > DL: inside the call
-        }
-    }
+    if constexpr (PEAK) TP::load_history(hist, a, chan, s, ch, c, sc.reset, live);
     float peak = 0.0f;
     double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;  // zero-state end state of the block
     uint32_t bad = 0;
@@ -432,7 +515,7 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
             const float* row = tile[step & 1u] + rd;
 #pragma unroll
             for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = row[k * C];  // (no select: Tile::stage zeroes the rows of dead streams, and a
-                                                                             //  dead lane's peak is never written)
+                                                                             //  dead lane's results are never written)
         } else {
             float x[STEP];
             bad |= dl.take(x);
@@ -440,8 +523,6 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
 #pragma unroll
             for (int k = 0; k < STEP; ++k) ext[STEP - 1 - k] = x[k];
         }
-#pragma unroll
-        for (int i = 0; i < H; ++i) ext[STEP + i] = hist[i];
         {   // zero-state end state: z += W[k] x[k] (wave-uniform weights: scalar loads)
             const double* w = a.zs_weights + (uint64_t)step * (STEP * 4);
 #pragma unroll
@@ -453,53 +534,11 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
                 z3 = fma(w[k * 4 + 3], xd, z3);
             }
         }
-        // The interpolator is 36 (4x) / 24 (2x) multiply-THEN-add pairs per sample — the reference does not fuse them
-        // (`output[phase] += sample * coefficients[phase]`, :139-143), so neither does this — i.e. 72 / 48 VALU instructions per sample
-        // when issued one float at a time (round 4: 79 measured).  Two samples half a tile apart are independent sums over the same
-        // taps: as lanes .x / .y of v_pk_mul_f32 / v_pk_add_f32 each keeps its own products and its own accumulation order (bit-
-        // identical peaks) at half the instruction count.  The leading `0.0 + p` of every sum is dropped: it can only turn -0.0 into
-        // +0.0, and only |o| is used.
-        constexpr int HALF = STEP / 2;
-        v2f pair[HALF + H];  // pair[j] = {ext[j], ext[j + HALF]}: window position j of the newer and of the older half
-#pragma unroll
-        for (int j = 0; j < HALF + H; ++j) pair[j] = v2f{ext[j], ext[j + HALF]};
-        // (three phases of one window position = three independent chains, written side by side: a dependent v_pk_*_f32 waits
-        // 8 cycles, an independent one issues after 4 — tools/microbench/issue_rate.hip — and the scheduler keeps source order)
-#pragma unroll
-        for (int m = 0; m < HALF; ++m) {
-            peak = fmaxf(fmaxf(peak, fabsf(ext[m])), fabsf(ext[m + HALF]));  // (max(max(a, |b|), |c|): one v_max3_f32)
-            if constexpr (DL == 12) {
-                v2f o0 = pair[m] * v2f{a.fir4[0][0], a.fir4[0][0]};
-                v2f o1 = pair[m] * v2f{a.fir4[0][1], a.fir4[0][1]};
-                v2f o2 = pair[m] * v2f{a.fir4[0][2], a.fir4[0][2]};
-#pragma unroll
-                for (int i = 1; i < 12; ++i) {
-                    const v2f p0 = pair[m + i] * v2f{a.fir4[i][0], a.fir4[i][0]};
-                    const v2f p1 = pair[m + i] * v2f{a.fir4[i][1], a.fir4[i][1]};
-                    const v2f p2 = pair[m + i] * v2f{a.fir4[i][2], a.fir4[i][2]};
-                    o0 = o0 + p0;
-                    o1 = o1 + p1;
-                    o2 = o2 + p2;
-                }
-                peak = fmaxf(fmaxf(peak, fabsf(o0.x)), fabsf(o0.y));
-                peak = fmaxf(fmaxf(peak, fabsf(o1.x)), fabsf(o1.y));
-                peak = fmaxf(fmaxf(peak, fabsf(o2.x)), fabsf(o2.y));
-            } else if constexpr (DL == 24) {
-                v2f o = pair[m] * v2f{a.fir2[0], a.fir2[0]};
-#pragma unroll
-                for (int i = 1; i < 24; ++i) o = o + pair[m + i] * v2f{a.fir2[i], a.fir2[i]};
-                peak = fmaxf(fmaxf(peak, fabsf(o.x)), fabsf(o.y));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < H; ++i) hist[i] = ext[i];
+        if constexpr (PEAK) TP::step(ext, hist, peak, a);
     }
     if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
     if (!live) return;
-    omx_loudness_snapshot* snap = a.snapshots + (uint64_t)s * a.n_blocks + c;
-    snap->true_peak_db[ch] = power_to_db(peak * peak, a.floor_db);
-    if (ch == 0)
-        for (uint32_t i = C; i < OMX_MAX_CHANNELS; ++i) snap->true_peak_db[i] = a.floor_db;  // with_floor (:197-207)
+    if constexpr (PEAK) TP::store(a, s, ch, c, peak);
     double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + c) * 4u;
     cf[0] = z0;
     cf[1] = z1;
@@ -677,6 +716,15 @@ __global__ __launch_bounds__(512) void loud_chunk_snapshot_kernel(LoudChunkArgs 
                 st.corrections[w][1] = 0.0;
             }
         }
+        if (last) {
+            // the true-peak delay line the next call starts from (TruePeakMeter::delay, :123-133): the newest delay_len - 1 samples of the
+            // stream's last block, newest first, straight from the PCM (block_frames >= 64 > delay_len); `peak` is taken at every
+            // snapshot (:301).  Written here, in the call's last kernel: the first block of pass A / B reads the carried line.
+            LoudnessChannelState& st = a.state[chan];
+            const float* p = a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)(c + 1u) * a.block_frames) * C + ch;
+            for (uint32_t i = 0; i + 1u < a.delay_len; ++i) st.delay[i] = *(p - (int64_t)(i + 1u) * C);
+            st.peak = 0.0f;
+        }
         part[ch][lane][0] = mean[0];
         part[ch][lane][1] = mean[1];
         snap->rms_fast_db[ch] = power_to_db((float)mean[2], a.floor_db);
@@ -728,27 +776,36 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
             else kernel_of(F{}, F{});
         }
     };
-    auto filter = [&](auto pass) {
-        constexpr int PASS = decltype(pass)::value;
-        with_shape([&](auto tiled_c, auto ragged_c) {
-            constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
-            if (PASS == 1 && a.tails) hipLaunchKernelGGL((loud_chunk_filter_kernel<1, TI, true, RG>), grid, dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL((loud_chunk_filter_kernel<PASS, TI, false, RG>), grid, dim3(64), 0, stream, a);
-        });
-    };
-    auto peak = [&](auto dl) {
+    // LOUD_PEAK_IN_B (default 1): the true peak rides pass B (see loud_chunk_filter_kernel); 0 = in pass A (the form until round 5, A/B builds)
+#ifndef LOUD_PEAK_IN_B
+#define LOUD_PEAK_IN_B 1
+#endif
+    constexpr bool kPeakInB = LOUD_PEAK_IN_B != 0;
+    auto pass_a = [&](auto dl) {
         constexpr int DL = decltype(dl)::value;
         with_shape([&](auto tiled_c, auto ragged_c) {
             constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
-            hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, TI, RG>), grid, dim3(64), 0, stream, a);
+            if constexpr (kPeakInB) hipLaunchKernelGGL((loud_chunk_peak_kernel<0, TI, RG, false>), grid, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, TI, RG, true>), grid, dim3(64), 0, stream, a);
         });
     };
-    if (a.delay_len == 12) peak(std::integral_constant<int, 12>{});
-    else if (a.delay_len == 24) peak(std::integral_constant<int, 24>{});
-    else peak(std::integral_constant<int, 0>{});
+    auto pass_b = [&](auto dl) {
+        constexpr int PK = kPeakInB ? decltype(dl)::value : -1;
+        with_shape([&](auto tiled_c, auto ragged_c) {
+            constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
+            if (a.tails) hipLaunchKernelGGL((loud_chunk_filter_kernel<1, TI, true, RG, PK>), grid, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((loud_chunk_filter_kernel<1, TI, false, RG, PK>), grid, dim3(64), 0, stream, a);
+        });
+    };
+    auto by_delay = [&](auto&& f) {
+        if (a.delay_len == 12) f(std::integral_constant<int, 12>{});
+        else if (a.delay_len == 24) f(std::integral_constant<int, 24>{});
+        else f(std::integral_constant<int, 0>{});
+    };
+    by_delay(pass_a);
     if (a.scan_dd) hipLaunchKernelGGL(loud_scan_filter_kernel<true>, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
     else hipLaunchKernelGGL(loud_scan_filter_kernel<false>, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a, d_T);
-    filter(std::integral_constant<int, 1>{});
+    by_delay(pass_b);
     hipLaunchKernelGGL(loud_scan_q_kernel, dim3((slots + 3u) / 4u), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(loud_chunk_snapshot_kernel, dim3(a.n_streams, (a.n_blocks + 63u) / 64u), dim3(64u << a.slot_shift), 0, stream, a);
     if (a.blocks_v) hipLaunchKernelGGL(loud_chunk_advance_kernel, dim3((a.n_streams + 255u) / 256u), dim3(256), 0, stream, a);
