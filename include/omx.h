@@ -980,7 +980,7 @@ typedef struct omx_capture_group_update {
 /* what omx_capture_group_ingest_ragged leaves behind: every enabled bank's own ragged update (per-stream counts in device memory) */
 typedef struct omx_capture_group_ragged_update {
     uint32_t produced;               /* OMX_VISUAL_* bits: which visuals produced an update for at least one capture */
-    uint32_t _pad;
+    uint32_t ingest_launches;        /* projection launches this call made: 1 when Spectrogram and Spectrum shared one */
     uint64_t block_frames;           /* how the block-based visuals saw the call: 0 = capture s ran ONE block of frames[s] frames
                                         (max_blocks = 1); B = cfg.block_frames: capture s ran frames[s] / B blocks ... */
     uint64_t max_blocks;             /* ... of at most frames_capacity / B */

@@ -390,12 +390,43 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     };
     bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
-        if (spectrogram)
-            note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, &up.spectrogram),
-                 OMX_VISUAL_SPECTROGRAM);
-        if (spectrum)
-            note(spectrum->process_ragged(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions, stream, &up.spectrum),
-                 OMX_VISUAL_SPECTRUM);
+        // ---- the caller's stream: the banks that keep pending audio.  Both plan their per-capture pushes on the device (skip / count /
+        //      head per stream); ONE projection launch then feeds the rings of both (registry.rs:407-417: one AudioBlock, every visual)
+        if (spectrogram && spectrum && shared_ingest_) {
+            IngestArgs parts[2];
+            const int rc_sg = spectrogram->ragged_plan(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, parts[0]);
+            const int rc_sp = rc_sg < 0 ? OMX_NONE : spectrum->ragged_plan(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions,
+                                                                           stream, parts[1]);
+            if (rc_sg < 0) note(rc_sg, 0);
+            if (rc_sp < 0) note(rc_sp, 0);
+            if (rc_sg >= 0 && rc_sp >= 0) {
+                const int n_parts = rc_sp == OMX_PRODUCED ? 2 : 1;  // (a Spectrum bank without an active trace takes no samples)
+                if (launch_ingest_ragged_parts(parts, n_parts, S, stream)) {
+                    up.ingest_launches += 1;
+                } else {  // other channel counts: the banks' own launches
+                    launch_ingest(parts[0], S, stream);
+                    up.ingest_launches += 1;
+                    if (n_parts == 2) {
+                        launch_ingest(parts[1], S, stream);
+                        up.ingest_launches += 1;
+                    }
+                }
+                OMX_HIP(hipGetLastError());
+                note(spectrogram->ragged_finish(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
+                if (rc_sp == OMX_PRODUCED) note(spectrum->ragged_finish(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
+            }
+        } else {
+            if (spectrogram) {
+                note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, &up.spectrogram),
+                     OMX_VISUAL_SPECTROGRAM);
+                up.ingest_launches += 1;
+            }
+            if (spectrum) {
+                note(spectrum->process_ragged(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions, stream, &up.spectrum),
+                     OMX_VISUAL_SPECTRUM);
+                up.ingest_launches += 1;
+            }
+        }
         if (loudness) {
             used[0] = true;
             OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));

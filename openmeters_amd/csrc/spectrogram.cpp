@@ -532,6 +532,19 @@ void SpectrogramBank::enter_ragged(hipStream_t stream) {
 int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
                                     uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                     omx_spectrogram_ragged_update* out) {
+    IngestArgs ia{};
+    const int rc = ragged_plan(d_pcm, frames_capacity, frames, reset_mask, channels_in, sample_rate_in, positions, stream, ia);
+    if (rc < 0) return rc;
+    launch_ingest(ia, n_streams_, stream);
+    OMX_HIP(hipGetLastError());
+    return ragged_finish(stream, out);
+}
+
+// process_ragged in two halves, so that a capture group can feed this bank's ring and the Spectrum bank's from ONE projection launch
+// (launch_ingest_ragged_parts): everything up to the plan kernel, which leaves the per-stream ingest parameters in `ia` ...
+int SpectrogramBank::ragged_plan(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                                 uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                                 IngestArgs& ia_out) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
     if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
@@ -615,8 +628,7 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
     ia.last_nonzero = last_nonzero_.ptr;
     partial_nonzero_.reserve((size_t)n_streams_ * ingest_partials_per_stream(frames_capacity));
     ia.partial_nonzero = partial_nonzero_.ptr;
-    launch_ingest(ia, n_streams_, stream);
-    OMX_HIP(hipGetLastError());
+    ia_out = ia;
     head_ = tail_ = 0;  // from here on only the bounds above use them (pending_bound = read_len - 1)
     {   // a stream that sat this call out still holds what update_config / the lock-step calls left it
         bool all_fed = true;
@@ -624,7 +636,16 @@ int SpectrogramBank::process_ragged(const float* d_pcm, uint64_t frames_capacity
         if (all_fed) ragged_pending_bound_ = 0;
         else ragged_pending_bound_ = pending_bound;
     }
+    pend_max_cols_ = max_cols;
+    return OMX_PRODUCED;
+}
 
+// ... and, once the samples are in the ring, the column kernels and the update
+int SpectrogramBank::ragged_finish(hipStream_t stream, omx_spectrogram_ragged_update* out) {
+    const uint64_t max_cols = pend_max_cols_, hop = cfg_.hop_size;
+    const bool reassign = cfg_.use_reassignment != 0;
+    const uint64_t bin_count = fft_size_ / 2 + 1;
+    const uint32_t kind = reassign ? OMX_COLUMN_REASSIGNED : OMX_COLUMN_CLASSIC;
     if (max_cols > 0) {
         launch_columns(max_cols, 0, r_col_tail_.ptr, r_ncols_.ptr, stream);
         OMX_HIP(hipGetLastError());

@@ -28,6 +28,10 @@ public:
     // (spectrogram_plan_kernel); the bank stays in ragged mode until reset_audio() of the whole bank.
     int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
                        float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrogram_ragged_update* out);
+    // the two halves of process_ragged (a capture group shares one projection launch between this bank and the Spectrum bank)
+    int ragged_plan(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                    float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, IngestArgs& ia_out);
+    int ragged_finish(hipStream_t stream, omx_spectrogram_ragged_update* out);
     int fetch_column(uint64_t stream_index, uint64_t column, void* dst, uint64_t cap, uint64_t* n_out, hipStream_t stream);
     EventTimer& timer() { return timer_; }
     void force_generic(bool on) { force_generic_ = on; }
@@ -66,6 +70,7 @@ private:
     OutBuffer<uint16_t> d_codes_;
     size_t host_output_limit_ = 0;
     // ragged mode: per-stream positions on the device
+    uint64_t pend_max_cols_ = 0;  // between ragged_plan and ragged_finish
     bool ragged_ = false;
     uint64_t ragged_pending_bound_ = 0;  // ragged mode: the most pending samples a stream can hold beyond read_len - 1 (after update_config)
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_col_tail_;

@@ -384,6 +384,18 @@ void SpectrumBank::enter_ragged(hipStream_t stream) {
 int SpectrumBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
                                  uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                  omx_spectrum_ragged_update* out) {
+    IngestArgs ia{};
+    const int rc = ragged_plan(d_pcm, frames_capacity, frames, reset_mask, channels_in, sample_rate_in, positions, stream, ia);
+    if (rc != OMX_PRODUCED) return rc;  // an error, or no active trace
+    launch_ingest(ia, n_streams_, stream);
+    OMX_HIP(hipGetLastError());
+    return ragged_finish(stream, out);
+}
+
+// process_ragged in two halves (see SpectrogramBank::ragged_plan): up to the plan kernel, `ia_out` = what the projection launch needs ...
+int SpectrumBank::ragged_plan(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,
+                              uint32_t channels_in, float sample_rate_in, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
+                              IngestArgs& ia_out) {
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     last_stream_ = stream;
     if (frames_capacity == 0 || frames_capacity > 0xFFFFFFFFull) {
@@ -481,11 +493,20 @@ int SpectrumBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, c
     ia.cap = ring_cap_;
     ia.last_nonzero = nullptr;
     ia.partial_nonzero = nullptr;
-    launch_ingest(ia, n_streams_, stream);
-    OMX_HIP(hipGetLastError());
+    ia_out = ia;
     head_ = tail_ = 0;  // from here on only the bound above uses them (pending_bound = N - 1)
     pending_skip_ = 0;
+    pend_max_hops_ = max_hops;
+    pend_hops_out_ = hops_out;
+    return OMX_PRODUCED;
+}
 
+// ... and the hop kernels + the update once the samples are in the rings
+int SpectrumBank::ragged_finish(hipStream_t stream, omx_spectrum_ragged_update* out) {
+    bool active[2];
+    active_traces(active);
+    const uint32_t n_traces = (active[0] ? 1 : 0) + (active[1] ? 1 : 0);
+    const uint64_t max_hops = pend_max_hops_, hops_out = pend_hops_out_, bins = cfg_.fft_size / 2 + 1;
     int rc = OMX_NONE;
     if (max_hops > 0) rc = launch_hops(0, r_hop_tail_.ptr, r_nhops_.ptr, max_hops, 0, n_traces, active, stream);
     if (out) {

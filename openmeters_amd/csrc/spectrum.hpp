@@ -24,6 +24,11 @@ public:
     // per-stream frame counts / reset (include/omx.h: omx_spectrum_bank_process_ragged); pcm in device memory
     int process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
                        float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, omx_spectrum_ragged_update* out);
+    // the two halves of process_ragged (a capture group shares one projection launch between the Spectrogram bank and this one);
+    // ragged_plan returns OMX_NONE when no trace is active (nothing to ingest, nothing to finish)
+    int ragged_plan(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels,
+                    float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream, IngestArgs& ia_out);
+    int ragged_finish(hipStream_t stream, omx_spectrum_ragged_update* out);
     int fetch(uint64_t stream_index, uint64_t hop, float* dst, hipStream_t stream);
     const std::vector<float>& frequency_bins() const { return freq_bins_; }
     uint64_t bins() const { return cfg_.fft_size / 2 + 1; }
@@ -60,6 +65,7 @@ private:
     EventTimer timer_;
     hipStream_t last_stream_ = nullptr;
     // ragged mode: per-stream positions on the device (the host-side head_ / tail_ then only bound the pending length)
+    uint64_t pend_max_hops_ = 0, pend_hops_out_ = 1;  // between ragged_plan and ragged_finish
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_hop_tail_;
     DeviceBuffer<uint32_t> r_frames_, r_ing_skip_, r_ing_count_, r_nhops_;

@@ -239,6 +239,204 @@ void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream) 
         hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, a.partial_nonzero, wgs, a.last_nonzero);
 }
 
+// ---- several ragged banks, one launch: output o pushes frame F of stream s iff skip_o[s] <= F < skip_o[s] + count_o[s], to slot
+// head_o[s] + F - skip_o[s] of its own ring (capacity cap_o).  Frames are indexed by their position in the block, so outputs whose
+// banks skip different numbers of leading frames (pending_skip after a hop longer than the window) share the loads all the same.
+struct IngestMultiArgs {
+    const float* pcm;
+    uint64_t frames_total;
+    AudioFormatArgs fmt;
+    int n_out;
+    int project[OMX_INGEST_MAX_OUT];
+    float* ring[OMX_INGEST_MAX_OUT];
+    uint64_t cap[OMX_INGEST_MAX_OUT];
+    const uint32_t* skips[OMX_INGEST_MAX_OUT];
+    const uint32_t* counts[OMX_INGEST_MAX_OUT];
+    const uint64_t* heads[OMX_INGEST_MAX_OUT];
+    long long* last_nonzero;     // of output 0, or nullptr
+    long long* partial_nonzero;  // [n_streams][gridDim.x]
+};
+__global__ __launch_bounds__(256) void ingest_project4_multi_kernel(IngestMultiArgs a) {
+    __shared__ long long wave_best[4];
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const uint32_t s = blockIdx.y;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * INGEST_FRAMES_PER_WG;
+    const uint64_t row_last = a.frames_total ? a.frames_total - 1 : 0;
+    const float* row = a.pcm + (uint64_t)s * a.frames_total * 2;
+    uint64_t skip_o[OMX_INGEST_MAX_OUT], count_o[OMX_INGEST_MAX_OUT], head_o[OMX_INGEST_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+        const bool on = o < a.n_out;
+        skip_o[o] = on ? a.skips[o][s] : 0;
+        count_o[o] = on ? a.counts[o][s] : 0;
+        head_o[o] = on ? a.heads[o][s] : 0;
+    }
+    long long best = -1;
+#pragma unroll
+    for (int k = 0; k < INGEST4_ROUNDS; ++k) {
+        const uint64_t F = wg_base + (uint64_t)k * 1024 + 4u * threadIdx.x;  // first of this lane's four frames
+        if (F > row_last) continue;
+        float fr[8];
+        if (F + 3 <= row_last) {
+            const f4u lo = *reinterpret_cast<const f4u*>(row + F * 2), hi = *reinterpret_cast<const f4u*>(row + F * 2 + 4);
+            fr[0] = lo.x; fr[1] = lo.y; fr[2] = lo.z; fr[3] = lo.w;
+            fr[4] = hi.x; fr[5] = hi.y; fr[6] = hi.z; fr[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v2f p = *reinterpret_cast<const v2f*>(row + min(F + (uint64_t)j, row_last) * 2);
+                fr[2 * j] = p.x;
+                fr[2 * j + 1] = p.y;
+            }
+        }
+        float left[4], right[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // dsp.rs:223-249: left = (0.0 + s0*w00) + s1*w10
+            left[j] = 0.0f + fr[2 * j] * a.fmt.m[0][0];
+            right[j] = 0.0f + fr[2 * j] * a.fmt.m[0][1];
+            left[j] = left[j] + fr[2 * j + 1] * a.fmt.m[1][0];
+            right[j] = right[j] + fr[2 * j + 1] * a.fmt.m[1][1];
+        }
+#pragma unroll
+        for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+            if (o >= a.n_out) break;
+            float v[4];
+            bool live[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = a.project[o] == OMX_PROJECT_RAW ? fr[2 * j] : project_lr(a.project[o], left[j], right[j]);
+                const uint64_t f = F + (uint64_t)j;
+                live[j] = f >= skip_o[o] && f - skip_o[o] < count_o[o];
+            }
+            const uint64_t cap = a.cap[o], first = head_o[o] + F - skip_o[o];  // (wraps when F < skip: then no lane of the quad below is live at j = 0)
+            float* ring = a.ring[o] + (uint64_t)s * cap;
+            const uint64_t p = first & (cap - 1);
+            if (live[0] && live[3] && p + 3 < cap) {
+                *reinterpret_cast<f4u*>(ring + p) = f4u{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (live[j]) ring[(first + (uint64_t)j) & (cap - 1)] = v[j];
+            }
+            if (o == 0 && a.partial_nonzero) {  // audio_last_nonzero (:423-425, :432-434): the newest non-zero sample pushed to ring 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (live[j] && v[j] != 0.0f) {
+                        const long long cand = (long long)(first + (uint64_t)j);
+                        best = cand > best ? cand : best;
+                    }
+            }
+        }
+    }
+    if (a.partial_nonzero) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const long long other = __shfl_xor(best, off);
+            best = other > best ? other : best;
+        }
+        if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long m = wave_best[0];
+            for (int w = 1; w < 4; ++w) m = wave_best[w] > m ? wave_best[w] : m;
+            if (gridDim.x == 1 && a.last_nonzero) {
+                if (m > a.last_nonzero[s]) a.last_nonzero[s] = m;
+            } else {
+                a.partial_nonzero[(uint64_t)s * gridDim.x + blockIdx.x] = m;
+            }
+        }
+    }
+}
+
+// the same for any channel count: one frame per lane and round (the fold of ingest_project_kernel)
+__global__ __launch_bounds__(256) void ingest_project_multi_kernel(IngestMultiArgs a) {
+    __shared__ long long wave_best[4];
+    const uint32_t s = blockIdx.y;
+    const uint64_t wg_base = (uint64_t)blockIdx.x * INGEST_FRAMES_PER_WG;
+    const uint32_t C = a.fmt.channels;
+    const float* row = a.pcm + (uint64_t)s * a.frames_total * C;
+    uint64_t skip_o[OMX_INGEST_MAX_OUT], count_o[OMX_INGEST_MAX_OUT], head_o[OMX_INGEST_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+        const bool on = o < a.n_out;
+        skip_o[o] = on ? a.skips[o][s] : 0;
+        count_o[o] = on ? a.counts[o][s] : 0;
+        head_o[o] = on ? a.heads[o][s] : 0;
+    }
+    long long best = -1;
+    for (int k = 0; k < INGEST_FRAMES_PER_THREAD; ++k) {
+        const uint64_t F = wg_base + (uint64_t)k * 256 + threadIdx.x;
+        if (F >= a.frames_total) continue;
+        const float* frame = row + F * C;
+        float left = 0.0f, right = 0.0f;  // dsp.rs:223-249
+        const float first = frame[0];
+        for (uint32_t c = 0; c < C; ++c) {
+            const float v = frame[c];
+            left = left + v * a.fmt.m[c][0];
+            right = right + v * a.fmt.m[c][1];
+        }
+#pragma unroll
+        for (int o = 0; o < OMX_INGEST_MAX_OUT; ++o) {
+            if (o >= a.n_out) break;
+            if (!(F >= skip_o[o] && F - skip_o[o] < count_o[o])) continue;
+            const float v = a.project[o] == OMX_PROJECT_RAW ? first : project_lr(a.project[o], left, right);
+            const uint64_t at = head_o[o] + F - skip_o[o];
+            a.ring[o][(uint64_t)s * a.cap[o] + (at & (a.cap[o] - 1))] = v;
+            if (o == 0 && v != 0.0f) best = (long long)at > best ? (long long)at : best;  // audio_last_nonzero (:423-425, :432-434)
+        }
+    }
+    if (a.partial_nonzero) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const long long other = __shfl_xor(best, off);
+            best = other > best ? other : best;
+        }
+        if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long m = wave_best[0];
+            for (int w = 1; w < 4; ++w) m = wave_best[w] > m ? wave_best[w] : m;
+            if (gridDim.x == 1 && a.last_nonzero) {
+                if (m > a.last_nonzero[s]) a.last_nonzero[s] = m;
+            } else {
+                a.partial_nonzero[(uint64_t)s * gridDim.x + blockIdx.x] = m;
+            }
+        }
+    }
+}
+
+bool launch_ingest_ragged_parts(const IngestArgs* parts, int n_parts, uint32_t n_streams, hipStream_t stream) {
+    if (n_parts <= 0 || n_streams == 0) return true;
+    IngestMultiArgs m{};
+    m.pcm = parts[0].pcm;
+    m.frames_total = parts[0].frames_total;
+    m.fmt = parts[0].fmt;
+    for (int b = 0; b < n_parts; ++b) {
+        const IngestArgs& ia = parts[b];
+        if (ia.pcm != m.pcm || ia.frames_total != m.frames_total || !ia.skips || !ia.counts || !ia.heads) return false;
+        if (b > 0 && ia.last_nonzero) return false;  // only the first part can track it
+        for (int o = 0; o < ia.n_out; ++o) {
+            if (m.n_out >= OMX_INGEST_MAX_OUT) return false;
+            m.project[m.n_out] = ia.project[o];
+            m.ring[m.n_out] = ia.ring[o];
+            m.cap[m.n_out] = ia.cap;
+            m.skips[m.n_out] = ia.skips;
+            m.counts[m.n_out] = ia.counts;
+            m.heads[m.n_out] = ia.heads;
+            ++m.n_out;
+        }
+    }
+    if (m.n_out == 0 || m.frames_total == 0) return true;
+    m.last_nonzero = parts[0].last_nonzero;
+    m.partial_nonzero = parts[0].partial_nonzero;
+    const uint32_t wgs = ingest_partials_per_stream(m.frames_total);
+    if (m.fmt.channels == 2) hipLaunchKernelGGL(ingest_project4_multi_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, m);
+    else hipLaunchKernelGGL(ingest_project_multi_kernel, dim3(wgs, n_streams), dim3(256), 0, stream, m);
+    if (m.partial_nonzero && m.last_nonzero && wgs > 1)
+        hipLaunchKernelGGL(ingest_finalize_kernel, dim3(n_streams), dim3(64), 0, stream, m.partial_nonzero, wgs, m.last_nonzero);
+    return true;
+}
+
 void launch_ingest_slots(const float* d_pcm, uint64_t frames, const AudioFormatArgs& fmt, const IngestSlots* const* banks, int n_banks,
                          uint32_t n_streams, hipStream_t stream) {
     IngestArgs ia{};

@@ -37,6 +37,11 @@ struct IngestArgs {
     uint64_t head_o[OMX_INGEST_MAX_OUT];
 };
 uint32_t ingest_partials_per_stream(uint64_t count);
+// One projection launch for the rings of SEVERAL ragged banks reading the same block (capture group: Spectrogram + Spectrum with per-
+// capture frame counts, registry.rs:396-418).  Every part is what a bank would have handed launch_ingest (per-stream skips / counts /
+// heads from its own plan kernel, its rings and their capacity); part 0 may carry last_nonzero.  Returns false when the parts cannot share
+// a launch (different blocks, more outputs than OMX_INGEST_MAX_OUT): the caller then launches them one by one.
+bool launch_ingest_ragged_parts(const IngestArgs* parts, int n_parts, uint32_t n_streams, hipStream_t stream);
 
 // What a lock-step bank wants pushed from one block (push_audio / push_sources of the reference): `skip` leading frames dropped,
 // `count` frames projected into its ring(s).  A bank fills its slots in push_begin(); whoever launches the ingest kernel — the bank

@@ -30,7 +30,7 @@ class CCaptureGroupUpdate(C.Structure):
 
 
 class CCaptureGroupRaggedUpdate(C.Structure):
-    _fields_ = [("produced", C.c_uint32), ("_pad", C.c_uint32), ("block_frames", C.c_uint64), ("max_blocks", C.c_uint64),
+    _fields_ = [("produced", C.c_uint32), ("ingest_launches", C.c_uint32), ("block_frames", C.c_uint64), ("max_blocks", C.c_uint64),
                 ("spectrogram", capi.CSpectrogramRaggedUpdate), ("spectrum", capi.CSpectrumRaggedUpdate), ("loudness", capi.CLoudnessRaggedUpdate),
                 ("stereometer", banks.CStereometerRaggedUpdate), ("oscilloscope", banks.COscilloscopeRaggedUpdate),
                 ("waveform", capi.CWaveformRaggedUpdate)]

@@ -262,6 +262,7 @@ def test_ragged_group_ingest_is_one_block_per_capture_chunk(omx, oracle, channel
         u = group.ingest_ragged(d.data_ptr(), cap, frames, channels, FS, positions, reset_mask=mask)
         torch.cuda.synchronize()
         assert int(u.block_frames) == 0 and int(u.max_blocks) == 1
+        assert u.ingest_launches == 1   # Spectrogram and Spectrum: one projection of the block for both, per-capture counts included
         nb = dview(torch, u.loudness.d_n_blocks, (S,)).cpu().numpy()
         assert np.array_equal(nb, (frames != 0).astype(nb.dtype))
         loud = dview(torch, u.loudness.d_snapshots, (S, 1, 30), "<f4").cpu().numpy()

@@ -373,6 +373,7 @@ def test_capture_group_ragged_ingest_with_toggles_and_config_changes_equals_its_
             at[s] += int(frames[s])
         nb = (frames // block).astype(np.uint32)
         u = group.ingest_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, reset_mask=mask)
+        assert u.ingest_launches == 1   # one shared projection for the Spectrogram and Spectrum banks (the twin banks below launch one each)
         with pytest.raises(capi.OmxError):
             group.ingest(chunk.data_ptr(), cap, 2, 48000.0, pos)
         r_sg = sg.process_ragged(chunk.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
