@@ -433,6 +433,8 @@ typedef struct omx_loudness_ragged_update {
     uint64_t max_blocks;
     const uint32_t* d_n_blocks;               /* device: [n_streams] */
     const omx_loudness_snapshot* d_snapshots; /* device: [n_streams][max_blocks] */
+    const uint8_t* d_reset;                   /* device: [n_streams] the call's reset flags */
+    const uint32_t* d_block_frames;           /* device: [n_streams] per-stream block length (process_chunks), or NULL (block_frames for all) */
 } omx_loudness_ragged_update;
 int omx_loudness_bank_process_ragged(omx_loudness_bank* b, const float* pcm, uint64_t block_frames, uint64_t max_blocks,
                                      const uint32_t* n_blocks, const uint8_t* reset_mask, uint32_t channels, float sample_rate,
@@ -990,6 +992,9 @@ typedef struct omx_capture_group_ragged_update {
     omx_stereometer_ragged_update stereometer;
     omx_oscilloscope_ragged_update oscilloscope;
     omx_waveform_ragged_update waveform;
+    const float* d_stats_rows;       /* [n_streams][OMX_STATS_COLUMNS] (OMX_OPT_GROUP_STATS; Spectrogram, Loudness and Stereometer enabled), or NULL.
+                                        Per-capture rows: a capture that delivered nothing in this call keeps its row (column 7, the
+                                        columns of this call, reads 0); its peak holds run on the capture's own sample clock */
 } omx_capture_group_ragged_update;
 typedef struct omx_capture_group omx_capture_group;
 void omx_capture_group_config_default(omx_capture_group_config* out); /* every visual's default config, none enabled, 1 stream */
@@ -1021,7 +1026,7 @@ int omx_capture_group_ingest(omx_capture_group* g, const float* pcm, uint64_t fr
  *   runs frames[s] / B blocks (omx_<visual>_bank_process_ragged).  Per stream the results equal a single-stream handle fed the same
  *   sequence of blocks.  A per-capture reset reaches the banks of DISABLED visuals too (VisualManager::reset_audio resets every
  *   entry, :360-365): it is applied by the bank's next call after the visual is enabled again.  After the first ragged call the group's positions are per capture: omx_capture_group_ingest is refused
- *   (OMX_ERR_INVALID) until omx_capture_group_reset_audio.  Summary rows (OMX_OPT_GROUP_STATS) are a lock-step feature. */
+ *   (OMX_ERR_INVALID) until omx_capture_group_reset_audio. */
 int omx_capture_group_set_enabled(omx_capture_group* g, uint32_t visual, int enabled);
 int omx_capture_group_enabled(const omx_capture_group* g);            /* OMX_VISUAL_* bits ingest currently feeds */
 int omx_capture_group_update_config(omx_capture_group* g, uint32_t visual, const void* config, void* stream);

@@ -118,7 +118,8 @@ class CWaveformRaggedUpdate(C.Structure):
 
 
 class CLoudnessRaggedUpdate(C.Structure):
-    _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("d_n_blocks", C.c_void_p), ("d_snapshots", C.c_void_p)]
+    _fields_ = [("n_streams", C.c_uint64), ("max_blocks", C.c_uint64), ("d_n_blocks", C.c_void_p), ("d_snapshots", C.c_void_p),
+                ("d_reset", C.c_void_p), ("d_block_frames", C.c_void_p)]
 
 
 class CSpectrumRaggedUpdate(C.Structure):

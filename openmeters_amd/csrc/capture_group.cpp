@@ -59,6 +59,7 @@ void CaptureGroup::reset_audio() {  // registry.rs:360-365: every module's reset
     if (waveform_) waveform_->reset_audio();
     holds_valid_ = false;  // LoudnessState::reset_audio: fresh PeakHolds (loudness/state.rs:153-160)
     clock_ = 0.0;          // ... on a fresh sample clock
+    ragged_stats_live_ = false;
     ragged_ = false;       // a bank-wide reset returns every bank to lock-step positions
     for (auto& p : pending_reset_) p.clear();  // every bank, enabled or not, has just been reset
     have_generation_ = false;  // registry.rs:361 format_generation = None
@@ -380,9 +381,26 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     const uint8_t* m_os = mask_for(4, oscilloscope != nullptr, oscilloscope_ != nullptr, reset_mask);
     const uint8_t* m_wf = mask_for(5, waveform != nullptr, waveform_ != nullptr, reset_mask);
     ragged_ = true;
-    if (reset_mask)   // LoudnessState::reset_audio of the reset captures: the summary-row peak holds restart with the next lock-step epoch
-        for (uint32_t s = 0; s < S; ++s)
-            if (reset_mask[s]) holds_valid_ = false;
+    // Summary rows per capture: the rows and the peak holds persist between calls (a capture that delivers nothing keeps its row), the
+    // holds run on every capture's own sample clock, and a per-capture reset restarts that capture's holds (LoudnessState::reset_audio).
+    // A reset that arrives while the Loudness visual is disabled is applied by the first stats pass after it is enabled again: the mask
+    // the bank gets (m_ld) carries it.
+    const bool stats = stats_ && spectrogram && loudness && stereometer;
+    if (stats && !ragged_stats_live_) {
+        rows_.reserve((size_t)S * OMX_STATS_COLUMNS);
+        holds_.reserve((size_t)S * 3);
+        clocks_.reserve(S);
+        if (!holds_valid_) {  // nothing carried over from lock-step calls
+            OMX_HIP(hipMemsetAsync(rows_.ptr, 0, (size_t)S * OMX_STATS_COLUMNS * sizeof(float), stream));
+            launch_peak_holds_reset(holds_.ptr, (uint64_t)S * 3, 0.0, stream);
+            clock_ = 0.0;
+        }
+        launch_fill_f64(clocks_.ptr, S, clock_, stream);  // every capture continues the common clock of the lock-step calls so far
+        OMX_HIP(hipGetLastError());
+        holds_valid_ = true;
+        ragged_stats_live_ = true;
+    }
+    const float sr = sanitize_sample_rate(sample_rate);
     int worst = OMX_NONE;
     auto note = [&](int rc, uint32_t bit) {
         if (rc < 0) worst = worst < 0 ? worst : rc;
@@ -434,6 +452,10 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                         : loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_ld, channels, sample_rate, positions,
                                                    side_[0], &up.loudness),
                  OMX_VISUAL_LOUDNESS);
+            if (stats && up.loudness.d_snapshots && up.loudness.d_n_blocks)
+                launch_stats_loudness_ragged(up.loudness.d_snapshots, S, up.loudness.max_blocks, up.loudness.d_n_blocks, up.loudness.d_block_frames,
+                                             (uint32_t)block, sr, up.loudness.d_reset, OMX_METER_TRUE_PEAK, OMX_METER_LUFS_SHORT_TERM, channels,
+                                             holds_.ptr, clocks_.ptr, rows_.ptr, side_[0]);
             OMX_HIP(hipGetLastError());
         }
         if (waveform) {
@@ -451,6 +473,9 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                         : stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_st, channels, sample_rate, positions,
                                                       side_[1], &up.stereometer),
                  OMX_VISUAL_STEREOMETER);
+            if (stats && up.stereometer.d_correlations && up.stereometer.d_n_blocks)
+                launch_stats_stereometer_ragged(up.stereometer.d_correlations, S, up.stereometer.max_blocks, up.stereometer.d_n_blocks, rows_.ptr,
+                                                side_[1]);
             OMX_HIP(hipGetLastError());
         }
         if (oscilloscope) {
@@ -465,6 +490,13 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         }
         return (int)OMX_NONE;
     });
+    // ---- joined; the spectrogram's summary columns follow its kernels on the caller's stream
+    if (stats) {
+        if (up.spectrogram.d_n_columns)
+            launch_stats_spectrogram_ragged(up.spectrogram.d_counts, S, up.spectrogram.max_columns, up.spectrogram.d_n_columns, rows_.ptr, stream);
+        OMX_HIP(hipGetLastError());
+        up.d_stats_rows = rows_.ptr;
+    }
     if (out) *out = up;
     if (worst < 0) return worst;
     return up.produced ? OMX_PRODUCED : OMX_NONE;

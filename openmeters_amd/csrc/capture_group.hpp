@@ -71,6 +71,9 @@ private:
     double clock_ = 0.0;
     DeviceBuffer<omx_meter_row> meters_;
     DeviceBuffer<float> rows_;
+    // per-capture calls: every capture's own sample clock (device), and whether rows_ / clocks_ already describe per-capture state
+    DeviceBuffer<double> clocks_;
+    bool ragged_stats_live_ = false;
 };
 
 }  // namespace omx

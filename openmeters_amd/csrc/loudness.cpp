@@ -284,6 +284,8 @@ int LoudnessBank::ragged_impl(const float* d_pcm, uint64_t row_frames, uint64_t 
         out->max_blocks = slots;
         out->d_n_blocks = r_blocks_.ptr;
         out->d_snapshots = snapshots_.ptr;
+        out->d_reset = r_mask_.ptr;
+        out->d_block_frames = frames_v ? r_frames_.ptr : nullptr;
     }
     return any ? OMX_PRODUCED : OMX_NONE;
 }

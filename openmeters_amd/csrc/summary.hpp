@@ -13,4 +13,16 @@ void launch_stats_loudness(const omx_loudness_snapshot* snapshots, const omx_met
                            uint32_t channels, float* rows, hipStream_t stream);
 void launch_stats_stereometer(const float* correlations, uint64_t n_streams, uint64_t n_blocks, float* rows, hipStream_t stream);
 void launch_stats_spectrogram(const uint32_t* counts, uint64_t n_streams, uint64_t n_columns, float* rows, hipStream_t stream);
+// the same for per-capture calls (omx_capture_group_ingest_ragged): capture s ran n_blocks_v[s] <= max_blocks blocks of block_frames_v[s]
+// (or block_frames) frames — rows / holds of captures that ran none stay as they are; reset_v[s] restarts the capture's holds on a fresh
+// sample clock (LoudnessState::reset_audio, loudness/state.rs:153-160).  clocks[s] = the sample clock of capture s's next snapshot.
+void launch_stats_loudness_ragged(const omx_loudness_snapshot* snapshots, uint64_t n_streams, uint64_t max_blocks, const uint32_t* n_blocks_v,
+                                  const uint32_t* block_frames_v, uint32_t block_frames, float sample_rate, const uint8_t* reset_v,
+                                  uint32_t left_mode, uint32_t right_mode, uint32_t channels, omx_peak_hold* holds, double* clocks, float* rows,
+                                  hipStream_t stream);
+void launch_stats_stereometer_ragged(const float* correlations, uint64_t n_streams, uint64_t max_blocks, const uint32_t* n_blocks_v, float* rows,
+                                     hipStream_t stream);
+void launch_stats_spectrogram_ragged(const uint32_t* counts, uint64_t n_streams, uint64_t max_columns, const uint32_t* n_columns_v, float* rows,
+                                     hipStream_t stream);
+void launch_fill_f64(double* dst, uint64_t n, double value, hipStream_t stream);
 }  // namespace omx

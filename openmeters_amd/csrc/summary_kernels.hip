@@ -218,6 +218,117 @@ __global__ __launch_bounds__(256) void stats_spectrogram_kernel(const uint32_t* 
     r[8] = (float)sum / (float)n_columns;
     r[9] = (float)counts[s * n_columns + n_columns - 1];
 }
+// ---- per-capture calls: one lane per capture walks ITS blocks (PeakHold::update on the capture's own sample clock) and rewrites its
+// row when it ran any; everything else stays
+__global__ __launch_bounds__(64) void stats_loudness_ragged_kernel(const omx_loudness_snapshot* __restrict__ snapshots, uint64_t n_streams,
+                                                                  uint64_t max_blocks, const uint32_t* __restrict__ n_blocks_v,
+                                                                  const uint32_t* __restrict__ block_frames_v, uint32_t block_frames,
+                                                                  float sample_rate, const uint8_t* __restrict__ reset_v, uint32_t left_mode,
+                                                                  uint32_t right_mode, uint32_t channels, omx_peak_hold* __restrict__ holds,
+                                                                  double* __restrict__ clocks, float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_streams) return;
+    omx_peak_hold h[3] = {holds[3 * s], holds[3 * s + 1], holds[3 * s + 2]};
+    double now = clocks[s];
+    if (reset_v && reset_v[s]) {  // LoudnessState::reset_audio: PeakHold::new(DB_RANGE.0, 0) x 3 on a fresh clock
+        now = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h[i] = omx_peak_hold{METER_DB_LO, 0, now};
+    }
+    const uint32_t n = n_blocks_v[s];
+    const double dt = (double)(block_frames_v ? block_frames_v[s] : block_frames) / (double)sample_rate;
+    float peaks[3] = {h[0].db, h[1].db, h[2].db};
+    for (uint32_t k = 0; k < n; ++k) {
+        const omx_loudness_snapshot snap = snapshots[s * max_blocks + k];
+        float values[3] = {aggregate(snap, left_mode, SIDE_LEFT), aggregate(snap, left_mode, SIDE_RIGHT), meter_value(snap, right_mode, 0)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float v = values[i];
+            v = v < METER_DB_LO ? METER_DB_LO : (v > METER_DB_HI ? METER_DB_HI : v);
+            if (v > h[i].db) {  // PeakHold::update :49-59
+                h[i].db = v;
+                h[i].decay_from = now + PEAK_HOLD_SECONDS;
+            } else if (now > h[i].decay_from) {
+                const float decay_dt = (float)(now - h[i].decay_from);
+                const float d = h[i].db - PEAK_DECAY_DB_PER_SEC * decay_dt;
+                h[i].db = d > v ? d : v;
+                h[i].decay_from = now;
+            }
+            peaks[i] = h[i].db;
+        }
+        now += dt;
+    }
+    holds[3 * s] = h[0];
+    holds[3 * s + 1] = h[1];
+    holds[3 * s + 2] = h[2];
+    clocks[s] = now;
+    if (n == 0) return;
+    const omx_loudness_snapshot& snap = snapshots[s * max_blocks + n - 1];  // the capture's newest block
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[0] = snap.momentary_loudness;
+    r[1] = snap.short_term_loudness;
+    float peak = snap.true_peak_db[0];
+    for (uint32_t c = 1; c < channels && c < OMX_MAX_CHANNELS; ++c) peak = fmaxf(peak, snap.true_peak_db[c]);
+    r[2] = peak;
+    r[10] = peaks[0];
+    r[11] = peaks[1];
+}
+__global__ __launch_bounds__(64) void stats_stereometer_ragged_kernel(const float* __restrict__ correlations, uint64_t n_streams, uint64_t max_blocks,
+                                                                     const uint32_t* __restrict__ n_blocks_v, float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_streams || n_blocks_v[s] == 0) return;
+    const float* c = correlations + (s * max_blocks + n_blocks_v[s] - 1) * 4;
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[3] = c[0];
+    r[4] = c[1];
+    r[5] = c[2];
+    r[6] = c[3];
+}
+__global__ __launch_bounds__(256) void stats_spectrogram_ragged_kernel(const uint32_t* __restrict__ counts, uint64_t n_streams, uint64_t max_columns,
+                                                                      const uint32_t* __restrict__ n_columns_v, float* __restrict__ rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // one wavefront per capture
+    if (s >= n_streams) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t n = n_columns_v[s];
+    unsigned long long sum = 0;
+    for (uint64_t c = lane; c < n; c += 64) sum += counts[s * max_columns + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane != 0) return;
+    float* r = rows + s * OMX_STATS_COLUMNS;
+    r[7] = (float)n;   // columns of THIS call (0: the capture's other spectrogram columns keep its last call's values)
+    if (n == 0) return;
+    r[8] = (float)sum / (float)n;
+    r[9] = (float)counts[s * max_columns + n - 1];
+}
+__global__ void fill_f64_kernel(double* dst, uint64_t n, double value) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+void launch_fill_f64(double* dst, uint64_t n, double value, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(fill_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, dst, n, value);
+}
+void launch_stats_loudness_ragged(const omx_loudness_snapshot* snapshots, uint64_t n_streams, uint64_t max_blocks, const uint32_t* n_blocks_v,
+                                  const uint32_t* block_frames_v, uint32_t block_frames, float sample_rate, const uint8_t* reset_v,
+                                  uint32_t left_mode, uint32_t right_mode, uint32_t channels, omx_peak_hold* holds, double* clocks, float* rows,
+                                  hipStream_t stream) {
+    if (n_streams == 0) return;
+    hipLaunchKernelGGL(stats_loudness_ragged_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, snapshots, n_streams, max_blocks,
+                       n_blocks_v, block_frames_v, block_frames, sample_rate, reset_v, left_mode, right_mode, channels, holds, clocks, rows);
+}
+void launch_stats_stereometer_ragged(const float* correlations, uint64_t n_streams, uint64_t max_blocks, const uint32_t* n_blocks_v, float* rows,
+                                     hipStream_t stream) {
+    if (n_streams == 0 || max_blocks == 0) return;
+    hipLaunchKernelGGL(stats_stereometer_ragged_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, correlations, n_streams,
+                       max_blocks, n_blocks_v, rows);
+}
+void launch_stats_spectrogram_ragged(const uint32_t* counts, uint64_t n_streams, uint64_t max_columns, const uint32_t* n_columns_v, float* rows,
+                                     hipStream_t stream) {
+    if (n_streams == 0) return;
+    hipLaunchKernelGGL(stats_spectrogram_ragged_kernel, dim3((uint32_t)((n_streams + 3) / 4)), dim3(256), 0, stream, counts, n_streams, max_columns,
+                       n_columns_v, rows);
+}
+
 void launch_stats_loudness(const omx_loudness_snapshot* snapshots, const omx_meter_row* meters, uint64_t n_streams, uint64_t n_blocks,
                            uint32_t channels, float* rows, hipStream_t stream) {
     if (n_streams == 0 || n_blocks == 0) return;

@@ -33,7 +33,7 @@ class CCaptureGroupRaggedUpdate(C.Structure):
     _fields_ = [("produced", C.c_uint32), ("ingest_launches", C.c_uint32), ("block_frames", C.c_uint64), ("max_blocks", C.c_uint64),
                 ("spectrogram", capi.CSpectrogramRaggedUpdate), ("spectrum", capi.CSpectrumRaggedUpdate), ("loudness", capi.CLoudnessRaggedUpdate),
                 ("stereometer", banks.CStereometerRaggedUpdate), ("oscilloscope", banks.COscilloscopeRaggedUpdate),
-                ("waveform", capi.CWaveformRaggedUpdate)]
+                ("waveform", capi.CWaveformRaggedUpdate), ("d_stats_rows", C.c_void_p)]
 
 
 _CONFIG_OF = {capi.VISUAL_SPECTROGRAM: "spectrogram", capi.VISUAL_SPECTRUM: "spectrum", capi.VISUAL_LOUDNESS: "loudness",
@@ -134,7 +134,7 @@ class _DeviceView:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
 
 
-def stats_rows_tensor(torch, device, update: CCaptureGroupUpdate, n_streams: int):
+def stats_rows_tensor(torch, device, update, n_streams: int):
     """The update's summary rows as a torch view [n_streams, 12] f32 of the library's device buffer (valid until the next ingest)."""
     if not update.d_stats_rows:
         return None

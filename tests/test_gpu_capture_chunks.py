@@ -226,8 +226,11 @@ def test_ragged_group_ingest_is_one_block_per_capture_chunk(omx, oracle, channel
     positions = capi.SURROUND if channels == 8 else capi.positions_fallback(channels)
     pcm = np.stack([capture_pcm(s, total, channels, rng) for s in range(S)])
     cfgs = configs()
-    group = CaptureGroup(omx, S, **cfgs)
+    group = CaptureGroup(omx, S, stats=True, **cfgs)   # + the per-capture summary rows (OMX_OPT_GROUP_STATS)
     refs = [OracleCapture(oracle, cfgs, channels, positions) for _ in range(S)]
+    holds = [capi.peak_holds_reset(oracle, 3, 0.0) for _ in range(S)]   # the oracle's PeakHolds, on every capture's own sample clock
+    clocks = [0.0] * S
+    rows_seen = 0
     f = fmt(channels, FS, 1)
     f.positions = (capi.C.c_uint8 * 8)(*positions)
     queues = []
@@ -276,21 +279,42 @@ def test_ragged_group_ingest_is_one_block_per_capture_chunk(omx, oracle, channel
         hops = dview(torch, u.spectrum.d_n_hops, (S,)).cpu().numpy()
         spec = dview(torch, u.spectrum.d_traces, (S, int(u.spectrum.n_hops_out), 2, 2, bins), "<f4").cpu().numpy() if u.spectrum.d_traces else None
         cols = dview(torch, u.spectrogram.d_n_columns, (S,)).cpu().numpy() if u.spectrogram.d_n_columns else np.zeros(S, np.int32)
+        assert u.d_stats_rows
+        table = dview(torch, u.d_stats_rows, (S, 12), "<f4").cpu().numpy().copy()
         for s in range(S):
             if mask[s]:
                 refs[s].reset_audio()
+                holds[s] = capi.peak_holds_reset(oracle, 3, 0.0)   # LoudnessState::reset_audio: fresh holds, fresh clock
+                clocks[s] = 0.0
             if not frames[s]:
+                assert table[s, 7] == 0 and (call == 0 or np.array_equal(table[s, :7], last_table[s, :7])), (call, s)   # the row stays
                 continue
             n = int(frames[s])
             want = refs[s].ingest(pcm[s, pos[s]:pos[s] + n])
+            # ---- the capture's summary row against its own oracle processors
+            meter = capi.loudness_meters(oracle, [want["ld"]], 1, capi.METER_TRUE_PEAK, capi.METER_LUFS_SHORT_TERM, clocks[s], n / FS, holds[s])
+            clocks[s] += n / FS
+            bar("group chunks: stats row, |d momentary / short-term LUFS|", max(abs(table[s, 0] - want["ld"].momentary_loudness),
+                                                                                abs(table[s, 1] - want["ld"].short_term_loudness)), 1e-4, (call, s))
+            bar("group chunks: stats row, |d max true peak dB|", abs(table[s, 2] - want["ld"].true_peak_db[:channels].max()), 1e-4, (call, s))
+            bar("group chunks: stats row, |d held true-peak bars|", np.abs(table[s, 10:12] - meter[0, -1]["peaks"][:2]).max(), 1e-4, (call, s))
+            if want["st"] is not None:
+                bar("group chunks: stats row, |d rho|", np.abs(table[s, 3:7] - want["st"].correlations).max(), 1e-6, (call, s))
+            n_cols = len(want["sg"].new_columns) if want["sg"] is not None else 0
+            assert table[s, 7] == n_cols, (call, s, table[s, 7], n_cols)
+            if n_cols:
+                cnt = [len(c) for c in want["sg"].new_columns]
+                assert abs(table[s, 8] - np.mean(cnt)) < 4.5 and abs(table[s, 9] - cnt[-1]) <= 4, (call, s, table[s, 7:10], cnt)
+            rows_seen += 1
             want["epoch_base"] = refs[s].epoch_base
             got = dict(loudness=loud[s, 0], scope_header=header_fields(hdrs[s, 0]), scope_samples=smps[s], scope_epoch=int(epochs[s]),
                        spectrum=spec[s, 0] if spec is not None else None, spectrum_hops=int(hops[s]),
                        stereo_produced=int(prod[s, 0]), stereo_rho=rho[s, 0], stereo_points=pts[s], spectrogram_columns=int(cols[s]))
             check_capture((channels, call, n, s), want, got, max_step[s], stats)
             pos[s] += n
+        last_table = table
         call += 1
-    assert mixed > 10, mixed                         # calls in which captures delivered chunks of different lengths
+    assert mixed > 10 and rows_seen > 60, (mixed, rows_seen)   # calls in which captures delivered chunks of different lengths
     assert stats["scope"] > 60 and stats["spectrum"] > 60 and stats["stereo"] > 60, stats
 
 
