@@ -304,11 +304,14 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
             OMX_HIP(hipGetLastError());
         }
         // ---- side stream 2: oscilloscope
+        // ---- oscilloscope: on the CALLER's stream, behind the spectrogram / spectrum kernels.  HIP maps streams onto four hardware
+        //      queues: with a side stream of its own (round 4) the fifth stream shared a queue with the waveform bank's and the trigger pass
+        //      — one 512-thread workgroup per CU holding > 100 KiB of LDS — started only when that was through (kernel trace of the
+        //      streaming cadence: scope chain 155 -> 276 us into the call).  More queues (GPU_MAX_HW_QUEUES = 8) measured WORSE, 353 against
+        //      307 us per call: every chain contends for the same 256 CUs.  Here: 291 us, and 466 against 530 for a 1024-frame chunk.
         if (oscilloscope) {
-            used[2] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[2], fork_, 0));
             {
-                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[2]);
+                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, stream);
                 note(rc, OMX_VISUAL_OSCILLOSCOPE);
                 if (rc == OMX_PRODUCED) {
                     up.oscilloscope.n_streams = S;
@@ -478,13 +481,11 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                                                 side_[1]);
             OMX_HIP(hipGetLastError());
         }
-        if (oscilloscope) {
-            used[2] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[2], fork_, 0));
-            note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, side_[2],
+        if (oscilloscope) {  // (on the caller's stream, as in the lock-step call)
+            note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, stream,
                                                        &up.oscilloscope)
                         : oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_os, channels, sample_rate, positions,
-                                                       side_[2], &up.oscilloscope),
+                                                       stream, &up.oscilloscope),
                  OMX_VISUAL_OSCILLOSCOPE);
             OMX_HIP(hipGetLastError());
         }

@@ -6,6 +6,8 @@ correlation on one GPU's shard of streams, summary rows gathered over RCCL once 
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 from typing import Optional, Sequence
 
 from . import banks, capi
@@ -114,12 +116,13 @@ class CaptureGroup:
         """capture s delivers its first frames[s] frames of [n_streams][frames_capacity][channels] (device memory)"""
         out = CCaptureGroupRaggedUpdate()
         n = self.n_streams
-        fr = (C.c_uint32 * n)(*[int(x) for x in frames])
-        mk = (C.c_uint8 * n)(*[int(x) for x in reset_mask]) if reset_mask is not None else None
+        fr = np.ascontiguousarray(frames, dtype=np.uint32)   # (numpy arrays pass through without a per-element conversion)
+        mk = np.ascontiguousarray(reset_mask, dtype=np.uint8) if reset_mask is not None else None
+        assert fr.shape == (n,) and (mk is None or mk.shape == (n,))
         f = self.api.fn("capture_group_ingest_ragged", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float,
                                                                  _u8x8, C.c_void_p, C.c_void_p])
-        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr, mk, channels, sample_rate, _u8x8(*positions), C.c_void_p(stream or 0),
-                         C.byref(out)))
+        self.api.check(f(self._h, C.c_void_p(device_ptr), frames_capacity, fr.ctypes.data, mk.ctypes.data if mk is not None else None, channels,
+                         sample_rate, _u8x8(*positions), C.c_void_p(stream or 0), C.byref(out)))
         return out
 
     def kernel_time(self):

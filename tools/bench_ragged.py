@@ -78,3 +78,28 @@ a, b = banks.OscilloscopeBank(api, osc, S2), banks.OscilloscopeBank(api, osc, S2
 lock = timed(lambda: a.process_device(p2.data_ptr(), 256, blocks, 2, FS, pos), 5)
 rag = timed(lambda: b.process_ragged(p2.data_ptr(), 256, blocks, [blocks] * S2, 2, FS, pos), 5)
 line("oscilloscope, 256 x 64 blocks", lock, rag, S2 * blocks, "blocks")
+# the capture group itself at the reference's cadence: 1024 captures x 2 ch, all six visuals at the reference's default configs, one
+# 256-frame chunk per capture and call (bench_stream.py's workload), summary rows on — lock-step ingest against ingest_ragged with
+# equal per-capture counts (one shared projection launch, per-capture rows)
+from openmeters_amd.pipeline import CaptureGroup
+import bench_stream
+S, F = 1024, 256
+cfgs = bench_stream.default_configs()
+n = torch.arange(F * 8, device=dev, dtype=torch.float32)
+base = (0.4 * torch.sin(2 * torch.pi * 440.0 * n / 48000.0))[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :]
+pcm = (base + 0.01 * (torch.rand((S, F * 8, 2), device=dev) - 0.5)).contiguous()
+chunks = [pcm[:, k * F:(k + 1) * F].contiguous() for k in range(8)]
+ga, gb = CaptureGroup(api, S, stats=True, **cfgs), CaptureGroup(api, S, stats=True, **cfgs)
+state = {"a": 0, "b": 0}
+def lock_step():
+    ga.ingest(chunks[state["a"] % 8].data_ptr(), F, 2, FS, pos)
+    state["a"] += 1
+def ragged():
+    gb.ingest_ragged(chunks[state["b"] % 8].data_ptr(), F, [F] * S, 2, FS, pos)
+    state["b"] += 1
+for _ in range(40):
+    lock_step()
+    ragged()
+lock = timed(lock_step, 200)
+rag = timed(ragged, 200)
+line("capture group, six visuals + rows, 1024 x 256 frames", lock, rag, S, "chunks")
