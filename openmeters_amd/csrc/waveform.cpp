@@ -580,6 +580,10 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
     uint64_t longest = 0;
     std::vector<uint32_t> h_cols(n_streams_, 0), resets;
     std::vector<float> h_progress(n_streams_, 0.0f);
+    // the mirror advances in copies: committed once the launches below have gone through (or this function has declined the call with
+    // the mirror still describing the device, which the sequential kernel then advances itself — see the commit points)
+    std::vector<uint64_t> new_pushes = h_pushes_;
+    std::vector<double> new_phase = h_phase_;
     for (auto& kv : classes) {
         const Key& k = kv.first;
         double phase;
@@ -599,8 +603,8 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
         g.streams = kv.second;
         for (uint32_t s : kv.second) {
             if (reset_mask && reset_mask[s]) resets.push_back(s);
-            h_pushes_[s] = k.pushes + (analysis_ ? k.frames : 0);
-            h_phase_[s] = phase;
+            new_pushes[s] = k.pushes + (analysis_ ? k.frames : 0);
+            new_phase[s] = phase;
             h_cols[s] = (uint32_t)std::min<uint64_t>(g.column_ends.size(), max_cols);
             h_progress[s] = progress;
         }
@@ -609,8 +613,27 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
         longest = std::max(longest, k.frames);
         groups.push_back(std::move(g));
     }
-    if (!servable || groups.empty()) return false;
-    if (form_ != 2 && longest < 2048) return false;  // (the lock-step rule: short calls stay on the sequential kernels)
+    // (declining from here on: the sequential kernel runs the call and advances the device counters exactly as replayed above, so the
+    // mirror takes the replayed values; an EXCEPTION below leaves the mirror untouched and invalid — the device did not move)
+    auto commit = [&] {
+        h_pushes_.swap(new_pushes);
+        h_phase_.swap(new_phase);
+    };
+    if (!servable || groups.empty()) {
+        commit();
+        return false;
+    }
+    if (form_ != 2 && longest < 2048) {  // (the lock-step rule: short calls stay on the sequential kernels)
+        commit();
+        return false;
+    }
+    struct Invalidate {  // (a throw between here and the commit: the mirror no longer knows what the device holds)
+        bool& valid;
+        bool armed = true;
+        ~Invalidate() {
+            if (armed) valid = false;
+        }
+    } guard{mirror_valid_};
     // reset_audio of single streams (:153-155 -> rebuild): their state is cleared before anything reads it (the rings need no clearing:
     // nothing older than the push count — now 0 — is read).  Harmless should the call fall back: the sequential kernel clears them too.
     if (!resets.empty()) {
@@ -618,7 +641,12 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
         reset_staging_.upload(resets.data(), resets.size() * sizeof(uint32_t), reset_list_.ptr, stream);
         launch_waveform_reset_streams(state_.ptr, reset_list_.ptr, (uint32_t)resets.size(), stream);
     }
-    if (!launch_chunk_groups(wa, groups, wa.frames, max_cols, stream)) return false;
+    if (!launch_chunk_groups(wa, groups, wa.frames, max_cols, stream)) {
+        guard.armed = false;
+        commit();
+        return false;
+    }
+    commit();
     // the per-stream counters the sequential kernels and the caller read: push counts, phases, column counts, preview progress
     const size_t n = n_streams_;
     std::vector<uint8_t> blob(n * (sizeof(uint64_t) + sizeof(double) + sizeof(uint32_t) + sizeof(float)));
@@ -631,6 +659,7 @@ bool WaveformBank::run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, 
     mirror_staging_.upload(blob.data(), blob.size(), mirror_dev_.ptr, stream);
     // ... copied into pushes_v / phase_v / cols_v / progress_v behind the chunk kernels, unless `bad` (then the sequential kernel writes them)
     launch_waveform_mirror_copy(mirror_dev_.ptr, n_streams_, wa.pushes_v, wa.phase_v, wa.cols_v, wa.progress_v, bad_.ptr, stream);
+    guard.armed = false;
     wa.run_if = bad_.ptr;
     return true;
 }

@@ -204,9 +204,13 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
                 const float bv[4] = {v.x, v.y, (v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f};
                 float cv[4], pw[4];
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {  // BandTracker::process (:108-121); everything is finite here
+                for (int ch = 0; ch < 4; ++ch) {  // BandTracker::process (:108-121): a non-finite colour value / power counts as 0.  This call's PCM
+                    // is bounded (pass A), but filter state carried over from an earlier call through the sequential kernels may be
+                    // finite and huge (|x| up to 3e38 is legal input): its square overflows here
                     cv[ch] = fabsf(bv[ch]) * gain;
                     pw[ch] = bv[ch] * bv[ch];
+                    cv[ch] = cv[ch] <= 3.4028235e38f ? cv[ch] : 0.0f;
+                    pw[ch] = pw[ch] <= 3.4028235e38f ? pw[ch] : 0.0f;
                     acc_c[ch] += (double)cv[ch];
                     if (history) acc_p[ch] += (double)pw[ch];
                 }

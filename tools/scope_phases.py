@@ -4,6 +4,8 @@ import os
 import sys
 
 os.environ["OMX_SCOPE_PHASES"] = "1"
+# the product library ignores tuning variables: the phase clocks live in the tuning build (make -C openmeters_amd/csrc TUNING=1)
+os.environ.setdefault("OMX_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openmeters_amd", "csrc", "libomx_hip_tuning.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
