@@ -925,8 +925,8 @@ int omx_spectrogram_history_splat(omx_spectrogram_history* h, float reassigned_p
  * and VisualManager::reset_audio (:360-365) resets every one of them.  Here the group owns one bank per enabled visual for
  * `n_streams` captures advancing in lock step; one omx_capture_group_ingest call
  *   - projects the block ONCE for the visuals that keep pending audio (Spectrogram and Spectrum are fed by a single ingest launch),
- *   - runs the Spectrogram / Spectrum banks on the caller's stream and the meter banks (Loudness + Waveform, Stereometer +
- *     Oscilloscope) on two streams of its own beside them, joined before the call returns to the caller's stream order,
+ *   - runs the Spectrogram / Spectrum banks and the Oscilloscope bank on the caller's stream and the other meter banks (Loudness,
+ *     Stereometer, Waveform) on three streams of its own beside them, joined before the call returns to the caller's stream order,
  *   - and, on request (OMX_OPT_GROUP_STATS), leaves the per-stream summary rows — the table that is gathered over RCCL once per
  *     epoch — in device memory: [n_streams][OMX_STATS_COLUMNS] f32 =
  *       momentary LUFS, short-term LUFS, max true peak dBTP, rho full / low / mid / high (newest block), columns of this call,

@@ -74,14 +74,34 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;  // cap <= 2^30 (host-checked)
     const uint32_t p32 = (uint32_t)(spectrum_tail(a, s) + (uint64_t)(a.first_hop + h0) * a.hop);
     float xa[16], xb[16], w[16];
+    // Buffer-addressed loads (buffer_device.hpp) while both hops' windows lie in one piece of the ring: one per-lane byte offset and
+    // scalar steps instead of a masked 32-bit index + 64-bit address per load (3 VALU per load, 96 per thread, of the kernel's 923)
+    const uint32_t off0 = (uint32_t)(((uint64_t)p32 << 2) & bytemask) >> 2;
+    const uint32_t hop_bytes = (uint32_t)a.hop * 4u;
+    const bool direct = F == 1 && (uint64_t)off0 + (has_b ? (uint64_t)a.hop : 0ull) + (uint64_t)N <= a.cap;
+    if (direct) {
+        const GlobalBuffer ringb = global_buffer(ring + (uint64_t)off0 * 4u, (has_b ? hop_bytes : 0u) + (uint32_t)N * 4u);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const uint32_t q = p32 + ju + (unsigned)T * (unsigned)t;
-        xa[t] = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
-        xb[t] = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
+        for (int t = 0; t < 16; ++t) {
+            xa[t] = load_f32(ringb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
+            xb[t] = has_b ? load_f32(ringb, ju * 4u, hop_bytes + 4u * (unsigned)T * (unsigned)t) : 0.0f;  // (has_b: uniform)
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t q = p32 + ju + (unsigned)T * (unsigned)t;
+            xa[t] = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
+            xb[t] = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
+        }
     }
+    if (F == 1) {
+        const GlobalBuffer winb = global_buffer(a.window, (uint32_t)N * 4u);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
+        for (int t = 0; t < 16; ++t) w[t] = load_f32(winb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
+    }
     TwiddlesPow2<LOGN> tw;
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N

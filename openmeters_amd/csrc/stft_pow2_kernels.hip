@@ -507,6 +507,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
     v2f* lds = reinterpret_cast<v2f*>(smem_raw);                      // [F][G::LDS]
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
     float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
+    float (*wave_max)[2][WPF] = wave_sum + F;                                        // [F][2][WPF]
     const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
     const uint32_t blk = blockIdx.x, xcd = blk & 7u, q = blk >> 3;
     const uint32_t s = (q / chunks) * 8u + xcd, chunk = q % chunks;
@@ -580,6 +581,37 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
         const bool inside = ju + (unsigned)T * (unsigned)t < Wn;
         v[t] = v2f{inside ? (xa[t] - mean_a) * w[t] : 0.0f, (inside && has_b) ? (xb[t] - mean_b) * w[t] : 0.0f};
     }
+    // Level equalisation (round 5).  The two columns ride one complex transform, and the split X_a = (Z[k] + conj Z[N-k]) / 2 cancels
+    // column b's spectrum only as far as the computed transform of b is Hermitian — to ~4e-7 of b's LARGEST bin.  A column far below
+    // its partner (an onset, a release: soak seeds 21028002 / 21093005 / 21109003, 97 / 64 / 42 dB apart) therefore came out 211 / 6 / 2
+    // codes off where the reference, one real transform per column, has no such coupling.  Each column is scaled by the power of two
+    // that brings its largest windowed sample to [1, 2) — exact in f32 — and its powers are scaled back by the exact inverse: the
+    // coupling is then relative to comparable levels whatever the columns' own levels were.
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        pa = fmaxf(pa, fabsf(v[t].x));
+        pb = fmaxf(pb, fabsf(v[t].y));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        pa = fmaxf(pa, __shfl_xor(pa, off));
+        pb = fmaxf(pb, __shfl_xor(pb, off));
+    }
+    if ((jf & 63) == 0) {
+        wave_max[fs][0][wf] = pa;
+        wave_max[fs][1][wf] = pb;
+    }
+    frame_sync<LOGN>();
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+        pa = fmaxf(pa, wave_max[fs][0][i]);
+        pb = fmaxf(pb, wave_max[fs][1][i]);
+    }
+    // frexp exponent e: p = m 2^e with m in [0.5, 1); a silent or non-finite column keeps its scale
+    const int ea = (pa > 0.0f && pa < INFINITY) ? __builtin_amdgcn_frexp_expf(pa) : 0, eb = (pb > 0.0f && pb < INFINITY) ? __builtin_amdgcn_frexp_expf(pb) : 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = v2f{ldexpf(v[t].x, -ea), ldexpf(v[t].y, -eb)};
     fftp_inplace<false, LOGN>(v, buf, jf, tw);
     frame_sync<LOGN>();
 #pragma unroll
@@ -596,8 +628,8 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
         const v2f zr = buf[pad16((int)(((unsigned)N - k) & (unsigned)(N - 1)))];
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr) / 2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr) / (2i)
-        out_a[k] = classic_code((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t]);
-        if (has_b) out_b[k] = classic_code((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t]);
+        out_a[k] = classic_code(ldexpf((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t], 2 * ea));
+        if (has_b) out_b[k] = classic_code(ldexpf((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t], 2 * eb));
     }
 }
 
@@ -605,7 +637,7 @@ template <int LOGN>
 static void launch_classic(const StftFastArgs& a, uint16_t* codes, hipStream_t stream) {
     using G = FftGeom<LOGN>;
     constexpr int F = G::FRAMES, WPF = G::T / 64;
-    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 2 * WPF * sizeof(float);
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 4 * WPF * sizeof(float);  // + wave sums, wave maxima
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_classic_pow2_kernel<LOGN>),

@@ -44,6 +44,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // (left, right)
 
 constexpr int STEP = 16;        // frames per staged tile
 constexpr int ROW_FLOATS = 34;  // 16 frames x 2 + 2 pad floats: lanes read their own row with conflict-free ds_read_b64
+// frames per ring exchange of pass B: the three band wavefronts of a workgroup hand their values to one another through LDS so that a lane
+// can store a 16-byte row piece.  8 (round 4): 24.5 KiB of exchange (49 with RMS history) beside 17 KiB of staged tiles = 3 (2)
+// workgroups per CU, and pass B was bound by that occupancy; 4 halves it: 5 (3) workgroups per CU for one more barrier pair per step.
+#ifndef WAVE_XF
+#define WAVE_XF 4
+#endif
+constexpr int XF = WAVE_XF;
 constexpr float kAbsurd = 1.0e18f;  // |sample| beyond this could overflow a squared band value: the sequential kernel's business
 
 // Biquad::process (dsp.rs:422-432), L and R at once, the reference's statement order (the build never contracts: -ffp-contract=off)
@@ -71,7 +78,7 @@ __device__ __forceinline__ float flush20(float v) { return fabsf(v) < 1.0e-20f ?
 // workgroup = (chunk, 64 consecutive streams): every lane of a wavefront sees the same cuts
 template <bool PASS_B>
 __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][ROW_FLOATS], then (pass B) the ring exchange [2 series][8][64][12]
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][ROW_FLOATS], then (pass B) the ring exchange [2 series][XF][64][12]
     if (PASS_B && *a.bad != 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -223,17 +230,17 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
                     }
                 }
                 fresh = false;
-                if ((f & 7) == 0) {
+                if ((f & (XF - 1)) == 0) {
                     half_slot_c = slot_c;
                     half_slot_h = slot_h;
                 }
                 if (chunk_writes_c) {
 #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) xbuf[((f & 7) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = cv[ch];
+                    for (int ch = 0; ch < 4; ++ch) xbuf[((f & (XF - 1)) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = cv[ch];
                 }
                 if (chunk_writes_h) {
 #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) xbuf[((8 + (f & 7)) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = pw[ch];
+                    for (int ch = 0; ch < 4; ++ch) xbuf[((XF + (f & (XF - 1))) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = pw[ch];
                 }
                 slot_c = slot_c + 1u == a.color_len ? 0u : slot_c + 1u;
                 slot_h = slot_h + 1u == a.slow_len ? 0u : slot_h + 1u;
@@ -266,14 +273,14 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
             }
             }
             if constexpr (PASS_B) {
-                // the end of an 8-frame half (or of the chunk): the three bands' values of its frames go to the rings, one row piece per lane
-                if ((chunk_writes_c || chunk_writes_h) && ((f & 7) == 7) && (uint32_t)(f & ~7) < nf) {
+                // the end of an XF-frame piece (or of the chunk): the three bands' values of its frames go to the rings, one row piece per lane
+                if ((chunk_writes_c || chunk_writes_h) && ((f & (XF - 1)) == XF - 1) && (uint32_t)(f & ~(XF - 1)) < nf) {
                     __syncthreads();
-                    const uint32_t g_half = f0 + step * STEP + (uint32_t)(f & ~7);
+                    const uint32_t g_half = f0 + step * STEP + (uint32_t)(f & ~(XF - 1));
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < XF; ++k) {
                         const uint32_t g = g_half + (uint32_t)k;
-                        if ((uint32_t)((f & ~7) + k) >= nf || !mine) continue;
+                        if ((uint32_t)((f & ~(XF - 1)) + k) >= nf || !mine) continue;
                         if (chunk_writes_c && g >= ring_c_from) {
                             uint32_t slot = half_slot_c + (uint32_t)k;
                             slot = slot >= a.color_len ? slot - a.color_len : slot;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
                         if (chunk_writes_h && g >= ring_h_from) {
                             uint32_t slot = half_slot_h + (uint32_t)k;
                             slot = slot >= a.slow_len ? slot - a.slow_len : slot;
-                            *reinterpret_cast<float4*>(hring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + ((8 + k) * 64 + (int)lane) * 12 + (int)role * 4);
+                            *reinterpret_cast<float4*>(hring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)lane) * 12 + (int)role * 4);
                         }
                     }
                     __syncthreads();
@@ -630,7 +637,7 @@ void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream) 
     const uint32_t groups = (a.n_local + 63u) / 64u;
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
     if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_local * 16u + 63u) / 64u), dim3(64), 0, stream, a);
-    const size_t lds_b = lds + (size_t)(a.history ? 2 : 1) * 8 * 64 * 12 * sizeof(float);  // + the ring exchange
+    const size_t lds_b = lds + (size_t)(a.history ? 2 : 1) * XF * 64 * 12 * sizeof(float);  // + the ring exchange
     static std::once_flag attr_once;  // (two host threads may race on the first launch; one device per process, omx.h)
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wave_chunk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

@@ -276,7 +276,9 @@ def conditioned_bar(name, err, fixed, sens, detail=None, plain=True, base=None):
 def arbitrate_reassigned(tag, hip, ora, exact, sample_rate, hop, metrics, fixed):
     """A column that passed through an exemption, judged against exact f64 arithmetic (`exact`: oracle/exact_f64.reassigned_column of the
     samples the oracle computed it from): for every metric in `metrics` (power / freq / time / orphan), |HIP - exact| must be within
-    max(its fixed bar, 2 |oracle - exact|).  The ledger records the ratio."""
+    max(its fixed bar, 2 |oracle - exact|) — `fixed` = the plain bars relative to the loudest column within reach, i.e. WITHOUT the
+    conditioning term: what a column may lean on is the level of its neighbourhood, never the oracle's own instability.  The ledger
+    records the ratio."""
     he = reassigned_column_metrics(hip, exact, sample_rate, hop)
     oe = reassigned_column_metrics(ora, exact, sample_rate, hop)
     for k in metrics:
@@ -309,8 +311,10 @@ def check_reassigned_conditioned(hip, ora, ora_perturbed, sample_rate, hop, tag=
     if needed and exact is not None:
         ex = exact() if callable(exact) else exact
         if ex is not None:
+            # (the fixed bars as the check used them: relative to the loudest column within reach — the product applies the window on the
+            # bins of the un-windowed slice's transform, so its absolute error scales with the loudest sample of the SLICE)
             arbitrate_reassigned(tag, hip, ora, ex, sample_rate, hop, sorted(set(needed)),
-                                 dict(power=BAR_POWER, freq=BAR_FREQ, time=time_bar, orphan=BAR_ORPHAN))
+                                 dict(power=BAR_POWER / scale, freq=BAR_FREQ / scale ** 0.5, time=time_bar / scale ** 0.5, orphan=BAR_ORPHAN / scale))
     return m, s
 
 

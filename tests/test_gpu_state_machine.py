@@ -8,6 +8,7 @@ from openmeters_amd import banks, capi
 from openmeters_amd.capi import (AudioBlock, LoudnessConfig, LoudnessProcessor, SpectrogramConfig, SpectrogramProcessor,
                                  SpectrumConfig, SpectrumProcessor, StereometerConfig, StereometerProcessor, WaveformConfig,
                                  WaveformProcessor)
+import parity
 from parity import (arbitrate_reassigned, bar, check_chunked_rho, check_classic, check_reassigned_conditioned, classic_column_metrics, conditioned_bar,
                     reassigned_column_metrics, stereometer_band_rms, ulp_perturbed)
 from test_gpu_parity import check_trace
@@ -137,7 +138,8 @@ def test_spectrogram_random_operation_sequences(omx, oracle, seed):
                         import exact_f64
                         ex, _ = exact_f64.reassigned_column(block, window_kind=eff.window, window_size=eff.fft_size,
                                                             zero_padding=eff.zero_padding_factor, hop=w.hop_size, sample_rate=rate)
-                        arbitrate_reassigned(tag, h, o, ex.astype(np.float32), rate, w.hop_size, needed, dict(power=1e-5, freq=3e-7, time=t_bar))
+                        arbitrate_reassigned(tag, h, o, ex.astype(np.float32), rate, w.hop_size, needed,
+                                             dict(power=1e-5 / scale, freq=3e-7 / scale ** 0.5, time=t_bar / scale ** 0.5))
                 # a bin present on one side only must sit on the 1e-14 keep-floor (relative to a weak column that is > 1e-8)
                 # ... or on the 0 < f < fs/2 edge of the keep test (a bin whose reassigned frequency sits at 0 or Nyquist)
                 # ... or be no stronger than what the oracle itself gains / loses under the one-ulp perturbation
@@ -419,8 +421,11 @@ def test_ragged_bank_random_per_stream_op_sequences_match_per_stream_oracles(omx
                                 return None
                             return exact_f64.reassigned_column(block, window_kind=cfg.window, window_size=W, zero_padding=1, hop=hop,
                                                                sample_rate=48000.0)[0].astype(np.float32)
+                        # (t-hat is measured in hops and ranges over +- W / (2 hop) of them: its fixed bar was set at W / hop = 16 and scales
+                        # with W / hop beyond, as in test_spectrogram_random_operation_sequences — soak seed 21012323: 4096 / hop 100, HIP
+                        # 1.12e-4 hops from exact f64 on a well-conditioned column)
                         check_reassigned_conditioned(h, o, o2 if len(o2) else o, 48000.0, hop, tag="ragged bank sequences", scale=scale,
-                                                     exact=exact_column)
+                                                     time_bar=parity.BAR_TIME * max(1.0, W / hop / 16.0), exact=exact_column)
             elif up.fft_size in (1024, 2048, 4096, 8192, 16384):
                 check_classic(got, w.new_columns)
             produced += want_cols
