@@ -54,6 +54,7 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
     float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
+    float (*wave_max)[2][WPF] = wave_sum + F;                                        // [F][2][WPF]
     // F == 1 (4096 points): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
     // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
     // exec-mask regions and per-lane 64-bit addresses
@@ -133,6 +134,34 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    // Level equalisation (round 5; see stft_classic_pow2_kernel): the two hops ride one complex transform and the split cancels the
+    // partner's spectrum only to ~4e-7 of ITS largest bin — a hop 60 dB under its partner came out 3e-5 of the trace maximum off
+    // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by the exact power of two that
+    // brings its largest windowed sample to [0.5, 1), and its powers are scaled back by the exact inverse.
+    float pka = 0.0f, pkb = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        pka = fmaxf(pka, fabsf(v[t].x));
+        pkb = fmaxf(pkb, fabsf(v[t].y));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        pka = fmaxf(pka, __shfl_xor(pka, off));
+        pkb = fmaxf(pkb, __shfl_xor(pkb, off));
+    }
+    if ((jf & 63) == 0) {
+        wave_max[fs][0][wf] = pka;
+        wave_max[fs][1][wf] = pkb;
+    }
+    frame_sync<LOGN>();
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+        pka = fmaxf(pka, wave_max[fs][0][i]);
+        pkb = fmaxf(pkb, wave_max[fs][1][i]);
+    }
+    const int ea = (pka > 0.0f && pka < INFINITY) ? __builtin_amdgcn_frexp_expf(pka) : 0, eb = (pkb > 0.0f && pkb < INFINITY) ? __builtin_amdgcn_frexp_expf(pkb) : 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = v2f{ldexpf(v[t].x, -ea), ldexpf(v[t].y, -eb)};
     // per-bin tables: issued before the last pass's butterflies would be ideal, but holding 18 more registers through the
     // transform costs the fourth resident workgroup (128-VGPR line); here they overlap the exchange below
     float norm[9], aw[9];
@@ -164,8 +193,8 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     auto split_power = [&](v2f z, v2f zr, float nrm, float& pa, float& pb) {
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
-        pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * nrm;
-        pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * nrm;
+        pa = ldexpf((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * nrm, 2 * ea);
+        pb = ldexpf((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * nrm, 2 * eb);
     };
     auto levels = [&](float p, float awk, float& wt, float& raw) {  // update_outputs with AveragingMode::None (:391-401), branch-free
         const float db = SPEC_KNOCK == 3 ? p : fast_power_db(p);
@@ -263,8 +292,8 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
         const v2f zr = A[(t == 0 && jf == 0) ? 0 : partner_base - (T + T / 16) * t];
         const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
         const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
-        const float pa = (xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t];
-        const float pb = (xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t];
+        const float pa = ldexpf((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t], 2 * ea);
+        const float pb = ldexpf((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t], 2 * eb);
         if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
             const float db_a = SPEC_KNOCK == 3 ? pa : fast_power_db(pa), db_b = SPEC_KNOCK == 3 ? pb : fast_power_db(pb);
             const bool low_a = pa < a.state_floor, low_b = pb < a.state_floor;
@@ -490,7 +519,7 @@ template <int LOGN>
 static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
     using G = FftGeom<LOGN>;
     constexpr int F = G::FRAMES, WPF = G::T / 64;
-    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 2 * WPF * sizeof(float);
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 4 * WPF * sizeof(float);  // + wave sums, wave maxima
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN>),
