@@ -77,7 +77,15 @@ __device__ __forceinline__ float flush20(float v) { return fabsf(v) < 1.0e-20f ?
 // role 0: low band (LP_low); role 1: mid (HP_low -> LP_high); role 2: high (HP_high) — ThreeBand<Biquad, false> (dsp.rs:473-495)
 // workgroup = (chunk, 64 consecutive streams): every lane of a wavefront sees the same cuts
 template <bool PASS_B>
-__global__ __launch_bounds__(192) void wave_chunk_kernel(WaveChunkArgs a) {
+#ifndef WAVE_WPE
+#define WAVE_WPE 0
+#endif
+#if WAVE_WPE
+#define WAVE_ATTR __attribute__((amdgpu_waves_per_eu(WAVE_WPE, WAVE_WPE)))
+#else
+#define WAVE_ATTR
+#endif
+__global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][ROW_FLOATS], then (pass B) the ring exchange [2 series][XF][64][12]
     if (PASS_B && *a.bad != 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
