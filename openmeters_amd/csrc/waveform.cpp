@@ -497,6 +497,12 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
         ca.hp_lo = wa.hp_lo;
         ca.lp_hi = wa.lp_hi;
         ca.hp_hi = wa.hp_hi;
+        auto widen = [](const BiquadCoef& c) {
+            return WaveChunkArgs::Coef64{{(double)c.b[0], (double)c.b[1], (double)c.b[2]}, {(double)c.a[0], (double)c.a[1]}};
+        };
+        ca.lp_lo64 = widen(wa.lp_lo);
+        ca.hp_lo64 = widen(wa.hp_lo);
+        ca.lp_hi64 = widen(wa.lp_hi);
         ca.history = history ? 1u : 0u;
         ca.chunk_frames = g.C;
         ca.n_chunks = g.n_chunks;

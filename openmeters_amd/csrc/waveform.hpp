@@ -68,6 +68,9 @@ struct WaveChunkArgs {
     uint32_t n_local;            // streams of the group: every scratch array is indexed by the LOCAL stream
     float m00, m10, m01, m11;  // the two-channel fold
     BiquadCoef lp_lo, hp_lo, lp_hi, hp_hi;
+    // the three sections the chunk kernel runs in f64, widened on the host: as kernel arguments they stay in SGPR pairs (converted on
+    // the device they occupied 20 VGPRs)
+    struct Coef64 { double b[3], a[2]; } lp_lo64, hp_lo64, lp_hi64;
     uint32_t history;
     uint32_t chunk_frames, n_chunks;
     uint64_t pushes0;  // tracker pushes before the call

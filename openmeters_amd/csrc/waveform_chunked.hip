@@ -10,7 +10,7 @@
 //   scan     per (stream, band, side): true start state of every chunk, s_{c+1} = T s_c + e_c, T = the C-frame zero-input
 //            transition of the cascade (host, f64) — wave-parallel over the chunks
 //   old      the tracker rings hold the last color_len / slow_len pushed values: their sums between the CUTS of the call (below)
-//   pass B   per (chunk, stream): the filters again from the TRUE start state -> band values -> the trackers' inputs
+//   pass B   per (chunk, stream): the filters again from the TRUE start state (low / mid: f64) -> band values -> the trackers' inputs
 //            (|v| gain, v^2: BandTracker::process :108-121), summed in f64 between cuts; min / max / last sample of the four derived
 //            channels between cuts; the newest ring-length values go to the rings; the last chunk leaves the filter states
 //   prefix   per (stream, value): a double-double running total over the segment sums
@@ -27,8 +27,9 @@
 // The only subtraction — running total at a window's end minus running total at its start — is done in double-double, so a
 // quiet window after a loud passage is as exact as the reference's compensated sum.
 //
-// Not bit-identical to the sequential order: pass B restarts every chunk from the (exact, for the low and mid bands) scanned state rounded to f32, every band value
-// after it differs by ~1e-7 relative, and the window means by less (they average).  Bars: tests/test_gpu_parity_meters.py.
+// Not bit-identical to the sequential order: the low and mid bands follow the f64 recurrence (below), the high band restarts every
+// chunk from a scanned f32 state; band values differ from the reference's f32 evaluation by what THAT is from exact (~1e-6 of
+// the band's level on steady signal, more through a free decay).  Bars: tests/test_gpu_parity_meters.py.
 // min / max fields are bit-identical (a reduction of the same samples).  What is NOT linear — Biquad::process' non-finite reset,
 // the non-finite rules of the trackers and of the min / max state machine — never runs here: `bad` sends the whole call through
 // the sequential kernel (nothing but scratch has been written by then).
@@ -60,8 +61,8 @@ __device__ __forceinline__ v2f biquad_lr(const BiquadCoef& c, v2f& z0, v2f& z1, 
     z1 = c.b[2] * x - c.a[1] * out;
     return out;
 }
-__device__ __forceinline__ void biquad_lr_f64(const BiquadCoef& c, double (&z0)[2], double (&z1)[2], double (&x)[2]) {
-    const double b0 = (double)c.b[0], b1 = (double)c.b[1], b2 = (double)c.b[2], a0 = (double)c.a[0], a1 = (double)c.a[1];
+__device__ __forceinline__ void biquad_lr_f64(const WaveChunkArgs::Coef64& c, double (&z0)[2], double (&z1)[2], double (&x)[2]) {
+    const double b0 = c.b[0], b1 = c.b[1], b2 = c.b[2], a0 = c.a[0], a1 = c.a[1];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
         const double out = __builtin_fma(b0, x[ch], z0[ch]);
@@ -79,6 +80,9 @@ __device__ __forceinline__ float flush20(float v) { return fabsf(v) < 1.0e-20f ?
 template <bool PASS_B>
 #ifndef WAVE_WPE
 #define WAVE_WPE 0
+#endif
+#ifndef WAVE_XGROUP
+#define WAVE_XGROUP 0
 #endif
 #if WAVE_WPE
 #define WAVE_ATTR __attribute__((amdgpu_waves_per_eu(WAVE_WPE, WAVE_WPE)))
@@ -140,24 +144,26 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
     const uint32_t sl = s0 + lane;
     const bool mine = sl < a.n_local;
     const uint32_t s = mine ? (a.stream_map ? a.stream_map[sl] : sl) : 0u;
-    const BiquadCoef ca = a.hp_lo, cb = role == 0 ? a.lp_lo : (role == 1 ? a.lp_hi : a.hp_hi);
-    v2f za0{0.0f, 0.0f}, za1{0.0f, 0.0f}, zb0{0.0f, 0.0f}, zb1{0.0f, 0.0f};  // stage A (mid band only), stage B
-    // pass A, roles 0 and 1 (the bands with a 200 Hz section): f64 — their chunk-boundary states follow the exact trajectory of the
-    // recurrence, and pass B (f32, the reference's precision) restarts every chunk from a state without rounding history.  With f32
-    // boundary states the mid band sat 3 ... 4x further from the f64 recurrence than the reference's own evaluation after level
-    // steps (tests/test_gpu_parity_meters.py, random sequences; the stereometer's low band taught the same in stereometer_chunked.hip)
+    const BiquadCoef cb = a.hp_hi;
+    const WaveChunkArgs::Coef64 ca64 = a.hp_lo64, cb64 = role == 0 ? a.lp_lo64 : a.lp_hi64;
+    v2f zb0{0.0f, 0.0f}, zb1{0.0f, 0.0f};  // the high band's section (f32, the reference's precision: well conditioned)
+    // Roles 0 and 1 (the bands with a 200 Hz section) run in f64 in BOTH passes: a rounding of a DF2T state of such a section
+    // excites its near-double pole (gain fs / (2 pi e 0.707 fc) = 20 at 48 kHz), the reference's own f32 evaluation pays that on
+    // every frame and a chunked f32 evaluation pays it differently — after level steps the two sat up to 5e-5 of the band's level
+    // apart (soak seeds 21051365, 21056365: above the 2e-5 + 3 |oracle - exact| bar).  In f64 this form follows the exact
+    // recurrence (band values rounded to f32 once, where the trackers take them), so its distance to the reference is the
+    // reference's own distance to exact.  Cost: none (v_fma_f64 is full rate on CDNA4; two dependent FMAs per frame against
+    // four dependent f32 operations of the un-contracted statement order).  The filters' states are rounded to f32 once per
+    // call, where the sequential kernels' layout takes them.
     double da0[2] = {0.0, 0.0}, da1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
     float* cs = a.chunk_state + (((uint64_t)c * a.n_local + (mine ? sl : 0u)) * 3u + role) * 16u;
     double* cs64 = reinterpret_cast<double*>(cs);
     if (PASS_B && mine) {  // the chunk's true start state ([state k][side]: role 0 LP z0, z1; role 1 A z0, A z1, B z0, B z1 — f64; role 2 f32)
         if (role == 0) {
-            zb0 = v2f{(float)cs64[0], (float)cs64[1]};
-            zb1 = v2f{(float)cs64[2], (float)cs64[3]};
+            d0[0] = cs64[0]; d0[1] = cs64[1]; d1[0] = cs64[2]; d1[1] = cs64[3];
         } else if (role == 1) {
-            za0 = v2f{(float)cs64[0], (float)cs64[1]};
-            za1 = v2f{(float)cs64[2], (float)cs64[3]};
-            zb0 = v2f{(float)cs64[4], (float)cs64[5]};
-            zb1 = v2f{(float)cs64[6], (float)cs64[7]};
+            da0[0] = cs64[0]; da0[1] = cs64[1]; da1[0] = cs64[2]; da1[1] = cs64[3];
+            d0[0] = cs64[4]; d0[1] = cs64[5]; d1[0] = cs64[6]; d1[1] = cs64[7];
         } else {
             zb0 = v2f{cs[0], cs[1]};
             zb1 = v2f{cs[2], cs[3]};
@@ -201,18 +207,28 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
         v2f x[STEP];
 #pragma unroll
         for (int f = 0; f < STEP; ++f) x[f] = *reinterpret_cast<const v2f*>(rowp + 2 * f);
+#if WAVE_XGROUP
+        // keep the reads (and the f32 -> f64 conversions behind them) of a later XF-frame group from being hoisted over an earlier group's
+        // recurrence: 16 converted frames live at once cost 64 VGPRs
+#define WAVE_GROUP_FENCE(f) if (((f) & (XF - 1)) == 0) __builtin_amdgcn_sched_barrier(0)
+#else
+#define WAVE_GROUP_FENCE(f)
+#endif
         const uint32_t nf = min((uint32_t)STEP, n - step * STEP);  // uniform
 #pragma unroll
         for (int f = 0; f < STEP; ++f) {
+            WAVE_GROUP_FENCE(f);
             if ((uint32_t)f < nf) {
             v2f v = x[f];
-            if (!PASS_B && role != 2) {  // (wave-uniform) the zero-state pass of the low and mid bands in f64: only the end state is used
+            if (role != 2) {  // (wave-uniform) the low and mid bands in f64, both passes (pass A uses the end state only)
                 double xd[2] = {(double)v.x, (double)v.y};
-                if (role == 1) biquad_lr_f64(ca, da0, da1, xd);
-                biquad_lr_f64(cb, d0, d1, xd);
+                if (role == 1) biquad_lr_f64(ca64, da0, da1, xd);
+                biquad_lr_f64(cb64, d0, d1, xd);
+                v = v2f{(float)xd[0], (float)xd[1]};
             } else {
-            if (role == 1) v = biquad_lr(ca, za0, za1, v);
-            v = biquad_lr(cb, zb0, zb1, v);
+                v = biquad_lr(cb, zb0, zb1, v);
+            }
+            {
             if constexpr (PASS_B) {
                 const uint32_t g = f0 + step * STEP + (uint32_t)f;  // frame of the call
                 // bands of Left, Right, Mid, Side (:262-268)
@@ -324,11 +340,16 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
         for (int ch = 0; ch < 4; ++ch) {
             WaveLaneState& st = a.state[(uint64_t)s * 16u + (uint32_t)ch * 3u + role];
             if (role == 1) {
-                st.za[0][0] = flush20(za0.x); st.za[0][1] = flush20(za1.x);
-                st.za[1][0] = flush20(za0.y); st.za[1][1] = flush20(za1.y);
+                st.za[0][0] = flush20((float)da0[0]); st.za[0][1] = flush20((float)da1[0]);
+                st.za[1][0] = flush20((float)da0[1]); st.za[1][1] = flush20((float)da1[1]);
             }
-            st.zb[0][0] = flush20(zb0.x); st.zb[0][1] = flush20(zb1.x);
-            st.zb[1][0] = flush20(zb0.y); st.zb[1][1] = flush20(zb1.y);
+            if (role != 2) {
+                st.zb[0][0] = flush20((float)d0[0]); st.zb[0][1] = flush20((float)d1[0]);
+                st.zb[1][0] = flush20((float)d0[1]); st.zb[1][1] = flush20((float)d1[1]);
+            } else {
+                st.zb[0][0] = flush20(zb0.x); st.zb[0][1] = flush20(zb1.x);
+                st.zb[1][0] = flush20(zb0.y); st.zb[1][1] = flush20(zb1.y);
+            }
         }
     }
 }
