@@ -9,6 +9,7 @@
 #include "buffer_device.hpp"
 #include "fft_pow2_device.hpp"
 #include "stft_kernels.hpp"
+#include "wave_device.hpp"
 
 namespace omx {
 
@@ -39,9 +40,6 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
     }
 }
 
-#ifndef SPEC_WIDE  // 1: four bins per thread and 16-byte row stores (default); 0: the bin-per-lane epilogue of rounds 1-3 (A/B)
-#define SPEC_WIDE 1
-#endif
 #ifndef SPEC_KNOCK  // pricing builds (WRONG rows): 1 no stores, 2 no transform, 3 no dB arithmetic
 #define SPEC_KNOCK 0
 #endif
@@ -53,8 +51,7 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
-    float (*wave_sum)[2][WPF] = reinterpret_cast<float (*)[2][WPF]>(tw2_lds + 256);  // [F][2][WPF]
-    float (*wave_max)[2][WPF] = wave_sum + F;                                        // [F][2][WPF]
+    float (*wave_red)[6][WPF] = reinterpret_cast<float (*)[6][WPF]>(tw2_lds + 256);  // [F][sum a, sum b, max a, max b, min a, min b][WPF]
     // F == 1 (4096 points): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
     // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
     // exec-mask regions and per-lane 64-bit addresses
@@ -74,25 +71,28 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     const char* ring = reinterpret_cast<const char*>(a.ring[tr] + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;  // cap <= 2^30 (host-checked)
     const uint32_t p32 = (uint32_t)(spectrum_tail(a, s) + (uint64_t)(a.first_hop + h0) * a.hop);
-    float xa[16], xb[16], w[16];
+    v2f x[16];  // (.x: hop 2p, .y: hop 2p + 1) — the pair the complex transform carries, and the operand layout of the packed f32 instructions
+    float w[16];
     // Buffer-addressed loads (buffer_device.hpp) while both hops' windows lie in one piece of the ring: one per-lane byte offset and
     // scalar steps instead of a masked 32-bit index + 64-bit address per load (3 VALU per load, 96 per thread, of the kernel's 923)
     const uint32_t off0 = (uint32_t)(((uint64_t)p32 << 2) & bytemask) >> 2;
     const uint32_t hop_bytes = (uint32_t)a.hop * 4u;
     const bool direct = F == 1 && (uint64_t)off0 + (has_b ? (uint64_t)a.hop : 0ull) + (uint64_t)N <= a.cap;
     if (direct) {
-        const GlobalBuffer ringb = global_buffer(ring + (uint64_t)off0 * 4u, (has_b ? hop_bytes : 0u) + (uint32_t)N * 4u);
+        // (hop b through a descriptor of its own: 0 bytes long when the pair has no second hop — every load then returns 0, no branch)
+        const GlobalBuffer ringb = global_buffer(ring + (uint64_t)off0 * 4u, (uint32_t)N * 4u);
+        const GlobalBuffer ringb2 = global_buffer(ring + (uint64_t)off0 * 4u + hop_bytes, has_b ? (uint32_t)N * 4u : 0u);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            xa[t] = load_f32(ringb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
-            xb[t] = has_b ? load_f32(ringb, ju * 4u, hop_bytes + 4u * (unsigned)T * (unsigned)t) : 0.0f;  // (has_b: uniform)
+            x[t].x = load_f32(ringb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
+            x[t].y = load_f32(ringb2, ju * 4u, 4u * (unsigned)T * (unsigned)t);
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const uint32_t q = p32 + ju + (unsigned)T * (unsigned)t;
-            xa[t] = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
-            xb[t] = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
+            x[t].x = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
+            x[t].y = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
         }
     }
     if (F == 1) {
@@ -107,82 +107,74 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     tw.tw2 = tw2_lds;
     tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N
     if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
-    float sa = 0.0f, sb = 0.0f;
+    // One reduction round for everything the hop's conditioning needs: the sum (window.rs:80-84 mean; tree order here, the generic
+    // kernel keeps the sequential order) and the largest / smallest sample of each hop (level equalisation, below).
+    v2f sum = x[0] + x[1];
+    float hi_a = wave::vmax(x[0].x, x[1].x), lo_a = wave::vmin(x[0].x, x[1].x), hi_b = wave::vmax(x[0].y, x[1].y), lo_b = wave::vmin(x[0].y, x[1].y);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        sa += xa[t];
-        sb += xb[t];
+    for (int t = 2; t < 16; t += 2) {
+        sum += x[t];
+        sum += x[t + 1];
+        hi_a = wave::vmax3(hi_a, x[t].x, x[t + 1].x);
+        lo_a = wave::vmin3(lo_a, x[t].x, x[t + 1].x);
+        hi_b = wave::vmax3(hi_b, x[t].y, x[t + 1].y);
+        lo_b = wave::vmin3(lo_b, x[t].y, x[t + 1].y);
     }
-    // window.rs:80-84 mean (tree order here; the generic kernel keeps the sequential order)
+    float sum_a = sum.x, sum_b = sum.y;
+    wave::scan_sum2_max2_min2(sum_a, sum_b, hi_a, hi_b, lo_a, lo_b);
+    const float red[6] = {sum_a, sum_b, hi_a, hi_b, lo_a, lo_b};
+    if ((jf & 63) == 63) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sa += __shfl_xor(sa, off);
-        sb += __shfl_xor(sb, off);
+        for (int q = 0; q < 6; ++q) wave_red[fs][q][wf] = red[q];
     }
-    if ((jf & 63) == 0) {
-        wave_sum[fs][0][wf] = sa;
-        wave_sum[fs][1][wf] = sb;
-    }
-    __syncthreads();  // wave sums and tw2_lds (shared by every frame slot)
+    __syncthreads();  // wave partials and tw2_lds (shared by every frame slot)
     float ta = 0.0f, tb = 0.0f;
+    hi_a = hi_b = -INFINITY;
+    lo_a = lo_b = INFINITY;
 #pragma unroll
     for (int i = 0; i < WPF; ++i) {
-        ta += wave_sum[fs][0][i];
-        tb += wave_sum[fs][1][i];
+        ta += wave_red[fs][0][i];
+        tb += wave_red[fs][1][i];
+        hi_a = wave::vmax(hi_a, wave_red[fs][2][i]);
+        hi_b = wave::vmax(hi_b, wave_red[fs][3][i]);
+        lo_a = wave::vmin(lo_a, wave_red[fs][4][i]);
+        lo_b = wave::vmin(lo_b, wave_red[fs][5][i]);
     }
-    const float mean_a = ta / (float)N, mean_b = tb / (float)N;
-    v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = v2f{(xa[t] - mean_a) * w[t], (xb[t] - mean_b) * w[t]};
+    const v2f mean{ta / (float)N, tb / (float)N};
     // Level equalisation (round 5; see stft_classic_pow2_kernel): the two hops ride one complex transform and the split cancels the
     // partner's spectrum only to ~4e-7 of ITS largest bin — a hop 60 dB under its partner came out 3e-5 of the trace maximum off
-    // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by the exact power of two that
-    // brings its largest windowed sample to [0.5, 1), and its powers are scaled back by the exact inverse.
-    float pka = 0.0f, pkb = 0.0f;
+    // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by an exact power of two that
+    // brings it to unit level — 2^-e, e = the exponent of its sample RANGE (max - min: within a factor 2 of the largest |x - mean|,
+    // and known before the mean is subtracted) — and its powers are scaled back by the exact inverse.  The scale rides the
+    // DC removal: fma(x, 2^-e, -mean 2^-e) = (x - mean) 2^-e bit for bit (both products are exact), so the conditioning of a sample
+    // is one packed FMA and one packed multiply by the window for both hops.  |e| <= 60 keeps 4^e a normal f32: levels beyond
+    // 2^+-60 are not audio, and are equalised as far as that.
+    const float range_a = hi_a - lo_a, range_b = hi_b - lo_b;
+    int ea = (range_a > 0.0f && range_a < INFINITY) ? __builtin_amdgcn_frexp_expf(range_a) : 0;
+    int eb = (range_b > 0.0f && range_b < INFINITY) ? __builtin_amdgcn_frexp_expf(range_b) : 0;
+    ea = min(max(ea, -60), 60);
+    eb = min(max(eb, -60), 60);
+    const v2f scale{wave::pow2f(-ea), wave::pow2f(-eb)};
+    const v2f shift = -(mean * scale);
+    v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        pka = fmaxf(pka, fabsf(v[t].x));
-        pkb = fmaxf(pkb, fabsf(v[t].y));
+        const v2f centred{__builtin_fmaf(x[t].x, scale.x, shift.x), __builtin_fmaf(x[t].y, scale.y, shift.y)};
+        v[t] = centred * v2f{w[t], w[t]};
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        pka = fmaxf(pka, __shfl_xor(pka, off));
-        pkb = fmaxf(pkb, __shfl_xor(pkb, off));
-    }
-    if ((jf & 63) == 0) {
-        wave_max[fs][0][wf] = pka;
-        wave_max[fs][1][wf] = pkb;
-    }
-    frame_sync<LOGN>();
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) {
-        pka = fmaxf(pka, wave_max[fs][0][i]);
-        pkb = fmaxf(pkb, wave_max[fs][1][i]);
-    }
-    const int ea = (pka > 0.0f && pka < INFINITY) ? __builtin_amdgcn_frexp_expf(pka) : 0, eb = (pkb > 0.0f && pkb < INFINITY) ? __builtin_amdgcn_frexp_expf(pkb) : 0;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = v2f{ldexpf(v[t].x, -ea), ldexpf(v[t].y, -eb)};
-    // per-bin tables: issued before the last pass's butterflies would be ideal, but holding 18 more registers through the
-    // transform costs the fourth resident workgroup (128-VGPR line); here they overlap the exchange below
-    float norm[9], aw[9];
     if (SPEC_KNOCK != 2) fftp_inplace<false, LOGN>(v, A, jf, tw);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const unsigned k = (t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u;
-        norm[t] = a.bin_norm[k];
-        aw[t] = a.fused_db ? a.a_weighting_db[k] : 0.0f;
-    }
     frame_sync<LOGN>();
     const int own_base = pad16(jf);  // pad16(j + T t) = pad16(j) + (T + T / 16) t
 #pragma unroll
     for (int t = 0; t < 16; ++t) A[own_base + (T + T / 16) * t] = v[t];
     frame_sync<LOGN>();
     if (!in_range) return;
-#if SPEC_WIDE
     // Epilogue, FOUR consecutive bins per thread and round (bins 4 j ... 4 j + 3, then 4 T + 4 j ...; thread 0 adds the Nyquist bin): every
     // row is written by 16-byte stores — a wavefront moves 1 KiB per store instruction where the bin-per-lane order moved 256 B.
-    // The step writes 1.07 GB of rows (configs[1]); with 33 four-byte stores per thread the kernel spent 0.15 of its 0.42 ms
-    // issuing them (knock-out build), not moving them.  Both Z[k] and its partner now come from the natural-order copy.
+    // Both Z[k] and its partner come from the natural-order copy.  The split keeps the (hop a, hop b) pair in one register pair:
+    //   U = Z + Zr = 2 (Re Xa, Re Xb),   V = (Z.y - Zr.y, Zr.x - Z.x) = 2 (Im Xa, Im Xb),   P = U U + V V = 4 (|Xa|^2, |Xb|^2)
+    // and the factors 1/4, 4^ea / 4^eb (the level equalisation undone) and the bin's normalisation are exact powers of two times
+    // one rounding: P * norm * (4^e / 4) rounds where (|X|^2 norm) rounded before.
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // rows start at multiples of `bins` floats: 4-byte alignment only
     float* out0 = nullptr;
     if (a.fused_db)
@@ -190,17 +182,24 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
     float* pw = a.fused_db ? nullptr : a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
     const bool write_a = a.emit_all || h0 + 1 == n_hops_s, write_b = has_b && (a.emit_all || h0 + 2 == n_hops_s);
-    auto split_power = [&](v2f z, v2f zr, float nrm, float& pa, float& pb) {
-        const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
-        const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
-        pa = ldexpf((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * nrm, 2 * ea);
-        pb = ldexpf((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * nrm, 2 * eb);
+    const v2f unscale{wave::pow2f(2 * ea - 2), wave::pow2f(2 * eb - 2)};
+    const float floor_v = a.floor_db;
+    auto split_power = [&](v2f z, v2f zr, float nrm) -> v2f {
+        const v2f u = z + zr;
+        const v2f q{z.y - zr.y, zr.x - z.x};
+        const v2f p = u * u + q * q;
+        return (p * v2f{nrm, nrm}) * unscale;
     };
-    auto levels = [&](float p, float awk, float& wt, float& raw) {  // update_outputs with AveragingMode::None (:391-401), branch-free
-        const float db = SPEC_KNOCK == 3 ? p : fast_power_db(p);
-        const bool low = p < a.state_floor;
-        raw = low ? a.floor_db : fmaxf(db, a.floor_db);
-        wt = low ? a.floor_db : fmaxf(db + awk, a.floor_db);
+    // update_outputs with AveragingMode::None (:391-401): a power under the state floor shows the floor in both rows — taken as
+    // log(0) = -inf here, which the two max() turn into the floor (and -inf + A-weighting stays -inf)
+    auto levels = [&](v2f p, float awk, float& wt_a, float& raw_a, float& wt_b, float& raw_b) {
+        const v2f kept{p.x < a.state_floor ? 0.0f : p.x, p.y < a.state_floor ? 0.0f : p.y};
+        const v2f db = v2f{__builtin_amdgcn_logf(kept.x), __builtin_amdgcn_logf(kept.y)} * v2f{3.0102999566f, 3.0102999566f};
+        const v2f dbw = db + v2f{awk, awk};
+        raw_a = wave::vmax(db.x, floor_v);
+        raw_b = wave::vmax(db.y, floor_v);
+        wt_a = wave::vmax(dbw.x, floor_v);
+        wt_b = wave::vmax(dbw.y, floor_v);
     };
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -215,11 +214,10 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
 #pragma unroll
         for (int c = 1; c < 4; ++c) zr[c] = A[pb3 + 4 - c];
         const float4 nrm = *reinterpret_cast<const float4*>(a.bin_norm + k0);
-        float pa[4], pb[4];
-        split_power(z[0], zr[0], nrm.x, pa[0], pb[0]);
-        split_power(z[1], zr[1], nrm.y, pa[1], pb[1]);
-        split_power(z[2], zr[2], nrm.z, pa[2], pb[2]);
-        split_power(z[3], zr[3], nrm.w, pa[3], pb[3]);
+        const float nrmv[4] = {nrm.x, nrm.y, nrm.z, nrm.w};
+        v2f p[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = split_power(z[c], zr[c], nrmv[c]);
         if (a.fused_db) {
             const float4 aw = *reinterpret_cast<const float4*>(a.a_weighting_db + k0);
             const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
@@ -227,8 +225,7 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float w0, r0, w1, r1;
-                levels(pa[c], awv[c], w0, r0);
-                levels(pb[c], awv[c], w1, r1);
+                levels(p[c], awv[c], w0, r0, w1, r1);
                 wt_a[c] = w0;
                 raw_a[c] = r0;
                 wt_b[c] = w1;
@@ -249,20 +246,17 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
                 *reinterpret_cast<f4u*>(out0 + hop_stride + a.bins + k0) = raw_b;
             }
         } else {
-            *reinterpret_cast<f4u*>(pw + k0) = f4u{pa[0], pa[1], pa[2], pa[3]};
-            if (has_b) *reinterpret_cast<f4u*>(pw + a.bins + k0) = f4u{pb[0], pb[1], pb[2], pb[3]};
+            *reinterpret_cast<f4u*>(pw + k0) = f4u{p[0].x, p[1].x, p[2].x, p[3].x};
+            if (has_b) *reinterpret_cast<f4u*>(pw + a.bins + k0) = f4u{p[0].y, p[1].y, p[2].y, p[3].y};
         }
     }
     if (jf == 0) {  // Nyquist bin N / 2 pairs with itself
         const uint32_t k = (unsigned)N / 2u;
         const v2f z = A[pad16(N / 2)];
-        float pa, pb;
-        split_power(z, z, a.bin_norm[k], pa, pb);
+        const v2f pn = split_power(z, z, a.bin_norm[k]);
         if (a.fused_db) {
             float w0, r0, w1, r1;
-            const float awk = a.a_weighting_db[k];
-            levels(pa, awk, w0, r0);
-            levels(pb, awk, w1, r1);
+            levels(pn, a.a_weighting_db[k], w0, r0, w1, r1);
             if (write_a && SPEC_KNOCK != 1) {
                 out0[k] = w0;
                 out0[a.bins + k] = r0;
@@ -272,54 +266,10 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
                 out0[hop_stride + a.bins + k] = r1;
             }
         } else {
-            pw[k] = pa;
-            if (has_b) pw[a.bins + k] = pb;
+            pw[k] = pn.x;
+            if (has_b) pw[a.bins + k] = pn.y;
         }
     }
-#else
-    const int partner_base = pad16(jf == 0 ? N : N - jf);
-    float* out0 = nullptr;
-    if (a.fused_db)
-        out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
-    const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t == 8 && jf != 0) break;
-        const uint32_t k = ju + (unsigned)T * (unsigned)t;
-        const v2f z = v[t];
-        // partner bin N - k = (N - j) - T t: pad16 is linear over multiples of 16, so its slot is one base + a compile-time offset
-        // (bin 0 pairs with itself)
-        const v2f zr = A[(t == 0 && jf == 0) ? 0 : partner_base - (T + T / 16) * t];
-        const v2f xa_k{(z.x + zr.x) * 0.5f, (z.y - zr.y) * 0.5f};  // (Z + conj Zr)/2
-        const v2f xb_k{(z.y + zr.y) * 0.5f, (zr.x - z.x) * 0.5f};  // (Z - conj Zr)/(2i)
-        const float pa = ldexpf((xa_k.x * xa_k.x + xa_k.y * xa_k.y) * norm[t], 2 * ea);
-        const float pb = ldexpf((xb_k.x * xb_k.x + xb_k.y * xb_k.y) * norm[t], 2 * eb);
-        if (a.fused_db) {  // update_outputs with AveragingMode::None (:391-401), branch-free
-            const float db_a = SPEC_KNOCK == 3 ? pa : fast_power_db(pa), db_b = SPEC_KNOCK == 3 ? pb : fast_power_db(pb);
-            const bool low_a = pa < a.state_floor, low_b = pb < a.state_floor;
-            const float raw_a = low_a ? a.floor_db : fmaxf(db_a, a.floor_db), wt_a = low_a ? a.floor_db : fmaxf(db_a + aw[t], a.floor_db);
-            const float raw_b = low_b ? a.floor_db : fmaxf(db_b, a.floor_db), wt_b = low_b ? a.floor_db : fmaxf(db_b + aw[t], a.floor_db);
-            // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
-            // a ragged call launches every hop and the stream's last one writes
-            if (SPEC_KNOCK == 1) {
-                if (wt_a + raw_a + wt_b + raw_b == 1.2345f) out0[k] = wt_a;
-                continue;
-            }
-            if (a.emit_all || h0 + 1 == n_hops_s) {
-                out0[k] = wt_a;
-                out0[a.bins + k] = raw_a;
-            }
-            if (has_b && (a.emit_all || h0 + 2 == n_hops_s)) {
-                out0[hop_stride + k] = wt_b;
-                out0[hop_stride + a.bins + k] = raw_b;
-            }
-        } else {
-            float* pw = a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
-            pw[k] = pa;
-            if (has_b) pw[a.bins + k] = pb;
-        }
-    }
-#endif
 }
 
 template <int LOGN>
@@ -519,7 +469,7 @@ template <int LOGN>
 static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
     using G = FftGeom<LOGN>;
     constexpr int F = G::FRAMES, WPF = G::T / 64;
-    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 4 * WPF * sizeof(float);  // + wave sums, wave maxima
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 6 * WPF * sizeof(float);  // + the wave partials (sum, max, min of both hops)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN>),

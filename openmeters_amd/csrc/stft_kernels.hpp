@@ -231,8 +231,16 @@ struct SpectrumPowerArgs {
     const uint64_t* tails;
     const uint32_t* hops;
 };
-__device__ __forceinline__ uint64_t spectrum_tail(const SpectrumPowerArgs& a, uint32_t s) { return a.tails ? a.tails[s] : a.tail; }
-__device__ __forceinline__ uint32_t spectrum_hops(const SpectrumPowerArgs& a, uint32_t s) { return a.hops ? a.hops[s] : a.n_hops; }
+// (s is workgroup-uniform at every call site; the per-stream values are LOADED, which makes them divergent for the compiler — every
+// predicate and address derived from them became exec-mask regions and per-lane arithmetic.  Pinned to SGPRs here.)
+__device__ __forceinline__ uint64_t spectrum_tail(const SpectrumPowerArgs& a, uint32_t s) {
+    const uint64_t t = a.tails ? a.tails[s] : a.tail;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t spectrum_hops(const SpectrumPowerArgs& a, uint32_t s) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.hops ? a.hops[s] : a.n_hops));
+}
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream);
 
 struct SpectrumLevelsArgs {
