@@ -26,6 +26,10 @@ struct FftGeom {
 // Barrier between the threads of ONE transform.  With T = 64 a transform lives in a single wavefront, whose LDS
 // instructions execute in order: no s_barrier is needed, only a fence that keeps the compiler from reordering the LDS
 // accesses — the 4 transforms of a workgroup then run free of each other.
+// Workgroup barrier for kernels whose threads exchange data through LDS only: waits for this wavefront's LDS traffic and leaves its global
+// loads and stores in flight.  __syncthreads() also drains vmcnt — every table load issued ahead of use, every point / row store — at each call.
+__device__ __forceinline__ void lds_workgroup_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int LOGN>
 __device__ __forceinline__ void frame_sync() {
     if constexpr (FftGeom<LOGN>::T == 64) {
@@ -33,7 +37,13 @@ __device__ __forceinline__ void frame_sync() {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
+#ifdef OMX_FRAME_SYNC_LDS_ONLY
+        // (a translation unit whose transforms exchange data through LDS only: the barrier waits for this wavefront's LDS traffic and
+        // leaves its global loads and stores in flight — __syncthreads() drains those too, vmcnt(0), at every pass of the transform)
+        lds_workgroup_barrier();
+#else
         __syncthreads();
+#endif
     }
 }
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "buffer_device.hpp"
+#define OMX_FRAME_SYNC_LDS_ONLY 1  // this file's pow2 transforms exchange data through LDS only (fft_pow2_device.hpp: frame_sync)
 #include "fft_pow2_device.hpp"
 #include "stft_kernels.hpp"
 #include "wave_device.hpp"
@@ -40,61 +41,77 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
     }
 }
 
-#ifndef SPEC_KNOCK  // pricing builds (WRONG rows): 1 no stores, 2 no transform, 3 no dB arithmetic
+#ifndef SPEC_KNOCK  // pricing builds (WRONG rows): 1 no stores, 2 no transform, 4 no ring loads
 #define SPEC_KNOCK 0
 #endif
-#ifndef SPEC_P  // hop pairs (F == 1) a workgroup runs one after the other: the row stores of one pair drain behind the loads and butterflies of the next
-#define SPEC_P 1
+#ifndef SPEC_NT  // 1 = non-temporal row stores (A/B: -3 % of the kernel)
+#define SPEC_NT 1
 #endif
-template <int LOGN>
+// One workgroup = F hop pairs of one (stream, trace), one complex transform each.
+// Tried and dropped (round 5, ledger SP-pipe): a persistent workgroup over 4 ... 32 consecutive pairs, software-pipelined across the pair
+// boundary (next pair's samples and this pair's tables loaded ahead of this pair's row stores, no conditional store so that hipcc's
+// static s_waitcnt placement keeps the stores in flight, hop == T sliding window of 17 registers) — 1-2 % at equal occupancy: the
+// kernel is not waiting at its workgroup edges.
+template <int LOGN, bool FUSED>
 __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs& a, uint32_t s, uint32_t tr, uint32_t chunk, v2f* lds) {
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
     float (*wave_red)[6][WPF] = reinterpret_cast<float (*)[6][WPF]>(tw2_lds + 256);  // [F][sum a, sum b, max a, max b, min a, min b][WPF]
-    // F == 1 (4096 points): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
+    // F == 1 (4096 points and up): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
     // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
     // exec-mask regions and per-lane 64-bit addresses
-    const int fs = F == 1 ? 0 : (int)(threadIdx.x / T), jf = F == 1 ? (int)threadIdx.x : (int)(threadIdx.x % T), wf = jf >> 6;
-    unsigned ju = (unsigned)jf;
-    if (SPEC_P > 1) asm volatile("" : "+v"(ju));  // per pair: keeps the table loads of the loop's pairs from being hoisted into 90 more registers
+    const int fs = F == 1 ? 0 : (int)(threadIdx.x / T), jf = F == 1 ? (int)threadIdx.x : (int)(threadIdx.x % T);
+    const unsigned ju = (unsigned)jf;
     v2f* A = lds + fs * G::LDS;
     const uint32_t n_hops_s = spectrum_hops(a, s), pairs_s = (n_hops_s + 1) / 2;  // ragged banks: this stream's own hop count
     if (chunk * F >= pairs_s) return;  // (whole workgroup)
-    const uint32_t pair_raw = chunk * F + (uint32_t)fs;
-    const bool in_range = pair_raw < pairs_s;
-    const uint32_t pr = in_range ? pair_raw : pairs_s - 1u;  // idle slots shadow the last pair (barriers stay uniform)
-    const uint32_t h0 = 2 * pr;
-    const bool has_b = h0 + 1 < n_hops_s;
-    // every global load of the workgroup is issued up front (unsigned 32-bit offsets: SGPR base + VGPR offset
-    // addressing), so one memory round trip covers the ring, the window, the twiddles and the per-bin tables
     const char* ring = reinterpret_cast<const char*>(a.ring[tr] + (uint64_t)s * a.cap);
     const uint32_t bytemask = (uint32_t)(a.cap - 1) << 2;  // cap <= 2^30 (host-checked)
-    const uint32_t p32 = (uint32_t)(spectrum_tail(a, s) + (uint64_t)(a.first_hop + h0) * a.hop);
-    v2f x[16];  // (.x: hop 2p, .y: hop 2p + 1) — the pair the complex transform carries, and the operand layout of the packed f32 instructions
-    float w[16];
-    // Buffer-addressed loads (buffer_device.hpp) while both hops' windows lie in one piece of the ring: one per-lane byte offset and
-    // scalar steps instead of a masked 32-bit index + 64-bit address per load (3 VALU per load, 96 per thread, of the kernel's 923)
-    const uint32_t off0 = (uint32_t)(((uint64_t)p32 << 2) & bytemask) >> 2;
+    const uint32_t ring_bytes = (uint32_t)min((uint64_t)a.cap * 4u, (uint64_t)0xFFFFFFFCu);
+    const uint64_t tail = spectrum_tail(a, s);
     const uint32_t hop_bytes = (uint32_t)a.hop * 4u;
-    const bool direct = F == 1 && (uint64_t)off0 + (has_b ? (uint64_t)a.hop : 0ull) + (uint64_t)N <= a.cap;
-    if (direct) {
-        // (hop b through a descriptor of its own: 0 bytes long when the pair has no second hop — every load then returns 0, no branch)
-        const GlobalBuffer ringb = global_buffer(ring + (uint64_t)off0 * 4u, (uint32_t)N * 4u);
-        const GlobalBuffer ringb2 = global_buffer(ring + (uint64_t)off0 * 4u + hop_bytes, has_b ? (uint32_t)N * 4u : 0u);
+    v2f x[16];  // (.x: hop 2p, .y: hop 2p + 1) at element j + T t — the pair the complex transform carries, and the operand layout of the packed f32 instructions
+    auto pair_of = [&](uint32_t chunk, uint32_t& h0, bool& has_b, bool& in_range) {
+        const uint32_t pair_raw = chunk * F + (uint32_t)fs;
+        in_range = pair_raw < pairs_s;
+        h0 = 2 * (in_range ? pair_raw : pairs_s - 1u);  // idle slots shadow the last pair (barriers stay uniform)
+        has_b = h0 + 1 < n_hops_s;
+    };
+    // every global load of a pair is issued in one go.  Buffer-addressed (buffer_device.hpp): one per-lane byte offset and scalar steps
+    // while both hops' windows lie in one piece of the ring, per-element wrapped offsets into a descriptor of the whole ring when the
+    // window wraps around its end.  Hop b through a descriptor of its own: 0 bytes long when the pair has no second hop — every load
+    // then returns 0, no branch.
+    auto load_pair = [&](uint32_t chunk, unsigned jl) {
+        uint32_t h0;
+        bool has_b, in_range;
+        pair_of(chunk, h0, has_b, in_range);
+        const uint32_t p32 = (uint32_t)(tail + (uint64_t)(a.first_hop + h0) * a.hop);
+        const uint32_t off0 = (uint32_t)(((uint64_t)p32 << 2) & bytemask) >> 2;
+        const bool direct = F == 1 && (uint64_t)off0 + (has_b ? (uint64_t)a.hop : 0ull) + (uint64_t)N <= a.cap;
+        if (SPEC_KNOCK == 4) {  // pricing build: no ring loads
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            x[t].x = load_f32(ringb, ju * 4u, 4u * (unsigned)T * (unsigned)t);
-            x[t].y = load_f32(ringb2, ju * 4u, 4u * (unsigned)T * (unsigned)t);
-        }
-    } else {
+            for (int t = 0; t < 16; ++t) x[t] = v2f{(float)(jl + 3u * (unsigned)t) * 1e-4f, (float)(jl ^ (unsigned)t) * 1e-4f};
+        } else if (direct) {
+            const GlobalBuffer ra = global_buffer(ring + (uint64_t)off0 * 4u, (uint32_t)N * 4u);
+            const GlobalBuffer rb = global_buffer(ring + (uint64_t)off0 * 4u + hop_bytes, has_b ? (uint32_t)N * 4u : 0u);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t q = p32 + ju + (unsigned)T * (unsigned)t;
-            x[t].x = *reinterpret_cast<const float*>(ring + ((q << 2) & bytemask));
-            x[t].y = has_b ? *reinterpret_cast<const float*>(ring + (((q + a.hop) << 2) & bytemask)) : 0.0f;
+            for (int t = 0; t < 16; ++t) {
+                x[t].x = load_f32(ra, jl * 4u, 4u * (unsigned)T * (unsigned)t);
+                x[t].y = load_f32(rb, jl * 4u, 4u * (unsigned)T * (unsigned)t);
+            }
+        } else {
+            const GlobalBuffer ra = global_buffer(ring, ring_bytes), rb = global_buffer(ring, has_b ? ring_bytes : 0u);
+            const uint32_t q0 = (p32 + jl) << 2, q1 = q0 + hop_bytes;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                x[t].x = load_f32(ra, (q0 + 4u * (unsigned)T * (unsigned)t) & bytemask, 0u);
+                x[t].y = load_f32(rb, (q1 + 4u * (unsigned)T * (unsigned)t) & bytemask, 0u);
+            }
         }
-    }
+    };
+    load_pair(chunk, ju);
+    float w[16];
     if (F == 1) {
         const GlobalBuffer winb = global_buffer(a.window, (uint32_t)N * 4u);
 #pragma unroll
@@ -103,196 +120,217 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
 #pragma unroll
         for (int t = 0; t < 16; ++t) w[t] = a.window[ju + (unsigned)T * (unsigned)t];
     }
-    TwiddlesPow2<LOGN> tw;
-    tw.tw2 = tw2_lds;
-    tw.load(a.tw4096, ju);  // exp(-2 pi i k / N) for this N
     if (threadIdx.x < 256) tw2_lds[threadIdx.x] = a.tw256[threadIdx.x];
-    // One reduction round for everything the hop's conditioning needs: the sum (window.rs:80-84 mean; tree order here, the generic
-    // kernel keeps the sequential order) and the largest / smallest sample of each hop (level equalisation, below).
-    v2f sum = x[0] + x[1];
-    float hi_a = wave::vmax(x[0].x, x[1].x), lo_a = wave::vmin(x[0].x, x[1].x), hi_b = wave::vmax(x[0].y, x[1].y), lo_b = wave::vmin(x[0].y, x[1].y);
-#pragma unroll
-    for (int t = 2; t < 16; t += 2) {
-        sum += x[t];
-        sum += x[t + 1];
-        hi_a = wave::vmax3(hi_a, x[t].x, x[t + 1].x);
-        lo_a = wave::vmin3(lo_a, x[t].x, x[t + 1].x);
-        hi_b = wave::vmax3(hi_b, x[t].y, x[t + 1].y);
-        lo_b = wave::vmin3(lo_b, x[t].y, x[t + 1].y);
-    }
-    float sum_a = sum.x, sum_b = sum.y;
-    wave::scan_sum2_max2_min2(sum_a, sum_b, hi_a, hi_b, lo_a, lo_b);
-    const float red[6] = {sum_a, sum_b, hi_a, hi_b, lo_a, lo_b};
-    if ((jf & 63) == 63) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) wave_red[fs][q][wf] = red[q];
-    }
-    __syncthreads();  // wave partials and tw2_lds (shared by every frame slot)
-    float ta = 0.0f, tb = 0.0f;
-    hi_a = hi_b = -INFINITY;
-    lo_a = lo_b = INFINITY;
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) {
-        ta += wave_red[fs][0][i];
-        tb += wave_red[fs][1][i];
-        hi_a = wave::vmax(hi_a, wave_red[fs][2][i]);
-        hi_b = wave::vmax(hi_b, wave_red[fs][3][i]);
-        lo_a = wave::vmin(lo_a, wave_red[fs][4][i]);
-        lo_b = wave::vmin(lo_b, wave_red[fs][5][i]);
-    }
-    const v2f mean{ta / (float)N, tb / (float)N};
-    // Level equalisation (round 5; see stft_classic_pow2_kernel): the two hops ride one complex transform and the split cancels the
-    // partner's spectrum only to ~4e-7 of ITS largest bin — a hop 60 dB under its partner came out 3e-5 of the trace maximum off
-    // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by an exact power of two that
-    // brings it to unit level — 2^-e, e = the exponent of its sample RANGE (max - min: within a factor 2 of the largest |x - mean|,
-    // and known before the mean is subtracted) — and its powers are scaled back by the exact inverse.  The scale rides the
-    // DC removal: fma(x, 2^-e, -mean 2^-e) = (x - mean) 2^-e bit for bit (both products are exact), so the conditioning of a sample
-    // is one packed FMA and one packed multiply by the window for both hops.  |e| <= 60 keeps 4^e a normal f32: levels beyond
-    // 2^+-60 are not audio, and are equalised as far as that.
-    const float range_a = hi_a - lo_a, range_b = hi_b - lo_b;
-    int ea = (range_a > 0.0f && range_a < INFINITY) ? __builtin_amdgcn_frexp_expf(range_a) : 0;
-    int eb = (range_b > 0.0f && range_b < INFINITY) ? __builtin_amdgcn_frexp_expf(range_b) : 0;
-    ea = min(max(ea, -60), 60);
-    eb = min(max(eb, -60), 60);
-    const v2f scale{wave::pow2f(-ea), wave::pow2f(-eb)};
-    const v2f shift = -(mean * scale);
-    v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const v2f centred{__builtin_fmaf(x[t].x, scale.x, shift.x), __builtin_fmaf(x[t].y, scale.y, shift.y)};
-        v[t] = centred * v2f{w[t], w[t]};
-    }
-    if (SPEC_KNOCK != 2) fftp_inplace<false, LOGN>(v, A, jf, tw);
-    frame_sync<LOGN>();
-    const int own_base = pad16(jf);  // pad16(j + T t) = pad16(j) + (T + T / 16) t
-#pragma unroll
-    for (int t = 0; t < 16; ++t) A[own_base + (T + T / 16) * t] = v[t];
-    frame_sync<LOGN>();
-    if (!in_range) return;
-    // Epilogue, FOUR consecutive bins per thread and round (bins 4 j ... 4 j + 3, then 4 T + 4 j ...; thread 0 adds the Nyquist bin): every
-    // row is written by 16-byte stores — a wavefront moves 1 KiB per store instruction where the bin-per-lane order moved 256 B.
-    // Both Z[k] and its partner come from the natural-order copy.  The split keeps the (hop a, hop b) pair in one register pair:
-    //   U = Z + Zr = 2 (Re Xa, Re Xb),   V = (Z.y - Zr.y, Zr.x - Z.x) = 2 (Im Xa, Im Xb),   P = U U + V V = 4 (|Xa|^2, |Xb|^2)
-    // and the factors 1/4, 4^ea / 4^eb (the level equalisation undone) and the bin's normalisation are exact powers of two times
-    // one rounding: P * norm * (4^e / 4) rounds where (|X|^2 norm) rounded before.
+    // the Nyquist bin's table entries, resident in SGPRs (a load in the epilogue would wait for the row stores)
+    const float nrm_ny = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bin_norm[N / 2])));
+    const float aw_ny = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.a_weighting_db[N / 2])));
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // rows start at multiples of `bins` floats: 4-byte alignment only
-    float* out0 = nullptr;
-    if (a.fused_db)
-        out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
-    const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
-    float* pw = a.fused_db ? nullptr : a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
-    const bool write_a = a.emit_all || h0 + 1 == n_hops_s, write_b = has_b && (a.emit_all || h0 + 2 == n_hops_s);
-    const v2f unscale{wave::pow2f(2 * ea - 2), wave::pow2f(2 * eb - 2)};
     const float floor_v = a.floor_db;
-    auto split_power = [&](v2f z, v2f zr, float nrm) -> v2f {
-        const v2f u = z + zr;
-        const v2f q{z.y - zr.y, zr.x - z.x};
-        const v2f p = u * u + q * q;
-        return (p * v2f{nrm, nrm}) * unscale;
-    };
-    // update_outputs with AveragingMode::None (:391-401): a power under the state floor shows the floor in both rows — taken as
-    // log(0) = -inf here, which the two max() turn into the floor (and -inf + A-weighting stays -inf)
-    auto levels = [&](v2f p, float awk, float& wt_a, float& raw_a, float& wt_b, float& raw_b) {
-        const v2f kept{p.x < a.state_floor ? 0.0f : p.x, p.y < a.state_floor ? 0.0f : p.y};
-        const v2f db = v2f{__builtin_amdgcn_logf(kept.x), __builtin_amdgcn_logf(kept.y)} * v2f{3.0102999566f, 3.0102999566f};
-        const v2f dbw = db + v2f{awk, awk};
-        raw_a = wave::vmax(db.x, floor_v);
-        raw_b = wave::vmax(db.y, floor_v);
-        wt_a = wave::vmax(dbw.x, floor_v);
-        wt_b = wave::vmax(dbw.y, floor_v);
-    };
+
+    {
+        const unsigned jl = ju;
+        const int jfl = jf;
+        uint32_t h0;
+        bool has_b, in_range;
+        pair_of(chunk, h0, has_b, in_range);
+        TwiddlesPow2<LOGN> tw;
+        tw.tw2 = tw2_lds;
+        tw.load(a.tw4096, jl);  // exp(-2 pi i k / N) for this N
+        // One reduction round for everything the hop's conditioning needs: the sum (window.rs:80-84 mean; tree order here, the generic
+        // kernel keeps the sequential order) and the largest / smallest sample of each hop (level equalisation, below).
+        v2f sum = x[0] + x[1];
+        float hi_a = wave::vmax(x[0].x, x[1].x), lo_a = wave::vmin(x[0].x, x[1].x), hi_b = wave::vmax(x[0].y, x[1].y), lo_b = wave::vmin(x[0].y, x[1].y);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t k0 = (unsigned)r * 4u * (unsigned)T + 4u * ju;
-        const int zb = pad16((int)k0);                           // bins k0 ... k0 + 3 share a 16-group: consecutive slots
-        const int pb3 = pad16(N - (int)k0 - 4);                  // partners N - k0 - 1 ... N - k0 - 3 at pb3 + 3 ... pb3 + 1
-        const int p0 = (r == 0 && jf == 0) ? 0 : pad16(N - (int)k0);  // partner of k0 itself (bin 0 pairs with itself)
-        v2f z[4], zr[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) z[c] = A[zb + c];
-        zr[0] = A[p0];
-#pragma unroll
-        for (int c = 1; c < 4; ++c) zr[c] = A[pb3 + 4 - c];
-        const float4 nrm = *reinterpret_cast<const float4*>(a.bin_norm + k0);
-        const float nrmv[4] = {nrm.x, nrm.y, nrm.z, nrm.w};
-        v2f p[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = split_power(z[c], zr[c], nrmv[c]);
-        if (a.fused_db) {
-            const float4 aw = *reinterpret_cast<const float4*>(a.a_weighting_db + k0);
-            const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
-            f4u wt_a, raw_a, wt_b, raw_b;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float w0, r0, w1, r1;
-                levels(p[c], awv[c], w0, r0, w1, r1);
-                wt_a[c] = w0;
-                raw_a[c] = r0;
-                wt_b[c] = w1;
-                raw_b[c] = r1;
-            }
-            if (SPEC_KNOCK == 1) {
-                if (wt_a[0] + raw_a[1] + wt_b[2] + raw_b[3] == 1.2345f) out0[k0] = wt_a[0];
-                continue;
-            }
-            // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
-            // a ragged call launches every hop and the stream's last one writes
-            if (write_a) {
-                *reinterpret_cast<f4u*>(out0 + k0) = wt_a;
-                *reinterpret_cast<f4u*>(out0 + a.bins + k0) = raw_a;
-            }
-            if (write_b) {
-                *reinterpret_cast<f4u*>(out0 + hop_stride + k0) = wt_b;
-                *reinterpret_cast<f4u*>(out0 + hop_stride + a.bins + k0) = raw_b;
-            }
-        } else {
-            *reinterpret_cast<f4u*>(pw + k0) = f4u{p[0].x, p[1].x, p[2].x, p[3].x};
-            if (has_b) *reinterpret_cast<f4u*>(pw + a.bins + k0) = f4u{p[0].y, p[1].y, p[2].y, p[3].y};
+        for (int t = 2; t < 16; t += 2) {
+            sum += x[t];
+            sum += x[t + 1];
+            hi_a = wave::vmax3(hi_a, x[t].x, x[t + 1].x);
+            lo_a = wave::vmin3(lo_a, x[t].x, x[t + 1].x);
+            hi_b = wave::vmax3(hi_b, x[t].y, x[t + 1].y);
+            lo_b = wave::vmin3(lo_b, x[t].y, x[t + 1].y);
         }
-    }
-    if (jf == 0) {  // Nyquist bin N / 2 pairs with itself
-        const uint32_t k = (unsigned)N / 2u;
-        const v2f z = A[pad16(N / 2)];
-        const v2f pn = split_power(z, z, a.bin_norm[k]);
-        if (a.fused_db) {
-            float w0, r0, w1, r1;
-            levels(pn, a.a_weighting_db[k], w0, r0, w1, r1);
-            if (write_a && SPEC_KNOCK != 1) {
-                out0[k] = w0;
-                out0[a.bins + k] = r0;
+        float sum_a = sum.x, sum_b = sum.y;
+        wave::scan_sum2_max2_min2(sum_a, sum_b, hi_a, hi_b, lo_a, lo_b);
+        const float red[6] = {sum_a, sum_b, hi_a, hi_b, lo_a, lo_b};
+        if ((jfl & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) wave_red[fs][q][jfl >> 6] = red[q];
+        }
+        if (F == 1) frame_sync<LOGN>();  // wave partials (and, for the first pair, tw2_lds)
+        else lds_workgroup_barrier();            // (tw2_lds is shared by every frame slot)
+        float ta = 0.0f, tb = 0.0f;
+        hi_a = hi_b = -INFINITY;
+        lo_a = lo_b = INFINITY;
+#pragma unroll
+        for (int i = 0; i < WPF; ++i) {
+            ta += wave_red[fs][0][i];
+            tb += wave_red[fs][1][i];
+            hi_a = wave::vmax(hi_a, wave_red[fs][2][i]);
+            hi_b = wave::vmax(hi_b, wave_red[fs][3][i]);
+            lo_a = wave::vmin(lo_a, wave_red[fs][4][i]);
+            lo_b = wave::vmin(lo_b, wave_red[fs][5][i]);
+        }
+        const v2f mean{ta / (float)N, tb / (float)N};
+        // Level equalisation (round 5; see stft_classic_pow2_kernel): the two hops ride one complex transform and the split cancels the
+        // partner's spectrum only to ~4e-7 of ITS largest bin — a hop 60 dB under its partner came out 3e-5 of the trace maximum off
+        // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by an exact power of two that
+        // brings it to unit level — 2^-e, e = the exponent of its sample RANGE (max - min: within a factor 2 of the largest |x - mean|,
+        // and known before the mean is subtracted) — and its powers are scaled back by the exact inverse.  The scale rides the
+        // DC removal: fma(x, 2^-e, -mean 2^-e) = (x - mean) 2^-e bit for bit (both products are exact), so the conditioning of a sample
+        // is one packed FMA and one packed multiply by the window for both hops.  |e| <= 60 keeps 4^e a normal f32: levels beyond
+        // 2^+-60 are not audio, and are equalised as far as that.
+        const float range_a = hi_a - lo_a, range_b = hi_b - lo_b;
+        int ea = (range_a > 0.0f && range_a < INFINITY) ? __builtin_amdgcn_frexp_expf(range_a) : 0;
+        int eb = (range_b > 0.0f && range_b < INFINITY) ? __builtin_amdgcn_frexp_expf(range_b) : 0;
+        ea = min(max(ea, -60), 60);
+        eb = min(max(eb, -60), 60);
+        const v2f scale{wave::pow2f(-ea), wave::pow2f(-eb)};
+        const v2f shift = -(mean * scale);
+        v2f v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const v2f centred{__builtin_fmaf(x[t].x, scale.x, shift.x), __builtin_fmaf(x[t].y, scale.y, shift.y)};
+            v[t] = centred * v2f{w[t], w[t]};
+        }
+        if (SPEC_KNOCK != 2) fftp_inplace<false, LOGN>(v, A, jfl, tw);
+        frame_sync<LOGN>();
+        const int own_base = pad16(jfl);  // pad16(j + T t) = pad16(j) + (T + T / 16) t
+#pragma unroll
+        for (int t = 0; t < 16; ++t) A[own_base + (T + T / 16) * t] = v[t];
+        // the per-bin tables of both epilogue rounds: issued here, ahead of the row stores (a load between the rounds would wait for the first round's stores)
+        float4 nrm4[2], aw4[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t k0 = (unsigned)r * 4u * (unsigned)T + 4u * jl;
+            nrm4[r] = *reinterpret_cast<const float4*>(a.bin_norm + k0);
+            aw4[r] = *reinterpret_cast<const float4*>(a.a_weighting_db + k0);  // (the table exists in every averaging mode)
+        }
+        frame_sync<LOGN>();
+        if (in_range) {
+        // Epilogue, FOUR consecutive bins per thread and round (bins 4 j ... 4 j + 3, then 4 T + 4 j ...; thread 0 adds the Nyquist bin): every
+        // row is written by 16-byte stores — a wavefront moves 1 KiB per store instruction where the bin-per-lane order moved 256 B.
+        // Both Z[k] and its partner come from the natural-order copy.  The split keeps the (hop a, hop b) pair in one register pair:
+        //   U = Z + Zr = 2 (Re Xa, Re Xb),   V = (Z.y - Zr.y, Zr.x - Z.x) = 2 (Im Xa, Im Xb),   P = U U + V V = 4 (|Xa|^2, |Xb|^2)
+        // and the factors 1/4, 4^ea / 4^eb (the level equalisation undone) and the bin's normalisation are exact powers of two times
+        // one rounding: P * norm * (4^e / 4) rounds where (|X|^2 norm) rounded before.
+        float* out0 = nullptr;
+        if (FUSED)
+            out0 = a.traces + (((uint64_t)s * a.n_hops_out + (a.emit_all ? h0 : 0)) * 2 + a.trace_slot[tr]) * 2 * a.bins;
+        const uint32_t hop_stride = a.emit_all ? 4u * a.bins : 0u;  // floats between consecutive hops of one stream
+        float* pw = FUSED ? nullptr : a.power + (((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins;
+        const bool write_a = a.emit_all || h0 + 1 == n_hops_s, write_b = has_b && (a.emit_all || h0 + 2 == n_hops_s);
+        const v2f unscale{wave::pow2f(2 * ea - 2), wave::pow2f(2 * eb - 2)};
+        auto split_power = [&](v2f z, v2f zr, float nrm) -> v2f {
+            const v2f u = z + zr;
+            const v2f q{z.y - zr.y, zr.x - z.x};
+            const v2f p = u * u + q * q;
+            return (p * v2f{nrm, nrm}) * unscale;
+        };
+        // update_outputs with AveragingMode::None (:391-401): a power under the state floor shows the floor in both rows — taken as
+        // log(0) = -inf here, which the two max() turn into the floor (and -inf + A-weighting stays -inf)
+        auto levels = [&](v2f p, float awk, float& wt_a, float& raw_a, float& wt_b, float& raw_b) {
+            const v2f kept{p.x < a.state_floor ? 0.0f : p.x, p.y < a.state_floor ? 0.0f : p.y};
+            const v2f db = v2f{__builtin_amdgcn_logf(kept.x), __builtin_amdgcn_logf(kept.y)} * v2f{3.0102999566f, 3.0102999566f};
+            const v2f dbw = db + v2f{awk, awk};
+            raw_a = wave::vmax(db.x, floor_v);
+            raw_b = wave::vmax(db.y, floor_v);
+            wt_a = wave::vmax(dbw.x, floor_v);
+            wt_b = wave::vmax(dbw.y, floor_v);
+        };
+        auto put = [&](float* p, f4u v4) {  // (rows are written once and read by another kernel: non-temporal, -3 % of the kernel)
+            if (SPEC_NT) __builtin_nontemporal_store(v4, reinterpret_cast<f4u*>(p));
+            else *reinterpret_cast<f4u*>(p) = v4;
+        };
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t k0 = (unsigned)r * 4u * (unsigned)T + 4u * jl;
+            const int zb = pad16((int)k0);                           // bins k0 ... k0 + 3 share a 16-group: consecutive slots
+            const int pb3 = pad16(N - (int)k0 - 4);                  // partners N - k0 - 1 ... N - k0 - 3 at pb3 + 3 ... pb3 + 1
+            const int p0 = (r == 0 && jfl == 0) ? 0 : pad16(N - (int)k0);  // partner of k0 itself (bin 0 pairs with itself)
+            v2f z[4], zr[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[c] = A[zb + c];
+            zr[0] = A[p0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) zr[c] = A[pb3 + 4 - c];
+            const float4 nrm = nrm4[r];
+            const float nrmv[4] = {nrm.x, nrm.y, nrm.z, nrm.w};
+            v2f p[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = split_power(z[c], zr[c], nrmv[c]);
+            if (FUSED) {
+                const float4 aw = aw4[r];
+                const float awv[4] = {aw.x, aw.y, aw.z, aw.w};
+                f4u wt_a, raw_a, wt_b, raw_b;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float w0, r0, w1, r1;
+                    levels(p[c], awv[c], w0, r0, w1, r1);
+                    wt_a[c] = w0;
+                    raw_a[c] = r0;
+                    wt_b[c] = w1;
+                    raw_b[c] = r1;
+                }
+                if (SPEC_KNOCK == 1) {
+                    if (wt_a[0] + raw_a[1] + wt_b[2] + raw_b[3] == 1.2345f) out0[k0] = wt_a[0];
+                    continue;
+                }
+                // emit_all == 0: only the newest hop is materialised (slot 0).  A lock-step call launches that hop alone (n_hops == 1);
+                // a ragged call launches every hop and the stream's last one writes
+                if (write_a) {
+                    put(out0 + k0, wt_a);
+                    put(out0 + a.bins + k0, raw_a);
+                }
+                if (write_b) {
+                    put(out0 + hop_stride + k0, wt_b);
+                    put(out0 + hop_stride + a.bins + k0, raw_b);
+                }
+            } else {
+                *reinterpret_cast<f4u*>(pw + k0) = f4u{p[0].x, p[1].x, p[2].x, p[3].x};
+                if (has_b) *reinterpret_cast<f4u*>(pw + a.bins + k0) = f4u{p[0].y, p[1].y, p[2].y, p[3].y};
             }
-            if (write_b && SPEC_KNOCK != 1) {
-                out0[hop_stride + k] = w1;
-                out0[hop_stride + a.bins + k] = r1;
+        }
+        if (jfl == 0) {  // Nyquist bin N / 2 pairs with itself
+            const uint32_t k = (unsigned)N / 2u;
+            const v2f z = A[pad16(N / 2)];
+            const v2f pn = split_power(z, z, nrm_ny);
+            if (FUSED) {
+                float w0, r0, w1, r1;
+                levels(pn, aw_ny, w0, r0, w1, r1);
+                if (write_a && SPEC_KNOCK != 1) {
+                    out0[k] = w0;
+                    out0[a.bins + k] = r0;
+                }
+                if (write_b && SPEC_KNOCK != 1) {
+                    out0[hop_stride + k] = w1;
+                    out0[hop_stride + a.bins + k] = r1;
+                }
+            } else {
+                pw[k] = pn.x;
+                if (has_b) pw[a.bins + k] = pn.y;
             }
-        } else {
-            pw[k] = pn.x;
-            if (has_b) pw[a.bins + k] = pn.y;
+        }
         }
     }
 }
 
-template <int LOGN>
-__global__ __launch_bounds__(FftGeom<LOGN>::WG, (LOGN == 12 && SPEC_P > 1) ? 4 : 1) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
+// FUSED: AveragingMode::None — the dB rows are written here; otherwise the per-hop powers go to the scratch buffer for spectrum_levels_kernel
+// (a template parameter, not a branch: with both forms in one body their row stores were tail-merged behind one `s_waitcnt vmcnt(0)`).
+template <int LOGN, bool FUSED>
+__global__ __launch_bounds__(FftGeom<LOGN>::WG, LOGN == 12 ? 4 : 1) void spectrum_power_pow2_kernel(SpectrumPowerArgs a) {
     using G = FftGeom<LOGN>;
-    constexpr int F = G::FRAMES, P = F == 1 ? SPEC_P : 1;
+    constexpr int F = G::FRAMES;
     extern __shared__ __attribute__((aligned(16))) unsigned char spectrum_smem[];
-    v2f* lds = reinterpret_cast<v2f*>(spectrum_smem);                 // [F][G::LDS] + tw2 + wave sums
-    const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F, groups = (chunks + P - 1) / P;
+    v2f* lds = reinterpret_cast<v2f*>(spectrum_smem);                 // [F][G::LDS] + tw2 + wave partials
+    const uint32_t pairs = (a.n_hops + 1) / 2, chunks = (pairs + F - 1) / F;
     // XCD-aware map (as block_to_stream_column in stft_kernels.hip): block b runs on XCD b % 8 and every (stream, trace) is pinned to
     // one XCD, so the 16 hops that share a sample find it in that XCD's L2 (chunk-fastest over all XCDs fetched the rings 8 times:
     // 524 MB per launch against 67 MB of new samples)
     const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
-    const uint32_t group = bq % groups, st = (bq / groups) * 8u + xcd;
+    const uint32_t chunk = bq % chunks, st = (bq / chunks) * 8u + xcd;
     if (st >= a.n_streams * a.n_traces) return;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
-#pragma unroll 1
-    for (uint32_t pp = 0; pp < (uint32_t)P; ++pp) {
-        const uint32_t chunk = group * P + pp;
-        if (chunk >= chunks) break;
-        if (pp) __syncthreads();  // the previous pair's partner reads
-        spectrum_power_pow2_body<LOGN>(a, s, tr, chunk, lds);
-    }
+    spectrum_power_pow2_body<LOGN, FUSED>(a, s, tr, chunk, lds);
 }
 
 // ---- K3a split: N = 16384 (the reference's default spectrum size) as ONE packed-real transform per hop on the tuned 4096-point dual
@@ -358,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum0 += __shfl_xor(sum0, off);
     if (lane == 0) wave_sum[wave] = sum0;
-    __syncthreads();  // wave sums, tw2_lds
+    lds_workgroup_barrier();  // wave sums, tw2_lds
     const float mean0 = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) / (float)N;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -369,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
     fft4096t_dual<false>(v0, v1, A, B, j, tw);
 
     // ---- radix-2 step and the natural-order copy for the partner reads -------------------------------------------------------------------------
-    __syncthreads();  // pass 3 still reads A and B
+    lds_workgroup_barrier();  // pass 3 still reads A and B
 #pragma unroll
     for (int t = 0; t < 16; ++t) {  // Z[k] = F0[k] + w2^k F1[k], Z[k + 4096] = F0[k] - w2^k F1[k], w2 = exp(-2 pi i / 8192)
         const v2f m = cmul(v1[t], load_v2f(Tb, ju * 16u, 4096u * (unsigned)t));
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
         A[pad16(j + 256 * t)] = lo;
         A[pad16(j + 256 * t + 4096)] = hi;
     }
-    __syncthreads();
+    lds_workgroup_barrier();
 
     // ---- real-input split, power, dB; bins k = j + 256 t' (t' < 32) and bin M (thread 0) ---------------------------------------------------------
     constexpr int PER = M / 256;
@@ -448,13 +486,13 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
         const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
         const uint64_t mask = a.cap - 1;
         const uint64_t p0 = spectrum_tail(a, s) + (uint64_t)(a.first_hop + h) * a.hop;
-        __syncthreads();
+        lds_workgroup_barrier();
         if (tid == 0) {
             float sum = -0.0f;
             for (uint32_t i = 0; i < a.fft_size; ++i) sum = sum + ring[(p0 + i) & mask];
             mean_sh = sum / (float)a.fft_size;
         }
-        __syncthreads();
+        lds_workgroup_barrier();
         const float mean = mean_sh;
         for (uint32_t i = tid; i < a.fft_size; i += nt) ws[i] = v2f{(ring[(p0 + i) & mask] - mean) * a.window[i], 0.0f};
         fft_forward_any(ws, a.fft_size, a.log_fft, a.tw_fft, ws + a.fft_size, a.blu, tid, nt);
@@ -465,20 +503,24 @@ __global__ __launch_bounds__(256) void spectrum_power_generic_kernel(SpectrumPow
     }
 }
 
-template <int LOGN>
-static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
+template <int LOGN, bool FUSED>
+static void launch_spectrum_pow2_form(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
     using G = FftGeom<LOGN>;
     constexpr int F = G::FRAMES, WPF = G::T / 64;
     const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 6 * WPF * sizeof(float);  // + the wave partials (sum, max, min of both hops)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    constexpr uint32_t P = F == 1 ? SPEC_P : 1;
     const uint32_t chunks = (hop_pairs + F - 1) / F;
-    hipLaunchKernelGGL(spectrum_power_pow2_kernel<LOGN>, dim3(stream_column_grid(stream_traces, (chunks + P - 1) / P)), dim3(G::WG), lds, stream, a);
+    hipLaunchKernelGGL((spectrum_power_pow2_kernel<LOGN, FUSED>), dim3(stream_column_grid(stream_traces, chunks)), dim3(G::WG), lds, stream, a);
+}
+template <int LOGN>
+static void launch_spectrum_pow2(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
+    if (a.fused_db) launch_spectrum_pow2_form<LOGN, true>(a, stream_traces, hop_pairs, stream);
+    else launch_spectrum_pow2_form<LOGN, false>(a, stream_traces, hop_pairs, stream);
 }
 
 void launch_spectrum_power(const SpectrumPowerArgs& a, bool fast4096, uint32_t generic_wgs, hipStream_t stream) {

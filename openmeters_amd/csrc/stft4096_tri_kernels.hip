@@ -29,8 +29,13 @@ namespace {
 #ifndef TRI_KNOCK
 #define TRI_KNOCK 0
 #endif
+#ifndef TRI_LDS_SYNC  // 1: the kernel's barriers wait for LDS traffic only (the workgroup exchanges nothing through global memory): __syncthreads()
+#define TRI_LDS_SYNC 1  // also drains vmcnt — column a's point stores — at column b's first barrier.  Same-box A/B: 1.337 -> 1.329 ms (K2-ldssync)
+#endif
 #if TRI_KNOCK == 3
 #define TRI_SYNC() __builtin_amdgcn_sched_barrier(0)
+#elif TRI_LDS_SYNC
+#define TRI_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #else
 #define TRI_SYNC() __syncthreads()
 #endif
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
         }
     };
     v2f ya[16], yb[16];
-    __syncthreads();  // pass 3 of chain b still reads X
+    TRI_SYNC();  // pass 3 of chain b still reads X
 #pragma unroll
     for (int t = 0; t < 16; ++t) X[xslot(j) + kTriStep * t] = va[t];
     if (j == 0) {
@@ -360,15 +365,15 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
         hil[2] = (vb[0].x + vb[0].y) * 0.5f;
         hil[3] = (vb[0].x - vb[0].y) * 0.5f;
     }
-    __syncthreads();
+    TRI_SYNC();
     hilbert_spectrum(ya, va);
-    __syncthreads();
+    TRI_SYNC();
 #pragma unroll
     for (int t = 0; t < 16; ++t) X[xslot(j) + kTriStep * t] = vb[t];
-    __syncthreads();
+    TRI_SYNC();
     hilbert_spectrum(yb, vb);
     const float half_x0a = hil[0], half_xna = hil[1], half_x0b = hil[2], half_xnb = hil[3];
-    __syncthreads();
+    TRI_SYNC();
     tri_dual<true>(ya, yb, X, tw2_lds, tw3, j);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + 256 t
 
     // ---- 3. the analytic slices s[i] = analytic[2048 + i], i = j + 256 t ----------------------------------------------------
@@ -390,14 +395,14 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     float xra[16], twina[16];
     load_real_half(xra, 0u, pa32);
     load_twindow(twina);
-    __syncthreads();
+    TRI_SYNC();
     float* imag_a = reinterpret_cast<float*>(X);
 #pragma unroll
     for (int t = 4; t < 12; ++t) {
         *reinterpret_cast<v2f*>(imag_a + 2 * (j + 256 * t - 1024)) = ya[t];
         *reinterpret_cast<v2f*>(imb + 2 * (j + 256 * t - 1024)) = yb[t];
     }
-    __syncthreads();
+    TRI_SYNC();
     constexpr int REACH = TERMS > 1 ? TERMS - 1 : 1;  // neighbour bins on either side (the natural-order copy always keeps 3)
     const float c0 = a.cos_c[0];
     float half_c[REACH], dscale[REACH];
@@ -409,29 +414,36 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
     v2f* lin_z = X;  // natural-order bins -3 ... 2111 of Z (slot 3 + k)
 
     // ---- 4. per column: Z = FFT(s), T = FFT(t w s) as one dual transform; w and w' applied on the bins of Z -----------------
-    auto column = [&](const float (&xr)[16], const float (&twin)[16], const float* imag, float half_x0, float half_xn, bool silent, uint32_t col, uint32_t* count_out) {
-        v2f z[16], z2[16];
-        {
-            const float par = (j & 1) ? -half_xn : half_xn;  // (-1)^n: n = 2048 + i has j's parity
+    // A column in three steps — build (the analytic slice and its time-weighted copy from the loaded halves), analyse (dual transform, window on
+    // the bins, reassignment, the kept points' positions), store.  (Issuing column a's stores behind column b's build, so that they drain
+    // behind its transforms, spilled 32 B and measured +1.5 %: ledger K2-latestore.)
+    struct ColumnPoints {
+        omx_spectrogram_point pts[9];
+        unsigned long long masks[9];
+        uint32_t exc, running;
+    };
+    auto build = [&](v2f (&z)[16], v2f (&z2)[16], const float (&xr)[16], const float (&twin)[16], const float* imag, float half_x0, float half_xn) {
+        const float par = (j & 1) ? -half_xn : half_xn;  // (-1)^n: n = 2048 + i has j's parity
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                z[t] = v2f{4096.0f * xr[t] - half_x0 + par, imag[j + 256 * t]};
-                z2[t] = v2f{z[t].x * twin[t], z[t].y * twin[t]};
-            }
+        for (int t = 0; t < 16; ++t) {
+            z[t] = v2f{4096.0f * xr[t] - half_x0 + par, imag[j + 256 * t]};
+            z2[t] = v2f{z[t].x * twin[t], z[t].y * twin[t]};
         }
-        __syncthreads();  // the slice reads above / the previous column's neighbour reads still use X
+    };
+    auto analyse = [&](v2f (&z)[16], v2f (&z2)[16], bool silent, ColumnPoints& o) {
+        omx_spectrogram_point (&pts)[9] = o.pts;
+        unsigned long long (&masks)[9] = o.masks;
+        TRI_SYNC();  // the slice reads of the build / the previous column's neighbour reads still use X
         tri_dual<false>(z, z2, X, tw2_lds, tw3, j);
         float pn[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) pn[t] = load_f32(normb, ju * 4u, 1024u * (unsigned)t);  // (t = 8, j > 0: past the table, reads 0, not used)
-        __syncthreads();  // pass 3 still reads X
+        TRI_SYNC();  // pass 3 still reads X
 #pragma unroll
         for (int t = 0; t < 8; ++t) lin_z[3 + j + 256 * t] = z[t];
         if (wave_u == 0) lin_z[3 + j + 2048] = z[8];  // bins 2048 ... 2111: the Nyquist bin and its upper neighbours
         if (j >= 253) lin_z[j - 253] = z[15];         // bins -3 ... -1 = bins 4093 ... 4095
-        __syncthreads();
-        omx_spectrogram_point pts[9];
-        unsigned long long masks[9];
+        TRI_SYNC();
         auto bins = [&](auto first, auto last) {
             constexpr int T0 = decltype(first)::value, T1 = decltype(last)::value;
             v2f nzm[T1 - T0][REACH], nzp[T1 - T0][REACH];
@@ -494,29 +506,36 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_4096_tri_kernel(StftFa
             masks[8] = 0ull;
             if (lane == 0) scan[32 + wave] = 0u;
         }
-        __syncthreads();
-        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
+        TRI_SYNC();
         const uint32_t cnt = lane < 36 ? scan[lane] : 0u;
         const uint32_t inc = wave_inclusive_sum(cnt);
-        const uint32_t exc = inc - cnt;
-        const uint32_t running = (uint32_t)__builtin_amdgcn_readlane((int)inc, 35);
+        o.exc = inc - cnt;
+        o.running = (uint32_t)__builtin_amdgcn_readlane((int)inc, 35);
+    };
+    auto store = [&](const ColumnPoints& o, uint32_t col, uint32_t* count_out) {
+        omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exc, 4 * t + wave_u);
-            if (TRI_KNOCK != 4 && ((masks[t] >> lane) & 1ull)) {
-                const uint32_t pos = before + lanes_below(masks[t]);
-                store_point(out, pos, pts[t]);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)o.exc, 4 * t + wave_u);
+            if (TRI_KNOCK != 4 && ((o.masks[t] >> lane) & 1ull)) {
+                const uint32_t pos = before + lanes_below(o.masks[t]);
+                store_point(out, pos, o.pts[t]);
             }
         }
-        if (j == 0) *count_out = running;
+        if (j == 0) *count_out = o.running;
     };
-    column(xra, twina, imag_a, half_x0a, half_xna, silent_a, col0, count_a);
+    v2f z[16], z2[16];
+    ColumnPoints pts;
+    build(z, z2, xra, twina, imag_a, half_x0a, half_xna);
+    analyse(z, z2, silent_a, pts);
+    store(pts, col0, count_a);
     if (have1) {
-        // (requested ahead of column a's point stores — loads and stores retire through one in-order counter — this measured the same)
         float xrb[16], twinb_v[16];
         load_real_half(xrb, hop_bytes, pb32);
         load_twindow(twinb_v);
-        column(xrb, twinb_v, imb, half_x0b, half_xnb, silent_b, col1, count_b);
+        build(z, z2, xrb, twinb_v, imb, half_x0b, half_xnb);
+        analyse(z, z2, silent_b, pts);
+        store(pts, col1, count_b);
     }
 }
 

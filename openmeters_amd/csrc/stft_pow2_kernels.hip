@@ -8,6 +8,8 @@
 #include <cstdlib>
 
 #include "buffer_device.hpp"
+#define OMX_FRAME_SYNC_LDS_ONLY 1  // every kernel of this file exchanges data between its threads through LDS only (global scratch is
+                                   // written by one kernel and read by the next): fft_pow2_device.hpp, frame_sync
 #include "fft_pow2_device.hpp"
 #include "reassign_device.hpp"
 #include "twiddle_run_device.hpp"
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG, FftGeom<LOGN>::WG == 256 ? 2 : 1
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) w2n[t] = a.tw8192[ju + (unsigned)T * (unsigned)t];  // exp(-2 pi i k / 2N)
-    __syncthreads();  // tw2_lds (shared by every frame slot)
+    lds_workgroup_barrier();  // tw2_lds (shared by every frame slot)
     fftp<false, LOGN>(v, A, B, jf, tw);  // v[t] = Zf[jf + T t]; last read: B
 
     // ---- 2. Hilbert transform with one half-length inverse (see stft_kernels.hip for the derivation) ------------------
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_pair_kernel(StftF
             vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
         }
     }
-    __syncthreads();  // tw2_lds (shared by every slot)
+    lds_workgroup_barrier();  // tw2_lds (shared by every slot)
     fftp_dual<false, LOGN>(va, vb, A, B, jf, tw);  // v[t] = Zf[jf + T t]
 
     // ---- 2. Hilbert transform with one half-length inverse per column (derivation: stft_kernels.hip step 2) ---------------------------
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
         wave_sum[fs][0][wf] = sa;
         wave_sum[fs][1][wf] = sb;
     }
-    __syncthreads();  // wave sums and tw2_lds (shared by every frame slot)
+    lds_workgroup_barrier();  // wave sums and tw2_lds (shared by every frame slot)
     float ta = 0.0f, tb = 0.0f;
 #pragma unroll
     for (int i = 0; i < WPF; ++i) {
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(FftGeom<LOGF>::WG, FftGeom<LOGF>::WG == 256 ? 2 : 1
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) w2n[t] = a.tw8192[jh + (unsigned)TW * (unsigned)t];
-    __syncthreads();  // tw2_lds (shared by every frame slot)
+    lds_workgroup_barrier();  // tw2_lds (shared by every frame slot)
     fftp_masked<false, LOGW, LOGF>(hact, v, A, B, jf, twh);
 
     // ---- 2. Hilbert transform with one half-length inverse ---------------------------------------------------------------------
@@ -941,16 +943,16 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFast
         v[t] = v2f{*reinterpret_cast<const float*>(ring_bytes + ((qq << 2) & bytemask)),
                    *reinterpret_cast<const float*>(ring_bytes + (((qq + 1u) << 2) & bytemask))};
     }
-    __syncthreads();  // tw2_lds
+    lds_workgroup_barrier();  // tw2_lds
     fftp_inplace<false, LOGN>(v, buf, j, tw);
-    __syncthreads();
+    lds_workgroup_barrier();
 #pragma unroll
     for (int t = 0; t < 16; ++t) buf[pad16(j + T * t)] = v[t];
     if (j == 0) {
         hil[0] = (v[0].x + v[0].y) * 0.5f;  // X[0] / 2
         hil[1] = (v[0].x - v[0].y) * 0.5f;  // X[N] / 2
     }
-    __syncthreads();
+    lds_workgroup_barrier();
     v2f y[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -964,13 +966,13 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void hilbert_big_kernel(StftFast
         if (k == 0) y[t] = v2f{0.0f, 0.0f};
     }
     const float half_x0 = hil[0], half_xn = hil[1];
-    __syncthreads();  // partners are read from the buffer the inverse is about to overwrite
+    lds_workgroup_barrier();  // partners are read from the buffer the inverse is about to overwrite
     fftp_inplace<true, LOGN>(y, buf, j, tw);  // y[t] = (Im a[2m], Im a[2m+1]), m = j + T t
-    __syncthreads();
+    lds_workgroup_barrier();
     float* imag = reinterpret_cast<float*>(buf);  // N floats: Im analytic[N/2 .. 3N/2)
 #pragma unroll
     for (int t = 4; t < 12; ++t) *reinterpret_cast<v2f*>(imag + 2 * (j + T * t - N / 4)) = y[t];
-    __syncthreads();
+    lds_workgroup_barrier();
     const float parity = (j & 1) ? -half_xn : half_xn;
     v2f* out = sc.sv + (uint64_t)blockIdx.x * N;
     const uint32_t qe = p32 + (uint32_t)(N / 2) + ju;
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void windowed_big_kernel(StftFas
         if (bins ? q == 1 : q == 2) w = ((float)ic - center) * w;  // compute_time_weighted (:601-608)
         v[u] = i < W ? v2f{x.x * w, x.y * w} : v2f{0.0f, 0.0f};
     }
-    __syncthreads();  // tw2_lds
+    lds_workgroup_barrier();  // tw2_lds
     fftp_inplace<false, LOGN>(v, buf, j, tw);
     if (bins) {  // bins -kBigHalo ... N/2 + kBigHalo (row slot = bin + kBigHalo): the window's cosine shifts by F / W <= 16 bins
         v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * kBigRow<LOGN> + kBigHalo;
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void reassign_big_kernel(StftFas
         masks[t] = __ballot(keep);
         if (lane == 0) scan[t * WPF + wf] = (uint32_t)__popcll(masks[t]);
     }
-    __syncthreads();
+    lds_workgroup_barrier();
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
     uint32_t running = 0;
 #pragma unroll
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(FftGeom<LOGW>::WG) void windowed_residue_kernel(Stf
         const v2f m = twF[(i * r) & (F - 1u)];     // exp(-2 pi i n r / F)
         v[u] = cmul(v2f{x.x * w, x.y * w}, m);
     }
-    __syncthreads();  // tw2_lds
+    lds_workgroup_barrier();  // tw2_lds
     fftp_inplace<false, LOGW>(v, buf, j, tw);
     v2f* out = sc.spec + ((uint64_t)q * sc.count + blockIdx.x) * (F / 2u + 1u);
 #pragma unroll
@@ -1217,7 +1219,7 @@ __global__ __launch_bounds__(1024) void reassign_stream_kernel(StftFastArgs a, B
         const bool keep = reassign_flat(bc, sb[bc], sb[per + bc], sb[2 * per + bc], a.bin_norm[bc], rc, pt) && valid;
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) scan[wf] = (uint32_t)__popcll(mask);
-        __syncthreads();
+        lds_workgroup_barrier();
         uint32_t before = running, total = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(1024) void reassign_stream_kernel(StftFastArgs a, B
             *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + (uint64_t)pos * 12u) = pt;
         }
         running += total;
-        __syncthreads();  // scan[] is rewritten by the next tile
+        lds_workgroup_barrier();  // scan[] is rewritten by the next tile
     }
     if (ju == 0) *count_out = running;
 }
@@ -1270,7 +1272,7 @@ __global__ __launch_bounds__(FftGeom<LOGW>::WG) void classic_residue_kernel(Stft
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     if ((j & 63) == 0) wave_sum[j >> 6] = sum;
-    __syncthreads();  // wave sums, tw2_lds
+    lds_workgroup_barrier();  // wave sums, tw2_lds
     float total = 0.0f;
 #pragma unroll
     for (int i = 0; i < WPF; ++i) total += wave_sum[i];
@@ -1547,7 +1549,7 @@ __global__ __launch_bounds__(256, 3) void stft_reassigned_pow2_tri_kernel(StftFa
             vb[t] = v2f{ring[qb & mask32], ring[(qb + 1u) & mask32]};
         }
     }
-    __syncthreads();  // tw2_lds (shared by every slot)
+    lds_workgroup_barrier();  // tw2_lds (shared by every slot)
     tri_dual_pow2<false, LOGN>(va, vb, X, jf, tw);  // v[t] = Zf[jf + T t]
 
     // ---- 2. Hilbert transform with one half-length inverse per column, one column at a time through X ----------------------------------
