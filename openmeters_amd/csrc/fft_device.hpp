@@ -16,6 +16,17 @@
 
 namespace omx {
 
+// Barrier of the transforms in this header.  A translation unit whose kernels exchange data between their threads through LDS only defines
+// OMX_FRAME_SYNC_LDS_ONLY before including it: the barrier then waits for LDS traffic and leaves global loads / stores in flight
+// (__syncthreads() drains vmcnt at every pass).
+__device__ __forceinline__ void fft_sync() {
+#ifdef OMX_FRAME_SYNC_LDS_ONLY
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));  // (re, im)
 
 // Complex products as two packed-f32 VALU ops.  hipcc lowers the plain C++ form to v_xor + v_mov +
@@ -137,7 +148,7 @@ __device__ __forceinline__ void fft4096_pass2(v2f* lds, int j, const Fft4096Tabl
 #pragma unroll
     for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tb.tw256[k * (unsigned)t]);
     dft16<INV>(v);
-    __syncthreads();  // every thread has read its inputs: in-place overwrite is safe
+    fft_sync();  // every thread has read its inputs: in-place overwrite is safe
     const int base = (j >> 4) * 272 + (int)k;  // pad16((j/16)*256 + k + 16 t) = (j/16)*272 + k + 17 t
 #pragma unroll
     for (int t = 0; t < 16; ++t) lds[base + 17 * t] = v[DFT16_OUT(t)];
@@ -159,9 +170,9 @@ __device__ __forceinline__ void fft4096_pass3(v2f (&out)[16], const v2f* lds, in
 template <bool INV>
 __device__ __forceinline__ void fft4096(v2f (&v)[16], v2f* lds, int j, const Fft4096Tables& tb) {
     fft4096_pass1<INV>(v, lds, j);
-    __syncthreads();
+    fft_sync();
     fft4096_pass2<INV>(lds, j, tb);
-    __syncthreads();
+    fft_sync();
     fft4096_pass3<INV>(v, lds, j, tb);
 }
 
@@ -191,7 +202,7 @@ __device__ __forceinline__ void fft4096t_pass2(const v2f* src, v2f* dst, int j, 
 #pragma unroll
     for (int t = 1; t < 16; ++t) v[t] = twmul<INV>(v[t], tw.w2(k, t));
     dft16<INV>(v);
-    if (same_buffer) __syncthreads();
+    if (same_buffer) fft_sync();
     const int base = (j >> 4) * 272 + (int)k;
 #pragma unroll
     for (int t = 0; t < 16; ++t) dst[base + 17 * t] = v[DFT16_OUT(t)];
@@ -212,14 +223,14 @@ __device__ __forceinline__ void fft4096t_pass3(v2f (&out)[16], const v2f* lds, i
 template <bool INV, bool PINGPONG, class TW>
 __device__ __forceinline__ void fft4096t(v2f (&v)[16], v2f* first, v2f* second, int j, const TW& tw) {
     fft4096_pass1<INV>(v, first, j);
-    __syncthreads();
+    fft_sync();
     if constexpr (PINGPONG) {
         fft4096t_pass2<INV>(first, second, j, tw, false);
-        __syncthreads();
+        fft_sync();
         fft4096t_pass3<INV>(v, second, j, tw);
     } else {
         fft4096t_pass2<INV>(first, first, j, tw, true);
-        __syncthreads();
+        fft_sync();
         fft4096t_pass3<INV>(v, first, j, tw);
     }
 }
@@ -228,7 +239,7 @@ template <bool INV, class TW>
 __device__ __forceinline__ void fft4096t_dual(v2f (&v0)[16], v2f (&v1)[16], v2f* A, v2f* B, int j, const TW& tw) {
     fft4096_pass1<INV>(v0, A, j);
     fft4096_pass1<INV>(v1, B, j);
-    __syncthreads();
+    fft_sync();
     {
         v2f a[16], b[16];
 #pragma unroll
@@ -245,7 +256,7 @@ __device__ __forceinline__ void fft4096t_dual(v2f (&v0)[16], v2f (&v1)[16], v2f*
         }
         dft16<INV>(a);
         dft16<INV>(b);
-        __syncthreads();
+        fft_sync();
         const int base = (j >> 4) * 272 + (int)k;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -253,7 +264,7 @@ __device__ __forceinline__ void fft4096t_dual(v2f (&v0)[16], v2f (&v1)[16], v2f*
             B[base + 17 * t] = b[DFT16_OUT(t)];
         }
     }
-    __syncthreads();
+    fft_sync();
     {
         v2f a[16], b[16];
 #pragma unroll
@@ -287,7 +298,7 @@ __device__ __forceinline__ unsigned bitrev(unsigned x, unsigned bits) { return b
 __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* tw, bool inverse, unsigned tid,
                                   unsigned nthreads, unsigned tw_step = 1) {
     if (n <= 1) return;
-    __syncthreads();
+    fft_sync();
     for (unsigned i = tid; i < n; i += nthreads) {
         const unsigned r = bitrev(i, logn);
         if (i < r) {
@@ -296,7 +307,7 @@ __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* 
             a[r] = t;
         }
     }
-    __syncthreads();
+    fft_sync();
     for (unsigned s = 1; s <= logn; ++s) {
         const unsigned half = 1u << (s - 1), stride = n >> s;
         for (unsigned b = tid; b < n / 2; b += nthreads) {
@@ -309,7 +320,7 @@ __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* 
             a[base] = u + t;
             a[base + half] = u - t;
         }
-        __syncthreads();
+        fft_sync();
     }
 }
 
@@ -319,7 +330,7 @@ __device__ inline void fft_radix2(v2f* a, unsigned n, unsigned logn, const v2f* 
 // whose transform `bf` = FFT_m(b) the host prepares in double precision.  `x` holds n values in and out; `scratch` m values.
 // The reference plans any length (rustfft), so shapes that are not powers of two are part of the path (generic kernels only).
 __device__ inline void fft_bluestein(v2f* x, unsigned n, v2f* scratch, const BluesteinPlan& bp, unsigned tid, unsigned nthreads) {
-    __syncthreads();
+    fft_sync();
     for (unsigned i = tid; i < bp.m; i += nthreads) {
         v2f v{0.0f, 0.0f};
         if (i < n) {
@@ -339,7 +350,7 @@ __device__ inline void fft_bluestein(v2f* x, unsigned n, v2f* scratch, const Blu
         const v2f a = scratch[k], c = bp.chirp[k];
         x[k] = v2f{(a.x * c.x - a.y * c.y) * inv_m, (a.x * c.y + a.y * c.x) * inv_m};
     }
-    __syncthreads();
+    fft_sync();
 }
 // forward transform of any length: radix-2 when it is a power of two, Bluestein otherwise
 __device__ inline void fft_forward_any(v2f* x, unsigned n, unsigned logn, const v2f* tw, v2f* scratch, const BluesteinPlan& bp, unsigned tid,

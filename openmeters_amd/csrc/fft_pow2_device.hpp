@@ -6,6 +6,7 @@
 // the 4096-point code: thread jf holds x[jf + T u] in v[u] on entry and X[jf + T u] in v[u] on return.
 #pragma once
 #include "fft_device.hpp"
+#include "wave_device.hpp"
 #include "fft_fused_device.hpp"
 
 namespace omx {
@@ -26,10 +27,6 @@ struct FftGeom {
 // Barrier between the threads of ONE transform.  With T = 64 a transform lives in a single wavefront, whose LDS
 // instructions execute in order: no s_barrier is needed, only a fence that keeps the compiler from reordering the LDS
 // accesses — the 4 transforms of a workgroup then run free of each other.
-// Workgroup barrier for kernels whose threads exchange data through LDS only: waits for this wavefront's LDS traffic and leaves its global
-// loads and stores in flight.  __syncthreads() also drains vmcnt — every table load issued ahead of use, every point / row store — at each call.
-__device__ __forceinline__ void lds_workgroup_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int LOGN>
 __device__ __forceinline__ void frame_sync() {
     if constexpr (FftGeom<LOGN>::T == 64) {

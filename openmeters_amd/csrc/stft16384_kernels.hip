@@ -10,6 +10,7 @@
 // Decimation in frequency, natural -> interleaved:  g_r[k] = (sum_q (+i)^(rq) y[k + 4096 q]) w^(-rk),  out[4n + r] = IFFT4096(g_r)[n]
 // (w = exp(-2 pi i / 16384)).  The analytic slice and the spectra still travel between the kernels through the HBM scratch
 // (launch_big in stft_pow2_kernels.hip): 128 registers hold ONE transform's values, so Z and Z2 cannot both stay resident.
+#define OMX_FRAME_SYNC_LDS_ONLY 1  // this file's kernels exchange data between their threads through LDS only (fft_device.hpp: fft_sync)
 #include "stft_kernels.hpp"
 
 #include <type_traits>
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void hilbert_16k_kernel(StftFastArgs a, Big
     load_pair(f0, f1, 0);
     fft4096t_dual<false>(f0, f1, A, B, j, tw);
     load_pair(f2, f3, 2);
-    __syncthreads();  // pass 3 of the previous dual still reads A and B
+    fft_sync();  // pass 3 of the previous dual still reads A and B
     fft4096t_dual<false>(f2, f3, A, B, j, tw);
     TwRun run;
     run.load(T, ju);
@@ -174,13 +175,13 @@ __global__ __launch_bounds__(256, 2) void hilbert_16k_kernel(StftFastArgs a, Big
     const int part = (j ? pad16(4096 - j) : 4352) - 272 * 15;
     auto exchange = [&](v2f (&lo)[16], v2f (&hi)[16], auto q_lo_c, auto q_hi_c, v2f self_lo, v2f self_hi) {
         constexpr int Q_LO = decltype(q_lo_c)::value, Q_HI = decltype(q_hi_c)::value;
-        __syncthreads();  // earlier reads of A and B are done
+        fft_sync();  // earlier reads of A and B are done
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             A[pad16(j + 256 * t)] = lo[t];
             B[pad16(j + 256 * t)] = hi[t];
         }
-        __syncthreads();
+        fft_sync();
         v2f zr_lo[16], zr_hi[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -201,9 +202,9 @@ __global__ __launch_bounds__(256, 2) void hilbert_16k_kernel(StftFastArgs a, Big
     // ---- inverse, decimation in frequency: g_r[k] = (sum_q (+i)^(rq) y[k + 4096 q]) conj(w^(rk)), four 4096-point inverses ----------------
     dif4_split(f0, f1, f2, f3, run);
     const float hx0 = hil[0], hxn = hil[1];
-    __syncthreads();  // the partner reads are done
+    fft_sync();  // the partner reads are done
     fft4096t_dual<true>(f0, f1, A, B, j, tw);
-    __syncthreads();
+    fft_sync();
     fft4096t_dual<true>(f2, f3, A, B, j, tw);  // f_r[t] = (Im a[2m], Im a[2m+1]), m = 4 (j + 256 t) + r
 
     // ---- analytic slice: samples 8 (j + 256 t) ... + 7 of the window, t = 4 ... 11, are slice elements i = 8 (j + 256 (t - 4)) ... + 7 ------
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void windowed_16k_kernel(StftFastArgs a, Bi
     load_pair(f0, f1, 0);
     fft4096t_dual<false>(f0, f1, A, B, j, tw);
     load_pair(f2, f3, 2);
-    __syncthreads();  // pass 3 of the previous dual still reads A and B
+    fft_sync();  // pass 3 of the previous dual still reads A and B
     fft4096t_dual<false>(f2, f3, A, B, j, tw);
     TwRun run;
     run.load(T, ju);
@@ -394,10 +395,10 @@ __global__ __launch_bounds__(256, 2) void windowed_reassign_16k_kernel(StftFastA
         load_pair(f0, f1, 0, ramp);
         fft4096t_dual<false>(f0, f1, A, B, j, tw);
         load_pair(f2, f3, 2, ramp);
-        __syncthreads();  // pass 3 of the previous dual still reads A and B
+        fft_sync();  // pass 3 of the previous dual still reads A and B
         fft4096t_dual<false>(f2, f3, A, B, j, tw);
         dit4_combine<2>(f0, f1, f2, f3, run);  // f0[t] = X[j + 256 t], f1[t] = X[4096 + j + 256 t]; f2[0] = X[8192 + j]; f3[15] = X[16128 + j]
-        __syncthreads();  // pass 3 still reads A and B
+        fft_sync();  // pass 3 still reads A and B
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             lin[j + 256 * t] = f0[t];
@@ -405,14 +406,14 @@ __global__ __launch_bounds__(256, 2) void windowed_reassign_16k_kernel(StftFastA
         }
         if (j <= kBigHalo) lin[8192 + j] = f2[0];
         if (j >= 256 - kBigHalo) lin[j - 256] = f3[15];  // bin 16384 - m sits at -m
-        __syncthreads();
+        fft_sync();
     };
     // window on the bins: cos(2 pi n / W) shifts an F-point spectrum by F / W bins
     const int shift = (int)(16384u / W);
     const float c0 = a.win_c0, half_c1 = 0.5f * a.win_c1, dscale = a.win_c1 * (3.14159265358979323846f / (float)W);
     v2f* park = sc.spec + (uint64_t)blockIdx.x * kBigRow<14>;  // FFT(t w s) of bins 0 ... 8192, written and read by this workgroup only
 
-    __syncthreads();  // tw2_lds
+    fft_sync();  // tw2_lds
     spectrum(true);
 #pragma unroll
     for (int t = 0; t < 33; ++t) {
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void windowed_reassign_16k_kernel(StftFastA
         const v2f zc = lin[bin], zm = lin[bin - shift], zp = lin[bin + shift];
         park[bin] = v2f{c0 * zc.x + half_c1 * (zm.x + zp.x), c0 * zc.y + half_c1 * (zm.y + zp.y)};
     }
-    __syncthreads();  // those reads are done before the next transform's pass 1 writes
+    fft_sync();  // those reads are done before the next transform's pass 1 writes
     spectrum(false);
 
     // reassignment + ordered compaction, eight (the last time nine) bins per thread at a time
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void windowed_reassign_16k_kernel(StftFastA
             masks[u] = __ballot(keep);
             if (lane == 0) scan[u * 4 + wave] = (uint32_t)__popcll(masks[u]);
         }
-        __syncthreads();
+        fft_sync();
         const uint32_t cnt = lane < 4 * NT ? scan[lane] : 0u;
         const uint32_t inc = wave_inclusive_sum(cnt);
         const uint32_t exc = inc - cnt;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void windowed_reassign_16k_kernel(StftFastA
                 *reinterpret_cast<omx_spectrogram_point*>(reinterpret_cast<char*>(out) + (before + lanes_below(masks[u])) * 12u) = pts[u];
         }
         emitted += (uint32_t)__builtin_amdgcn_readlane((int)inc, 4 * NT - 1);
-        __syncthreads();  // the wave counts are rewritten by the next chunk
+        fft_sync();  // the wave counts are rewritten by the next chunk
     };
     chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
     chunk(std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});

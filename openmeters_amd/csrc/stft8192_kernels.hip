@@ -14,6 +14,7 @@
 // four-pass transforms and one workgroup per CU (11.2 M frames/s).
 // Windows: the two-term cosine sums (Hann, Hamming), applied on the bins (see stft4096_pair_kernels.hip); other windows stay on
 // the size-templated kernel.
+#define OMX_FRAME_SYNC_LDS_ONLY 1  // this file's kernels exchange data between their threads through LDS only (fft_device.hpp: fft_sync)
 #include "stft_kernels.hpp"
 
 #include "buffer_device.hpp"
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
     }
 
     // ---- 2. Hilbert transform with ONE half-length inverse (derivation: stft_kernels.hip step 2, N = 8192) -----------------------
-    __syncthreads();  // pass 3 of the dual transform still reads A and B
+    fft_sync();  // pass 3 of the dual transform still reads A and B
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         A[pad16(j + 256 * t)] = xl[t];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
         hil[0] = (xl[0].x + xl[0].y) * 0.5f;  // X[0] / 2
         hil[1] = (xl[0].x - xl[0].y) * 0.5f;  // X[8192] / 2
     }
-    __syncthreads();
+    fft_sync();
     v2f yl[16], yh[16];
     {
         // partner Zf[(8192 - k) & 8191] of k = j + 256 t' sits at pad16(8192 - j) - 272 t' (thread 0: 8704 - 272 t'; its t' = 0 read
@@ -141,11 +142,11 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
         v0[t] = lo + hi;
         v1[t] = cmulc(lo - hi, wk[t]);
     }
-    __syncthreads();  // partners are read from the buffers the inverse is about to overwrite
+    fft_sync();  // partners are read from the buffers the inverse is about to overwrite
     fft4096t_dual<true>(v0, v1, A, B, j, tw);  // v_r[t] = (Im a[2m], Im a[2m+1]), m = 2 (j + 256 t) + r
 
     // ---- 3. analytic slice s[i] = analytic[4096 + i]: imaginary parts through LDS, read back interleaved -------------------------
-    __syncthreads();  // pass 3 of the inverse reads all over A and B
+    fft_sync();  // pass 3 of the inverse reads all over A and B
     float* imag = reinterpret_cast<float*>(A);  // 8192 floats
 #pragma unroll
     for (int t = 4; t < 12; ++t) {  // samples 4 (j + 256 t) ... + 3 of the 16384-sample window; the slice is [4096, 12288)
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
             for (int t = 0; t < 16; ++t) xr[t] = v2f{ring[(qx + 512u * (unsigned)t) & mask32], ring[(qx + 512u * (unsigned)t + 1u) & mask32]};
         }
     }
-    __syncthreads();
+    fft_sync();
     v2f s0[16], s1[16];  // s[2 (j + 256 t)], s[2 (j + 256 t) + 1]
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
         v2f w[16];  // w^k again (not held across the transform: 32 registers it needs)
 #pragma unroll
         for (int t = 0; t < 16; ++t) w[t] = load_v2f(T8192b, ju * 8u, 2048u * (unsigned)t);
-        __syncthreads();  // pass 3 still reads A and B
+        fft_sync();  // pass 3 still reads A and B
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const v2f m = cmul(f1[t], w[t]);
@@ -200,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
             f0[t] = v2f{s0[t].x * nc, s0[t].y * nc};
             f1[t] = v2f{s1[t].x * (nc + 1.0f), s1[t].y * (nc + 1.0f)};
         }
-        __syncthreads();  // the gather above still reads A
+        fft_sync();  // the gather above still reads A
         spectrum(f0, f1, lin_z2);
     }
     // (Z's pass 1 writes A and B: the Z2 copy in B must be consumed first -> t = FFT(t w s) is formed now and parked in registers)
-    __syncthreads();
+    fft_sync();
     v2f bt[17];
 #pragma unroll
     for (int t = 0; t < 17; ++t) {
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
         const v2f z2s{z2m.x + z2p.x, z2m.y + z2p.y};
         bt[t] = v2f{c0 * z2c.x + half_c1 * z2s.x, c0 * z2c.y + half_c1 * z2s.y};
     }
-    __syncthreads();  // those reads are done before Z's pass 1 writes
+    fft_sync();  // those reads are done before Z's pass 1 writes
     spectrum(s0, s1, lin_z);
-    __syncthreads();
+    fft_sync();
 
     // ---- 5. reassignment + ordered compaction (bins j + 256 t, t < 16, and bin 4096 on thread 0), in two halves of the bins ---------
     omx_spectrogram_point* out = a.points + ((uint64_t)s * a.n_cols + col) * a.column_stride;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
                 if (lane == 0) scan[i * 4 + wave] = (uint32_t)__popcll(masks[i]);
             }
         }
-        __syncthreads();
+        fft_sync();
         // exclusive prefix of this half's wave counts ([t][wave] row-major = bin order)
         const uint32_t cnt = lane < 4 * NT ? scan[lane] : 0u;
         const uint32_t inc = wave_inclusive_sum(cnt);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void stft_reassigned_8192_kernel(StftFastAr
         emitted += (uint32_t)__builtin_amdgcn_readlane((int)inc, 4 * NT - 1);
     };
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
-    __syncthreads();  // the wave counts are rewritten
+    fft_sync();  // the wave counts are rewritten
     half(std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{});
     if (j == 0) *count_out = emitted;
 }

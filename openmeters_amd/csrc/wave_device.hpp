@@ -5,6 +5,12 @@
 #include <hip/hip_runtime.h>
 
 namespace omx {
+
+// Workgroup barrier for kernels whose threads exchange data through LDS only: waits for this wavefront's LDS traffic and leaves its global
+// loads and stores in flight.  __syncthreads() also drains vmcnt at each call — the next tile's prefetch issued just before it, every ring
+// / row / point store since the last one.
+__device__ __forceinline__ void lds_workgroup_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 namespace wave {
 
 // max / min as the bare instructions: fmaxf / fminf make hipcc quiet every operand it cannot prove canonical first (v_max_f32 v, v, v
