@@ -397,6 +397,30 @@ def test_classic_quiet_column_paired_with_a_loud_one(omx, oracle, W, level_db):
         bar("classic (fused): |d code| within 40 dB of max, a quiet column paired with a loud one", m["loud_code_diff"], 1, m)
 
 
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_spectrum_hop_with_a_large_offset_paired_with_a_loud_one(omx, oracle, N):
+    """the level equalisation of the paired hops takes its scale from a hop's sample RANGE (max - min), not from its largest sample: a
+    hop that is a large constant plus a signal 80 dB below it is scaled by its signal — the constant leaves with the mean (window.rs:80-84)
+    — and must come out as the oracle's; also a hop of one constant (range 0: scale 1) and an all-zero hop beside a loud one"""
+    from openmeters_amd import banks
+    cfg = SpectrumConfig(fft_size=N, hop_size=N, floor_db=-140.0)
+    rng = np.random.default_rng(77)
+    loud = rng.uniform(-1.0, 1.0, (N, 2)).astype(np.float32)
+    offset = (0.5 + 5e-5 * rng.uniform(-1.0, 1.0, (N, 2))).astype(np.float32)
+    flat = np.full((N, 2), 0.25, np.float32)
+    zero = np.zeros((N, 2), np.float32)
+    pcm = np.concatenate([offset, loud, loud, flat, zero, loud])   # pairs (offset, loud), (loud, flat), (zero, loud)
+    bank = banks.SpectrumBank(omx, cfg, 1, emit_all_hops=True)
+    up = bank.process_host(pcm[None], 2, 48000.0)
+    assert up is not None and int(up.n_hops) == 6
+    ref = SpectrumProcessor(oracle, cfg)
+    for h in range(6):
+        w = ref.process_block(AudioBlock(pcm[h * N:(h + 1) * N].reshape(-1), 2, 48000.0))
+        g = bank.fetch(0, h, N // 2 + 1)
+        check_trace(g[0][0], w.traces[0][0], floor=-140.0)
+        check_trace(g[0][1], w.traces[0][1], floor=-140.0)
+
+
 @pytest.mark.parametrize("N,level_db", [(1024, -90.0), (4096, -60.0)])
 def test_spectrum_quiet_hop_paired_with_a_loud_one(omx, oracle, N, level_db):
     """the same mechanism in the spectrum bank (two consecutive hops share one complex transform): every hop's trace — emit_all_hops —

@@ -8,7 +8,7 @@ TOTAL=$(mktemp)
 for b in $(seq $FIRST $((FIRST + COUNT - 1))); do
   OMX_SOAK_SEED=$b OMX_PARITY_REPORT=$REP python -m pytest tests/test_gpu_soak.py -q -m gpu 2>&1 | grep -E "passed|failed|^FAILED|AssertionError" | head -8 | sed "s/^/base $b: /"
   grep "^exemption:" $REP | awk '{ n = NF; if ($(n-2) + 0 > 0) print }' | sed "s/^/base $b: /"
-  grep -E "^exemption:|exact f64\)" $REP >> $TOTAL
+  grep -E "^exemption:|exempted columns" $REP >> $TOTAL
 done
 python3 - "$TOTAL" <<'PY'
 import re, sys, collections
