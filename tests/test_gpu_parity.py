@@ -398,18 +398,18 @@ def test_classic_quiet_column_paired_with_a_loud_one(omx, oracle, W, level_db):
 
 
 @pytest.mark.parametrize("N", [1024, 4096])
-def test_spectrum_hop_with_a_large_offset_paired_with_a_loud_one(omx, oracle, N):
-    """the level equalisation of the paired hops takes its scale from a hop's sample RANGE (max - min), not from its largest sample: a
-    hop that is a large constant plus a signal 80 dB below it is scaled by its signal — the constant leaves with the mean (window.rs:80-84)
-    — and must come out as the oracle's; also a hop of one constant (range 0: scale 1) and an all-zero hop beside a loud one"""
+def test_spectrum_constant_and_silent_hops_paired_with_loud_ones(omx, oracle, N):
+    """edge cases of the level equalisation of the paired hops (its scale comes from a hop's sample range, max - min): a hop of one
+    constant (range 0: scale 1, the constant leaves with the mean, window.rs:80-84) and an all-zero hop, each beside a loud one.
+    (A hop that is a LARGE constant plus a small signal is not in here on purpose: an f32 mean of ~0.5 is good to 1e-7 ... 1e-6 whatever
+    the summation order, and that residue times the window's DC gain moves bins 0 ... 2 by up to 1e-4 of the trace maximum in the
+    reference's own evaluation — measured against exact f64, DESIGN §7 — so there is no 1e-5 bar to hold either side to.)"""
     from openmeters_amd import banks
     cfg = SpectrumConfig(fft_size=N, hop_size=N, floor_db=-140.0)
     rng = np.random.default_rng(77)
     loud = rng.uniform(-1.0, 1.0, (N, 2)).astype(np.float32)
-    offset = (0.5 + 5e-5 * rng.uniform(-1.0, 1.0, (N, 2))).astype(np.float32)
-    flat = np.full((N, 2), 0.25, np.float32)
-    zero = np.zeros((N, 2), np.float32)
-    pcm = np.concatenate([offset, loud, loud, flat, zero, loud])   # pairs (offset, loud), (loud, flat), (zero, loud)
+    flat, zero = np.full((N, 2), 0.25, np.float32), np.zeros((N, 2), np.float32)
+    pcm = np.concatenate([flat, loud, loud, flat, zero, loud])   # pairs (flat, loud), (loud, flat), (zero, loud)
     bank = banks.SpectrumBank(omx, cfg, 1, emit_all_hops=True)
     up = bank.process_host(pcm[None], 2, 48000.0)
     assert up is not None and int(up.n_hops) == 6
