@@ -496,10 +496,14 @@ __global__ __launch_bounds__(256) void wave_prefix_kernel(WaveChunkArgs a) {
     a.prefix_hi[t] = 0.0;
     a.prefix_lo[t] = 0.0;
     const double* src = a.seg_sum + t;
-    for (uint32_t j0 = 0; j0 < a.n_segs; j0 += 16u) {
-        double x[16];
+    // One thread per value, 384 wavefronts in all: less than one per SIMD, so nothing hides a load's latency but the thread itself —
+    // two batches of 16 segment sums are kept in flight ahead of the batch being added (as one batch per round trip the kernel spent
+    // 67 us on ~38 round trips per thread; the dependent double-double additions themselves are ~27 us).
+    auto fetch = [&](double (&x)[16], uint32_t j0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = j0 + (uint32_t)k < a.n_segs ? src[(uint64_t)(j0 + (uint32_t)k) * total] : 0.0;
+    };
+    auto add = [&](const double (&x)[16], uint32_t j0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (j0 + (uint32_t)k >= a.n_segs) break;
@@ -514,6 +518,19 @@ __global__ __launch_bounds__(256) void wave_prefix_kernel(WaveChunkArgs a) {
             a.prefix_hi[(uint64_t)(j0 + (uint32_t)k + 1u) * total + t] = hi;
             a.prefix_lo[(uint64_t)(j0 + (uint32_t)k + 1u) * total + t] = lo;
         }
+    };
+    double x0[16], x1[16], x2[16];
+    fetch(x0, 0u);
+    fetch(x1, 16u);
+    for (uint32_t j0 = 0; j0 < a.n_segs; j0 += 48u) {
+        fetch(x2, j0 + 32u);
+        add(x0, j0);
+        if (j0 + 16u >= a.n_segs) break;
+        fetch(x0, j0 + 48u);
+        add(x1, j0 + 16u);
+        if (j0 + 32u >= a.n_segs) break;
+        fetch(x1, j0 + 64u);
+        add(x2, j0 + 32u);
     }
 }
 
