@@ -251,10 +251,11 @@ enum {
     OMX_OPT_KERNEL_TIMING = 1, /* value != 0: bracket the dominant kernel with HIP events */
     OMX_OPT_FORCE_GENERIC = 2, /* value != 0: route through the generic any-size kernels (A/B checks) */
     OMX_OPT_KERNEL_FORM = 3,   /* spectrogram bank, reassigned 4096 / hop any: which of the equivalent kernel forms runs.
-                                * 0 = tuned kernel (default; round 4: three workgroups per CU); 1 = the round-1 kernel (five transforms
-                                * per frame); 2 = the round-2 pair kernel (two workgroups per CU, two LDS buffers);
-                                * 30 = size-templated kernel; 31 = three-kernel form through an HBM scratch.  All compute
-                                * the same columns (tests cross-check them); unknown values are rejected. */
+                                * 0 = tuned kernel (default; round 4: three workgroups per CU); 30 = size-templated kernel; 31 = three-kernel
+                                * form through an HBM scratch (both are live code for other sizes).  1 = the round-1 kernel (five
+                                * transforms per frame), 2 = the round-2 pair kernel: superseded, compiled into the TUNING library only
+                                * (`make TUNING=1`) — the product returns OMX_ERR_UNSUPPORTED for them.  All compute the same columns
+                                * (tests cross-check them); unknown values are rejected with OMX_ERR_INVALID. */
     OMX_OPT_LOUDNESS_REBASE_FRAMES = 4 /* loudness bank: a call that finds the chunk-parallel form's running totals older than this many frames
                                 * takes them afresh from the sample ring first (default 2^22; checked once per call).  The totals are
                                 * double-double pairs, so a window sum — the difference of two of them — is good to ~1e-16 of itself whatever

@@ -234,15 +234,17 @@ int omx_debug_k2_phase_cycles(uint64_t* out, uint32_t n, int reset) {
     if (!out || n < (uint32_t)K2_PHASES) return OMX_ERR_INVALID;
     REQUIRE_DEVICE();
 #ifndef OMX_TUNING
+    (void)reset;
     set_last_error("omx_debug_k2_phase_cycles: phase-timing kernels exist only in the tuning build (make TUNING=1)");
     return OMX_ERR_UNSUPPORTED;
-#endif
+#else
     return guarded([&] {
         unsigned long long c[K2_PHASES];
         k2_phase_cycles(c, reset != 0);
         for (int i = 0; i < K2_PHASES; ++i) out[i] = c[i];
         return (int)K2_PHASES;
     });
+#endif
 }
 int omx_spectrogram_bank_process_ragged(omx_spectrogram_bank* b, const float* pcm, uint64_t frames_capacity, const uint32_t* frames,
                                         const uint8_t* reset_mask, uint32_t channels, float sample_rate,
@@ -259,6 +261,12 @@ int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, ui
         case OMX_OPT_FORCE_GENERIC: b->impl.force_generic(value != 0); return OMX_NONE;
         case OMX_OPT_KERNEL_FORM:
             if (value != 0 && value != 1 && value != 2 && value != 30 && value != 31) return OMX_ERR_INVALID;
+#ifndef OMX_TUNING
+            if (value == 1 || value == 2) {  // the round-1 kernel and the round-2 pair kernel: superseded, compiled into the tuning library only
+                set_last_error("OMX_OPT_KERNEL_FORM 1 / 2: superseded kernels, built by `make TUNING=1` (libomx_hip_tuning.so) only");
+                return OMX_ERR_UNSUPPORTED;
+            }
+#endif
             b->impl.kernel_form((int)value);
             return OMX_NONE;
         default: return OMX_ERR_INVALID;

@@ -632,6 +632,9 @@ __device__ __forceinline__ bool reassign_bin_fast(uint32_t i, v2f b, v2f d, v2f 
 //   4. per-bin reassignment + ordered compaction (ascending bin), 12-byte points
 // ================================================================================================
 // Compile-time switches of the fused kernel (A/B-tested on MI355X; see DESIGN.md §4 and profiles/).
+// Round 5: this kernel — the round-1 form of K2, OMX_OPT_KERNEL_FORM = 1 — and every variant of it are compiled into the TUNING library only
+// (make TUNING=1); the product runs the tri kernel (stft4096_tri_kernels.hip) for every window of the reference.
+#ifdef OMX_TUNING
 template <uint32_t COLS, bool TW2_LDS_, bool TW3_REGS_, bool DUAL_, bool PINGPONG_, bool ONEBUF_ = false, int MINW = 2,
           bool RECOMPUTE_S_ = false, bool TWIN_CALC_ = false, bool PHASES_ = false,
           bool EARLY_ = false, bool PHASE_WAIT_ = false, bool FAST_REASSIGN_ = false,
@@ -1170,12 +1173,18 @@ void k2_phase_cycles(unsigned long long out[K2_PHASES], bool reset) {
 }
 
 using K2Default = K2Variant<1, true, true, true, true, false, 2, false, true, false, true>;
+#endif  // OMX_TUNING (the round-1 kernel and its variants)
 
 int stft_reassigned_4096_transforms_per_frame() { return 4; }
 
 void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
-#ifdef OMX_TUNING
+#ifndef OMX_TUNING
+    // product: one form — three workgroups per CU, every window of the reference (1 ... 4 cosine terms) applied on the bins.  Forms 1
+    // (round 1) and 2 (round 2, pair kernel) are refused by omx_spectrogram_bank_set_option; they live in the tuning library.
+    (void)form;
+    launch_stft_reassigned_4096_tri(a, stream);
+#else
     if (form == 0 && a.win_terms == 2) {  // 50 / 51: the structural alternatives of stft4096_swz_kernels.hip (same columns, slower)
         static const int swz_variant = [] {
             const char* e = getenv("OMX_K2_VARIANT");
@@ -1184,7 +1193,6 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
         if (swz_variant == 50) { launch_stft_reassigned_4096_swz_pair(a, stream); return; }
         if (swz_variant == 51) { launch_stft_reassigned_4096_col(a, stream); return; }
     }
-#endif
     {
         static const int env_form = [] {  // tuning build: OMX_K2_FORM = 2 pins the pair kernel (tools/k2_forms.sh)
             const char* e = tuning_env("OMX_K2_FORM");
@@ -1196,7 +1204,6 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
         // round 2: two workgroups per CU, two LDS buffers (Hann / Hamming)
         if (f == 2 && a.win_terms == 2) { launch_stft_reassigned_4096_pair(a, stream); return; }
     }
-#ifdef OMX_TUNING
     // Tuning build only (make TUNING=1 -> libomx_hip_tuning.so, loaded through OMX_HIP_LIB): OMX_K2_VARIANT selects an A/B
     // build of the kernel.  100 / 1 / 2 / 3 / 12 / 13 / 14 / 20 compute the same columns as the default; 7 / 8 / 9 add phase
     // timing; 41-49 are KNOCK-OUT builds that leave one stage out and return WRONG columns (pricing a stage by the kernel
@@ -1232,8 +1239,8 @@ void launch_stft_reassigned_4096(const StftFastArgs& a, int form, hipStream_t st
         case 12: launch_k2_variant<K2Variant<1, true, true, true, true>>(a, stream); return;  // default until the early-load form
         default: break;
     }
-#endif
     launch_k2_variant<K2Default>(a, stream);
+#endif  // OMX_TUNING
 }
 
 // ================================================================================================

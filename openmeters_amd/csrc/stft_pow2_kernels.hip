@@ -267,6 +267,8 @@ __device__ __forceinline__ void half_twiddle_run(v2f (&w8)[16], v2f base) {  // 
     }
 }
 
+// (superseded by the tri kernels below since round 4: compiled into the tuning library and into tools/build_ab.sh's POW2_FORCE_PAIR builds only)
+#if defined(OMX_TUNING) || defined(POW2_FORCE_PAIR)
 template <int LOGN>
 __global__ __launch_bounds__(256, 2) void stft_reassigned_pow2_pair_kernel(StftFastArgs a) {
     using G = FftGeom<LOGN>;
@@ -485,6 +487,7 @@ static void launch_pow2_pair(const StftFastArgs& a, hipStream_t stream) {
     const uint32_t pairs = (a.n_cols + 1u) / 2u, chunks = (pairs + F - 1) / F;
     hipLaunchKernelGGL((stft_reassigned_pow2_pair_kernel<LOGN>), dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a);
 }
+#endif  // OMX_TUNING || POW2_FORCE_PAIR
 
 // ================================================================================================
 // K1p: fused classic column (reference spectrogram/processor.rs:350-380, window.rs:66-88) for W = F = 1024 / 2048 / 4096.
@@ -1742,11 +1745,13 @@ void launch_stft_reassigned_pow2(const StftFastArgs& a, uint32_t fft_size, hipSt
         else launch_pow2_tri<11>(a, stream);
         return;
     }
+#if defined(OMX_TUNING) || defined(POW2_FORCE_PAIR)
     if (a.win_terms == 2 && !one_column_slots && (fft_size == 1024 || fft_size == 2048)) {  // Hann / Hamming: two columns per slot
         if (fft_size == 1024) launch_pow2_pair<10>(a, stream);
         else launch_pow2_pair<11>(a, stream);
         return;
     }
+#endif
     switch (fft_size) {
         case 1024: launch_pow2<10>(a, stream); break;
         case 2048: launch_pow2<11>(a, stream); break;

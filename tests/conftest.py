@@ -88,6 +88,14 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def omx_tuning():
+    """the tuning library (make TUNING=1): the superseded kernel forms and the A/B builds, for cross-checks; None when it is not built"""
+    from openmeters_amd.capi import Api
+    path = os.path.join(os.path.dirname(__file__), "..", "openmeters_amd", "csrc", "libomx_hip_tuning.so")
+    return Api(path, "omx_") if os.path.exists(path) else None
+
+
+@pytest.fixture(scope="session")
 def omx():
     import openmeters_amd
     return openmeters_amd.api()

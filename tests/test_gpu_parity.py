@@ -216,11 +216,19 @@ def test_spectrum_bank_all_hops_equal_per_block_snapshots(omx, oracle):
 
 
 @pytest.mark.parametrize("form", [1, 2, 30, 31])
-def test_equivalent_kernel_forms_compute_the_same_columns(omx, oracle, form):
-    """OMX_OPT_KERNEL_FORM: the previous tuned kernel (1), the size-templated kernel (30) and the three-kernel form (31)
+def test_equivalent_kernel_forms_compute_the_same_columns(omx, omx_tuning, oracle, form):
+    """OMX_OPT_KERNEL_FORM: the size-templated kernel (30) and the three-kernel form (31) of the product, and the superseded round-1 (1)
+    and round-2 pair (2) kernels — compiled into the tuning library only since round 5 (`make TUNING=1`; the product refuses them) —
     must produce the tuned kernel's columns: every form against the oracle at the usual bars, and against form 0 with the
     same point counts on strong columns; a silent stream and an odd window start (unaligned ring pairs) included.  Unknown
-    forms are rejected.  (The A/B, phase-timing and knock-out builds live in the tuning library only: make TUNING=1.)"""
+    forms are rejected.  (The A/B, phase-timing and knock-out builds live in the tuning library as well.)"""
+    if form in (1, 2):
+        probe = banks.SpectrogramBank(omx, SpectrogramConfig(fft_size=4096, hop_size=255, use_reassignment=True, history_length=8192), 1)
+        with pytest.raises(capi.OmxError):
+            probe.set_option(capi.OPT_KERNEL_FORM, form)   # the product holds no superseded form
+        if omx_tuning is None:
+            pytest.skip("libomx_hip_tuning.so is not built (make -C openmeters_amd/csrc TUNING=1)")
+        omx = omx_tuning
     S, ncols = 5, 7
     cfg = SpectrogramConfig(fft_size=4096, hop_size=255, use_reassignment=True, history_length=8192)   # odd hop: odd starts
     pcm = np.stack([stream_pcm(s, 8192 + 255 * (ncols - 1)) for s in range(S)])

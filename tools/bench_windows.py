@@ -1,5 +1,6 @@
-"""Reassigned 4096 / 256 per window kind (run on the GPU box): the three-workgroups-per-CU kernel (form 0, every window on the bins) against the
-round-1 five-transform kernel (form 1, windows in the time domain)."""
+"""Reassigned 4096 / 256 per window kind (run on the GPU box): the three-workgroups-per-CU kernel (form 0, every window on the bins) and — with the
+tuning library loaded (OMX_HIP_LIB=.../libomx_hip_tuning.so; the product refuses superseded forms since round 5) — the round-1
+five-transform kernel (form 1, windows in the time domain)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +13,7 @@ frames = 2 * W + hop * (cols - 1)
 n = torch.arange(frames + hop * cols * 4, device="cuda:0", dtype=torch.float64)
 tone = (0.5 * torch.sin(2 * torch.pi * (300.0 + 0.002 * n) * n / 48000.0)).to(torch.float32)
 pcm = (tone[None, :, None] * torch.tensor([1.0, 0.8], device="cuda:0")[None, None, :] + 0.001 * (torch.rand((S, len(n), 2), device="cuda:0") - 0.5)).contiguous()
-for form in (0, 1):
+for form in ((0, 1) if "tuning" in os.path.basename(openmeters_amd.LIB_PATH) else (0,)):
   for kind, name in enumerate(["rectangular", "hann", "hamming", "blackman", "blackman-harris"]):
     bank = banks.SpectrogramBank(api, capi.SpectrogramConfig(fft_size=W, hop_size=hop, window=kind, use_reassignment=True, history_length=8192), S)
     bank.set_option(capi.OPT_KERNEL_TIMING, 1)

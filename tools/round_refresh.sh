@@ -23,7 +23,7 @@ echo "== tools/bench_meters.py waveform, OMX_WAVEFORM_SINGLE=1 (the one-wavefron
 echo "== tools/bench_meter_forms.py / bench_wave_forms.py (sequential kernels against the chunk-parallel forms over bank and call sizes) =="; python tools/bench_meter_forms.py 2>&1 | grep streams; python tools/bench_wave_forms.py 2>&1 | grep streams
 echo "== tools/bench_pipeline.py (capture group against separate bank calls) =="; python tools/bench_pipeline.py 2>&1 | grep -v amdgpu.ids
 echo "== tools/latency_c.sh (single-stream handles, host in / host out, 256-frame blocks) =="; bash tools/latency_c.sh 2>&1 | tail -7
-echo "== tools/bench_windows.py (4096 / 256 per window kind; form 1 = the round-1 five-transform kernel) =="; python tools/bench_windows.py 2>&1 | grep 4096
+echo "== tools/bench_windows.py (4096 / 256 per window kind) =="; python tools/bench_windows.py 2>&1 | grep 4096
 echo "== tools/bench_scope_rates.py =="; python tools/bench_scope_rates.py 2>&1 | grep oscillo
 echo "== tools/bench_stream.py --each (the reference's cadence: one batcher block per call) =="; python tools/bench_stream.py --each 2>&1 | grep captures
 echo "== tools/bench_stream.py --frames 1024 =="; python tools/bench_stream.py --frames 1024 --calls 100 2>&1 | grep captures
