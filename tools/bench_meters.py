@@ -50,6 +50,12 @@ def roofline(alg_bytes, ms, kernels, match_all=False):
             "traffic": meter_traffic(kernels, match_all)}
 
 
+# Calls between the two synchronisations of `timed`.  5 through round 4: for a call of ten launches and ~80 us of host-side planning (the
+# waveform bank's chunk-parallel form) a five-call sample measures the pipeline's fill as much as its throughput — same kernels, same box:
+# 0.61 ms per call over 5 calls, 0.49 over 30 (tools/debug/wave_reps.py).  The banks with one or two launches per call read the same either way.
+REPS = 30
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -60,7 +66,7 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def loudness(S=1024, C=8, blocks=64, reps=5, out=sys.stdout):
+def loudness(S=1024, C=8, blocks=64, reps=REPS, out=sys.stdout):
     frames = 256 * blocks
     n = torch.arange(frames, device=dev, dtype=torch.float64)
     pcm = torch.empty((S, frames, C), device=dev, dtype=torch.float32)
@@ -96,7 +102,7 @@ def loudness(S=1024, C=8, blocks=64, reps=5, out=sys.stdout):
             "momentary_lufs_stream0": float(snap.momentary_loudness)}
 
 
-def scope_stereo(S=256, blocks=64, reps=5, out=sys.stdout):
+def scope_stereo(S=256, blocks=64, reps=REPS, out=sys.stdout):
     frames = 256 * blocks
     n = torch.arange(frames, device=dev, dtype=torch.float64)
     pcm = torch.empty((S, frames, 2), device=dev, dtype=torch.float32)
@@ -165,7 +171,7 @@ def reference_defaults(S=64, out=sys.stdout):
     return res
 
 
-def waveform(blocks=64, reps=5, out=sys.stdout, sizes=(64, 1024, 4096), histories=(False, True)):
+def waveform(blocks=64, reps=REPS, out=sys.stdout, sizes=(64, 1024, 4096), histories=(False, True)):
     """the waveform bank (band analysis on; with and without RMS history), 256-frame blocks x `blocks` per call.
     `sizes` = the bank sizes run (tools/profile_meters_pmc.sh profiles ONE size per pass so that its traffic record is per launch)."""
     frames = 256 * blocks
