@@ -1,6 +1,7 @@
 """The column-alignment helper of the GPU parity tests is test infrastructure that every reassigned-column verdict rests on:
 pin its behaviour on synthetic columns (no GPU)."""
 import numpy as np
+import pytest
 
 from parity import align_points, reassigned_column_metrics
 
@@ -35,6 +36,31 @@ def test_alignment_keeps_floor_level_points_with_noisy_frequencies_paired():
     hip[weak, 1] += rng.normal(scale=40.0, size=int(weak.sum())).astype(np.float32)   # f-hat of a floor-level bin is noise
     pairs, oa, ob = align_points(hip, ora, float(ora[:, 2].max()))
     assert len(pairs) == len(ora) and not oa and not ob
+
+
+@pytest.mark.exemptions_allowed   # (the reproducer of the rule it pins: tests/conftest.py fails any other fixed-seed test that needs one)
+def test_floor_level_pairs_are_judged_on_power_only():
+    """soak seed 24012004 (round 5), the mechanism on synthetic columns: a very quiet column (maximum 6e-10) in which each side kept ONE
+    bin the other dropped at the 1e-14 keep threshold — equal powers, 6.4 kHz apart.  The alignment pairs them (it pairs by power); the
+    metrics must not read that as an f-hat error of r |df| = 1e-3, while a pair above the floor with the same distance still counts."""
+    import parity
+    rng = np.random.default_rng(5)
+    n = 60
+    f = np.sort(rng.uniform(500.0, 12000.0, n))
+    p = 10.0 ** rng.uniform(-12.5, -9.4, n)
+    p[7] = 6.0e-10
+    ora = np.stack([rng.normal(size=n), f, p], 1)
+    hip = ora.copy()
+    hip[:, 2] *= 1.0 + 1e-7 * rng.normal(size=n)
+    ora_x = np.vstack([ora, [[-28.2, 21116.0, 1.0054e-14]]]).astype(np.float32)   # kept by the oracle only
+    hip_x = np.vstack([hip, [[-29.9, 14672.0, 1.0051e-14]]]).astype(np.float32)   # kept by HIP only
+    m = reassigned_column_metrics(hip_x, ora_x, 48000.0, 100)
+    assert m["n"] == n + 1 and m["orphans"] == 0            # the two are paired ...
+    assert m["floor_pairs_over"] == 1 and m["freq"] < 1e-9 and m["time"] < 1e-6 and m["power"] < 1e-6   # ... and judged on power only
+    hip_y = hip_x.copy()
+    hip_y[-1, 2] = ora_x[-1, 2] = 5.0e-14                   # the same two points just above the floor band: judged
+    m = reassigned_column_metrics(hip_y, ora_x, 48000.0, 100)
+    assert m["floor_pairs_over"] == 0 and m["freq"] > 1e-3
 
 
 def test_alignment_of_empty_and_one_sided_columns():
