@@ -430,8 +430,9 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
             if (!(a.emit_all || h0 + 1 == n_hops_s)) return;  // emit_all == 0: the stream's last hop is the one materialised
             const float db = fast_power_db(p);
             const bool low = p < a.state_floor;
-            out0[k] = low ? a.floor_db : fmaxf(db + aw, a.floor_db);
-            out0[a.bins + k] = low ? a.floor_db : fmaxf(db, a.floor_db);
+            // (rows are written once and read by another kernel: non-temporal, 2.815 -> 2.74 ms per 65 536 hops)
+            __builtin_nontemporal_store(low ? a.floor_db : fmaxf(db + aw, a.floor_db), out0 + k);
+            __builtin_nontemporal_store(low ? a.floor_db : fmaxf(db, a.floor_db), out0 + a.bins + k);
         } else {
             a.power[(((uint64_t)s * a.n_traces + tr) * a.n_hops + h0) * a.bins + k] = p;
         }
