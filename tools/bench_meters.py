@@ -154,7 +154,7 @@ def reference_defaults(S=64, out=sys.stdout):
     by = hop * 2 * 4 + 4 + 12 * (W // 2 + 1)
     print(f"default spectrogram {W}/{hop} reassigned: {dt*1e3:.3f} ms per {n} frames (kernel {kms:.3f}) -> {n/dt/1e6:.1f} M frames/s", file=out)
     res["default_spectrogram_2048_64"] = {"workload": f"{S} streams, {cols} columns per call", "frames_per_s": n / dt, "ms_per_call": dt * 1e3,
-                                           "kernel_ms": kms, "roofline": roofline(n * float(by), kms, ["stft_reassigned_pow2_pair"])}
+                                           "kernel_ms": kms, "roofline": roofline(n * float(by), kms, ["stft_reassigned_pow2_tri"])}
     del bank, pcm, chunks
     N, hop, hops = 16384, 1024, 256
     frames = N + hop * (hops - 1)
@@ -168,6 +168,21 @@ def reference_defaults(S=64, out=sys.stdout):
     print(f"default spectrum {N}/{hop}: {dt*1e3:.3f} ms per {n} hops -> {n/dt/1e6:.2f} M hops/s", file=out)
     res["default_spectrum_16384_1024"] = {"workload": f"{S} streams, {hops} hops per call, every hop materialised", "hops_per_s": n / dt,
                                           "ms_per_call": dt * 1e3, "roofline": roofline(n * float(by), dt * 1e3, ["spectrum_"])}
+    del sp, pcm, chunks
+    # BASELINE configs[0] — the reference's own CPU-runnable case, the shape `cpu_baseline.cfg1_classic_1024` times on the host: 1024-pt Hann,
+    # hop 256, classic columns (u16 dB codes), here for 64 streams x 4096 columns per call
+    W, hop, cols = 1024, 256, 4096
+    frames = W + hop * (cols - 1)
+    pcm = (torch.rand((S, frames + hop * cols * 3, 2), device=dev) - 0.5).contiguous()
+    bank = banks.SpectrogramBank(api, capi.SpectrogramConfig(fft_size=W, hop_size=hop, use_reassignment=False, history_length=8192), S)
+    bank.process_device(pcm[:, :frames].contiguous().data_ptr(), frames, 2, FS, pos)
+    chunks = [pcm[:, frames + it * hop * cols: frames + (it + 1) * hop * cols].contiguous() for it in range(3)]
+    dt = timed(lambda: [bank.process_device(c.data_ptr(), hop * cols, 2, FS, pos) for c in chunks], 2) / 3
+    n = S * cols
+    by = hop * 2 * 4 + (W // 2 + 1) * 2   # PCM in + one u16 code per bin out
+    print(f"cfg1 classic {W}/{hop}: {dt*1e3:.3f} ms per {n} frames -> {n/dt/1e6:.1f} M frames/s", file=out)
+    res["cfg1_classic_1024"] = {"workload": f"BASELINE configs[0] shape: {S} streams, {cols} classic columns per call (ingest included)", "frames_per_s": n / dt,
+                                "ms_per_call": dt * 1e3, "roofline": roofline(n * float(by), dt * 1e3, ["stft_classic_pow2"])}
     return res
 
 
