@@ -279,6 +279,11 @@ int omx_debug_scope_phase_cycles(uint64_t* out, uint32_t n, int reset);
  * offset as the sweeps compute it.  The arrays must fit the LDS of one CU. */
 int omx_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len, uint32_t search, float period, uint32_t* best_off,
                               float* frac_offset, float* best_score, float* scores);
+/* test hook: the pre-pass that takes the DC-removed window's mean in the reference's order (window.rs:76-79, a sequential f32 fold).
+ * `samples[n_streams][cap]` are rings of `cap` samples (a power of two); hop h of stream s covers the `window` samples from absolute
+ * position tail + h * hop (mod cap).  sums[n_streams][n_hops] receives every hop's sum, bit for bit the reference's. */
+int omx_debug_window_sums(const float* samples, uint32_t n_streams, uint64_t cap, uint64_t tail, uint32_t hop, uint32_t window, uint32_t n_hops,
+                          float* sums);
 int omx_spectrogram_bank_set_option(omx_spectrogram_bank* b, uint32_t option, uint64_t value);
 
 /* ===================================================================== *

@@ -224,6 +224,33 @@ int omx_debug_scope_find_best(const float* work, const float* tmpl, uint32_t len
         return (int)OMX_PRODUCED;
     });
 }
+int omx_debug_window_sums(const float* samples, uint32_t n_streams, uint64_t cap, uint64_t tail, uint32_t hop, uint32_t window, uint32_t n_hops,
+                          float* sums) {
+    if (!samples || !sums || n_streams == 0 || n_hops == 0 || hop == 0 || window == 0 || cap == 0 || (cap & (cap - 1)) != 0 || cap > (uint64_t(1) << 30))
+        return OMX_ERR_INVALID;
+    REQUIRE_DEVICE();
+    return guarded([&] {
+        DeviceBuffer<float> d_ring, d_sums;
+        d_ring.reserve((size_t)(n_streams * cap));
+        d_sums.reserve((size_t)n_streams * n_hops);
+        OMX_HIP(hipMemcpy(d_ring.ptr, samples, (size_t)(n_streams * cap) * sizeof(float), hipMemcpyHostToDevice));
+        WindowSumArgs w{};
+        w.ring[0] = d_ring.ptr;
+        w.n_rings = 1;
+        w.cap = cap;
+        w.tail = tail;
+        w.hop = hop;
+        w.window = window;
+        w.n_hops = n_hops;
+        w.n_streams = n_streams;
+        w.sums = d_sums.ptr;
+        launch_window_sums(w, nullptr);
+        OMX_HIP(hipGetLastError());
+        OMX_HIP(hipDeviceSynchronize());
+        OMX_HIP(hipMemcpy(sums, d_sums.ptr, (size_t)n_streams * n_hops * sizeof(float), hipMemcpyDeviceToHost));
+        return (int)OMX_PRODUCED;
+    });
+}
 int omx_debug_transforms_per_frame(void) { return stft_reassigned_4096_transforms_per_frame(); }
 int omx_debug_k_weighting_transition(double sample_rate, uint64_t frames, double* out) {
     if (!out || frames == 0 || !(sample_rate > 0.0)) return OMX_ERR_INVALID;

@@ -320,6 +320,10 @@ void SpectrogramBank::launch_columns(uint64_t n_cols, uint64_t tail, const uint6
         }
         fa.points = d_points_.ptr;
         fa.counts = d_counts_.ptr;
+        if (!reassign) {  // classic columns: per-column sequential window sums (window.rs:76-79), written ahead of the transform kernel
+            d_col_sums_.reserve((size_t)(n_streams_ * n_cols));
+            fa.col_sums = d_col_sums_.ptr;
+        }
         const bool cross_check = kernel_form_ == 30;  // OMX_OPT_KERNEL_FORM: 4096 through the size-templated kernel
         const bool split_check = kernel_form_ == 31;  // ... or through the three-kernel form
         if (reassign && fft_size_ == 4096 && !fast_zp_ && split_check) {

@@ -61,7 +61,7 @@ private:
     DeviceBuffer<float> ring_;
     HostStage staging_;
     DeviceBuffer<long long> last_nonzero_, partial_nonzero_;
-    DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_;
+    DeviceBuffer<float> d_window_, d_dwindow_, d_twindow_, d_bin_norm_, d_col_sums_;
     DeviceBuffer<float> d_tw_fft_, d_tw_hilbert_, d_tw256_, d_tw4096_, d_tw8192_, d_twF_, d_workspace_;
     DeviceBuffer<float> d_blu_chirp_, d_blu_bf_, d_blu_tw_;  // Bluestein tables when the transform length is not a power of two
     size_t blu_m_ = 0;

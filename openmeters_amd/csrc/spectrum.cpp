@@ -55,6 +55,7 @@ void SpectrumBank::reset_audio() {  // :112-118
     if (prepared_) reset_level_buffers(last_stream_);
     tail_ = head_;
     pending_skip_ = 0;
+    carry_valid_ = false;
     ragged_ = false;  // every stream drops its pending audio: the common host-side positions describe the bank again
 }
 
@@ -111,6 +112,7 @@ void SpectrumBank::reset_buffers(hipStream_t stream) {  // :138-150
     reset_level_buffers(stream);
     tail_ = head_;
     pending_skip_ = 0;
+    carry_valid_ = false;
 }
 
 void SpectrumBank::reset_level_buffers(hipStream_t stream) {  // :152-168
@@ -264,6 +266,77 @@ int SpectrumBank::process_pushed(hipStream_t stream, omx_spectrum_bank_update* o
     return rc;
 }
 
+// window.rs:76-79: every hop's mean is the reference's sequential f32 fold over the window / N.  The fold of the hops of this call, ahead
+// of the transform kernel (window_sum_kernels.hip), one of two ways:
+//   walk   four consecutive hops per lane quad walk the union of their windows: (W + 3 hop) dependent adds of latency whatever the
+//          call's size — calls that complete many hops;
+//   carry  lock-step calls that bring few samples (the reference's cadence, one batcher block per call): every window that has started
+//          keeps its running fold in a slot between calls, and a call adds only the samples that arrived since (head - carry_pos adds).
+// The carried folds are valid while the bank's positions move by lock-step pushes alone; reset_audio, any reconfiguration that drops
+// the pending audio, a ragged call and a walked call invalidate them, and the next carried call folds its open windows from their
+// first sample again (still in the ring: pending audio is exactly the open windows).
+// (Tried and dropped, round 6: the walk on a side stream in the shadow of the capture group's spectrogram kernel — step 1.731 ... 1.741 ms
+// against 1.712 with the walk in line: beside K2 it runs 120 us instead of 65, K2 stretches, and in line it leaves the ring in L2 for
+// the transform kernel that follows, 344 -> 283 us.)
+bool SpectrumBank::carry_applies(uint64_t tail0) const {
+    const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size;
+    if (hop > N || (N + hop - 1) / hop > 64) return false;
+    const uint64_t from = carry_valid_ ? carry_pos_ : tail0;
+    return head_ - from <= N + 3 * hop;  // (the walk's latency)
+}
+
+void SpectrumBank::launch_window_sums_for(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop,
+                                          uint32_t n_traces, const bool active[2], hipStream_t stream) {
+    const uint64_t N = cfg_.fft_size, hop = cfg_.hop_size;
+    const uint64_t slots = (N + hop - 1) / hop;
+    const uint64_t hops_launch = n_hops - first_hop;
+    d_hop_sums_.reserve((size_t)(n_streams_ * n_traces * hops_launch));
+    const float* rings[2] = {nullptr, nullptr};
+    uint32_t slot = 0;
+    for (int t = 0; t < 2; ++t)
+        if (active[t]) rings[slot++] = ring_[t].ptr;
+    if (!tails && carry_applies(tail0)) {
+        d_carry_.reserve((size_t)(n_streams_ * n_traces * slots));
+        WindowCarryArgs c{};
+        for (uint32_t t = 0; t < n_traces; ++t) c.ring[t] = rings[t];
+        c.n_rings = n_traces;
+        c.cap = ring_cap_;
+        c.tail = tail0;
+        c.carry_pos = carry_valid_ ? carry_pos_ : tail0;
+        c.head = head_;
+        c.n_windows = (head_ - tail0 + hop - 1) / hop;
+        c.hop = (uint32_t)hop;
+        c.window = (uint32_t)N;
+        c.slots = (uint32_t)slots;
+        c.slot0 = carry_valid_ ? carry_slot0_ : 0u;
+        c.first_hop = (uint32_t)first_hop;
+        c.n_hops = (uint32_t)hops_launch;
+        c.n_streams = n_streams_;
+        c.carry = d_carry_.ptr;
+        c.sums = d_hop_sums_.ptr;
+        launch_window_sums_carry(c, stream);
+        carry_slot0_ = (uint32_t)((c.slot0 + n_hops) % slots);
+        carry_pos_ = head_;
+        carry_valid_ = true;
+        return;
+    }
+    carry_valid_ = false;
+    WindowSumArgs w{};
+    for (uint32_t t = 0; t < n_traces; ++t) w.ring[t] = rings[t];
+    w.n_rings = n_traces;
+    w.cap = ring_cap_;
+    w.tail = tail0;
+    w.tails = tails;
+    w.hops = hops;
+    w.hop = (uint32_t)hop;
+    w.window = (uint32_t)N;
+    w.first_hop = (uint32_t)first_hop;
+    w.n_hops = (uint32_t)hops_launch;
+    w.n_streams = n_streams_;
+    w.sums = d_hop_sums_.ptr;
+    launch_window_sums(w, stream);
+}
+
 // The power (+ levels) launches of `n_hops` hops per stream slot, starting at hop `first_hop`.  Lock-step: every stream from
 // `tail0`; ragged: stream s from tails[s], hops[s] of them (n_hops = the layout stride).
 int SpectrumBank::launch_hops(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop, uint32_t n_traces,
@@ -323,6 +396,10 @@ int SpectrumBank::launch_hops(uint64_t tail0, const uint64_t* tails, const uint3
         pa.workspace = reinterpret_cast<v2f*>(d_workspace_.ptr);
     }
     pa.power = d_power_.ptr;
+    if (fast) {
+        launch_window_sums_for(tail0, tails, hops, n_hops, first_hop, n_traces, active, stream);
+        pa.hop_sums = d_hop_sums_.ptr;
+    }
     pa.fused_db = averaging ? 0 : 1;
     pa.emit_all = emit_all_ ? 1 : 0;
     pa.n_hops_out = (uint32_t)hops_out;
@@ -379,6 +456,7 @@ void SpectrumBank::enter_ragged(hipStream_t stream) {
     OMX_HIP(hipMemcpyAsync(r_skip_.ptr, k.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     OMX_HIP(hipStreamSynchronize(stream));
     ragged_ = true;
+    carry_valid_ = false;
 }
 
 int SpectrumBank::process_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask,

@@ -44,6 +44,9 @@ private:
     void active_traces(bool out[2]) const;
     void ensure_ring(uint64_t incoming, hipStream_t stream);
     void enter_ragged(hipStream_t stream);
+    bool carry_applies(uint64_t tail0) const;
+    void launch_window_sums_for(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop, uint32_t n_traces,
+                                const bool active[2], hipStream_t stream);
     int launch_hops(uint64_t tail0, const uint64_t* tails, const uint32_t* hops, uint64_t n_hops, uint64_t first_hop, uint32_t n_traces,
                     const bool active[2], hipStream_t stream);
 
@@ -56,7 +59,11 @@ private:
     DeviceBuffer<float> ring_[2];
     HostStage staging_;
     DeviceBuffer<float> d_window_, d_bin_norm_, d_a_weight_, d_freq_bins_, d_tw_fft_, d_tw256_, d_tw4096_, d_workspace_;
-    DeviceBuffer<float> d_power_, d_smoothed_;
+    DeviceBuffer<float> d_power_, d_smoothed_, d_hop_sums_, d_carry_;
+    // running window folds carried between lock-step calls (launch_window_sums_for)
+    bool carry_valid_ = false;
+    uint64_t carry_pos_ = 0;
+    uint32_t carry_slot0_ = 0;
     OutBuffer<float> d_traces_;
     bool host_outputs_ = false;
     std::vector<float> freq_bins_, a_weight_;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
     using G = FftGeom<LOGN>;
     constexpr int N = G::N, T = G::T, F = G::FRAMES, WPF = T / 64;  // a transform = T threads; F transforms per workgroup
     v2f* tw2_lds = lds + F * G::LDS;                                  // [256]
-    float (*wave_red)[6][WPF] = reinterpret_cast<float (*)[6][WPF]>(tw2_lds + 256);  // [F][sum a, sum b, max a, max b, min a, min b][WPF]
+    float (*wave_red)[4][WPF] = reinterpret_cast<float (*)[4][WPF]>(tw2_lds + 256);  // [F][max a, max b, min a, min b][WPF]
     // F == 1 (4096 points and up): the frame slot is the workgroup — spelled out so that everything derived from it (hop indices, store
     // bases, the has_b / in_range predicates) is wave-uniform for the compiler: scalar branches and SGPR-base stores instead of
     // exec-mask regions and per-lane 64-bit addresses
@@ -136,41 +136,44 @@ __device__ __forceinline__ void spectrum_power_pow2_body(const SpectrumPowerArgs
         TwiddlesPow2<LOGN> tw;
         tw.tw2 = tw2_lds;
         tw.load(a.tw4096, jl);  // exp(-2 pi i k / N) for this N
-        // One reduction round for everything the hop's conditioning needs: the sum (window.rs:80-84 mean; tree order here, the generic
-        // kernel keeps the sequential order) and the largest / smallest sample of each hop (level equalisation, below).
-        v2f sum = x[0] + x[1];
+        // window.rs:76-79: the hop's mean is the reference's SEQUENTIAL f32 sum / N — taken by window_sums_seq_kernel ahead of this launch
+        // (a.hop_sums; round 6: as a tree sum here, a hop with a large constant offset sat 8e-5 of the trace maximum from the reference
+        // in bins 0 ... 2).  One reduction round for what is left: the largest / smallest sample of each hop (level equalisation, below).
+        const float* hs = a.hop_sums + ((uint64_t)s * a.n_traces + tr) * a.n_hops + h0;
+        float sum_a, sum_b;
+        if (F == 1) {  // the pair is the workgroup's: scalar loads
+            sum_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hs[0])));
+            sum_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hs[has_b ? 1 : 0])));
+        } else {
+            sum_a = hs[0];
+            sum_b = hs[has_b ? 1 : 0];
+        }
         float hi_a = wave::vmax(x[0].x, x[1].x), lo_a = wave::vmin(x[0].x, x[1].x), hi_b = wave::vmax(x[0].y, x[1].y), lo_b = wave::vmin(x[0].y, x[1].y);
 #pragma unroll
         for (int t = 2; t < 16; t += 2) {
-            sum += x[t];
-            sum += x[t + 1];
             hi_a = wave::vmax3(hi_a, x[t].x, x[t + 1].x);
             lo_a = wave::vmin3(lo_a, x[t].x, x[t + 1].x);
             hi_b = wave::vmax3(hi_b, x[t].y, x[t + 1].y);
             lo_b = wave::vmin3(lo_b, x[t].y, x[t + 1].y);
         }
-        float sum_a = sum.x, sum_b = sum.y;
-        wave::scan_sum2_max2_min2(sum_a, sum_b, hi_a, hi_b, lo_a, lo_b);
-        const float red[6] = {sum_a, sum_b, hi_a, hi_b, lo_a, lo_b};
+        wave::scan_max2_min2(hi_a, hi_b, lo_a, lo_b);
+        const float red[4] = {hi_a, hi_b, lo_a, lo_b};
         if ((jfl & 63) == 63) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) wave_red[fs][q][jfl >> 6] = red[q];
+            for (int q = 0; q < 4; ++q) wave_red[fs][q][jfl >> 6] = red[q];
         }
         if (F == 1) frame_sync<LOGN>();  // wave partials (and, for the first pair, tw2_lds)
         else lds_workgroup_barrier();            // (tw2_lds is shared by every frame slot)
-        float ta = 0.0f, tb = 0.0f;
         hi_a = hi_b = -INFINITY;
         lo_a = lo_b = INFINITY;
 #pragma unroll
         for (int i = 0; i < WPF; ++i) {
-            ta += wave_red[fs][0][i];
-            tb += wave_red[fs][1][i];
-            hi_a = wave::vmax(hi_a, wave_red[fs][2][i]);
-            hi_b = wave::vmax(hi_b, wave_red[fs][3][i]);
-            lo_a = wave::vmin(lo_a, wave_red[fs][4][i]);
-            lo_b = wave::vmin(lo_b, wave_red[fs][5][i]);
+            hi_a = wave::vmax(hi_a, wave_red[fs][0][i]);
+            hi_b = wave::vmax(hi_b, wave_red[fs][1][i]);
+            lo_a = wave::vmin(lo_a, wave_red[fs][2][i]);
+            lo_b = wave::vmin(lo_b, wave_red[fs][3][i]);
         }
-        const v2f mean{ta / (float)N, tb / (float)N};
+        const v2f mean{sum_a / (float)N, has_b ? sum_b / (float)N : 0.0f};
         // Level equalisation (round 5; see stft_classic_pow2_kernel): the two hops ride one complex transform and the split cancels the
         // partner's spectrum only to ~4e-7 of ITS largest bin — a hop 60 dB under its partner came out 3e-5 of the trace maximum off
         // (tests/test_gpu_parity.py::test_spectrum_quiet_hop_paired_with_a_loud_one).  Each hop is scaled by an exact power of two that
@@ -347,14 +350,13 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
     v2f* A = reinterpret_cast<v2f*>(spectrum_smem);
     v2f* B = A + FFT4096_LDS;        // contiguous with A: one 8704-slot buffer for the partner exchange
     v2f* tw2_lds = B + FFT4096_LDS;  // [256]
-    float* wave_sum = reinterpret_cast<float*>(tw2_lds + 256);  // [4]
     const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
     const uint32_t h0 = bq % a.n_hops, st = (bq / a.n_hops) * 8u + xcd;  // XCD-aware: a (stream, trace) stays on one XCD
     if (st >= a.n_streams * a.n_traces) return;
     const uint32_t tr = st % a.n_traces, s = st / a.n_traces;
     const uint32_t n_hops_s = spectrum_hops(a, s);  // ragged banks: this stream's own hop count
     if (h0 >= n_hops_s) return;
-    const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const int j = threadIdx.x;
     const unsigned ju = threadIdx.x;
     const float* ring = a.ring[tr] + (uint64_t)s * a.cap;
     const uint32_t mask32 = (uint32_t)(a.cap - 1);  // cap <= 2^30 (host-checked)
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
     const TW tw{tw2_lds, T, ju * 4u};
     tw2_lds[j] = a.tw256[ju];
 
-    // ---- load, remove the mean, window (window.rs:66-88; the mean in tree order, like the size-templated kernel) ---------------------------
+    // ---- load, remove the mean, window (window.rs:66-88) ----------------------------------------------------------------------------------
     // v0 / v1 = even / odd packed elements 2 (j + 256 t) + r -> samples 4 (j + 256 t) + 2r, + 1
     v2f v0[16], v1[16];
     // the samples of the hop lie in one piece of the ring and pairs are 8-byte aligned: buffer loads (buffer_device.hpp)
@@ -390,14 +392,11 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
             v1[t] = v2f{ring[(q + 2u) & mask32], ring[(q + 3u) & mask32]};
         }
     }
-    float sum0 = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) sum0 += (v0[t].x + v0[t].y) + (v1[t].x + v1[t].y);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum0 += __shfl_xor(sum0, off);
-    if (lane == 0) wave_sum[wave] = sum0;
-    lds_workgroup_barrier();  // wave sums, tw2_lds
-    const float mean0 = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) / (float)N;
+    lds_workgroup_barrier();  // tw2_lds
+    // window.rs:76-79: the reference's sequential f32 sum of the hop, from window_sums_seq_kernel (round 6; a tree sum before)
+    const float sum0 = __builtin_bit_cast(
+        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.hop_sums[((uint64_t)s * a.n_traces + tr) * a.n_hops + h0])));
+    const float mean0 = sum0 / (float)N;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const v2f wl = load_v2f(winb, ju * 16u, 4096u * (unsigned)t), wh = load_v2f(winb, ju * 16u + 8u, 4096u * (unsigned)t);
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void spectrum_power_16384_kernel(SpectrumPo
 }
 
 static void launch_spectrum_16384(const SpectrumPowerArgs& a, uint32_t stream_traces, hipStream_t stream) {
-    const size_t lds = (size_t)(2 * FFT4096_LDS + 256) * sizeof(v2f) + 4 * sizeof(float);
+    const size_t lds = (size_t)(2 * FFT4096_LDS + 256) * sizeof(v2f);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_16384_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -508,7 +507,7 @@ template <int LOGN, bool FUSED>
 static void launch_spectrum_pow2_form(const SpectrumPowerArgs& a, uint32_t stream_traces, uint32_t hop_pairs, hipStream_t stream) {
     using G = FftGeom<LOGN>;
     constexpr int F = G::FRAMES, WPF = G::T / 64;
-    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 6 * WPF * sizeof(float);  // + the wave partials (sum, max, min of both hops)
+    const size_t lds = (size_t)(F * G::LDS + 256) * sizeof(v2f) + (size_t)F * 4 * WPF * sizeof(float);  // + the wave partials (max, min of both hops)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_power_pow2_kernel<LOGN, FUSED>),

@@ -87,6 +87,42 @@ void launch_spectrogram_ragged_config(uint32_t n_streams, const uint64_t* head, 
                                       long long* last_nonzero, bool trim, uint64_t keep, bool zero_skip, bool clear_nonzero, hipStream_t stream);
 void launch_ingest(const IngestArgs& a, uint32_t n_streams, hipStream_t stream);
 
+// ---------------------------------------------------------------- window sums in the reference's order (window_sum_kernels.hip)
+// sums[s][r][h] = the sequential f32 fold (window.rs:76-79) over the `window` samples of hop first_hop + h of ring r of stream s.
+// The fused classic / spectrum kernels divide it by the window length for the DC-removed copy's mean.
+struct WindowSumArgs {
+    const float* ring[2];   // [n_streams][cap] each
+    uint32_t n_rings;       // 1 or 2
+    uint64_t cap;           // power of two <= 2^31
+    uint64_t tail;          // absolute position of hop 0's first sample (lock-step)
+    const uint64_t* tails;  // ragged: per stream, or nullptr
+    const uint32_t* hops;   // ragged: hops of every stream in this call (n_hops = layout stride), or nullptr
+    uint32_t hop, window;
+    uint32_t first_hop;     // first hop computed (hop h of the launch is hop first_hop + h of the call)
+    uint32_t n_hops;        // hops per (stream, ring) computed by this launch = layout stride of `sums`
+    uint32_t n_streams;
+    float* sums;            // [n_streams][n_rings][n_hops]
+};
+void launch_window_sums(const WindowSumArgs& a, hipStream_t stream);
+// The same sums carried from call to call (lock-step banks fed a few samples per call): every window that has started keeps its running
+// fold in one of `slots` = ceil(window / hop) slots per (stream, ring); see window_sums_carry_kernel.
+struct WindowCarryArgs {
+    const float* ring[2];
+    uint32_t n_rings;
+    uint64_t cap;
+    uint64_t tail;        // first sample of window 0 of this call (the bank's tail before its hops were drained)
+    uint64_t carry_pos;   // samples below this position are already in the carried folds (== tail: nothing is carried)
+    uint64_t head;        // one past the newest sample in the ring
+    uint64_t n_windows;   // windows that start below `head`: ceil((head - tail) / hop)
+    uint32_t hop, window;
+    uint32_t slots, slot0;  // slot of window k = (slot0 + k) % slots
+    uint32_t first_hop, n_hops;  // sums[s][r][k - first_hop] for completed windows first_hop <= k < first_hop + n_hops
+    uint32_t n_streams;
+    float* carry;         // [n_streams][n_rings][slots]
+    float* sums;          // [n_streams][n_rings][n_hops]
+};
+void launch_window_sums_carry(const WindowCarryArgs& a, hipStream_t stream);
+
 // ---------------------------------------------------------------- K2 fast reassigned STFT (W = F = 4096)
 struct StftFastArgs {
     const float* ring;  // [n_streams][cap]
@@ -120,6 +156,9 @@ struct StftFastArgs {
     const uint32_t* cols;
     omx_spectrogram_point* points;  // [n_streams][n_cols][column_stride]
     uint32_t* counts;               // [n_streams][n_cols]
+    // classic columns: [n_streams][n_cols] sequential f32 window sums (window.rs:76-79; window_sum_kernels.hip), written by the classic
+    // launchers ahead of the transform kernel
+    float* col_sums;
 };
 __device__ __forceinline__ uint64_t stft_tail(const StftFastArgs& a, uint32_t s) { return a.tails ? a.tails[s] : a.tail; }
 __device__ __forceinline__ uint32_t stft_cols(const StftFastArgs& a, uint32_t s) { return a.cols ? a.cols[s] : a.n_cols; }
@@ -218,6 +257,8 @@ struct SpectrumPowerArgs {
     const v2f* tw4096;
     v2f* workspace;        // generic: [wgs][fft_size]
     float* power;          // [n_streams][n_traces][n_hops][bins] (when !fused_db)
+    const float* hop_sums; // fast kernels: [n_streams][n_traces][n_hops] sequential f32 window sums (window_sum_kernels.hip), written by
+                           // the bank ahead of this launch (SpectrumBank::launch_window_sums_for)
     // AveragingMode::None: dB conversion fused into the power kernel, traces written directly
     uint32_t fused_db, emit_all, n_hops_out;
     uint32_t trace_slot[2];

@@ -555,30 +555,11 @@ __global__ __launch_bounds__(FftGeom<LOGN>::WG) void stft_classic_pow2_kernel(St
     float norm[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) norm[t] = a.bin_norm[(t < 8 || jf == 0) ? ju + (unsigned)T * (unsigned)t : 0u];
-    // window.rs:80-84 mean (tree order; the generic kernel keeps the reference's sequential order)
-    float sa = 0.0f, sb = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const bool inside = ju + (unsigned)T * (unsigned)t < Wn;
-        sa += inside ? xa[t] : 0.0f;
-        sb += (inside && has_b) ? xb[t] : 0.0f;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sa += __shfl_xor(sa, off);
-        sb += __shfl_xor(sb, off);
-    }
-    if ((jf & 63) == 0) {
-        wave_sum[fs][0][wf] = sa;
-        wave_sum[fs][1][wf] = sb;
-    }
-    lds_workgroup_barrier();  // wave sums and tw2_lds (shared by every frame slot)
-    float ta = 0.0f, tb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) {
-        ta += wave_sum[fs][0][i];
-        tb += wave_sum[fs][1][i];
-    }
+    // window.rs:76-79: the column's mean is the reference's sequential f32 sum over the window / W — taken by window_sums_seq_kernel ahead of
+    // this launch (a.col_sums; round 6: a tree sum here before, 8e-5 of the column maximum from the reference on a hop with a large offset)
+    const float* cs = a.col_sums + (uint64_t)s * a.n_cols + col_a;
+    const float ta = cs[0], tb = has_b ? cs[1] : 0.0f;
+    lds_workgroup_barrier();  // tw2_lds (shared by every frame slot)
     const float mean_a = ta / (float)Wn, mean_b = tb / (float)Wn;  // mean over the window (window.rs:80-84)
     v2f v[16];
 #pragma unroll
@@ -652,8 +633,26 @@ static void launch_classic(const StftFastArgs& a, uint16_t* codes, hipStream_t s
     const uint32_t pairs = (a.n_cols + 1) / 2, chunks = (pairs + F - 1) / F;
     hipLaunchKernelGGL(stft_classic_pow2_kernel<LOGN>, dim3(stream_column_grid(a.n_streams, chunks)), dim3(G::WG), lds, stream, a, codes);
 }
+// window.rs:76-79: every classic column's sequential f32 window sum, ahead of the transform kernel that divides it by the window length
+static void launch_classic_window_sums(const StftFastArgs& a, uint32_t window, hipStream_t stream) {
+    WindowSumArgs w{};
+    w.ring[0] = a.ring;
+    w.n_rings = 1;
+    w.cap = a.cap;
+    w.tail = a.tail;
+    w.tails = a.tails;
+    w.hops = a.cols;
+    w.hop = a.hop;
+    w.window = window;
+    w.first_hop = 0;
+    w.n_hops = a.n_cols;
+    w.n_streams = a.n_streams;
+    w.sums = a.col_sums;
+    launch_window_sums(w, stream);
+}
 void launch_stft_classic_pow2(const StftFastArgs& a, uint16_t* codes, uint32_t fft_size, hipStream_t stream) {
     if (a.n_cols == 0 || a.n_streams == 0) return;
+    launch_classic_window_sums(a, a.window_size ? a.window_size : fft_size, stream);
     switch (fft_size) {
         case 1024: launch_classic<10>(a, codes, stream); break;
         case 2048: launch_classic<11>(a, codes, stream); break;
@@ -1247,11 +1246,10 @@ template <int LOGW>
 __global__ __launch_bounds__(FftGeom<LOGW>::WG) void classic_residue_kernel(StftFastArgs a, uint16_t* __restrict__ codes, const v2f* __restrict__ twF,
                                                                            uint32_t zp) {
     using G = FftGeom<LOGW>;
-    constexpr int N = G::N, T = G::T, WPF = T / 64;
+    constexpr int N = G::N, T = G::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* buf = reinterpret_cast<v2f*>(smem_raw);
     v2f* tw2_lds = buf + G::LDS;
-    float* wave_sum = reinterpret_cast<float*>(tw2_lds + 256);  // [WPF]
     const uint32_t item = blockIdx.x, r = blockIdx.y;
     const uint32_t s = item / a.n_cols, col = item % a.n_cols;
     if (col >= stft_cols(a, s)) return;
@@ -1266,20 +1264,11 @@ __global__ __launch_bounds__(FftGeom<LOGW>::WG) void classic_residue_kernel(Stft
     tw.load(a.tw4096, ju);  // exp(-2 pi i k / W)
     for (unsigned i = threadIdx.x; i < 256u; i += (unsigned)T) tw2_lds[i] = a.tw256[i];
     float x[16];
-    float sum = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        x[t] = *reinterpret_cast<const float*>(ring_bytes + (((p32 + ju + (unsigned)T * (unsigned)t) << 2) & bytemask));
-        sum += x[t];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    if ((j & 63) == 0) wave_sum[j >> 6] = sum;
-    lds_workgroup_barrier();  // wave sums, tw2_lds
-    float total = 0.0f;
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) total += wave_sum[i];
-    const float mean = total / (float)N;  // window.rs:80-84 (tree order, as in the fused classic kernel)
+    for (int t = 0; t < 16; ++t) x[t] = *reinterpret_cast<const float*>(ring_bytes + (((p32 + ju + (unsigned)T * (unsigned)t) << 2) & bytemask));
+    lds_workgroup_barrier();  // tw2_lds
+    const float total = a.col_sums[(uint64_t)s * a.n_cols + col];  // the reference's sequential f32 sum (window_sum_kernels.hip)
+    const float mean = total / (float)N;  // window.rs:76-79
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -1310,6 +1299,7 @@ static void launch_classic_residue_w(const StftFastArgs& a, uint16_t* codes, con
 }
 bool launch_stft_classic_residue(const StftFastArgs& a, uint16_t* codes, uint32_t window, uint32_t zp, const v2f* twF, hipStream_t stream) {
     if (a.n_streams == 0 || a.n_cols == 0) return true;
+    if (window == 1024 || window == 2048 || window == 4096 || window == 8192 || window == 16384) launch_classic_window_sums(a, window, stream);
     switch (window) {
         case 1024: launch_classic_residue_w<10>(a, codes, twF, zp, stream); return true;
         case 2048: launch_classic_residue_w<11>(a, codes, twF, zp, stream); return true;

@@ -79,6 +79,22 @@ __device__ __forceinline__ void scan_sum2_max2_min2(float& s0, float& s1, float&
         : "+v"(s0), "+v"(s1), "+v"(hi0), "+v"(hi1), "+v"(lo0), "+v"(lo1));
 }
 #undef OMX_DPP6
+// the same for two maxima and two minima (the hop pair's sample ranges; the sums come from window_sum_kernels.hip since round 6).
+// Each value is touched once per group of four instructions: the two wait states a DPP read needs after a VALU write are covered.
+#define OMX_DPP4(step)                                          \
+    "v_max_f32_dpp %0, %0, %0 " step "\n v_max_f32_dpp %1, %1, %1 " step "\n" \
+    "v_min_f32_dpp %2, %2, %2 " step "\n v_min_f32_dpp %3, %3, %3 " step "\n"
+__device__ __forceinline__ void scan_max2_min2(float& hi0, float& hi1, float& lo0, float& lo1) {
+    asm("s_nop 1\n"
+        OMX_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf")
+        OMX_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf")
+        OMX_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf")
+        OMX_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf")
+        OMX_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        OMX_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(hi0), "+v"(hi1), "+v"(lo0), "+v"(lo1));
+}
+#undef OMX_DPP4
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (uint32_t)(127 + e) << 23); }  // 2^e, -126 <= e <= 127
 
 }  // namespace wave

@@ -409,9 +409,8 @@ def test_classic_quiet_column_paired_with_a_loud_one(omx, oracle, W, level_db):
 def test_spectrum_constant_and_silent_hops_paired_with_loud_ones(omx, oracle, N):
     """edge cases of the level equalisation of the paired hops (its scale comes from a hop's sample range, max - min): a hop of one
     constant (range 0: scale 1, the constant leaves with the mean, window.rs:80-84) and an all-zero hop, each beside a loud one.
-    (A hop that is a LARGE constant plus a small signal is not in here on purpose: an f32 mean of ~0.5 is good to 1e-7 ... 1e-6 whatever
-    the summation order, and that residue times the window's DC gain moves bins 0 ... 2 by up to 1e-4 of the trace maximum in the
-    reference's own evaluation — measured against exact f64, DESIGN §7 — so there is no 1e-5 bar to hold either side to.)"""
+    (Hops that are a LARGE constant plus a small signal: tests/test_gpu_dc_offset.py — the kernels take the mean in the reference's
+    sequential order since round 6.)"""
     from openmeters_amd import banks
     cfg = SpectrumConfig(fft_size=N, hop_size=N, floor_db=-140.0)
     rng = np.random.default_rng(77)

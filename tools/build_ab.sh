@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build an A/B variant of the product library: the named sources recompiled with extra flags, every other object reused.
-# usage: bash tools/build_ab.sh <tag> <source.hip[,source2.hip...]> "<extra flags>"   ->  ab_libs/libomx_<tag>.so
+# usage: bash tools/build_ab.sh <tag> <source.hip|source.cpp[,source2...]> "<extra flags>"   ->  ab_libs/libomx_<tag>.so
 # (run them with tools/ab_bench.sh / tools/ab_spectrum.sh, or OMX_HIP_LIB=$PWD/ab_libs/libomx_<tag>.so <any tool>)
 set -e
 TAG=$1; SRCS=$2; EXTRA=$3
@@ -10,10 +10,11 @@ mkdir -p $ROOT/ab_libs/obj
 OTHERS=$(ls $C/*.o)
 NEW=""
 for SRC in ${SRCS//,/ }; do
-  OBJ=$ROOT/ab_libs/obj/${TAG}_$(basename $SRC .hip).o
+  BASE=$(basename ${SRC%.*})
+  OBJ=$ROOT/ab_libs/obj/${TAG}_$BASE.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $EXTRA -I$C -x hip -c $C/$SRC -o $OBJ \
     -Rpass-analysis=kernel-resource-usage > $OBJ.log 2>&1 || { grep -E "error" -A3 $OBJ.log | head -20; exit 1; }
-  OTHERS=$(echo "$OTHERS" | grep -v "/$(basename $SRC .hip).o")
+  OTHERS=$(echo "$OTHERS" | grep -v "/$BASE.o")
   NEW="$NEW $OBJ"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab_libs/libomx_$TAG.so $OTHERS $NEW
