@@ -417,6 +417,9 @@ def main():
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
+        # ranks the collective backend itself reports after its init (N > 1: torch.distributed over RCCL; N = 1: no communicator is made)
+        "rccl_ranks_seen": (dist.get_world_size() if world > 1 else 1),
+        "collective_backend": (backend if world > 1 else None),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,

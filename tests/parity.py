@@ -427,7 +427,7 @@ def classic_noise_budget(p_rel, n_points=4096):
     return 2.0 * np.sqrt(p_rel) * n + n ** 2
 
 
-def check_classic(got, want, plain=False):
+def check_classic(got, want):
     """fused-kernel bars.  Codes are a quantiser's output: 1 is the smallest bar that can hold between two implementations at all (a
     value within the arithmetic error of a code boundary lands on either side), and a difference of 2 needs |d dB| > 0.0024, i.e. 5.5e-4
     relative.  (1) Every bin within 40 dB of the column maximum: |d code| <= 1.  (2) Below that the f32 transform noise (amplitude n
@@ -449,19 +449,13 @@ def check_classic(got, want, plain=False):
         p_h, p_o = 10.0 ** ((db_h - top) / 10.0), 10.0 ** ((db_o - top) / 10.0)
         far = np.abs(h.astype(np.int64) - o.astype(np.int64)) > 1
         budget = classic_noise_budget(np.maximum(p_h, p_o), 2 * (len(o) - 1))
-        # the window's own transform lines (bins 0 ... 3: a cosine-sum window has at most four) of a DC-REMOVED column hold sum w (x - mean),
-        # i.e. the rounding of the mean times the window's line — with the rectangular window bin 0 is exactly that and nothing else.  The
-        # reference sums the mean sequentially in f32, the kernels as a tree: what is left there is rounding residue on both sides (soak seed
-        # 12072005: rectangular 1024, oracle -104 dB under the column maximum, HIP below the -140 dB floor).  Allowance: 1e-9 of the maximum.
-        plain_budget = budget.copy()
-        if not plain:   # (plain: the DC-offset tests of round 6 — the kernels take the mean in the reference's order, no allowance)
-            budget[:4] = np.maximum(budget[:4], 1e-9)
+        # (Through round 5 the window's own transform lines, bins 0 ... 3, carried an allowance of 1e-9 of the maximum: a DC-removed column
+        # holds sum w (x - mean) there, i.e. the rounding of the mean, and the kernels summed it as a tree where the reference folds
+        # sequentially.  Since round 6 the kernels take the reference's fold — window_sum_kernels.hip — and the rule is gone: soak seed
+        # 12072005, rectangular 1024, is a plain fixed-bar case now, tests/test_gpu_dc_offset.py.)
         dp = np.abs(p_h - p_o)
-        exemption("classic: 1e-9 allowance on the window's own lines (bins 0 ... 3)", bool((far[:4] & (dp[:4] > plain_budget[:4])).any()), m)
         if far.any() and top != tops[i]:   # the budget taken from the column alone
             own = classic_noise_budget(np.maximum(p_h, p_o) * 10.0 ** ((top - tops[i]) / 10.0), 2 * (len(o) - 1)) * 10.0 ** ((tops[i] - top) / 10.0)
-            if not plain:
-                own[:4] = np.maximum(own[:4], 1e-9)
             exemption("classic: noise budget relative to the louder column of the transformed pair", bool((dp[far] > own[far]).any()), m)
         ratio = float((dp[far] / budget[far]).max()) if far.any() else 0.0
         bar("classic (fused): |dP| / f32 transform noise budget, bins more than one code apart", ratio, 1.0, m)

@@ -106,3 +106,62 @@ def test_c99_capture_group_behaves_like_one_visual_manager_per_capture(tmp_path,
     v = parse(r.stdout.strip())
     assert v["columns"] > 100 and v["blocks"] > 40 and v["rho_checks"] > 60   # (blocks = chunks: one per capture and call since round 5)
     assert v["worst_lufs"] < 1e-4 and v["worst_rho"] < 1e-6
+
+
+RCCL_SRC = os.path.join(ROOT, "tests", "c_abi", "group_rccl.c")
+
+
+def build_rccl(tmp_path):
+    out = str(tmp_path / "group_rccl")
+    libdir = os.path.join(ROOT, "openmeters_amd", "csrc")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), RCCL_SRC, "-o", out,
+           "-L", libdir, "-lomx_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
+def parse_rank_line(line):
+    tok = line.split()
+    return {tok[i]: float(tok[i + 1]) for i in range(0, len(tok) - 1, 2)}
+
+
+def test_c99_rccl_host_builds_and_restates_the_shard_rule(tmp_path, omx):
+    """tests/c_abi/group_rccl.c — the native N-rank host north_star describes (one process per GPU, its own RCCL communicator, ncclAllGather on
+    the capture group's summary rows) — compiles as C99 against include/omx.h + librccl, and its shard rule is sharding.shard_streams"""
+    from openmeters_amd.sharding import shard_streams
+    exe = build_rccl(tmp_path)
+    for total, world in ((8192, 8), (16, 1), (10, 4), (3, 8), (1000, 7)):
+        r = subprocess.run([exe, "--shards", str(total), str(world)], capture_output=True, text=True, check=True)
+        got = [tuple(int(x) for x in ln.split()) for ln in r.stdout.strip().splitlines()]
+        assert got == [(k,) + tuple(shard_streams(total, k, world)) for k in range(world)]
+
+
+@pytest.mark.gpu
+def test_c99_rccl_host_gathers_the_summary_rows(tmp_path, omx):
+    """world size 1 on every box (the RCCL communicator, the all-gather and the capture group from one plain C process); with more than one
+    GPU visible also one process per GPU — every rank must print the SAME gathered table (checksum), and that table must equal the
+    one-rank run's: captures are independent, so sharding them changes nothing."""
+    import torch
+    exe = build_rccl(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    total = 16
+    one = subprocess.run([exe, str(total), "9"], capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    v = parse_rank_line(one.stdout.strip().splitlines()[-1])
+    assert v["world"] == 1 and v["rows"] == total and v["finite"] == 1 and v["shard_count"] == total
+    assert -10.0 < v["mean_momentary"] < 0.0 and -1.0 <= v["mean_rho"] < -0.9     # 0.5-amplitude tones, R = -side * L
+    n = torch.cuda.device_count()
+    if n < 2:
+        return
+    id_file = str(tmp_path / "nccl_id")
+    procs = [subprocess.Popen([exe, str(total), "9"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), OMX_RCCL_ID_FILE=id_file)) for r in range(n)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [parse_rank_line(o[0].strip().splitlines()[-1]) for o in outs]
+    assert all(l["world"] == n and l["rows"] == total and l["finite"] == 1 for l in lines)
+    assert len({l["checksum"] for l in lines}) == 1
+    assert abs(lines[0]["checksum"] - v["checksum"]) <= 1e-6 * abs(v["checksum"])

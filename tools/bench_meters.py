@@ -50,6 +50,26 @@ def roofline(alg_bytes, ms, kernels, match_all=False):
             "traffic": meter_traffic(kernels, match_all)}
 
 
+def parity_bar(*rows):
+    """The parity bar(s) a measured FORM holds, as the ledger states them: row name, bar and measured maximum from the newest
+    profiles/parity_r*.txt (written by `OMX_PARITY_REPORT=... pytest -m gpu`; tools/parity_report.py).  VERDICT r5 weak #2: a reader of
+    a `secondary` number must see which evaluation order it was measured on and what that order is held to."""
+    import glob
+    out = []
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "parity_r*.txt")), reverse=True)
+    lines = open(paths[0]).read().splitlines() if paths else []
+    for row in rows:
+        rec = {"ledger_row": row, "bar": None, "measured_max": None, "source": "profiles/" + os.path.basename(paths[0]) if paths else None}
+        for ln in lines:
+            if ln.startswith(row + " ") or ln.startswith(row + "\t"):
+                f = ln[len(row):].split()
+                if len(f) >= 3:
+                    rec["bar"], rec["measured_max"], rec["checks"] = float(f[0]), float(f[1]), int(f[2])
+                break
+        out.append(rec)
+    return out
+
+
 # Calls between the two synchronisations of `timed`.  5 through round 4: for a call of ten launches and ~80 us of host-side planning (the
 # waveform bank's chunk-parallel form) a five-call sample measures the pipeline's fill as much as its throughput — same kernels, same box:
 # 0.61 ms per call over 5 calls, 0.49 over 30 (tools/debug/wave_reps.py).  The banks with one or two launches per call read the same either way.
@@ -73,33 +93,47 @@ def loudness(S=1024, C=8, blocks=64, reps=REPS, out=sys.stdout):
     for c in range(C):
         f = 60.0 if c == 3 else 997.0 + 10.0 * c
         pcm[:, :, c] = (0.5 * torch.sin(2 * np.pi * f * n / FS)).to(torch.float32)[None, :]
-    bank = banks.LoudnessBank(api, capi.LoudnessConfig(), S, C)
-    bank.set_option(capi.OPT_KERNEL_TIMING, 1)
-    run = lambda: bank.process_device(pcm.data_ptr(), 256, blocks, C, FS, capi.SURROUND, stream)
-    for _ in range(12):  # > 4 s of audio so all four windows are full
-        run()
-    bank.kernel_time()
-    dt = timed(run, reps)
-    kms, _ = bank.kernel_time()
     cs = S * C * frames
+    res = {}
+    # both evaluation orders of the same call (include/omx.h "WHICH EVALUATION ORDER A CALL GETS"): the chunk-parallel form is what a call of
+    # this shape runs by default; the sequential kernels follow the reference's operation order (dsp.rs:264-371) and are the <= 1e-5 form
+    for form, key in ((0, "chunk_parallel"), (1, "sequential")):
+        bank = banks.LoudnessBank(api, capi.LoudnessConfig(), S, C)
+        bank.set_option(capi.OPT_KERNEL_FORM, form)
+        bank.set_option(capi.OPT_KERNEL_TIMING, 1)
+        run = lambda: bank.process_device(pcm.data_ptr(), 256, blocks, C, FS, capi.SURROUND, stream)
+        for _ in range(12):  # > 4 s of audio so all four windows are full
+            run()
+        bank.kernel_time()
+        dt = timed(run, reps if form == 0 else max(reps // 6, 3))
+        kms, _ = bank.kernel_time()
+        snap = bank.fetch(0, blocks - 1)
+        res[key] = (dt, kms, snap)
+        del bank
+    dt, kms, snap = res["chunk_parallel"]
+    dts, kmss, snaps = res["sequential"]
     # SURVEY §8(d) prices the REFERENCE formulation (sliding Kahan sums over a ring of f64 squares): 4 B PCM + 8 B ring write + 4 x 8 B
     # expiring reads = 44 B per channel-sample.  The chunk-parallel form (loudness_chunked.hip, what a bank call of this size runs)
-    # needs no expiring reads and its ring holds the f32 sample (the square is exact, loudness.hpp RingT): compulsory 4 + 4 = 8 B;
-    # it actually moves ~16.5 B (the PCM is read by three passes, + sub-block sums).  The roofline object below prices the 8 B.
+    # needs no expiring reads and its ring holds the f32 sample (the square is exact, loudness.hpp RingT): compulsory 4 + 4 = 8 B.
     print(f"cfg3 loudness: {S}x{C}ch, {blocks} blocks/call: {dt*1e3:.2f} ms/call (kernel {kms:.2f} ms) -> {cs/dt/1e9:.2f} G channel-samples/s, "
-          f"{cs/dt/(S*C*FS):.0f}x real time; HBM: {cs*8/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s at this form's 8 B/channel-sample "
-          f"({cs*16.5/(kms*1e-3)/8e12*100:.1f}% counting its three PCM passes), {cs*44/(kms*1e-3)/8e12*100:.1f}% at the reference formulation's 44 B", file=out)
-    snap = bank.fetch(0, blocks - 1)
+          f"{cs/dt/(S*C*FS):.0f}x real time; HBM: {cs*8/(kms*1e-3)/8e12*100:.1f}% of 8 TB/s at this form's 8 B/channel-sample; "
+          f"sequential form {dts*1e3:.2f} ms/call", file=out)
     print("   stream0 last snapshot:", snap.short_term_loudness, snap.momentary_loudness, snap.true_peak_db[:3], file=out)
     return {"workload": f"{S} streams x {C} ch, {blocks} blocks of 256 per call", "channel_samples_per_s": cs / dt, "x_real_time": cs / dt / (S * C * FS),
-            "ms_per_call": dt * 1e3, "kernel_ms": kms, "form": "chunk-parallel (loudness_chunked.hip)",
-            "hbm_frac_compulsory_8B": cs * 8 / (kms * 1e-3) / 8e12, "hbm_frac_moved_16p5B": cs * 16.5 / (kms * 1e-3) / 8e12,
+            "ms_per_call": dt * 1e3, "kernel_ms": kms, "form": "chunk-parallel (loudness_chunked.hip): the default of a bank call of >= 4 blocks",
+            "parity_bar": parity_bar("loudness (chunk-parallel): |d momentary LUFS|", "loudness (chunk-parallel): |d rms_fast_db|",
+                                     "loudness (chunk-parallel): |d true_peak_db|"),
+            "hbm_frac_compulsory_8B": cs * 8 / (kms * 1e-3) / 8e12,
             "hbm_frac_reference_formulation_44B": cs * 44 / (kms * 1e-3) / 8e12,
             # algorithmic bytes of THIS formulation: 8 B per channel-sample (PCM in, f32 ring out) + 104 B per snapshot; SURVEY §8(d)'s
             # 44 B belongs to the sliding-sum formulation (its fraction is the field above: >= 1.0 means this form beats what that
             # formulation could do at the HBM peak)
             "roofline": roofline(cs * 8.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan", "loudness_"]),
-            "momentary_lufs_stream0": float(snap.momentary_loudness)}
+            "momentary_lufs_stream0": float(snap.momentary_loudness),
+            "sequential_form": {"form": "sequential (loudness_kernels.hip): the reference's operation order, OMX_OPT_KERNEL_FORM = 1",
+                                "ms_per_call": dts * 1e3, "kernel_ms": kmss, "channel_samples_per_s": cs / dts, "x_real_time": cs / dts / (S * C * FS),
+                                "parity_bar": parity_bar("loudness: |d momentary LUFS|", "loudness: |d rms_fast_db|", "loudness: |d true_peak_db|"),
+                                "momentary_lufs_stream0": float(snaps.momentary_loudness)}}
 
 
 def scope_stereo(S=256, blocks=64, reps=REPS, out=sys.stdout):
@@ -112,26 +146,55 @@ def scope_stereo(S=256, blocks=64, reps=REPS, out=sys.stdout):
         pcm[s, :, 0] = left
         pcm[s, :, 1] = -0.7 * left
     pos = capi.positions_fallback(2)
-    st = banks.StereometerBank(api, capi.StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02,
-                                                           target_sample_count=2000), S)
-    dt = timed(lambda: st.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
+    st_cfg = capi.StereometerConfig(analyze_bands=True, correlation_window=0.05, segment_duration=0.02, target_sample_count=2000)
+    st_res = {}
+    for form, key in ((0, "chunk_parallel"), (1, "sequential")):   # both evaluation orders of the same call (include/omx.h, stereometer bank)
+        st = banks.StereometerBank(api, st_cfg, S)
+        st.set_option(capi.OPT_KERNEL_FORM, form)
+        st_res[key] = timed(lambda: st.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps if form == 0 else max(reps // 3, 3))
+        del st
+    dt, dts = st_res["chunk_parallel"], st_res["sequential"]
     print(f"cfg4 stereometer: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.0f} k blocks/s, "
-          f"{S*frames/dt/(S*FS):.0f}x real time", file=out)
+          f"{S*frames/dt/(S*FS):.0f}x real time; sequential form {dts*1e3:.2f} ms/call", file=out)
     res = {"stereometer": {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
                            "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3,
+                           "form": "chunk-parallel (stereometer_chunked.hip): the default of a bank call of >= 4 blocks",
+                           "parity_bar": parity_bar("stereometer (chunk-parallel): |d point| vs oracle",
+                                                    "stereometer (chunk-parallel): |d rho| / (1e-6 + 0.5 eta sqrt(1 - rho^2) + 0.5 eta^2)",
+                                                    "stereometer (chunk-parallel) vs exact f64: |d rho|"),
                            # §8(d): ~16 B per stereo frame (8 B PCM in + 8 B per point out on emit)
-                           "roofline": roofline(S * frames * 16.0, dt * 1e3, ["stereo_chunk", "stereo_scan", "stereometer_"])}}
+                           "roofline": roofline(S * frames * 16.0, dt * 1e3, ["stereo_chunk", "stereo_scan", "stereometer_"]),
+                           "sequential_form": {"form": "sequential (stereometer_kernels.hip): the reference's operation order, bit-identical points and rho, "
+                                                       "OMX_OPT_KERNEL_FORM = 1",
+                                               "ms_per_call": dts * 1e3, "blocks_per_s": S * blocks / dts, "x_real_time": frames / dts / FS,
+                                               "parity_bar": parity_bar("stereometer: |d rho|", "stereometer (ragged bank): |d band point|")}}}
     sc = banks.OscilloscopeBank(api, capi.OscilloscopeConfig(segment_duration=0.02, trigger_mode=capi.TRIGGER_STABLE, num_cycles=2,
                                                              trigger_source=capi.CH_LEFT, channel_1=capi.CH_LEFT, channel_2=capi.CH_RIGHT), S)
     dt = timed(lambda: sc.process_device(pcm.data_ptr(), 256, blocks, 2, FS, pos, stream), reps)
     hdr, _ = sc.fetch(0, blocks - 1)
+    # compulsory bytes of a block: its PCM in (256 x C x 4 B) + the snapshot it emits (samples_per_channel x channels x 4 B + the header).
+    # SURVEY §8(d)'s 34 816 B is the UPPER bound (two 4096-point traces); the snapshots of this workload are `spc` points per channel
+    # (priced on the bound the fraction was overstated 4.5x)
+    spc = np.zeros(S, np.int64)
+    for s_ in range(0, S, max(S // 32, 1)):
+        h_, _ = sc.fetch(s_, blocks - 1)
+        spc[s_] = h_.samples_per_channel
+    mean_spc = float(spc[spc > 0].mean()) if (spc > 0).any() else 0.0
+    block_bytes = 256 * 2 * 4.0 + mean_spc * 2 * 4.0 + 64.0
     print(f"cfg4 oscilloscope: {S} streams, {blocks} blocks/call: {dt*1e3:.2f} ms/call -> {S*blocks/dt/1e3:.1f} k blocks/s, "
-          f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel}", file=out)
+          f"{S*frames/dt/(S*FS):.0f}x real time; stream0 locked={hdr.locked} period={hdr.period:.3f} spc={hdr.samples_per_channel} "
+          f"(mean over sampled streams {mean_spc:.0f})", file=out)
     res["oscilloscope"] = {"workload": f"{S} streams x 2 ch, {blocks} blocks of 256 per call", "blocks_per_s": S * blocks / dt,
                            "x_real_time": frames / dt / FS, "ms_per_call": dt * 1e3, "stream0_locked": int(hdr.locked),
-                           "stream0_period": float(hdr.period),
-                           # §8(d): <= 34 816 B per block (256 x 2 ch x 4 B in + <= 2 x 4096 x 4 B snapshot out)
-                           "roofline": roofline(S * blocks * 34816.0, dt * 1e3, ["scope_"])}
+                           "stream0_period": float(hdr.period), "mean_samples_per_channel": mean_spc,
+                           "form": "wide form (scope_fast_kernels.hip): estimates per (stream, block), one trigger workgroup per stream in timeline order; "
+                                   "the only form at this rate",
+                           "parity_bar": parity_bar("oscilloscope: rel |d cycle rate|", "oscilloscope (Stable): |d frac_offset| samples",
+                                                    "oscilloscope (Stable): |d trace| - |d pos| * max input step"),
+                           "roofline": dict(roofline(S * blocks * block_bytes, dt * 1e3, ["scope_"]),
+                                            note="latency-bound by construction (a dozen dependent reductions per block in one workgroup per stream): "
+                                                 "the HBM fraction says how far, not how good",
+                                            algorithmic_bytes_per_block=block_bytes, upper_bound_bytes_per_block_survey_8d=34816.0)}
     return res
 
 
@@ -154,7 +217,9 @@ def reference_defaults(S=64, out=sys.stdout):
     by = hop * 2 * 4 + 4 + 12 * (W // 2 + 1)
     print(f"default spectrogram {W}/{hop} reassigned: {dt*1e3:.3f} ms per {n} frames (kernel {kms:.3f}) -> {n/dt/1e6:.1f} M frames/s", file=out)
     res["default_spectrogram_2048_64"] = {"workload": f"{S} streams, {cols} columns per call", "frames_per_s": n / dt, "ms_per_call": dt * 1e3,
-                                           "kernel_ms": kms, "roofline": roofline(n * float(by), kms, ["stft_reassigned_pow2_tri"])}
+                                           "kernel_ms": kms, "form": "fused (stft_reassigned_pow2_tri_kernel): the only form of this shape",
+                                           "parity_bar": parity_bar("reassigned: |dP| / max P", "reassigned: r |df| / (fs/2)", "reassigned: r |dt| hops"),
+                                           "roofline": roofline(n * float(by), kms, ["stft_reassigned_pow2_tri"])}
     del bank, pcm, chunks
     N, hop, hops = 16384, 1024, 256
     frames = N + hop * (hops - 1)
@@ -167,7 +232,10 @@ def reference_defaults(S=64, out=sys.stdout):
     by = hop * 2 * 4 + 2 * (N // 2 + 1) * 4   # §8(d): PCM in + weighted and raw trace out per materialised hop
     print(f"default spectrum {N}/{hop}: {dt*1e3:.3f} ms per {n} hops -> {n/dt/1e6:.2f} M hops/s", file=out)
     res["default_spectrum_16384_1024"] = {"workload": f"{S} streams, {hops} hops per call, every hop materialised", "hops_per_s": n / dt,
-                                          "ms_per_call": dt * 1e3, "roofline": roofline(n * float(by), dt * 1e3, ["spectrum_"])}
+                                          "ms_per_call": dt * 1e3,
+                                          "form": "window folds in the reference's order (window_sums_seq_kernel) + fused transform (spectrum_power_16384_kernel)",
+                                          "parity_bar": parity_bar("spectrum: |d 10^(dB/10)| / max", "spectrum: |d dB| within 60 dB of max"),
+                                          "roofline": roofline(n * float(by), dt * 1e3, ["spectrum_", "window_sums"])}
     del sp, pcm, chunks
     # BASELINE configs[0] — the reference's own CPU-runnable case, the shape `cpu_baseline.cfg1_classic_1024` times on the host: 1024-pt Hann,
     # hop 256, classic columns (u16 dB codes), here for 64 streams x 4096 columns per call
@@ -182,7 +250,11 @@ def reference_defaults(S=64, out=sys.stdout):
     by = hop * 2 * 4 + (W // 2 + 1) * 2   # PCM in + one u16 code per bin out
     print(f"cfg1 classic {W}/{hop}: {dt*1e3:.3f} ms per {n} frames -> {n/dt/1e6:.1f} M frames/s", file=out)
     res["cfg1_classic_1024"] = {"workload": f"BASELINE configs[0] shape: {S} streams, {cols} classic columns per call (ingest included)", "frames_per_s": n / dt,
-                                "ms_per_call": dt * 1e3, "roofline": roofline(n * float(by), dt * 1e3, ["stft_classic_pow2"])}
+                                "ms_per_call": dt * 1e3,
+                                "form": "window folds in the reference's order (window_sums_seq_kernel) + two columns per complex transform (stft_classic_pow2_kernel)",
+                                "parity_bar": parity_bar("classic (fused): |d code| within 40 dB of max",
+                                                         "classic (fused): |dP| / f32 transform noise budget, bins more than one code apart"),
+                                "roofline": roofline(n * float(by), dt * 1e3, ["stft_classic_pow2", "window_sums"])}
     return res
 
 
@@ -208,6 +280,10 @@ def waveform(blocks=64, reps=REPS, out=sys.stdout, sizes=(64, 1024, 4096), histo
             names = ["wave_", f"@{S}"] if chunked else [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", f"@{S}"]
             res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3,
                                                            "form": "chunk-parallel (waveform_chunked.hip)" if chunked else "sequential (waveform_roles_kernels.hip)",
+                                                           "parity_bar": parity_bar(*(["waveform (chunk-parallel, 1024 streams): colour |HIP - oracle| / (fix + 3 |oracle - exact|)",
+                                                                                       "waveform (chunk-parallel, 1024 streams): colour |HIP - exact| / (fix + 2 |oracle - exact|)",
+                                                                                       "waveform (chunk-parallel) vs exact f64: |d colour| / max colour"] if chunked else
+                                                                                      ["waveform: |d band colour| / max(1, max)", "waveform: |d RMS history dB|"])),
                                                            "roofline": roofline(alg, dt * 1e3, names, match_all=True)}
             bank.close()
     return res

@@ -15,6 +15,11 @@ from openmeters_amd.pipeline import FullPipeline
 from pipeline_reference import SeparateBanks
 
 
+def bench_meters_parity(*rows):
+    import bench_meters
+    return bench_meters.parity_bar(*rows)
+
+
 def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
     api = openmeters_amd.api()
     dev = torch.device("cuda", 0)
@@ -47,7 +52,10 @@ def shard_pipeline(S=1024, frames=16384, out=sys.stdout):
         print(f"{mode}: {ms:.3f} ms per step of {S} streams x {frames} frames -> {S * frames / ms / 1e6:.2f} G stream-frames/s, "
               f"{S * (frames // 256) / ms / 1e3:.2f} M STFT frames/s, {frames / 48000.0 / (ms * 1e-3):.0f}x real time; "
               f"rho mean {float(table[:, 3].mean()):.3f}", file=out)
-        res[mode] = {"ms_per_step": ms, "stft_frames_per_s": S * (frames // 256) / (ms * 1e-3), "x_real_time": frames / 48000.0 / (ms * 1e-3)}
+        res[mode] = {"ms_per_step": ms, "stft_frames_per_s": S * (frames // 256) / (ms * 1e-3), "x_real_time": frames / 48000.0 / (ms * 1e-3),
+                     "form": "K2 fused (stft_reassigned_4096_tri_kernel) + chunk-parallel loudness and stereometer (the default of a 64-block call)",
+                     "parity_bar": bench_meters_parity("reassigned: |dP| / max P", "loudness (chunk-parallel): |d rms_fast_db|",
+                                                       "stereometer (chunk-parallel): |d point| vs oracle")}
         if mode == "group":
             # the step's algorithmic bytes: K2 26 640 B per STFT frame (PCM hop in, 2049 points out) + the loudness form's
             # 8 B per channel-sample + the stereometer's 16 B per stereo frame (the PCM itself is counted once, with K2)

@@ -50,7 +50,10 @@ def streaming(streams=1024, calls=200, out=sys.stdout):
     """`secondary.streaming_256` of bench.py: the six-visual group at the reference's cadence — one 256-frame block per capture and call,
     and one 1024-frame catch-up chunk (meter.rs:15-25, :40-69)"""
     api = openmeters_amd.api()
-    rec = {"workload": f"{streams} captures x 2 ch, all six visuals at the reference's default configs, one omx_capture_group_ingest per batcher block"}
+    rec = {"workload": f"{streams} captures x 2 ch, all six visuals at the reference's default configs, one omx_capture_group_ingest per batcher block",
+           "form": "one block per call: every meter bank on its SEQUENTIAL kernels (the reference's operation order), spectrum window folds carried "
+                   "between calls (window_sums_carry_kernel), reassigned spectrogram 2048 / 64 fused",
+           "parity_bar": "group chunks: rows of profiles/parity_r*.txt (tests/test_gpu_capture_chunks.py: every capture against oracle handles fed each chunk whole)"}
     for frames, key in ((256, "block_256"), (1024, "catch_up_1024")):
         us = run(api, streams, frames, calls if frames == 256 else max(calls // 4, 20), list(NAMES.values()))
         audio_us = frames / 48000.0 * 1e6
