@@ -113,6 +113,14 @@ int omx_device_count(void);
 int omx_set_device(int index);
 /* Library version string. */
 const char* omx_version(void);
+/* ABI revision of this header: bumped whenever a struct a host passes or receives changes layout, or an argument changes meaning.  A host
+ * compares omx_abi_version() of the library it loaded with the OMX_ABI_VERSION it was compiled against and refuses a mismatch
+ * ("ABI revisions" lists what changed in each).
+ *   5  round 5: cfg.block_frames == 0 means ONE block per ingest call (registry.rs:396-418), not the batcher quantum;
+ *      omx_capture_group_ragged_update grew d_reset / d_block_frames per bank and d_stats_rows, its block_frames reads 0 in that mode
+ *   6  round 6: omx_debug_window_sums added; no layout change */
+#define OMX_ABI_VERSION 6
+int omx_abi_version(void);
 
 /* ===================================================================== *
  * Spectrogram — reference src/visuals/spectrogram/processor.rs

@@ -89,7 +89,8 @@ const char* omx_last_error(void) { return last_error().c_str(); }
 int omx_device_available(void) { return device_ready() == OMX_NONE ? 1 : 0; }
 int omx_device_count(void) { return device_count(); }
 int omx_set_device(int index) { return select_device(index); }
-const char* omx_version(void) { return "openmeters_amd 0.1 (HIP, gfx950)"; }
+const char* omx_version(void) { return "openmeters_amd 0.6 (HIP, gfx950)"; }
+int omx_abi_version(void) { return OMX_ABI_VERSION; }
 void omx_positions_fallback(uint32_t channels, uint8_t out[OMX_MAX_CHANNELS]) { positions_fallback(channels, out); }
 void omx_positions_normalize(uint32_t channels, const uint8_t in[OMX_MAX_CHANNELS], uint8_t out[OMX_MAX_CHANNELS]) {
     positions_normalize(channels, in, out);

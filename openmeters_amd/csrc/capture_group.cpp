@@ -145,7 +145,10 @@ const uint8_t* CaptureGroup::mask_for(int vi, bool bank_enabled, bool bank_exist
     std::vector<uint8_t>& m = mask_scratch_[vi];
     m.assign(S, 0);
     for (uint32_t s = 0; s < S; ++s) m[s] = (pend[s] || (reset_mask && reset_mask[s])) ? 1 : 0;
-    pend.clear();
+    // the merged mask stays pending until the bank's call has succeeded (ingest_ragged's `note`): a call that fails before the bank has
+    // applied it — a plan error, an exception — must not lose the resets that arrived while the visual was disabled
+    pend = m;
+    mask_merged_[vi] = true;
     return m.data();
 }
 
@@ -408,6 +411,14 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     auto note = [&](int rc, uint32_t bit) {
         if (rc < 0) worst = worst < 0 ? worst : rc;
         else if (rc == OMX_PRODUCED) up.produced |= bit;
+        if (rc >= 0 && bit) {  // the bank has taken its mask: the resets it had missed while disabled are delivered
+            int vi = 0;
+            while ((1u << vi) != bit) ++vi;
+            if (mask_merged_[vi]) {
+                pending_reset_[vi].clear();
+                mask_merged_[vi] = false;
+            }
+        }
     };
     bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
@@ -416,12 +427,22 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         if (spectrogram && spectrum && shared_ingest_) {
             IngestArgs parts[2];
             const int rc_sg = spectrogram->ragged_plan(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, parts[0]);
-            const int rc_sp = rc_sg < 0 ? OMX_NONE : spectrum->ragged_plan(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions,
-                                                                           stream, parts[1]);
             if (rc_sg < 0) note(rc_sg, 0);
-            if (rc_sp < 0) note(rc_sp, 0);
-            if (rc_sg >= 0 && rc_sp >= 0) {
-                const int n_parts = rc_sp == OMX_PRODUCED ? 2 : 1;  // (a Spectrum bank without an active trace takes no samples)
+            if (rc_sg >= 0) {
+                // The spectrogram's plan has advanced its per-capture positions: from here on its samples MUST be written and its columns
+                // computed, whatever happens to the spectrum's plan (an error code, an exception from a reservation) — otherwise its rings
+                // would claim samples nobody wrote.
+                int rc_sp = OMX_NONE;
+                bool sp_threw = false;
+                BackendError sp_error{OMX_ERR_BACKEND};
+                try {
+                    rc_sp = spectrum->ragged_plan(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions, stream, parts[1]);
+                } catch (const BackendError& e) {
+                    sp_threw = true;
+                    sp_error = e;
+                }
+                if (rc_sp < 0) note(rc_sp, 0);
+                const int n_parts = (!sp_threw && rc_sp == OMX_PRODUCED) ? 2 : 1;  // (a Spectrum bank without an active trace takes no samples)
                 if (launch_ingest_ragged_parts(parts, n_parts, S, stream)) {
                     up.ingest_launches += 1;
                 } else {  // other channel counts: the banks' own launches
@@ -434,7 +455,8 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                 }
                 OMX_HIP(hipGetLastError());
                 note(spectrogram->ragged_finish(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
-                if (rc_sp == OMX_PRODUCED) note(spectrum->ragged_finish(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
+                if (n_parts == 2) note(spectrum->ragged_finish(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
+                if (sp_threw) throw sp_error;  // (the message set_last_error recorded stands)
             }
         } else {
             if (spectrogram) {

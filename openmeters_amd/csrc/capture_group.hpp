@@ -55,6 +55,7 @@ private:
     // registry.rs:360-365): OR-ed into the bank's next ragged call; index = log2(OMX_VISUAL_* bit)
     std::vector<uint8_t> pending_reset_[6];
     std::vector<uint8_t> mask_scratch_[6];
+    bool mask_merged_[6] = {false, false, false, false, false, false};  // mask_for merged pending resets into this call's mask (cleared on success)
     const uint8_t* mask_for(int visual_index, bool bank_enabled, bool bank_exists, const uint8_t* reset_mask);
     std::unique_ptr<SpectrogramBank> spectrogram_;
     std::unique_ptr<SpectrumBank> spectrum_;

@@ -41,7 +41,10 @@ __device__ __forceinline__ void spectrum_store(const SpectrumPowerArgs& a, uint3
     }
 }
 
-#ifndef SPEC_KNOCK  // pricing builds (WRONG rows): 1 no stores, 2 no transform, 4 no ring loads
+// SPEC_KNOCK: pricing builds of the TUNING library only (`make TUNING=1 EXTRA=-DSPEC_KNOCK=n`; WRONG rows): 1 no stores, 2 no transform,
+// 4 no ring loads.  Product objects ignore the macro.
+#if !defined(SPEC_KNOCK) || !defined(OMX_TUNING)
+#undef SPEC_KNOCK
 #define SPEC_KNOCK 0
 #endif
 #ifndef SPEC_NT  // 1 = non-temporal row stores (A/B: -3 % of the kernel)

@@ -25,8 +25,9 @@ namespace omx {
 
 namespace {
 
-// TRI_KNOCK (pricing builds, WRONG columns): 1 no LDS traffic in the transforms, 2 no butterflies, 3 no barriers in the transforms, 4 no point stores, 5 no Hilbert-spectrum arithmetic, 6 no reassignment arithmetic, 7 no window / table loads, 8 no Hilbert LDS round trip
-#ifndef TRI_KNOCK
+// TRI_KNOCK (pricing builds of the TUNING library only — `make TUNING=1 EXTRA=-DTRI_KNOCK=n` — WRONG columns): 1 no LDS traffic in the transforms, 2 no butterflies, 3 no barriers in the transforms, 4 no point stores, 5 no Hilbert-spectrum arithmetic, 6 no reassignment arithmetic, 7 no window / table loads, 8 no Hilbert LDS round trip
+#if !defined(TRI_KNOCK) || !defined(OMX_TUNING)  // (product objects cannot be built to emit wrong columns: the knock-outs exist under OMX_TUNING only)
+#undef TRI_KNOCK
 #define TRI_KNOCK 0
 #endif
 #ifndef TRI_LDS_SYNC  // 1: the kernel's barriers wait for LDS traffic only (the workgroup exchanges nothing through global memory): __syncthreads()

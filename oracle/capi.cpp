@@ -148,6 +148,7 @@ struct omxo_oscilloscope {
 
 extern "C" {
 
+int omxo_abi_version(void) { return OMX_ABI_VERSION; }
 const char* omxo_version(void) { return "omx-oracle 0.1 (CPU restatement; parity unpinned through the FFT boundary)"; }
 
 void omxo_positions_fallback(uint32_t channels, uint8_t out[8]) {
