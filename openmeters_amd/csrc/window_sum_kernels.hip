@@ -15,8 +15,11 @@
 // the owning lane's component — no LDS, no select, no per-step predicate.  Steps between one window's end and the next one's start
 // (hop > W) are skipped.  Resets and takes are wave-uniform events (every quad of a launch has the same hop and W): scalar control flow.
 //
-// Cost: (3 hop + W) dependent adds per lane; cfg2's spectrum (2 traces x 64 streams x 1024 hops of 4096 / 256) is 2048 wavefronts of
-// 4864 steps.
+// G consecutive hops walk together (G = 4 or 8 lanes = 1 or 2 quads): every quad of a group loads the SAME tile — identical addresses
+// in one load instruction are one request to L2 — and broadcasts inside itself, so a group costs ((G - 1) hop + W) dependent adds per
+// lane and fetches each sample once per G hops.  Quads alone (G = 4) re-read every sample (W + 3 hop) / (4 hop) = 4.75 times at
+// 4096 / 256 (311 MB per launch: the neighbour quad read it four tiles earlier and the XCD's 128 wavefronts had moved 8 MB through its
+// 4 MB L2 meanwhile); G = 8: 188 MB and 5888 steps instead of 4864 (launch_window_sums has the measurements).
 #include "stft_kernels.hpp"
 
 namespace omx {
@@ -60,6 +63,18 @@ __device__ __forceinline__ Tile load_tile(const float* ring, uint32_t mask, uint
     return t;
 }
 
+// The aligned kernel's tile load: positions are multiples of 4 samples there (host-checked), so no 16-byte piece straddles the ring's end
+// and every load wraps on its own — sixteen loads, no branch (with the wave-uniform branch above in its loop hipcc kept the NEXT tile's
+// loads next to the adds that free their registers instead of ahead of the whole tile).
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+__device__ __forceinline__ void load_tile_aligned(Tile& t, const float* ring, uint32_t mask, uint32_t pos, unsigned jq) {
+#pragma unroll
+    for (int i = 0; i < kTileLoads; ++i) {
+        const f4a v = *reinterpret_cast<const f4a*>(ring + ((pos + 16u * (unsigned)i + 4u * jq) & mask));
+        t.v[i] = f4u{v.x, v.y, v.z, v.w};
+    }
+}
+
 // steps [0, n) of the tile; n is wave-uniform
 __device__ __forceinline__ float add_tile_partial(float sum, const Tile& t, uint32_t n) {
 #pragma unroll
@@ -80,6 +95,17 @@ __device__ __forceinline__ float add_tile_partial(float sum, const Tile& t, uint
 // (tools/microbench/dpp_chain.hip: same sums without the nops).  The hazard the ISA names is a VALU write followed by a DPP READ of that
 // register: the accumulator is the plain operand here, and the DPP-read tile registers are written by loads — or by a copy the
 // compiler may have placed just ahead, which the leading s_nop 1 of every 16-step group covers.
+// the 16 steps of one load group (the tile's samples 16 i ... 16 i + 15)
+__device__ __forceinline__ float add_group(float sum, const f4u& g) {
+#define OMX_Q(Q) \
+    "v_add_f32_dpp %0, %1, %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_add_f32_dpp %0, %2, %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_add_f32_dpp %0, %3, %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_add_f32_dpp %0, %4, %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+    asm volatile("s_nop 1\n" OMX_Q(0) OMX_Q(1) OMX_Q(2) OMX_Q(3) : "+v"(sum) : "v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w));
+#undef OMX_Q
+    return sum;
+}
 __device__ __forceinline__ float add_tile_full(float sum, const Tile& t) {
 #define OMX_Q(Q) \
     "v_add_f32_dpp %0, %1, %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
@@ -96,7 +122,78 @@ __device__ __forceinline__ float add_tile_full(float sum, const Tile& t) {
 
 }  // namespace
 
-// One wavefront = 16 quads = 64 consecutive hops of one (stream, ring).
+// The walk for shapes whose events fall on the tile's 16-step load groups (hop and W multiples of 16: every size the fused transform
+// kernels serve at every hop a GUI offers): a tile is always consumed whole, group by group, and window starts / ends are handled
+// between two groups — no partially consumed tiles, no 256-way predicated unroll beside the hot path (with it in the same kernel hipcc
+// ran out of its 256 VGPRs and parked the NEXT tile's loads in front of every group of adds).
+template <int G>
+__global__ __launch_bounds__(64) void window_sums_aligned_kernel(WindowSumArgs a) {
+    const uint32_t waves_per_sr = (a.n_hops + 63u) / 64u;
+    const uint32_t xcd = blockIdx.x & 7u, bq = blockIdx.x >> 3;
+    const uint32_t chunk = bq % waves_per_sr, sr = (bq / waves_per_sr) * 8u + xcd;
+    if (sr >= a.n_streams * a.n_rings) return;
+    const uint32_t s = sr / a.n_rings, r = sr % a.n_rings;
+    const uint32_t n_hops_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.hops ? a.hops[s] : a.n_hops));
+    if (chunk * 64u >= n_hops_s) return;
+    const uint32_t lane = threadIdx.x, j = lane % (uint32_t)G, group = lane / (uint32_t)G, jq = lane & 3u;
+    const uint32_t live = min((uint32_t)G, n_hops_s - chunk * 64u);
+    const uint32_t hop = a.hop, W = a.window;
+    const uint32_t mask = (uint32_t)(a.cap - 1u);
+    const float* ring = a.ring[r] + (uint64_t)s * a.cap;
+    const uint64_t tail = a.tails ? a.tails[s] : a.tail;
+    const uint32_t h_group = chunk * 64u + group * (uint32_t)G;
+    const uint32_t p0 = (uint32_t)(tail + (uint64_t)(a.first_hop + h_group) * hop);
+
+    float sum = -0.0f, taken = 0.0f;
+    uint32_t step = 0, resets = 1, takes = 0;
+    uint32_t next_take = W, next_reset = live > 1u ? hop : 0xFFFFFFFFu;   // (steps fit 32 bits: (G - 1) hop + W < 2^32 is host-checked)
+    uint32_t next_event = min(next_take, next_reset);
+    // the events at `step` (rare: 2 G of them in a walk of hundreds of groups); false once the last window has been taken.
+    // hop <= W (host-checked): from lane 0's start to the last take some window is always open — no gaps to skip.
+    auto events = [&]() -> bool {
+        while (step == next_take) {
+            taken = j == takes ? sum : taken;
+            ++takes;
+            if (takes == live) return false;
+            next_take = takes * hop + W;
+        }
+        while (step == next_reset) {
+            sum = j == resets ? -0.0f : sum;
+            ++resets;
+            next_reset = resets < live ? resets * hop : 0xFFFFFFFFu;
+        }
+        next_event = min(next_take, next_reset);
+        return true;
+    };
+    // one tile, group by group.  THREE tile buffers in rotation: `far` receives the loads of the tile after next before this tile's adds
+    // start, so a load has two tiles of adds (~2.4 us) to land.  With one tile ahead the walk ran at the memory latency of a chip with
+    // 1024 wavefronts x 16 KiB in flight — ~3 us per tile whatever the group size, 65 ... 93 us per launch where the adds take 20 ... 38:
+    // the ring has left the caches behind the spectrogram kernel's 1.7 GB.  (One wavefront per SIMD: 200 VGPRs cost nothing.)
+    auto walk_tile = [&](const Tile& cur, Tile& far) -> bool {
+        load_tile_aligned(far, ring, mask, p0 + step + 2u * (uint32_t)kTileSteps, jq);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < kTileLoads; ++i) {
+            if (__builtin_expect(step == next_event, 0)) {
+                if (!events()) return false;
+            }
+            sum = add_group(sum, cur.v[i]);
+            step += 16u;
+        }
+        return true;
+    };
+    Tile t0, t1, t2;
+    load_tile_aligned(t0, ring, mask, p0, jq);
+    load_tile_aligned(t1, ring, mask, p0 + (uint32_t)kTileSteps, jq);
+    while (walk_tile(t0, t2) && walk_tile(t1, t0) && walk_tile(t2, t1)) {
+    }
+    const uint32_t h = h_group + j;
+    if (h < n_hops_s) a.sums[((uint64_t)s * a.n_rings + r) * a.n_hops + h] = taken;
+}
+
+// The general walk (any hop, any window length): tiles may be consumed partially, up to the next event.
+// One wavefront = 64 / G groups = 64 consecutive hops of one (stream, ring).
+template <int G>
 __global__ __launch_bounds__(64) void window_sums_seq_kernel(WindowSumArgs a) {
     const uint32_t waves_per_sr = (a.n_hops + 63u) / 64u;
     // XCD-aware map, the consumers' (spectrum_power_pow2_kernel / stft_classic_pow2_kernel): a (stream, ring) lives on one XCD
@@ -106,45 +203,52 @@ __global__ __launch_bounds__(64) void window_sums_seq_kernel(WindowSumArgs a) {
     const uint32_t s = sr / a.n_rings, r = sr % a.n_rings;
     const uint32_t n_hops_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.hops ? a.hops[s] : a.n_hops));
     if (chunk * 64u >= n_hops_s) return;
-    const uint32_t lane = threadIdx.x, j = lane & 3u, quad = lane >> 2;
-    const uint32_t live = min(4u, n_hops_s - chunk * 64u);  // lanes of the wavefront's fullest quad (its first): the walk ends with their last take
+    const uint32_t lane = threadIdx.x, j = lane % (uint32_t)G, group = lane / (uint32_t)G, jq = lane & 3u;
+    const uint32_t live = min((uint32_t)G, n_hops_s - chunk * 64u);  // lanes of the wavefront's fullest group (its first): the walk ends with their last take
     const uint32_t hop = a.hop, W = a.window;
     const uint32_t mask = (uint32_t)(a.cap - 1u);
     const float* ring = a.ring[r] + (uint64_t)s * a.cap;
     const uint64_t tail = a.tails ? a.tails[s] : a.tail;
-    const uint32_t h_quad = chunk * 64u + quad * 4u;  // first hop of the quad (of this launch)
-    const uint32_t p0 = (uint32_t)(tail + (uint64_t)(a.first_hop + h_quad) * hop);  // the walk's step 0 (positions mod 2^32: cap <= 2^30 divides it)
+    const uint32_t h_group = chunk * 64u + group * (uint32_t)G;  // first hop of the group (of this launch)
+    const uint32_t p0 = (uint32_t)(tail + (uint64_t)(a.first_hop + h_group) * hop);  // the walk's step 0 (positions mod 2^32: cap <= 2^30 divides it)
 
     float sum = -0.0f, taken = 0.0f;
     uint32_t step = 0, resets = 1, takes = 0;  // lane 0's reset is the initial value
-    Tile cur = load_tile(ring, mask, p0, j);
-    while (true) {
-        // events at `step`: window ends first (a lane's take), then window starts
-        while (takes < live && (uint64_t)takes * hop + W == step) {
-            taken = j == takes ? sum : taken;
-            ++takes;
-        }
-        if (takes == live) break;
-        while (resets < live && (uint64_t)resets * hop == step) {
-            sum = j == resets ? -0.0f : sum;
-            ++resets;
+    // One tile of the walk: the events at `step`, then the next tile's loads (into `nxt`: in flight behind this tile's adds), then the adds
+    // of `cur`.  Returns false when the last window has been taken.  Called with the two tile buffers in alternating roles — a
+    // `cur = nxt` at the end of a loop body made hipcc wait for the NEW loads ahead of every group of adds (vmcnt(15) ... vmcnt(0) through
+    // the sixteen groups): 65 us per launch at the ring's load latency where the adds take 20.
+    auto walk_tile = [&](Tile& cur, Tile& nxt) -> bool {
+        while (true) {
+            // events at `step`: window ends first (a lane's take), then window starts
+            while (takes < live && (uint64_t)takes * hop + W == step) {
+                taken = j == takes ? sum : taken;
+                ++takes;
+            }
+            if (takes == live) return false;
+            while (resets < live && (uint64_t)resets * hop == step) {
+                sum = j == resets ? -0.0f : sum;
+                ++resets;
+            }
+            if (resets != takes) break;
+            // no window open (hop > W): skip to the next start
+            step = (uint32_t)((uint64_t)resets * hop);
+            cur = load_tile(ring, mask, p0 + step, jq);
         }
         uint64_t next_event = (uint64_t)takes * hop + W;
         if (resets < live) next_event = min(next_event, (uint64_t)resets * hop);
-        if (resets == takes) {  // no window open (hop > W): skip to the next start
-            step = (uint32_t)next_event;
-            cur = load_tile(ring, mask, p0 + step, j);
-            continue;
-        }
         const uint32_t n = (uint32_t)min<uint64_t>(next_event - step, (uint64_t)kTileSteps);
-        const Tile nxt = load_tile(ring, mask, p0 + step + n, j);  // in flight behind this tile's adds
+        nxt = load_tile(ring, mask, p0 + step + n, jq);
         asm volatile("" ::: "memory");  // (the loads stay ahead of the adds: hipcc sinks them behind the chain otherwise, to save registers)
         if (n == (uint32_t)kTileSteps) sum = add_tile_full(sum, cur);
         else sum = add_tile_partial(sum, cur, n);
         step += n;
-        cur = nxt;
+        return true;
+    };
+    Tile ta = load_tile(ring, mask, p0, jq), tb;
+    while (walk_tile(ta, tb) && walk_tile(tb, ta)) {
     }
-    const uint32_t h = h_quad + j;
+    const uint32_t h = h_group + j;
     if (h < n_hops_s) a.sums[((uint64_t)s * a.n_rings + r) * a.n_hops + h] = taken;
 }
 
@@ -238,7 +342,23 @@ void launch_window_sums(const WindowSumArgs& a, hipStream_t stream) {
     const uint32_t waves_per_sr = (a.n_hops + 63u) / 64u;
     const uint32_t sr = a.n_streams * a.n_rings;
     const uint32_t grid = ((sr + 7u) / 8u) * 8u * waves_per_sr;
-    window_sums_seq_kernel<<<grid, 64, 0, stream>>>(a);
+    // hops per group: as many as overlap one sample (W / hop), between one quad and four
+    const uint32_t overlap = a.hop ? a.window / a.hop : 1u;
+    // Measured at 4096 / 256, 65536 hops (round 6, kernel alone, same box): G = 4 / 8 / 16 take 72 / 77 / 79 us and the step 1.733 ... 1.741 /
+    // 1.732 ... 1.738 / 1.738 ... 1.739 ms — inside each other's noise: a group of 4 re-reads every sample 4.75 times (311 MB through an
+    // L2 that cannot hold the reuse distance), a group of 16 reads it twice but walks 7936 steps instead of 4864, and the kernel is the
+    // chain of dependent adds either way (a build without any load runs as long: 13 us + 4.6 ... 5.3 ns per step).  8 is the middle.
+    const uint32_t g = (overlap >= 8u && a.n_hops >= 8u) ? 8u : 4u;
+    // (lock-step launches whose positions are multiples of 4 samples: every 16-byte load then lies inside the ring)
+    const bool aligned = a.hop % 16u == 0u && a.window % 16u == 0u && (uint64_t)(g - 1u) * a.hop + a.window < 0xFFFFFF00ull && a.hop <= a.window && !a.tails &&
+                         (a.tail + (uint64_t)a.first_hop * a.hop) % 4u == 0u && a.cap % 4u == 0u && reinterpret_cast<uintptr_t>(a.ring[0]) % 16u == 0u &&
+                         (a.n_rings < 2u || reinterpret_cast<uintptr_t>(a.ring[1]) % 16u == 0u);
+    if (aligned) {
+        if (g == 8u) window_sums_aligned_kernel<8><<<grid, 64, 0, stream>>>(a);
+        else window_sums_aligned_kernel<4><<<grid, 64, 0, stream>>>(a);
+    } else {
+        window_sums_seq_kernel<4><<<grid, 64, 0, stream>>>(a);
+    }
 }
 
 }  // namespace omx
