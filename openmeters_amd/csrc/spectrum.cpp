@@ -320,8 +320,30 @@ void SpectrumBank::launch_window_sums_for(uint64_t tail0, const uint64_t* tails,
         carry_valid_ = true;
         return;
     }
+    if (tails && hop <= N && slots <= 64) {  // ragged: the plan kernel has decided per stream (fold_mode); the carried streams first
+        d_carry_.reserve((size_t)(n_streams_ * n_traces * slots));
+        WindowCarryArgs c{};
+        for (uint32_t t = 0; t < n_traces; ++t) c.ring[t] = rings[t];
+        c.n_rings = n_traces;
+        c.cap = ring_cap_;
+        c.hop = (uint32_t)hop;
+        c.window = (uint32_t)N;
+        c.slots = (uint32_t)slots;
+        c.first_hop = (uint32_t)first_hop;
+        c.n_hops = (uint32_t)hops_launch;
+        c.n_streams = n_streams_;
+        c.carry = d_carry_.ptr;
+        c.sums = d_hop_sums_.ptr;
+        c.tails = tails;
+        c.froms = r_fold_from_.ptr;
+        c.heads = r_head_.ptr;
+        c.slot0s = r_fold_slot0_.ptr;
+        c.modes = r_fold_mode_.ptr;
+        launch_window_sums_carry(c, stream);
+    }
     carry_valid_ = false;
     WindowSumArgs w{};
+    w.modes = tails ? r_fold_mode_.ptr : nullptr;
     for (uint32_t t = 0; t < n_traces; ++t) w.ring[t] = rings[t];
     w.n_rings = n_traces;
     w.cap = ring_cap_;
@@ -454,6 +476,10 @@ void SpectrumBank::enter_ragged(hipStream_t stream) {
     OMX_HIP(hipMemcpyAsync(r_head_.ptr, h.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     OMX_HIP(hipMemcpyAsync(r_tail_.ptr, t.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     OMX_HIP(hipMemcpyAsync(r_skip_.ptr, k.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    // the carried window folds per stream (spectrum_plan_kernel keeps the books): nothing is carried across the switch
+    for (DeviceBuffer<uint32_t>* b : {&r_carry_slot0_, &r_carry_valid_, &r_fold_mode_, &r_fold_slot0_}) b->reserve(S);
+    for (DeviceBuffer<uint64_t>* b : {&r_carry_pos_, &r_fold_from_}) b->reserve(S);
+    OMX_HIP(hipMemsetAsync(r_carry_valid_.ptr, 0, S * sizeof(uint32_t), stream));
     OMX_HIP(hipStreamSynchronize(stream));
     ragged_ = true;
     carry_valid_ = false;
@@ -555,6 +581,17 @@ int SpectrumBank::ragged_plan(const float* d_pcm, uint64_t frames_capacity, cons
     pl.ing_head = r_ing_head_.ptr;
     pl.hop_tail = r_hop_tail_.ptr;
     pl.n_hops = r_nhops_.ptr;
+    {
+        const uint64_t slots = (N + hop - 1) / hop;
+        const bool fast = fast4096_ && !force_generic_ && ring_cap_ <= (uint64_t(1) << 30);
+        pl.fold_slots = (fast && hop <= N && slots <= 64) ? (uint32_t)slots : 0u;
+        pl.carry_pos = r_carry_pos_.ptr;
+        pl.carry_slot0 = r_carry_slot0_.ptr;
+        pl.carry_valid = r_carry_valid_.ptr;
+        pl.fold_mode = r_fold_mode_.ptr;
+        pl.fold_from = r_fold_from_.ptr;
+        pl.fold_slot0 = r_fold_slot0_.ptr;
+    }
     launch_spectrum_plan(pl, stream);
 
     IngestArgs ia{};

@@ -623,6 +623,30 @@ __global__ __launch_bounds__(64) void spectrum_plan_kernel(SpectrumPlanArgs a) {
             ++n_hops;
         }
     }
+    // the window folds of this call (SpectrumBank::launch_window_sums_for has the lock-step form of the same rule): carried while the
+    // stream's positions move by pushes alone and the call brings few samples, walked otherwise.  The bookkeeping moves here, ahead of
+    // the fold kernels, which only read it.
+    if (a.fold_mode) {
+        uint32_t mode = kFoldNone, valid = a.carry_valid[s];
+        if (a.reset_mask && a.reset_mask[s]) valid = 0u;
+        if (n_hops != 0u) {
+            const uint64_t from = valid ? a.carry_pos[s] : tail0;
+            if (a.fold_slots != 0u && head - from <= a.fft_size + 3u * a.hop) {
+                mode = kFoldCarry;
+                const uint32_t slot0 = valid ? a.carry_slot0[s] : 0u;
+                a.fold_from[s] = from;
+                a.fold_slot0[s] = slot0;
+                a.carry_slot0[s] = (uint32_t)(((uint64_t)slot0 + n_hops) % a.fold_slots);
+                a.carry_pos[s] = head;
+                valid = 1u;
+            } else {
+                mode = kFoldWalk;
+                valid = 0u;
+            }
+        }
+        a.carry_valid[s] = valid;
+        a.fold_mode[s] = mode;
+    }
     a.ing_skip[s] = skip32;
     a.ing_count[s] = count32;
     a.ing_head[s] = head_before;

@@ -102,7 +102,9 @@ struct WindowSumArgs {
     uint32_t n_hops;        // hops per (stream, ring) computed by this launch = layout stride of `sums`
     uint32_t n_streams;
     float* sums;            // [n_streams][n_rings][n_hops]
+    const uint32_t* modes;  // ragged banks: per stream kFoldWalk / kFoldCarry / kFoldNone (spectrum_plan_kernel); the walk serves kFoldWalk
 };
+enum : uint32_t { kFoldNone = 0, kFoldCarry = 1, kFoldWalk = 2 };
 void launch_window_sums(const WindowSumArgs& a, hipStream_t stream);
 // The same sums carried from call to call (lock-step banks fed a few samples per call): every window that has started keeps its running
 // fold in one of `slots` = ceil(window / hop) slots per (stream, ring); see window_sums_carry_kernel.
@@ -120,6 +122,13 @@ struct WindowCarryArgs {
     uint32_t n_streams;
     float* carry;         // [n_streams][n_rings][slots]
     float* sums;          // [n_streams][n_rings][n_hops]
+    // ragged banks: every stream's own positions (spectrum_plan_kernel) — tail / carry_pos / head / slot0 above are then unused, and
+    // only the streams whose mode is kFoldCarry are served
+    const uint64_t* tails;
+    const uint64_t* froms;
+    const uint64_t* heads;
+    const uint32_t* slot0s;
+    const uint32_t* modes;
 };
 void launch_window_sums_carry(const WindowCarryArgs& a, hipStream_t stream);
 
@@ -311,6 +320,14 @@ struct SpectrumPlanArgs {
     uint64_t* ing_head;
     uint64_t* hop_tail;                // [n_streams] absolute position of hop 0's first sample
     uint32_t* n_hops;                  // [n_streams]
+    // the window folds of the call (window_sum_kernels.hip): which kernel serves stream s, and the carried folds' bookkeeping per stream
+    uint32_t fold_slots;               // ceil(fft_size / hop), or 0 when folds are not carried (hop > fft_size, more than 64 slots, generic path)
+    uint64_t* carry_pos;               // [n_streams] state: samples below this position are in the carried folds
+    uint32_t* carry_slot0;             //             state: slot of the window that starts at the stream's tail
+    uint32_t* carry_valid;             //             state
+    uint32_t* fold_mode;               // out [n_streams]: kFoldNone / kFoldCarry / kFoldWalk
+    uint64_t* fold_from;               //                  carry: first sample to add to the windows that have started
+    uint32_t* fold_slot0;              //                  carry: slot of this call's window 0
 };
 void launch_spectrum_plan(const SpectrumPlanArgs& a, hipStream_t stream);
 // reset_audio of the masked streams' level state: averaging state to 0, trace rows back to the floor

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64) void window_sums_seq_kernel(WindowSumArgs a) {
     const uint32_t s = sr / a.n_rings, r = sr % a.n_rings;
     const uint32_t n_hops_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.hops ? a.hops[s] : a.n_hops));
     if (chunk * 64u >= n_hops_s) return;
+    if (a.modes && a.modes[s] != kFoldWalk) return;  // ragged banks: this stream's folds are carried (window_sums_carry_kernel)
     const uint32_t lane = threadIdx.x, j = lane % (uint32_t)G, group = lane / (uint32_t)G, jq = lane & 3u;
     const uint32_t live = min((uint32_t)G, n_hops_s - chunk * 64u);  // lanes of the wavefront's fullest group (its first): the walk ends with their last take
     const uint32_t hop = a.hop, W = a.window;
@@ -286,13 +287,17 @@ __global__ __launch_bounds__(64) void window_sums_carry_kernel(WindowCarryArgs a
     if (idx >= a.n_streams * a.n_rings * G) return;
     const uint32_t sr = idx / G, g = idx % G;
     const uint32_t s = sr / a.n_rings, r = sr % a.n_rings;
+    if (a.modes && a.modes[s] != kFoldCarry) return;
+    const uint64_t tail = a.tails ? a.tails[s] : a.tail, carry_pos = a.froms ? a.froms[s] : a.carry_pos, head = a.heads ? a.heads[s] : a.head;
+    const uint32_t slot0 = a.slot0s ? a.slot0s[s] : a.slot0;
+    const uint64_t n_windows = a.tails ? (head - tail + a.hop - 1u) / a.hop : a.n_windows;
     const uint32_t mask = (uint32_t)(a.cap - 1u);
     const float* ring = a.ring[r] + (uint64_t)s * a.cap;
-    float* slot = a.carry + (uint64_t)sr * G + (a.slot0 + g) % G;  // window k = g, g + G, ... of this call all live in this slot
-    for (uint64_t k = g; k < a.n_windows; k += G) {
-        const uint64_t p = a.tail + k * a.hop, end = p + a.window;
-        const uint64_t from = max(p, a.carry_pos), to = min(end, a.head);
-        float sum = p < a.carry_pos ? *slot : -0.0f;
+    float* slot = a.carry + (uint64_t)sr * G + (slot0 + g) % G;  // window k = g, g + G, ... of this call all live in this slot
+    for (uint64_t k = g; k < n_windows; k += G) {
+        const uint64_t p = tail + k * a.hop, end = p + a.window;
+        const uint64_t from = max(p, carry_pos), to = min(end, head);
+        float sum = p < carry_pos ? *slot : -0.0f;
         uint32_t pos = (uint32_t)from;        // (positions mod 2^32: cap <= 2^30 divides it)
         uint64_t n = to - from;
         if (n >= 64u) {
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(64) void window_sums_carry_kernel(WindowCarryArgs a
                 if (4u * (unsigned)i + 3u < m) sum += last.v[i].w;
             }
         }
-        if (end <= a.head) {
+        if (end <= head) {
             if (k >= a.first_hop && k - a.first_hop < a.n_hops) a.sums[(uint64_t)sr * a.n_hops + (k - a.first_hop)] = sum;
         } else {
             *slot = sum;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(64) void window_sums_carry_kernel(WindowCarryArgs a
 
 void launch_window_sums_carry(const WindowCarryArgs& a, hipStream_t stream) {
     const uint64_t lanes = (uint64_t)a.n_streams * a.n_rings * a.slots;
-    if (lanes == 0 || a.n_windows == 0) return;
+    if (lanes == 0 || (a.n_windows == 0 && !a.tails)) return;
     window_sums_carry_kernel<<<(uint32_t)((lanes + 63u) / 64u), 64, 0, stream>>>(a);
 }
 

@@ -197,3 +197,50 @@ def test_classic_rectangular_window_bin_zero_is_a_plain_fixed_bar_case(omx, orac
     want = SpectrogramProcessor(oracle, cfg).process_block(AudioBlock(pcm, 2, 48000.0))
     assert len(got.new_columns) == len(want.new_columns) == 16
     check_classic(got.new_columns, want.new_columns)
+
+
+@pytest.mark.parametrize("N,hop", [(1024, 256), (4096, 256), (16384, 1024)])
+def test_ragged_spectrum_bank_carries_the_folds_per_stream(omx, oracle, N, hop):
+    """per-capture frame counts and resets (omx_spectrum_bank_process_ragged): spectrum_plan_kernel keeps every stream's carried folds on
+    the device — carried while the stream moves by small pushes, walked after a long one or a reset.  Offset signals, every completed
+    snapshot of every stream against its own oracle handle at the plain bars."""
+    import torch
+    rng = np.random.default_rng(N * 7 + hop)
+    S, cap = 5, 1024
+    cfg = SpectrumConfig(fft_size=N, hop_size=hop, floor_db=-140.0)
+    bank = banks.SpectrumBank(omx, cfg, S)
+    refs = [SpectrumProcessor(oracle, cfg) for _ in range(S)]
+    feeds = [_offset_hop(rng, 6 * N + 40 * cap) for _ in range(S)]
+    at = [0] * S
+    pos = capi.positions_fallback(2)
+    bins = N // 2 + 1
+    compared = 0
+    for call in range(int(2.5 * N / 256) + 24):
+        frames = rng.choice([0, 100, 256, 256, 256, 512, 1024], S)
+        if call == 5:
+            frames[:] = 1024                                  # (everyone long: several hops at the small sizes)
+        mask = (rng.random(S) < 0.05).astype(np.uint8)
+        pcm = np.zeros((S, cap, 2), np.float32)
+        for s in range(S):
+            pcm[s, :frames[s]] = feeds[s][at[s]:at[s] + frames[s]]
+        d_pcm = torch.from_numpy(pcm).to("cuda:0")
+        up = bank.process_ragged(d_pcm.data_ptr(), cap, frames, 2, 48000.0, pos, mask)
+        torch.cuda.synchronize()
+        n_hops = torch.as_tensor(_DeviceView(up.d_n_hops, (S,), "<u4"), device="cuda:0").cpu().numpy()
+        traces = torch.as_tensor(_DeviceView(up.d_traces, (S, up.n_hops_out, 2, 2, bins), "<f4"), device="cuda:0").cpu().numpy() if up.d_traces else None
+        for s in range(S):
+            if mask[s]:
+                refs[s].reset_audio()
+            w = refs[s].process_block(AudioBlock(pcm[s, :frames[s]].reshape(-1), 2, 48000.0)) if frames[s] else None
+            at[s] += int(frames[s])
+            assert (int(n_hops[s]) > 0) == (w is not None), (call, s, int(n_hops[s]))
+            if w is not None:
+                for wt in range(2):
+                    check_trace(traces[s, 0, 0, wt], np.asarray(w.traces[0][wt]), floor=-140.0)
+                compared += 1
+    assert compared >= 3 * S
+
+
+class _DeviceView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
