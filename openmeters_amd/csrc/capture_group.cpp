@@ -260,49 +260,66 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
                 note(spectrum->process_pushed(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
             }
         }
+        // Which stream carries which meter bank: -1 = the caller's stream (behind the spectrogram / spectrum kernels), 0 ... 3 = a side stream.
+        // HIP maps streams onto four hardware queues, and the chains are latency-bound kernels on a few dozen workgroups each (alone, per
+        // 1024-capture 256-frame call: spectrogram 64 us, spectrum 27, loudness 70, stereometer 75, oscilloscope 115, waveform 69).
+        //   regular cadence (one batcher block per call, meter.rs:61-64): caller {spectrogram, spectrum}, side 0 {loudness},
+        //     side 1 {stereometer, waveform}, side 2 {oscilloscope} — four chains of 91 / 70 / 144 / 115 us: 260 ... 264 us per call against
+        //     280 ... 295 with the oscilloscope behind the spectrum kernel on the caller's stream (round 5's layout; same box, three passes);
+        //   catch-up chunks and replayed calls (>= 512 frames at 48 kHz): round 5's layout — caller {spectrogram, spectrum, oscilloscope},
+        //     one side stream per meter bank — 462 us per 1024-frame chunk against 512 with the layout above (the trigger pass's > 100 KiB of
+        //     LDS per workgroup wait for the waveform kernel's 66 KiB on every CU whichever queue they sit on, ledger Q-anyorder).
+        const bool regular = (double)frames * 48000.0 < 512.0 * (double)sr;
+        const int lay_regular[4] = {0, 1, 1, 2}, lay_long[4] = {0, 3, 1, -1};  // loudness, waveform, stereometer, oscilloscope
+        const int* lay = regular ? lay_regular : lay_long;
+        auto on = [&](int k) -> hipStream_t {
+            if (k < 0) return stream;
+            if (!used[k]) {
+                used[k] = true;
+                OMX_HIP(hipStreamWaitEvent(side_[k], fork_, 0));
+            }
+            return side_[k];
+        };
         // ---- one side stream per meter bank (round 4: until then loudness + waveform and stereometer + oscilloscope shared one each, and
         //      at the reference's cadence — one 256-frame block per call, kernels of 50 ... 100 us on a few dozen workgroups — the
         //      longer pair was the call's critical path)
         // ---- side stream 0: loudness (+ its summary columns)
         if (loudness) {
-            used[0] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
+            const hipStream_t s_ld = on(lay[0]);
             {
-                const int rc = loudness->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[0], &up.d_loudness);
+                const int rc = loudness->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, s_ld, &up.d_loudness);
                 note(rc, OMX_VISUAL_LOUDNESS);
                 if (stats && rc == OMX_PRODUCED && up.d_loudness) {
                     // K9: true-peak bars + their peak holds on the sample clock (loudness/state.rs:36-60, 178-217)
                     if (!holds_valid_) {
                         holds_.reserve((size_t)S * 3);
-                        launch_peak_holds_reset(holds_.ptr, (uint64_t)S * 3, clock_, side_[0]);
+                        launch_peak_holds_reset(holds_.ptr, (uint64_t)S * 3, clock_, s_ld);
                         holds_valid_ = true;
                     }
                     meters_.reserve((size_t)S * n_blocks);
                     const double dt = (double)block / (double)sr;
                     launch_loudness_meters(up.d_loudness, S, n_blocks, OMX_METER_TRUE_PEAK, OMX_METER_LUFS_SHORT_TERM, clock_, dt, holds_.ptr,
-                                           meters_.ptr, side_[0]);
+                                           meters_.ptr, s_ld);
                     clock_ += (double)n_blocks * dt;
-                    launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, side_[0]);
+                    launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, s_ld);
                 }
             }
             OMX_HIP(hipGetLastError());
         }
         // ---- side stream 3: waveform
         if (waveform) {
-            used[3] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[3], fork_, 0));
-            note(waveform->process(d_pcm, true, frames, channels, sample_rate, positions, side_[3], &up.waveform), OMX_VISUAL_WAVEFORM);
+            const hipStream_t s_wf = on(lay[1]);
+            note(waveform->process(d_pcm, true, frames, channels, sample_rate, positions, s_wf, &up.waveform), OMX_VISUAL_WAVEFORM);
             OMX_HIP(hipGetLastError());
         }
         // ---- side stream 1: stereometer (+ its summary columns)
         if (stereometer) {
-            used[1] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
+            const hipStream_t s_st = on(lay[2]);
             {
-                const int rc = stereometer->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, side_[1], &up.stereometer);
+                const int rc = stereometer->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, s_st, &up.stereometer);
                 note(rc, OMX_VISUAL_STEREOMETER);
                 if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations)
-                    launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, side_[1]);
+                    launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, s_st);
             }
             OMX_HIP(hipGetLastError());
         }
@@ -314,7 +331,7 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
         //      307 us per call: every chain contends for the same 256 CUs.  Here: 291 us, and 466 against 530 for a 1024-frame chunk.
         if (oscilloscope) {
             {
-                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, stream);
+                const int rc = oscilloscope->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, on(lay[3]));
                 note(rc, OMX_VISUAL_OSCILLOSCOPE);
                 if (rc == OMX_PRODUCED) {
                     up.oscilloscope.n_streams = S;

@@ -128,7 +128,9 @@ def loudness(S=1024, C=8, blocks=64, reps=REPS, out=sys.stdout):
             # algorithmic bytes of THIS formulation: 8 B per channel-sample (PCM in, f32 ring out) + 104 B per snapshot; SURVEY §8(d)'s
             # 44 B belongs to the sliding-sum formulation (its fraction is the field above: >= 1.0 means this form beats what that
             # formulation could do at the HBM peak)
-            "roofline": roofline(cs * 8.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan", "loudness_"]),
+            # (traffic: the chunk-parallel form's kernels only — the sequential kernel is enqueued behind them, predicated off, and the same
+            # process also runs the sequential form for the entry below)
+            "roofline": roofline(cs * 8.0 + S * blocks * 104.0, kms, ["loud_chunk", "loud_scan"]),
             "momentary_lufs_stream0": float(snap.momentary_loudness),
             "sequential_form": {"form": "sequential (loudness_kernels.hip): the reference's operation order, OMX_OPT_KERNEL_FORM = 1",
                                 "ms_per_call": dts * 1e3, "kernel_ms": kmss, "channel_samples_per_s": cs / dts, "x_real_time": cs / dts / (S * C * FS),
@@ -163,7 +165,7 @@ def scope_stereo(S=256, blocks=64, reps=REPS, out=sys.stdout):
                                                     "stereometer (chunk-parallel): |d rho| / (1e-6 + 0.5 eta sqrt(1 - rho^2) + 0.5 eta^2)",
                                                     "stereometer (chunk-parallel) vs exact f64: |d rho|"),
                            # §8(d): ~16 B per stereo frame (8 B PCM in + 8 B per point out on emit)
-                           "roofline": roofline(S * frames * 16.0, dt * 1e3, ["stereo_chunk", "stereo_scan", "stereometer_"]),
+                           "roofline": roofline(S * frames * 16.0, dt * 1e3, ["stereo_chunk", "stereo_scan", "stereometer_points", "stereometer_produced"]),
                            "sequential_form": {"form": "sequential (stereometer_kernels.hip): the reference's operation order, bit-identical points and rho, "
                                                        "OMX_OPT_KERNEL_FORM = 1",
                                                "ms_per_call": dts * 1e3, "blocks_per_s": S * blocks / dts, "x_real_time": frames / dts / FS,
