@@ -487,44 +487,54 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                 up.ingest_launches += 1;
             }
         }
+        // stream layout by call length, as in the lock-step call (see there)
+        const bool regular = (double)frames_capacity * 48000.0 < 512.0 * (double)sr;
+        const int lay_regular[4] = {0, 1, 1, 2}, lay_long[4] = {0, 3, 1, -1};  // loudness, waveform, stereometer, oscilloscope
+        const int* lay = regular ? lay_regular : lay_long;
+        auto on = [&](int k) -> hipStream_t {
+            if (k < 0) return stream;
+            if (!used[k]) {
+                used[k] = true;
+                OMX_HIP(hipStreamWaitEvent(side_[k], fork_, 0));
+            }
+            return side_[k];
+        };
         if (loudness) {
-            used[0] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[0], fork_, 0));
-            note(chunks ? loudness->process_chunks(d_pcm, frames_capacity, frames, m_ld, channels, sample_rate, positions, side_[0], &up.loudness)
+            const hipStream_t s_ld = on(lay[0]);
+            note(chunks ? loudness->process_chunks(d_pcm, frames_capacity, frames, m_ld, channels, sample_rate, positions, s_ld, &up.loudness)
                         : loudness->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_ld, channels, sample_rate, positions,
-                                                   side_[0], &up.loudness),
+                                                   s_ld, &up.loudness),
                  OMX_VISUAL_LOUDNESS);
             if (stats && up.loudness.d_snapshots && up.loudness.d_n_blocks)
                 launch_stats_loudness_ragged(up.loudness.d_snapshots, S, up.loudness.max_blocks, up.loudness.d_n_blocks, up.loudness.d_block_frames,
                                              (uint32_t)block, sr, up.loudness.d_reset, OMX_METER_TRUE_PEAK, OMX_METER_LUFS_SHORT_TERM, channels,
-                                             holds_.ptr, clocks_.ptr, rows_.ptr, side_[0]);
+                                             holds_.ptr, clocks_.ptr, rows_.ptr, s_ld);
             OMX_HIP(hipGetLastError());
         }
         if (waveform) {
-            used[3] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[3], fork_, 0));
-            note(waveform->process_ragged(d_pcm, frames_capacity, frames, m_wf, channels, sample_rate, positions, side_[3], &up.waveform),
+            const hipStream_t s_wf = on(lay[1]);
+            note(waveform->process_ragged(d_pcm, frames_capacity, frames, m_wf, channels, sample_rate, positions, s_wf, &up.waveform),
                  OMX_VISUAL_WAVEFORM);
             OMX_HIP(hipGetLastError());
         }
         if (stereometer) {
-            used[1] = true;
-            OMX_HIP(hipStreamWaitEvent(side_[1], fork_, 0));
-            note(chunks ? stereometer->process_chunks(d_pcm, frames_capacity, frames, m_st, channels, sample_rate, positions, side_[1],
+            const hipStream_t s_st = on(lay[2]);
+            note(chunks ? stereometer->process_chunks(d_pcm, frames_capacity, frames, m_st, channels, sample_rate, positions, s_st,
                                                       &up.stereometer)
                         : stereometer->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_st, channels, sample_rate, positions,
-                                                      side_[1], &up.stereometer),
+                                                      s_st, &up.stereometer),
                  OMX_VISUAL_STEREOMETER);
             if (stats && up.stereometer.d_correlations && up.stereometer.d_n_blocks)
                 launch_stats_stereometer_ragged(up.stereometer.d_correlations, S, up.stereometer.max_blocks, up.stereometer.d_n_blocks, rows_.ptr,
-                                                side_[1]);
+                                                s_st);
             OMX_HIP(hipGetLastError());
         }
-        if (oscilloscope) {  // (on the caller's stream, as in the lock-step call)
-            note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, stream,
+        if (oscilloscope) {
+            const hipStream_t s_sc = on(lay[3]);
+            note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, s_sc,
                                                        &up.oscilloscope)
                         : oscilloscope->process_ragged(d_pcm, block, max_blocks, blocks_scratch_.data(), m_os, channels, sample_rate, positions,
-                                                       stream, &up.oscilloscope),
+                                                       s_sc, &up.oscilloscope),
                  OMX_VISUAL_OSCILLOSCOPE);
             OMX_HIP(hipGetLastError());
         }
