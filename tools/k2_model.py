@@ -68,11 +68,27 @@ def main():
         def grab(name):
             m = re.search(r"stft_reassigned_4096_tri_kernel<2>\s+" + name + r"\s+mean=([0-9.e+]+)", prof)
             return float(m.group(1)) if m else None
-        for name, mine in (("SQ_INSTS_VALU", n_valu), ("SQ_INSTS_LDS", sum(lds.values())), ("SQ_INSTS_SALU", None), ("SQ_WAVES", None)):
+        waves = grab("SQ_WAVES") or WAVES
+        for name, mine in (("SQ_INSTS_VALU", n_valu), ("SQ_INSTS_LDS", sum(lds.values())), ("SQ_INSTS_SALU", None)):
             v = grab(name)
             if v:
-                per_wave = v / (grab("SQ_WAVES") or WAVES)
-                print(f"profile {name}: {v:.4g} per launch = {per_wave:.0f} per wavefront" + (f" (static census {mine})" if mine else ""))
+                print(f"profile {name}: {v:.4g} per launch = {v / waves:.0f} per wavefront" + (f" (static census {mine}: the census includes the cold wrapped-ring path)" if mine else ""))
+        dyn_valu = grab("SQ_INSTS_VALU")
+        if dyn_valu:
+            t_dyn = dyn_valu / SIMDS * 4 / (CLOCK_GHZ * 1e6)
+            print(f"VALU issue from the DYNAMIC count: {dyn_valu / waves:.0f} instructions x 4 cycles x {waves_per_simd:.1f} wavefronts per SIMD = {t_dyn:.3f} ms at {CLOCK_GHZ} GHz "
+                  f"-> VALU busy {t_dyn / kernel_ms * 100:.0f} %, VALU + LDS pipe = {(t_dyn + t_lds):.3f} ms = {(t_dyn + t_lds) / kernel_ms * 100:.0f} % of the measured kernel")
+        wc = grab("SQ_WAVE_CYCLES")
+        if wc:
+            print("wave cycles (SQ_WAVE_CYCLES = ACTIVE_INST_ANY + WAIT_INST_ANY + WAIT_ANY, guide):")
+            for name, label in (("SQ_ACTIVE_INST_ANY", "issuing an instruction"), ("SQ_ACTIVE_INST_VALU", "  of which VALU"), ("SQ_ACTIVE_INST_LDS", "  of which LDS"),
+                                ("SQ_WAIT_INST_ANY", "stalled at issue"), ("SQ_WAIT_INST_LDS", "  of which at the LDS queue"), ("SQ_WAIT_ANY", "parked at s_waitcnt / s_barrier")):
+                v = grab(name)
+                if v:
+                    print(f"  {label:34s} {v / wc * 100:5.1f} %")
+            conf, idx = grab("SQ_LDS_BANK_CONFLICT"), grab("SQ_LDS_IDX_ACTIVE")
+            if conf and idx:
+                print(f"  LDS bank-conflict cycles / LDS-array cycles {conf / idx * 100:.1f} %")
 
 
 if __name__ == "__main__":
