@@ -51,6 +51,33 @@ void WaveformBank::reset_trackers() {  // :199-201 (band_analysis is None when a
     clear_trackers_ = true;
     pushes_ = 0;
     ragged_zero_pushes_ = true;
+    kept_invalidate();
+}
+void WaveformBank::kept_invalidate() {
+    kept_.clear();
+    kept_free_.clear();
+    for (uint32_t k = kept_slots_; k-- > 0;) kept_free_.push_back(k);
+    kept_zero_void_ = true;
+}
+// room for `slots` totals (contents preserved); false when the table would pass 1 GiB — the call then leaves no totals and later
+// calls read the rings
+bool WaveformBank::kept_reserve(size_t slots, hipStream_t stream) {
+    if (slots <= kept_slots_) return true;
+    const size_t per_slot = (size_t)n_streams_ * 24 * 2;
+    const size_t most = ((size_t)1 << 30) / (per_slot * sizeof(double));
+    if (slots > most) return false;
+    const size_t grown = std::min(most, std::max<size_t>(slots * 2, 64));
+    DeviceBuffer<double> bigger;
+    bigger.reserve(grown * per_slot);
+    if (kept_slots_) {
+        OMX_HIP(hipMemcpyAsync(bigger.ptr, kept_totals_.ptr, (size_t)kept_slots_ * per_slot * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        OMX_HIP(hipStreamSynchronize(stream));
+    }
+    std::swap(bigger.ptr, kept_totals_.ptr);
+    std::swap(bigger.count, kept_totals_.count);
+    for (uint32_t k = (uint32_t)grown; k-- > kept_slots_;) kept_free_.push_back(k);
+    kept_slots_ = (uint32_t)grown;
+    return true;
 }
 void WaveformBank::prepare(hipStream_t) {  // :169-173
     if (cfg_.analyze_bands && !analysis_) reset_trackers();
@@ -112,6 +139,7 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
         clear_trackers_ = true;
         pushes_ = 0;
         ragged_zero_pushes_ = true;
+        kept_invalidate();
     }
     if (clear_minmax_ && clear_trackers_) {
         OMX_HIP(hipMemsetAsync(state_.ptr, 0, state_.count * sizeof(WaveLaneState), stream));
@@ -143,6 +171,7 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
 
     const double step = std::min(std::max((double)cfg_.scroll_speed / (double)cfg_.sample_rate, 0.0), 1.0);
     if (ragged) {
+        kept_invalidate();  // (per-stream push counts: the kept totals are a lock-step bank's)
         // every stream advances its own phase on the device; a call emits at most floor(phase + frames x step) <= max_cols columns
         const uint64_t max_cols = (uint64_t)std::floor(1.0 + (double)frames * step) + 1;
         if (max_cols > cfg_.max_columns)  // cap_pending_columns (:293-298) would drop the oldest ones: not modelled per stream
@@ -266,7 +295,8 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
     // chunk-parallel evaluation for bank-sized calls (waveform_chunked.hip); the sequential kernels — bit-identical to the reference's
     // order — serve everything else and are the fallback when the chunk form meets non-finite input
     last_form_ = 1;
-    if (record_ends && channels == 2 && run_chunked(wa, column_ends, stream)) last_form_ = 2;
+    if (record_ends && channels == 2 && run_chunked(wa, column_ends, phase, stream)) last_form_ = 2;
+    if (last_form_ != 2) kept_invalidate();  // the sequential kernels do not keep totals
     launch_waveform(wa, stream);
     OMX_HIP(hipGetLastError());
     column_phase_ = phase;
@@ -334,6 +364,10 @@ struct WaveformBank::ChunkGroup {
     uint64_t first_kept = 0;             // columns before this one are dropped (cap_pending_columns, lock-step calls)
     std::vector<uint32_t> streams;       // bank indices (empty: all streams, identity)
     uint32_t write_preview = 0;
+    // kept totals (lock-step calls): the table to take old segments from, and the cuts of this call to leave totals at
+    const std::map<uint64_t, uint32_t>* kept = nullptr;
+    std::vector<int32_t> keep_cuts;
+    std::vector<uint32_t> old_slot;  // (planner) [n_old + 1]
     // filled by the planner
     std::vector<int32_t> cuts;
     std::vector<uint32_t> chunk_seg;
@@ -357,8 +391,11 @@ static bool plan_chunk_group(WaveformBank::ChunkGroup& g, uint32_t C, bool histo
     cuts.clear();
     cuts.reserve(n_emit + (size_t)(kept + 1) * nwin + n_chunks + (size_t)(maxcap / 256) + 16);
     cuts.push_back(-1);
-    cuts.push_back((int32_t)-maxcap);
-    for (int64_t q = -1 - 256; q > -maxcap; q -= 256) cuts.push_back((int32_t)q);  // a grid over the rings' contents (parallelism of the old sums)
+    if (!g.kept) {
+        cuts.push_back((int32_t)-maxcap);
+        for (int64_t q = -1 - 256; q > -maxcap; q -= 256) cuts.push_back((int32_t)q);  // a grid over the rings' contents (parallelism of the old sums)
+    }
+    for (int32_t c : g.keep_cuts) cuts.push_back(c);
     for (uint32_t c = 1; c <= n_chunks; ++c) cuts.push_back((int32_t)(std::min<int64_t>((int64_t)c * C, F) - 1));
     for (uint32_t f : g.column_ends) cuts.push_back((int32_t)f);
     auto add_windows = [&](int64_t f) {
@@ -374,6 +411,25 @@ static bool plan_chunk_group(WaveformBank::ChunkGroup& g, uint32_t C, bool histo
     }
     std::sort(cuts.begin(), cuts.end());
     cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    g.old_slot.clear();
+    if (g.kept) {
+        // the total at a cut = the total of `pushes covered` values (a window that starts before the stream's first push starts at zero)
+        auto slot_of = [&](int32_t cut) {
+            const int64_t covered = std::max<int64_t>((int64_t)P0 + (int64_t)cut + 1, 0);
+            const auto it = g.kept->find((uint64_t)covered);
+            return it == g.kept->end() ? kWaveNoSlot : it->second;
+        };
+        const size_t n_old_cuts = (size_t)(std::lower_bound(cuts.begin(), cuts.end(), -1) - cuts.begin()) + 1;
+        std::vector<int32_t> grid;  // old stretches without kept totals at both ends are read from the rings: a grid for their parallelism
+        for (size_t j = 0; j + 1 < n_old_cuts; ++j)
+            if (slot_of(cuts[j]) == kWaveNoSlot || slot_of(cuts[j + 1]) == kWaveNoSlot)
+                for (int64_t q = (int64_t)cuts[j] + 256; q < (int64_t)cuts[j + 1]; q += 256) grid.push_back((int32_t)q);
+        if (!grid.empty()) {
+            cuts.insert(cuts.end(), grid.begin(), grid.end());
+            std::sort(cuts.begin(), cuts.end());
+        }
+        for (size_t j = 0; j < cuts.size() && cuts[j] <= -1; ++j) g.old_slot.push_back(slot_of(cuts[j]));
+    }
     g.n_segs = (uint32_t)cuts.size() - 1;
     if (g.n_segs > 4096) return false;  // (thousands of columns per call: the plan's scratch grows with segments x streams)
     auto index_of = [&](int64_t cut) { return (uint32_t)(std::lower_bound(cuts.begin(), cuts.end(), (int32_t)cut) - cuts.begin()); };
@@ -445,7 +501,8 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
     for (ChunkGroup& g : groups) {
         const uint32_t n_local = g.streams.empty() ? n_streams_ : (uint32_t)g.streams.size();
         blob_bytes += pad16(g.cuts.size() * sizeof(int32_t)) + pad16(g.chunk_seg.size() * sizeof(uint32_t)) + pad16(g.evals.size() * sizeof(WaveEval)) +
-                      pad16(g.streams.size() * sizeof(uint32_t));
+                      pad16(g.streams.size() * sizeof(uint32_t)) + pad16(g.old_slot.size() * sizeof(uint32_t)) +
+                      pad16(g.keep_cuts.size() * 2 * sizeof(uint32_t));
         state_floats += (uint64_t)g.n_chunks * n_local * 3 * 16;
         segs_room = std::max<uint64_t>(segs_room, ((uint64_t)g.n_segs + 1 + 63) / 64 * 64 + 64);  // (the count moves by a few from call to call)
         local_max = std::max<uint64_t>(local_max, n_local);
@@ -466,6 +523,7 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
     OMX_HIP(hipMemsetAsync(bad_.ptr, 0, sizeof(uint32_t), stream));
 
     std::vector<WaveChunkArgs> args(groups.size());
+    std::vector<std::pair<uint64_t, uint32_t>> kept_new;
     size_t at = 0;
     uint64_t state_at = 0;
     for (size_t k = 0; k < groups.size(); ++k) {
@@ -522,6 +580,30 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
         ca.prefix_hi = prefix_.ptr;
         ca.prefix_lo = prefix_.ptr + (uint64_t)(g.n_segs + 1) * n_local * 24;
         ca.bad = bad_.ptr;
+        ca.base_slot = kWaveNoSlot;
+        if (g.kept) {
+            // slots for the totals this call leaves (none when the table is full: later calls then read the rings)
+            std::vector<uint32_t> keep;
+            if (kept_reserve(kept_.size() + g.keep_cuts.size(), stream)) {
+                for (int32_t c : g.keep_cuts) {
+                    const uint64_t covered = g.pushes0 + (uint64_t)((int64_t)c + 1);
+                    const uint32_t slot = kept_free_.back();
+                    kept_free_.pop_back();
+                    kept_new.emplace_back(covered, slot);
+                    keep.push_back((uint32_t)(std::lower_bound(g.cuts.begin(), g.cuts.end(), c) - g.cuts.begin()));
+                    keep.push_back(slot);
+                }
+            }
+            ca.old_slot = reinterpret_cast<const uint32_t*>(put(g.old_slot.data(), g.old_slot.size() * sizeof(uint32_t)));
+            ca.keep = reinterpret_cast<const uint32_t*>(put(keep.data(), keep.size() * sizeof(uint32_t)));
+            ca.n_keep = (uint32_t)(keep.size() / 2);
+            ca.totals = kept_totals_.ptr;
+            const auto base = kept_.find(g.pushes0);
+            if (base != kept_.end()) ca.base_slot = base->second;
+            ca.void_end = void_end_.ptr;
+            ca.first_count = (uint64_t)std::max<int64_t>((int64_t)g.pushes0 + (int64_t)g.cuts[0] + 1, 0);
+            ca.end_count = g.pushes0 + g.frames;
+        }
         ca.columns = wa.columns;
         ca.preview = wa.preview;
         ca.col_stride = col_stride;
@@ -531,12 +613,13 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
     for (const WaveChunkArgs& ca : args) launch_waveform_chunked_phase1(ca, transition_.ptr, stream);
     for (const WaveChunkArgs& ca : args) launch_waveform_chunked_phase2(ca, stream);
     OMX_HIP(hipGetLastError());
+    for (const auto& kv : kept_new) kept_[kv.first] = kv.second;
     return true;
 }
 
 // The chunk-parallel form of one lock-step call.  Returns false when the call's shape is not served (the caller then runs the
 // sequential kernel alone); after a true return the caller still launches the sequential kernel, predicated on the `bad` flag.
-bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream) {
+bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, double end_phase, hipStream_t stream) {
     const uint64_t frames = wa.frames;
     if (form_ == 1 || !analysis_ || !chunk_shape_ok(frames)) return false;
     if (color_len_ < 64 || slow_len_ < 64 || slow_len_ > 0x3FFFFFFFu) return false;
@@ -550,6 +633,48 @@ bool WaveformBank::run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& co
     groups[0].column_ends = column_ends;
     groups[0].first_kept = wa.first_kept;
     groups[0].write_preview = wa.write_preview;
+    // ---- kept totals: what later calls will start a window at, inside this call
+    {
+        const bool history = wa.track_history != 0;
+        const uint32_t nwin = history ? 3u : 1u;
+        const int64_t caps[3] = {(int64_t)color_len_, (int64_t)color_len_, (int64_t)slow_len_};
+        const int64_t maxcap = history ? (int64_t)slow_len_ : (int64_t)color_len_, F = (int64_t)frames;
+        const uint64_t P0 = pushes_, Pend = pushes_ + frames;
+        for (auto it = kept_.begin(); it != kept_.end() && it->first + (uint64_t)maxcap < P0;) {  // out of every window's reach
+            kept_free_.push_back(it->second);
+            it = kept_.erase(it);
+        }
+        if (!kept_.empty() && kept_.find(P0) == kept_.end()) kept_invalidate();  // (a call that left no totals: nothing to continue from)
+        void_end_.reserve(1);
+        if (kept_zero_void_) OMX_HIP(hipMemsetAsync(void_end_.ptr, 0, sizeof(uint64_t), stream));
+        kept_zero_void_ = false;
+        if (P0 == 0 && kept_.empty() && kept_reserve(1, stream)) {  // the total of nothing
+            const uint32_t slot = kept_free_.back();
+            kept_free_.pop_back();
+            OMX_HIP(hipMemsetAsync(kept_totals_.ptr + (size_t)slot * n_streams_ * 48, 0, (size_t)n_streams_ * 48 * sizeof(double), stream));
+            kept_[0] = slot;
+        }
+        std::vector<int32_t>& keep = groups[0].keep_cuts;
+        auto want = [&](int64_t cut) {
+            if (cut >= 0 && cut <= F - 1) keep.push_back((int32_t)cut);
+        };
+        double phase = end_phase;  // the columns of the frames to come (processor.rs:287-291), as far as a window reaches
+        for (int64_t f = F; f < F + maxcap; ++f) {
+            phase += wa.step;
+            if (phase >= 1.0) {
+                phase -= 1.0;
+                for (uint32_t w = 0; w < nwin; ++w) want(f - caps[w]);
+            }
+        }
+        for (int64_t e = 2 * F - 1; e - maxcap <= F - 1; e += F)  // the ends of later calls of this length (their pseudo-columns)
+            for (uint32_t w = 0; w < nwin; ++w) want(e - caps[w]);
+        for (uint32_t w = 0; w < nwin; ++w)  // refresh points (dsp.rs:346-352): the multiples of the window length
+            for (uint64_t m = P0 / (uint64_t)caps[w] + 1; m * (uint64_t)caps[w] <= Pend; ++m) want((int64_t)(m * (uint64_t)caps[w] - P0) - 1);
+        want(F - 1);
+        std::sort(keep.begin(), keep.end());
+        keep.erase(std::unique(keep.begin(), keep.end()), keep.end());
+        groups[0].kept = &kept_;
+    }
     if (!launch_chunk_groups(wa, groups, frames, wa.n_emit - wa.first_kept, stream)) return false;
     wa.run_if = bad_.ptr;
     return true;

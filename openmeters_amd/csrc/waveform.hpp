@@ -2,6 +2,8 @@
 // 16 lanes per stream: lane = channel * 3 + band for channel in {Left, Right, Mid, Side}, band in {low, mid, high}
 // (12 live lanes); band-0 lanes also carry the channel's min/max column state machine.
 #pragma once
+#include <map>
+
 #include "stereometer.hpp"  // BiquadCoef, make_biquad
 
 namespace omx {
@@ -59,6 +61,7 @@ struct WaveEval {  // one kept column, or (out = 0xFFFFFFFF) the pseudo-column a
     uint32_t out;             // kept-column index
     uint32_t carry;           // the column began before this call: merge the carried column state
 };
+constexpr uint32_t kWaveNoSlot = 0xFFFFFFFFu;
 struct WaveChunkArgs {
     const float* pcm;  // [n_streams][pcm_stride][2]
     uint64_t frames;   // frames of this group's streams in this call
@@ -89,6 +92,15 @@ struct WaveChunkArgs {
     double* prefix_hi;          // [n_segs + 1][n_streams][24]
     double* prefix_lo;
     uint32_t* bad;
+    // running totals kept from call to call (lock-step calls, waveform.cpp WaveformBank::Totals); old_slot == nullptr: not in use
+    const uint32_t* old_slot;   // [n_old_segs + 1] slot of the total at each cut up to and including -1, or kWaveNoSlot
+    double* totals;             // [slots][2][n_streams x 24]: double-double totals of everything pushed up to a cut, since the trackers' clear
+    const uint32_t* keep;       // [n_keep][2]: (cut index, slot) of the totals this call leaves for later calls
+    uint32_t n_keep;
+    uint32_t base_slot;         // slot of the total at the call's start (cut -1), or kWaveNoSlot: zero
+    uint64_t* void_end;         // push count below which kept totals are void (a call the sequential kernel had to do)
+    uint64_t first_count;       // pushes covered by cut 0
+    uint64_t end_count;         // pushes covered by the call's last frame
     omx_wave_column* columns;   // [n_streams][col_stride][4]
     omx_wave_column* preview;
     uint64_t col_stride;
@@ -167,7 +179,7 @@ private:
     DeviceBuffer<uint8_t> r_mask_;
     RaggedStaging r_staging_;
     // chunk-parallel form
-    bool run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, hipStream_t stream);
+    bool run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, double end_phase, hipStream_t stream);
     bool run_chunked_ragged(WaveformArgs& wa, const uint32_t* frames, const uint8_t* reset_mask, uint64_t max_cols, double step, hipStream_t stream);
     bool launch_chunk_groups(const WaveformArgs& wa, std::vector<ChunkGroup>& groups, uint64_t pcm_stride, uint64_t col_stride, hipStream_t stream);
     // ragged mode: the host's mirror of the per-stream push counts and column phases (valid while few distinct values exist)
@@ -186,6 +198,18 @@ private:
     DeviceBuffer<float> chunk_state_, seg_mm_;
     DeviceBuffer<double> seg_sum_, prefix_;
     DeviceBuffer<uint32_t> bad_;
+    // Running totals kept between lock-step calls of the chunk-parallel form (waveform_chunked.hip, wave_keep_totals_kernel): the
+    // double-double total of every tracker input pushed so far, at the push counts later calls will start a window at.  Any call the
+    // chunk-parallel form does not do (sequential by shape or by choice, ragged) empties the table; a call the device hands to the
+    // sequential kernel behind the host's back (`bad`) voids it on the device (void_end_).
+    std::map<uint64_t, uint32_t> kept_;  // pushes covered -> slot
+    std::vector<uint32_t> kept_free_;
+    uint32_t kept_slots_ = 0;
+    bool kept_zero_void_ = true;
+    DeviceBuffer<double> kept_totals_;
+    DeviceBuffer<uint64_t> void_end_;
+    void kept_invalidate();
+    bool kept_reserve(size_t slots, hipStream_t stream);
 };
 
 }  // namespace omx

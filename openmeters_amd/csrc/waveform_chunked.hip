@@ -52,6 +52,20 @@ constexpr int ROW_FLOATS = 34;  // 16 frames x 2 + 2 pad floats: lanes read thei
 #define WAVE_XF 4
 #endif
 constexpr int XF = WAVE_XF;
+#ifndef WAVE_DENSE_UNROLL
+#define WAVE_DENSE_UNROLL 2
+#endif
+#ifndef WAVE_DENSE_NT
+#define WAVE_DENSE_NT 1
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ring_store(float* dst, float4 v) {
+#if WAVE_DENSE_NT
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(dst));
+#else
+    *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
 constexpr float kAbsurd = 1.0e18f;  // |sample| beyond this could overflow a squared band value: the sequential kernel's business
 
 // Biquad::process (dsp.rs:422-432), L and R at once, the reference's statement order (the build never contracts: -ffp-contract=off)
@@ -77,7 +91,7 @@ __device__ __forceinline__ float flush20(float v) { return fabsf(v) < 1.0e-20f ?
 
 // role 0: low band (LP_low); role 1: mid (HP_low -> LP_high); role 2: high (HP_high) — ThreeBand<Biquad, false> (dsp.rs:473-495)
 // workgroup = (chunk, 64 consecutive streams): every lane of a wavefront sees the same cuts
-template <bool PASS_B>
+template <bool PASS_B, bool DENSE>
 #ifndef WAVE_WPE
 #define WAVE_WPE 0
 #endif
@@ -90,6 +104,7 @@ template <bool PASS_B>
 #define WAVE_ATTR
 #endif
 __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs a) {
+    static_assert(PASS_B || !DENSE, "pass A writes no rings");
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][ROW_FLOATS], then (pass B) the ring exchange [2 series][XF][64][12]
     if (PASS_B && *a.bad != 0u) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -301,6 +316,34 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
                 if ((chunk_writes_c || chunk_writes_h) && ((f & (XF - 1)) == XF - 1) && (uint32_t)(f & ~(XF - 1)) < nf) {
                     __syncthreads();
                     const uint32_t g_half = f0 + step * STEP + (uint32_t)(f & ~(XF - 1));
+                    if constexpr (DENSE) {
+                        // identity stream map: the 64 streams' rows of one frame are 4 KiB in a row.  One store instruction = 16 whole rows
+                        // (lane = stream x quarter row, the pad quarter written as zeros): every 128-byte line leaves complete, in one
+                        // piece — as quarter rows 64 bytes apart (below) a line was assembled from six partial writes and its pad never
+                        // written, which HBM with ECC answers with read-modify-write
+#pragma unroll WAVE_DENSE_UNROLL
+                        for (int it = (int)role; it < 4 * XF; it += 3) {  // (frame of the piece, block of 16 streams), dealt round robin to the three wavefronts
+                            const int k = it >> 2;
+                            const uint32_t st = (uint32_t)(it & 3) * 16u + (lane >> 2), piece = lane & 3u;
+                            const uint32_t g = g_half + (uint32_t)k;
+                            if ((uint32_t)((f & ~(XF - 1)) + k) >= nf) break;
+                            if (s0 + st >= a.n_local) continue;
+                            const uint64_t col = (uint64_t)(s0 + st) * 16u + piece * 4u;
+                            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if (chunk_writes_c && g >= ring_c_from) {
+                                uint32_t slot = half_slot_c + (uint32_t)k;
+                                slot = slot >= a.color_len ? slot - a.color_len : slot;
+                                const float4 v4 = piece < 3u ? *reinterpret_cast<const float4*>(xbuf + (k * 64 + (int)st) * 12 + (int)piece * 4) : zero4;
+                                ring_store(a.color_ring + (uint64_t)slot * row + col, v4);
+                            }
+                            if (chunk_writes_h && g >= ring_h_from) {
+                                uint32_t slot = half_slot_h + (uint32_t)k;
+                                slot = slot >= a.slow_len ? slot - a.slow_len : slot;
+                                const float4 v4 = piece < 3u ? *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)st) * 12 + (int)piece * 4) : zero4;
+                                ring_store(a.hist_ring + (uint64_t)slot * row + col, v4);
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int k = 0; k < XF; ++k) {
                         const uint32_t g = g_half + (uint32_t)k;
@@ -443,10 +486,66 @@ __global__ __launch_bounds__(256) void wave_scan_states_kernel(WaveChunkArgs a, 
     else scan_wave<2, false>(a, T + 192, s, role, side, lane);
 }
 
+// ---- kept totals: a lock-step bank leaves the double-double running total at every cut a LATER call will start a window at
+// (the column phase is host arithmetic, so those cuts are known while the frames are still being summed), and a later call takes
+// an old segment's sum as the difference of two kept totals instead of reading the segment back from the ring.
+struct DD {
+    double hi, lo;
+};
+__device__ __forceinline__ DD dd_add(DD x, DD y) {
+    const double s = x.hi + y.hi;
+    const double bb = s - x.hi;
+    const double e = ((x.hi - (s - bb)) + (y.hi - bb)) + (x.lo + y.lo);
+    const double h = s + e;
+    return DD{h, e - (h - s)};
+}
+// an old segment is served from the kept totals when both of its cuts have one and no voided call lies behind cut 0
+__device__ __forceinline__ bool old_seg_kept(const WaveChunkArgs& a, uint32_t j) {
+    return a.old_slot && a.old_slot[j] != kWaveNoSlot && a.old_slot[j + 1u] != kWaveNoSlot && *a.void_end <= a.first_count;
+}
+
+__global__ __launch_bounds__(256) void wave_old_kept_kernel(WaveChunkArgs a) {
+    if (*a.bad != 0u) return;
+    const uint64_t total = (uint64_t)a.n_local * 24u;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (t >= total || (!a.history && t % 24u >= 12u) || !old_seg_kept(a, j)) return;
+    const double* t0 = a.totals + (uint64_t)a.old_slot[j] * 2u * total;
+    const double* t1 = a.totals + (uint64_t)a.old_slot[j + 1u] * 2u * total;
+    a.seg_sum[(uint64_t)j * total + t] = (t1[t] - t0[t]) + (t1[total + t] - t0[total + t]);
+}
+
+// thread = (kept cut, stream, value): total at the cut = total at the call's start + (running total at the cut - at cut -1).
+// A call the sequential kernel had to do (`bad`) leaves the start's total at its cuts — finite, and never used: void_end keeps later
+// calls off every difference that would reach behind this call's end.
+__global__ __launch_bounds__(256) void wave_keep_totals_kernel(WaveChunkArgs a) {
+    const uint64_t total = (uint64_t)a.n_local * 24u;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t k = blockIdx.y;
+    if (t >= total || (!a.history && t % 24u >= 12u)) return;
+    DD at{0.0, 0.0};
+    if (a.base_slot != kWaveNoSlot) {
+        const double* b = a.totals + (uint64_t)a.base_slot * 2u * total;
+        at = DD{b[t], b[total + t]};
+    }
+    if (*a.bad != 0u) {
+        if (k == 0u && t == 0u) atomicMax(reinterpret_cast<unsigned long long*>(a.void_end), (unsigned long long)a.end_count);
+    } else {
+        const uint64_t i = a.keep[2u * k], i0 = a.n_old_segs;
+        const DD run{a.prefix_hi[i * total + t], a.prefix_lo[i * total + t]};
+        const DD start{-a.prefix_hi[i0 * total + t], -a.prefix_lo[i0 * total + t]};
+        at = dd_add(at, dd_add(run, start));
+    }
+    double* out = a.totals + (uint64_t)a.keep[2u * k + 1u] * 2u * total;
+    out[t] = at.hi;
+    out[total + t] = at.lo;
+}
+
 // ---- old: sums of the rings' contents between the cuts that precede the call.  wavefront = (old segment, four streams x 16 ring lanes)
 __global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
     if (*a.bad != 0u) return;
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    if (old_seg_kept(a, j)) return;
     const uint32_t gid = blockIdx.y * 64u + lane;
     const uint32_t sl = gid >> 4, ln = gid & 15u;
     const bool live = sl < a.n_local && ln < 12u;
@@ -676,20 +775,28 @@ void launch_waveform_mirror_copy(const uint8_t* src, uint32_t n, uint64_t* pushe
 void launch_waveform_chunked_phase1(const WaveChunkArgs& a, const double* d_T, hipStream_t stream) {
     const uint32_t groups = (a.n_local + 63u) / 64u;
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((wave_chunk_kernel<false>), dim3(groups * a.n_chunks), dim3(192), lds, stream, a);
+    hipLaunchKernelGGL((wave_chunk_kernel<false, false>), dim3(groups * a.n_chunks), dim3(192), lds, stream, a);
     hipLaunchKernelGGL(wave_scan_states_kernel, dim3((a.n_local * 6u + 3u) / 4u), dim3(256), 0, stream, a, d_T);
 }
 void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream) {
     const uint32_t groups = (a.n_local + 63u) / 64u;
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
+    const uint32_t value_groups = (uint32_t)(((uint64_t)a.n_local * 24u + 255u) / 256u);
     if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_local * 16u + 63u) / 64u), dim3(64), 0, stream, a);
+    if (a.n_old_segs && a.old_slot) hipLaunchKernelGGL(wave_old_kept_kernel, dim3(value_groups, a.n_old_segs), dim3(256), 0, stream, a);
     const size_t lds_b = lds + (size_t)(a.history ? 2 : 1) * XF * 64 * 12 * sizeof(float);  // + the ring exchange
     static std::once_flag attr_once;  // (two host threads may race on the first launch; one device per process, omx.h)
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wave_chunk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wave_chunk_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wave_chunk_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     });
-    hipLaunchKernelGGL((wave_chunk_kernel<true>), dim3(groups * a.n_chunks), dim3(192), lds_b, stream, a);
-    hipLaunchKernelGGL(wave_prefix_kernel, dim3((uint32_t)(((uint64_t)a.n_local * 24u + 255u) / 256u)), dim3(256), 0, stream, a);
+    // identity stream map and the RMS-history ring (every frame of the call leaves a 64-byte row per stream): whole ring rows per store
+    // instruction.  Without the history ring only the last color_len frames leave rows and the plain form's register allocation is the
+    // better one (0.48 against 0.54 ms per 1024 x 16 384 call)
+    if (a.stream_map || !a.history) hipLaunchKernelGGL((wave_chunk_kernel<true, false>), dim3(groups * a.n_chunks), dim3(192), lds_b, stream, a);
+    else hipLaunchKernelGGL((wave_chunk_kernel<true, true>), dim3(groups * a.n_chunks), dim3(192), lds_b, stream, a);
+    hipLaunchKernelGGL(wave_prefix_kernel, dim3(value_groups), dim3(256), 0, stream, a);
+    if (a.n_keep) hipLaunchKernelGGL(wave_keep_totals_kernel, dim3(value_groups, a.n_keep), dim3(256), 0, stream, a);
     // the columns first, then — behind them in the stream — the pseudo-column: it overwrites the column state the first column reads
     WaveChunkArgs cols = a, tail = a;
     cols.n_evals = a.n_evals - 1u;

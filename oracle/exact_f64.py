@@ -414,9 +414,10 @@ class WaveformExact:
 
     _biquad = StereometerExact._biquad
 
-    def run(self, pcm_lr):
+    def run(self, pcm_lr, scroll_changes=()):
         """pcm_lr [frames][2] f32, the whole stream from reset.  Returns (column end frames, colour [cols][4][3], power [cols][4][2][3]):
-        the colour bands and the mean band powers (fast, slow window) of every column the stream emits."""
+        the colour bands and the mean band powers (fast, slow window) of every column the stream emits.  scroll_changes: (frame,
+        scroll_speed) pairs — update_config between two blocks changes the step and nothing else (:336-352)."""
         from scipy.signal import lfilter
         x = np.asarray(pcm_lr, np.float64)
         f = lambda c, v: lfilter(c[0], c[1], v, axis=0)
@@ -434,8 +435,11 @@ class WaveformExact:
         cc = np.concatenate([zero.astype(ld), np.cumsum(colour.astype(ld), axis=0)])
         cp = np.concatenate([zero.astype(ld), np.cumsum(power.astype(ld), axis=0)])
         ends, phase = [], 0.0
+        steps = np.full(x.shape[0], self.step)
+        for frame, scroll in scroll_changes:
+            steps[frame:] = min(max(float(np.float32(scroll)) / self.rate, 0.0), 1.0)
         for k in range(x.shape[0]):
-            phase += self.step
+            phase += steps[k]
             if phase >= 1.0:
                 ends.append(k)
                 phase -= 1.0

@@ -859,12 +859,12 @@ WAVE_MEMORY_S = 0.05
 class WaveExact:
     """the f64 recurrence's columns of one stream from reset (oracle/exact_f64.py::WaveformExact) and the scales of the three-way bars"""
 
-    def __init__(self, pcm_stream, rate, scroll=300.0):
+    def __init__(self, pcm_stream, rate, scroll=300.0, scroll_changes=()):
         sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
         import exact_f64 as ex
         model = ex.WaveformExact(rate, scroll)
         self.rate = float(rate)
-        self.ends, self.colour, self.power = model.run(pcm_stream)
+        self.ends, self.colour, self.power = model.run(pcm_stream, scroll_changes)
 
         def reach_max(top, length):   # top [cols][1][3]: running maximum over the columns whose end lies within `length` frames back
             out = np.empty_like(top)
@@ -1022,6 +1022,49 @@ def test_waveform_chunk_parallel_random_sequences(omx, oracle, seed):
         total += int(up.n_columns)
     assert total == len(exact[0])
     assert chunked >= sum(1 for n in sizes if n >= 1024 and n % 2 == 0) - 8 * (scroll >= 650.0)   # (thousands of columns per call: sequential)
+
+
+@pytest.mark.parametrize("rate,history,sizes", [
+    (48000.0, True, [2048] * 14 + [1024] * 5 + [256] + [2048] * 11 + [4096, 4096, 16384, 16384, 2048]),
+    (48000.0, False, [2048] * 6 + [1000] + [4096] * 4 + [1024] * 4),
+    (44100.0, True, [16384] * 2 + [4096] * 6 + [16384] + [6000] * 4),
+])
+def test_waveform_chunk_parallel_form_keeps_running_totals_between_calls(omx, oracle, rate, history, sizes):
+    """lock-step calls of the chunk-parallel form leave the double-double running total at every push count a later call starts a
+    window at (wave_keep_totals_kernel) and a later call takes its old segments from those instead of the rings.  Runs of equal calls
+    (every start was foreseen), changes of the call length (the pseudo-column's starts were not: those segments come from the
+    rings), a sequential call in between (the table empties and refills), a scroll-speed change (columns end where nobody foresaw),
+    windows that reach back over 17 calls, a quiet passage after a loud one."""
+    from openmeters_amd.capi import WaveformConfig, WaveformProcessor
+    S, total_frames = 2, sum(sizes)
+    change_at = sum(sizes[:len(sizes) // 2])
+    pcm = np.stack([cfg4_pcm(70 + s, total_frames) for s in range(S)])
+    pcm[1, total_frames // 3:total_frames // 3 + 30000] *= np.float32(1e-5)
+    cfg = WaveformConfig(sample_rate=rate, scroll_speed=300.0, max_columns=1024, analyze_bands=True, track_history=history)
+    exact = [WaveExact(pcm[s], rate, 300.0, [(change_at, 420.0)]) for s in range(S)]
+    bank = banks.WaveformBank(omx, cfg, S)
+    bank.set_option(capi.OPT_KERNEL_FORM, 2)
+    refs = [WaveformProcessor(oracle, cfg) for _ in range(S)]
+    at, total = 0, 0
+    for n in sizes:
+        if at == change_at:
+            cfg.scroll_speed = 420.0
+            bank.update_config(cfg)
+            for r in refs:
+                r.update_config(cfg)
+        chunk = pcm[:, at:at + n]
+        at += n
+        up = bank.process_host(chunk, 2, rate)
+        assert bank.last_form() == (2 if n >= 1024 and n % 2 == 0 else 1)
+        for s, r in enumerate(refs):
+            w = r.process_block(AudioBlock(chunk[s].reshape(-1), 2, rate))
+            assert up.n_columns == len(w.columns)
+            got, _ = bank.fetch(s, int(up.n_columns))
+            assert np.array_equal(got[:, :, :2], w.columns[:, :, :2]), (n, s)
+            if len(got):
+                check_wave_three_way("waveform (chunk-parallel, kept totals)", got, w.columns, exact[s], slice(total, total + len(got)), history, (at, n, s))
+        total += int(up.n_columns)
+    assert total == len(exact[0])
 
 
 @pytest.mark.parametrize("history", [False, True])
