@@ -598,6 +598,7 @@ bool WaveformBank::launch_chunk_groups(const WaveformArgs& wa, std::vector<Chunk
             ca.keep = reinterpret_cast<const uint32_t*>(put(keep.data(), keep.size() * sizeof(uint32_t)));
             ca.n_keep = (uint32_t)(keep.size() / 2);
             ca.totals = kept_totals_.ptr;
+            ca.all_kept = std::find(g.old_slot.begin(), g.old_slot.end(), kWaveNoSlot) == g.old_slot.end() ? 1u : 0u;
             const auto base = kept_.find(g.pushes0);
             if (base != kept_.end()) ca.base_slot = base->second;
             ca.void_end = void_end_.ptr;

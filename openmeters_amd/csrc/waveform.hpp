@@ -98,6 +98,7 @@ struct WaveChunkArgs {
     const uint32_t* keep;       // [n_keep][2]: (cut index, slot) of the totals this call leaves for later calls
     uint32_t n_keep;
     uint32_t base_slot;         // slot of the total at the call's start (cut -1), or kWaveNoSlot: zero
+    uint32_t all_kept;          // every entry of old_slot is a slot
     uint64_t* void_end;         // push count below which kept totals are void (a call the sequential kernel had to do)
     uint64_t first_count;       // pushes covered by cut 0
     uint64_t end_count;         // pushes covered by the call's last frame
@@ -198,7 +199,7 @@ private:
     DeviceBuffer<float> chunk_state_, seg_mm_;
     DeviceBuffer<double> seg_sum_, prefix_;
     DeviceBuffer<uint32_t> bad_;
-    // Running totals kept between lock-step calls of the chunk-parallel form (waveform_chunked.hip, wave_keep_totals_kernel): the
+    // Running totals kept between lock-step calls of the chunk-parallel form (waveform_chunked.hip: wave_keep_totals_kernel writes them, wave_columns_kernel reads them): the
     // double-double total of every tracker input pushed so far, at the push counts later calls will start a window at.  Any call the
     // chunk-parallel form does not do (sequential by shape or by choice, ragged) empties the table; a call the device hands to the
     // sequential kernel behind the host's back (`bad`) voids it on the device (void_end_).

@@ -504,6 +504,11 @@ __device__ __forceinline__ bool old_seg_kept(const WaveChunkArgs& a, uint32_t j)
     return a.old_slot && a.old_slot[j] != kWaveNoSlot && a.old_slot[j + 1u] != kWaveNoSlot && *a.void_end <= a.first_count;
 }
 
+// every old cut has a kept total (the host's flag) and none of them is void: nothing old is summed or scanned at all — the columns
+// take a window's start from the kept totals directly (wave_columns_kernel), the scan starts at cut -1
+__device__ __forceinline__ bool old_all_kept(const WaveChunkArgs& a) { return a.all_kept != 0u && *a.void_end <= a.first_count; }
+
+// some old cuts have kept totals, some not: the segments between two that have
 __global__ __launch_bounds__(256) void wave_old_kept_kernel(WaveChunkArgs a) {
     if (*a.bad != 0u) return;
     const uint64_t total = (uint64_t)a.n_local * 24u;
@@ -542,11 +547,11 @@ __global__ __launch_bounds__(256) void wave_keep_totals_kernel(WaveChunkArgs a) 
 }
 
 // ---- old: sums of the rings' contents between the cuts that precede the call.  wavefront = (old segment, four streams x 16 ring lanes)
-__global__ __launch_bounds__(64) void wave_old_sums_kernel(WaveChunkArgs a) {
+__global__ __launch_bounds__(256) void wave_old_sums_kernel(WaveChunkArgs a) {
     if (*a.bad != 0u) return;
-    const uint32_t j = blockIdx.x, lane = threadIdx.x;
-    if (old_seg_kept(a, j)) return;
-    const uint32_t gid = blockIdx.y * 64u + lane;
+    const uint32_t j = blockIdx.x;
+    if (old_all_kept(a) || old_seg_kept(a, j)) return;
+    const uint32_t gid = blockIdx.y * 256u + threadIdx.x;
     const uint32_t sl = gid >> 4, ln = gid & 15u;
     const bool live = sl < a.n_local && ln < 12u;
     const uint32_t s = live ? (a.stream_map ? a.stream_map[sl] : sl) : 0u;
@@ -591,9 +596,10 @@ __global__ __launch_bounds__(256) void wave_prefix_kernel(WaveChunkArgs a) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x, total = (uint64_t)a.n_local * 24u;
     if (t >= total) return;
     if (!a.history && t % 24u >= 12u) return;
+    const uint32_t first = old_all_kept(a) ? a.n_old_segs : 0u;  // (all kept: the running totals start at cut -1)
     double hi = 0.0, lo = 0.0;
-    a.prefix_hi[t] = 0.0;
-    a.prefix_lo[t] = 0.0;
+    a.prefix_hi[(uint64_t)first * total + t] = 0.0;
+    a.prefix_lo[(uint64_t)first * total + t] = 0.0;
     const double* src = a.seg_sum + t;
     // One thread per value, 384 wavefronts in all: less than one per SIMD, so nothing hides a load's latency but the thread itself —
     // two batches of 16 segment sums are kept in flight ahead of the batch being added (as one batch per round trip the kernel spent
@@ -619,9 +625,9 @@ __global__ __launch_bounds__(256) void wave_prefix_kernel(WaveChunkArgs a) {
         }
     };
     double x0[16], x1[16], x2[16];
-    fetch(x0, 0u);
-    fetch(x1, 16u);
-    for (uint32_t j0 = 0; j0 < a.n_segs; j0 += 48u) {
+    fetch(x0, first);
+    fetch(x1, first + 16u);
+    for (uint32_t j0 = first; j0 < a.n_segs; j0 += 48u) {
         fetch(x2, j0 + 32u);
         add(x0, j0);
         if (j0 + 16u >= a.n_segs) break;
@@ -646,10 +652,21 @@ __global__ __launch_bounds__(256) void wave_columns_kernel(WaveChunkArgs a) {
     const WaveEval ev = a.evals[e];
     const bool final_eval = ev.out == 0xFFFFFFFFu;
     const uint64_t total = (uint64_t)a.n_local * 24u;
+    const bool all_kept = old_all_kept(a);
     auto window_sum = [&](uint32_t series, uint32_t band, uint32_t from_cut) -> double {  // running total at idx_end minus at from_cut
         const uint64_t v = (uint64_t)sl * 24u + series * 12u + ch * 3u + band;
         const double h1 = a.prefix_hi[(uint64_t)ev.idx_end * total + v], l1 = a.prefix_lo[(uint64_t)ev.idx_end * total + v];
-        const double h0 = a.prefix_hi[(uint64_t)from_cut * total + v], l0 = a.prefix_lo[(uint64_t)from_cut * total + v];
+        double h0, l0;
+        if (all_kept && from_cut < a.n_old_segs) {  // a start before the call: (kept total there) - (kept total at the call's start), <= 0
+            const double* t0 = a.totals + (uint64_t)a.old_slot[from_cut] * 2u * total;
+            const double* tb = a.totals + (uint64_t)a.old_slot[a.n_old_segs] * 2u * total;
+            const DD d = dd_add(DD{t0[v], t0[total + v]}, DD{-tb[v], -tb[total + v]});
+            h0 = d.hi;
+            l0 = d.lo;
+        } else {
+            h0 = a.prefix_hi[(uint64_t)from_cut * total + v];
+            l0 = a.prefix_lo[(uint64_t)from_cut * total + v];
+        }
         return (h1 - h0) + (l1 - l0);
     };
     // ---- min / max (:213-250): the column's samples, extended by the last sample of the column before it
@@ -782,8 +799,8 @@ void launch_waveform_chunked_phase2(const WaveChunkArgs& a, hipStream_t stream) 
     const uint32_t groups = (a.n_local + 63u) / 64u;
     const size_t lds = (size_t)2 * 64 * ROW_FLOATS * sizeof(float);
     const uint32_t value_groups = (uint32_t)(((uint64_t)a.n_local * 24u + 255u) / 256u);
-    if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_local * 16u + 63u) / 64u), dim3(64), 0, stream, a);
-    if (a.n_old_segs && a.old_slot) hipLaunchKernelGGL(wave_old_kept_kernel, dim3(value_groups, a.n_old_segs), dim3(256), 0, stream, a);
+    if (a.n_old_segs) hipLaunchKernelGGL(wave_old_sums_kernel, dim3(a.n_old_segs, (a.n_local * 16u + 255u) / 256u), dim3(256), 0, stream, a);
+    if (a.n_old_segs && a.old_slot && !a.all_kept) hipLaunchKernelGGL(wave_old_kept_kernel, dim3(value_groups, a.n_old_segs), dim3(256), 0, stream, a);
     const size_t lds_b = lds + (size_t)(a.history ? 2 : 1) * XF * 64 * 12 * sizeof(float);  // + the ring exchange
     static std::once_flag attr_once;  // (two host threads may race on the first launch; one device per process, omx.h)
     std::call_once(attr_once, [] {
