@@ -566,76 +566,6 @@ __global__ __launch_bounds__(64) void loud_chunk_peak_kernel(LoudChunkArgs a) {
     cf[3] = z3;
 }
 
-// ---- pass A without the LDS transposition (round 6; lock-step calls, 1 / 2 / 4 / 8 channels, the true peak in pass B): the zero-state end
-// state z = sum_k W[k] x[k] is a plain weighted sum, so nothing has to bring a slot's samples to ONE lane.  A wavefront takes one
-// (stream, block) — block_frames x C floats, contiguous in the interleaved PCM — as 16-byte loads in the PCM's own order, every load of the
-// block in flight at once; a lane accumulates the partial sums of the (at most four) channels its elements belong to, and a butterfly over
-// the lanes that share those channels finishes them.  (The tile kernel stages 16 frames x 64 slots through LDS behind a barrier per step, one
-// or two tiles in flight per wavefront: 150 ... 160 us for cfg3's 537 MB where the bytes alone take 100.)
-template <int C>
-__global__ __launch_bounds__(64) void loud_block_state_kernel(LoudChunkArgs a) {
-    constexpr int CH = C >= 4 ? 4 : C;       // channels a lane's four elements cover
-    constexpr int FR = 4 / CH;               // frames they cover
-    const uint32_t lane = threadIdx.x, s = blockIdx.x, c = blockIdx.y;
-    const uint32_t L = a.block_frames;
-    const uint32_t loads = L * (uint32_t)C / 256u;  // 16-byte loads per lane (block_frames is a multiple of 64: at least 1 for C = 4, 8;
-                                                    // C = 1, 2 need block_frames multiples of 256 / 128: host-checked)
-    const float4* src = reinterpret_cast<const float4*>(a.pcm + ((uint64_t)s * a.frames_total + (uint64_t)c * L) * C);
-    double z[CH][4];
-#pragma unroll
-    for (int q = 0; q < CH; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[q][i] = 0.0;
-    uint32_t bad = 0;
-    for (uint32_t n0 = 0; n0 < loads; n0 += 8u) {  // eight loads in flight
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (n0 + (uint32_t)u < loads) v[u] = src[(n0 + (uint32_t)u) * 64u + lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (n0 + (uint32_t)u >= loads) break;
-            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            const uint32_t elem = ((n0 + (uint32_t)u) * 64u + lane) * 4u;  // first element of the load within the block
-            const uint32_t frame = elem / (uint32_t)C;
-#pragma unroll
-            for (int fr = 0; fr < FR; ++fr) {
-                const double* w = a.zs_weights + (uint64_t)(frame + (uint32_t)fr) * 4u;
-                const double w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-#pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const float x = e[fr * CH + q];
-                    bad |= isfinite(x) ? 0u : 1u;
-                    const double xd = (double)x;
-                    z[q][0] = fma(w0, xd, z[q][0]);
-                    z[q][1] = fma(w1, xd, z[q][1]);
-                    z[q][2] = fma(w2, xd, z[q][2]);
-                    z[q][3] = fma(w3, xd, z[q][3]);
-                }
-            }
-        }
-    }
-    // lanes that hold the same channels: all of them for C <= 4, every second one for C = 8
-    constexpr int FIRST = C == 8 ? 2 : 1;
-#pragma unroll
-    for (int d = FIRST; d < 64; d <<= 1)
-#pragma unroll
-        for (int q = 0; q < CH; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                z[q][i] += __hiloint2double(__shfl_xor(__double2hiint(z[q][i]), d), __shfl_xor(__double2loint(z[q][i]), d));
-    if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
-    if (lane < (uint32_t)(C == 8 ? 2 : 1)) {
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const uint32_t chan = (s << a.slot_shift) + lane * 4u + (uint32_t)q;
-            double* cf = a.chunk_filter + ((uint64_t)chan * a.n_blocks + c) * 4u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cf[i] = z[q][i];
-        }
-    }
-}
-
 // ---- prefix of the sub-block sums: Q[g] = sum of every squared sample up to the end of sub-block g since the last reset.
 // wavefront = slot, lane = sub-block (64 per sweep)
 __global__ __launch_bounds__(256) void loud_scan_q_kernel(LoudChunkArgs a) {
@@ -875,18 +805,6 @@ void launch_loudness_chunked(const LoudChunkArgs& a, const double* d_T, hipStrea
         constexpr int DL = decltype(dl)::value;
         with_shape([&](auto tiled_c, auto ragged_c) {
             constexpr bool TI = decltype(tiled_c)::value, RG = decltype(ragged_c)::value;
-            if constexpr (kPeakInB && TI && !RG) {  // lock-step, whole streams per slot group: the weighted sums without the LDS tile
-                const uint32_t per_load = 256u / a.channels;  // frames one wavefront-wide 16-byte load covers
-                if (a.block_frames % per_load == 0u && (reinterpret_cast<uintptr_t>(a.pcm) & 15u) == 0u && (a.frames_total * a.channels) % 4u == 0u) {
-                    const dim3 g2(a.n_streams, a.n_blocks);
-                    switch (a.channels) {
-                        case 1: hipLaunchKernelGGL(loud_block_state_kernel<1>, g2, dim3(64), 0, stream, a); return;
-                        case 2: hipLaunchKernelGGL(loud_block_state_kernel<2>, g2, dim3(64), 0, stream, a); return;
-                        case 4: hipLaunchKernelGGL(loud_block_state_kernel<4>, g2, dim3(64), 0, stream, a); return;
-                        default: hipLaunchKernelGGL(loud_block_state_kernel<8>, g2, dim3(64), 0, stream, a); return;
-                    }
-                }
-            }
             if constexpr (kPeakInB) hipLaunchKernelGGL((loud_chunk_peak_kernel<0, TI, RG, false>), grid, dim3(64), 0, stream, a);
             else hipLaunchKernelGGL((loud_chunk_peak_kernel<DL, TI, RG, true>), grid, dim3(64), 0, stream, a);
         });
