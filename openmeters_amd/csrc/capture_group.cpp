@@ -1,8 +1,41 @@
 // CaptureGroup — see capture_group.hpp / include/omx.h.  Reference: VisualManager::{ingest_samples, reset_audio}
 // (src/visuals/registry.rs:360-365, :396-418); the block partition of the block-based visuals is the batcher's (src/meter.rs:16-25).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "capture_group.hpp"
 
 namespace omx {
+
+#ifdef OMX_TUNING
+// host time per section of ingest_ragged (tuning build, OMX_GROUP_HOST_TIMES=1): printed when the process ends
+struct HostSections {
+    static constexpr int kN = 12;
+    double us[kN] = {};
+    uint64_t calls = 0;
+    bool on = std::getenv("OMX_GROUP_HOST_TIMES") != nullptr;
+    ~HostSections() {
+        if (!on || !calls) return;
+        const char* names[kN] = {"prologue", "spectrum finish", "loudness", "waveform", "stereometer", "oscilloscope", "join+stats",
+                                 "spectrogram plan", "spectrum plan", "shared ingest", "spectrogram finish", ""};
+        for (int k = 0; k < 11; ++k) std::fprintf(stderr, "ingest_ragged host: %-22s %7.1f us per call\n", names[k], us[k] / (double)calls);
+    }
+};
+static HostSections g_host_sections;
+struct HostLap {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int k) {
+        const auto n = std::chrono::steady_clock::now();
+        g_host_sections.us[k] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+};
+#define OMX_LAP(k) host_lap.lap(k)
+#else
+struct HostLap {};
+#define OMX_LAP(k) (void)0
+#endif
 
 void capture_group_config_default(omx_capture_group_config* c) {
     std::memset(c, 0, sizeof(*c));
@@ -272,6 +305,10 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
         const bool regular = (double)frames * 48000.0 < 512.0 * (double)sr;
         const int lay_regular[4] = {0, 1, 1, 2}, lay_long[4] = {0, 3, 1, -1};  // loudness, waveform, stereometer, oscilloscope
         const int* lay = regular ? lay_regular : lay_long;
+        int lay_env[4];
+        if (const char* e = tuning_env(regular ? "OMX_GROUP_LAYOUT" : "OMX_GROUP_LAYOUT_LONG")) {  // tuning hook: "ld,wf,st,sc" (side stream, -1 = the caller's)
+            if (std::sscanf(e, "%d,%d,%d,%d", &lay_env[0], &lay_env[1], &lay_env[2], &lay_env[3]) == 4) lay = lay_env;
+        }
         auto on = [&](int k) -> hipStream_t {
             if (k < 0) return stream;
             if (!used[k]) {
@@ -367,6 +404,8 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
 int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, const uint32_t* frames, const uint8_t* reset_mask, uint32_t channels_in,
                                 float sample_rate, const uint8_t positions[OMX_MAX_CHANNELS], hipStream_t stream,
                                 omx_capture_group_ragged_update* out) {
+    HostLap host_lap;
+    (void)host_lap;
     const uint32_t channels = std::min<uint32_t>(std::max<uint32_t>(channels_in, 1), OMX_MAX_CHANNELS);
     const uint32_t S = cfg_.n_streams;
     omx_capture_group_ragged_update up;
@@ -439,11 +478,13 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
     };
     bool used[kSideStreams] = {false, false, false, false};
     forked(stream, side_, fork_, join_, used, [&] {
+        OMX_LAP(0);
         // ---- the caller's stream: the banks that keep pending audio.  Both plan their per-capture pushes on the device (skip / count /
         //      head per stream); ONE projection launch then feeds the rings of both (registry.rs:407-417: one AudioBlock, every visual)
         if (spectrogram && spectrum && shared_ingest_) {
             IngestArgs parts[2];
             const int rc_sg = spectrogram->ragged_plan(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, parts[0]);
+            OMX_LAP(7);
             if (rc_sg < 0) note(rc_sg, 0);
             if (rc_sg >= 0) {
                 // The spectrogram's plan has advanced its per-capture positions: from here on its samples MUST be written and its columns
@@ -458,6 +499,7 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                     sp_threw = true;
                     sp_error = e;
                 }
+                OMX_LAP(8);
                 if (rc_sp < 0) note(rc_sp, 0);
                 const int n_parts = (!sp_threw && rc_sp == OMX_PRODUCED) ? 2 : 1;  // (a Spectrum bank without an active trace takes no samples)
                 if (launch_ingest_ragged_parts(parts, n_parts, S, stream)) {
@@ -471,7 +513,9 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                     }
                 }
                 OMX_HIP(hipGetLastError());
+                OMX_LAP(9);
                 note(spectrogram->ragged_finish(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
+                OMX_LAP(10);
                 if (n_parts == 2) note(spectrum->ragged_finish(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
                 if (sp_threw) throw sp_error;  // (the message set_last_error recorded stands)
             }
@@ -487,10 +531,15 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                 up.ingest_launches += 1;
             }
         }
+        OMX_LAP(1);
         // stream layout by call length, as in the lock-step call (see there)
         const bool regular = (double)frames_capacity * 48000.0 < 512.0 * (double)sr;
         const int lay_regular[4] = {0, 1, 1, 2}, lay_long[4] = {0, 3, 1, -1};  // loudness, waveform, stereometer, oscilloscope
         const int* lay = regular ? lay_regular : lay_long;
+        int lay_env[4];
+        if (const char* e = tuning_env(regular ? "OMX_GROUP_LAYOUT" : "OMX_GROUP_LAYOUT_LONG")) {  // tuning hook: "ld,wf,st,sc" (side stream, -1 = the caller's)
+            if (std::sscanf(e, "%d,%d,%d,%d", &lay_env[0], &lay_env[1], &lay_env[2], &lay_env[3]) == 4) lay = lay_env;
+        }
         auto on = [&](int k) -> hipStream_t {
             if (k < 0) return stream;
             if (!used[k]) {
@@ -511,12 +560,14 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                                              holds_.ptr, clocks_.ptr, rows_.ptr, s_ld);
             OMX_HIP(hipGetLastError());
         }
+        OMX_LAP(2);
         if (waveform) {
             const hipStream_t s_wf = on(lay[1]);
             note(waveform->process_ragged(d_pcm, frames_capacity, frames, m_wf, channels, sample_rate, positions, s_wf, &up.waveform),
                  OMX_VISUAL_WAVEFORM);
             OMX_HIP(hipGetLastError());
         }
+        OMX_LAP(3);
         if (stereometer) {
             const hipStream_t s_st = on(lay[2]);
             note(chunks ? stereometer->process_chunks(d_pcm, frames_capacity, frames, m_st, channels, sample_rate, positions, s_st,
@@ -529,6 +580,7 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                                                 s_st);
             OMX_HIP(hipGetLastError());
         }
+        OMX_LAP(4);
         if (oscilloscope) {
             const hipStream_t s_sc = on(lay[3]);
             note(chunks ? oscilloscope->process_chunks(d_pcm, frames_capacity, frames, m_os, channels, sample_rate, positions, s_sc,
@@ -538,6 +590,7 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                  OMX_VISUAL_OSCILLOSCOPE);
             OMX_HIP(hipGetLastError());
         }
+        OMX_LAP(5);
         return (int)OMX_NONE;
     });
     // ---- joined; the spectrogram's summary columns follow its kernels on the caller's stream
@@ -548,6 +601,10 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         up.d_stats_rows = rows_.ptr;
     }
     if (out) *out = up;
+    OMX_LAP(6);
+#ifdef OMX_TUNING
+    ++g_host_sections.calls;
+#endif
     if (worst < 0) return worst;
     return up.produced ? OMX_PRODUCED : OMX_NONE;
 }

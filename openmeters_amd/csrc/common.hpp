@@ -185,10 +185,14 @@ inline void copy_out(void* dst, const void* src, size_t bytes, bool pinned, hipS
 // The per-call host arrays of a ragged bank call (per-stream counts, reset flags) on their way to the device: two pinned staging sets
 // used alternately, each guarded by an event recorded behind its copies — a call waits only if the copies of the call BEFORE the
 // previous one are still in flight (practically never), instead of synchronising the stream on every call.
+// a device array somebody else owns (RaggedStaging's blob)
+template <class T>
+struct DeviceView {
+    T* ptr = nullptr;
+};
 struct RaggedStaging {
-    PinnedBuffer<uint32_t> counts[2];
-    PinnedBuffer<uint32_t> lengths[2];
-    PinnedBuffer<uint8_t> mask[2];
+    PinnedBuffer<uint8_t> host[2];
+    DeviceBuffer<uint8_t> dev;  // [counts: n u32][mask: n u8, padded to 4][lengths: n u32]
     hipEvent_t done[2] = {nullptr, nullptr};
     int next = 0;
     RaggedStaging() = default;
@@ -198,28 +202,28 @@ struct RaggedStaging {
         for (auto& e : done)
             if (e) (void)hipEventDestroy(e);
     }
-    // counts_in[n] -> d_counts, mask_in[n] (nullptr = all zero) -> d_mask, asynchronously on `stream`; the caller's arrays are free
-    // again when this returns
-    // lengths_in (chunk calls: one block of lengths_in[s] frames per stream) -> d_lengths the same way when both are given
-    void upload(const uint32_t* counts_in, const uint8_t* mask_in, uint32_t n, uint32_t* d_counts, uint8_t* d_mask, hipStream_t stream,
-                const uint32_t* lengths_in = nullptr, uint32_t* d_lengths = nullptr) {
+    // counts_in[n], mask_in[n] (nullptr = all zero) and — chunk calls: one block of lengths_in[s] frames per stream — lengths_in[n] go
+    // to the device as ONE copy on `stream` (round 6: three copies and their stream latency per bank and call before); the views
+    // point into the staging's own device blob afterwards.  The caller's arrays are free again when this returns.
+    void upload(const uint32_t* counts_in, const uint8_t* mask_in, uint32_t n, DeviceView<uint32_t>& d_counts, DeviceView<uint8_t>& d_mask,
+                hipStream_t stream, const uint32_t* lengths_in = nullptr, DeviceView<uint32_t>* d_lengths = nullptr) {
         const int b = next;
         next ^= 1;
         if (done[b]) OMX_HIP(hipEventSynchronize(done[b]));
         else OMX_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
-        counts[b].reserve(n);
-        mask[b].reserve(n);
-        std::memcpy(counts[b].ptr, counts_in, (size_t)n * sizeof(uint32_t));
-        if (mask_in) std::memcpy(mask[b].ptr, mask_in, n);
-        else std::memset(mask[b].ptr, 0, n);
-        OMX_HIP(hipMemcpyAsync(d_counts, counts[b].ptr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        OMX_HIP(hipMemcpyAsync(d_mask, mask[b].ptr, n, hipMemcpyHostToDevice, stream));
-        if (lengths_in && d_lengths) {
-            lengths[b].reserve(n);
-            std::memcpy(lengths[b].ptr, lengths_in, (size_t)n * sizeof(uint32_t));
-            OMX_HIP(hipMemcpyAsync(d_lengths, lengths[b].ptr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        }
+        const size_t mask_at = (size_t)n * 4, lengths_at = mask_at + ((size_t)n + 3) / 4 * 4, all = lengths_at + (size_t)n * 4;
+        const bool with_lengths = lengths_in && d_lengths;
+        host[b].reserve(all);
+        dev.reserve(all);
+        std::memcpy(host[b].ptr, counts_in, (size_t)n * 4);
+        if (mask_in) std::memcpy(host[b].ptr + mask_at, mask_in, n);
+        else std::memset(host[b].ptr + mask_at, 0, n);
+        if (with_lengths) std::memcpy(host[b].ptr + lengths_at, lengths_in, (size_t)n * 4);
+        OMX_HIP(hipMemcpyAsync(dev.ptr, host[b].ptr, with_lengths ? all : lengths_at, hipMemcpyHostToDevice, stream));
         OMX_HIP(hipEventRecord(done[b], stream));
+        d_counts.ptr = reinterpret_cast<uint32_t*>(dev.ptr);
+        d_mask.ptr = dev.ptr + mask_at;
+        if (d_lengths) d_lengths->ptr = with_lengths ? reinterpret_cast<uint32_t*>(dev.ptr + lengths_at) : nullptr;
     }
 };
 

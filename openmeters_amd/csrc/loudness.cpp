@@ -246,10 +246,7 @@ int LoudnessBank::ragged_impl(const float* d_pcm, uint64_t row_frames, uint64_t 
     }
     if (!any && !any_reset) return OMX_NONE;
     // per-stream counts / flags: pinned staging -> device (the caller's arrays are borrowed for the call only)
-    r_blocks_.reserve(n_streams_);
-    r_mask_.reserve(n_streams_);
-    if (frames_v) r_frames_.reserve(n_streams_);
-    r_staging_.upload(n_blocks, reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, frames_v, frames_v ? r_frames_.ptr : nullptr);
+    r_staging_.upload(n_blocks, reset_mask, n_streams_, r_blocks_, r_mask_, stream, frames_v, &r_frames_);
     const uint64_t slots = std::max<uint64_t>(max_blocks, 1);
     snapshots_.reserve((size_t)(n_streams_ * slots), false);
     LoudnessArgs la{};

@@ -166,8 +166,8 @@ private:
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_seen_;
     std::vector<uint64_t> h_seen_;  // the host's mirror of r_seen_ (the call arguments determine it)
-    DeviceBuffer<uint32_t> r_blocks_, r_frames_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceView<uint32_t> r_blocks_, r_frames_;  // (views into r_staging_)
+    DeviceView<uint8_t> r_mask_;
     std::vector<uint32_t> h_blocks_;
     RaggedStaging r_staging_;
 public:

@@ -311,11 +311,8 @@ int OscilloscopeBank::process_impl(const float* pcm, bool pcm_on_device, uint64_
             r_epoch_.upload(std::vector<uint64_t>(n_streams_, epoch_), stream);
             ragged_ = true;
         }
-        r_blocks_.reserve(n_streams_);
-        r_mask_.reserve(n_streams_);
-        if (chunk_call) r_frames_.reserve(n_streams_);
-        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, ragged->frames_v,
-                          chunk_call ? r_frames_.ptr : nullptr);
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_, r_mask_, stream, chunk_call ? ragged->frames_v : nullptr,
+                          &r_frames_);
         sa.frames_v = chunk_call ? r_frames_.ptr : nullptr;
         sa.pos_v = r_pos_.ptr;
         sa.blocks_v = r_blocks_.ptr;

@@ -183,9 +183,9 @@ private:
     // ragged mode: per-stream ring positions and epochs on the device
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_pos_, r_epoch_;
-    DeviceBuffer<uint32_t> r_blocks_, r_frames_;
+    DeviceView<uint32_t> r_blocks_, r_frames_;  // (views into r_staging_)
     std::vector<uint32_t> h_blocks_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceView<uint8_t> r_mask_;
     RaggedStaging r_staging_;
 };
 

@@ -528,8 +528,7 @@ void SpectrogramBank::enter_ragged(hipStream_t stream) {
     r_skip_.upload(k, stream);
     r_reset_flag_.upload(r, stream);
     for (DeviceBuffer<uint64_t>* b : {&r_ing_head_, &r_col_tail_}) b->reserve(n_streams_);
-    for (DeviceBuffer<uint32_t>* b : {&r_frames_, &r_ing_skip_, &r_ing_count_, &r_ncols_, &r_reset_out_}) b->reserve(n_streams_);
-    r_mask_.reserve(n_streams_);
+    for (DeviceBuffer<uint32_t>* b : {&r_ing_skip_, &r_ing_count_, &r_ncols_, &r_reset_out_}) b->reserve(n_streams_);
     ragged_ = true;
 }
 
@@ -595,7 +594,7 @@ int SpectrogramBank::ragged_plan(const float* d_pcm, uint64_t frames_capacity, c
         ring_cap_ = cap;
     }
     // the call's per-stream inputs (small: through double-buffered pinned memory, no stream synchronisation)
-    r_staging_.upload(frames, reset_mask, n_streams_, r_frames_.ptr, r_mask_.ptr, stream);
+    r_staging_.upload(frames, reset_mask, n_streams_, r_frames_, r_mask_, stream);
     SpectrogramPlanArgs pa{};
     pa.n_streams = n_streams_;
     pa.read_len = read_len;

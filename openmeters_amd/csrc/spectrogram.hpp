@@ -74,8 +74,9 @@ private:
     bool ragged_ = false;
     uint64_t ragged_pending_bound_ = 0;  // ragged mode: the most pending samples a stream can hold beyond read_len - 1 (after update_config)
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_col_tail_;
-    DeviceBuffer<uint32_t> r_reset_flag_, r_frames_, r_ing_skip_, r_ing_count_, r_ncols_, r_reset_out_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceBuffer<uint32_t> r_reset_flag_, r_ing_skip_, r_ing_count_, r_ncols_, r_reset_out_;
+    DeviceView<uint32_t> r_frames_;  // (views into r_staging_)
+    DeviceView<uint8_t> r_mask_;
     RaggedStaging r_staging_;
     uint64_t last_cols_ = 0, last_stride_ = 0;
     uint32_t last_kind_ = OMX_COLUMN_REASSIGNED;

@@ -470,8 +470,7 @@ int SpectrumBank::launch_hops(uint64_t tail0, const uint64_t* tails, const uint3
 void SpectrumBank::enter_ragged(hipStream_t stream) {
     const size_t S = n_streams_;
     for (DeviceBuffer<uint64_t>* b : {&r_head_, &r_tail_, &r_skip_, &r_ing_head_, &r_hop_tail_}) b->reserve(S);
-    for (DeviceBuffer<uint32_t>* b : {&r_frames_, &r_ing_skip_, &r_ing_count_, &r_nhops_}) b->reserve(S);
-    r_mask_.reserve(S);
+    for (DeviceBuffer<uint32_t>* b : {&r_ing_skip_, &r_ing_count_, &r_nhops_}) b->reserve(S);
     std::vector<uint64_t> h(S, head_), t(S, tail_), k(S, pending_skip_);  // the common lock-step state becomes every stream's state
     OMX_HIP(hipMemcpyAsync(r_head_.ptr, h.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     OMX_HIP(hipMemcpyAsync(r_tail_.ptr, t.data(), S * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -561,7 +560,7 @@ int SpectrumBank::ragged_plan(const float* d_pcm, uint64_t frames_capacity, cons
         last_hops_out_ = hops_out;
     }
     // the call's per-stream inputs (small: through double-buffered pinned memory, no stream synchronisation)
-    r_staging_.upload(frames, reset_mask, n_streams_, r_frames_.ptr, r_mask_.ptr, stream);
+    r_staging_.upload(frames, reset_mask, n_streams_, r_frames_, r_mask_, stream);
     if (reset_mask) {
         launch_spectrum_reset_streams(r_mask_.ptr, n_streams_, averaging ? d_smoothed_.ptr : nullptr, 2 * bins, d_traces_.ptr, hops_out * 4 * bins,
                                       cfg_.floor_db, stream);

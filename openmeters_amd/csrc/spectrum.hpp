@@ -75,11 +75,12 @@ private:
     uint64_t pend_max_hops_ = 0, pend_hops_out_ = 1;  // between ragged_plan and ragged_finish
     bool ragged_ = false;
     DeviceBuffer<uint64_t> r_head_, r_tail_, r_skip_, r_ing_head_, r_hop_tail_;
-    DeviceBuffer<uint32_t> r_frames_, r_ing_skip_, r_ing_count_, r_nhops_;
+    DeviceBuffer<uint32_t> r_ing_skip_, r_ing_count_, r_nhops_;
+    DeviceView<uint32_t> r_frames_;  // (views into r_staging_)
     // ragged mode: the carried window folds' bookkeeping per stream (spectrum_plan_kernel)
     DeviceBuffer<uint64_t> r_carry_pos_, r_fold_from_;
     DeviceBuffer<uint32_t> r_carry_slot0_, r_carry_valid_, r_fold_mode_, r_fold_slot0_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceView<uint8_t> r_mask_;
     RaggedStaging r_staging_;
 };
 

@@ -347,13 +347,10 @@ int StereometerBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t
             ragged_ = true;
             ragged_zero_mask_ = 0;  // (the host lengths just uploaded already carry it)
         }
-        r_blocks_.reserve(n_streams_);
-        r_mask_.reserve(n_streams_);
         r_start_.reserve((size_t)n_streams_ * 4);
         r_valid_.reserve((size_t)n_streams_ * 4);
-        if (chunk_call) r_frames_.reserve(n_streams_);
-        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_.ptr, r_mask_.ptr, stream, ragged->frames_v,
-                          chunk_call ? r_frames_.ptr : nullptr);
+        r_staging_.upload(ragged->n_blocks, ragged->reset_mask, n_streams_, r_blocks_, r_mask_, stream, chunk_call ? ragged->frames_v : nullptr,
+                          &r_frames_);
         produced_.reserve((size_t)(n_streams_ * n_blocks));
         StereoPlanArgs pa{};
         pa.n_streams = n_streams_;

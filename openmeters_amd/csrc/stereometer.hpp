@@ -163,8 +163,9 @@ private:
     bool ragged_ = false;
     uint32_t ragged_zero_mask_ = 0;  // bands whose deques a config change emptied (applied by the next plan kernel)
     DeviceBuffer<uint64_t> r_pos_, r_len_, r_start_;
-    DeviceBuffer<uint32_t> r_blocks_, r_valid_, r_frames_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceBuffer<uint32_t> r_valid_;
+    DeviceView<uint32_t> r_blocks_, r_frames_;  // (views into r_staging_)
+    DeviceView<uint8_t> r_mask_;
     std::vector<uint32_t> h_blocks_;
     RaggedStaging r_staging_;
     float transition_rate_ = 0.0f;

@@ -195,11 +195,9 @@ int WaveformBank::process_impl(const float* pcm, bool pcm_on_device, uint64_t fr
         }
         if (ragged_zero_phase_ && ragged_zero_pushes_) mirror_valid_ = true;  // (a rebuild makes every stream equal again)
         ragged_zero_phase_ = ragged_zero_pushes_ = false;
-        r_frames_.reserve(n_streams_);
-        r_mask_.reserve(n_streams_);
         r_cols_.reserve(n_streams_);
         r_progress_.reserve(n_streams_);
-        r_staging_.upload(ragged->frames, ragged->reset_mask, n_streams_, r_frames_.ptr, r_mask_.ptr, stream);
+        r_staging_.upload(ragged->frames, ragged->reset_mask, n_streams_, r_frames_, r_mask_, stream);
         columns_.reserve((size_t)(n_streams_ * max_cols * 4), false);
         preview_.reserve((size_t)n_streams_ * 4, false);
         WaveformArgs wa{};

@@ -175,9 +175,10 @@ private:
     bool ragged_ = false, ragged_zero_phase_ = false, ragged_zero_pushes_ = false;
     DeviceBuffer<uint64_t> r_pushes_;
     DeviceBuffer<double> r_phase_;
-    DeviceBuffer<uint32_t> r_frames_, r_cols_;
+    DeviceView<uint32_t> r_frames_;  // (views into r_staging_)
+    DeviceBuffer<uint32_t> r_cols_;
     DeviceBuffer<float> r_progress_;
-    DeviceBuffer<uint8_t> r_mask_;
+    DeviceView<uint8_t> r_mask_;
     RaggedStaging r_staging_;
     // chunk-parallel form
     bool run_chunked(WaveformArgs& wa, const std::vector<uint32_t>& column_ends, double end_phase, hipStream_t stream);

@@ -89,17 +89,29 @@ n = torch.arange(F * 8, device=dev, dtype=torch.float32)
 base = (0.4 * torch.sin(2 * torch.pi * 440.0 * n / 48000.0))[None, :, None] * torch.tensor([1.0, -0.7], device=dev)[None, None, :]
 pcm = (base + 0.01 * (torch.rand((S, F * 8, 2), device=dev) - 0.5)).contiguous()
 chunks = [pcm[:, k * F:(k + 1) * F].contiguous() for k in range(8)]
-ga, gb = CaptureGroup(api, S, stats=True, **cfgs), CaptureGroup(api, S, stats=True, **cfgs)
-state = {"a": 0, "b": 0}
-def lock_step():
-    ga.ingest(chunks[state["a"] % 8].data_ptr(), F, 2, FS, pos)
-    state["a"] += 1
-def ragged():
-    gb.ingest_ragged(chunks[state["b"] % 8].data_ptr(), F, [F] * S, 2, FS, pos)
-    state["b"] += 1
-for _ in range(40):
-    lock_step()
-    ragged()
-lock = timed(lock_step, 200)
-rag = timed(ragged, 200)
+# one group at a time: two live groups own eight side streams between them, and which of the four hardware queues a stream lands on
+# then decides the number (0.35 against 0.30 ms for the same ragged call)
+group_counts = np.full(S, F, np.uint32)   # (prebuilt: converting a 1024-entry list costs the tool ~40 us per call, a sixth of the call)
+state = {"k": 0}
+
+
+def run_group(ragged_calls):
+    g = CaptureGroup(api, S, stats=True, **cfgs)
+
+    def call():
+        if ragged_calls:
+            g.ingest_ragged(chunks[state["k"] % 8].data_ptr(), F, group_counts, 2, FS, pos)
+        else:
+            g.ingest(chunks[state["k"] % 8].data_ptr(), F, 2, FS, pos)
+        state["k"] += 1
+    for _ in range(40):
+        call()
+    ms = timed(call, 200)
+    torch.cuda.synchronize()
+    g.close()
+    return ms
+
+
+lock = run_group(False)
+rag = run_group(True)
 line("capture group, six visuals + rows, 1024 x 256 frames", lock, rag, S, "chunks")
