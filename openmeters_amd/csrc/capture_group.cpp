@@ -287,6 +287,10 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
             if (rc_sg == OMX_PRODUCED) {
                 spectrogram->push_end(sg);
                 note(spectrogram->process_pushed(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
+                // its summary columns right behind its kernel, INSIDE the fork: behind the join they were 12 us of kernel and a launch gap
+                // that every call waited for before the next one's side streams could start (the rows' columns are disjoint per visual)
+                if (stats && (up.produced & OMX_VISUAL_SPECTROGRAM) && up.spectrogram.d_counts)
+                    launch_stats_spectrogram(up.spectrogram.d_counts, S, up.spectrogram.n_columns, rows_.ptr, stream);
             }
             if (rc_sp == OMX_PRODUCED) {
                 spectrum->push_end(sp);
@@ -383,10 +387,8 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
         }
         return (int)OMX_NONE;
     });
-    // ---- joined; the spectrogram's summary columns follow its kernel on the caller's stream
+    // ---- joined
     if (stats) {
-        if ((up.produced & OMX_VISUAL_SPECTROGRAM) && up.spectrogram.d_counts)
-            launch_stats_spectrogram(up.spectrogram.d_counts, S, up.spectrogram.n_columns, rows_.ptr, stream);
         OMX_HIP(hipGetLastError());
         up.d_stats_rows = rows_.ptr;
     }
@@ -515,6 +517,8 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                 OMX_HIP(hipGetLastError());
                 OMX_LAP(9);
                 note(spectrogram->ragged_finish(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
+                if (stats && up.spectrogram.d_n_columns)  // (inside the fork, as in the lock-step call)
+                    launch_stats_spectrogram_ragged(up.spectrogram.d_counts, S, up.spectrogram.max_columns, up.spectrogram.d_n_columns, rows_.ptr, stream);
                 OMX_LAP(10);
                 if (n_parts == 2) note(spectrum->ragged_finish(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
                 if (sp_threw) throw sp_error;  // (the message set_last_error recorded stands)
@@ -524,6 +528,8 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
                 note(spectrogram->process_ragged(d_pcm, frames_capacity, frames, m_sg, channels, sample_rate, positions, stream, &up.spectrogram),
                      OMX_VISUAL_SPECTROGRAM);
                 up.ingest_launches += 1;
+                if (stats && up.spectrogram.d_n_columns)
+                    launch_stats_spectrogram_ragged(up.spectrogram.d_counts, S, up.spectrogram.max_columns, up.spectrogram.d_n_columns, rows_.ptr, stream);
             }
             if (spectrum) {
                 note(spectrum->process_ragged(d_pcm, frames_capacity, frames, m_sp, channels, sample_rate, positions, stream, &up.spectrum),
@@ -593,10 +599,8 @@ int CaptureGroup::ingest_ragged(const float* d_pcm, uint64_t frames_capacity, co
         OMX_LAP(5);
         return (int)OMX_NONE;
     });
-    // ---- joined; the spectrogram's summary columns follow its kernels on the caller's stream
+    // ---- joined
     if (stats) {
-        if (up.spectrogram.d_n_columns)
-            launch_stats_spectrogram_ragged(up.spectrogram.d_counts, S, up.spectrogram.max_columns, up.spectrogram.d_n_columns, rows_.ptr, stream);
         OMX_HIP(hipGetLastError());
         up.d_stats_rows = rows_.ptr;
     }
