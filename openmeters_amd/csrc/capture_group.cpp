@@ -65,8 +65,14 @@ CaptureGroup::CaptureGroup(const omx_capture_group_config& cfg) : cfg_(cfg) {
     enabled_ = cfg.visuals & kAllVisuals;
     for (uint32_t bit = 1; bit <= OMX_VISUAL_WAVEFORM; bit <<= 1)
         if (enabled_ & bit) ensure_bank(bit);
+    int prio_low = 0, prio_high = 0;
+    OMX_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    const char* prio_env = tuning_env("OMX_GROUP_PRIO");  // tuning hook: "p0,p1,p2,p3" with 1 = the highest priority, 0 = default, -1 = lowest
+    int want[kSideStreams] = {0, 0, 0, 0};
+    if (prio_env) (void)std::sscanf(prio_env, "%d,%d,%d,%d", &want[0], &want[1], &want[2], &want[3]);
     for (int i = 0; i < kSideStreams; ++i) {
-        OMX_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+        if (want[i] != 0) OMX_HIP(hipStreamCreateWithPriority(&side_[i], hipStreamNonBlocking, want[i] > 0 ? prio_high : prio_low));
+        else OMX_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
         OMX_HIP(hipEventCreateWithFlags(&join_[i], hipEventDisableTiming));
     }
     OMX_HIP(hipEventCreateWithFlags(&fork_, hipEventDisableTiming));
@@ -247,16 +253,16 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
     up.n_blocks = n_blocks;
     up.block_frames = block;
     const bool stats = stats_ && spectrogram && loudness && stereometer;
-    if (stats) {
-        rows_.reserve((size_t)S * OMX_STATS_COLUMNS);
-        OMX_HIP(hipMemsetAsync(rows_.ptr, 0, (size_t)S * OMX_STATS_COLUMNS * sizeof(float), stream));  // ahead of the fork
-    }
+    // (no clear of the table ahead of the fork: that was a fill kernel and its launch gap in the one stretch of a call nothing overlaps.
+    // Every visual writes its own columns on its own stream, or zeroes them when it produced nothing)
+    if (stats) rows_.reserve((size_t)S * OMX_STATS_COLUMNS);
     int worst = OMX_NONE;
     auto note = [&](int rc, uint32_t bit) {
         if (rc < 0) worst = worst < 0 ? worst : rc;
         else if (rc == OMX_PRODUCED) up.produced |= bit;
     };
     bool used[kSideStreams] = {false, false, false, false};
+    uint32_t stats_written = 0;
     forked(stream, side_, fork_, join_, used, [&] {
         // ---- the caller's stream: the banks that keep pending audio, fed by one projection of the block
         {
@@ -289,9 +295,12 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
                 note(spectrogram->process_pushed(stream, &up.spectrogram), OMX_VISUAL_SPECTROGRAM);
                 // its summary columns right behind its kernel, INSIDE the fork: behind the join they were 12 us of kernel and a launch gap
                 // that every call waited for before the next one's side streams could start (the rows' columns are disjoint per visual)
-                if (stats && (up.produced & OMX_VISUAL_SPECTROGRAM) && up.spectrogram.d_counts)
+                if (stats && (up.produced & OMX_VISUAL_SPECTROGRAM) && up.spectrogram.d_counts && up.spectrogram.n_columns) {
                     launch_stats_spectrogram(up.spectrogram.d_counts, S, up.spectrogram.n_columns, rows_.ptr, stream);
+                    stats_written |= kStatsSpectrogramColumns;
+                }
             }
+            if (stats && !(stats_written & kStatsSpectrogramColumns)) launch_stats_clear_columns(rows_.ptr, S, kStatsSpectrogramColumns, stream);
             if (rc_sp == OMX_PRODUCED) {
                 spectrum->push_end(sp);
                 note(spectrum->process_pushed(stream, &up.spectrum), OMX_VISUAL_SPECTRUM);
@@ -343,8 +352,10 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
                                            meters_.ptr, s_ld);
                     clock_ += (double)n_blocks * dt;
                     launch_stats_loudness(up.d_loudness, meters_.ptr, S, n_blocks, channels, rows_.ptr, s_ld);
+                    stats_written |= kStatsLoudnessColumns;
                 }
             }
+            if (stats && !(stats_written & kStatsLoudnessColumns)) launch_stats_clear_columns(rows_.ptr, S, kStatsLoudnessColumns, s_ld);
             OMX_HIP(hipGetLastError());
         }
         // ---- side stream 3: waveform
@@ -359,8 +370,11 @@ int CaptureGroup::ingest(const float* d_pcm, uint64_t frames, uint32_t channels_
             {
                 const int rc = stereometer->process(d_pcm, true, block, n_blocks, channels, sample_rate, positions, s_st, &up.stereometer);
                 note(rc, OMX_VISUAL_STEREOMETER);
-                if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations)
+                if (stats && rc == OMX_PRODUCED && up.stereometer.d_correlations) {
                     launch_stats_stereometer(up.stereometer.d_correlations, S, n_blocks, rows_.ptr, s_st);
+                    stats_written |= kStatsStereometerColumns;
+                }
+                if (stats && !(stats_written & kStatsStereometerColumns)) launch_stats_clear_columns(rows_.ptr, S, kStatsStereometerColumns, s_st);
             }
             OMX_HIP(hipGetLastError());
         }

@@ -12,6 +12,9 @@ void launch_loudness_meters(const omx_loudness_snapshot* snapshots, uint64_t n_s
 void launch_stats_loudness(const omx_loudness_snapshot* snapshots, const omx_meter_row* meters, uint64_t n_streams, uint64_t n_blocks,
                            uint32_t channels, float* rows, hipStream_t stream);
 void launch_stats_stereometer(const float* correlations, uint64_t n_streams, uint64_t n_blocks, float* rows, hipStream_t stream);
+// columns per visual: loudness 0-2, 10, 11; stereometer 3-6; spectrogram 7-9
+constexpr uint32_t kStatsLoudnessColumns = 0x0C07u, kStatsStereometerColumns = 0x0078u, kStatsSpectrogramColumns = 0x0380u;
+void launch_stats_clear_columns(float* rows, uint64_t n_streams, uint32_t columns, hipStream_t stream);
 void launch_stats_spectrogram(const uint32_t* counts, uint64_t n_streams, uint64_t n_columns, float* rows, hipStream_t stream);
 // the same for per-capture calls (omx_capture_group_ingest_ragged): capture s ran n_blocks_v[s] <= max_blocks blocks of block_frames_v[s]
 // (or block_frames) frames — rows / holds of captures that ran none stay as they are; reset_v[s] restarts the capture's holds on a fresh

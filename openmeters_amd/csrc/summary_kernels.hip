@@ -340,6 +340,19 @@ void launch_stats_stereometer(const float* correlations, uint64_t n_streams, uin
     hipLaunchKernelGGL(stats_stereometer_kernel, dim3((uint32_t)((n_streams + 63) / 64)), dim3(64), 0, stream, correlations, n_streams,
                        n_blocks, rows);
 }
+// the columns of a visual that produced nothing this call (bit c of `columns` = column c): zero, as a cleared table would have left them
+__global__ __launch_bounds__(256) void stats_clear_columns_kernel(float* __restrict__ rows, uint64_t n_streams, uint32_t columns) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_streams) return;
+    float* r = rows + s * OMX_STATS_COLUMNS;
+#pragma unroll
+    for (uint32_t c = 0; c < OMX_STATS_COLUMNS; ++c)
+        if (columns & (1u << c)) r[c] = 0.0f;
+}
+void launch_stats_clear_columns(float* rows, uint64_t n_streams, uint32_t columns, hipStream_t stream) {
+    if (n_streams == 0 || columns == 0) return;
+    hipLaunchKernelGGL(stats_clear_columns_kernel, dim3((uint32_t)((n_streams + 255) / 256)), dim3(256), 0, stream, rows, n_streams, columns);
+}
 void launch_stats_spectrogram(const uint32_t* counts, uint64_t n_streams, uint64_t n_columns, float* rows, hipStream_t stream) {
     if (n_streams == 0 || n_columns == 0) return;
     hipLaunchKernelGGL(stats_spectrogram_kernel, dim3((uint32_t)((n_streams + 3) / 4)), dim3(256), 0, stream, counts, n_streams, n_columns,
