@@ -279,7 +279,9 @@ def waveform(blocks=64, reps=REPS, out=sys.stdout, sizes=(64, 1024, 4096), histo
             # §8(d)-style algorithmic bytes: C * 4 B of PCM in per frame + 4 columns x 44 B out per emitted column (scroll 300 / s: one per 160 frames)
             alg = S * frames * 2 * 4.0 + S * (frames / 160.0) * 4 * 44.0
             chunked = bank.last_form() == 2   # waveform_chunked.hip: seven launches per call, all named wave_*
-            names = ["wave_", f"@{S}"] if chunked else [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", f"@{S}"]
+            # (the traffic record holds the 1024-stream bank twice: "@1024" RMS history off, "#1024" on — tools/profile_meters_pmc.sh)
+            mark = f"#{S}" if history else f"@{S}"
+            names = ["wave_", mark] if chunked else [f"waveform_roles_kernel<8, 2, {'true' if history else 'false'}", mark]
             res[f"{S}_streams_history_{int(history)}"] = {"blocks_per_s": S * blocks / dt, "ms_per_call": dt * 1e3,
                                                            "form": "chunk-parallel (waveform_chunked.hip)" if chunked else "sequential (waveform_roles_kernels.hip)",
                                                            "parity_bar": parity_bar(*(["waveform (chunk-parallel, 1024 streams): colour |HIP - oracle| / (fix + 3 |oracle - exact|)",

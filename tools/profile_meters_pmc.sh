@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the cfg3 / cfg4 meter kernels and of the waveform bank at ONE size
-# (1024 streams, the default configuration — RMS history off: a per-launch record); outputs under gpurun_out/$1
+# (1024 streams, RMS history off "@1024" and on "#1024": per-launch records); outputs under gpurun_out/$1
 set -u
 TAG=${1:-meters_pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -10,12 +10,14 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $GR
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py nowave > $OUT/write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/wf_fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $OUT/wf_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wf_write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $OUT/wf_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/wh_fetch -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 1 > $OUT/wh_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wh_write -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 1 > $OUT/wh_write.log 2>&1
 python3 - <<PY
 import csv, glob, os
 from collections import defaultdict
 out = "$OUT"
 agg = defaultdict(lambda: defaultdict(list))
-for d, suffix in (("fetch", ""), ("write", ""), ("wf_fetch", "@1024"), ("wf_write", "@1024")):
+for d, suffix in (("fetch", ""), ("write", ""), ("wf_fetch", "@1024"), ("wf_write", "@1024"), ("wh_fetch", "#1024"), ("wh_write", "#1024")):
     for f in glob.glob(os.path.join(out, d, "*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):

@@ -41,3 +41,7 @@ cp gpurun_out/${TAG}_stream/t_kernel_stats.csv gpurun_out/${TAG}_stream_kernel_s
 # kernel trace of the waveform bank's chunk-parallel form (1024 streams x 16384 frames, history off)
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave.log 2>&1 )
 cp gpurun_out/${TAG}_wave/t_kernel_stats.csv gpurun_out/${TAG}_wave_kernel_stats.csv 2>/dev/null
+
+# ... and with RMS history on (round 6: running totals kept between calls)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave_history -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_meters.py waveform 1024 1 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_wave_history.log 2>&1 )
+cp gpurun_out/${TAG}_wave_history/t_kernel_stats.csv gpurun_out/${TAG}_wave_history_kernel_stats.csv 2>/dev/null
