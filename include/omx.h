@@ -748,6 +748,28 @@ uint64_t omx_batcher_pending(const omx_batcher* b, float* dst, uint64_t cap);
 /* 1 and *out filled when a format is latched (batcher.format), else 0 */
 int omx_batcher_format(const omx_batcher* b, omx_audio_format* out);
 
+/* ---- S DspBatchers with their samples resident on the device (meter.rs:27-80, one DspBatcher per capture; registry.rs:396-418) ----
+ * The packet LENGTHS are host values (they come from the capture API); the chunk plan — DspBatcher::push's integer arithmetic
+ * (meter.rs:40-69) — is a pure function of them and of the pending counts, so it is made on the host, and the SAMPLES never leave the
+ * device: one launch assembles the chunks of every capture, a second one keeps the remainders.  A push yields ROUNDS: round r holds
+ * the r-th chunk of every capture that has one, laid out as omx_capture_group_ingest_ragged takes it (one block per capture per call).
+ * No CPU fallback: create returns OMX_ERR_NO_DEVICE without a gfx950 device. */
+typedef struct omx_batcher_bank omx_batcher_bank;
+int omx_batcher_bank_create(uint32_t n_captures, uint64_t max_packet_frames, omx_batcher_bank** out);
+void omx_batcher_bank_destroy(omx_batcher_bank* b);
+/* One packet per capture: capture s delivers packet_frames[s] <= max_packet_frames frames (0: nothing arrived), interleaved, the first
+ * at d_packets + s * packet_stride * format->channels (device memory; packet_frames: host).  clear_mask[s] != 0 (NULL: none) =
+ * DspBatcher::clear of capture s before its packet (:76-79: that capture's reset).  A `format` that differs from the previous push's
+ * drops every capture's pending samples (:46-48).  *n_rounds = the number of rounds this push produced (0: no capture completed a batch). */
+int omx_batcher_bank_push(omx_batcher_bank* b, const float* d_packets, uint64_t packet_stride, const uint32_t* packet_frames,
+                          const uint8_t* clear_mask, const omx_audio_format* format, void* stream, uint32_t* n_rounds);
+/* Round r of the last push: *d_pcm = device [n_captures][*chunk_capacity][channels] f32, capture s's chunk = its first (*frames)[s]
+ * frames; *frames = host [n_captures], valid until the next push.  (d_pcm, *chunk_capacity, *frames) are the (d_pcm, frames_capacity,
+ * frames) of omx_capture_group_ingest_ragged; enqueue that call on the stream the push was given. */
+int omx_batcher_bank_round(const omx_batcher_bank* b, uint32_t r, const float** d_pcm, uint64_t* chunk_capacity, const uint32_t** frames);
+/* pending samples of capture s (batcher.samples.len()); copies up to `cap` of them to dst (host) when dst != NULL (synchronises `stream`) */
+uint64_t omx_batcher_bank_pending(omx_batcher_bank* b, uint32_t s, float* dst, uint64_t cap, void* stream);
+
 /* ---- batched bank: S independent OscilloscopeProcessors, one workgroup per stream ---- */
 typedef struct omx_oscilloscope_bank omx_oscilloscope_bank;
 /* per (stream, block) result header; `produced` mirrors `process_block(..).is_some()`,

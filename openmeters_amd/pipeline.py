@@ -132,6 +132,59 @@ class CaptureGroup:
         return ms.value, n.value
 
 
+class CAudioFormat(C.Structure):   # omx_audio_format (reference src/dsp.rs:79-85)
+    _fields_ = [("generation", C.c_uint64), ("sample_rate", C.c_float), ("channels", C.c_uint32), ("positions", C.c_uint8 * 8)]
+
+
+class BatcherBank:
+    """omx_batcher_bank_*: one DspBatcher per capture (reference src/meter.rs:27-80) with the samples resident on the device.  `push`
+    takes one packet per capture (device memory, host lengths) and returns the rounds it produced: (device pointer, chunk capacity in
+    frames, host frame counts) per round — the arguments of CaptureGroup.ingest_ragged."""
+
+    def __init__(self, api: capi.Api, n_captures: int, max_packet_frames: int):
+        self.api, self.n_captures = api, n_captures
+        self._h = C.c_void_p()
+        api.check(api.fn("batcher_bank_create", C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)])(n_captures, max_packet_frames, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.fn("batcher_bank_destroy", None, [C.c_void_p])(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, device_ptr: int, packet_stride: int, packet_frames: Sequence[int], channels: int, sample_rate: float,
+             positions: Sequence[int], generation: int = 0, clear_mask: Optional[Sequence[int]] = None, stream: int = 0):
+        fr = np.ascontiguousarray(packet_frames, dtype=np.uint32)
+        mk = np.ascontiguousarray(clear_mask, dtype=np.uint8) if clear_mask is not None else None
+        assert fr.shape == (self.n_captures,) and (mk is None or mk.shape == (self.n_captures,))
+        fmt = CAudioFormat(generation, sample_rate, channels, (C.c_uint8 * 8)(*positions))
+        n = C.c_uint32()
+        f = self.api.fn("batcher_bank_push", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.POINTER(C.c_uint32)])
+        self.api.check(f(self._h, C.c_void_p(device_ptr), packet_stride, fr.ctypes.data, mk.ctypes.data if mk is not None else None, C.byref(fmt),
+                         C.c_void_p(stream or 0), C.byref(n)))
+        rounds = []
+        g = self.api.fn("batcher_bank_round", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)])
+        for r in range(n.value):
+            ptr, cap, frames = C.c_void_p(), C.c_uint64(), C.c_void_p()
+            self.api.check(g(self._h, r, C.byref(ptr), C.byref(cap), C.byref(frames)))
+            counts = np.ctypeslib.as_array(C.cast(frames, C.POINTER(C.c_uint32)), shape=(self.n_captures,)).copy()
+            rounds.append((int(ptr.value or 0), int(cap.value), counts))
+        return rounds
+
+    def pending(self, capture: int, stream: int = 0):
+        f = self.api.fn("batcher_bank_pending", C.c_uint64, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p])
+        n = int(f(self._h, capture, None, 0, C.c_void_p(stream or 0)))
+        buf = np.zeros(max(n, 1), np.float32)
+        f(self._h, capture, buf.ctypes.data, n, C.c_void_p(stream or 0))
+        return buf[:n]
+
+
 class _DeviceView:
     def __init__(self, ptr, shape, typestr):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
