@@ -78,6 +78,34 @@ def test_c99_capture_group_drives_three_visuals_with_one_ingest_per_block(tmp_pa
     assert v["worst_lufs"] < 1e-4 and v["worst_rho"] < 1e-6 and v["rho_full"] < -0.99
 
 
+BATCHER_BANK_SRC = os.path.join(ROOT, "tests", "c_abi", "batcher_bank_demo.c")
+
+
+def build_batcher_bank(tmp_path):
+    out = str(tmp_path / "batcher_bank_demo")
+    libdir = os.path.join(ROOT, "openmeters_amd", "csrc")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), BATCHER_BANK_SRC, "-o", out,
+           "-L", libdir, "-lomx_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out
+
+
+def test_c99_batcher_bank_host_builds_against_the_header(tmp_path, omx):
+    """the device-side batchers are reachable from plain C: tests/c_abi/batcher_bank_demo.c compiles (-Wall -Wextra -pedantic -Werror) and links"""
+    assert os.path.exists(build_batcher_bank(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c99_batcher_bank_emits_the_host_batchers_chunks(tmp_path, omx):
+    """batcher_bank_demo.c: five captures, thirty packet rounds from device memory; every chunk and every remainder against the host
+    batcher of the same library (DspBatcher for one capture, KAT-pinned), compared in C with memcmp"""
+    r = subprocess.run([build_batcher_bank(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    v = parse(r.stdout.strip())
+    assert v["mismatches"] == 0 and v["chunks"] > 100 and v["multi"] > 5
+
+
 MANAGER_SRC = os.path.join(ROOT, "tests", "c_abi", "group_manager.c")
 
 

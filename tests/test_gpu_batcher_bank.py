@@ -67,8 +67,9 @@ def test_every_capture_emits_the_chunks_of_its_own_host_batcher(omx, channels, r
             seen |= {len(x) // channels for x in want}
             multi += len(want) > 1
             assert np.array_equal(bank.pending(s).view(np.uint32), hosts[s].pending().view(np.uint32)), (push, s)
-    batch = max(int(round(256 * rate / 48000.0)), 1)
-    assert {batch, 2 * batch, 4 * batch} <= seen and multi > 10   # regular blocks, catch-up chunks, several chunks from one packet
+    batch, chunk = max(int(round(256 * rate / 48000.0)), 1), max(int(round(1024 * rate / 48000.0)), 1)
+    # regular blocks, catch-up chunks up to the cap (470 frames at 22.05 kHz: not a multiple of the 118-frame batch), several chunks from one packet
+    assert {batch, 2 * batch, chunk} <= seen and max(seen) == chunk and multi > 10
 
 
 def test_a_format_change_drops_every_pending_sample_and_rescales_the_batch(omx):

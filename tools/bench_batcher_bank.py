@@ -20,7 +20,8 @@ pushes = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 api = openmeters_amd.api()
 pos = capi.positions_fallback(2)
 rng = np.random.default_rng(1)
-for name, sizes in (("256-frame packets", [256]), ("PipeWire quanta of 441 / 480 / 512 / 1024 frames", [441, 480, 512, 1024])):
+# (the first bank of a process times the runtime's own warm-up — 240 ... 310 us per push against 22 for the same pushes later: not printed)
+for name, sizes in ((None, [256]), ("256-frame packets", [256]), ("PipeWire quanta of 441 / 480 / 512 / 1024 frames", [441, 480, 512, 1024])):
     bank = BatcherBank(api, S, 1024)
     packets = torch.rand((S, 1024, 2), device="cuda:0")
     lengths = [np.full(S, sizes[k % len(sizes)], np.uint32) for k in range(8)]
@@ -33,7 +34,8 @@ for name, sizes in (("256-frame packets", [256]), ("PipeWire quanta of 441 / 480
         bank.push(packets.data_ptr(), 1024, lengths[k % 8], 2, 48000.0, pos, generation=1)
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / pushes * 1e6
-    print(f"batcher bank, {S} captures, {name}: {us:.1f} us per push (all captures)")
+    if name:
+        print(f"batcher bank, {S} captures, {name}: {us:.1f} us per push (all captures)")
     bank.close()
 
 # the reference's structure: one host batcher per capture, samples through host memory
