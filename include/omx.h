@@ -763,6 +763,13 @@ void omx_batcher_bank_destroy(omx_batcher_bank* b);
  * drops every capture's pending samples (:46-48).  *n_rounds = the number of rounds this push produced (0: no capture completed a batch). */
 int omx_batcher_bank_push(omx_batcher_bank* b, const float* d_packets, uint64_t packet_stride, const uint32_t* packet_frames,
                           const uint8_t* clear_mask, const omx_audio_format* format, void* stream, uint32_t* n_rounds);
+/* ingest_silence (meter.rs:145-166) for every capture: capture s is fed silence_frames[s] frames of silence (0: none; host array) the
+ * way the reference feeds it — through DspBatcher::push in pieces of the silence scratch — or, beyond MAX_SILENCE_SECONDS = 2 s of
+ * it, is reset instead (:154-157): its pending samples are dropped and reset_out[s] (host, may be NULL) is set to 1 — the caller
+ * passes that as the reset mask of its next omx_capture_group_ingest_ragged.  Rounds as after a push (only a capture's FIRST chunk can
+ * hold samples — its pending partial batch completed with zeros; every later chunk is zeros and shares one buffer). */
+int omx_batcher_bank_push_silence(omx_batcher_bank* b, const uint64_t* silence_frames, const omx_audio_format* format, void* stream,
+                                  uint32_t* n_rounds, uint8_t* reset_out);
 /* Round r of the last push: *d_pcm = device [n_captures][*chunk_capacity][channels] f32, capture s's chunk = its first (*frames)[s]
  * frames; *frames = host [n_captures], valid until the next push.  (d_pcm, *chunk_capacity, *frames) are the (d_pcm, frames_capacity,
  * frames) of omx_capture_group_ingest_ragged; enqueue that call on the stream the push was given. */

@@ -91,6 +91,22 @@ __global__ __launch_bounds__(256) void batcher_keep_kernel(BatcherArgs a) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) pend[dst0 + i] = packet[src0 + i];
 }
 
+// ingest_silence (meter.rs:145-166) for S captures: only the FIRST chunk of a capture's silence can hold samples (its pending partial
+// batch, completed with zeros); every later chunk is zeros.  One workgroup per capture: round 0's row, then the pending row.
+// table [n_captures][4]: pending frames before, frames of the capture's first chunk (0: none), 1 when that chunk completes the pending
+// batch, pending frames afterwards
+__global__ __launch_bounds__(256) void batcher_silence_kernel(BatcherArgs a) {
+    const uint32_t s = blockIdx.x, C = a.channels;
+    const uint32_t pending = a.table[4u * s], first = a.table[4u * s + 1u], completes = a.table[4u * s + 2u], after = a.table[4u * s + 3u];
+    float* pend = a.pending + (uint64_t)s * a.batch * C;
+    float* out = a.rounds + (uint64_t)s * a.chunk * C;  // round 0
+    const uint32_t lead = completes ? pending * C : 0u;
+    for (uint32_t i = threadIdx.x; i < first * C; i += 256u) out[i] = i < lead ? pend[i] : 0.0f;
+    __syncthreads();  // (the pending frames are read above and overwritten below)
+    const uint32_t from = (completes || pending == 0u) ? 0u : pending * C;  // no chunk at all: the zeros go behind the pending frames
+    for (uint32_t i = from + threadIdx.x; i < after * C; i += 256u) pend[i] = 0.0f;
+}
+
 uint32_t scaled_frames(uint32_t frames_at_48k, float sample_rate) {  // meter.rs:20-25 (frames; the reference counts samples = frames x channels)
     const double v = std::round((double)frames_at_48k * (double)sample_rate / (double)kDefaultSampleRate);
     return (uint32_t)f2usize(std::fmax(v, 1.0));
@@ -105,6 +121,7 @@ bool same_format(const omx_audio_format& a, const omx_audio_format& b) {  // der
 }  // namespace omx
 
 struct omx_batcher_bank {
+    bool zero_rounds = false;   // the last push was silence: rounds >= 1 share one slab of zeros
     uint32_t n_captures = 0;
     uint64_t max_packet_frames = 0;
     bool has_format = false;
@@ -185,6 +202,7 @@ int omx_batcher_bank_push(omx_batcher_bank* b, const float* d_packets, uint64_t 
             b->pending[s] = p.rest;
         }
         b->n_rounds = rounds;
+        b->zero_rounds = false;
         *n_rounds = rounds;
         if (longest == 0) return (int)OMX_NONE;  // nothing arrived anywhere: no chunk, nothing to keep
         b->d_pending.reserve((size_t)S * batch * C);  // (a format change re-sizes it; the pending counts were cleared above)
@@ -212,6 +230,86 @@ int omx_batcher_bank_push(omx_batcher_bank* b, const float* d_packets, uint64_t 
     });
 }
 
+int omx_batcher_bank_push_silence(omx_batcher_bank* b, const uint64_t* silence_frames, const omx_audio_format* format, void* stream_v,
+                                  uint32_t* n_rounds, uint8_t* reset_out) {
+    return omx::guarded([&] {
+        if (!b || !format || !silence_frames || !n_rounds) {
+            omx::set_last_error("omx_batcher_bank_push_silence: null argument");
+            return (int)OMX_ERR_INVALID;
+        }
+        omx::bind_thread_device();
+        const hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+        const uint32_t S = b->n_captures, C = std::min<uint32_t>(std::max<uint32_t>(format->channels, 1), OMX_MAX_CHANNELS);
+        if (b->has_format && !omx::same_format(b->format, *format)) std::fill(b->pending.begin(), b->pending.end(), 0u);
+        b->has_format = true;
+        b->format = *format;
+        b->batch = omx::scaled_frames(256, format->sample_rate);
+        b->chunk = omx::scaled_frames(1024, format->sample_rate);
+        const uint32_t batch = b->batch, chunk = b->chunk;
+        const double lim = std::fmax(std::round(2.0 * (double)format->sample_rate), 1.0);  // MAX_SILENCE_SECONDS (:18, :151-153)
+        const uint64_t limit = lim >= 18446744073709551615.0 ? UINT64_MAX : (uint64_t)lim;
+        const uint64_t piece_cap = (uint64_t)4096 * OMX_MAX_CHANNELS / std::max<uint32_t>(format->channels, 1);  // the scratch's frames (:96, :159)
+        std::vector<std::vector<uint32_t>> per(S);  // every capture's chunk lengths, in order
+        b->table.assign((size_t)S * 4, 0u);
+        uint32_t rounds = 0;
+        bool any = false;
+        for (uint32_t s = 0; s < S; ++s) {
+            if (reset_out) reset_out[s] = 0;
+            const uint32_t pending0 = b->pending[s];
+            b->table[4 * s] = pending0;
+            b->table[4 * s + 3] = pending0;
+            if (silence_frames[s] == 0) continue;
+            if (silence_frames[s] > limit) {  // batcher.reset(manager) (:154-157): the caller resets that capture's visuals
+                b->pending[s] = 0;
+                b->table[4 * s + 3] = 0;
+                if (reset_out) reset_out[s] = 1;
+                continue;
+            }
+            any = true;
+            bool first_piece = true;
+            for (uint64_t remaining = silence_frames[s]; remaining > 0;) {  // one DspBatcher::push per piece of the scratch (:160-165)
+                const uint32_t piece = (uint32_t)std::min<uint64_t>(remaining, piece_cap);
+                const omx::BatcherPlan p = omx::batcher_plan(b->pending[s], piece, batch);
+                if (p.completes) {
+                    if (first_piece && per[s].empty()) b->table[4 * s + 2] = 1u;
+                    per[s].push_back(batch);
+                }
+                for (uint32_t off = 0; off < p.ready; off += chunk) per[s].push_back(std::min(chunk, p.ready - off));
+                b->pending[s] = p.rest;
+                remaining -= piece;
+                first_piece = false;
+            }
+            b->table[4 * s + 1] = per[s].empty() ? 0u : per[s][0];
+            b->table[4 * s + 3] = b->pending[s];
+            rounds = std::max<uint32_t>(rounds, (uint32_t)per[s].size());
+        }
+        b->round_frames.assign(rounds, std::vector<uint32_t>(S, 0u));
+        for (uint32_t s = 0; s < S; ++s)
+            for (size_t r = 0; r < per[s].size(); ++r) b->round_frames[r][s] = per[s][r];
+        b->n_rounds = rounds;
+        b->zero_rounds = true;
+        *n_rounds = rounds;
+        if (!any) return (int)OMX_NONE;
+        b->d_pending.reserve((size_t)S * batch * C);
+        b->d_table.reserve((size_t)S * 4);
+        b->staging.upload(b->table.data(), b->table.size() * sizeof(uint32_t), b->d_table.ptr, stream);
+        b->d_rounds.reserve((size_t)2 * S * chunk * C);  // round 0, and the zeros every later round is
+        OMX_HIP(hipMemsetAsync(b->d_rounds.ptr + (size_t)S * chunk * C, 0, (size_t)S * chunk * C * sizeof(float), stream));
+        omx::BatcherArgs a{};
+        a.table = b->d_table.ptr;
+        a.pending = b->d_pending.ptr;
+        a.rounds = b->d_rounds.ptr;
+        a.n_captures = S;
+        a.channels = C;
+        a.batch = batch;
+        a.chunk = chunk;
+        a.n_rounds = rounds;
+        hipLaunchKernelGGL(omx::batcher_silence_kernel, dim3(S), dim3(256), 0, stream, a);
+        OMX_HIP(hipGetLastError());
+        return (int)OMX_NONE;
+    });
+}
+
 int omx_batcher_bank_round(const omx_batcher_bank* b, uint32_t r, const float** d_pcm, uint64_t* chunk_capacity, const uint32_t** frames) {
     return omx::guarded([&] {
         if (!b || r >= b->n_rounds) {
@@ -219,7 +317,8 @@ int omx_batcher_bank_round(const omx_batcher_bank* b, uint32_t r, const float** 
             return (int)OMX_ERR_INVALID;
         }
         const uint32_t C = std::min<uint32_t>(std::max<uint32_t>(b->format.channels, 1), OMX_MAX_CHANNELS);
-        if (d_pcm) *d_pcm = b->d_rounds.ptr + (size_t)r * b->n_captures * b->chunk * C;
+        const size_t slab = b->zero_rounds ? std::min<size_t>(r, 1) : r;  // (silence: every round behind the first is the same zeros)
+        if (d_pcm) *d_pcm = b->d_rounds.ptr + slab * b->n_captures * b->chunk * C;
         if (chunk_capacity) *chunk_capacity = b->chunk;
         if (frames) *frames = b->round_frames[r].data();
         return (int)OMX_NONE;

@@ -168,14 +168,29 @@ class BatcherBank:
                                                        C.POINTER(C.c_uint32)])
         self.api.check(f(self._h, C.c_void_p(device_ptr), packet_stride, fr.ctypes.data, mk.ctypes.data if mk is not None else None, C.byref(fmt),
                          C.c_void_p(stream or 0), C.byref(n)))
+        return self._rounds(n.value)
+
+    def _rounds(self, n: int):
         rounds = []
         g = self.api.fn("batcher_bank_round", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)])
-        for r in range(n.value):
+        for r in range(n):
             ptr, cap, frames = C.c_void_p(), C.c_uint64(), C.c_void_p()
             self.api.check(g(self._h, r, C.byref(ptr), C.byref(cap), C.byref(frames)))
             counts = np.ctypeslib.as_array(C.cast(frames, C.POINTER(C.c_uint32)), shape=(self.n_captures,)).copy()
             rounds.append((int(ptr.value or 0), int(cap.value), counts))
         return rounds
+
+    def push_silence(self, silence_frames: Sequence[int], channels: int, sample_rate: float, positions: Sequence[int], generation: int = 0,
+                     stream: int = 0):
+        """ingest_silence (meter.rs:145-166) per capture; returns (rounds, reset flags): a capture whose silence exceeds 2 s is reset"""
+        fr = np.ascontiguousarray(silence_frames, dtype=np.uint64)
+        assert fr.shape == (self.n_captures,)
+        fmt = CAudioFormat(generation, sample_rate, channels, (C.c_uint8 * 8)(*positions))
+        n = C.c_uint32()
+        reset = np.zeros(self.n_captures, np.uint8)
+        f = self.api.fn("batcher_bank_push_silence", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p])
+        self.api.check(f(self._h, fr.ctypes.data, C.byref(fmt), C.c_void_p(stream or 0), C.byref(n), reset.ctypes.data))
+        return self._rounds(n.value), reset
 
     def pending(self, capture: int, stream: int = 0):
         f = self.api.fn("batcher_bank_pending", C.c_uint64, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p])

@@ -93,6 +93,57 @@ def test_a_format_change_drops_every_pending_sample_and_rescales_the_batch(omx):
     assert np.array_equal(bank.pending(0), y[0, :511, 0].cpu().numpy())
 
 
+@pytest.mark.parametrize("channels,rate", [(2, 48000.0), (1, 44100.0), (8, 96000.0)])
+def test_silence_goes_through_every_capture_as_ingest_silence_feeds_it(omx, channels, rate):
+    """ingest_silence (meter.rs:145-166): silence is pushed through DspBatcher::push in pieces of the scratch, or — beyond two seconds of it —
+    the capture is reset.  Packets and silence alternate; chunks, remainders and resets against every capture's host batcher
+    (omx_batcher_push_silence)."""
+    import torch
+    from openmeters_amd.pipeline import BatcherBank
+    from test_gpu_fullsize import dview
+    rng = np.random.default_rng(99 + channels)
+    S = 11
+    positions = capi.positions_fallback(channels)
+    bank = BatcherBank(omx, S, 1024)
+    hosts = [Batcher(omx) for _ in range(S)]
+    f = fmt(channels, rate, 1)
+    resets = chunks_with_samples = long_silences = 0
+    for step in range(24):
+        if step % 2 == 0:   # a packet round: leaves partial batches behind
+            n = packets_for(rng, S, 1024, quiet=0.2)
+            host = rng.uniform(-1.0, 1.0, (S, 1024, channels)).astype(np.float32)
+            d = torch.from_numpy(host).to("cuda:0")
+            bank.push(d.data_ptr(), 1024, n, channels, rate, positions, generation=1)
+            for s in range(S):
+                hosts[s].blocks = []
+                hosts[s].push(host[s, :n[s]].reshape(-1), f)
+            continue
+        sil = np.zeros(S, np.uint64)
+        for s in range(S):
+            u = rng.random()
+            sil[s] = 0 if u < 0.2 else (int(rng.integers(1, 300)) if u < 0.5 else (int(rng.integers(300, 40000)) if u < 0.9 else int(2 * rate) + int(rng.integers(1, 50))))
+        rounds, reset = bank.push_silence(sil, channels, rate, positions, generation=1)
+        torch.cuda.synchronize()
+        got = [[] for _ in range(S)]
+        for ptr, cap, frames in rounds:
+            buf = dview(torch, ptr, (S, cap, channels), "<f4").cpu().numpy()
+            for s in range(S):
+                if frames[s]:
+                    got[s].append(buf[s, :frames[s]].reshape(-1).copy())
+        for s in range(S):
+            hosts[s].blocks, hosts[s].resets = [], 0
+            hosts[s].push_silence(int(sil[s]), f)
+            assert int(reset[s]) == hosts[s].resets, (step, s, sil[s])
+            resets += hosts[s].resets
+            long_silences += len(hosts[s].blocks) > 20
+            assert [len(x) for x in got[s]] == [len(x) for x in hosts[s].blocks], (step, s, sil[s])
+            for k, (a, b) in enumerate(zip(got[s], hosts[s].blocks)):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (step, s, k)
+                chunks_with_samples += bool(np.any(b != 0))
+            assert np.array_equal(bank.pending(s).view(np.uint32), hosts[s].pending().view(np.uint32)), (step, s)
+    assert resets >= 3 and chunks_with_samples >= 5 and long_silences >= 5
+
+
 def test_rounds_feed_the_capture_group_like_the_host_batchers_chunks(omx):
     """end to end: packets -> omx_batcher_bank_push -> omx_capture_group_ingest_ragged per round, against a second group fed the host
     batchers' chunks through a host-assembled buffer: the summary rows and every spectrogram column agree bit for bit"""
