@@ -52,6 +52,8 @@ struct BatcherArgs {
     uint32_t n_captures, channels, batch, chunk, n_rounds;
 };
 
+}  // namespace
+
 // thread = (capture, round, float of the chunk)
 __global__ __launch_bounds__(256) void batcher_rounds_kernel(BatcherArgs a) {
     const uint32_t s = blockIdx.y, r = blockIdx.z;
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(256) void batcher_silence_kernel(BatcherArgs a) {
     const uint32_t from = (completes || pending == 0u) ? 0u : pending * C;  // no chunk at all: the zeros go behind the pending frames
     for (uint32_t i = from + threadIdx.x; i < after * C; i += 256u) pend[i] = 0.0f;
 }
+
+namespace {
 
 uint32_t scaled_frames(uint32_t frames_at_48k, float sample_rate) {  // meter.rs:20-25 (frames; the reference counts samples = frames x channels)
     const double v = std::round((double)frames_at_48k * (double)sample_rate / (double)kDefaultSampleRate);
