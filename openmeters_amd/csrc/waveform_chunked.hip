@@ -34,6 +34,7 @@
 // the non-finite rules of the trackers and of the min / max state machine — never runs here: `bad` sends the whole call through
 // the sequential kernel (nothing but scratch has been written by then).
 #include <mutex>
+#include <type_traits>
 
 #include "waveform_device.hpp"
 
@@ -57,6 +58,9 @@ constexpr int XF = WAVE_XF;
 #endif
 #ifndef WAVE_DENSE_NT
 #define WAVE_DENSE_NT 1
+#endif
+#ifndef WAVE_ROLE_COPIES
+#define WAVE_ROLE_COPIES 1
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ring_store(float* dst, float4 v) {
@@ -213,157 +217,174 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
     float* hring = a.hist_ring + (uint64_t)s * 16u + role * 4u;
     uint32_t half_slot_c = 0, half_slot_h = 0;
 
-    issue(0);
-    for (uint32_t step = 0; step < steps; ++step) {
-        stage(step & 1u);
-        if (step + 1u < steps) issue(step + 1u);
-        __syncthreads();
-        const float* rowp = tile + (step & 1u) * (64 * ROW_FLOATS) + lane * ROW_FLOATS;
-        v2f x[STEP];
-#pragma unroll
-        for (int f = 0; f < STEP; ++f) x[f] = *reinterpret_cast<const v2f*>(rowp + 2 * f);
-#if WAVE_XGROUP
-        // keep the reads (and the f32 -> f64 conversions behind them) of a later XF-frame group from being hoisted over an earlier group's
-        // recurrence: 16 converted frames live at once cost 64 VGPRs
-#define WAVE_GROUP_FENCE(f) if (((f) & (XF - 1)) == 0) __builtin_amdgcn_sched_barrier(0)
-#else
-#define WAVE_GROUP_FENCE(f)
+    // The step loop once per band, the band a compile-time constant in each copy (WAVE_ROLE_COPIES): with the wave-uniform `role` tested at
+    // run time inside it, every frame paid three scalar branches and the register copies at their merges — a third of the pass's 132
+    // VALU instructions per frame and wavefront were moves (static census, round 6).  The copies execute the same barriers in the same order.
+    auto run = [&](auto role_c) {
+#if WAVE_ROLE_COPIES
+        constexpr uint32_t role = decltype(role_c)::value;
 #endif
-        const uint32_t nf = min((uint32_t)STEP, n - step * STEP);  // uniform
-#pragma unroll
-        for (int f = 0; f < STEP; ++f) {
-            WAVE_GROUP_FENCE(f);
-            if ((uint32_t)f < nf) {
-            v2f v = x[f];
-            if (role != 2) {  // (wave-uniform) the low and mid bands in f64, both passes (pass A uses the end state only)
-                double xd[2] = {(double)v.x, (double)v.y};
-                if (role == 1) biquad_lr_f64(ca64, da0, da1, xd);
-                biquad_lr_f64(cb64, d0, d1, xd);
-                v = v2f{(float)xd[0], (float)xd[1]};
-            } else {
-                v = biquad_lr(cb, zb0, zb1, v);
-            }
-            {
-            if constexpr (PASS_B) {
-                const uint32_t g = f0 + step * STEP + (uint32_t)f;  // frame of the call
-                // bands of Left, Right, Mid, Side (:262-268)
-                const float bv[4] = {v.x, v.y, (v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f};
-                float cv[4], pw[4];
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {  // BandTracker::process (:108-121): a non-finite colour value / power counts as 0.  This call's PCM
-                    // is bounded (pass A), but filter state carried over from an earlier call through the sequential kernels may be
-                    // finite and huge (|x| up to 3e38 is legal input): its square overflows here
-                    cv[ch] = fabsf(bv[ch]) * gain;
-                    pw[ch] = bv[ch] * bv[ch];
-                    cv[ch] = cv[ch] <= 3.4028235e38f ? cv[ch] : 0.0f;
-                    pw[ch] = pw[ch] <= 3.4028235e38f ? pw[ch] : 0.0f;
-                    acc_c[ch] += (double)cv[ch];
-                    if (history) acc_p[ch] += (double)pw[ch];
+        issue(0);
+        for (uint32_t step = 0; step < steps; ++step) {
+            stage(step & 1u);
+            if (step + 1u < steps) issue(step + 1u);
+            __syncthreads();
+            const float* rowp = tile + (step & 1u) * (64 * ROW_FLOATS) + lane * ROW_FLOATS;
+            v2f x[STEP];
+    #pragma unroll
+            for (int f = 0; f < STEP; ++f) x[f] = *reinterpret_cast<const v2f*>(rowp + 2 * f);
+    #if WAVE_XGROUP
+            // keep the reads (and the f32 -> f64 conversions behind them) of a later XF-frame group from being hoisted over an earlier group's
+            // recurrence: 16 converted frames live at once cost 64 VGPRs
+    #define WAVE_GROUP_FENCE(f) if (((f) & (XF - 1)) == 0) __builtin_amdgcn_sched_barrier(0)
+    #else
+    #define WAVE_GROUP_FENCE(f)
+    #endif
+            const uint32_t nf = min((uint32_t)STEP, n - step * STEP);  // uniform
+    #pragma unroll
+            for (int f = 0; f < STEP; ++f) {
+                WAVE_GROUP_FENCE(f);
+                if ((uint32_t)f < nf) {
+                v2f v = x[f];
+                if (role != 2) {  // (wave-uniform) the low and mid bands in f64, both passes (pass A uses the end state only)
+                    double xd[2] = {(double)v.x, (double)v.y};
+                    if (role == 1) biquad_lr_f64(ca64, da0, da1, xd);
+                    biquad_lr_f64(cb64, d0, d1, xd);
+                    v = v2f{(float)xd[0], (float)xd[1]};
+                } else {
+                    v = biquad_lr(cb, zb0, zb1, v);
                 }
-                if (role == 0) {  // derived_frame (:123-125) and the min / max of ingest_derived (:275-286)
-                    const float dv[4] = {x[f].x, x[f].y, (x[f].x + x[f].y) * 0.5f, (x[f].x - x[f].y) * 0.5f};
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
-                        mn[ch] = fresh ? dv[ch] : wf::min_finite(mn[ch], dv[ch]);
-                        mx[ch] = fresh ? dv[ch] : wf::max_finite(mx[ch], dv[ch]);
+                {
+                if constexpr (PASS_B) {
+                    const uint32_t g = f0 + step * STEP + (uint32_t)f;  // frame of the call
+                    // bands of Left, Right, Mid, Side (:262-268)
+                    const float bv[4] = {v.x, v.y, (v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f};
+                    float cv[4], pw[4];
+    #pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {  // BandTracker::process (:108-121): a non-finite colour value / power counts as 0.  This call's PCM
+                        // is bounded (pass A), but filter state carried over from an earlier call through the sequential kernels may be
+                        // finite and huge (|x| up to 3e38 is legal input): its square overflows here
+                        cv[ch] = fabsf(bv[ch]) * gain;
+                        pw[ch] = bv[ch] * bv[ch];
+                        cv[ch] = cv[ch] <= 3.4028235e38f ? cv[ch] : 0.0f;
+                        pw[ch] = pw[ch] <= 3.4028235e38f ? pw[ch] : 0.0f;
+                        acc_c[ch] += (double)cv[ch];
+                        if (history) acc_p[ch] += (double)pw[ch];
                     }
-                }
-                fresh = false;
-                if ((f & (XF - 1)) == 0) {
-                    half_slot_c = slot_c;
-                    half_slot_h = slot_h;
-                }
-                if (chunk_writes_c) {
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) xbuf[((f & (XF - 1)) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = cv[ch];
-                }
-                if (chunk_writes_h) {
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) xbuf[((XF + (f & (XF - 1))) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = pw[ch];
-                }
-                slot_c = slot_c + 1u == a.color_len ? 0u : slot_c + 1u;
-                slot_h = slot_h + 1u == a.slow_len ? 0u : slot_h + 1u;
-                if ((int32_t)g == next_cut) {  // uniform: the segment ends with this frame
-                    if (mine) {
-                        double* out = a.seg_sum + ((uint64_t)seg * a.n_local + sl) * 24u + role;
-#pragma unroll
+                    if (role == 0) {  // derived_frame (:123-125) and the min / max of ingest_derived (:275-286)
+                        const float dv[4] = {x[f].x, x[f].y, (x[f].x + x[f].y) * 0.5f, (x[f].x - x[f].y) * 0.5f};
+    #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
-                            out[ch * 3] = acc_c[ch];
-                            if (history) out[12 + ch * 3] = acc_p[ch];
+                            mn[ch] = fresh ? dv[ch] : wf::min_finite(mn[ch], dv[ch]);
+                            mx[ch] = fresh ? dv[ch] : wf::max_finite(mx[ch], dv[ch]);
                         }
-                        if (role == 0) {
-                            float* mm = a.seg_mm + ((uint64_t)(seg - a.n_old_segs) * a.n_local + sl) * 12u;
-                            const float dv[4] = {x[f].x, x[f].y, (x[f].x + x[f].y) * 0.5f, (x[f].x - x[f].y) * 0.5f};
-#pragma unroll
+                    }
+                    fresh = false;
+                    if ((f & (XF - 1)) == 0) {
+                        half_slot_c = slot_c;
+                        half_slot_h = slot_h;
+                    }
+                    if (chunk_writes_c) {
+    #pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) xbuf[((f & (XF - 1)) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = cv[ch];
+                    }
+                    if (chunk_writes_h) {
+    #pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) xbuf[((XF + (f & (XF - 1))) * 64 + (int)lane) * 12 + ch * 3 + (int)role] = pw[ch];
+                    }
+                    slot_c = slot_c + 1u == a.color_len ? 0u : slot_c + 1u;
+                    slot_h = slot_h + 1u == a.slow_len ? 0u : slot_h + 1u;
+                    if ((int32_t)g == next_cut) {  // uniform: the segment ends with this frame
+                        if (mine) {
+                            double* out = a.seg_sum + ((uint64_t)seg * a.n_local + sl) * 24u + role;
+    #pragma unroll
                             for (int ch = 0; ch < 4; ++ch) {
-                                mm[ch * 3] = mn[ch];
-                                mm[ch * 3 + 1] = mx[ch];
-                                mm[ch * 3 + 2] = dv[ch];
+                                out[ch * 3] = acc_c[ch];
+                                if (history) out[12 + ch * 3] = acc_p[ch];
+                            }
+                            if (role == 0) {
+                                float* mm = a.seg_mm + ((uint64_t)(seg - a.n_old_segs) * a.n_local + sl) * 12u;
+                                const float dv[4] = {x[f].x, x[f].y, (x[f].x + x[f].y) * 0.5f, (x[f].x - x[f].y) * 0.5f};
+    #pragma unroll
+                                for (int ch = 0; ch < 4; ++ch) {
+                                    mm[ch * 3] = mn[ch];
+                                    mm[ch * 3 + 1] = mx[ch];
+                                    mm[ch * 3 + 2] = dv[ch];
+                                }
                             }
                         }
+    #pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) acc_c[ch] = acc_p[ch] = 0.0;
+                        fresh = true;
+                        ++seg;
+                        next_cut = a.cuts[seg + 1u];
                     }
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) acc_c[ch] = acc_p[ch] = 0.0;
-                    fresh = true;
-                    ++seg;
-                    next_cut = a.cuts[seg + 1u];
                 }
-            }
-            }
-            }
-            if constexpr (PASS_B) {
-                // the end of an XF-frame piece (or of the chunk): the three bands' values of its frames go to the rings, one row piece per lane
-                if ((chunk_writes_c || chunk_writes_h) && ((f & (XF - 1)) == XF - 1) && (uint32_t)(f & ~(XF - 1)) < nf) {
-                    __syncthreads();
-                    const uint32_t g_half = f0 + step * STEP + (uint32_t)(f & ~(XF - 1));
-                    if constexpr (DENSE) {
-                        // identity stream map: the 64 streams' rows of one frame are 4 KiB in a row.  One store instruction = 16 whole rows
-                        // (lane = stream x quarter row, the pad quarter written as zeros): every 128-byte line leaves complete, in one
-                        // piece — as quarter rows 64 bytes apart (below) a line was assembled from six partial writes and its pad never
-                        // written, which HBM with ECC answers with read-modify-write
-#pragma unroll WAVE_DENSE_UNROLL
-                        for (int it = (int)role; it < 4 * XF; it += 3) {  // (frame of the piece, block of 16 streams), dealt round robin to the three wavefronts
-                            const int k = it >> 2;
-                            const uint32_t st = (uint32_t)(it & 3) * 16u + (lane >> 2), piece = lane & 3u;
+                }
+                }
+                if constexpr (PASS_B) {
+                    // the end of an XF-frame piece (or of the chunk): the three bands' values of its frames go to the rings, one row piece per lane
+                    if ((chunk_writes_c || chunk_writes_h) && ((f & (XF - 1)) == XF - 1) && (uint32_t)(f & ~(XF - 1)) < nf) {
+                        __syncthreads();
+                        const uint32_t g_half = f0 + step * STEP + (uint32_t)(f & ~(XF - 1));
+                        if constexpr (DENSE) {
+                            // identity stream map: the 64 streams' rows of one frame are 4 KiB in a row.  One store instruction = 16 whole rows
+                            // (lane = stream x quarter row, the pad quarter written as zeros): every 128-byte line leaves complete, in one
+                            // piece — as quarter rows 64 bytes apart (below) a line was assembled from six partial writes and its pad never
+                            // written, which HBM with ECC answers with read-modify-write
+    #pragma unroll WAVE_DENSE_UNROLL
+                            for (int it = (int)role; it < 4 * XF; it += 3) {  // (frame of the piece, block of 16 streams), dealt round robin to the three wavefronts
+                                const int k = it >> 2;
+                                const uint32_t st = (uint32_t)(it & 3) * 16u + (lane >> 2), piece = lane & 3u;
+                                const uint32_t g = g_half + (uint32_t)k;
+                                if ((uint32_t)((f & ~(XF - 1)) + k) >= nf) break;
+                                if (s0 + st >= a.n_local) continue;
+                                const uint64_t col = (uint64_t)(s0 + st) * 16u + piece * 4u;
+                                const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                if (chunk_writes_c && g >= ring_c_from) {
+                                    uint32_t slot = half_slot_c + (uint32_t)k;
+                                    slot = slot >= a.color_len ? slot - a.color_len : slot;
+                                    const float4 l4 = *reinterpret_cast<const float4*>(xbuf + (k * 64 + (int)st) * 12 + (int)(piece < 3u ? piece : 2u) * 4);  // (read whatever the lane is: a load chosen by a condition becomes a chosen POINTER)
+                                    const float4 v4 = piece < 3u ? l4 : zero4;
+                                    ring_store(a.color_ring + (uint64_t)slot * row + col, v4);
+                                }
+                                if (chunk_writes_h && g >= ring_h_from) {
+                                    uint32_t slot = half_slot_h + (uint32_t)k;
+                                    slot = slot >= a.slow_len ? slot - a.slow_len : slot;
+                                    const float4 l4 = *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)st) * 12 + (int)(piece < 3u ? piece : 2u) * 4);
+                                    const float4 v4 = piece < 3u ? l4 : zero4;
+                                    ring_store(a.hist_ring + (uint64_t)slot * row + col, v4);
+                                }
+                            }
+                        } else
+    #pragma unroll
+                        for (int k = 0; k < XF; ++k) {
                             const uint32_t g = g_half + (uint32_t)k;
-                            if ((uint32_t)((f & ~(XF - 1)) + k) >= nf) break;
-                            if (s0 + st >= a.n_local) continue;
-                            const uint64_t col = (uint64_t)(s0 + st) * 16u + piece * 4u;
-                            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if ((uint32_t)((f & ~(XF - 1)) + k) >= nf || !mine) continue;
                             if (chunk_writes_c && g >= ring_c_from) {
                                 uint32_t slot = half_slot_c + (uint32_t)k;
                                 slot = slot >= a.color_len ? slot - a.color_len : slot;
-                                const float4 v4 = piece < 3u ? *reinterpret_cast<const float4*>(xbuf + (k * 64 + (int)st) * 12 + (int)piece * 4) : zero4;
-                                ring_store(a.color_ring + (uint64_t)slot * row + col, v4);
+                                *reinterpret_cast<float4*>(cring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + (k * 64 + (int)lane) * 12 + (int)role * 4);
                             }
                             if (chunk_writes_h && g >= ring_h_from) {
                                 uint32_t slot = half_slot_h + (uint32_t)k;
                                 slot = slot >= a.slow_len ? slot - a.slow_len : slot;
-                                const float4 v4 = piece < 3u ? *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)st) * 12 + (int)piece * 4) : zero4;
-                                ring_store(a.hist_ring + (uint64_t)slot * row + col, v4);
+                                *reinterpret_cast<float4*>(hring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)lane) * 12 + (int)role * 4);
                             }
                         }
-                    } else
-#pragma unroll
-                    for (int k = 0; k < XF; ++k) {
-                        const uint32_t g = g_half + (uint32_t)k;
-                        if ((uint32_t)((f & ~(XF - 1)) + k) >= nf || !mine) continue;
-                        if (chunk_writes_c && g >= ring_c_from) {
-                            uint32_t slot = half_slot_c + (uint32_t)k;
-                            slot = slot >= a.color_len ? slot - a.color_len : slot;
-                            *reinterpret_cast<float4*>(cring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + (k * 64 + (int)lane) * 12 + (int)role * 4);
-                        }
-                        if (chunk_writes_h && g >= ring_h_from) {
-                            uint32_t slot = half_slot_h + (uint32_t)k;
-                            slot = slot >= a.slow_len ? slot - a.slow_len : slot;
-                            *reinterpret_cast<float4*>(hring + (uint64_t)slot * row) = *reinterpret_cast<const float4*>(xbuf + ((XF + k) * 64 + (int)lane) * 12 + (int)role * 4);
-                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
             }
         }
-    }
+    };
+#if WAVE_ROLE_COPIES
+    if (role == 0u) run(std::integral_constant<uint32_t, 0>{});
+    else if (role == 1u) run(std::integral_constant<uint32_t, 1>{});
+    else run(std::integral_constant<uint32_t, 2>{});
+#else
+    run(0);
+#endif
     if constexpr (!PASS_B) {
         if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
         if (!mine) return;
