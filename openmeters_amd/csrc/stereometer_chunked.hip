@@ -18,6 +18,7 @@
 // e.g. 256 streams x 64 blocks = 256 workgroups of three wavefronts): every kernel then works on chunks, the correlations of a
 // block are those of its last chunk, and the once-per-block denormal flush is applied at block ends only.
 // Single-stream handles and short calls stay on the sequential kernels (bit-identical form, the A/B reference).
+#include <type_traits>
 #include "stereometer.hpp"
 
 namespace omx {
@@ -179,56 +180,64 @@ __global__ __launch_bounds__(192) void stereo_chunk_kernel(StereoChunkArgs a) {
         pos_band = a.start_v[s * 4u + band_id];
     }
 
-    issue(0);
-    for (uint32_t step = 0; step < steps; ++step) {
-        stage(step & 1u);
-        if (step + 1u < steps) issue(step + 1u);
-        __syncthreads();
-        const float* row = tile + (step & 1u) * (64 * ROW_FLOATS) + lane * ROW_FLOATS;
-        v2f x[STEP];
-#pragma unroll
-        for (int f = 0; f < STEP; ++f) x[f] = *reinterpret_cast<const v2f*>(row + 2 * f);
-        v2f y[STEP];
-#pragma unroll
-        for (int f = 0; f < STEP; ++f) {
-            v2f v = x[f];
-            if (!PASS_B && role == 0) {   // (wave-uniform) the low band's zero-state pass in f64: only its end state is used
-                if (bands) {
-                    double xd[2] = {(double)v.x, (double)v.y};
-                    biquad_lr_f64(ca, d0[0], d1[0], xd, poison64);
-                    biquad_lr_f64(ca, d0[1], d1[1], xd, poison64);
-                }
-            } else if (bands) {
-                v = biquad_lr(ca, z0[0], z1[0], v, poison);
-                v = biquad_lr(ca, z0[1], z1[1], v, poison);
-                if (role != 0) {
-                    v = biquad_lr(cb, z0[2], z1[2], v, poison);
-                    v = biquad_lr(cb, z0[3], z1[3], v, poison);
-                }
-            }
-            y[f] = v;
-            if constexpr (PASS_B) {
-                if (role == 0) full.update(x[f], alpha);
-                if (bands) band.update(v, alpha);
-            }
-        }
-        if (PASS_B && wave_in_tail) {
-#pragma unroll
+    // The step loop once per band wavefront, the band a compile-time constant in each copy: tested at run time inside the loop, the
+    // wave-uniform `role` cost scalar branches and register copies on every frame (waveform_chunked.hip has the census; round 6).
+    auto run = [&](auto role_c) {
+        constexpr uint32_t role = decltype(role_c)::value;
+        issue(0);
+        for (uint32_t step = 0; step < steps; ++step) {
+            stage(step & 1u);
+            if (step + 1u < steps) issue(step + 1u);
+            __syncthreads();
+            const float* row = tile + (step & 1u) * (64 * ROW_FLOATS) + lane * ROW_FLOATS;
+            v2f x[STEP];
+    #pragma unroll
+            for (int f = 0; f < STEP; ++f) x[f] = *reinterpret_cast<const v2f*>(row + 2 * f);
+            v2f y[STEP];
+    #pragma unroll
             for (int f = 0; f < STEP; ++f) {
-                const uint64_t g = c * (uint64_t)L + step * STEP + (uint32_t)f;
-                if (chunk_in_tail && g >= tail_from) {
-                    if (role == 0) {
-                        const uint64_t slot = (pos_full + g) % a.hist_frames;
-                        *reinterpret_cast<v2f*>(hist_full + slot * 2u) = x[f];
+                v2f v = x[f];
+                if (!PASS_B && role == 0) {   // (wave-uniform) the low band's zero-state pass in f64: only its end state is used
+                    if (bands) {
+                        double xd[2] = {(double)v.x, (double)v.y};
+                        biquad_lr_f64(ca, d0[0], d1[0], xd, poison64);
+                        biquad_lr_f64(ca, d0[1], d1[1], xd, poison64);
                     }
-                    if (bands && a.emit_band_points) {
-                        const uint64_t slot = (pos_band + g) % a.hist_frames;
-                        *reinterpret_cast<v2f*>(hist_band + slot * 2u) = y[f];
+                } else if (bands) {
+                    v = biquad_lr(ca, z0[0], z1[0], v, poison);
+                    v = biquad_lr(ca, z0[1], z1[1], v, poison);
+                    if (role != 0) {
+                        v = biquad_lr(cb, z0[2], z1[2], v, poison);
+                        v = biquad_lr(cb, z0[3], z1[3], v, poison);
+                    }
+                }
+                y[f] = v;
+                if constexpr (PASS_B) {
+                    if (role == 0) full.update(x[f], alpha);
+                    if (bands) band.update(v, alpha);
+                }
+            }
+            if (PASS_B && wave_in_tail) {
+    #pragma unroll
+                for (int f = 0; f < STEP; ++f) {
+                    const uint64_t g = c * (uint64_t)L + step * STEP + (uint32_t)f;
+                    if (chunk_in_tail && g >= tail_from) {
+                        if (role == 0) {
+                            const uint64_t slot = (pos_full + g) % a.hist_frames;
+                            *reinterpret_cast<v2f*>(hist_full + slot * 2u) = x[f];
+                        }
+                        if (bands && a.emit_band_points) {
+                            const uint64_t slot = (pos_band + g) % a.hist_frames;
+                            *reinterpret_cast<v2f*>(hist_band + slot * 2u) = y[f];
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (role == 0u) run(std::integral_constant<uint32_t, 0>{});
+    else if (role == 1u) run(std::integral_constant<uint32_t, 1>{});
+    else run(std::integral_constant<uint32_t, 2>{});
     if (!(poison.x == 0.0f && poison.y == 0.0f) || !(poison64 == 0.0)) bad = 1u;
     if (__ballot(bad != 0u) != 0ull && lane == 0) atomicOr(a.bad, 1u);
     if (!mine) return;
