@@ -190,7 +190,7 @@ __global__ __launch_bounds__(192) WAVE_ATTR void wave_chunk_kernel(WaveChunkArgs
     }
     // pass B: sums between cuts, the rings' newest values
     const float gain = role == 0 ? 1.0f : (role == 1 ? 0.7f : 2.0f);  // BAND_COLOR_GAINS (:22)
-    const bool history = a.history != 0u;
+    const bool history = DENSE || a.history != 0u;  // (DENSE is launched for banks with RMS history only: a constant there)
     double acc_c[4] = {0.0, 0.0, 0.0, 0.0}, acc_p[4] = {0.0, 0.0, 0.0, 0.0};
     float mn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool fresh = true;  // no frame since the last cut (uniform)
