@@ -1312,9 +1312,10 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const uint32_t i0 = 2u * (uint32_t)(j + 256 * t);
-        const float x0 = i0 < n ? ring[(start + i0) & mask] : 0.0f;
-        const float x1 = i0 + 1u < n ? ring[(start + i0 + 1u) & mask] : 0.0f;
-        v[t] = v2f{x0, x1};
+        // (unconditional loads — the index is masked into the ring whatever i0 is — and a select: a load under a per-lane condition
+        // is an exec-mask region of its own, 32 of them here)
+        const float r0 = ring[(start + i0) & mask], r1 = ring[(start + i0 + 1u) & mask];
+        v[t] = v2f{i0 < n ? r0 : 0.0f, i0 + 1u < n ? r1 : 0.0f};
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -1363,7 +1364,8 @@ __global__ __launch_bounds__(256, 3) void scope_estimate2_kernel(ScopeArgs a) {
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 const uint32_t i = lo + (uint32_t)q;
-                sq[q] = (uint32_t)q < chunk && i < hi ? E[i] : 0.0f;
+                const float e = E[i];  // (i <= n + 32: inside the buffer; read unconditionally, selected below)
+                sq[q] = (uint32_t)q < chunk && i < hi ? e : 0.0f;
                 local = sq[q] + local;
             }
             const float incl = wave_scan<OP_SUM>(local);  // inclusive over the wavefront
