@@ -403,6 +403,7 @@ class StereometerExact:
 # evaluations of this recurrence.  Finite two-channel (FL, FR) input only; min / max fields are not modelled (bit-exact elsewhere).
 class WaveformExact:
     GAINS = (1.0, 0.7, 2.0)   # BAND_COLOR_GAINS (:22), as f32 values
+    GRID = 32                 # frames between the window means kept for the scales of the parity bars (run: grid_*)
 
     def __init__(self, sample_rate=48000.0, scroll_speed=300.0):
         self.rate = float(np.float32(sample_rate))
@@ -445,8 +446,14 @@ class WaveformExact:
                 phase -= 1.0
         ends = np.array(ends, np.int64)
 
-        def mean(c, cap):
-            hi = ends + 1
+        def mean(c, cap, at=None):
+            hi = (ends if at is None else at) + 1
             lo = np.maximum(hi - cap, 0)
             return ((c[hi] - c[lo]) / np.maximum(np.minimum(hi, cap), 1)[:, None, None]).astype(np.float64)
+        # the same window means on a grid of frames (every GRID-th frame, whether a column ends there or not): the scale "the loudest the
+        # windows have been within reach" must not depend on where the columns happen to end (at 10 columns per second a 40 ms passage
+        # can lie between two of them)
+        self.grid_ends = np.arange(self.GRID - 1, x.shape[0], self.GRID, dtype=np.int64)
+        self.grid_colour = mean(cc, self.color_len, self.grid_ends)
+        self.grid_power = np.stack([mean(cp, self.color_len, self.grid_ends), mean(cp, self.slow_len, self.grid_ends)], axis=2)
         return ends, mean(cc, self.color_len), np.stack([mean(cp, self.color_len), mean(cp, self.slow_len)], axis=2)
