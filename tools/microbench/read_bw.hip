@@ -32,6 +32,38 @@ __global__ __launch_bounds__(64) void pieces_kernel(const float4* __restrict__ i
     if (acc == 12345.678f) out[blockIdx.x] = acc;
 }
 
+// the loudness chunk kernels' tile shape: wavefront = (group of 8 streams, block of 256 frames x 8 channels); a tile = 16 frames of the
+// eight streams = eight 512-byte pieces 512 KiB apart, four 16-byte loads per lane; INFLIGHT tiles requested ahead
+template <int INFLIGHT>
+__global__ __launch_bounds__(64) void tiles_kernel(const float4* __restrict__ in, size_t stream_f4, float* out) {
+    const uint32_t group = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    // lane + 64 n -> byte (lane + 64 n) * 16 of the tile: row = byte / 512 (stream of the group), inrow = byte % 512
+    const float4* src[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t byte = (lane + 64u * n) * 16u, row = byte / 512u, inrow = byte % 512u;
+        src[n] = in + ((size_t)(group * 8u + row) * stream_f4 + (size_t)c * 512u) + inrow / 16u;
+    }
+    float acc = 0.0f;
+    float4 v[INFLIGHT][4];
+#pragma unroll
+    for (int t = 0; t < INFLIGHT; ++t)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[t][n] = src[n][(size_t)t * 32u];
+    for (uint32_t t0 = 0; t0 < 16u; t0 += INFLIGHT) {
+#pragma unroll
+        for (int t = 0; t < INFLIGHT; ++t) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc += v[t][n].x + v[t][n].y + v[t][n].z + v[t][n].w;
+            const uint32_t nxt = t0 + (uint32_t)t + INFLIGHT;
+            if (nxt < 16u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) v[t][n] = src[n][(size_t)nxt * 32u];
+        }
+    }
+    if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
 template <class F>
 static double time_ms(F&& launch, int reps) {
     hipEvent_t a, b;
@@ -68,6 +100,13 @@ int main() {
         for (int bm : {0, 1}) {
             double t = time_ms([&] { hipLaunchKernelGGL(pieces_kernel, bm ? dim3(blocks, n_streams) : dim3(n_streams, blocks), dim3(64), 0, 0, in, stream_f4, n_streams, out, bm); }, 20);
             printf("pieces %5zu MiB (%u streams x %u blocks of 8 KiB, %s): %.2f TB/s\n", mb, n_streams, blocks, bm ? "block-major" : "stream-major", bytes / t * 1e-9);
+        }
+        if (blocks >= 1) {
+            double t2 = time_ms([&] { hipLaunchKernelGGL(tiles_kernel<2>, dim3(n_streams / 8, blocks), dim3(64), 0, 0, in, stream_f4, out); }, 20);
+            double t4 = time_ms([&] { hipLaunchKernelGGL(tiles_kernel<4>, dim3(n_streams / 8, blocks), dim3(64), 0, 0, in, stream_f4, out); }, 20);
+            double t8 = time_ms([&] { hipLaunchKernelGGL(tiles_kernel<8>, dim3(n_streams / 8, blocks), dim3(64), 0, 0, in, stream_f4, out); }, 20);
+            printf("tiles  %5zu MiB (wavefront = 8 streams x 8 KiB as 16 tiles of eight 512-byte pieces): 2 tiles in flight %.2f TB/s, 4: %.2f, 8: %.2f\n", mb,
+                   bytes / t2 * 1e-9, bytes / t4 * 1e-9, bytes / t8 * 1e-9);
         }
         hipFree(in);
         hipFree(out);
